@@ -1,0 +1,548 @@
+"""Offline model compiler: MJCF subset + STL meshes -> flat `.ksm` model blob.
+
+Replaces what `mujoco_py.load_model_from_path` does for the reference at
+kinova_gripper_env.py:62,102,878,1002 (reference: gym-kinova-gripper/gym_kinova_gripper/envs/).
+Only the MJCF features used by `kinova_description/j2s7s300_end_effector_v1_*.xml`
+are understood: compiler angle=radian, option timestep/impratio, default geom margin,
+default joint damping/armature, nested bodies (pos/quat/euler), inertial, slide/hinge/free
+joints, mesh geoms, plane geom, sites, explicit contact pairs, fixed tendons + tendon
+equalities, velocity/motor actuators, jointpos/rangefinder sensors.
+
+The topology is fixed (Kinova j2s7s300 end effector: 3 slides on link_7, 3 fingers x
+(proximal, distal) hinges, one free object, ground plane); every numeric parameter is read
+from the XML / STL.  Compiler-derived quantities (not in the XML):
+per-mesh convex hull, centroid, principal frame, AABB half extents, bounding radius,
+hull face planes, object inertia from mesh at the given mass, dof/body/tendon inverse
+weights at qpos0.
+
+This module runs in the authoring container (it needs the MJCF/STL assets); the compiled
+blobs are committed under kinovagrasping_amd/assets/ and are what travels to the GPU box.
+"""
+from __future__ import annotations
+
+import re
+import struct
+import xml.etree.ElementTree as ET
+from pathlib import Path
+
+import numpy as np
+
+MAGIC = b"KSMB"
+VERSION = 3
+
+# fixed topology ------------------------------------------------------------------------------
+NQ, NV, NU = 16, 15, 9
+NBODY, NGEOM, NSITE = 10, 9, 17
+BODY_NAMES = ["world", "root", "j2s7s300_link_7",
+              "j2s7s300_link_finger_1", "j2s7s300_link_finger_tip_1",
+              "j2s7s300_link_finger_2", "j2s7s300_link_finger_tip_2",
+              "j2s7s300_link_finger_3", "j2s7s300_link_finger_tip_3", "object"]
+GEOM_NAMES = ["ground", "palm", "f1_prox", "f1_dist", "f2_prox", "f2_dist", "f3_prox", "f3_dist", "object"]
+GEOM_BODY = [0, 2, 3, 4, 5, 6, 7, 8, 9]
+GEOM_MESH = [-1, 0, 1, 2, 1, 2, 1, 2, 3]   # mesh slot: 0 palm, 1 proximal, 2 distal, 3 object
+# the two debug bar sites on `root` (XML:55-56, absent from some siblings) are never read -> dropped
+SITE_NAMES = ["palm", "palm_1", "palm_2", "palm_3", "palm_4",
+              "f1_prox", "f1_prox_1", "f1_dist", "f1_dist_1",
+              "f2_prox", "f2_prox_1", "f2_dist", "f2_dist_1",
+              "f3_prox", "f3_prox_1", "f3_dist", "f3_dist_1"]
+
+
+# ---------------------------------------------------------------------------------------------
+# small math helpers
+def quat_mul(a, b):
+    w1, x1, y1, z1 = a
+    w2, x2, y2, z2 = b
+    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2,
+                     w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                     w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
+
+
+def quat_to_mat(q):
+    w, x, y, z = q / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def mat_to_quat(R):
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = np.zeros(4)
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    if q[0] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def euler_to_quat(e):
+    """MJCF euler, default eulerseq 'xyz' (intrinsic): R = Rx(a) Ry(b) Rz(c)  (SURVEY App. B.10)."""
+    a, b, c = e
+    qx = np.array([np.cos(a / 2), np.sin(a / 2), 0, 0])
+    qy = np.array([np.cos(b / 2), 0, np.sin(b / 2), 0])
+    qz = np.array([np.cos(c / 2), 0, 0, np.sin(c / 2)])
+    return quat_mul(quat_mul(qx, qy), qz)
+
+
+def truncated_euler(values):
+    """The reference patches hand eulers into the XML as str(v)[:5] (kinova_gripper_env.py:870-874).
+
+    SURVEY note N4: ordinary values are truncated to a 5-character decimal string; for
+    |v| < 1e-4 numpy prints scientific notation and the slice is nonsense, so we map those to 0.
+    """
+    out = []
+    for v in values:
+        v = float(v)
+        if abs(v) < 1e-4:
+            out.append(0.0)
+            continue
+        s = repr(v)
+        if "e" in s or "E" in s:
+            s = f"{v:.10f}"
+        out.append(float(s[:5]))
+    return np.array(out)
+
+
+# ---------------------------------------------------------------------------------------------
+# STL + mesh processing
+def load_stl(path: Path) -> np.ndarray:
+    """Returns triangles [n,3,3] float64 (vertices are float32 in binary STL)."""
+    raw = path.read_bytes()
+    n = struct.unpack("<I", raw[80:84])[0] if len(raw) >= 84 else -1
+    if n >= 0 and len(raw) == 84 + 50 * n:
+        rec = np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")])
+        return np.frombuffer(raw[84:], dtype=rec)["v"].astype(np.float64)
+    verts = []
+    for line in raw.decode("latin1").splitlines():
+        s = line.split()
+        if s and s[0] == "vertex":
+            verts.append([float(x) for x in s[1:4]])
+    return np.array(verts, dtype=np.float64).reshape(-1, 3, 3)
+
+
+def mesh_mass_properties(tri: np.ndarray):
+    """Exact signed-volume integration over the triangle soup (unit density).
+
+    Returns (volume, com[3], inertia_about_com[3,3]).  Inward-wound meshes (negative signed
+    volume: CylinderS.stl, Vase1S.stl, ... SURVEY note N3) are flipped.
+    """
+    a, b, c = tri[:, 0], tri[:, 1], tri[:, 2]
+    d6 = np.einsum("ij,ij->i", a, np.cross(b, c))
+    vol = d6.sum() / 6.0
+    sign = 1.0 if vol >= 0 else -1.0
+    d6 = d6 * sign
+    vol = abs(vol)
+    com = ((a + b + c) * d6[:, None]).sum(0) / 24.0 / vol
+    # second moments of each tetra (origin, a, b, c): integral x_i x_j dV =
+    #   d6/120 * (sum_k v_k,i v_k,j + s_i s_j), s = a+b+c
+    s = a + b + c
+    C = (np.einsum("n,ni,nj->ij", d6, a, a) + np.einsum("n,ni,nj->ij", d6, b, b)
+         + np.einsum("n,ni,nj->ij", d6, c, c) + np.einsum("n,ni,nj->ij", d6, s, s)) / 120.0
+    C = C - vol * np.outer(com, com)          # covariance about com
+    inertia = np.trace(C) * np.eye(3) - C
+    return vol, com, inertia
+
+
+def principal_frame(I: np.ndarray):
+    """Jacobi diagonalisation started from identity, then eigenvalues sorted descending by
+    90-degree axis swaps (right-handed).  Mirrors the convention described for MuJoCo's
+    mju_eig3 in SURVEY hard-part 6: a nearly diagonal, already-descending tensor (the palm)
+    yields the nearby small rotation, a degenerate one (square prisms) yields identity.
+    """
+    A = I.copy()
+    R = np.eye(3)
+    scale = np.abs(np.diag(A)).max()
+    for _ in range(100):
+        off = [(abs(A[0, 1]), 0, 1), (abs(A[0, 2]), 0, 2), (abs(A[1, 2]), 1, 2)]
+        m, p, q = max(off)
+        if m < 1e-12 * scale:
+            break
+        theta = 0.5 * np.arctan2(2 * A[p, q], A[q, q] - A[p, p])
+        # choose the small rotation |theta| <= pi/4
+        if theta > np.pi / 4:
+            theta -= np.pi / 2
+        if theta < -np.pi / 4:
+            theta += np.pi / 2
+        G = np.eye(3)
+        cth, sth = np.cos(theta), np.sin(theta)
+        G[p, p], G[q, q], G[p, q], G[q, p] = cth, cth, sth, -sth
+        A = G.T @ A @ G
+        R = R @ G
+    ev = np.diag(A).copy()
+    # sort descending with right-handed 90 degree swaps: swapping axes i,j -> new_i = old_j, new_j = -old_i
+    for _ in range(3):
+        for i, j in ((0, 1), (1, 2)):
+            if ev[i] < ev[j] * (1 - 1e-9):
+                ev[i], ev[j] = ev[j], ev[i]
+                ci, cj = R[:, i].copy(), R[:, j].copy()
+                R[:, i], R[:, j] = cj, -ci
+    assert np.linalg.det(R) > 0.999
+    return ev, R
+
+
+class CompiledMesh:
+    def __init__(self, tri: np.ndarray, name: str):
+        from scipy.spatial import ConvexHull
+        self.name = name
+        self.ntri = len(tri)
+        self.volume, self.com, inertia = mesh_mass_properties(tri)
+        self.principal, self.R = principal_frame(inertia)        # unit-density moments
+        self.quat = mat_to_quat(self.R)
+        pts = np.unique(tri.reshape(-1, 3), axis=0)
+        hull = ConvexHull(pts)
+        hv = pts[np.sort(hull.vertices)]
+        # vertices in the geom frame (origin = com, axes = principal frame)
+        self.verts = (hv - self.com) @ self.R
+        allv = (pts - self.com) @ self.R
+        self.size = np.maximum(np.abs(allv.min(0)), np.abs(allv.max(0)))
+        self.rbound = float(np.linalg.norm(self.verts, axis=1).max())
+        # hull faces in geom frame: merge coplanar simplices into unique planes n.x <= d
+        h2 = ConvexHull(self.verts)
+        eq = h2.equations                           # n.x + off <= 0 inside
+        planes = np.concatenate([eq[:, :3], -eq[:, 3:4]], axis=1)
+        key = np.round(planes / 1e-7).astype(np.int64)
+        _, idx = np.unique(key, axis=0, return_index=True)
+        self.planes = planes[np.sort(idx)]
+        self.nsimplex = len(h2.simplices)
+
+
+# ---------------------------------------------------------------------------------------------
+def _floats(s, n=None):
+    v = np.array([float(x) for x in s.split()], dtype=np.float64)
+    if n is not None:
+        assert len(v) == n, (s, n)
+    return v
+
+
+def _frame_of(elem):
+    pos = _floats(elem.get("pos", "0 0 0"), 3)
+    if elem.get("quat") is not None:
+        q = _floats(elem.get("quat"), 4)
+        q = q / np.linalg.norm(q)
+    elif elem.get("euler") is not None:
+        q = euler_to_quat(_floats(elem.get("euler"), 3))
+    else:
+        q = np.array([1.0, 0, 0, 0])
+    return pos, q
+
+
+def compile_model(xml_path: Path) -> dict:
+    xml_path = Path(xml_path)
+    root = ET.parse(xml_path).getroot()
+    comp = root.find("compiler")
+    assert comp.get("angle") == "radian"
+    meshdir = xml_path.parent / comp.get("meshdir", "")
+    opt = root.find("option")
+    dt = float(opt.get("timestep"))
+    impratio = float(opt.get("impratio", "1"))
+    dflt = root.find("default")
+    margin = float(dflt.find("geom").get("margin", "0"))
+    dj = dflt.find("joint")
+    damping = float(dj.get("damping", "0"))
+    armature = float(dj.get("armature", "0"))
+    assert dj.get("limited", "false") == "false"
+
+    mesh_assets = {m.get("name"): m for m in root.find("asset").findall("mesh")}
+
+    def get_mesh(name):
+        m = mesh_assets[name]
+        tri = load_stl(meshdir / m.get("file"))
+        sc = _floats(m.get("scale", "1 1 1"), 3)
+        return CompiledMesh(tri * sc, name)
+
+    wb = root.find("worldbody")
+    bodies = {b.get("name"): b for b in wb.iter("body")}
+    parent = {c: p for p in wb.iter() for c in p}
+
+    M = {}
+    M["opt"] = np.array([dt, impratio, -9.81, margin, 0.02, 1.0, 0.9, 0.95, 0.001, 1e-6, 50.0])
+    # opt layout: dt, impratio, gravity_z, margin, solref[2], solimp[3], mpr_tolerance, mpr_iterations
+
+    # bodies ----------------------------------------------------------------------------------
+    body_pos = np.zeros((NBODY, 3))
+    body_quat = np.tile(np.array([1.0, 0, 0, 0]), (NBODY, 1))
+    body_mass = np.zeros(NBODY)
+    body_ipos = np.zeros((NBODY, 3))
+    body_iquat = np.tile(np.array([1.0, 0, 0, 0]), (NBODY, 1))
+    body_inertia = np.zeros((NBODY, 3))
+    for i, name in enumerate(BODY_NAMES):
+        if i == 0:
+            continue
+        b = bodies[name]
+        body_pos[i], body_quat[i] = _frame_of(b)
+        ine = b.find("inertial")
+        if ine is not None:
+            body_mass[i] = float(ine.get("mass"))
+            body_ipos[i] = _floats(ine.get("pos"), 3)
+            body_inertia[i] = _floats(ine.get("diaginertia"), 3)
+            assert ine.get("quat") is None
+    assert np.allclose(body_pos[1], 0) and np.allclose(body_quat[1], [1, 0, 0, 0])
+    assert parent[bodies["object"]] is wb
+
+    # joints ----------------------------------------------------------------------------------
+    l7 = bodies[BODY_NAMES[2]]
+    slides = l7.findall("joint")
+    assert [j.get("type") for j in slides] == ["slide"] * 3
+    slide_axis = np.array([_floats(j.get("axis"), 3) for j in slides])
+    slide_range = np.array([_floats(j.get("range"), 2) for j in slides])
+    assert all(j.get("limited") == "true" for j in slides)
+    hinge_range = np.zeros((6, 2))
+    hinge_limited = np.zeros(6)
+    for k in range(6):
+        j = bodies[BODY_NAMES[3 + k]].find("joint")
+        assert j.get("type", "hinge") == "hinge" and np.allclose(_floats(j.get("axis"), 3), [0, 0, 1])
+        assert np.allclose(_floats(j.get("pos", "0 0 0"), 3), 0)
+        hinge_range[k] = _floats(j.get("range"), 2)
+        hinge_limited[k] = 1.0 if j.get("limited", "false") == "true" else 0.0
+    assert bodies["object"].find("joint").get("type") == "free"
+    M["slide_axis"], M["slide_range"] = slide_axis, slide_range
+    M["hinge_range"], M["hinge_limited"] = hinge_range, hinge_limited
+    M["dof_damping"] = np.full(NV, damping)
+    M["dof_armature"] = np.full(NV, armature)
+
+    # geoms + meshes ---------------------------------------------------------------------------
+    meshes = [None] * 4
+    geom_pos = np.zeros((NGEOM, 3))
+    geom_quat = np.tile(np.array([1.0, 0, 0, 0]), (NGEOM, 1))
+    geom_size = np.zeros((NGEOM, 3))
+    geom_rbound = np.zeros(NGEOM)
+    geom_elems = {g.get("name"): g for g in wb.iter("geom")}
+    for gi, gname in enumerate(GEOM_NAMES):
+        g = geom_elems[gname]
+        if gi == 0:
+            assert g.get("class") == "ground"
+            geom_size[gi] = _floats(g.get("size"), 3)
+            continue
+        assert g.get("type") == "mesh", f"{xml_path.name}: only mesh objects are compiled (got {g.get('type')})"
+        slot = GEOM_MESH[gi]
+        if meshes[slot] is None:
+            meshes[slot] = get_mesh(g.get("mesh"))
+        cm = meshes[slot]
+        gp, gq = _frame_of(g)                       # user frame of the geom in the body (identity here)
+        Rg = quat_to_mat(gq)
+        geom_pos[gi] = gp + Rg @ cm.com
+        geom_quat[gi] = mat_to_quat(Rg @ cm.R)
+        geom_size[gi] = cm.size
+        geom_rbound[gi] = cm.rbound
+    # object inertial inferred from its geom (mass on the geom, XML:153)
+    og = geom_elems["object"]
+    omass = float(og.get("mass"))
+    cm = meshes[3]
+    body_mass[9] = omass
+    body_ipos[9] = geom_pos[8]
+    body_iquat[9] = geom_quat[8]
+    body_inertia[9] = cm.principal * (omass / cm.volume)
+    M["body_pos"], M["body_quat"], M["body_mass"] = body_pos, body_quat, body_mass
+    M["body_ipos"], M["body_iquat"], M["body_inertia"] = body_ipos, body_iquat, body_inertia
+    M["geom_pos"], M["geom_quat"], M["geom_size"], M["geom_rbound"] = geom_pos, geom_quat, geom_size, geom_rbound
+    M["geom_body"] = np.array(GEOM_BODY, dtype=np.int32)
+    M["geom_mesh"] = np.array(GEOM_MESH, dtype=np.int32)
+    for s, cm in enumerate(meshes):
+        M[f"mesh{s}_vert"] = cm.verts
+        M[f"mesh{s}_plane"] = cm.planes
+    M["mesh_info"] = np.array([[cm.volume, len(cm.verts), len(cm.planes), cm.ntri, cm.nsimplex] for cm in meshes])
+
+    # sites -------------------------------------------------------------------------------------
+    site_pos = np.zeros((NSITE, 3))
+    site_quat = np.zeros((NSITE, 4))
+    site_body = np.zeros(NSITE, dtype=np.int32)
+    site_elems = {s.get("name"): s for s in wb.iter("site")}
+    for si, sname in enumerate(SITE_NAMES):
+        s = site_elems[sname]
+        site_pos[si], site_quat[si] = _frame_of(s)
+        site_body[si] = BODY_NAMES.index(parent[s].get("name"))
+    M["site_pos"], M["site_quat"], M["site_body"] = site_pos, site_quat, site_body
+
+    # contact pairs -------------------------------------------------------------------------------
+    # explicit pairs first (XML order), then the dynamic candidates of SURVEY App. A
+    pairs = []
+    seen = set()
+    for p in root.find("contact").findall("pair"):
+        g1, g2 = GEOM_NAMES.index(p.get("geom1")), GEOM_NAMES.index(p.get("geom2"))
+        fr = _floats(p.get("friction"), 5)
+        assert p.get("condim") == "3"
+        a, b = min(g1, g2), max(g1, g2)
+        pairs.append([a, b, fr[0], fr[1], margin])
+        seen.add((a, b))
+    hand = list(range(1, 8))
+    for a in range(0, 8):
+        for b in range(a + 1, 8):
+            if (a, b) in seen:
+                continue
+            if a == 0:
+                pass                                   # ground x hand geom (conaffinity 1 vs contype 1)
+            else:
+                ba, bb = GEOM_BODY[a], GEOM_BODY[b]
+                # parent-child filter: palm(2)-prox(3,5,7); prox(i)-dist(i+1)
+                if (ba == 2 and bb in (3, 5, 7)) or (bb == ba + 1 and ba in (3, 5, 7)):
+                    continue
+            pairs.append([a, b, 1.0, 1.0, margin])     # geom default friction 1 0.005 0.0001, condim 3
+    M["pairs"] = np.array(pairs)
+    assert len(pairs) == 30, len(pairs)
+
+    # tendons / equality / actuators -----------------------------------------------------------------
+    tend = root.find("tendon").findall("fixed")
+    coefs = []
+    for t in tend:
+        js = t.findall("joint")
+        coefs.append([float(js[0].get("coef")), float(js[1].get("coef"))])
+    M["tendon_coef"] = np.array(coefs)
+    acts = list(root.find("actuator"))
+    assert [a.tag for a in acts] == ["velocity", "motor"] * 3 + ["velocity"] * 3
+    M["actuator"] = np.array([float(acts[0].get("kv")), float(acts[1].get("gear")),
+                              _floats(acts[0].get("ctrlrange"), 2)[1],
+                              float(acts[6].get("kv")), _floats(acts[6].get("ctrlrange"), 2)[1]])
+    # actuator layout: kv_slide, gear_motor, ctrlrange_slide, kv_finger, ctrlrange_finger
+
+    # inverse weights at qpos0 ------------------------------------------------------------------------
+    M.update(_invweights(M))
+    M["obj_size_obs"] = object_size_obs(geom_size[8], xml_path.name)
+    return M
+
+
+def object_size_obs(size, filename):
+    """Restatement of KinovaGripper_Env._get_obj_size (kinova_gripper_env.py:706-746) for a
+    single object geom; the observation stores [s0, s1, 2*s2] (kinova_gripper_env.py:529)."""
+    size = np.array(size, dtype=np.float64).copy()
+    final = np.zeros(3)
+    if size[2] == 0:
+        size[2] = size[1]
+        size[1] = size[0]
+    diffs = [abs(size[0] - size[1]), abs(size[1] - size[2]), abs(size[0] - size[2])]
+    if ("lemon" in filename) or (int(np.argmin(diffs)) != 0):
+        size[0], size[2] = size[2], size[0]
+    final[0] = max(size[0], final[0])
+    final[1] = max(size[1], final[1])
+    final[2] += size[2]
+    return np.array([final[0], final[1], final[2] * 2.0])
+
+
+def _invweights(M):
+    """dof_invweight0 / body_invweight0 / tendon_invweight0 at qpos0 with the hand in its
+    link frame (the result is invariant to the per-episode hand orientation)."""
+    nb = NBODY
+    # FK at qpos0
+    R = [np.eye(3)] * nb
+    p = [np.zeros(3)] * nb
+    par = [0, 0, 1, 2, 3, 2, 5, 2, 7, 0]
+    for b in range(1, nb):
+        R[b] = R[par[b]] @ quat_to_mat(M["body_quat"][b])
+        p[b] = p[par[b]] + R[par[b]] @ M["body_pos"][b]
+    # jacobians at COM per body
+    def jac(b, x):
+        Jp = np.zeros((3, NV))
+        Jr = np.zeros((3, NV))
+        chain = []
+        c = b
+        while c != 0:
+            chain.append(c)
+            c = par[c]
+        if 2 in chain:
+            for k in range(3):
+                Jp[:, k] = R[2] @ M["slide_axis"][k]
+        for k in range(6):
+            hb = 3 + k
+            if hb in chain:
+                z = R[hb][:, 2]
+                Jr[:, 3 + k] = z
+                Jp[:, 3 + k] = np.cross(z, x - p[hb])
+        if b == 9:
+            Jp[:, 9:12] = np.eye(3)
+            for k in range(3):
+                Jr[:, 12 + k] = R[9][:, k]
+                Jp[:, 12 + k] = np.cross(R[9][:, k], x - p[9])
+        return Jp, Jr
+    Mm = np.diag(M["dof_armature"]).astype(np.float64)
+    coms = []
+    for b in range(2, nb):
+        x = p[b] + R[b] @ M["body_ipos"][b]
+        coms.append(x)
+        Jp, Jr = jac(b, x)
+        Ri = R[b] @ quat_to_mat(M["body_iquat"][b])
+        Iw = Ri @ np.diag(M["body_inertia"][b]) @ Ri.T
+        Mm += M["body_mass"][b] * Jp.T @ Jp + Jr.T @ Iw @ Jr
+    Minv = np.linalg.inv(Mm)
+    body_inv = np.zeros((nb, 2))
+    for b in range(2, nb):
+        Jp, Jr = jac(b, coms[b - 2])
+        body_inv[b, 0] = np.trace(Jp @ Minv @ Jp.T) / 3
+        body_inv[b, 1] = np.trace(Jr @ Minv @ Jr.T) / 3
+    dof_inv = np.diag(Minv).copy()
+    dof_inv[9:12] = dof_inv[9:12].mean()
+    dof_inv[12:15] = dof_inv[12:15].mean()
+    tinv = np.zeros(3)
+    for t in range(3):
+        Jt = np.zeros(NV)
+        Jt[3 + 2 * t] = M["tendon_coef"][t, 0]
+        Jt[4 + 2 * t] = M["tendon_coef"][t, 1]
+        tinv[t] = Jt @ Minv @ Jt
+    return {"dof_invweight0": dof_inv, "body_invweight0": body_inv, "tendon_invweight0": tinv,
+            "M0": Mm}
+
+
+# ---------------------------------------------------------------------------------------------
+def write_blob(M: dict, path: Path):
+    recs = []
+    for name, arr in M.items():
+        arr = np.ascontiguousarray(arr)
+        if arr.dtype.kind in "iu":
+            arr = arr.astype("<i4")
+            code = 1
+        else:
+            arr = arr.astype("<f8")
+            code = 0
+        nb = name.encode()
+        assert len(nb) < 24
+        shape = list(arr.shape) + [0] * (4 - arr.ndim)
+        hdr = nb.ljust(24, b"\0") + struct.pack("<II4I", code, arr.size, *shape)
+        data = arr.tobytes()
+        pad = (-len(data)) % 8
+        recs.append(hdr + data + b"\0" * pad)
+    with open(path, "wb") as f:
+        f.write(MAGIC + struct.pack("<II", VERSION, len(recs)))
+        f.write(b"\0" * 4)
+        for r in recs:
+            f.write(r)
+
+
+def read_blob(path_or_bytes) -> dict:
+    raw = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else Path(path_or_bytes).read_bytes()
+    assert raw[:4] == MAGIC, "not a KSMB model blob"
+    ver, n = struct.unpack("<II", raw[4:12])
+    assert ver == VERSION, f"model blob version {ver} != {VERSION}"
+    off = 16
+    out = {}
+    for _ in range(n):
+        name = raw[off:off + 24].rstrip(b"\0").decode()
+        code, size, s0, s1, s2, s3 = struct.unpack("<II4I", raw[off + 24:off + 48])
+        off += 48
+        dt = "<i4" if code == 1 else "<f8"
+        isz = 4 if code == 1 else 8
+        arr = np.frombuffer(raw[off:off + size * isz], dtype=dt).copy()
+        shape = [s for s in (s0, s1, s2, s3) if s > 0]
+        out[name] = arr.reshape(shape) if shape else arr.reshape(())
+        off += size * isz + ((-size * isz) % 8)
+    return out
+
+
+def load_coords_table(path: Path) -> np.ndarray:
+    """Object start coordinates as the reference reads them (kinova_gripper_env.py:1008-1028):
+    the first line is consumed by the delimiter sniffer, the rest are rows of x,y,z[,rx,ry,rz]."""
+    lines = Path(path).read_text().splitlines()
+    delim = "," if "," in lines[0] else " "
+    rows = []
+    for ln in lines[1:]:
+        parts = [p for p in re.split(delim, ln.strip()) if p != ""]
+        if len(parts) >= 3:
+            rows.append([float(x) for x in parts[:6]])
+    width = max(len(r) for r in rows)
+    return np.array([r + [0.0] * (width - len(r)) for r in rows])

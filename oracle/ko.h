@@ -1,0 +1,136 @@
+/* oracle/ko.h -- CPU oracle for the Kinova gripper hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product path (kinovagrasping_amd/csrc) never includes, links or calls anything here.
+ *
+ * What it restates (reference = /root/reference/gym-kinova-gripper/gym_kinova_gripper/envs/
+ * kinova_gripper_env.py, "ENV"):
+ *   - env layer, PINNED by tests/golden/env_layer.npz generated from the reference's own
+ *     Python (tools/gen_golden_env.py): action->ctrl mapping ENV:1495-1535, palm transform
+ *     ENV:274-288, 82-d / 74-d observation ENV:438-534 (+ helpers ENV:290-343, 356-362,
+ *     538-608), reward/termination ENV:631-687.
+ *   - physics (mj_step, called at ENV:1535): lives in MuJoCo 1.50 / mujoco-py 1.50.1.0, a
+ *     third-party binary that is NOT under /root/reference and not installable here.  The
+ *     restatement follows MuJoCo's published algorithm (Computation chapter) on the compiled
+ *     model data.  PARITY UNPINNED at the mj_step boundary: the reference holds no golden
+ *     vectors, known-answer tests or fixtures for it.
+ */
+#ifndef KO_H
+#define KO_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KO_NQ 16
+#define KO_NV 15
+#define KO_NU 9
+#define KO_NBODY 10
+#define KO_NGEOM 9
+#define KO_NSITE 17
+#define KO_NSENSOR 26
+#define KO_NPAIR_MAX 32
+#define KO_NCON_MAX 24
+#define KO_NEFC_MAX (3 + 9 + 4 * KO_NCON_MAX)
+#define KO_NOBS 82
+#define KO_NOBS_GLOBAL 74
+
+typedef struct {
+    double dt, impratio, gravity_z, margin, solref[2], solimp[3], mpr_tolerance;
+    int mpr_iterations;
+    double body_pos[KO_NBODY][3], body_quat[KO_NBODY][4], body_mass[KO_NBODY];
+    double body_ipos[KO_NBODY][3], body_iquat[KO_NBODY][4], body_inertia[KO_NBODY][3];
+    double slide_axis[3][3], slide_range[3][2], hinge_range[6][2];
+    int hinge_limited[6];
+    double dof_damping[KO_NV], dof_armature[KO_NV];
+    double geom_pos[KO_NGEOM][3], geom_quat[KO_NGEOM][4], geom_size[KO_NGEOM][3], geom_rbound[KO_NGEOM];
+    int geom_body[KO_NGEOM], geom_mesh[KO_NGEOM];
+    int mesh_nvert[4], mesh_nplane[4];
+    double *mesh_vert[4], *mesh_plane[4];
+    double site_pos[KO_NSITE][3], site_quat[KO_NSITE][4];
+    int site_body[KO_NSITE];
+    int npair;
+    double pairs[KO_NPAIR_MAX][5]; /* g1, g2, mu1, mu2, margin */
+    double tendon_coef[3][2];
+    double actuator[5]; /* kv_slide, gear_motor, ctrlrange_slide, kv_finger, ctrlrange_finger */
+    double dof_invweight0[KO_NV], body_invweight0[KO_NBODY][2], tendon_invweight0[3];
+    double obj_size_obs[3];
+} ko_model;
+
+typedef struct {
+    double dist, pos[3], frame[9], mu[2], margin;
+    int geom1, geom2;
+} ko_contact;
+
+typedef struct {
+    const ko_model *m;
+    double hand_quat[4];
+    int solver;            /* 0 = Newton (default, MuJoCo's default), 1 = PGS (comparison) */
+    int solver_iterations; /* fixed iteration count: Newton steps or PGS sweeps */
+    int ncon_max;
+    /* state */
+    double qpos[KO_NQ], qvel[KO_NV], qacc_warmstart[KO_NV], ctrl[KO_NU];
+    /* position-dependent */
+    double xpos[KO_NBODY][3], xmat[KO_NBODY][9], xipos[KO_NBODY][3], ximat[KO_NBODY][9];
+    double geom_xpos[KO_NGEOM][3], geom_xmat[KO_NGEOM][9];
+    double site_xpos[KO_NSITE][3], site_xmat[KO_NSITE][9];
+    double M[KO_NV][KO_NV], L[KO_NV][KO_NV];
+    int ncon, ncon_dropped;
+    ko_contact contact[KO_NCON_MAX];
+    int nefc;
+    int efc_type[KO_NEFC_MAX]; /* 0 equality, 1 limit, 2 contact */
+    double efc_J[KO_NEFC_MAX][KO_NV], efc_pos[KO_NEFC_MAX], efc_margin[KO_NEFC_MAX];
+    double efc_R[KO_NEFC_MAX], efc_aref[KO_NEFC_MAX], efc_b[KO_NEFC_MAX], efc_force[KO_NEFC_MAX];
+    double sensordata[KO_NSENSOR];
+    /* velocity / force */
+    double qfrc_bias[KO_NV], qfrc_passive[KO_NV], qfrc_actuator[KO_NV], qfrc_constraint[KO_NV];
+    double qacc_smooth[KO_NV], qacc[KO_NV];
+    /* env layer bookkeeping */
+    int mpr_calls, mpr_support_calls;
+    double newton_last_grad;
+} ko_sim;
+
+/* ---- model ---- */
+ko_model *ko_model_load(const void *blob, size_t nbytes);
+void ko_model_free(ko_model *m);
+
+/* ---- physics (S0-S8) ---- */
+ko_sim *ko_sim_new(const ko_model *m, const double hand_quat[4]);
+void ko_sim_free(ko_sim *s);
+void ko_set_state(ko_sim *s, const double *qpos, const double *qvel, const double *qacc_warmstart);
+void ko_forward(ko_sim *s); /* mj_forward */
+void ko_step(ko_sim *s);    /* mj_step = forward + Euler */
+void ko_kinematics(ko_sim *s);
+
+/* ---- env layer (E1, O1-O3, L5) ---- */
+typedef struct { /* what the reference reads from mujoco-py (fake-sim inputs of the golden vectors) */
+    double palm_xpos[3], palm_xmat[9];
+    double finger_xpos[6][3]; /* f1_prox f2_prox f3_prox f1_dist f2_dist f3_dist */
+    double obj_xpos[3];
+    double link7_xpos[3];
+    double site_xpos[KO_NSITE][3]; /* model site order */
+    double sensordata[KO_NSENSOR];
+    double obj_size[3]; /* _get_obj_size(): [s0, s1, s2] before the x2 */
+} ko_env_inputs;
+
+void ko_env_palm_transform(const double palm_xpos[3], const double palm_xmat[9], double Tfw[16], double wrist[3]);
+void ko_env_ctrl(const double Tfw[16], const double *action, int naction, double ctrl[9]);
+void ko_env_obs_local(const ko_env_inputs *in, double obs[KO_NOBS]);
+void ko_env_obs_global(const ko_env_inputs *in, double obs[KO_NOBS_GLOBAL]);
+void ko_env_reward(double obj_z_world, double *reward, int *done, double info[3]);
+int ko_check_grasp(const double f_dist_old[9], const double f_dist_new[9]);
+
+void ko_env_inputs_from_sim(const ko_sim *s, ko_env_inputs *in);
+/* full env.step(): 15 x mj_step then obs/reward exactly as ENV:1495-1552 */
+void ko_env_step(ko_sim *s, const double *action, int naction, int frame_skip, double obs[KO_NOBS],
+                 double *reward, int *done, double info[3]);
+void ko_env_reset(ko_sim *s, const double qpos0[KO_NQ], double obs[KO_NOBS]);
+
+size_t ko_sizeof_sim(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

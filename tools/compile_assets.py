@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Dev-only: compile the reference's MJCF + STL assets into committed `.ksm` model blobs and
+`.npy` start-coordinate tables under kinovagrasping_amd/assets/.
+
+Reads /root/reference (absent on the GPU box) - run in the authoring container only.
+"""
+import sys
+from pathlib import Path
+import numpy as np
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from kinovagrasping_amd import model_compiler as mc
+
+KD = Path("/root/reference/gym-kinova-gripper/gym_kinova_gripper/envs/kinova_description")
+OUT = Path(__file__).resolve().parents[1] / "kinovagrasping_amd" / "assets"
+SHAPES = [s + z for s in ["Cube", "Cylinder", "Cube45", "Cone1", "Cone2", "Vase1", "Vase2"] for z in "SB"]  # README.md:59
+
+
+def main():
+    OUT.mkdir(exist_ok=True)
+    for shape in SHAPES:
+        M = mc.compile_model(KD / f"j2s7s300_end_effector_v1_{shape}.xml")
+        mc.write_blob(M, OUT / f"{shape}.ksm")
+        info = M["mesh_info"]
+        print(shape, "hull verts", info[:, 1].astype(int), "planes", info[:, 2].astype(int),
+              "obj inertia", M["body_inertia"][9], "size_obs", M["obj_size_obs"])
+    # start-coordinate tables (no_noise; SURVEY note N5), float64 [rows,3]
+    tables = {}
+    for orient in ["Normal", "Rotated", "Top"]:
+        for shape in SHAPES:
+            p = KD / "obj_hand_coords" / "no_noise" / "train_coords" / orient / f"{shape}.txt"
+            if p.exists():
+                tables[f"{orient}/{shape}"] = mc.load_coords_table(p)[:, :3].astype(np.float32)
+    np.savez_compressed(OUT / "start_coords_no_noise_train.npz", **tables)
+    print("tables:", {k: v.shape for k, v in list(tables.items())[:4]}, "...", len(tables))
+
+
+if __name__ == "__main__":
+    main()
