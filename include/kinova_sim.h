@@ -1,0 +1,109 @@
+/* include/kinova_sim.h -- C ABI of libkinova_sim.so, the MI355X-native batched replacement for the
+ * mujoco-py engine object that KinovaGripper_Env drives one env at a time.
+ *
+ * Reference interface each entry point replaces (reference root = /root/reference/, file
+ * gym-kinova-gripper/gym_kinova_gripper/envs/kinova_gripper_env.py, "ENV"):
+ *
+ *   ks_create / ks_destroy   <- MjSim(model) construction / garbage collection      ENV:102, 879, 1003
+ *   ks_load_model            <- mujoco_py.load_model_from_path(xml)                 ENV:62, 878, 1002
+ *                               (the MJCF+STL compile happens offline: model_compiler.py -> .ksm)
+ *   ks_reset                 <- KinovaGripper_Env.reset: write_xml (hand euler) + _set_state
+ *                               + sim.forward() + _get_obs()                        ENV:1310-1410, 851-881, 692-703
+ *   ks_step                  <- KinovaGripper_Env.step: action->ctrl, 15 x sim.step(),
+ *                               _get_obs(), _get_reward()                           ENV:1495-1552
+ *                               + gym TimeLimit (max_episode_steps)                 gym_kinova_gripper/__init__.py:3-7, main_DDPGfD.py:384
+ *   ks_get_state/ks_set_state<- sim.data.qpos / qvel / qacc_warmstart, sim.data.ncon,
+ *                               contact forces (parity taps)                        ENV:109, 347-353
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers unless the name ends in _host.  The caller (PyTorch) owns
+ *     every buffer; the library owns only its context and scratch.  Pointers are borrowed for the
+ *     duration of the stream operation.
+ *   - Real-valued buffers have the context precision: float for precision 32 (the product), double
+ *     for precision 64 (algorithm-exactness checks only).
+ *   - Batched arrays are struct-of-arrays, field-major: x[k * n_envs + env].  The observation may be
+ *     requested env-major (obs[env * 82 + k]) with obs_env_major = 1.
+ *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*); no hidden host syncs.
+ *   - One context per GPU per process; a context is not thread safe.
+ *   - Return value: 0 on success, negative ks_status otherwise; ks_last_error gives a message.
+ *   - There is NO CPU path: ks_create fails when no HIP device is available.
+ */
+#ifndef KINOVA_SIM_H
+#define KINOVA_SIM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KS_NQ 16
+#define KS_NV 15
+#define KS_NACT 4
+#define KS_NOBS 82
+#define KS_NINFO 3
+#define KS_NCON_MAX 24
+#define KS_CONTACT_STRIDE 20
+
+typedef enum {
+    KS_OK = 0,
+    KS_ERR_INVALID = -1,  /* bad argument */
+    KS_ERR_NO_DEVICE = -2,
+    KS_ERR_HIP = -3,      /* a HIP runtime call failed */
+    KS_ERR_MODEL = -4,    /* malformed or unsupported model blob */
+    KS_ERR_STATE = -5     /* call sequence error (e.g. step before load_model) */
+} ks_status;
+
+typedef struct {
+    int32_t n_envs;
+    int32_t frame_skip;         /* 15 (ENV:51) */
+    int32_t horizon;            /* episode time limit in env steps, 30 (main_DDPGfD.py:384); <= 0 disables */
+    int32_t solver_iterations;  /* Newton iterations per substep */
+    int32_t precision;          /* 32 or 64 */
+    int32_t auto_reset;         /* 1: envs that finish are reset to their stored initial state inside ks_step */
+    int32_t obs_env_major;      /* 0: obs[k*N+env], 1: obs[env*82+k] */
+    int32_t reserved;
+} ks_config;
+
+typedef struct ks_ctx ks_ctx;
+
+void ks_default_config(ks_config *cfg);
+int ks_create(const ks_config *cfg, int device, ks_ctx **out);
+void ks_destroy(ks_ctx *ctx);
+const char *ks_last_error(const ks_ctx *ctx);   /* ctx may be NULL: last creation error */
+
+/* blob_host: KSMB model blob in HOST memory (copied; may be freed after the call) */
+int ks_load_model(ks_ctx *ctx, const void *blob_host, size_t nbytes);
+
+/* Reset `n` envs.  env_ids: device int32[n] or NULL for envs 0..n-1 (then n must be n_envs).
+ * qpos0: [16, n] start configuration (3 slides, 6 finger joints, object xyz + quat wxyz),
+ * hand_quat: [4, n] orientation of j2s7s300_link_7 (the euler the reference patches into the XML).
+ * Both are stored as the env's initial state for auto-reset.  obs (optional): observation buffer of
+ * the WHOLE batch (layout per cfg); only the rows of the reset envs are written. */
+int ks_reset(ks_ctx *ctx, const int32_t *env_ids, int32_t n, const void *qpos0, const void *hand_quat, void *obs, void *stream);
+
+/* One env.step() for every env.  action: [4, N] (wrist, finger1..3), obs: N x 82, reward: [N],
+ * done: uint8 [N] (bit0 lifted, bit1 time limit), info: [3, N] (finger, grasp, lift reward).
+ * final_obs (optional): with auto_reset, rows of envs that finished hold their terminal
+ * observation while `obs` already holds the observation after the reset. */
+int ks_step(ks_ctx *ctx, const void *action, void *obs, void *reward, uint8_t *done, void *info, void *final_obs, void *stream);
+
+/* Parity taps; any pointer may be NULL.  contact: [KS_NCON_MAX*KS_CONTACT_STRIDE, N] records of the
+ * last substep (pos3 normal3 dist mu bodies R aref4 force3(normal,t1,t2) Jp3), ncon: int32 [N],
+ * status: int32 [N] sticky bit flags (1 contact overflow, 2 non-finite state). */
+int ks_get_state(ks_ctx *ctx, void *qpos, void *qvel, void *qacc_warmstart, void *contact, int32_t *ncon, int32_t *status, void *stream);
+int ks_set_state(ks_ctx *ctx, const void *qpos, const void *qvel, const void *qacc_warmstart, void *stream);
+
+/* Advance by ONE mj_step with explicit controls ctrl [9, N] (no observation); parity testing. */
+int ks_substep(ks_ctx *ctx, const void *ctrl, void *stream);
+
+/* HIP event timing of the dominant kernel: average duration (ms) of the env-step kernel launches
+ * since the last call with reset != 0, measured with hipEvents on the launch stream.  Host sync. */
+int ks_kernel_time(ks_ctx *ctx, int reset, double *avg_ms_host, int64_t *launches_host);
+
+int ks_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,429 @@
+// ks_api.hip -- gfx950 kernels + C ABI of libkinova_sim.so (see include/kinova_sim.h).
+//
+// Kernels (one env per wavefront lane unless noted):
+//   k_env_step   15 x mj_step per launch; per-lane dynamic state in LDS (144 KB / wave), model tables
+//                through wave-uniform scalar loads.  THE dominant kernel.
+//   k_reset      state <- stored initial state for flagged envs, kinematics -> snapshot
+//   k_rays       17 rangefinder rays, one (env, ray) per lane: grid (N/64, 17)
+//   k_obs        82-d observation, reward, termination, time limit, auto-reset flagging
+//   k_substep    one mj_step with explicit controls (parity tap)
+// No CPU fallback exists in this library.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/kinova_sim.h"
+#include "ks_env.h"
+#include "ks_model_host.h"
+
+using namespace ks;
+
+namespace {
+
+constexpr int WAVE = 64;
+thread_local std::string g_create_error;
+
+template <typename T> struct Buffers {
+    T *qpos, *qvel, *warm;        // [16|15|15][N]
+    T *hand_quat, *qpos0;         // [4][N], [16][N]   stored initial state
+    T *snap;                      // [SNAP_TOTAL][N]
+    T *rays;                      // [17][N]
+    T *contact;                   // [NCON_MAX*CON_STRIDE][N] parity tap (last substep)
+    T *gscratch;                  // [SCR_TOTAL][N] (fp64 contexts only; fp32 uses LDS)
+    int32_t *ncon, *status, *step_count;
+    uint8_t *flag;                // envs to (re)initialise
+};
+
+template <typename T> struct ColW {
+    T* base;
+    long stride;
+    __device__ void operator()(int k, T v) const { base[(long)k * stride] = v; }
+};
+
+template <typename T, bool USE_LDS> __device__ __forceinline__ Scratch<T> lane_scratch(const Buffers<T>& b, int env, int N, T* lds) {
+    if constexpr (USE_LDS) return Scratch<T>{lds + threadIdx.x, WAVE};
+    else return Scratch<T>{b.gscratch + env, N};
+}
+
+template <typename T> __device__ __forceinline__ void load_state(const Buffers<T>& b, int env, int N, LaneState<T>& st) {
+    KS_UNROLL
+    for (int i = 0; i < NQ; i++) st.qpos[i] = b.qpos[(long)i * N + env];
+    KS_UNROLL
+    for (int i = 0; i < NV; i++) { st.qvel[i] = b.qvel[(long)i * N + env]; st.warm[i] = b.warm[(long)i * N + env]; }
+}
+template <typename T> __device__ __forceinline__ void store_state(const Buffers<T>& b, int env, int N, const LaneState<T>& st) {
+    KS_UNROLL
+    for (int i = 0; i < NQ; i++) b.qpos[(long)i * N + env] = st.qpos[i];
+    KS_UNROLL
+    for (int i = 0; i < NV; i++) { b.qvel[(long)i * N + env] = st.qvel[i]; b.warm[(long)i * N + env] = st.warm[i]; }
+}
+
+template <typename T, bool USE_LDS>
+__global__ __launch_bounds__(WAVE) void k_env_step(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ action, int N,
+                                                   int frame_skip, int iters) {
+    __shared__ T lds[USE_LDS ? SCR_TOTAL * WAVE : 1];
+    const int env = blockIdx.x * WAVE + threadIdx.x;
+    if (env >= N) return;
+    const Model<T>& m = *mp;
+    Scratch<T> scr = lane_scratch<T, USE_LDS>(b, env, N, lds);
+    LaneState<T> st;
+    load_state(b, env, N, st);
+    T hq[4], act[4];
+    KS_UNROLL
+    for (int i = 0; i < 4; i++) { hq[i] = b.hand_quat[(long)i * N + env]; act[i] = action[(long)i * N + env]; }
+    int ncon = 0, status = 0;
+    ColW<T> snap{b.snap + env, N};
+    lane_env_step(m, st, hq, act, scr, snap, frame_skip, iters, ncon, status);
+    store_state(b, env, N, st);
+    b.ncon[env] = ncon;
+    if (status) b.status[env] |= status;
+    for (int k = 0; k < ncon * CON_STRIDE; k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
+}
+
+template <typename T, bool USE_LDS>
+__global__ __launch_bounds__(WAVE) void k_substep(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ ctrl, int N, int iters) {
+    __shared__ T lds[USE_LDS ? SCR_TOTAL * WAVE : 1];
+    const int env = blockIdx.x * WAVE + threadIdx.x;
+    if (env >= N) return;
+    const Model<T>& m = *mp;
+    Scratch<T> scr = lane_scratch<T, USE_LDS>(b, env, N, lds);
+    LaneState<T> st;
+    load_state(b, env, N, st);
+    T hq[4], c[NU], R7[9];
+    KS_UNROLL
+    for (int i = 0; i < 4; i++) hq[i] = b.hand_quat[(long)i * N + env];
+    KS_UNROLL
+    for (int i = 0; i < NU; i++) c[i] = ctrl[(long)i * N + env];
+    hand_rotation(hq, R7);
+    int ncon = 0, status = 0;
+    mj_forward_step(m, st.qpos, st.qvel, st.warm, c, R7, scr, iters, true, ncon, status);
+    store_state(b, env, N, st);
+    b.ncon[env] = ncon;
+    if (status) b.status[env] |= status;
+    for (int k = 0; k < ncon * CON_STRIDE; k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
+}
+
+// (re)initialise flagged envs from their stored initial state
+template <typename T, bool USE_LDS> __global__ __launch_bounds__(WAVE) void k_reset(const Model<T>* __restrict__ mp, Buffers<T> b, int N) {
+    __shared__ T lds[USE_LDS ? SCR_TOTAL * WAVE : 1];
+    const int env = blockIdx.x * WAVE + threadIdx.x;
+    if (env >= N || !b.flag[env]) return;
+    const Model<T>& m = *mp;
+    Scratch<T> scr = lane_scratch<T, USE_LDS>(b, env, N, lds);
+    LaneState<T> st;
+    T hq[4], q0[NQ];
+    KS_UNROLL
+    for (int i = 0; i < 4; i++) hq[i] = b.hand_quat[(long)i * N + env];
+    KS_UNROLL
+    for (int i = 0; i < NQ; i++) q0[i] = b.qpos0[(long)i * N + env];
+    ColW<T> snap{b.snap + env, N};
+    lane_reset(m, st, hq, q0, scr, snap);
+    store_state(b, env, N, st);
+    b.step_count[env] = 0;
+    b.ncon[env] = 0;
+}
+
+// scatter caller-provided initial states into the stored per-env initial state and flag the envs
+template <typename T>
+__global__ void k_store_init(Buffers<T> b, const int32_t* __restrict__ env_ids, int n, const T* __restrict__ qpos0, const T* __restrict__ hq, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int env = env_ids ? env_ids[i] : i;
+    if (env < 0 || env >= N) return;
+    for (int k = 0; k < NQ; k++) b.qpos0[(long)k * N + env] = qpos0[(long)k * n + i];
+    for (int k = 0; k < 4; k++) b.hand_quat[(long)k * N + env] = hq[(long)k * n + i];
+    b.flag[env] = 1;
+}
+
+// one (env, ray) per lane; the ray index is uniform per workgroup so hull tables stay scalar loads
+template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model<T>* __restrict__ mp, Buffers<T> b, int N, int masked) {
+    const int env = blockIdx.x * WAVE + threadIdx.x, ray = blockIdx.y;
+    if (env >= N || (masked && !b.flag[env])) return;
+    Col<T> snap{b.snap + env, N};
+    b.rays[(long)ray * N + env] = rangefinder(*mp, snap, ray);
+}
+
+// mode 0: after a step (reward / done / time limit / auto-reset flagging); mode 1: after a reset
+// (observation of flagged envs only, flag cleared)
+template <typename T>
+__global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ mp, Buffers<T> b, int N, int mode, int horizon, int auto_reset,
+                                              int env_major, T* __restrict__ obs, T* __restrict__ reward, uint8_t* __restrict__ done,
+                                              T* __restrict__ info, T* __restrict__ final_obs) {
+    const int env = blockIdx.x * WAVE + threadIdx.x;
+    if (env >= N) return;
+    if (mode == 1) {
+        if (!b.flag[env]) return;
+        b.flag[env] = 0;
+        if (!obs) return;
+    }
+    Col<T> snap{b.snap + env, N};
+    T rays[NRAY];
+    KS_UNROLL
+    for (int i = 0; i < NRAY; i++) rays[i] = b.rays[(long)i * N + env];
+    T o[NOBS], rew, inf[3];
+    bool lifted;
+    build_obs(*mp, snap, rays, [&](int j, T v) { o[j] = v; }, rew, lifted, inf);
+    uint8_t d = 0;
+    if (mode == 0) {
+        const int sc = b.step_count[env] + 1;
+        b.step_count[env] = sc;
+        d = (lifted ? 1 : 0) | ((horizon > 0 && sc >= horizon) ? 2 : 0);
+        if (reward) reward[env] = rew;
+        if (done) done[env] = d;
+        if (info) { info[env] = inf[0]; info[(long)N + env] = inf[1]; info[2L * N + env] = inf[2]; }
+        if (d && auto_reset) b.flag[env] = 1;
+    }
+    T* dst = obs;
+    if (mode == 0 && d && auto_reset) dst = final_obs;   // obs row is rewritten by the reset pass
+    if (dst) {
+        if (env_major) {
+            KS_UNROLL
+            for (int j = 0; j < NOBS; j++) dst[(long)env * NOBS + j] = o[j];
+        } else {
+            KS_UNROLL
+            for (int j = 0; j < NOBS; j++) dst[(long)j * N + env] = o[j];
+        }
+    }
+}
+
+struct CtxBase {
+    ks_config cfg;
+    int device;
+    std::string error;
+    bool model_loaded = false;
+    virtual ~CtxBase() {}
+    virtual int load_model(const void* blob, size_t n) = 0;
+    virtual int reset(const int32_t* ids, int n, const void* q0, const void* hq, void* obs, hipStream_t s) = 0;
+    virtual int step(const void* action, void* obs, void* reward, uint8_t* done, void* info, void* final_obs, hipStream_t s) = 0;
+    virtual int get_state(void* qpos, void* qvel, void* warm, void* contact, int32_t* ncon, int32_t* status, hipStream_t s) = 0;
+    virtual int set_state(const void* qpos, const void* qvel, const void* warm, hipStream_t s) = 0;
+    virtual int substep(const void* ctrl, hipStream_t s) = 0;
+    virtual int kernel_time(int reset, double* avg_ms, int64_t* launches) = 0;
+};
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            error = std::string(#expr) + ": " + hipGetErrorString(e_);                       \
+            return KS_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+template <typename T> struct Ctx : CtxBase {
+    static constexpr bool USE_LDS = sizeof(T) == 4;
+    Buffers<T> b{};
+    Model<T>* d_model = nullptr;
+    T* d_vert[4] = {nullptr, nullptr, nullptr, nullptr};
+    T* d_plane[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<void*> allocs;
+    // HIP-event timing of k_env_step
+    static constexpr int NEV = 512;
+    std::vector<hipEvent_t> ev0, ev1;
+    int ev_used = 0;
+    double ev_ms = 0;
+    int64_t ev_launches = 0;
+
+    template <typename U> int alloc(U** p, size_t count) {
+        HIPCHK(hipMalloc((void**)p, count * sizeof(U)));
+        HIPCHK(hipMemset(*p, 0, count * sizeof(U)));
+        allocs.push_back(*p);
+        return KS_OK;
+    }
+    int init() {
+        const size_t N = cfg.n_envs;
+        int r;
+        if ((r = alloc(&b.qpos, NQ * N))) return r;
+        if ((r = alloc(&b.qvel, NV * N))) return r;
+        if ((r = alloc(&b.warm, NV * N))) return r;
+        if ((r = alloc(&b.hand_quat, 4 * N))) return r;
+        if ((r = alloc(&b.qpos0, NQ * N))) return r;
+        if ((r = alloc(&b.snap, SNAP_TOTAL * N))) return r;
+        if ((r = alloc(&b.rays, NRAY * N))) return r;
+        if ((r = alloc(&b.contact, (size_t)NCON_MAX * CON_STRIDE * N))) return r;
+        if (!USE_LDS && (r = alloc(&b.gscratch, (size_t)SCR_TOTAL * N))) return r;
+        if ((r = alloc(&b.ncon, N))) return r;
+        if ((r = alloc(&b.status, N))) return r;
+        if ((r = alloc(&b.step_count, N))) return r;
+        if ((r = alloc(&b.flag, N))) return r;
+        if ((r = alloc(&d_model, 1))) return r;
+        ev0.resize(NEV); ev1.resize(NEV);
+        for (int i = 0; i < NEV; i++) { HIPCHK(hipEventCreate(&ev0[i])); HIPCHK(hipEventCreate(&ev1[i])); }
+        return KS_OK;
+    }
+    ~Ctx() override {
+        for (void* p : allocs) (void)hipFree(p);
+        for (auto& e : ev0) (void)hipEventDestroy(e);
+        for (auto& e : ev1) (void)hipEventDestroy(e);
+    }
+    int load_model(const void* blob, size_t n) override {
+        HostModel<T> hm;
+        if (!parse_model<T>(blob, n, hm)) { error = "ks_load_model: " + hm.error; return KS_ERR_MODEL; }
+        for (int s = 0; s < 4; s++) {
+            int r;
+            if ((r = alloc(&d_vert[s], hm.vert[s].size()))) return r;
+            if ((r = alloc(&d_plane[s], hm.plane[s].size()))) return r;
+            HIPCHK(hipMemcpy(d_vert[s], hm.vert[s].data(), hm.vert[s].size() * sizeof(T), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_plane[s], hm.plane[s].data(), hm.plane[s].size() * sizeof(T), hipMemcpyHostToDevice));
+            hm.m.mesh_vert[s] = d_vert[s];
+            hm.m.mesh_plane[s] = d_plane[s];
+        }
+        HIPCHK(hipMemcpy(d_model, &hm.m, sizeof(Model<T>), hipMemcpyHostToDevice));
+        model_loaded = true;
+        return KS_OK;
+    }
+    int blocks() const { return (cfg.n_envs + WAVE - 1) / WAVE; }
+    int post_reset(void* obs, hipStream_t s) {
+        const int N = cfg.n_envs;
+        hipLaunchKernelGGL((k_reset<T, USE_LDS>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N);
+        hipLaunchKernelGGL((k_rays<T>), dim3(blocks(), NRAY), dim3(WAVE), 0, s, d_model, b, N, 1);
+        hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 1, cfg.horizon, cfg.auto_reset, cfg.obs_env_major,
+                           (T*)obs, (T*)nullptr, (uint8_t*)nullptr, (T*)nullptr, (T*)nullptr);
+        HIPCHK(hipGetLastError());
+        return KS_OK;
+    }
+    int reset(const int32_t* ids, int n, const void* q0, const void* hq, void* obs, hipStream_t s) override {
+        if (!model_loaded) { error = "ks_reset before ks_load_model"; return KS_ERR_STATE; }
+        if (n <= 0 || n > cfg.n_envs || !q0 || !hq || (!ids && n != cfg.n_envs)) { error = "ks_reset: bad arguments"; return KS_ERR_INVALID; }
+        hipLaunchKernelGGL((k_store_init<T>), dim3((n + 255) / 256), dim3(256), 0, s, b, ids, n, (const T*)q0, (const T*)hq, cfg.n_envs);
+        return post_reset(obs, s);
+    }
+    int step(const void* action, void* obs, void* reward, uint8_t* done, void* info, void* final_obs, hipStream_t s) override {
+        if (!model_loaded) { error = "ks_step before ks_load_model"; return KS_ERR_STATE; }
+        if (!action) { error = "ks_step: action is NULL"; return KS_ERR_INVALID; }
+        const int N = cfg.n_envs;
+        const bool timed = ev_used < NEV;
+        if (timed) HIPCHK(hipEventRecord(ev0[ev_used], s));
+        hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, (const T*)action, N, cfg.frame_skip,
+                           cfg.solver_iterations);
+        if (timed) { HIPCHK(hipEventRecord(ev1[ev_used], s)); ev_used++; }
+        hipLaunchKernelGGL((k_rays<T>), dim3(blocks(), NRAY), dim3(WAVE), 0, s, d_model, b, N, 0);
+        hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0, cfg.horizon, cfg.auto_reset, cfg.obs_env_major,
+                           (T*)obs, (T*)reward, done, (T*)info, (T*)final_obs);
+        HIPCHK(hipGetLastError());
+        if (cfg.auto_reset) return post_reset(obs, s);
+        return KS_OK;
+    }
+    int substep(const void* ctrl, hipStream_t s) override {
+        if (!model_loaded) { error = "ks_substep before ks_load_model"; return KS_ERR_STATE; }
+        hipLaunchKernelGGL((k_substep<T, USE_LDS>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, (const T*)ctrl, cfg.n_envs, cfg.solver_iterations);
+        HIPCHK(hipGetLastError());
+        return KS_OK;
+    }
+    int get_state(void* qpos, void* qvel, void* warm, void* contact, int32_t* ncon, int32_t* status, hipStream_t s) override {
+        const size_t N = cfg.n_envs;
+        if (qpos) HIPCHK(hipMemcpyAsync(qpos, b.qpos, NQ * N * sizeof(T), hipMemcpyDefault, s));
+        if (qvel) HIPCHK(hipMemcpyAsync(qvel, b.qvel, NV * N * sizeof(T), hipMemcpyDefault, s));
+        if (warm) HIPCHK(hipMemcpyAsync(warm, b.warm, NV * N * sizeof(T), hipMemcpyDefault, s));
+        if (contact) HIPCHK(hipMemcpyAsync(contact, b.contact, (size_t)NCON_MAX * CON_STRIDE * N * sizeof(T), hipMemcpyDefault, s));
+        if (ncon) HIPCHK(hipMemcpyAsync(ncon, b.ncon, N * sizeof(int32_t), hipMemcpyDefault, s));
+        if (status) HIPCHK(hipMemcpyAsync(status, b.status, N * sizeof(int32_t), hipMemcpyDefault, s));
+        return KS_OK;
+    }
+    int set_state(const void* qpos, const void* qvel, const void* warm, hipStream_t s) override {
+        const size_t N = cfg.n_envs;
+        if (qpos) HIPCHK(hipMemcpyAsync(b.qpos, qpos, NQ * N * sizeof(T), hipMemcpyDefault, s));
+        if (qvel) HIPCHK(hipMemcpyAsync(b.qvel, qvel, NV * N * sizeof(T), hipMemcpyDefault, s));
+        if (warm) HIPCHK(hipMemcpyAsync(b.warm, warm, NV * N * sizeof(T), hipMemcpyDefault, s));
+        return KS_OK;
+    }
+    int kernel_time(int reset, double* avg_ms, int64_t* launches) override {
+        HIPCHK(hipDeviceSynchronize());
+        for (int i = 0; i < ev_used; i++) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, ev0[i], ev1[i]));
+            ev_ms += ms;
+            ev_launches++;
+        }
+        ev_used = 0;
+        if (avg_ms) *avg_ms = ev_launches ? ev_ms / (double)ev_launches : 0.0;
+        if (launches) *launches = ev_launches;
+        if (reset) { ev_ms = 0; ev_launches = 0; }
+        return KS_OK;
+    }
+};
+
+}  // namespace
+
+struct ks_ctx {
+    CtxBase* impl;
+};
+
+extern "C" {
+
+int ks_version(void) { return 1; }
+
+void ks_default_config(ks_config* cfg) {
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->n_envs = 1024;
+    cfg->frame_skip = 15;
+    cfg->horizon = 30;
+    cfg->solver_iterations = 6;
+    cfg->precision = 32;
+    cfg->auto_reset = 0;
+    cfg->obs_env_major = 1;
+}
+
+const char* ks_last_error(const ks_ctx* ctx) { return ctx ? ctx->impl->error.c_str() : g_create_error.c_str(); }
+
+int ks_create(const ks_config* cfg, int device, ks_ctx** out) {
+    if (!cfg || !out || cfg->n_envs <= 0 || cfg->frame_skip <= 0 || cfg->solver_iterations <= 0 || (cfg->precision != 32 && cfg->precision != 64)) {
+        g_create_error = "ks_create: invalid configuration";
+        return KS_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        g_create_error = "ks_create: no usable HIP device (this library has no CPU path)";
+        return KS_ERR_NO_DEVICE;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "ks_create: hipSetDevice failed"; return KS_ERR_HIP; }
+    CtxBase* impl = cfg->precision == 32 ? (CtxBase*)new Ctx<float>() : (CtxBase*)new Ctx<double>();
+    impl->cfg = *cfg;
+    impl->device = device;
+    int r = cfg->precision == 32 ? static_cast<Ctx<float>*>(impl)->init() : static_cast<Ctx<double>*>(impl)->init();
+    if (r != KS_OK) { g_create_error = impl->error; delete impl; return r; }
+    *out = new ks_ctx{impl};
+    return KS_OK;
+}
+
+void ks_destroy(ks_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->impl->device);
+    (void)hipDeviceSynchronize();
+    delete ctx->impl;
+    delete ctx;
+}
+
+int ks_load_model(ks_ctx* ctx, const void* blob, size_t n) {
+    if (!ctx || !blob) return KS_ERR_INVALID;
+    return ctx->impl->load_model(blob, n);
+}
+int ks_reset(ks_ctx* ctx, const int32_t* ids, int32_t n, const void* q0, const void* hq, void* obs, void* stream) {
+    if (!ctx) return KS_ERR_INVALID;
+    return ctx->impl->reset(ids, n, q0, hq, obs, (hipStream_t)stream);
+}
+int ks_step(ks_ctx* ctx, const void* action, void* obs, void* reward, uint8_t* done, void* info, void* final_obs, void* stream) {
+    if (!ctx) return KS_ERR_INVALID;
+    return ctx->impl->step(action, obs, reward, done, info, final_obs, (hipStream_t)stream);
+}
+int ks_get_state(ks_ctx* ctx, void* qpos, void* qvel, void* warm, void* contact, int32_t* ncon, int32_t* status, void* stream) {
+    if (!ctx) return KS_ERR_INVALID;
+    return ctx->impl->get_state(qpos, qvel, warm, contact, ncon, status, (hipStream_t)stream);
+}
+int ks_set_state(ks_ctx* ctx, const void* qpos, const void* qvel, const void* warm, void* stream) {
+    if (!ctx) return KS_ERR_INVALID;
+    return ctx->impl->set_state(qpos, qvel, warm, (hipStream_t)stream);
+}
+int ks_substep(ks_ctx* ctx, const void* ctrl, void* stream) {
+    if (!ctx) return KS_ERR_INVALID;
+    return ctx->impl->substep(ctrl, (hipStream_t)stream);
+}
+int ks_kernel_time(ks_ctx* ctx, int reset, double* avg_ms, int64_t* launches) {
+    if (!ctx) return KS_ERR_INVALID;
+    return ctx->impl->kernel_time(reset, avg_ms, launches);
+}
+
+}  // extern "C"

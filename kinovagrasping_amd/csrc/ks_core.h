@@ -1,0 +1,1166 @@
+// ks_core.h -- one-env-per-lane mj_step for the Kinova j2s7s300 end effector (S1-S7).
+//
+// What it replaces: `self._sim.step()` at kinova_gripper_env.py:1535 (MuJoCo 1.50 mj_step through
+// mujoco-py), 15 times per env.step() (frame_skip, kinova_gripper_env.py:51,1516).
+//
+// Design (MI355X-first, NOT a translation of a generic engine):
+//  * one env per wavefront lane; fixed topology (3 slides, 3 planar two-link fingers, one free
+//    object) is exploited analytically: block-structured mass matrix, closed-form finger
+//    Coriolis terms, contact Jacobians rebuilt from contact geometry instead of being stored;
+//  * per-lane dynamic state that needs runtime indexing (body poses, contact list, per-contact
+//    solver scalars) lives in a lane-interleaved scratch `S` (LDS, stride 64 floats -> bank ==
+//    lane, conflict free); everything with static indexing stays in registers;
+//  * hull vertex / face tables are wave-uniform reads (scalar loads through the constant cache);
+//  * constraint solver: exact Newton on the 15-dim primal problem (MuJoCo's default solver for
+//    this model) with a fixed iteration count so lanes stay in lock step.
+//
+// The code is KS_HD so the same source is lane-checked on the CPU against the fp64 oracle.
+#pragma once
+#include "ks_model.h"
+
+namespace ks {
+
+// ---------------------------------------------------------------- scratch layout (units of T)
+// body poses b = 2..9: 12 each (R row-major 9, p 3)
+constexpr int SCR_BP = 0;
+constexpr int SCR_CON = SCR_BP + 8 * 12;
+constexpr int CON_STRIDE = 20;
+// per contact: 0-2 pos, 3-5 normal, 6 dist, 7 mu, 8 bodies (b1 + 16*b2), 9 R, 10-13 aref[4],
+//              14-16 J.a basis (n,t1,t2), 17-19 J.p basis
+constexpr int SCR_TOTAL = SCR_CON + NCON_MAX * CON_STRIDE;   // 576
+
+// Lane-interleaved scratch accessor: element k of this lane lives at base[k*stride].
+template <typename T> struct Scratch {
+    T* base;
+    int stride;
+    KS_HD T& operator()(int k) const { return base[(long)k * stride]; }
+};
+
+template <typename T> struct LaneState {
+    T qpos[NQ], qvel[NV], warm[NV];
+};
+
+// kinematics of the hand + object kept in registers for the smooth dynamics
+template <typename T> struct Kin {
+    T ax[3][3];              // world slide axes
+    T p7[3];
+    T Rp[3][9], pp[3][3];    // proximal links
+    T Rd[3][9], pd[3][3];    // distal links
+    T Ro[9], po[3];
+};
+
+// ---------------------------------------------------------------- S1 forward kinematics
+template <typename T, typename S>
+KS_HD void forward_kinematics(const Model<T>& m, const T* qpos, const T* R7, Kin<T>& k, S scr) {
+    KS_UNROLL
+    for (int i = 0; i < 3; i++) mulRv(k.ax[i], R7, m.slide_axis[i]);
+    KS_UNROLL
+    for (int i = 0; i < 3; i++) k.p7[i] = m.l7_pos[i] + k.ax[0][i] * qpos[0] + k.ax[1][i] * qpos[1] + k.ax[2][i] * qpos[2];
+    KS_UNROLL
+    for (int f = 0; f < 3; f++) {
+        T Rb[9], Rz[9], t[3];
+        mulRR(Rb, R7, m.fbase_R[f]);
+        T a = qpos[3 + 2 * f], c = kcos(a), s = ksin(a);
+        Rz[0] = c; Rz[1] = -s; Rz[2] = 0; Rz[3] = s; Rz[4] = c; Rz[5] = 0; Rz[6] = 0; Rz[7] = 0; Rz[8] = 1;
+        mulRR(k.Rp[f], Rb, Rz);
+        mulRv(t, R7, m.fbase_pos[f]);
+        add3(k.pp[f], k.p7, t);
+        mulRR(Rb, k.Rp[f], m.ftip_R[f]);
+        a = qpos[4 + 2 * f]; c = kcos(a); s = ksin(a);
+        Rz[0] = c; Rz[1] = -s; Rz[3] = s; Rz[4] = c;
+        mulRR(k.Rd[f], Rb, Rz);
+        mulRv(t, k.Rp[f], m.ftip_pos[f]);
+        add3(k.pd[f], k.pp[f], t);
+    }
+    T q[4] = {qpos[12], qpos[13], qpos[14], qpos[15]};
+    quatnormalize(q);
+    quat2mat(k.Ro, q);
+    copy3(k.po, &qpos[9]);
+    // body poses -> scratch (runtime-indexed by collision / contact code)
+    KS_UNROLL
+    for (int j = 0; j < 9; j++) scr(SCR_BP + j) = R7[j];
+    KS_UNROLL
+    for (int j = 0; j < 3; j++) scr(SCR_BP + 9 + j) = k.p7[j];
+    KS_UNROLL
+    for (int f = 0; f < 3; f++) {
+        int o1 = SCR_BP + (1 + 2 * f) * 12, o2 = SCR_BP + (2 + 2 * f) * 12;
+        KS_UNROLL
+        for (int j = 0; j < 9; j++) { scr(o1 + j) = k.Rp[f][j]; scr(o2 + j) = k.Rd[f][j]; }
+        KS_UNROLL
+        for (int j = 0; j < 3; j++) { scr(o1 + 9 + j) = k.pp[f][j]; scr(o2 + 9 + j) = k.pd[f][j]; }
+    }
+    KS_UNROLL
+    for (int j = 0; j < 9; j++) scr(SCR_BP + 7 * 12 + j) = k.Ro[j];
+    KS_UNROLL
+    for (int j = 0; j < 3; j++) scr(SCR_BP + 7 * 12 + 9 + j) = k.po[j];
+}
+
+// world pose of geom g (1..8) from the body pose in scratch
+template <typename T, typename S> KS_HD void geom_pose(const Model<T>& m, S scr, int g, T* R, T* p) {
+    int o = SCR_BP + (m.geom_body[g] - 2) * 12;
+    T Rb[9], pb[3], t[3];
+    KS_UNROLL
+    for (int j = 0; j < 9; j++) Rb[j] = scr(o + j);
+    KS_UNROLL
+    for (int j = 0; j < 3; j++) pb[j] = scr(o + 9 + j);
+    mulRR(R, Rb, m.geom_R[g]);
+    mulRv(t, Rb, m.geom_pos[g]);
+    add3(p, pb, t);
+}
+
+// ---------------------------------------------------------------- S2+S3 smooth dynamics
+// Mh: hand 9x9 (row-major full, symmetric), Mo: object 6x6.  qfrc = passive - bias + actuator.
+template <typename T>
+KS_HD void smooth_dynamics(const Model<T>& m, const Kin<T>& k, const T* qvel, const T* ctrl, T* Mh, T* Mo, T* qfrc) {
+    KS_UNROLL
+    for (int i = 0; i < 81; i++) Mh[i] = 0;
+    KS_UNROLL
+    for (int i = 0; i < 36; i++) Mo[i] = 0;
+    T bias[NV];
+    KS_UNROLL
+    for (int i = 0; i < NV; i++) bias[i] = 0;
+    const T g = -m.gravity_z;   // a_com - gravity = a_com + (0,0,g)
+    // link_7 and total hand mass on the slides
+    T mt = m.mass[2];
+    KS_UNROLL
+    for (int b = 3; b <= 8; b++) mt += m.mass[b];
+    KS_UNROLL
+    for (int i = 0; i < 3; i++) {
+        KS_UNROLL
+        for (int j = 0; j < 3; j++) Mh[i * 9 + j] = mt * dot3(k.ax[i], k.ax[j]);
+        bias[i] += m.mass[2] * g * k.ax[i][2];
+    }
+    KS_UNROLL
+    for (int f = 0; f < 3; f++) {
+        const int hp = 3 + 2 * f, hd = 4 + 2 * f, bP = 3 + 2 * f, bD = 4 + 2 * f;
+        const T mP = m.mass[bP], mD = m.mass[bD];
+        T z[3] = {k.Rp[f][2], k.Rp[f][5], k.Rp[f][8]};
+        T rPP[3], rDD[3], rDP[3], t[3];
+        mulRv(rPP, k.Rp[f], m.ipos[bP]);
+        mulRv(rDD, k.Rd[f], m.ipos[bD]);
+        sub3(t, k.pd[f], k.pp[f]);
+        add3(rDP, t, rDD);
+        T jP[3], jDp[3], jDd[3];
+        cross3(jP, z, rPP);
+        cross3(jDp, z, rDP);
+        cross3(jDd, z, rDD);
+        Mh[hp * 9 + hp] = mP * dot3(jP, jP) + mD * dot3(jDp, jDp) + m.izz[bP] + m.izz[bD];
+        Mh[hp * 9 + hd] = Mh[hd * 9 + hp] = mD * dot3(jDp, jDd) + m.izz[bD];
+        Mh[hd * 9 + hd] = mD * dot3(jDd, jDd) + m.izz[bD];
+        T sP[3] = {mP * jP[0] + mD * jDp[0], mP * jP[1] + mD * jDp[1], mP * jP[2] + mD * jDp[2]};
+        KS_UNROLL
+        for (int i = 0; i < 3; i++) {
+            Mh[i * 9 + hp] = Mh[hp * 9 + i] = dot3(k.ax[i], sP);
+            Mh[i * 9 + hd] = Mh[hd * 9 + i] = mD * dot3(k.ax[i], jDd);
+        }
+        // velocity-product accelerations of the two COMs (planar chain about z):
+        // a = w x (w x r) = -w^2 * r_perp
+        T wP = qvel[hp], wD = qvel[hp] + qvel[hd];
+        T aP[3], aD[3], u[3], zs[3];
+        scl3(zs, z, wP);
+        cross3(u, zs, rPP); cross3(aP, zs, u);
+        cross3(u, zs, t); cross3(aD, zs, u);           // distal origin
+        scl3(zs, z, wD);
+        cross3(u, zs, rDD); cross3(u, zs, u);
+        add3(aD, aD, u);
+        aP[2] += g; aD[2] += g;
+        T FP[3], FD[3];
+        scl3(FP, aP, mP);
+        scl3(FD, aD, mD);
+        KS_UNROLL
+        for (int i = 0; i < 3; i++) bias[i] += dot3(k.ax[i], FP) + dot3(k.ax[i], FD);
+        bias[hp] += dot3(jP, FP) + dot3(jDp, FD);
+        bias[hd] += dot3(jDd, FD);
+    }
+    // object (free joint: linear world, angular body frame)
+    {
+        const T mo = m.mass[9];
+        T c[3];
+        mulRv(c, k.Ro, m.ipos[9]);
+        KS_UNROLL
+        for (int i = 0; i < 3; i++) Mo[i * 6 + i] = mo;
+        T cb[3] = {m.ipos[9][0], m.ipos[9][1], m.ipos[9][2]};
+        T cc = dot3(cb, cb);
+        KS_UNROLL
+        for (int a = 0; a < 3; a++) {
+            T e[3] = {T(a == 0), T(a == 1), T(a == 2)}, ec[3], w[3];
+            cross3(ec, e, cb);
+            mulRv(w, k.Ro, ec);                        // R_a x c (world)
+            KS_UNROLL
+            for (int i = 0; i < 3; i++) Mo[i * 6 + 3 + a] = Mo[(3 + a) * 6 + i] = mo * w[i];
+            KS_UNROLL
+            for (int b = 0; b < 3; b++) Mo[(3 + a) * 6 + 3 + b] = m.obj_Ib[a * 3 + b] + mo * ((a == b ? cc : T(0)) - cb[a] * cb[b]);
+        }
+        // bias: F = m (w x (w x c) + g e_z), T = w x I w (world) ; angular rows in the body frame
+        T wl[3] = {qvel[12], qvel[13], qvel[14]}, w[3], u[3], ac[3];
+        mulRv(w, k.Ro, wl);
+        cross3(u, w, c); cross3(ac, w, u);
+        ac[2] += g;
+        T F[3];
+        scl3(F, ac, mo);
+        T Iwl[3], tl[3];
+        mulRv(Iwl, m.obj_Ib, wl);
+        cross3(tl, wl, Iwl);                            // body frame torque w x I w
+        T cF[3], cFl[3];
+        cross3(cF, c, F);
+        mulRtv(cFl, k.Ro, cF);
+        KS_UNROLL
+        for (int i = 0; i < 3; i++) { bias[9 + i] = F[i]; bias[12 + i] = cFl[i] + tl[i]; }
+    }
+    KS_UNROLL
+    for (int i = 0; i < 9; i++) Mh[i * 9 + i] += m.armature[i];
+    KS_UNROLL
+    for (int i = 0; i < 6; i++) Mo[i * 6 + i] += m.armature[9 + i];
+    // passive (joint damping) + actuation (XML:214-222)
+    KS_UNROLL
+    for (int i = 0; i < NV; i++) qfrc[i] = -m.damping[i] * qvel[i] - bias[i];
+    KS_UNROLL
+    for (int j = 0; j < 3; j++) {
+        qfrc[j] += m.act[0] * (clampT(ctrl[2 * j], -m.act[2], m.act[2]) - qvel[j]) + m.act[1] * ctrl[2 * j + 1];
+        qfrc[3 + 2 * j] += m.act[3] * (clampT(ctrl[6 + j], -m.act[4], m.act[4]) - qvel[3 + 2 * j]);
+    }
+}
+
+// y = M x  (block diagonal)
+template <typename T> KS_HD void mul_M(const T* Mh, const T* Mo, const T* x, T* y) {
+    KS_UNROLL
+    for (int i = 0; i < 9; i++) {
+        T v = 0;
+        KS_UNROLL
+        for (int j = 0; j < 9; j++) v += Mh[i * 9 + j] * x[j];
+        y[i] = v;
+    }
+    KS_UNROLL
+    for (int i = 0; i < 6; i++) {
+        T v = 0;
+        KS_UNROLL
+        for (int j = 0; j < 6; j++) v += Mo[i * 6 + j] * x[9 + j];
+        y[9 + i] = v;
+    }
+}
+
+// ---------------------------------------------------------------- S4 collision
+template <typename T> struct Supp { T v[3], v1[3], v2[3]; };
+
+template <typename T> struct PairGeo {
+    T R1[9], p1[3], R2[9], p2[3];
+    const T* V1; const T* V2;
+    int n1, n2;
+    T half_margin;
+};
+
+template <typename T> KS_HD void hull_support(const T* R, const T* p, const T* V, int n, const T* dir, T hm, T* out) {
+    T ld[3];
+    mulRtv(ld, R, dir);
+    T best = -Lim<T>::big;
+    int bi = 0;
+    for (int i = 0; i < n; i++) {
+        T d = V[3 * i] * ld[0] + V[3 * i + 1] * ld[1] + V[3 * i + 2] * ld[2];
+        if (d > best) { best = d; bi = i; }
+    }
+    T v[3] = {V[3 * bi], V[3 * bi + 1], V[3 * bi + 2]};
+    mulRv(out, R, v);
+    add3(out, out, p);
+    addscl3(out, dir, hm);
+}
+
+template <typename T> KS_HD void mpr_support(const PairGeo<T>& g, const T* dir, Supp<T>& o) {
+    T nd[3] = {-dir[0], -dir[1], -dir[2]};
+    hull_support(g.R1, g.p1, g.V1, g.n1, dir, g.half_margin, o.v1);
+    hull_support(g.R2, g.p2, g.V2, g.n2, nd, g.half_margin, o.v2);
+    sub3(o.v, o.v1, o.v2);
+}
+
+template <typename T> KS_HD bool is_zero(T x) { return kabs(x) < T(1e-15); }
+template <typename T> KS_HD bool vec_is_zero(const T* v) { return is_zero(v[0]) && is_zero(v[1]) && is_zero(v[2]); }
+
+template <typename T> KS_HD void portal_dir(const Supp<T>& v1, const Supp<T>& v2, const Supp<T>& v3, T* dir) {
+    T a[3], b[3];
+    sub3(a, v2.v, v1.v);
+    sub3(b, v3.v, v1.v);
+    cross3(dir, a, b);
+    normalize3(dir);
+}
+
+template <typename T>
+KS_HD bool portal_reach_tol(const Supp<T>& v1, const Supp<T>& v2, const Supp<T>& v3, const Supp<T>& v4, const T* dir, T tol) {
+    T dv4 = dot3(v4.v, dir);
+    T d1 = dv4 - dot3(v1.v, dir), d2 = dv4 - dot3(v2.v, dir), d3 = dv4 - dot3(v3.v, dir);
+    T d = d1 < d2 ? d1 : d2;
+    d = d < d3 ? d : d3;
+    return is_zero(d) || d < tol;
+}
+
+template <typename T> KS_HD void assign(Supp<T>& d, const Supp<T>& s) {
+    KS_UNROLL
+    for (int i = 0; i < 3; i++) { d.v[i] = s.v[i]; d.v1[i] = s.v1[i]; d.v2[i] = s.v2[i]; }
+}
+
+template <typename T>
+KS_HD void expand_portal(const Supp<T>& v0, Supp<T>& v1, Supp<T>& v2, Supp<T>& v3, const Supp<T>& v4) {
+    T c[3];
+    cross3(c, v4.v, v0.v);
+    if (dot3(v1.v, c) > 0) {
+        if (dot3(v2.v, c) > 0) assign(v1, v4); else assign(v3, v4);
+    } else {
+        if (dot3(v3.v, c) > 0) assign(v2, v4); else assign(v1, v4);
+    }
+}
+
+template <typename T> KS_HD T origin_segment_dist2(const T* a, const T* b, T* wit) {
+    T d[3];
+    sub3(d, b, a);
+    T t = -dot3(a, d), dd = dot3(d, d);
+    if (t <= 0 || dd < T(1e-15)) copy3(wit, a);
+    else if (t >= dd) copy3(wit, b);
+    else { copy3(wit, a); addscl3(wit, d, t / dd); }
+    return dot3(wit, wit);
+}
+
+template <typename T> KS_HD T origin_tri_dist2(const T* a, const T* b, const T* c, T* wit) {
+    T d1[3], d2[3];
+    sub3(d1, b, a);
+    sub3(d2, c, a);
+    T v = dot3(d1, d1), w = dot3(d2, d2), p = dot3(a, d1), q = dot3(a, d2), r = dot3(d1, d2);
+    T den = w * v - r * r, sp = -1, tp = -1;
+    if (!is_zero(den)) {
+        sp = (q * r - w * p) / den;
+        tp = (-sp * r - q) / w;
+    }
+    if (sp >= 0 && sp <= 1 && tp >= 0 && tp <= 1 && sp + tp <= 1) {
+        copy3(wit, a);
+        addscl3(wit, d1, sp);
+        addscl3(wit, d2, tp);
+        return dot3(wit, wit);
+    }
+    T w2[3], dist = origin_segment_dist2(a, b, wit), dd;
+    dd = origin_segment_dist2(a, c, w2);
+    if (dd < dist) { dist = dd; copy3(wit, w2); }
+    dd = origin_segment_dist2(b, c, w2);
+    if (dd < dist) { dist = dd; copy3(wit, w2); }
+    return dist;
+}
+
+template <typename T>
+KS_HD void find_pos(const Supp<T>& v0, const Supp<T>& v1, const Supp<T>& v2, const Supp<T>& v3, T* pos) {
+    T dir[3], b[4], t[3], sum;
+    portal_dir(v1, v2, v3, dir);
+    cross3(t, v1.v, v2.v); b[0] = dot3(t, v3.v);
+    cross3(t, v3.v, v2.v); b[1] = dot3(t, v0.v);
+    cross3(t, v0.v, v1.v); b[2] = dot3(t, v3.v);
+    cross3(t, v2.v, v1.v); b[3] = dot3(t, v0.v);
+    sum = b[0] + b[1] + b[2] + b[3];
+    if (is_zero(sum) || sum < 0) {
+        b[0] = 0;
+        cross3(t, v2.v, v3.v); b[1] = dot3(t, dir);
+        cross3(t, v3.v, v1.v); b[2] = dot3(t, dir);
+        cross3(t, v1.v, v2.v); b[3] = dot3(t, dir);
+        sum = b[1] + b[2] + b[3];
+    }
+    T inv = T(1) / sum;
+    KS_UNROLL
+    for (int i = 0; i < 3; i++) {
+        T p1 = b[0] * v0.v1[i] + b[1] * v1.v1[i] + b[2] * v2.v1[i] + b[3] * v3.v1[i];
+        T p2 = b[0] * v0.v2[i] + b[1] * v1.v2[i] + b[2] * v2.v2[i] + b[3] * v3.v2[i];
+        pos[i] = T(0.5) * (p1 + p2) * inv;
+    }
+}
+
+// Minkowski Portal Refinement penetration query (same decision structure as the oracle's
+// mpr_penetration / libccd's ccdMPRPenetration).  Returns true on overlap.
+template <typename T>
+KS_HD bool mpr_penetration(const PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir, T* pos) {
+    Supp<T> v0, v1, v2, v3, v4;
+    T d[3], va[3], vb[3];
+    copy3(v0.v1, g.p1);
+    copy3(v0.v2, g.p2);
+    sub3(v0.v, v0.v1, v0.v2);
+    if (vec_is_zero(v0.v)) v0.v[0] += T(1e-5);
+    scl3(d, v0.v, T(-1));
+    normalize3(d);
+    mpr_support(g, d, v1);
+    T dt = dot3(v1.v, d);
+    if (is_zero(dt) || dt < 0) return false;
+    cross3(d, v0.v, v1.v);
+    if (vec_is_zero(d)) {
+        if (vec_is_zero(v1.v)) return false;
+        *depth = norm3(v1.v);
+        copy3(dir, v1.v);
+        normalize3(dir);
+        KS_UNROLL
+        for (int i = 0; i < 3; i++) pos[i] = T(0.5) * (v1.v1[i] + v1.v2[i]);
+        return true;
+    }
+    normalize3(d);
+    mpr_support(g, d, v2);
+    dt = dot3(v2.v, d);
+    if (is_zero(dt) || dt < 0) return false;
+    sub3(va, v1.v, v0.v);
+    sub3(vb, v2.v, v0.v);
+    cross3(d, va, vb);
+    normalize3(d);
+    if (dot3(d, v0.v) > 0) {
+        Supp<T> t;
+        assign(t, v1); assign(v1, v2); assign(v2, t);
+        scl3(d, d, T(-1));
+    }
+    for (int it = 0;; it++) {
+        if (it > 100) return false;
+        mpr_support(g, d, v3);
+        dt = dot3(v3.v, d);
+        if (is_zero(dt) || dt < 0) return false;
+        bool cont = false;
+        cross3(va, v1.v, v3.v);
+        dt = dot3(va, v0.v);
+        if (dt < 0 && !is_zero(dt)) { assign(v2, v3); cont = true; }
+        if (!cont) {
+            cross3(va, v3.v, v2.v);
+            dt = dot3(va, v0.v);
+            if (dt < 0 && !is_zero(dt)) { assign(v1, v3); cont = true; }
+        }
+        if (!cont) break;
+        sub3(va, v1.v, v0.v);
+        sub3(vb, v2.v, v0.v);
+        cross3(d, va, vb);
+        normalize3(d);
+    }
+    for (int it = 0;; it++) {
+        if (it > 100) return false;
+        portal_dir(v1, v2, v3, d);
+        dt = dot3(d, v1.v);
+        if (is_zero(dt) || dt > 0) break;
+        mpr_support(g, d, v4);
+        dt = dot3(v4.v, d);
+        if (!(is_zero(dt) || dt > 0)) return false;
+        if (portal_reach_tol(v1, v2, v3, v4, d, tol)) return false;
+        expand_portal(v0, v1, v2, v3, v4);
+    }
+    for (int it = 0;; it++) {
+        portal_dir(v1, v2, v3, d);
+        mpr_support(g, d, v4);
+        if (portal_reach_tol(v1, v2, v3, v4, d, tol) || it > max_iter) {
+            T wit[3];
+            *depth = ksqrt(origin_tri_dist2(v1.v, v2.v, v3.v, wit));
+            if (vec_is_zero(wit)) return false;
+            copy3(dir, wit);
+            normalize3(dir);
+            find_pos(v0, v1, v2, v3, pos);
+            return true;
+        }
+        expand_portal(v0, v1, v2, v3, v4);
+    }
+}
+
+
+// ---- GJK closest-features query on the un-inflated hulls (margin-zone contacts), same decision
+// structure as the oracle's gjk_distance.  The simplex lives in 4 fixed register slots (compacted,
+// newest vertex last); every slot access is static so nothing spills to scratch memory.
+template <typename T> struct Simplex {
+    T y[4][3], a[4][3], b[4][3];
+    int n;
+};
+
+template <typename T> KS_HD void gjk_support(const PairGeo<T>& g, const T* dir, T* y, T* a, T* b) {
+    T nd[3] = {-dir[0], -dir[1], -dir[2]};
+    hull_support(g.R1, g.p1, g.V1, g.n1, dir, T(0), a);
+    hull_support(g.R2, g.p2, g.V2, g.n2, nd, T(0), b);
+    sub3(y, a, b);
+}
+
+// closest point to the origin on a triangle: barycentric weights (Ericson, RTCD 5.1.5)
+template <typename T> KS_HD void closest_tri(const T* A, const T* B, const T* C, T* l) {
+    T ab[3], ac[3];
+    sub3(ab, B, A); sub3(ac, C, A);
+    T d1 = -dot3(ab, A), d2 = -dot3(ac, A);
+    if (d1 <= 0 && d2 <= 0) { l[0] = 1; l[1] = 0; l[2] = 0; return; }
+    T d3 = -dot3(ab, B), d4 = -dot3(ac, B);
+    if (d3 >= 0 && d4 <= d3) { l[0] = 0; l[1] = 1; l[2] = 0; return; }
+    T vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) { T v = d1 / (d1 - d3); l[0] = 1 - v; l[1] = v; l[2] = 0; return; }
+    T d5 = -dot3(ab, C), d6 = -dot3(ac, C);
+    if (d6 >= 0 && d5 <= d6) { l[0] = 0; l[1] = 0; l[2] = 1; return; }
+    T vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) { T w = d2 / (d2 - d6); l[0] = 1 - w; l[1] = 0; l[2] = w; return; }
+    T va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { T w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); l[0] = 0; l[1] = 1 - w; l[2] = w; return; }
+    T den = T(1) / (va + vb + vc);
+    l[1] = vb * den; l[2] = vc * den; l[0] = 1 - l[1] - l[2];
+}
+
+template <typename T> KS_HD void swap_slots(Simplex<T>& S, T* l, int i, int j, bool doit) {
+    KS_UNROLL
+    for (int c = 0; c < 3; c++) {
+        T t;
+        t = S.y[i][c]; S.y[i][c] = doit ? S.y[j][c] : t; S.y[j][c] = doit ? t : S.y[j][c];
+        t = S.a[i][c]; S.a[i][c] = doit ? S.a[j][c] : t; S.a[j][c] = doit ? t : S.a[j][c];
+        t = S.b[i][c]; S.b[i][c] = doit ? S.b[j][c] : t; S.b[j][c] = doit ? t : S.b[j][c];
+    }
+    T t = l[i]; l[i] = doit ? l[j] : t; l[j] = doit ? t : l[j];
+}
+
+// closest point on the simplex; reduces it to the supporting sub-simplex (stable compaction),
+// lam = weights of the kept vertices, v = closest point.  Returns true if the origin is inside.
+template <typename T> KS_HD bool gjk_closest(Simplex<T>& S, T* lam, T* v) {
+    T l[4] = {0, 0, 0, 0};
+    if (S.n == 1) l[0] = 1;
+    else if (S.n == 2) {
+        T d[3];
+        sub3(d, S.y[1], S.y[0]);
+        T t = -dot3(S.y[0], d), dd = dot3(d, d);
+        if (t <= 0 || dd < T(1e-15)) { l[0] = 1; l[1] = 0; }
+        else if (t >= dd) { l[0] = 0; l[1] = 1; }
+        else { l[1] = t / dd; l[0] = 1 - l[1]; }
+    } else if (S.n == 3) closest_tri(S.y[0], S.y[1], S.y[2], l);
+    else {
+        T best = Lim<T>::big;
+        bool any = false;
+        KS_UNROLL
+        for (int f = 0; f < 4; f++) {
+            // faces (0,1,2|3) (0,2,3|1) (0,3,1|2) (1,3,2|0)
+            const int i0 = f == 3 ? 1 : 0, i1 = f == 0 ? 1 : (f == 1 ? 2 : 3), i2 = f == 0 ? 2 : (f == 1 ? 3 : (f == 2 ? 1 : 2)), i3 = f == 0 ? 3 : (f == 1 ? 1 : (f == 2 ? 2 : 0));
+            T ab[3], ac[3], n[3], ad[3];
+            sub3(ab, S.y[i1], S.y[i0]); sub3(ac, S.y[i2], S.y[i0]); cross3(n, ab, ac); sub3(ad, S.y[i3], S.y[i0]);
+            T sp = -dot3(S.y[i0], n), sd = dot3(ad, n);
+            // a sliver tetrahedron cannot certify "inside": evaluate its faces instead
+            const bool flat = sd * sd <= T(1e-6) * dot3(n, n) * dot3(ad, ad);
+            if (sp * sd < 0 || flat) {
+                T lt[3], q[3] = {0, 0, 0};
+                closest_tri(S.y[i0], S.y[i1], S.y[i2], lt);
+                addscl3(q, S.y[i0], lt[0]); addscl3(q, S.y[i1], lt[1]); addscl3(q, S.y[i2], lt[2]);
+                T d2 = dot3(q, q);
+                if (d2 < best) {
+                    best = d2; any = true;
+                    l[0] = l[1] = l[2] = l[3] = 0;
+                    l[i0] = lt[0]; l[i1] = lt[1]; l[i2] = lt[2];
+                }
+            }
+        }
+        if (!any) return true;
+    }
+    // stable compaction of the vertices with positive weight (static slot indices only)
+    KS_UNROLL
+    for (int i = 0; i < 4; i++)
+        if (i >= S.n) l[i] = 0;
+    KS_UNROLL
+    for (int pass = 0; pass < 3; pass++) {
+        KS_UNROLL
+        for (int i = 0; i < 3; i++) swap_slots(S, l, i, i + 1, !(l[i] > 0) && (l[i + 1] > 0));
+    }
+    int n = 0;
+    KS_UNROLL
+    for (int i = 0; i < 4; i++) { lam[i] = l[i]; n += (l[i] > 0) ? 1 : 0; }
+    S.n = n;
+    v[0] = v[1] = v[2] = 0;
+    KS_UNROLL
+    for (int i = 0; i < 4; i++)
+        if (l[i] > 0) addscl3(v, S.y[i], l[i]);
+    return false;
+}
+
+// 0: separated by >= margin, 1: contact in the margin zone, 2: overlap (fall back to MPR)
+template <typename T> KS_HD int gjk_distance(const PairGeo<T>& g, T margin, T* dist, T* normal, T* pos) {
+    Simplex<T> S;
+    T lam[4] = {1, 0, 0, 0}, v[3], d[3];
+    const T tol = T(1e-6);
+    KS_UNROLL
+    for (int i = 0; i < 4; i++) {
+        KS_UNROLL
+        for (int c = 0; c < 3; c++) { S.y[i][c] = 0; S.a[i][c] = 0; S.b[i][c] = 0; }
+    }
+    sub3(d, g.p2, g.p1);
+    if (dot3(d, d) < T(1e-15)) { d[0] = 1; d[1] = 0; d[2] = 0; }
+    gjk_support(g, d, S.y[0], S.a[0], S.b[0]);
+    S.n = 1;
+    copy3(v, S.y[0]);
+    for (int it = 0; it < 48; it++) {
+        T vv = dot3(v, v);
+        if (vv < T(1e-24)) return 2;
+        T nd[3] = {-v[0], -v[1], -v[2]}, w[3], wa[3], wb[3];
+        gjk_support(g, nd, w, wa, wb);
+        T vw = dot3(v, w);
+#ifdef KS_DEBUG_GJK
+        printf("  gjk[%d] it %d n %d vv %.9g vw %.9g |v| %.9g\n", (int)sizeof(T), it, S.n, (double)vv, (double)vw, (double)ksqrt(vv));
+#endif
+        if (vw > 0 && vw * vw >= margin * margin * vv) return 0;
+        if (vv - vw <= tol * vv) break;
+        bool dup = false;
+        KS_UNROLL
+        for (int i = 0; i < 4; i++)
+            if (i < S.n && S.y[i][0] == w[0] && S.y[i][1] == w[1] && S.y[i][2] == w[2]) dup = true;
+        if (dup) break;
+        Simplex<T> prev = S;
+        T plam[4] = {lam[0], lam[1], lam[2], lam[3]}, pv[3] = {v[0], v[1], v[2]};
+        KS_UNROLL
+        for (int i = 0; i < 4; i++)
+            if (i == S.n) { copy3(S.y[i], w); copy3(S.a[i], wa); copy3(S.b[i], wb); }
+        S.n++;
+        if (gjk_closest(S, lam, v)) return 2;
+        if (dot3(v, v) >= vv) {
+            copy3(v, pv);
+            S = prev;
+            lam[0] = plam[0]; lam[1] = plam[1]; lam[2] = plam[2]; lam[3] = plam[3];
+            break;
+        }
+    }
+    T dd = norm3(v);
+    if (dd < T(1e-12)) return 2;
+    if (dd >= margin) return 0;
+    T p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
+    KS_UNROLL
+    for (int i = 0; i < 4; i++)
+        if (i < S.n) { addscl3(p1, S.a[i], lam[i]); addscl3(p2, S.b[i], lam[i]); }
+    *dist = dd;
+    KS_UNROLL
+    for (int i = 0; i < 3; i++) { normal[i] = -v[i] / dd; pos[i] = T(0.5) * (p1[i] + p2[i]); }
+    return 1;
+}
+
+template <typename T> KS_HD void make_frame(const T* n, T* t1, T* t2) {
+    t1[0] = 0; t1[1] = 0; t1[2] = 0;
+    if (n[1] < T(0.5) && n[1] > T(-0.5)) t1[1] = 1; else t1[2] = 1;
+    T d = dot3(n, t1);
+    addscl3(t1, n, -d);
+    normalize3(t1);
+    cross3(t2, n, t1);
+}
+
+template <typename T, typename S>
+KS_HD void add_contact(S scr, int& ncon, int& status, int b1, int b2, T mu, T dist, const T* pos, const T* normal) {
+    if (ncon >= NCON_MAX) { status |= ST_CONTACT_OVERFLOW; return; }
+    int o = SCR_CON + ncon * CON_STRIDE;
+    T n[3] = {normal[0], normal[1], normal[2]};
+    normalize3(n);
+    KS_UNROLL
+    for (int i = 0; i < 3; i++) { scr(o + i) = pos[i]; scr(o + 3 + i) = n[i]; }
+    scr(o + 6) = dist;
+    scr(o + 7) = mu;
+    scr(o + 8) = T(b1 + 16 * b2);
+    ncon++;
+}
+
+// all contact pairs of the model (explicit pairs first, then the dynamic candidates), S4
+template <typename T, typename S> KS_HD void collision(const Model<T>& m, S scr, int& ncon, int& status) {
+    ncon = 0;
+    const T PLANE_MESH_TOL = T(0.3);
+    for (int pi = 0; pi < m.npair; pi++) {
+        const int g1 = m.pair_g1[pi], g2 = m.pair_g2[pi];
+        const T margin = m.pair_margin[pi], mu = m.pair_mu[pi];
+        T R2[9], p2[3];
+        geom_pose(m, scr, g2, R2, p2);
+        const int mesh2 = m.geom_mesh[g2], nv2 = m.mesh_nvert[mesh2];
+        const T* V2 = m.mesh_vert[mesh2];
+        if (g1 == 0) {
+            // ground plane z = 0 (normal +z) vs hull: deepest vertex, then up to 3 more within the
+            // margin that are > 0.3*rbound from every accepted vertex
+            const T cdist = p2[2];
+            if (cdist > m.geom_rbound[g2] + margin) continue;
+            T ln[3] = {R2[6], R2[7], R2[8]};          // R2^T e_z
+            int best = 0;
+            T bd = Lim<T>::big;
+            for (int i = 0; i < nv2; i++) {
+                T d = cdist + V2[3 * i] * ln[0] + V2[3 * i + 1] * ln[1] + V2[3 * i + 2] * ln[2];
+                if (d < bd) { bd = d; best = i; }
+            }
+            if (bd > margin) continue;
+            T cv[4][3];
+            int nc = 1;
+            cv[0][0] = V2[3 * best]; cv[0][1] = V2[3 * best + 1]; cv[0][2] = V2[3 * best + 2];
+            T thr2 = PLANE_MESH_TOL * m.geom_rbound[g2];
+            thr2 *= thr2;
+            for (int i = 0; i < nv2; i++) {
+                T v[3] = {V2[3 * i], V2[3 * i + 1], V2[3 * i + 2]};
+                T d = cdist + dot3(v, ln);
+                bool ok = (d <= margin) && (nc < 4);
+                KS_UNROLL
+                for (int k = 0; k < 4; k++) {
+                    if (k < nc) {
+                        T dv[3];
+                        sub3(dv, v, cv[k]);
+                        if (dot3(dv, dv) <= thr2) ok = false;
+                    }
+                }
+                if (ok) {
+                    KS_UNROLL
+                    for (int k = 0; k < 4; k++)
+                        if (k == nc) { cv[k][0] = v[0]; cv[k][1] = v[1]; cv[k][2] = v[2]; }
+                    nc++;
+                }
+            }
+            const T normal[3] = {0, 0, 1};
+            KS_UNROLL
+            for (int k = 0; k < 4; k++) {
+                if (k < nc) {
+                    T d = cdist + dot3(cv[k], ln), w[3];
+                    mulRv(w, R2, cv[k]);
+                    add3(w, w, p2);
+                    w[2] -= T(0.5) * d;
+                    add_contact(scr, ncon, status, 0, m.geom_body[g2], mu, d, w, normal);
+                }
+            }
+        } else {
+            PairGeo<T> pg;
+            geom_pose(m, scr, g1, pg.R1, pg.p1);
+            T t[3];
+            sub3(t, pg.p1, p2);
+            T bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin;
+            if (dot3(t, t) > bound * bound) continue;
+            KS_UNROLL
+            for (int j = 0; j < 9; j++) pg.R2[j] = R2[j];
+            copy3(pg.p2, p2);
+            const int mesh1 = m.geom_mesh[g1];
+            pg.V1 = m.mesh_vert[mesh1]; pg.n1 = m.mesh_nvert[mesh1];
+            pg.V2 = V2; pg.n2 = nv2;
+            pg.half_margin = T(0);
+            T depth, dist, dir[3], pos[3];
+            const int r = gjk_distance(pg, margin, &dist, dir, pos);
+            if (r == 1) add_contact(scr, ncon, status, m.geom_body[g1], m.geom_body[g2], mu, dist, pos, dir);
+            else if (r == 2 && mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, dir, pos))
+                add_contact(scr, ncon, status, m.geom_body[g1], m.geom_body[g2], mu, -depth, pos, dir);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- S5 constraint rows
+template <typename T> KS_HD T impedance(const T* solimp, T x) {
+    T dmin = solimp[0], dmax = solimp[1], width = solimp[2], y;
+    x = kabs(x) / width;
+    if (x >= 1) return dmax;
+    if (x <= T(0.5)) y = 2 * x * x; else y = 1 - 2 * (1 - x) * (1 - x);
+    return dmin + y * (dmax - dmin);
+}
+
+// Basis Jacobian of a contact, B[a][j] = frame_a . (Jp_b2(pos) - Jp_b1(pos))[:,j], rebuilt from
+// the contact geometry and the body poses in scratch (nothing per-contact is stored but 9 floats).
+template <typename T, typename S>
+KS_HD void contact_basis(const Kin<T>& k, S scr, int ci, T B[3][NV], T& dist, T& mu) {
+    const int o = SCR_CON + ci * CON_STRIDE;
+    T pos[3] = {scr(o), scr(o + 1), scr(o + 2)};
+    T fr[3][3];
+    fr[0][0] = scr(o + 3); fr[0][1] = scr(o + 4); fr[0][2] = scr(o + 5);
+    make_frame(fr[0], fr[1], fr[2]);
+    dist = scr(o + 6);
+    mu = scr(o + 7);
+    const int bb = (int)scr(o + 8);
+    T Jd[3][NV];
+    KS_UNROLL
+    for (int i = 0; i < 3; i++) {
+        KS_UNROLL
+        for (int j = 0; j < NV; j++) Jd[i][j] = 0;
+    }
+    KS_UNROLL
+    for (int side = 0; side < 2; side++) {
+        const int b = side == 0 ? (bb & 15) : (bb >> 4);
+        const T sg = side == 0 ? T(-1) : T(1);
+        if (b >= 2 && b <= 8) {
+            KS_UNROLL
+            for (int s = 0; s < 3; s++) {
+                KS_UNROLL
+                for (int i = 0; i < 3; i++) Jd[i][s] += sg * k.ax[s][i];
+            }
+        }
+        KS_UNROLL
+        for (int f = 0; f < 3; f++) {
+            const int bP = 3 + 2 * f, bD = 4 + 2 * f;
+            if (b == bP || b == bD) {
+                T z[3] = {k.Rp[f][2], k.Rp[f][5], k.Rp[f][8]}, r[3], c[3];
+                sub3(r, pos, k.pp[f]);
+                cross3(c, z, r);
+                KS_UNROLL
+                for (int i = 0; i < 3; i++) Jd[i][3 + 2 * f] += sg * c[i];
+                if (b == bD) {
+                    sub3(r, pos, k.pd[f]);
+                    cross3(c, z, r);
+                    KS_UNROLL
+                    for (int i = 0; i < 3; i++) Jd[i][4 + 2 * f] += sg * c[i];
+                }
+            }
+        }
+        if (b == 9) {
+            T r[3];
+            sub3(r, pos, k.po);
+            KS_UNROLL
+            for (int a = 0; a < 3; a++) {
+                Jd[a][9 + a] += sg;
+                T axv[3] = {k.Ro[a], k.Ro[3 + a], k.Ro[6 + a]}, c[3];
+                cross3(c, axv, r);
+                KS_UNROLL
+                for (int i = 0; i < 3; i++) Jd[i][12 + a] += sg * c[i];
+            }
+        }
+    }
+    KS_UNROLL
+    for (int a = 0; a < 3; a++) {
+        KS_UNROLL
+        for (int j = 0; j < NV; j++) B[a][j] = fr[a][0] * Jd[0][j] + fr[a][1] * Jd[1][j] + fr[a][2] * Jd[2][j];
+    }
+}
+
+// Scalar (non-contact) rows kept in registers: 3 tendon equalities + up to 6 joint limits
+template <typename T> struct ScalarRows {
+    T eq_aref[3], eq_R[3];
+    T lim_sign[6], lim_aref[6], lim_R[6];   // sign 0 = inactive; joints: slides 0-2, proximal hinges 3,5,7
+};
+
+template <typename T, typename S>
+KS_HD void make_constraints(const Model<T>& m, const Kin<T>& k, const T* qpos, const T* qvel, S scr, int ncon, ScalarRows<T>& r) {
+    KS_UNROLL
+    for (int t = 0; t < 3; t++) {
+        const T c0 = m.tendon_coef[t][0], c1 = m.tendon_coef[t][1];
+        T pos = c0 * qpos[3 + 2 * t] + c1 * qpos[4 + 2 * t];
+        T vel = c0 * qvel[3 + 2 * t] + c1 * qvel[4 + 2 * t];
+        T imp = impedance(m.solimp, pos);
+        r.eq_aref[t] = -m.solref_b * vel - m.solref_k * imp * pos;
+        T R = (1 - imp) / imp * m.tendon_invw[t];
+        r.eq_R[t] = R > T(1e-15) ? R : T(1e-15);
+    }
+    KS_UNROLL
+    for (int j = 0; j < 6; j++) {
+        const int dof = j < 3 ? j : 3 + 2 * (j - 3);
+        T lo, hi;
+        bool limited = true;
+        if (j < 3) { lo = m.slide_range[j][0]; hi = m.slide_range[j][1]; }
+        else { lo = m.hinge_range[2 * (j - 3)][0]; hi = m.hinge_range[2 * (j - 3)][1]; limited = m.hinge_limited[2 * (j - 3)] != 0; }
+        T q = qpos[dof], sign = 0, pos = 0;
+        if (limited && q - lo < 0) { sign = 1; pos = q - lo; }
+        if (limited && hi - q < 0) { sign = -1; pos = hi - q; }
+        T imp = impedance(m.solimp, pos);
+        r.lim_sign[j] = sign;
+        r.lim_aref[j] = -m.solref_b * sign * qvel[dof] - m.solref_k * imp * pos;
+        T R = (1 - imp) / imp * m.dof_invw[dof];
+        r.lim_R[j] = R > T(1e-15) ? R : T(1e-15);
+    }
+    for (int ci = 0; ci < ncon; ci++) {
+        const int o = SCR_CON + ci * CON_STRIDE;
+        T B[3][NV], dist, mu;
+        contact_basis(k, scr, ci, B, dist, mu);
+        T vb[3];
+        KS_UNROLL
+        for (int a = 0; a < 3; a++) {
+            T v = 0;
+            KS_UNROLL
+            for (int j = 0; j < NV; j++) v += B[a][j] * qvel[j];
+            vb[a] = v;
+        }
+        const int bb = (int)scr(o + 8);
+        const T margin = m.pair_margin[0];   // one margin for every pair of this model (XML:40)
+        T rr = dist - margin;
+        T imp = impedance(m.solimp, rr);
+        T w = m.body_invw[bb & 15] + m.body_invw[bb >> 4];
+        T diag = (w + mu * mu * w) * 2 * mu * mu / m.impratio;
+        T R = (1 - imp) / imp * diag;
+        // rows with dist >= margin are inactive: flag with R < 0
+        scr(o + 9) = (dist < margin) ? (R > T(1e-15) ? R : T(1e-15)) : T(-1);
+        T base = -m.solref_k * imp * rr;
+        scr(o + 10) = -m.solref_b * (vb[0] + mu * vb[1]) + base;
+        scr(o + 11) = -m.solref_b * (vb[0] - mu * vb[1]) + base;
+        scr(o + 12) = -m.solref_b * (vb[0] + mu * vb[2]) + base;
+        scr(o + 13) = -m.solref_b * (vb[0] - mu * vb[2]) + base;
+    }
+}
+
+// ---------------------------------------------------------------- S6 Newton solver
+// cost of the constraint part + Gauss part at acceleration a (used for the warm-start choice)
+template <typename T, typename S>
+KS_HD T primal_cost(const Model<T>& m, const Kin<T>& k, const T* Mh, const T* Mo, const T* qacc_smooth, const ScalarRows<T>& r, S scr,
+                    int ncon, const T* a) {
+    T d[NV], Md[NV], c = 0;
+    KS_UNROLL
+    for (int i = 0; i < NV; i++) d[i] = a[i] - qacc_smooth[i];
+    mul_M(Mh, Mo, d, Md);
+    KS_UNROLL
+    for (int i = 0; i < NV; i++) c += T(0.5) * d[i] * Md[i];
+    KS_UNROLL
+    for (int t = 0; t < 3; t++) {
+        T x = m.tendon_coef[t][0] * a[3 + 2 * t] + m.tendon_coef[t][1] * a[4 + 2 * t] - r.eq_aref[t];
+        c += T(0.5) * x * x / r.eq_R[t];
+    }
+    KS_UNROLL
+    for (int j = 0; j < 6; j++) {
+        const int dof = j < 3 ? j : 3 + 2 * (j - 3);
+        T x = r.lim_sign[j] * a[dof] - r.lim_aref[j];
+        if (r.lim_sign[j] != 0 && x < 0) c += T(0.5) * x * x / r.lim_R[j];
+    }
+    for (int ci = 0; ci < ncon; ci++) {
+        const int o = SCR_CON + ci * CON_STRIDE;
+        T R = scr(o + 9);
+        if (R < 0) continue;
+        T B[3][NV], dist, mu, xb[3];
+        contact_basis(k, scr, ci, B, dist, mu);
+        KS_UNROLL
+        for (int q = 0; q < 3; q++) {
+            T v = 0;
+            KS_UNROLL
+            for (int j = 0; j < NV; j++) v += B[q][j] * a[j];
+            xb[q] = v;
+        }
+        KS_UNROLL
+        for (int kk = 0; kk < 4; kk++) {
+            T x = xb[0] + ((kk & 1) ? -mu : mu) * xb[1 + (kk >> 1)] - scr(o + 10 + kk);
+            if (x < 0) c += T(0.5) * x * x / R;
+        }
+    }
+    return c;
+}
+
+// Solve for qacc.  Outputs a (qacc) and qfrc_c (J^T f).
+template <typename T, typename S>
+KS_HD void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T* Mo, const T* qfrc_smooth, const T* qacc_smooth,
+                        const T* warm, const ScalarRows<T>& r, S scr, int ncon, int iterations, T* a, T* qfrc_c) {
+    {
+        T cw = primal_cost(m, k, Mh, Mo, qacc_smooth, r, scr, ncon, warm);
+        T cs = primal_cost(m, k, Mh, Mo, qacc_smooth, r, scr, ncon, qacc_smooth);
+        const bool use_warm = cw < cs;
+        KS_UNROLL
+        for (int i = 0; i < NV; i++) a[i] = use_warm ? warm[i] : qacc_smooth[i];
+    }
+    for (int it = 0; it < iterations; it++) {
+        T H[NV * NV], g[NV], Ma[NV];
+        mul_M(Mh, Mo, a, Ma);
+        KS_UNROLL
+        for (int i = 0; i < NV; i++) { Ma[i] -= qfrc_smooth[i]; g[i] = Ma[i]; }
+        KS_UNROLL
+        for (int i = 0; i < NV; i++) {
+            KS_UNROLL
+            for (int j = 0; j <= i; j++) H[i * NV + j] = (i < 9 && j < 9) ? Mh[i * 9 + j] : ((i >= 9 && j >= 9) ? Mo[(i - 9) * 6 + (j - 9)] : T(0));
+        }
+        // scalar rows
+        T eq_x[3], lim_x[6];
+        KS_UNROLL
+        for (int t = 0; t < 3; t++) {
+            const T c0 = m.tendon_coef[t][0], c1 = m.tendon_coef[t][1];
+            const int ip = 3 + 2 * t, id = 4 + 2 * t;
+            T x = c0 * a[ip] + c1 * a[id] - r.eq_aref[t], D = T(1) / r.eq_R[t];
+            eq_x[t] = x;
+            g[ip] += c0 * D * x; g[id] += c1 * D * x;
+            H[ip * NV + ip] += D * c0 * c0; H[id * NV + ip] += D * c0 * c1; H[id * NV + id] += D * c1 * c1;
+        }
+        KS_UNROLL
+        for (int j = 0; j < 6; j++) {
+            const int dof = j < 3 ? j : 3 + 2 * (j - 3);
+            T x = r.lim_sign[j] * a[dof] - r.lim_aref[j];
+            lim_x[j] = x;
+            if (r.lim_sign[j] != 0 && x < 0) {
+                T D = T(1) / r.lim_R[j];
+                g[dof] += r.lim_sign[j] * D * x;
+                H[dof * NV + dof] += D;
+            }
+        }
+        // contacts: gradient + Hessian, basis values J.a cached in scratch
+        for (int ci = 0; ci < ncon; ci++) {
+            const int o = SCR_CON + ci * CON_STRIDE;
+            T R = scr(o + 9);
+            if (R < 0) continue;
+            T B[3][NV], dist, mu, xb[3];
+            contact_basis(k, scr, ci, B, dist, mu);
+            KS_UNROLL
+            for (int q = 0; q < 3; q++) {
+                T v = 0;
+                KS_UNROLL
+                for (int j = 0; j < NV; j++) v += B[q][j] * a[j];
+                xb[q] = v;
+                scr(o + 14 + q) = v;
+            }
+            const T D = T(1) / R;
+            T act[4], y[4];
+            KS_UNROLL
+            for (int kk = 0; kk < 4; kk++) {
+                T x = xb[0] + ((kk & 1) ? -mu : mu) * xb[1 + (kk >> 1)] - scr(o + 10 + kk);
+                act[kk] = x < 0 ? T(1) : T(0);
+                y[kk] = D * x * act[kk];
+            }
+            const T gn = y[0] + y[1] + y[2] + y[3], gt1 = mu * (y[0] - y[1]), gt2 = mu * (y[2] - y[3]);
+            const T Cnn = D * (act[0] + act[1] + act[2] + act[3]);
+            const T Cn1 = D * mu * (act[0] - act[1]), Cn2 = D * mu * (act[2] - act[3]);
+            const T C11 = D * mu * mu * (act[0] + act[1]), C22 = D * mu * mu * (act[2] + act[3]);
+            if (Cnn == 0) continue;
+            T W[3][NV];
+            KS_UNROLL
+            for (int j = 0; j < NV; j++) {
+                g[j] += B[0][j] * gn + B[1][j] * gt1 + B[2][j] * gt2;
+                W[0][j] = Cnn * B[0][j] + Cn1 * B[1][j] + Cn2 * B[2][j];
+                W[1][j] = Cn1 * B[0][j] + C11 * B[1][j];
+                W[2][j] = Cn2 * B[0][j] + C22 * B[2][j];
+            }
+            KS_UNROLL
+            for (int i = 0; i < NV; i++) {
+                KS_UNROLL
+                for (int j = 0; j <= i; j++) H[i * NV + j] += B[0][i] * W[0][j] + B[1][i] * W[1][j] + B[2][i] * W[2][j];
+            }
+        }
+        // Newton direction
+        chol_inplace<T, NV>(H);
+        T ng[NV], p[NV], Mp[NV];
+        KS_UNROLL
+        for (int i = 0; i < NV; i++) ng[i] = -g[i];
+        chol_solve<T, NV>(H, ng, p);
+        mul_M(Mh, Mo, p, Mp);
+        T pMa = 0, pMp = 0;
+        KS_UNROLL
+        for (int i = 0; i < NV; i++) { pMa += p[i] * Ma[i]; pMp += p[i] * Mp[i]; }
+        T eq_p[3], lim_p[6];
+        KS_UNROLL
+        for (int t = 0; t < 3; t++) eq_p[t] = m.tendon_coef[t][0] * p[3 + 2 * t] + m.tendon_coef[t][1] * p[4 + 2 * t];
+        KS_UNROLL
+        for (int j = 0; j < 6; j++) lim_p[j] = r.lim_sign[j] * p[j < 3 ? j : 3 + 2 * (j - 3)];
+        for (int ci = 0; ci < ncon; ci++) {
+            const int o = SCR_CON + ci * CON_STRIDE;
+            if (scr(o + 9) < 0) continue;
+            T B[3][NV], dist, mu;
+            contact_basis(k, scr, ci, B, dist, mu);
+            KS_UNROLL
+            for (int q = 0; q < 3; q++) {
+                T v = 0;
+                KS_UNROLL
+                for (int j = 0; j < NV; j++) v += B[q][j] * p[j];
+                scr(o + 17 + q) = v;
+            }
+        }
+        // exact line search on phi'(alpha) (piecewise linear, increasing)
+        T alpha = 0, lo = 0, hi = -1;
+        for (int ls = 0; ls < 30; ls++) {
+            T d1 = pMa + alpha * pMp, d2 = pMp;
+            KS_UNROLL
+            for (int t = 0; t < 3; t++) {
+                T x = eq_x[t] + alpha * eq_p[t], D = T(1) / r.eq_R[t];
+                d1 += D * x * eq_p[t]; d2 += D * eq_p[t] * eq_p[t];
+            }
+            KS_UNROLL
+            for (int j = 0; j < 6; j++) {
+                T x = lim_x[j] + alpha * lim_p[j];
+                if (r.lim_sign[j] != 0 && x < 0) { T D = T(1) / r.lim_R[j]; d1 += D * x * lim_p[j]; d2 += D * lim_p[j] * lim_p[j]; }
+            }
+            for (int ci = 0; ci < ncon; ci++) {
+                const int o = SCR_CON + ci * CON_STRIDE;
+                T R = scr(o + 9);
+                if (R < 0) continue;
+                const T D = T(1) / R, mu = scr(o + 7);
+                T xb[3], pb[3];
+                KS_UNROLL
+                for (int q = 0; q < 3; q++) { xb[q] = scr(o + 14 + q); pb[q] = scr(o + 17 + q); }
+                KS_UNROLL
+                for (int kk = 0; kk < 4; kk++) {
+                    const T sm = (kk & 1) ? -mu : mu;
+                    T jp = pb[0] + sm * pb[1 + (kk >> 1)];
+                    T x = xb[0] + sm * xb[1 + (kk >> 1)] - scr(o + 10 + kk) + alpha * jp;
+                    if (x < 0) { d1 += D * x * jp; d2 += D * jp * jp; }
+                }
+            }
+            if (d2 < T(1e-15)) break;
+            if (d1 < 0) lo = alpha; else hi = alpha;
+            T next = alpha - d1 / d2;
+            if (hi >= 0 && (next <= lo || next >= hi)) next = T(0.5) * (lo + hi);
+            if (next < lo) next = lo;
+            const bool stop = kabs(next - alpha) <= T(1e-14) * (1 + kabs(alpha)) || kabs(next - alpha) <= T(4) * T(sizeof(T) == 4 ? 6e-8 : 1.2e-16) * kabs(alpha);
+            alpha = next;
+            if (stop) break;
+        }
+        KS_UNROLL
+        for (int i = 0; i < NV; i++) a[i] += alpha * p[i];
+    }
+    // constraint forces at the final a -> qfrc_c = J^T f
+    KS_UNROLL
+    for (int i = 0; i < NV; i++) qfrc_c[i] = 0;
+    KS_UNROLL
+    for (int t = 0; t < 3; t++) {
+        const T c0 = m.tendon_coef[t][0], c1 = m.tendon_coef[t][1];
+        T x = c0 * a[3 + 2 * t] + c1 * a[4 + 2 * t] - r.eq_aref[t], f = -x / r.eq_R[t];
+        qfrc_c[3 + 2 * t] += c0 * f; qfrc_c[4 + 2 * t] += c1 * f;
+    }
+    KS_UNROLL
+    for (int j = 0; j < 6; j++) {
+        const int dof = j < 3 ? j : 3 + 2 * (j - 3);
+        T x = r.lim_sign[j] * a[dof] - r.lim_aref[j];
+        if (r.lim_sign[j] != 0 && x < 0) qfrc_c[dof] += r.lim_sign[j] * (-x / r.lim_R[j]);
+    }
+    for (int ci = 0; ci < ncon; ci++) {
+        const int o = SCR_CON + ci * CON_STRIDE;
+        T R = scr(o + 9);
+        if (R < 0) { scr(o + 14) = 0; scr(o + 15) = 0; scr(o + 16) = 0; continue; }
+        T B[3][NV], dist, mu, xb[3];
+        contact_basis(k, scr, ci, B, dist, mu);
+        KS_UNROLL
+        for (int q = 0; q < 3; q++) {
+            T v = 0;
+            KS_UNROLL
+            for (int j = 0; j < NV; j++) v += B[q][j] * a[j];
+            xb[q] = v;
+        }
+        T f[4];
+        KS_UNROLL
+        for (int kk = 0; kk < 4; kk++) {
+            T x = xb[0] + ((kk & 1) ? -mu : mu) * xb[1 + (kk >> 1)] - scr(o + 10 + kk);
+            f[kk] = x < 0 ? -x / R : T(0);
+        }
+        const T fn = f[0] + f[1] + f[2] + f[3], ft1 = mu * (f[0] - f[1]), ft2 = mu * (f[2] - f[3]);
+        // contact force in the contact frame (normal, tangent1, tangent2): parity tap
+        scr(o + 14) = fn; scr(o + 15) = ft1; scr(o + 16) = ft2;
+        KS_UNROLL
+        for (int j = 0; j < NV; j++) qfrc_c[j] += B[0][j] * fn + B[1][j] * ft1 + B[2][j] * ft2;
+    }
+}
+
+// ---------------------------------------------------------------- one mj_step (forward + Euler)
+template <typename T, typename S>
+KS_HD void mj_forward_step(const Model<T>& m, T* qpos, T* qvel, T* warm, const T* ctrl, const T* R7, S scr, int solver_iterations,
+                           bool integrate, int& ncon_out, int& status) {
+    Kin<T> k;
+    forward_kinematics(m, qpos, R7, k, scr);
+    T Mh[81], Mo[36], qfrc[NV];
+    smooth_dynamics(m, k, qvel, ctrl, Mh, Mo, qfrc);
+    int ncon = 0;
+    collision(m, scr, ncon, status);
+    ncon_out = ncon;
+    if (!integrate) return;
+    ScalarRows<T> rows;
+    make_constraints(m, k, qpos, qvel, scr, ncon, rows);
+    // qacc_smooth = M^-1 qfrc
+    T Lh[81], Lo[36], qacc_s[NV];
+    KS_UNROLL
+    for (int i = 0; i < 81; i++) Lh[i] = Mh[i];
+    KS_UNROLL
+    for (int i = 0; i < 36; i++) Lo[i] = Mo[i];
+    chol_inplace<T, 9>(Lh);
+    chol_inplace<T, 6>(Lo);
+    chol_solve<T, 9>(Lh, qfrc, qacc_s);
+    chol_solve<T, 6>(Lo, qfrc + 9, qacc_s + 9);
+    T a[NV], qfrc_c[NV];
+    solve_newton(m, k, Mh, Mo, qfrc, qacc_s, warm, rows, scr, ncon, solver_iterations, a, qfrc_c);
+    // S7 Euler with implicit joint damping: (M + h D) qacc' = qfrc_smooth + qfrc_constraint
+    const T h = m.dt;
+    KS_UNROLL
+    for (int i = 0; i < NV; i++) warm[i] = a[i];
+    KS_UNROLL
+    for (int i = 0; i < 81; i++) Lh[i] = Mh[i];
+    KS_UNROLL
+    for (int i = 0; i < 36; i++) Lo[i] = Mo[i];
+    KS_UNROLL
+    for (int i = 0; i < 9; i++) Lh[i * 9 + i] += h * m.damping[i];
+    KS_UNROLL
+    for (int i = 0; i < 6; i++) Lo[i * 6 + i] += h * m.damping[9 + i];
+    T f[NV], qa[NV];
+    KS_UNROLL
+    for (int i = 0; i < NV; i++) f[i] = qfrc[i] + qfrc_c[i];
+    chol_inplace<T, 9>(Lh);
+    chol_inplace<T, 6>(Lo);
+    chol_solve<T, 9>(Lh, f, qa);
+    chol_solve<T, 6>(Lo, f + 9, qa + 9);
+    bool finite = true;
+    KS_UNROLL
+    for (int i = 0; i < NV; i++) {
+        qvel[i] += h * qa[i];
+        finite = finite && (qvel[i] == qvel[i]) && kabs(qvel[i]) < T(1e10);
+    }
+    KS_UNROLL
+    for (int i = 0; i < 12; i++) qpos[i] += h * qvel[i];
+    T w[3] = {qvel[12], qvel[13], qvel[14]};
+    T ang = norm3(w) * h;
+    if (ang > T(1e-15)) {
+        normalize3(w);
+        T sa = ksin(T(0.5) * ang), dq[4] = {kcos(T(0.5) * ang), w[0] * sa, w[1] * sa, w[2] * sa};
+        quatmul(&qpos[12], &qpos[12], dq);
+    }
+    quatnormalize(&qpos[12]);
+    if (!finite) status |= ST_NONFINITE;
+}
+
+}  // namespace ks

@@ -1,0 +1,47 @@
+// ks_model.h -- device-side model constants (one per loaded .ksm blob), templated on real type.
+// Filled on the host by ks_model_host.cpp from the blob written by model_compiler.py; lives in
+// device memory and is read through wave-uniform (scalar) loads by every kernel.
+#pragma once
+#include "ks_math.h"
+
+namespace ks {
+
+constexpr int NQ = 16, NV = 15, NU = 9, NBODY = 10, NGEOM = 9, NSITE = 17, NSENSOR = 26, NOBS = 82;
+constexpr int NPAIR_MAX = 32;
+constexpr int NCON_MAX = 24;   // contacts kept per env per substep (oracle: KO_NCON_MAX)
+constexpr int NRAY = 17;
+
+// status bits reported per env
+constexpr int ST_CONTACT_OVERFLOW = 1, ST_NONFINITE = 2;
+
+template <typename T> struct Model {
+    T dt, impratio, gravity_z, mpr_tol;
+    T solref_k, solref_b;      // k = 1/(dmax^2 tc^2 dr^2), b = 2/(dmax tc), tc >= 2 dt
+    T solimp[3];
+    int mpr_iters;
+    T l7_pos[3];
+    T slide_axis[3][3], slide_range[3][2];
+    T hinge_range[6][2];
+    int hinge_limited[6];
+    T damping[NV], armature[NV];
+    T mass[NBODY], ipos[NBODY][3];
+    T izz[NBODY];              // inertia about the body z axis (hinge axis) for finger links
+    T fbase_pos[3][3], fbase_R[3][9];   // proximal body frames in link_7
+    T ftip_pos[3][3], ftip_R[3][9];     // distal body frames in the proximal
+    T obj_Ib[9];               // object inertia about its COM, body frame (row-major)
+    T geom_pos[NGEOM][3], geom_R[NGEOM][9], geom_rbound[NGEOM], geom_size[NGEOM][3];
+    int geom_body[NGEOM], geom_mesh[NGEOM];
+    T site_pos[NSITE][3], site_z[NSITE][3];
+    int site_body[NSITE];
+    int npair, pair_g1[NPAIR_MAX], pair_g2[NPAIR_MAX];
+    T pair_mu[NPAIR_MAX], pair_margin[NPAIR_MAX];
+    T tendon_coef[3][2];
+    T act[5];                  // kv_slide, gear_motor, ctrlrange_slide, kv_finger, ctrlrange_finger
+    T dof_invw[NV], body_invw[NBODY], tendon_invw[3];
+    T obj_size_obs[3];
+    int mesh_nvert[4], mesh_nplane[4];
+    const T* mesh_vert[4];     // [nvert][3] in the geom frame
+    const T* mesh_plane[4];    // [nplane][4]  n.x <= d
+};
+
+}  // namespace ks

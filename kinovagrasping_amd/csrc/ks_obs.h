@@ -1,0 +1,251 @@
+// ks_obs.h -- rangefinder rays (S8), 82-d observation (O1,O2), reward / termination (O3).
+//
+// Replaces kinova_gripper_env.py:_get_obs (438-534) with its helpers (274-343, 356-362, 538-608)
+// and _get_reward (631-687); the rangefinder part replaces MuJoCo's mj_sensorPos for the 17
+// <rangefinder> sensors (XML:265-288).
+//
+// Inputs are the body poses that mj_forward computed at the START of the last substep (the
+// reference never calls sim.forward() after its 15th sim.step(), so everything the observation
+// reads lags qpos by one substep) -- the "snapshot".  KS_HD: lane-checked on the CPU too.
+#pragma once
+#include "ks_model.h"
+
+namespace ks {
+
+constexpr int SNAP_BP = 0;           // body poses b = 2..9, 12 each
+constexpr int SNAP_JPOS = 96;        // 9 jointpos sensors: slides, proximal 1-3, distal 1-3
+constexpr int SNAP_TOTAL = 105;
+
+// strided view of one env's column in a [K][N] struct-of-arrays buffer
+template <typename T> struct Col {
+    const T* base;
+    long stride;
+    KS_HD T operator()(int k) const { return base[(long)k * stride]; }
+};
+
+template <typename T, typename C> KS_HD void snap_body(C snap, int b, T* R, T* p) {
+    const int o = SNAP_BP + (b - 2) * 12;
+    KS_UNROLL
+    for (int j = 0; j < 9; j++) R[j] = snap(o + j);
+    KS_UNROLL
+    for (int j = 0; j < 3; j++) p[j] = snap(o + 9 + j);
+}
+
+// ray vs convex hull given as face planes n.x <= d in the geom frame; -1 = miss
+template <typename T> KS_HD T ray_hull(const T* P, int np, const T* lp, const T* lv) {
+    T tin = -Lim<T>::big, tout = Lim<T>::big;
+    bool miss = false;
+    for (int i = 0; i < np; i++) {
+        const T nx = P[4 * i], ny = P[4 * i + 1], nz = P[4 * i + 2], d = P[4 * i + 3];
+        T den = nx * lv[0] + ny * lv[1] + nz * lv[2];
+        T num = d - (nx * lp[0] + ny * lp[1] + nz * lp[2]);
+        if (kabs(den) < T(1e-15)) { if (num < 0) miss = true; continue; }
+        T tt = num / den;
+        if (den < 0) { if (tt > tin) tin = tt; } else { if (tt < tout) tout = tt; }
+    }
+    if (miss || tin > tout || tout < 0) return T(-1);
+    return tin >= 0 ? tin : tout;
+}
+
+// one rangefinder: ray from site `si` along its +z, geoms of the site's own body excluded
+template <typename T, typename C> KS_HD T rangefinder(const Model<T>& m, C snap, int si) {
+    T Rb[9], pb[3], pnt[3], vec[3], t[3];
+    const int sb = m.site_body[si];
+    snap_body<T>(snap, sb, Rb, pb);
+    mulRv(t, Rb, m.site_pos[si]);
+    add3(pnt, pb, t);
+    mulRv(vec, Rb, m.site_z[si]);
+    T best = T(-1);
+    // ground plane z = 0 with finite half-size (XML:148)
+    if (kabs(vec[2]) > T(1e-15)) {
+        T tt = -pnt[2] / vec[2];
+        if (tt >= 0) {
+            T x = pnt[0] + tt * vec[0], y = pnt[1] + tt * vec[1];
+            if (kabs(x) <= m.geom_size[0][0] && kabs(y) <= m.geom_size[0][1]) best = tt;
+        }
+    }
+    for (int g = 1; g < NGEOM; g++) {
+        const int gb = m.geom_body[g];
+        if (gb == sb) continue;
+        T R[9], p[3], Rg[9], pg[3];
+        snap_body<T>(snap, gb, R, p);
+        mulRR(Rg, R, m.geom_R[g]);
+        mulRv(t, R, m.geom_pos[g]);
+        add3(pg, p, t);
+        // bounding-sphere cull (conservative: a ray that misses the sphere misses the hull)
+        T oc[3];
+        sub3(oc, pg, pnt);
+        T tc = dot3(oc, vec), d2 = dot3(oc, oc) - tc * tc, rb = m.geom_rbound[g];
+        if (d2 > rb * rb || (tc < 0 && dot3(oc, oc) > rb * rb)) continue;
+        T lp[3], lv[3];
+        sub3(t, pnt, pg);
+        mulRtv(lp, Rg, t);
+        mulRtv(lv, Rg, vec);
+        const int mesh = m.geom_mesh[g];
+        T d = ray_hull(m.mesh_plane[mesh], m.mesh_nplane[mesh], lp, lv);
+        if (d >= 0 && (best < 0 || d < best)) best = d;
+    }
+    return best;
+}
+
+template <typename T> KS_HD T tri_area(const T* a, const T* b) {
+    T c[3];
+    cross3(c, a, b);
+    return norm3(c) * T(0.5);
+}
+
+template <typename T> KS_HD T dot_product20(const T* obj, const T* hand) {
+    T ox = kabs(obj[0] - hand[0]), oy = kabs(obj[1] - hand[1]);
+    T on = ksqrt(ox * ox + oy * oy);
+    T cx = kabs(hand[0]), cy = kabs(hand[1]);
+    T cn = ksqrt(cx * cx + cy * cy);
+    T d = (ox / on) * (cx / cn) + (oy / on) * (cy / cn);
+    // d^20 by repeated squaring (d in [0,1]); same value as pow(d,20) to rounding
+    T d2 = d * d, d4 = d2 * d2, d8 = d4 * d4, d16 = d8 * d8;
+    return d16 * d4;
+}
+
+// palm transform (ENV:274-288): T3 = (R_palm C)^T rows, wrist = p_palm + T3^T [-0.009, 0.048, 0]
+template <typename T> KS_HD void palm_transform(const T* Rpalm, const T* ppalm, T* T3, T* wrist) {
+    // (R C) with C = [[0,0,1],[-1,0,0],[0,-1,0]]: columns of RC = (-R[:,1], -R[:,2], R[:,0])
+    KS_UNROLL
+    for (int i = 0; i < 3; i++) {
+        T3[0 * 3 + i] = -Rpalm[3 * i + 1];
+        T3[1 * 3 + i] = -Rpalm[3 * i + 2];
+        T3[2 * 3 + i] = Rpalm[3 * i + 0];
+    }
+    const T off[3] = {T(-0.009), T(0.048), T(0)};
+    KS_UNROLL
+    for (int i = 0; i < 3; i++) wrist[i] = ppalm[i] + T3[i] * off[0] + T3[3 + i] * off[1] + T3[6 + i] * off[2];
+}
+
+// action (4) -> 9 controls (ENV:1495-1535); R_palm is constant over an episode for this model
+template <typename T> KS_HD void action_to_ctrl(const T* T3, const T* act4, T* ctrl) {
+    const T a[6] = {0, 0, act4[0], act4[1], act4[2], act4[3]};
+    const T ff = T(0.733) * T(10) / T(25);
+    KS_UNROLL
+    for (int i = 0; i < 3; i++) {
+        T stuff = T3[3 * i + 2] * ff;
+        T slide = T3[3 * i] * a[0] + T3[3 * i + 1] * a[1] + T3[3 * i + 2] * a[2];
+        if (i < 2) { stuff = -stuff; slide = -slide; }
+        ctrl[2 * i] = slide;
+        ctrl[2 * i + 1] = stuff;
+        ctrl[6 + i] = a[3 + i];
+    }
+}
+
+// Full local observation + reward from a snapshot and the 17 ray distances.
+// obs is written through `put(j, value)`.
+template <typename T, typename C, typename Put>
+KS_HD void build_obs(const Model<T>& m, C snap, const T* rays, Put put, T& reward, bool& lifted, T* info) {
+    T R7[9], p7[3], Rpalm[9], ppalm[3], t[3];
+    snap_body<T>(snap, 2, R7, p7);
+    mulRR(Rpalm, R7, m.geom_R[1]);
+    mulRv(t, R7, m.geom_pos[1]);
+    add3(ppalm, p7, t);
+    T T3[9], wrist[3];
+    palm_transform(Rpalm, ppalm, T3, wrist);
+    // finger link geom centres, order f1_prox f2_prox f3_prox f1_dist f2_dist f3_dist (ENV:478)
+    T fw[6][3], fl[18];
+    KS_UNROLL
+    for (int kq = 0; kq < 6; kq++) {
+        const int g = kq < 3 ? 2 + 2 * kq : 3 + 2 * (kq - 3);
+        T R[9], p[3];
+        snap_body<T>(snap, m.geom_body[g], R, p);
+        mulRv(t, R, m.geom_pos[g]);
+        add3(fw[kq], p, t);
+        T d[3];
+        sub3(d, fw[kq], wrist);
+        mulRv(&fl[3 * kq], T3, d);
+    }
+    T Ro[9], po[3], ow[3], ol[3];
+    snap_body<T>(snap, 9, Ro, po);
+    mulRv(t, Ro, m.geom_pos[8]);
+    add3(ow, po, t);
+    sub3(t, ow, wrist);
+    mulRv(ol, T3, t);
+    KS_UNROLL
+    for (int j = 0; j < 18; j++) put(j, fl[j]);
+    // wrist in its own frame: T3 (wrist - wrist) = 0 (ENV:513-516)
+    put(18, T(0)); put(19, T(0)); put(20, T(0));
+    put(21, ol[0]); put(22, ol[1]); put(23, ol[2]);
+    // joint states: jointpos sensors with the first two negated (ENV:356-362)
+    KS_UNROLL
+    for (int j = 0; j < 9; j++) {
+        T v = snap(SNAP_JPOS + j);
+        put(24 + j, j < 2 ? -v : v);
+    }
+    put(33, m.obj_size_obs[0]); put(34, m.obj_size_obs[1]); put(35, m.obj_size_obs[2]);
+    // finger-site to object distances (ENV:538-548), site order f1_prox f1_prox_1 f2_prox ... f1_dist ...
+    {
+        const int order[12] = {5, 6, 9, 10, 13, 14, 7, 8, 11, 12, 15, 16};
+        KS_UNROLL
+        for (int kq = 0; kq < 12; kq++) {
+            const int si = order[kq];
+            T R[9], p[3], sp[3], d[3];
+            snap_body<T>(snap, m.site_body[si], R, p);
+            mulRv(t, R, m.site_pos[si]);
+            add3(sp, p, t);
+            sub3(d, sp, ow);
+            put(36 + kq, norm3(d));
+        }
+    }
+    // x / z angles (ENV:563-582)
+    {
+        T n = norm3(ol), w0 = ol[0] / n, w1 = ol[1] / n, w2 = ol[2] / n;
+        T za = kacos(clampT(w1 / ksqrt(w0 * w0 + w1 * w1), T(-1), T(1)));
+        T xa = kacos(clampT(w1 / ksqrt(w1 * w1 + w2 * w2), T(-1), T(1)));
+        put(48, xa); put(49, za);
+    }
+    T rng[NRAY];
+    KS_UNROLL
+    for (int i = 0; i < NRAY; i++) { rng[i] = rays[i] == T(-1) ? T(6) : rays[i]; put(50 + i, rng[i]); }
+    const T g[3] = {-T3[2], -T3[5], -T3[8]};
+    put(67, g[0]); put(68, g[1]); put(69, g[2]);
+    // experimental_sensor (ENV:290-343)
+    {
+        T s1[3], s2[3];
+        KS_UNROLL
+        for (int i = 0; i < 3; i++) { s1[i] = fl[i] - fl[6 + i]; s2[i] = fl[i] - fl[3 + i]; }
+        T front_area = tri_area(s1, s2);
+        T top1 = tri_area(&fl[0], &fl[9]), top2 = tri_area(&fl[9], &fl[12]), top3 = tri_area(&fl[3], &fl[12]);
+        T top4 = tri_area(&fl[6], &fl[15]), top5 = tri_area(&fl[9], &fl[15]);
+        T total1 = top1 + top2 + top3, total2 = top1 + top4 + top5, top_area = total1 > total2 ? total1 : total2;
+        T sx = 0, sy = 0, sz = 0, nh = 0;
+        KS_UNROLL
+        for (int i = 0; i < 5; i++) {
+            if (rng[i] < T(0.06)) {
+                T sp[3], d[3], l[3];
+                mulRv(t, R7, m.site_pos[i]);
+                add3(sp, p7, t);
+                sub3(d, sp, wrist);
+                mulRv(l, T3, d);
+                l[1] += rng[i];
+                sx += l[0]; sy += l[1]; sz += l[2];
+                nh += 1;
+            }
+        }
+        if (nh == 0) { put(70, T(0.2)); put(71, T(0.2)); put(72, T(0.2)); }
+        else { put(70, sx / nh); put(71, sy / nh); put(72, sz / nh); }
+        const T z0 = m.obj_size_obs[0], z1 = m.obj_size_obs[1], z2 = m.obj_size_obs[2] * T(0.5);
+        int am = 0;
+        if (kabs(g[1]) > kabs(g[am])) am = 1;
+        if (kabs(g[2]) > kabs(g[am])) am = 2;
+        T fp, tp;
+        if (am == 2) { fp = kabs(z0 * z2) / front_area; tp = kabs(z0 * z1) / top_area; }
+        else if (am == 1) { fp = kabs(z0 * z2) / front_area; tp = kabs(z1 * z2) / top_area; }
+        else { fp = kabs(z0 * z1) / front_area; tp = kabs(z0 * z2) / top_area; }
+        put(73, fp); put(74, tp);
+    }
+    KS_UNROLL
+    for (int kq = 0; kq < 6; kq++) put(75 + kq, dot_product20(fw[kq], p7));
+    put(81, dot_product20(ow, p7));
+    // reward / termination (ENV:631-687, with_grasp_reward False)
+    const T target = T(0.2);
+    lifted = (kabs(ow[2] - target) < T(0.005)) || (ow[2] >= target);
+    T lift = lifted ? T(50) : T(0);
+    info[0] = 0; info[1] = 0; info[2] = lift;
+    reward = lift;
+}
+
+}  // namespace ks

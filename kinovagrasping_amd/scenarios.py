@@ -1,0 +1,60 @@
+"""Start states and action streams of the BASELINE.md configurations (host side, numpy)."""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+
+from .model_compiler import euler_to_quat, truncated_euler
+
+ASSETS = Path(__file__).resolve().parent / "assets"
+
+# hand orientation classes, kinova_gripper_env.py:1267-1273 (all non-default xml files)
+ORIENTATION_EULER = {"normal": (-1.57, 0.0, -1.57), "rotated": (-1.2, 0.0, 0.0), "top": (0.0, 0.0, 0.0)}
+SHAPES = [s + z for s in ["Cube", "Cylinder", "Cube45", "Cone1", "Cone2", "Vase1", "Vase2"] for z in "SB"]  # README.md:59
+
+_tables = None
+
+
+def start_coord_table(shape: str, orientation: str = "normal") -> np.ndarray:
+    """Rows of obj_hand_coords/no_noise/train_coords/<Orient>/<shape>.txt as the reference's sampler
+    sees them (first line consumed by the delimiter sniffer, kinova_gripper_env.py:1012)."""
+    global _tables
+    if _tables is None:
+        _tables = np.load(ASSETS / "start_coords_no_noise_train.npz")
+    return _tables[f"{orientation.capitalize()}/{shape}"].astype(np.float64)
+
+
+def hand_quat_for(orientation: str) -> np.ndarray:
+    """Quaternion of j2s7s300_link_7 for an orientation class, including the 5-character string
+    truncation the reference applies when patching the XML (kinova_gripper_env.py:870-874)."""
+    return euler_to_quat(truncated_euler(ORIENTATION_EULER[orientation]))
+
+
+def config1_state(shape: str = "CubeS"):
+    """BASELINE config 1: hand joints 0, object at row 2 of Normal/<shape>.txt, identity quaternion."""
+    q = np.zeros(16)
+    q[9:12] = start_coord_table(shape)[0]
+    q[12] = 1.0
+    return q, hand_quat_for("normal")
+
+
+def config2_states(n_envs: int, shape: str = "CubeS"):
+    """BASELINE config 2: env i starts at row 2 + (i mod 4498) of the same table.  Returns
+    qpos0 [16, N], hand_quat [4, N]."""
+    tab = start_coord_table(shape)
+    idx = np.arange(n_envs) % 4498
+    q = np.zeros((16, n_envs))
+    q[9:12] = tab[idx].T
+    q[12] = 1.0
+    hq = np.repeat(hand_quat_for("normal")[:, None], n_envs, axis=1)
+    return q, hq
+
+
+def config_actions(n_envs: int, n_steps: int = 30, base_seed: int = 1000) -> np.ndarray:
+    """Per-env action streams Generator(PCG64(base_seed + i)).uniform(-0.8, 0.8, (n_steps, 4)) as
+    float32; returns [n_steps, 4, N].  (Config 1 is base_seed=0 with one env.)"""
+    out = np.empty((n_steps, 4, n_envs), dtype=np.float32)
+    for i in range(n_envs):
+        out[:, :, i] = np.random.Generator(np.random.PCG64(base_seed + i)).uniform(-0.8, 0.8, (n_steps, 4)).astype(np.float32)
+    return out

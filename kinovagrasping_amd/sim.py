@@ -1,0 +1,153 @@
+"""ctypes binding of libkinova_sim.so (include/kinova_sim.h).  PyTorch is plumbing here: it owns the
+device tensors and the stream; every compute call goes through the C ABI into the HIP kernels.
+There is no CPU path: constructing a KinovaSim without the library or without a GPU raises."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import build as _build
+
+NQ, NV, NACT, NOBS, NINFO, NCON_MAX, CONTACT_STRIDE = 16, 15, 4, 82, 3, 24, 20
+ASSETS = Path(__file__).resolve().parent / "assets"
+
+
+class KsConfig(C.Structure):
+    _fields_ = [("n_envs", C.c_int32), ("frame_skip", C.c_int32), ("horizon", C.c_int32), ("solver_iterations", C.c_int32),
+                ("precision", C.c_int32), ("auto_reset", C.c_int32), ("obs_env_major", C.c_int32), ("reserved", C.c_int32)]
+
+
+EXPORTS = ["ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_load_model", "ks_reset", "ks_step",
+           "ks_get_state", "ks_set_state", "ks_substep", "ks_kernel_time", "ks_version"]
+
+_lib = None
+
+
+def load_library(path: Path | None = None):
+    """Load libkinova_sim.so (must have been built: kinovagrasping_amd.build.build()).  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(path) if path else _build.LIB
+    if not path.exists():
+        raise RuntimeError(f"{path} is missing: build it with kinovagrasping_amd.build.build() (hipcc, gfx950). "
+                           "There is no fallback implementation.")
+    L = C.CDLL(str(path))
+    vp, i32p = C.c_void_p, C.c_void_p
+    L.ks_default_config.argtypes = [C.POINTER(KsConfig)]
+    L.ks_create.argtypes = [C.POINTER(KsConfig), C.c_int, C.POINTER(vp)]
+    L.ks_destroy.argtypes = [vp]
+    L.ks_last_error.argtypes = [vp]
+    L.ks_last_error.restype = C.c_char_p
+    L.ks_load_model.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.ks_reset.argtypes = [vp, i32p, C.c_int32, vp, vp, vp, vp]
+    L.ks_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ks_get_state.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ks_set_state.argtypes = [vp, vp, vp, vp, vp]
+    L.ks_substep.argtypes = [vp, vp, vp]
+    L.ks_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    _lib = L
+    return L
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class KinovaSim:
+    """N batched envs on one GPU.  All tensors are torch CUDA tensors, field-major [K, N] unless noted."""
+
+    def __init__(self, n_envs: int, model: str | bytes = "CubeS", device: int | torch.device = 0, precision: int = 32,
+                 frame_skip: int = 15, horizon: int = 30, solver_iterations: int = 6, auto_reset: bool = False,
+                 obs_env_major: bool = True):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("KinovaSim needs a HIP GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))
+        self.n_envs = int(n_envs)
+        self.dtype = torch.float32 if precision == 32 else torch.float64
+        self.obs_env_major = bool(obs_env_major)
+        cfg = KsConfig()
+        self.lib.ks_default_config(C.byref(cfg))
+        cfg.n_envs, cfg.frame_skip, cfg.horizon, cfg.solver_iterations = self.n_envs, frame_skip, horizon, solver_iterations
+        cfg.precision, cfg.auto_reset, cfg.obs_env_major = precision, int(auto_reset), int(obs_env_major)
+        self.cfg = cfg
+        self.ctx = C.c_void_p()
+        rc = self.lib.ks_create(C.byref(cfg), self.device.index, C.byref(self.ctx))
+        if rc != 0:
+            raise RuntimeError(f"ks_create failed ({rc}): {self.lib.ks_last_error(None).decode()}")
+        blob = model if isinstance(model, (bytes, bytearray)) else (ASSETS / f"{model}.ksm").read_bytes()
+        self._check(self.lib.ks_load_model(self.ctx, bytes(blob), len(blob)))
+        N, dt, dev = self.n_envs, self.dtype, self.device
+        self.obs = torch.zeros((N, NOBS) if obs_env_major else (NOBS, N), dtype=dt, device=dev)
+        self.final_obs = torch.zeros_like(self.obs)
+        self.reward = torch.zeros(N, dtype=dt, device=dev)
+        self.done = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.info = torch.zeros((NINFO, N), dtype=dt, device=dev)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"libkinova_sim error {rc}: {self.lib.ks_last_error(self.ctx).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.ks_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, qpos0: torch.Tensor, hand_quat: torch.Tensor, env_ids: torch.Tensor | None = None):
+        """qpos0 [16, n], hand_quat [4, n]; env_ids int32 [n] or None (all envs).  Returns the obs buffer."""
+        qpos0 = qpos0.to(self.device, self.dtype).contiguous()
+        hand_quat = hand_quat.to(self.device, self.dtype).contiguous()
+        n = qpos0.shape[1]
+        ids = None if env_ids is None else env_ids.to(self.device, torch.int32).contiguous()
+        self._check(self.lib.ks_reset(self.ctx, _ptr(ids), n, _ptr(qpos0), _ptr(hand_quat), _ptr(self.obs), self._stream()))
+        self._keep = (qpos0, hand_quat, ids)
+        return self.obs
+
+    def step(self, action: torch.Tensor):
+        """action [4, N].  Returns (obs, reward, done, info) views of the context's output buffers."""
+        action = action.to(self.device, self.dtype).contiguous()
+        self._check(self.lib.ks_step(self.ctx, _ptr(action), _ptr(self.obs), _ptr(self.reward), _ptr(self.done), _ptr(self.info),
+                                     _ptr(self.final_obs), self._stream()))
+        self._keep_a = action
+        return self.obs, self.reward, self.done, self.info
+
+    def substep(self, ctrl: torch.Tensor):
+        ctrl = ctrl.to(self.device, self.dtype).contiguous()
+        self._check(self.lib.ks_substep(self.ctx, _ptr(ctrl), self._stream()))
+        self._keep_c = ctrl
+
+    def get_state(self, contacts: bool = False):
+        N, dt, dev = self.n_envs, self.dtype, self.device
+        out = dict(qpos=torch.empty((NQ, N), dtype=dt, device=dev), qvel=torch.empty((NV, N), dtype=dt, device=dev),
+                   qacc_warmstart=torch.empty((NV, N), dtype=dt, device=dev),
+                   ncon=torch.empty(N, dtype=torch.int32, device=dev), status=torch.empty(N, dtype=torch.int32, device=dev))
+        con = torch.empty((NCON_MAX * CONTACT_STRIDE, N), dtype=dt, device=dev) if contacts else None
+        self._check(self.lib.ks_get_state(self.ctx, _ptr(out["qpos"]), _ptr(out["qvel"]), _ptr(out["qacc_warmstart"]), _ptr(con),
+                                          _ptr(out["ncon"]), _ptr(out["status"]), self._stream()))
+        if contacts:
+            out["contact"] = con.view(NCON_MAX, CONTACT_STRIDE, N)
+        return out
+
+    def set_state(self, qpos=None, qvel=None, qacc_warmstart=None):
+        ts = [None if t is None else t.to(self.device, self.dtype).contiguous() for t in (qpos, qvel, qacc_warmstart)]
+        self._check(self.lib.ks_set_state(self.ctx, _ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def kernel_time(self, reset: bool = False):
+        """(average ms of the env-step kernel measured with HIP events on the launch stream, launches)."""
+        ms, n = C.c_double(0), C.c_int64(0)
+        self._check(self.lib.ks_kernel_time(self.ctx, int(reset), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -120,7 +120,7 @@ void ko_env_ctrl(const double Tfw[16], const double *action, int naction, double
 void ko_env_obs_local(const ko_env_inputs *in, double obs[KO_NOBS]);
 void ko_env_obs_global(const ko_env_inputs *in, double obs[KO_NOBS_GLOBAL]);
 void ko_env_reward(double obj_z_world, double *reward, int *done, double info[3]);
-int ko_check_grasp(const double f_dist_old[9], const double f_dist_new[9]);
+int ko_check_grasp(const double *f_dist_old, const double *f_dist_new);
 
 void ko_env_inputs_from_sim(const ko_sim *s, ko_env_inputs *in);
 /* full env.step(): 15 x mj_step then obs/reward exactly as ENV:1495-1552 */

@@ -502,6 +502,144 @@ static int mpr_penetration(mpr_ctx *c, double *depth, double *dir, double *pos) 
     }
 }
 
+
+/* ---- GJK closest-features query on the UN-inflated hulls.
+ * Contacts live in the margin zone (0 <= dist < margin) almost all the time; there the closest
+ * points of two convex polytopes are unique and well conditioned, whereas MPR on margin-inflated
+ * supports mixes inflation directions and returns normals that are sensitive to round-off.  MuJoCo
+ * >= 3.2 ("native ccd") makes the same choice; MuJoCo 1.50 used libccd MPR for both regimes.
+ * Returns 0: separated by >= margin (no contact), 1: contact with dist in (0, margin),
+ * 2: hulls overlap (caller falls back to MPR without inflation). */
+typedef struct { double y[4][3], a[4][3], b[4][3]; int n; } gjk_simplex;
+
+static void gjk_support(mpr_ctx *c, const double *dir, double *y, double *a, double *b) {
+    double nd[3] = {-dir[0], -dir[1], -dir[2]};
+    hull_support(c->s, c->g1, dir, 0.0, a);
+    hull_support(c->s, c->g2, nd, 0.0, b);
+    sub3(y, a, b);
+    c->s->mpr_support_calls++;
+}
+
+/* closest point to the origin on triangle (p0,p1,p2): barycentric l[3] (Ericson, RTCD 5.1.5) */
+static void closest_tri(const double *A, const double *B, const double *C, double *l) {
+    double ab[3], ac[3];
+    sub3(ab, B, A); sub3(ac, C, A);
+    double d1 = -dot3(ab, A), d2 = -dot3(ac, A);
+    if (d1 <= 0 && d2 <= 0) { l[0] = 1; l[1] = 0; l[2] = 0; return; }
+    double d3 = -dot3(ab, B), d4 = -dot3(ac, B);
+    if (d3 >= 0 && d4 <= d3) { l[0] = 0; l[1] = 1; l[2] = 0; return; }
+    double vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) { double v = d1 / (d1 - d3); l[0] = 1 - v; l[1] = v; l[2] = 0; return; }
+    double d5 = -dot3(ab, C), d6 = -dot3(ac, C);
+    if (d6 >= 0 && d5 <= d6) { l[0] = 0; l[1] = 0; l[2] = 1; return; }
+    double vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) { double w = d2 / (d2 - d6); l[0] = 1 - w; l[1] = 0; l[2] = w; return; }
+    double va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { double w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); l[0] = 0; l[1] = 1 - w; l[2] = w; return; }
+    double den = 1.0 / (va + vb + vc);
+    l[1] = vb * den; l[2] = vc * den; l[0] = 1 - l[1] - l[2];
+}
+
+/* closest point to the origin on the simplex; reduces it to the supporting sub-simplex, writes
+ * the barycentric weights of the kept vertices.  Returns 1 if the origin is inside a tetrahedron. */
+static int gjk_closest(gjk_simplex *S, double *lam, double *v) {
+    double l[4] = {0, 0, 0, 0};
+    int keep[4] = {0, 1, 2, 3}, nk = S->n;
+    if (S->n == 1) { l[0] = 1; }
+    else if (S->n == 2) {
+        double d[3];
+        sub3(d, S->y[1], S->y[0]);
+        double t = -dot3(S->y[0], d), dd = dot3(d, d);
+        if (t <= 0 || dd < MINVAL) { l[0] = 1; l[1] = 0; }
+        else if (t >= dd) { l[0] = 0; l[1] = 1; }
+        else { l[1] = t / dd; l[0] = 1 - l[1]; }
+    } else if (S->n == 3) closest_tri(S->y[0], S->y[1], S->y[2], l);
+    else {
+        /* tetrahedron: test the faces the origin lies outside of, keep the nearest */
+        static const int F[4][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 3, 2, 0}};
+        double best = 1e300;
+        int any = 0;
+        for (int f = 0; f < 4; f++) {
+            const double *A = S->y[F[f][0]], *B = S->y[F[f][1]], *C = S->y[F[f][2]], *D = S->y[F[f][3]];
+            double ab[3], ac[3], n[3], ad[3];
+            sub3(ab, B, A); sub3(ac, C, A); cross3(n, ab, ac); sub3(ad, D, A);
+            double sp = -dot3(A, n), sd = dot3(ad, n);
+            /* a sliver (4th vertex within 1e-3 rad of the face plane) cannot certify "inside": its
+             * faces are all evaluated instead, which keeps fp32 and fp64 on the same branch */
+            int flat = sd * sd <= 1e-6 * dot3(n, n) * dot3(ad, ad);
+            if (sp * sd < 0 || flat) { /* origin outside this face (or sliver tetra) */
+                double lt[3], q[3] = {0, 0, 0};
+                closest_tri(A, B, C, lt);
+                addscl3(q, A, lt[0]); addscl3(q, B, lt[1]); addscl3(q, C, lt[2]);
+                double d2 = dot3(q, q);
+                if (d2 < best) {
+                    best = d2; any = 1;
+                    l[0] = l[1] = l[2] = l[3] = 0;
+                    l[F[f][0]] = lt[0]; l[F[f][1]] = lt[1]; l[F[f][2]] = lt[2];
+                }
+            }
+        }
+        if (!any) return 1;
+    }
+    /* compact */
+    gjk_simplex R;
+    R.n = 0;
+    for (int i = 0; i < nk; i++)
+        if (l[keep[i]] > 0) {
+            copy3(R.y[R.n], S->y[i]); copy3(R.a[R.n], S->a[i]); copy3(R.b[R.n], S->b[i]);
+            lam[R.n] = l[i];
+            R.n++;
+        }
+    *S = R;
+    v[0] = v[1] = v[2] = 0;
+    for (int i = 0; i < S->n; i++) addscl3(v, S->y[i], lam[i]);
+    return 0;
+}
+
+static int gjk_distance(mpr_ctx *c, double margin, double *dist, double *normal, double *pos) {
+    gjk_simplex S;
+    double lam[4] = {1, 0, 0, 0}, v[3], d[3];
+    const double tol = 1e-6; /* relative progress tolerance; polytopes normally stop on a repeated vertex */
+    sub3(d, c->s->geom_xpos[c->g2], c->s->geom_xpos[c->g1]);
+    if (dot3(d, d) < MINVAL) { d[0] = 1; d[1] = 0; d[2] = 0; }
+    gjk_support(c, d, S.y[0], S.a[0], S.b[0]);
+    S.n = 1;
+    copy3(v, S.y[0]);
+    for (int it = 0; it < 48; it++) {
+        double vv = dot3(v, v);
+        if (vv < 1e-24) return 2;
+        double nd[3] = {-v[0], -v[1], -v[2]}, w[3], wa[3], wb[3];
+        gjk_support(c, nd, w, wa, wb);
+        double vw = dot3(v, w);
+        if (vw > 0 && vw * vw >= margin * margin * vv) return 0; /* separating plane beyond the margin */
+        if (vv - vw <= tol * vv) break;                          /* no further progress possible */
+        int dup = 0;
+        for (int i = 0; i < S.n; i++)
+            if (S.y[i][0] == w[0] && S.y[i][1] == w[1] && S.y[i][2] == w[2]) dup = 1;
+        if (dup) break;
+        copy3(S.y[S.n], w); copy3(S.a[S.n], wa); copy3(S.b[S.n], wb);
+        S.n++;
+        gjk_simplex prev = S;
+        double plam[4] = {lam[0], lam[1], lam[2], lam[3]}, pv[3] = {v[0], v[1], v[2]};
+        (void)prev;
+        if (gjk_closest(&S, lam, v)) return 2;
+        if (dot3(v, v) >= vv) { /* round-off: no decrease -> keep the previous iterate */
+            copy3(v, pv);
+            S = prev; S.n--;
+            lam[0] = plam[0]; lam[1] = plam[1]; lam[2] = plam[2]; lam[3] = plam[3];
+            break;
+        }
+    }
+    double dd = norm3(v);
+    if (dd < 1e-12) return 2;
+    if (dd >= margin) return 0;
+    double p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
+    for (int i = 0; i < S.n; i++) { addscl3(p1, S.a[i], lam[i]); addscl3(p2, S.b[i], lam[i]); }
+    *dist = dd;
+    for (int i = 0; i < 3; i++) { normal[i] = -v[i] / dd; pos[i] = 0.5 * (p1[i] + p2[i]); }
+    return 1;
+}
+
 /* MuJoCo's mju_makeFrame: complete a contact frame from its normal */
 static void make_frame(double *f) {
     normalize3(f);
@@ -578,9 +716,11 @@ static void collide_hull_hull(ko_sim *s, int g1, int g2, const double *pair) {
     sub3(t, s->geom_xpos[g1], s->geom_xpos[g2]);
     double bound = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
     if (dot3(t, t) > bound * bound) return;
-    mpr_ctx c = {s, g1, g2, 0.5 * margin};
-    double depth, dir[3], pos[3];
-    if (mpr_penetration(&c, &depth, dir, pos) == 0) add_contact(s, g1, g2, pair, margin - depth, pos, dir);
+    mpr_ctx c = {s, g1, g2, 0.0};
+    double depth, dist, dir[3], pos[3];
+    int r = gjk_distance(&c, margin, &dist, dir, pos);
+    if (r == 1) add_contact(s, g1, g2, pair, dist, pos, dir);
+    else if (r == 2 && mpr_penetration(&c, &depth, dir, pos) == 0) add_contact(s, g1, g2, pair, -depth, pos, dir);
 }
 
 static void collision(ko_sim *s) {

@@ -1,0 +1,193 @@
+"""GPU parity tests: the HIP path (through the C ABI, libkinova_sim.so) against the fp64 CPU oracle on
+the same seeded inputs.  Run with `-m gpu` on an MI355X.
+
+Tolerances (fp32 product vs fp64 oracle), stated once:
+  * one mj_step from identical states (teacher forced): |dqpos|_inf <= 2e-6 for >= 95% of the states
+    and median <= 2e-7; the tail is the single-point contact *position* on parallel features
+    (DESIGN.md "known limits"), for which the bound is 5e-3.
+  * free-running config-1 episode: relative qpos error <= 1e-4 (north_star) for at least the first
+    200 substeps; afterwards contact make/break makes trajectories chaotic (SURVEY hard part 2) and
+    the test only reports the first substep that exceeds the tolerance.
+  * fp64 instantiation of the same kernels: <= 1e-9 everywhere (algorithm exactness).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ko_py as ko
+from kinovagrasping_amd import scenarios
+
+pytestmark = pytest.mark.gpu
+
+
+def _sim(*a, **k):
+    from kinovagrasping_amd.sim import KinovaSim
+    return KinovaSim(*a, **k)
+
+
+@pytest.fixture(scope="module")
+def cube(assets_dir):
+    return ko.OracleModel((assets_dir / "CubeS.ksm").read_bytes())
+
+
+def oracle_grasp_trajectory(model, n_sub=330, x0=0.0, y0=0.0, iters=6):
+    """closing fingers, then lifting: returns per-substep (state before, ctrl, state after)"""
+    hq = scenarios.hand_quat_for("normal")
+    s = ko.OracleSim(model, hq, solver_iterations=iters)
+    q0 = np.zeros(16); q0[9:12] = [x0, y0, 0.0654]; q0[12] = 1
+    s.env_reset(q0)
+    ctrl = np.zeros(9); ctrl[5] = 0.2932; ctrl[6:9] = 0.5
+    rec = []
+    for i in range(n_sub):
+        if i == 250:
+            ctrl[4] = 0.5
+        before = (s.view("qpos").copy(), s.view("qvel").copy(), s.view("qacc_warmstart").copy())
+        s.step(ctrl)
+        after = (s.view("qpos").copy(), s.view("qvel").copy(), s.view("qacc_warmstart").copy())
+        rec.append((before, ctrl.copy(), after, s.s.ncon))
+    return hq, rec
+
+
+def run_teacher_forced(precision, model, rec, hq, iters=6):
+    n = len(rec)
+    sim = _sim(n, "CubeS", precision=precision, solver_iterations=iters)
+    dt = sim.dtype
+    q0 = np.stack([r[0][0] for r in rec], 1)
+    sim.reset(torch.as_tensor(q0), torch.as_tensor(np.repeat(hq[:, None], n, 1)))
+    sim.set_state(torch.as_tensor(q0), torch.as_tensor(np.stack([r[0][1] for r in rec], 1)), torch.as_tensor(np.stack([r[0][2] for r in rec], 1)))
+    sim.substep(torch.as_tensor(np.stack([r[1] for r in rec], 1)))
+    st = sim.get_state()
+    torch.cuda.synchronize()
+    qp = st["qpos"].double().cpu().numpy()
+    qv = st["qvel"].double().cpu().numpy()
+    ncon = st["ncon"].cpu().numpy()
+    eq = np.abs(qp - np.stack([r[2][0] for r in rec], 1)).max(0)
+    ev = np.abs(qv - np.stack([r[2][1] for r in rec], 1)).max(0)
+    onc = np.array([r[3] for r in rec])
+    assert (st["status"].cpu().numpy() == 0).all()
+    sim.close()
+    return eq, ev, ncon, onc
+
+
+def test_one_step_fp64_matches_oracle(cube):
+    hq, rec = oracle_grasp_trajectory(cube)
+    eq, ev, ncon, onc = run_teacher_forced(64, cube, rec, hq)
+    assert (ncon == onc).all()
+    assert eq.max() < 1e-9, eq.max()
+    assert ev.max() < 1e-7, ev.max()
+
+
+def test_one_step_fp32_matches_oracle(cube):
+    hq, rec = oracle_grasp_trajectory(cube)
+    eq, ev, ncon, onc = run_teacher_forced(32, cube, rec, hq)
+    print(f"one-step |dqpos|: median {np.median(eq):.2e} p95 {np.percentile(eq, 95):.2e} max {eq.max():.2e};"
+          f" contact-count mismatches {int((ncon != onc).sum())}/{len(onc)}")
+    assert np.median(eq) <= 2e-7
+    assert np.percentile(eq, 95) <= 2e-6
+    assert eq.max() <= 5e-3
+    assert (ncon != onc).mean() <= 0.02
+
+
+def test_config1_episode_free_running(cube):
+    """BASELINE config 1: one CubeS env, PCG64(0) actions, 30 env-steps, GPU fp32 vs oracle."""
+    q0, hq = scenarios.config1_state("CubeS")
+    acts = scenarios.config_actions(1, 30, base_seed=0)[:, :, 0]
+    o = ko.OracleSim(cube, hq, solver_iterations=6)
+    obs_o = [o.env_reset(q0)]
+    sim = _sim(1, "CubeS", solver_iterations=6, horizon=0)
+    obs_g = [sim.reset(torch.as_tensor(q0[:, None]), torch.as_tensor(hq[:, None])).double().cpu().numpy()[0].copy()]
+    first_bad = None
+    for t in range(30):
+        ob, r, d, info = o.env_step(acts[t])
+        og, rg, dg, ig = sim.step(torch.as_tensor(acts[t][:, None]))
+        torch.cuda.synchronize()
+        qg = sim.get_state()["qpos"].double().cpu().numpy()[:, 0]
+        qo = o.view("qpos")
+        rel = np.abs(qg - qo).max() / max(1e-3, np.abs(qo).max())
+        if first_bad is None and rel > 1e-4:
+            first_bad = (t, rel)
+        obs_o.append(ob)
+        obs_g.append(og.double().cpu().numpy()[0].copy())
+        if first_bad is None:
+            assert rg.item() == r and bool(dg.item() & 1) == d
+    print("config1: first env-step with rel qpos error > 1e-4:", first_bad)
+    # reset observation: pure kinematics + rays, must agree tightly
+    np.testing.assert_allclose(obs_g[0], obs_o[0], rtol=2e-4, atol=2e-5)
+    assert first_bad is None or first_bad[0] * 15 >= 200, first_bad
+    sim.close()
+
+
+def test_batch_config2_first_steps(cube):
+    """128 envs of config 2 (different start rows / action streams): 3 env-steps against 128 oracle runs."""
+    n = 128
+    q0, hq = scenarios.config2_states(n)
+    acts = scenarios.config_actions(n, 3)
+    sim = _sim(n, "CubeS", solver_iterations=6)
+    og = sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+    orc = [ko.OracleSim(cube, hq[:, i], solver_iterations=6) for i in range(n)]
+    oo = np.stack([orc[i].env_reset(q0[:, i]) for i in range(n)])
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(og.double().cpu().numpy(), oo, rtol=2e-4, atol=2e-5)
+    worst = 0.0
+    for t in range(3):
+        g = sim.step(torch.as_tensor(acts[t]))[0]
+        torch.cuda.synchronize()
+        qg = sim.get_state()["qpos"].double().cpu().numpy()
+        for i in range(n):
+            orc[i].env_step(acts[t][:, i])
+        qo = np.stack([orc[i].view("qpos").copy() for i in range(n)], 1)
+        rel = np.abs(qg - qo).max(0) / np.maximum(1e-3, np.abs(qo).max(0))
+        worst = max(worst, np.median(rel))
+        assert np.median(rel) < 1e-5, (t, np.median(rel))
+        assert (rel < 1e-4).mean() > 0.9, (t, (rel < 1e-4).mean())
+    print("config2 x128: worst median relative qpos error over 3 env-steps", worst)
+    sim.close()
+
+
+def test_time_limit_done_and_auto_reset():
+    n = 64
+    q0, hq = scenarios.config2_states(n)
+    sim = _sim(n, "CubeS", horizon=3, auto_reset=True)
+    obs0 = sim.reset(torch.as_tensor(q0), torch.as_tensor(hq)).clone()
+    a = torch.zeros(4, n)
+    for t in range(3):
+        obs, rew, done, info = sim.step(a)
+        torch.cuda.synchronize()
+        assert ((done & 2) != 0).all().item() == (t == 2)
+    # after the time limit every env is back at its own initial state and `obs` is the reset observation
+    torch.testing.assert_close(obs, obs0, rtol=0, atol=0)
+    st = sim.get_state()
+    np.testing.assert_allclose(st["qpos"].cpu().numpy(), q0.astype(np.float32), rtol=0, atol=0)
+    assert st["qvel"].abs().max().item() == 0
+    # the terminal observation of the finished episode is kept in final_obs and differs from the reset one
+    assert (sim.final_obs - obs0).abs().max().item() > 1e-4
+    sim.close()
+
+
+def test_full_size_properties():
+    """BASELINE size (4096 envs): size-independent properties instead of a per-env oracle run."""
+    n = 4096
+    q0, hq = scenarios.config2_states(n)
+    acts = torch.as_tensor(scenarios.config_actions(64, 4)).repeat(1, 1, n // 64)
+    outs = []
+    for rep in range(2):
+        sim = _sim(n, "CubeS")
+        sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+        for t in range(4):
+            obs, rew, done, info = sim.step(acts[t])
+        torch.cuda.synchronize()
+        st = sim.get_state()
+        outs.append((obs.clone(), st["qpos"].clone(), st["status"].clone()))
+        sim.close()
+    # determinism: bit-identical across two runs
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    obs, qpos, status = outs[0]
+    assert torch.isfinite(obs).all() and torch.isfinite(qpos).all()
+    assert (status & 2).sum().item() == 0
+    # envs i and i+64k share the action stream but start elsewhere: results must differ (no aliasing)
+    assert (qpos[:, 0] - qpos[:, 64]).abs().max().item() > 1e-6
+    # tendon equality keeps distal ~ proximal/2 (XML:171-188)
+    prox, dist = qpos[3:9:2], qpos[4:9:2]
+    assert (prox - 2 * dist).abs().max().item() < 0.05
+    # object quaternion stays normalised
+    assert (qpos[12:16].norm(dim=0) - 1).abs().max().item() < 1e-5

@@ -1,0 +1,105 @@
+"""CPU checks of the kernel SOURCE (ks_core.h / ks_obs.h / ks_env.h compiled for the host, one lane)
+against the fp64 oracle.  This is the no-GPU coverage of the HIP path's logic; the real parity tests
+(tests/test_gpu_parity.py, -m gpu) run the compiled gfx950 kernels through the C ABI."""
+import numpy as np
+import pytest
+
+from oracle import ko_py as ko
+from kinovagrasping_amd import scenarios
+from tests.native_build import Lane
+
+
+@pytest.fixture(scope="module")
+def blob(assets_dir):
+    return (assets_dir / "CubeS.ksm").read_bytes()
+
+
+def grasp_states(blob, n_sub=330, iters=6):
+    m = ko.OracleModel(blob)
+    hq = scenarios.hand_quat_for("normal")
+    s = ko.OracleSim(m, hq, solver_iterations=iters)
+    q0 = np.zeros(16); q0[9:12] = [0, 0, 0.0654]; q0[12] = 1
+    s.env_reset(q0)
+    ctrl = np.zeros(9); ctrl[5] = 0.2932; ctrl[6:9] = 0.5
+    for i in range(n_sub):
+        if i == 250:
+            ctrl[4] = 0.5
+        before = (s.view("qpos").copy(), s.view("qvel").copy(), s.view("qacc_warmstart").copy())
+        s.step(ctrl)
+        yield before, ctrl.copy(), (s.view("qpos").copy(), s.view("qvel").copy(), s.view("qacc_warmstart").copy()), s.s.ncon, hq
+
+
+def test_fp64_lane_reproduces_oracle_substeps(blob):
+    """two independent formulations (dense generic oracle vs specialised analytic kernel) agree to round-off"""
+    lane = Lane(blob, 64)
+    worst = 0
+    for before, ctrl, after, ncon, hq in grasp_states(blob):
+        qp, qv, qw, nc, con, st = lane.substep(*before, ctrl, hq)
+        assert nc == ncon and st == 0
+        worst = max(worst, np.abs(qp - after[0]).max())
+        assert np.abs(qp - after[0]).max() < 1e-9
+        assert np.abs(qv - after[1]).max() < 1e-7
+        assert np.abs(qw - after[2]).max() < 1e-5
+    print("fp64 lane vs oracle, worst one-step qpos error", worst)
+
+
+def test_fp32_lane_one_step_error_distribution(blob):
+    lane = Lane(blob, 32)
+    errs, mism = [], 0
+    for before, ctrl, after, ncon, hq in grasp_states(blob):
+        qp, qv, qw, nc, con, st = lane.substep(*before, ctrl, hq)
+        errs.append(np.abs(qp - after[0]).max())
+        mism += nc != ncon
+    errs = np.array(errs)
+    print(f"fp32 lane one-step |dqpos|: median {np.median(errs):.2e} p95 {np.percentile(errs, 95):.2e} max {errs.max():.2e}; ncon mismatches {mism}")
+    assert np.median(errs) <= 2e-7
+    assert np.percentile(errs, 95) <= 2e-6
+    assert errs.max() <= 5e-3          # single-point contact position on parallel features
+    assert mism <= 0.02 * len(errs)
+
+
+@pytest.mark.parametrize("prec,tol", [(64, 1e-9), (32, 2e-4)])
+def test_env_step_and_observation(blob, prec, tol):
+    """full env.step (ctrl mapping, 15 substeps, lagged snapshot, rays, 82-d obs, reward) for 8 steps"""
+    m = ko.OracleModel(blob)
+    q0, hq = scenarios.config1_state("CubeS")
+    acts = scenarios.config_actions(1, 8, base_seed=0)[:, :, 0]
+    o = ko.OracleSim(m, hq, solver_iterations=6)
+    lane = Lane(blob, prec)
+    obs_o = o.env_reset(q0)
+    obs_l, rays = lane.reset_obs(q0, hq)
+    np.testing.assert_allclose(obs_l, obs_o, rtol=tol, atol=tol)
+    np.testing.assert_allclose(rays, o.view("sensordata")[9:], rtol=tol, atol=tol)
+    qp, qv, qw = q0.copy(), np.zeros(15), np.zeros(15)
+    for t in range(8):
+        ob, r, d, info = o.env_step(acts[t])
+        qp, qv, qw, obs_l, rew, done, rays, st = lane.env_step(qp, qv, qw, hq, acts[t])
+        assert st == 0
+        scale = 1 if prec == 64 else 20          # fp32 free-running drift over up to 120 substeps
+        np.testing.assert_allclose(qp, o.view("qpos"), rtol=tol * scale, atol=tol * scale)
+        # per-slot tolerances: 48-49 are arccos of a ratio near 1, 75-81 are 20th powers
+        t_obs = np.full(82, tol * scale)
+        t_obs[48:50] *= 50
+        t_obs[73:82] *= 50
+        assert (np.abs(obs_l - ob) <= t_obs + t_obs * np.abs(ob)).all(), np.abs(obs_l - ob).argmax()
+        assert rew == r and done == d
+
+
+def test_shapes_load_and_rest(assets_dir):
+    """every README shape: kernel-source lane and oracle agree on a drop-and-rest run (fp64)"""
+    for shape in ("CylinderB", "Cone1S", "Vase2B", "Cube45S"):
+        blob = (assets_dir / f"{shape}.ksm").read_bytes()
+        m = ko.OracleModel(blob)
+        hq = scenarios.hand_quat_for("normal")
+        o = ko.OracleSim(m, hq, solver_iterations=6)
+        q0 = np.zeros(16); q0[9:12] = [0.03, 0.01, 0.08]; q0[12] = 1
+        o.env_reset(q0)
+        lane = Lane(blob, 64)
+        ctrl = np.zeros(9); ctrl[5] = 0.2932
+        for i in range(60):
+            before = (o.view("qpos").copy(), o.view("qvel").copy(), o.view("qacc_warmstart").copy())
+            o.step(ctrl)
+            qp, qv, qw, nc, con, st = lane.substep(*before, ctrl, hq)
+            assert nc == o.s.ncon
+            assert np.abs(qp - o.view("qpos")).max() < 1e-9, (shape, i)
+        assert o.s.ncon >= 3 and abs(o.view("qvel")[11]) < 0.05, shape   # resting on the ground

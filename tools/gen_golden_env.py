@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Dev-only: generate tests/golden/env_layer.npz by running the REFERENCE's own Python env layer
+(kinova_gripper_env.py: _get_obs / _get_reward / step / _get_trans_mat_wrist_pose) on a fake
+`_sim`, and expert_data.check_grasp.
+
+The reference cannot travel to the GPU box, so only these input/output vectors are committed.
+Reads /root/reference by absolute path; needs no MuJoCo (mujoco_py, gym, glfw ... are stubbed,
+the object is built with __new__ to skip __init__, which needs MuJoCo + the missing gc_model.pkl).
+
+Fake-sim inputs are realistic: they are kinematics snapshots of the repo's own fp64 oracle at
+random states (any consistent numbers would do - the env layer is a pure function of them).
+
+numpy >= 1.25 caveat: `if xs ==[]:` at kinova_gripper_env.py:328 raises when a palm
+ray is < 0.06 because xs is an ndarray by then; legacy numpy evaluated it False -> average
+branch.  Cases with palm hits are run with np.append patched to return a list subclass whose
+`== []` is False when non-empty, i.e. the legacy semantics; flagged in `palm_hit`.
+"""
+import os
+import sys
+import types
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parents[1]
+REF = Path("/root/reference/gym-kinova-gripper")
+sys.path.insert(0, str(REPO))
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+    class Env:  # noqa
+        pass
+    class Box:  # noqa
+        def __init__(self, low=None, high=None, dtype=None, shape=None):
+            self.low, self.high = low, high
+    gym = mod("gym", Env=Env)
+    gym.spaces = mod("gym.spaces", Box=Box)
+    gym.utils = mod("gym.utils")
+    gym.utils.seeding = mod("gym.utils.seeding", np_random=lambda seed=None: (np.random.RandomState(seed), seed))
+    gym.wrappers = mod("gym.wrappers")
+    gym.make = lambda *a, **k: None
+    mod("glfw")
+    mod("mujoco_py", MjViewer=object, load_model_from_path=lambda p: None, MjSim=object)
+    mod("classifier_network", LinearNetwork=object, ReducedLinearNetwork=object)
+    mod("tensorboardX", SummaryWriter=object)
+    try:
+        import PIL  # noqa
+    except Exception:
+        pil = mod("PIL")
+        for n in ("Image", "ImageFont", "ImageDraw"):
+            setattr(pil, n, mod("PIL." + n))
+
+
+class FakeData:
+    def __init__(self, snap):
+        self.s = snap
+        self.sensordata = np.array(snap["sensordata"], dtype=np.float64)
+        self.ctrl = np.zeros(9)
+        self.qpos = np.zeros(16)
+        self.ncon = 0
+    def get_geom_xpos(self, name):
+        return np.array(self.s["geom_xpos"][name])
+    def get_geom_xmat(self, name):
+        return np.array(self.s["geom_xmat"][name]).reshape(3, 3)
+    def get_site_xpos(self, name):
+        return np.array(self.s["site_xpos"][name])
+    def get_body_xpos(self, name):
+        return np.array(self.s["body_xpos"][name])
+
+
+GEOM_NAMES = ["ground", "palm", "f1_prox", "f1_dist", "f2_prox", "f2_dist", "f3_prox", "f3_dist", "object"]
+SITE_NAMES = ["palm", "palm_1", "palm_2", "palm_3", "palm_4", "f1_prox", "f1_prox_1", "f1_dist", "f1_dist_1",
+              "f2_prox", "f2_prox_1", "f2_dist", "f2_dist_1", "f3_prox", "f3_prox_1", "f3_dist", "f3_dist_1"]
+
+
+def snapshot(sim, geom_size):
+    gx = sim.view("geom_xpos").reshape(9, 3).copy()
+    gm = sim.view("geom_xmat").reshape(9, 9).copy()
+    sx = sim.view("site_xpos").reshape(17, 3).copy()
+    return {
+        "geom_xpos": {n: gx[i] for i, n in enumerate(GEOM_NAMES)},
+        "geom_xmat": {n: gm[i] for i, n in enumerate(GEOM_NAMES)},
+        "site_xpos": {n: sx[i] for i, n in enumerate(SITE_NAMES)},
+        "body_xpos": {"j2s7s300_link_7": sim.view("xpos").reshape(10, 3)[2].copy()},
+        "sensordata": sim.view("sensordata").copy(),
+        "geom_size": geom_size,
+    }
+
+
+def main():
+    install_stubs()
+    os.chdir(REF)
+    sys.path.insert(0, str(REF))
+    sys.path.insert(0, str(REF / "gym_kinova_gripper" / "envs"))
+    import kinova_gripper_env as kge
+    import expert_data
+
+    from oracle import ko_py as ko
+    from kinovagrasping_amd import model_compiler as mc
+
+    rng = np.random.Generator(np.random.PCG64(20260930))
+    cases = []
+    orient = {"normal": [-1.57, 0, -1.57], "rotated": [-1.2, 0, 0], "top": [0, 0, 0]}
+    shapes = ["CubeS", "CylinderB", "Cone1S", "Vase2B"]
+    for shape in shapes:
+        blob = (REPO / "kinovagrasping_amd" / "assets" / f"{shape}.ksm").read_bytes()
+        M = mc.read_blob(blob)
+        om = ko.OracleModel(blob)
+        for oname, eul in orient.items():
+            sim = ko.OracleSim(om, mc.euler_to_quat(eul))
+            for k in range(6):
+                q = np.zeros(16)
+                q[0:3] = rng.uniform(-0.05, 0.05, 3)
+                q[3:9:2] = rng.uniform(0, 1.2, 3)
+                q[4:9:2] = q[3:9:2] / 2 + rng.uniform(-0.02, 0.02, 3)
+                q[9:12] = rng.uniform([-0.07, -0.02, 0.04], [0.07, 0.06, 0.22])
+                if k == 5:
+                    q[11] = rng.uniform(0.194, 0.206)      # straddle the lift threshold
+                quat = rng.normal(size=4) * (0.15 if k % 2 else 0.0) + np.array([1, 0, 0, 0])
+                q[12:16] = quat / np.linalg.norm(quat)
+                sim.env_reset(q)
+                snap = snapshot(sim, M["geom_size"].copy())
+                if k in (2, 3):                                 # force palm-ray hits (< 0.06) on some rays
+                    nh = 1 + (k == 3) * 2
+                    snap["sensordata"][9:9 + nh] = rng.uniform(0.01, 0.055, nh)
+                if k == 4:                                      # "no hit" marker -1 -> 6 mapping on all rays
+                    snap["sensordata"][9:] = -1
+                cases.append((shape, oname, snap, rng.uniform(-0.8, 0.8, 4)))
+
+    out = {k: [] for k in ("palm_xpos", "palm_xmat", "finger_xpos", "obj_xpos", "link7_xpos", "site_xpos", "sensordata",
+                           "obj_size", "obs_local", "obs_global", "reward", "done", "info", "action", "ctrl", "Tfw",
+                           "wrist", "palm_hit", "shape_idx")}
+    for shape, oname, snap, action in cases:
+        env = kge.KinovaGripper_Env.__new__(kge.KinovaGripper_Env)
+        data = FakeData(snap)
+        nsteps = [0]
+        def fake_step():
+            nsteps[0] += 1
+        env._sim = SimpleNamespace(data=data, model=SimpleNamespace(geom_size=np.array(snap["geom_size"])), step=fake_step)
+        env.filename = f"/kinova_description/j2s7s300_end_effector_v1_{shape}.xml"
+        env.obj_size = "b" if shape.endswith("B") else "s"
+        env.state_rep = "local"
+        env.pid = False
+        env.arm_or_hand = "hand"
+        env.step_coords = "global"
+        env.orientation = oname
+        env.frame_skip = 15
+        env.with_grasp_reward = False
+        env.Grasp_Reward = False
+        env.Tfw = np.zeros((4, 4))
+        env.wrist_pose = np.zeros(3)
+        palm_hit = bool((np.array([6 if v == -1 else v for v in snap["sensordata"][9:14]]) < 0.06).any())
+        orig_append = np.append
+        if palm_hit:
+            class LegacyList(list):
+                def __eq__(self, other):
+                    return False if len(self) else list.__eq__(self, other)
+            def patched(arr, values, axis=None):
+                r = orig_append(arr, values, axis)
+                return LegacyList(r.tolist()) if np.ndim(values) == 0 else r
+            kge.np.append = patched
+        try:
+            obs_l = env._get_obs()
+            obs_g = env._get_obs("global")
+            reward, info, done = env._get_reward(False)
+            obs_s, reward_s, done_s, info_s = env.step(list(action))
+        finally:
+            kge.np.append = orig_append
+        assert nsteps[0] == 15
+        assert np.allclose(obs_s, obs_l) and reward_s == reward and done_s == done
+        out["palm_xpos"].append(snap["geom_xpos"]["palm"])
+        out["palm_xmat"].append(snap["geom_xmat"]["palm"])
+        out["finger_xpos"].append([snap["geom_xpos"][n] for n in ("f1_prox", "f2_prox", "f3_prox", "f1_dist", "f2_dist", "f3_dist")])
+        out["obj_xpos"].append(snap["geom_xpos"]["object"])
+        out["link7_xpos"].append(snap["body_xpos"]["j2s7s300_link_7"])
+        out["site_xpos"].append([snap["site_xpos"][n] for n in SITE_NAMES])
+        out["sensordata"].append(snap["sensordata"])
+        out["obj_size"].append(env._get_obj_size())
+        out["obs_local"].append(obs_l)
+        out["obs_global"].append(obs_g)
+        out["reward"].append(reward)
+        out["done"].append(done)
+        out["info"].append([info["finger_reward"], info["grasp_reward"], info["lift_reward"]])
+        out["action"].append(action)
+        out["ctrl"].append(np.array(data.ctrl))
+        out["Tfw"].append(env.Tfw)
+        out["wrist"].append(env.wrist_pose)
+        out["palm_hit"].append(palm_hit)
+        out["shape_idx"].append(shapes.index(shape))
+    # check_grasp known answers (expert_data.py:559-593)
+    cg_old = rng.uniform(-0.1, 0.1, (40, 8))
+    cg_new = cg_old + rng.uniform(-1, 1, (40, 8)) * rng.choice([1e-4, 1e-3, 1e-2], (40, 1))
+    cg = np.array([expert_data.check_grasp(list(o), list(n))[0] for o, n in zip(cg_old, cg_new)])
+    arrays = {k: np.array(v, dtype=np.float64) for k, v in out.items()}
+    arrays["cg_old"], arrays["cg_new"], arrays["cg_out"] = cg_old, cg_new, cg.astype(np.float64)
+    arrays["shapes"] = np.array(shapes)
+    dst = REPO / "tests" / "golden" / "env_layer.npz"
+    np.savez_compressed(dst, **arrays)
+    print("wrote", dst, {k: v.shape for k, v in arrays.items()})
+    print("palm_hit cases:", int(arrays["palm_hit"].sum()), "done cases:", int(arrays["done"].sum()), "of", len(cases))
+
+
+if __name__ == "__main__":
+    main()
