@@ -111,7 +111,7 @@ template <typename T, typename S> KS_HD void geom_pose(const Model<T>& m, S scr,
 // ---------------------------------------------------------------- S2+S3 smooth dynamics
 // Mh: hand 9x9 (row-major full, symmetric), Mo: object 6x6.  qfrc = passive - bias + actuator.
 template <typename T>
-KS_HD void smooth_dynamics(const Model<T>& m, const Kin<T>& k, const T* qvel, const T* ctrl, T* Mh, T* Mo, T* qfrc) {
+KS_FN void smooth_dynamics(const Model<T>& m, const Kin<T>& k, const T* qvel, const T* ctrl, T* Mh, T* Mo, T* qfrc) {
     KS_UNROLL
     for (int i = 0; i < 81; i++) Mh[i] = 0;
     KS_UNROLL
@@ -639,7 +639,7 @@ KS_HD void add_contact(S scr, int& ncon, int& status, int b1, int b2, T mu, T di
 }
 
 // all contact pairs of the model (explicit pairs first, then the dynamic candidates), S4
-template <typename T, typename S> KS_HD void collision(const Model<T>& m, S scr, int& ncon, int& status) {
+template <typename T, typename S> KS_FN void collision(const Model<T>& m, S scr, int& ncon, int& status) {
     ncon = 0;
     const T PLANE_MESH_TOL = T(0.3);
     for (int pi = 0; pi < m.npair; pi++) {
@@ -802,7 +802,7 @@ template <typename T> struct ScalarRows {
 };
 
 template <typename T, typename S>
-KS_HD void make_constraints(const Model<T>& m, const Kin<T>& k, const T* qpos, const T* qvel, S scr, int ncon, ScalarRows<T>& r) {
+KS_FN void make_constraints(const Model<T>& m, const Kin<T>& k, const T* qpos, const T* qvel, S scr, int ncon, ScalarRows<T>& r) {
     KS_UNROLL
     for (int t = 0; t < 3; t++) {
         const T c0 = m.tendon_coef[t][0], c1 = m.tendon_coef[t][1];
@@ -904,7 +904,7 @@ KS_HD T primal_cost(const Model<T>& m, const Kin<T>& k, const T* Mh, const T* Mo
 
 // Solve for qacc.  Outputs a (qacc) and qfrc_c (J^T f).
 template <typename T, typename S>
-KS_HD void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T* Mo, const T* qfrc_smooth, const T* qacc_smooth,
+KS_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T* Mo, const T* qfrc_smooth, const T* qacc_smooth,
                         const T* warm, const ScalarRows<T>& r, S scr, int ncon, int iterations, T* a, T* qfrc_c) {
     {
         T cw = primal_cost(m, k, Mh, Mo, qacc_smooth, r, scr, ncon, warm);
@@ -1048,7 +1048,7 @@ KS_HD void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T
             if (d2 < T(1e-15)) break;
             if (d1 < 0) lo = alpha; else hi = alpha;
             T next = alpha - d1 / d2;
-            if (hi >= 0 && (next <= lo || next >= hi)) next = T(0.5) * (lo + hi);
+            if (hi >= 0 && (next < lo || next > hi)) next = T(0.5) * (lo + hi);
             if (next < lo) next = lo;
             const bool stop = kabs(next - alpha) <= T(1e-14) * (1 + kabs(alpha)) || kabs(next - alpha) <= T(4) * T(sizeof(T) == 4 ? 6e-8 : 1.2e-16) * kabs(alpha);
             alpha = next;

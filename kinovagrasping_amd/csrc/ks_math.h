@@ -8,9 +8,11 @@
 #include <hip/hip_runtime.h>
 #define KS_HD __host__ __device__ __forceinline__
 #define KS_UNROLL _Pragma("unroll")
+#define KS_FN __host__ __device__ __attribute__((noinline))
 #else
 #define KS_HD inline
 #define KS_UNROLL
+#define KS_FN inline
 #endif
 
 #include <math.h>
@@ -31,6 +33,8 @@ KS_HD float kcos(float x) { return cosf(x); }
 KS_HD double kcos(double x) { return cos(x); }
 KS_HD float kacos(float x) { return acosf(x); }
 KS_HD double kacos(double x) { return acos(x); }
+KS_HD float katan2(float y, float x) { return atan2f(y, x); }
+KS_HD double katan2(double y, double x) { return atan2(y, x); }
 KS_HD float kpow(float x, float y) { return powf(x, y); }
 KS_HD double kpow(double x, double y) { return pow(x, y); }
 

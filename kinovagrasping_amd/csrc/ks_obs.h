@@ -192,9 +192,10 @@ KS_HD void build_obs(const Model<T>& m, C snap, const T* rays, Put put, T& rewar
     }
     // x / z angles (ENV:563-582)
     {
-        T n = norm3(ol), w0 = ol[0] / n, w1 = ol[1] / n, w2 = ol[2] / n;
-        T za = kacos(clampT(w1 / ksqrt(w0 * w0 + w1 * w1), T(-1), T(1)));
-        T xa = kacos(clampT(w1 / ksqrt(w1 * w1 + w2 * w2), T(-1), T(1)));
+        // arccos(y / sqrt(y^2 + s^2)) == atan2(|s|, y): identical value, but well conditioned in
+        // fp32 when the object sits on the palm centre line (ratio -> 1, SURVEY O2 caution)
+        T za = katan2(kabs(ol[0]), ol[1]);
+        T xa = katan2(kabs(ol[2]), ol[1]);
         put(48, xa); put(49, za);
     }
     T rng[NRAY];

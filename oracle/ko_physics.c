@@ -969,7 +969,7 @@ static void solve_newton(ko_sim *s) {
             if (d2 < MINVAL) break;
             if (d1 < 0) lo = alpha; else hi = alpha;
             double next = alpha - d1 / d2;
-            if (hi >= 0 && (next <= lo || next >= hi)) next = 0.5 * (lo + hi); /* safeguard: bisect */
+            if (hi >= 0 && (next < lo || next > hi)) next = 0.5 * (lo + hi); /* safeguard: bisect */
             if (next < lo) next = lo;
             if (fabs(next - alpha) <= 1e-14 * (1 + fabs(alpha))) { alpha = next; break; }
             alpha = next;

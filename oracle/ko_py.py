@@ -102,9 +102,12 @@ class OracleModel:
             raise ValueError("ko_model_load failed")
 
     def __del__(self):
-        if getattr(self, "ptr", None):
-            lib().ko_model_free(self.ptr)
-            self.ptr = None
+        try:
+            if getattr(self, "ptr", None) and _lib is not None:
+                _lib.ko_model_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
 
 
 class OracleSim:
@@ -119,9 +122,12 @@ class OracleSim:
         self.s.solver = solver
 
     def __del__(self):
-        if getattr(self, "p", None):
-            lib().ko_sim_free(self.p)
-            self.p = None
+        try:
+            if getattr(self, "p", None) and _lib is not None:
+                _lib.ko_sim_free(self.p)
+                self.p = None
+        except Exception:
+            pass
 
     def view(self, name):
         return _np(getattr(self.s, name))
