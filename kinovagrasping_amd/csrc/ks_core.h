@@ -249,16 +249,37 @@ template <typename T> struct PairGeo {
     T half_margin;
 };
 
+// Hull vertex tables are stored padded: stride 4 reals (x, y, z, 0) and the count rounded up to a
+// multiple of HULL_CHUNK with copies of vertex 0 (a copy never wins the strict `>` arg-max, so the
+// selected vertex is the same as for the unpadded table).
+constexpr int HULL_CHUNK = 8;
+
 template <typename T> KS_HD void hull_support(const T* R, const T* p, const T* V, int n, const T* dir, T hm, T* out) {
     T ld[3];
     mulRtv(ld, R, dir);
     T best = -Lim<T>::big;
     int bi = 0;
+    // The table index is wave-uniform -> scalar loads; HULL_CHUNK vertices are requested per
+    // iteration so the loads overlap instead of paying one round trip per vertex.
+    const T* Vl = V;
+#ifdef KS_OLD_SUPPORT
     for (int i = 0; i < n; i++) {
-        T d = V[3 * i] * ld[0] + V[3 * i + 1] * ld[1] + V[3 * i + 2] * ld[2];
+        T d = V[4 * i] * ld[0] + V[4 * i + 1] * ld[1] + V[4 * i + 2] * ld[2];
         if (d > best) { best = d; bi = i; }
     }
-    T v[3] = {V[3 * bi], V[3 * bi + 1], V[3 * bi + 2]};
+#else
+    for (int i = 0; i < n; i += HULL_CHUNK) {
+        T vx[HULL_CHUNK], vy[HULL_CHUNK], vz[HULL_CHUNK];
+        KS_UNROLL
+        for (int j = 0; j < HULL_CHUNK; j++) { vx[j] = Vl[4 * (i + j)]; vy[j] = Vl[4 * (i + j) + 1]; vz[j] = Vl[4 * (i + j) + 2]; }
+        KS_UNROLL
+        for (int j = 0; j < HULL_CHUNK; j++) {
+            T d = vx[j] * ld[0] + vy[j] * ld[1] + vz[j] * ld[2];
+            if (d > best) { best = d; bi = i + j; }
+        }
+    }
+#endif
+    T v[3] = {V[4 * bi], V[4 * bi + 1], V[4 * bi + 2]};
     mulRv(out, R, v);
     add3(out, out, p);
     addscl3(out, dir, hm);
@@ -369,7 +390,7 @@ KS_HD void find_pos(const Supp<T>& v0, const Supp<T>& v1, const Supp<T>& v2, con
 // Minkowski Portal Refinement penetration query (same decision structure as the oracle's
 // mpr_penetration / libccd's ccdMPRPenetration).  Returns true on overlap.
 template <typename T>
-KS_HD bool mpr_penetration(const PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir, T* pos) {
+KS_FN bool mpr_penetration(const PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir, T* pos) {
     Supp<T> v0, v1, v2, v3, v4;
     T d[3], va[3], vb[3];
     copy3(v0.v1, g.p1);
@@ -558,7 +579,7 @@ template <typename T> KS_HD bool gjk_closest(Simplex<T>& S, T* lam, T* v) {
 }
 
 // 0: separated by >= margin, 1: contact in the margin zone, 2: overlap (fall back to MPR)
-template <typename T> KS_HD int gjk_distance(const PairGeo<T>& g, T margin, T* dist, T* normal, T* pos) {
+template <typename T> KS_FN int gjk_distance(const PairGeo<T>& g, T margin, T* dist, T* normal, T* pos) {
     Simplex<T> S;
     T lam[4] = {1, 0, 0, 0}, v[3], d[3];
     const T tol = T(1e-6);
@@ -615,6 +636,44 @@ template <typename T> KS_HD int gjk_distance(const PairGeo<T>& g, T margin, T* d
     return 1;
 }
 
+
+// Exact-result cull for hull pairs: separating-axis test of the two geoms' bounding boxes (half
+// extents about the geom origin, in the geom frame).  A gap >= margin along any of the 15 axes
+// means the hulls (inside the boxes) are >= margin apart, which is exactly when GJK reports
+// "no contact", so skipping the pair never changes the contact set.
+template <typename T>
+KS_HD bool obb_separated(const T* R1, const T* p1, const T* e1, const T* R2, const T* p2, const T* e2, T margin) {
+    T R[3][3], A[3][3], tw[3], t[3];
+    sub3(tw, p2, p1);
+    mulRtv(t, R1, tw);
+    KS_UNROLL
+    for (int i = 0; i < 3; i++) {
+        KS_UNROLL
+        for (int j = 0; j < 3; j++) {
+            R[i][j] = R1[i] * R2[j] + R1[3 + i] * R2[3 + j] + R1[6 + i] * R2[6 + j];   // (R1^T R2)[i][j]
+            A[i][j] = kabs(R[i][j]) + T(1e-6);
+        }
+    }
+    bool sep = false;
+    KS_UNROLL
+    for (int i = 0; i < 3; i++) sep = sep || (kabs(t[i]) > e1[i] + e2[0] * A[i][0] + e2[1] * A[i][1] + e2[2] * A[i][2] + margin);
+    KS_UNROLL
+    for (int j = 0; j < 3; j++)
+        sep = sep || (kabs(t[0] * R[0][j] + t[1] * R[1][j] + t[2] * R[2][j]) > e1[0] * A[0][j] + e1[1] * A[1][j] + e1[2] * A[2][j] + e2[j] + margin);
+    KS_UNROLL
+    for (int i = 0; i < 3; i++) {
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+        KS_UNROLL
+        for (int j = 0; j < 3; j++) {
+            const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            T ra = e1[i1] * A[i2][j] + e1[i2] * A[i1][j];
+            T rb = e2[j1] * A[i][j2] + e2[j2] * A[i][j1];
+            sep = sep || (kabs(t[i2] * R[i1][j] - t[i1] * R[i2][j]) > ra + rb + margin);
+        }
+    }
+    return sep;
+}
+
 template <typename T> KS_HD void make_frame(const T* n, T* t1, T* t2) {
     t1[0] = 0; t1[1] = 0; t1[2] = 0;
     if (n[1] < T(0.5) && n[1] > T(-0.5)) t1[1] = 1; else t1[2] = 1;
@@ -655,35 +714,51 @@ template <typename T, typename S> KS_FN void collision(const Model<T>& m, S scr,
             const T cdist = p2[2];
             if (cdist > m.geom_rbound[g2] + margin) continue;
             T ln[3] = {R2[6], R2[7], R2[8]};          // R2^T e_z
+            // exact cull: lowest point of the geom's bounding box (half extents geom_size about the
+            // geom origin) is above the margin -> every hull vertex is too
+            if (cdist - (kabs(ln[0]) * m.geom_size[g2][0] + kabs(ln[1]) * m.geom_size[g2][1] + kabs(ln[2]) * m.geom_size[g2][2]) > margin) continue;
+            const T* Vl = V2;
+            const int nv2p = m.mesh_nvert_pad[mesh2];  // padding rows repeat vertex 0: never a new minimum
             int best = 0;
             T bd = Lim<T>::big;
-            for (int i = 0; i < nv2; i++) {
-                T d = cdist + V2[3 * i] * ln[0] + V2[3 * i + 1] * ln[1] + V2[3 * i + 2] * ln[2];
-                if (d < bd) { bd = d; best = i; }
+            for (int i = 0; i < nv2p; i += HULL_CHUNK) {
+                T dd[HULL_CHUNK];
+                KS_UNROLL
+                for (int j = 0; j < HULL_CHUNK; j++) dd[j] = cdist + Vl[4 * (i + j)] * ln[0] + Vl[4 * (i + j) + 1] * ln[1] + Vl[4 * (i + j) + 2] * ln[2];
+                KS_UNROLL
+                for (int j = 0; j < HULL_CHUNK; j++)
+                    if (dd[j] < bd) { bd = dd[j]; best = i + j; }
             }
             if (bd > margin) continue;
             T cv[4][3];
             int nc = 1;
-            cv[0][0] = V2[3 * best]; cv[0][1] = V2[3 * best + 1]; cv[0][2] = V2[3 * best + 2];
+            cv[0][0] = V2[4 * best]; cv[0][1] = V2[4 * best + 1]; cv[0][2] = V2[4 * best + 2];
             T thr2 = PLANE_MESH_TOL * m.geom_rbound[g2];
             thr2 *= thr2;
-            for (int i = 0; i < nv2; i++) {
-                T v[3] = {V2[3 * i], V2[3 * i + 1], V2[3 * i + 2]};
-                T d = cdist + dot3(v, ln);
-                bool ok = (d <= margin) && (nc < 4);
+            for (int i0 = 0; i0 < nv2p; i0 += HULL_CHUNK) {
+                T vx[HULL_CHUNK], vy[HULL_CHUNK], vz[HULL_CHUNK];
                 KS_UNROLL
-                for (int k = 0; k < 4; k++) {
-                    if (k < nc) {
-                        T dv[3];
-                        sub3(dv, v, cv[k]);
-                        if (dot3(dv, dv) <= thr2) ok = false;
-                    }
-                }
-                if (ok) {
+                for (int j = 0; j < HULL_CHUNK; j++) { vx[j] = Vl[4 * (i0 + j)]; vy[j] = Vl[4 * (i0 + j) + 1]; vz[j] = Vl[4 * (i0 + j) + 2]; }
+                KS_UNROLL
+                for (int j = 0; j < HULL_CHUNK; j++) {
+                    T v[3] = {vx[j], vy[j], vz[j]};
+                    T d = cdist + dot3(v, ln);
+                    // padding rows duplicate vertex 0, which is either chosen already or rejected again
+                    bool ok = (d <= margin) && (nc < 4);
                     KS_UNROLL
-                    for (int k = 0; k < 4; k++)
-                        if (k == nc) { cv[k][0] = v[0]; cv[k][1] = v[1]; cv[k][2] = v[2]; }
-                    nc++;
+                    for (int k = 0; k < 4; k++) {
+                        if (k < nc) {
+                            T dv[3];
+                            sub3(dv, v, cv[k]);
+                            if (dot3(dv, dv) <= thr2) ok = false;
+                        }
+                    }
+                    if (ok) {
+                        KS_UNROLL
+                        for (int k = 0; k < 4; k++)
+                            if (k == nc) { cv[k][0] = v[0]; cv[k][1] = v[1]; cv[k][2] = v[2]; }
+                        nc++;
+                    }
                 }
             }
             const T normal[3] = {0, 0, 1};
@@ -704,12 +779,15 @@ template <typename T, typename S> KS_FN void collision(const Model<T>& m, S scr,
             sub3(t, pg.p1, p2);
             T bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin;
             if (dot3(t, t) > bound * bound) continue;
+#ifndef KS_NO_OBB
+            if (obb_separated(pg.R1, pg.p1, m.geom_size[g1], R2, p2, m.geom_size[g2], margin)) continue;
+#endif
             KS_UNROLL
             for (int j = 0; j < 9; j++) pg.R2[j] = R2[j];
             copy3(pg.p2, p2);
             const int mesh1 = m.geom_mesh[g1];
-            pg.V1 = m.mesh_vert[mesh1]; pg.n1 = m.mesh_nvert[mesh1];
-            pg.V2 = V2; pg.n2 = nv2;
+            pg.V1 = m.mesh_vert[mesh1]; pg.n1 = m.mesh_nvert_pad[mesh1];
+            pg.V2 = V2; pg.n2 = m.mesh_nvert_pad[mesh2];
             pg.half_margin = T(0);
             T depth, dist, dir[3], pos[3];
             const int r = gjk_distance(pg, margin, &dist, dir, pos);

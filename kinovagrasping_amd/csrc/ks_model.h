@@ -39,8 +39,8 @@ template <typename T> struct Model {
     T act[5];                  // kv_slide, gear_motor, ctrlrange_slide, kv_finger, ctrlrange_finger
     T dof_invw[NV], body_invw[NBODY], tendon_invw[3];
     T obj_size_obs[3];
-    int mesh_nvert[4], mesh_nplane[4];
-    const T* mesh_vert[4];     // [nvert][3] in the geom frame
+    int mesh_nvert[4], mesh_nvert_pad[4], mesh_nplane[4];
+    const T* mesh_vert[4];     // [nvert_pad][4] (x,y,z,0) in the geom frame; rows >= nvert repeat vertex 0
     const T* mesh_plane[4];    // [nplane][4]  n.x <= d
 };
 

@@ -169,9 +169,14 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
         BlobRec r;
         std::snprintf(nm, sizeof nm, "mesh%d_vert", s);
         if (!blob_find(b, n, nm, r) || r.code != 0) { e = std::string("missing ") + nm; return false; }
-        hm.vert[s].resize(r.count);
-        for (uint32_t i = 0; i < r.count; i++) { double v; std::memcpy(&v, r.data + 8 * i, 8); hm.vert[s][i] = (T)v; }
-        m.mesh_nvert[s] = (int)r.shape[0];
+        {
+            const int nv = (int)r.shape[0], npad = (nv + 7) / 8 * 8;   // HULL_CHUNK
+            hm.vert[s].assign((size_t)npad * 4, T(0));
+            for (int i = 0; i < npad; i++)
+                for (int c = 0; c < 3; c++) { double v; std::memcpy(&v, r.data + 8 * (3 * (i < nv ? i : 0) + c), 8); hm.vert[s][4 * i + c] = (T)v; }
+            m.mesh_nvert[s] = nv;
+            m.mesh_nvert_pad[s] = npad;
+        }
         std::snprintf(nm, sizeof nm, "mesh%d_plane", s);
         if (!blob_find(b, n, nm, r) || r.code != 0) { e = std::string("missing ") + nm; return false; }
         hm.plane[s].resize(r.count);

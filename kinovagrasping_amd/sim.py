@@ -31,7 +31,8 @@ def load_library(path: Path | None = None):
     global _lib
     if _lib is not None:
         return _lib
-    path = Path(path) if path else _build.LIB
+    import os
+    path = Path(path) if path else Path(os.environ.get("KS_LIB", _build.LIB))
     if not path.exists():
         raise RuntimeError(f"{path} is missing: build it with kinovagrasping_amd.build.build() (hipcc, gfx950). "
                            "There is no fallback implementation.")
