@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
-"""bench.py -- env-steps/s of the batched Kinova gripper simulator on N MI355X (one process per GPU).
+"""bench.py -- env-steps/s of the batched Kinova gripper simulator + DDPG rollout on N MI355X (one process
+per GPU).
 
 One "step" = one env.step() (15 mj_step substeps + 82-d observation + reward/done) for every env of
-the rank.  Workload: 4096 envs per GPU (BASELINE metric), CubeS, 'normal' hand pose, env i starts at
-row 2 + (i mod 4498) of the no_noise start table and replays the action stream
-Generator(PCG64(1000 + i)).uniform(-0.8, 0.8, (30, 4)) every 30-step episode (auto-reset) -- BASELINE
-config 2 at the metric's env count.  Inputs (actions) are resident in HBM before the timed region.
+the rank.  4096 envs per GPU (BASELINE metric), CubeS, 'normal' hand pose, env i starts at row
+2 + (i mod 4498) of the no_noise start table, 30-step episodes with auto-reset.
+  --mode ddpg (default, BASELINE config 3; config 4 with --gpus 8): actions a = clip(pi(s) + N(0, 0.08), 0, 0.8)
+      from the 256-256 actor, scripted lift after check_grasp, transitions into the device replay, and ONE
+      DDPGfD update per env-step on 64 episodes x 25 five-step windows (1600 rows); with N > 1 GPUs the
+      gradients are averaged by RCCL all-reduce.  Nothing is skipped inside the timed region.
+  --mode sim (BASELINE config 2 at the metric's env count): replays Generator(PCG64(1000 + i)).uniform(-0.8, 0.8)
+      action streams resident in HBM; sim kernels only.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel k_env_step, HIP-event timed on the
 launch stream inside this process) and `cpu_baseline` (the fp64 CPU oracle on the host cores, N=1 only).
@@ -59,7 +64,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--mode", choices=["ddpg", "sim"], default="ddpg")
+    ap.add_argument("--hidden", type=int, nargs=2, default=[256, 256])
+    ap.add_argument("--serial-learner", action="store_true", help="run the learner update after the sim step instead of beside it")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -77,13 +85,12 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n = args.envs_per_gpu
-    # envs shard by global index: rank r owns envs [r*n, (r+1)*n); no data-path collective
+    dev = torch.device("cuda", local_rank)
+    # envs shard by global index: rank r owns envs [r*n, (r+1)*n); no data-path collective in the sim
     q0_all, hq_all = scenarios.config2_states(n * world)
     q0, hq = q0_all[:, rank * n:(rank + 1) * n], hq_all[:, rank * n:(rank + 1) * n]
-    base = scenarios.config_actions(min(n, 256), 30, base_seed=1000 + rank * n)
-    acts = torch.as_tensor(np.tile(base, (1, 1, (n + base.shape[2] - 1) // base.shape[2]))[:, :, :n]).cuda(local_rank)
     sim = KinovaSim(n, "CubeS", device=local_rank, auto_reset=True, horizon=30)
-    sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+    obs0 = sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
 
     def barrier():
         torch.cuda.synchronize()
@@ -91,18 +98,61 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    updates = 0
+    if args.mode == "sim":
+        base = scenarios.config_actions(min(n, 256), 30, base_seed=1000 + rank * n)
+        acts = torch.as_tensor(np.tile(base, (1, 1, (n + base.shape[2] - 1) // base.shape[2]))[:, :, :n]).to(dev)
+        step_fn = lambda t: sim.step(acts[t % 30])
+    else:
+        from kinovagrasping_amd.ddpgfd import DDPGfD
+        from kinovagrasping_amd.replay import DeviceEpisodeReplay
+        from kinovagrasping_amd.rollout import RolloutEngine
+        torch.manual_seed(2)                                   # reference default seed (main_DDPGfD.py:884): identical replicas
+        policy = DDPGfD(82, 4, 0.8, 5, batch_size=64, hidden=tuple(args.hidden), device=dev)
+        gen = torch.Generator(device=dev).manual_seed(2 + rank)
+        replay = DeviceEpisodeReplay(n, capacity=max(4 * n, 1024), horizon=30, device=dev)
+        eng = RolloutEngine(sim, policy, replay, expl_noise=0.1, generator=gen)
+        eng.start(obs0)
+
+        # The sim kernel keeps 64 of the 256 CUs busy (one wave per 64 envs); the learner update runs on a
+        # second HIP stream beside it.  Ordering: the update starts after the actor forward of this step was
+        # enqueued and finishes before the replay is written / the next actor forward reads the weights.
+        main, side = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+        lgen = torch.Generator(device=dev).manual_seed(1002 + rank)
+
+        acted = torch.cuda.Event()
+
+        def learner_update():
+            nonlocal updates
+            if replay.count < 2:
+                return
+            side.wait_event(acted)                 # weights are free once this step's actor forward is done
+            with torch.cuda.stream(side), torch.enable_grad():   # called from inside the no_grad rollout step
+                st, ac, ns, rw, nd, w = replay.sample_batch_nstep(64, generator=lgen)
+                policy.train_on_batch(st, ac, ns, rw, w)
+            updates += 1
+
+        def step_fn(t):
+            if args.serial_learner:
+                eng.step()
+                learner_update()
+                main.wait_stream(side)
+            else:
+                eng.step(after_act=lambda: acted.record(main), after_launch=learner_update, before_store=lambda: main.wait_stream(side))
+
     for t in range(args.warmup):
-        sim.step(acts[t % 30])
+        step_fn(t)
     barrier()
     sim.kernel_time(reset=True)
+    upd0 = updates
     t0 = time.perf_counter()
     for t in range(args.steps):
-        sim.step(acts[(args.warmup + t) % 30])
+        step_fn(args.warmup + t)
     barrier()
     dt = time.perf_counter() - t0
     kern_ms, launches = sim.kernel_time()
     if world > 1:
-        tt = torch.tensor([dt], device=f"cuda:{local_rank}", dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     status = sim.get_state()["status"]
@@ -114,10 +164,14 @@ def main():
             "metric": "env-steps/sec (whole node) at 4096 envs/GPU", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n} envs/GPU CubeS normal-pose grasp sim, random-action rollout (BASELINE config 2 at the metric's "
-                                   "4096 envs/GPU), 15 substeps/env-step, 30-step episodes with auto-reset; sim kernels only "
-                                   "(DDPG learner not in the loop yet)",
-                       "envs_per_gpu": n, "frame_skip": 15, "solver": "newton x6", "parallelism": f"env-shard x{world}"},
+            "config": {"workload": (f"{n} envs/GPU DDPG training, 256-256 actor/critic, CubeS normal pose: actor inference + exploration noise + "
+                                    "scripted lift in the loop, device replay, one DDPGfD update (64 episodes x 25 five-step windows) per "
+                                    "env-step (BASELINE config 3; config 4 when n_gpus=8)") if args.mode == "ddpg" else
+                                   (f"{n} envs/GPU CubeS normal-pose grasp sim, PCG64(1000+i) random-action rollout (BASELINE config 2 at the "
+                                    "metric's env count); sim kernels only"),
+                       "mode": args.mode, "envs_per_gpu": n, "frame_skip": 15, "solver": "newton x6", "hidden": list(args.hidden),
+                       "learner_updates_timed": updates - upd0 if args.mode == "ddpg" else 0,
+                       "parallelism": f"env-shard x{world}" + (" + grad all-reduce" if world > 1 and args.mode == "ddpg" else "")},
             "roofline": {"bound": "hbm", "kernel": "k_env_step", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": None,
                          "avg_launch_ms": round(kern_ms, 4), "launches_timed": launches,

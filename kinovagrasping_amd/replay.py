@@ -1,0 +1,123 @@
+"""Episode replay for n-step DDPGfD (L4): restatement of ReplayBuffer_Queue (gym-kinova-gripper/utils.py:9-343)
+as (a) a host sampler that consumes the same np.random stream as the reference (golden-vector parity)
+and (b) a device-resident, fixed-shape episode ring for the batched rollout.
+
+Reference semantics kept (utils.py:240-306): episodes drawn with np.random.randint(replay_ep_num - 1)
+(the newest episode is never sampled); for an episode of length L, ceiling = L - n windows:
+ceiling - 1 uniform random starts in [0, ceiling) plus the final window starting at `ceiling`.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def sample_windows_host(ep_lens, n_steps: int, batch_size: int, rng=np.random):
+    """Exactly the draws of ReplayBuffer_Queue.sample_batch_nstep: returns [(episode, start), ...]."""
+    out = []
+    if batch_size < 1:
+        return out
+    episode_idx = rng.randint(len(ep_lens) - 1, size=batch_size)
+    for idx in episode_idx:
+        ceiling = int(ep_lens[idx]) - n_steps
+        for _ in range(ceiling - 1):
+            out.append((int(idx), int(rng.randint(ceiling))))
+        out.append((int(idx), ceiling))
+    return out
+
+
+class HostEpisodeReplay:
+    """Flat-array host replay with the reference's sampler; used for expert data and parity tests."""
+
+    def __init__(self, state_dim=82, action_dim=4, n_steps=5):
+        self.n_steps = n_steps
+        self.lens, self.offsets = [], []
+        self.state, self.action, self.next_state, self.reward, self.not_done = [], [], [], [], []
+
+    def add_episode_arrays(self, state, action, next_state, reward, not_done):
+        self.offsets.append(sum(self.lens))
+        self.lens.append(len(reward))
+        for lst, arr in ((self.state, state), (self.action, action), (self.next_state, next_state), (self.reward, reward), (self.not_done, not_done)):
+            lst.append(np.asarray(arr, dtype=np.float32))
+
+    @property
+    def replay_ep_num(self):
+        return len(self.lens)
+
+    def sample_batch_nstep(self, batch_size, num_ts_from_ep=5, rng=np.random):
+        wins = sample_windows_host(self.lens, self.n_steps, batch_size, rng)
+        n = self.n_steps
+        pick = lambda lst: torch.from_numpy(np.stack([lst[e][s:s + n] for e, s in wins])) if wins else torch.zeros(0)
+        return pick(self.state), pick(self.action), pick(self.next_state), pick(self.reward), pick(self.not_done)
+
+
+class DeviceEpisodeReplay:
+    """Fixed-shape episode ring on the GPU: [capacity, horizon, ...] plus per-episode lengths.
+    Envs append to their own open episode; a finished episode is committed to the ring (FIFO)."""
+
+    def __init__(self, n_envs, capacity, horizon=30, state_dim=82, action_dim=4, n_steps=5, device="cuda"):
+        self.n_envs, self.capacity, self.horizon, self.n_steps = n_envs, capacity, horizon, n_steps
+        self.device = torch.device(device)
+        z = lambda *s: torch.zeros(*s, device=self.device)
+        self.ep_state, self.ep_next = z(capacity, horizon, state_dim), z(capacity, horizon, state_dim)
+        self.ep_action, self.ep_reward, self.ep_not_done = z(capacity, horizon, action_dim), z(capacity, horizon), z(capacity, horizon)
+        self.ep_len = torch.zeros(capacity, dtype=torch.long, device=self.device)
+        self.count, self.head = 0, 0                      # committed episodes, next ring slot
+        self.cur_state, self.cur_next = z(n_envs, horizon, state_dim), z(n_envs, horizon, state_dim)
+        self.cur_action, self.cur_reward, self.cur_not_done = z(n_envs, horizon, action_dim), z(n_envs, horizon), z(n_envs, horizon)
+        self.cur_len = torch.zeros(n_envs, dtype=torch.long, device=self.device)
+        self._env_ar = torch.arange(n_envs, device=self.device)
+
+    def add(self, state, action, next_state, reward, done, store_mask=None):
+        """Append one transition per env (where store_mask is True; utils.py:34-64)."""
+        m = torch.ones(self.n_envs, dtype=torch.bool, device=self.device) if store_mask is None else store_mask
+        t = self.cur_len.clamp(max=self.horizon - 1)
+        idx = self._env_ar[m]
+        tt = t[m]
+        self.cur_state[idx, tt] = state[m]
+        self.cur_next[idx, tt] = next_state[m]
+        self.cur_action[idx, tt] = action[m]
+        self.cur_reward[idx, tt] = reward[m]
+        self.cur_not_done[idx, tt] = 1.0 - done[m].float()
+        self.cur_len[idx] = tt + 1
+
+    def replace_last(self, env_mask, reward):
+        """utils.py:309-343: overwrite the last stored transition of the open episode with the lift outcome."""
+        idx = self._env_ar[env_mask & (self.cur_len > 0)]
+        last = self.cur_len[idx] - 1
+        self.cur_reward[idx, last] = reward[idx]
+        self.cur_not_done[idx, last] = 0.0
+
+    def end_episodes(self, env_mask):
+        """Commit the open episodes of `env_mask` envs; episodes with len - n <= 1 are dropped
+        (main_DDPGfD.py:469-471)."""
+        keep = env_mask & (self.cur_len - self.n_steps > 1)
+        idx = self._env_ar[keep]
+        k = int(idx.numel())
+        if k:
+            slots = (self.head + torch.arange(k, device=self.device)) % self.capacity
+            self.ep_state[slots], self.ep_next[slots] = self.cur_state[idx], self.cur_next[idx]
+            self.ep_action[slots], self.ep_reward[slots], self.ep_not_done[slots] = self.cur_action[idx], self.cur_reward[idx], self.cur_not_done[idx]
+            self.ep_len[slots] = self.cur_len[idx]
+            self.head = (self.head + k) % self.capacity
+            self.count = min(self.capacity, self.count + k)
+        self.cur_len[env_mask] = 0
+        return k
+
+    def sample_batch_nstep(self, batch_size, generator=None):
+        """Fixed-shape batch: batch_size episodes x (horizon - n) window rows, padding rows have weight 0.
+        Returns state [R,n,S], action [R,n,A], next_state [R,n,S], reward [R,n], not_done [R,n], weight [R]."""
+        n, W = self.n_steps, self.horizon - self.n_steps
+        hi = max(1, self.count - 1)                        # newest episode excluded (utils.py:259)
+        ep = torch.randint(hi, (batch_size,), device=self.device, generator=generator)
+        ceiling = (self.ep_len[ep] - n).clamp(min=1)       # [B]
+        row = torch.arange(W, device=self.device).unsqueeze(0)              # [1,W]
+        u = torch.rand(batch_size, W, device=self.device, generator=generator)
+        start = (u * ceiling.unsqueeze(1)).long().clamp(max=self.horizon - n)
+        start = torch.where(row == (ceiling.unsqueeze(1) - 1), ceiling.unsqueeze(1).expand(-1, W), start)
+        start = start.clamp(max=self.horizon - n)
+        weight = (row < ceiling.unsqueeze(1)).float().reshape(-1)
+        t = start.unsqueeze(-1) + torch.arange(n, device=self.device)        # [B,W,n]
+        e = ep.view(-1, 1, 1).expand(-1, W, n)
+        g = lambda x: x[e, t].reshape(batch_size * W, n, *x.shape[2:])
+        return g(self.ep_state), g(self.ep_action), g(self.ep_next), g(self.ep_reward), g(self.ep_not_done), weight

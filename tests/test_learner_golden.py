@@ -1,0 +1,124 @@
+"""Learner path (L1-L4) against golden vectors produced by the reference's own DDPGfD.py / utils.py
+(tools/gen_golden_learner.py -> tests/golden/learner.npz).  CPU, fp32, 400-300 widths (reference)."""
+import numpy as np
+import pytest
+import torch
+
+from kinovagrasping_amd.ddpgfd import DDPGfD
+from kinovagrasping_amd.replay import HostEpisodeReplay, DeviceEpisodeReplay, sample_windows_host
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(golden_dir / "learner.npz")
+
+
+def build_buffers(G):
+    lens = G["ep_lens"]
+    bufs = [HostEpisodeReplay(), HostEpisodeReplay()]
+    so = ao = 0
+    for i, L in enumerate(lens):
+        s = G["ep_state"][so:so + L + 1]
+        a = G["ep_action"][ao:ao + L]
+        r = G["ep_reward"][ao:ao + L]
+        nd = np.ones(L, np.float32); nd[-1] = 0
+        bufs[i // (len(lens) // 2)].add_episode_arrays(s[:-1], a, s[1:], r, nd)
+        so += L + 1; ao += L
+    return bufs
+
+
+def load_init(pol, G):
+    for name, net in (("actor", pol.actor), ("critic", pol.critic)):
+        sd = {k: torch.from_numpy(G[f"init_{name}.{k}"]) for k in net.state_dict()}
+        net.load_state_dict(sd)
+    pol.actor_target.load_state_dict(pol.actor.state_dict())
+    pol.critic_target.load_state_dict(pol.critic.state_dict())
+
+
+def test_sampler_consumes_the_same_random_stream(G):
+    agent, _ = build_buffers(G)
+    np.random.seed(11)
+    st, ac, ns, rw, nd = agent.sample_batch_nstep(4)
+    np.testing.assert_array_equal(st.numpy(), G["samp_state"])
+    np.testing.assert_array_equal(ac.numpy(), G["samp_action"])
+    np.testing.assert_array_equal(ns.numpy(), G["samp_next"])
+    np.testing.assert_array_equal(rw.numpy(), G["samp_reward"])
+    np.testing.assert_array_equal(nd.numpy(), G["samp_not_done"])
+
+
+def test_select_action_and_state_dict_compat(G):
+    pol = DDPGfD(82, 4, 0.8, 5, batch_size=6)
+    assert list(pol.actor.state_dict()) == ["l1.weight", "l1.bias", "l2.weight", "l2.bias", "l3.weight", "l3.bias"]
+    load_init(pol, G)
+    # golden select_action was taken after 10 updates; check the initial forward through batch 0 instead
+    s = torch.from_numpy(G["batch0_state"])[:, 0]
+    a = pol.select_action(s)
+    assert a.shape == (s.shape[0], 4) and (a > 0).all() and (a < 0.8).all()
+
+
+def test_train_batch_losses_and_parameters(G):
+    """10 calls of train_batch on the same seeded sample stream: losses to 1e-5 rel, parameters to 1e-6 abs."""
+    torch.manual_seed(0)
+    pol = DDPGfD(82, 4, 0.8, 5, batch_size=6)
+    load_init(pol, G)
+    agent, expert = build_buffers(G)
+    np.random.seed(5)
+    for it in range(10):
+        if it == 0:
+            ag = agent.sample_batch_nstep(int(6 * 0.7))
+            ex = expert.sample_batch_nstep(6 - int(6 * 0.7))
+            batch = [torch.cat((a, e), 0) for a, e in zip(ag, ex)]
+            for j, nm in enumerate(("state", "action", "next", "reward", "not_done")):
+                np.testing.assert_array_equal(batch[j].numpy(), G[f"batch0_{nm}"])
+            losses = [x.item() for x in pol.train_on_batch(*batch[:4])]
+        else:
+            losses = pol.train_batch(30, expert, agent, 5, prob=0.3)
+        np.testing.assert_allclose(losses, G["losses"][it], rtol=1e-5, atol=1e-6, err_msg=f"call {it}")
+        if it in (0, 9):
+            for name, net in (("actor", pol.actor), ("critic", pol.critic), ("actor_target", pol.actor_target), ("critic_target", pol.critic_target)):
+                for k, v in net.state_dict().items():
+                    v = v.numpy()
+                    np.testing.assert_allclose(v.ravel()[::max(1, v.size // 256)][:256], G[f"after{it + 1}_{name}.{k}.sample"], rtol=0, atol=1e-6)
+                    st = G[f"after{it + 1}_{name}.{k}.stats"]
+                    np.testing.assert_allclose([v.astype(np.float64).sum(), np.abs(v.astype(np.float64)).sum()], st, rtol=1e-6, atol=1e-4)
+
+
+def test_masked_fixed_shape_batch_equals_ragged_batch(G):
+    """the device replay pads every episode to horizon - n rows with weight 0: same losses as the ragged batch"""
+    pol_a, pol_b = DDPGfD(82, 4, 0.8, 5), DDPGfD(82, 4, 0.8, 5)
+    load_init(pol_a, G); load_init(pol_b, G)
+    b = [torch.from_numpy(G[f"batch0_{nm}"]) for nm in ("state", "action", "next", "reward")]
+    R = b[0].shape[0]
+    pad = [torch.cat((x, torch.randn(7, *x.shape[1:])), 0) for x in b]
+    w = torch.cat((torch.ones(R), torch.zeros(7)))
+    la = pol_a.train_on_batch(*b)
+    lb = pol_b.train_on_batch(*pad, weight=w)
+    for x, y in zip(la, lb):
+        assert abs(x.item() - y.item()) <= 1e-5 * max(1, abs(x.item()))
+    for p, q in zip(pol_a.critic.parameters(), pol_b.critic.parameters()):
+        torch.testing.assert_close(p, q, rtol=1e-5, atol=1e-6)
+
+
+def test_device_replay_ring_and_sampling_distribution():
+    torch.manual_seed(0)
+    rep = DeviceEpisodeReplay(n_envs=4, capacity=8, horizon=30, device="cpu")
+    lens = [30, 12, 30, 6]            # the last one is dropped (len - n <= 1)
+    for t in range(30):
+        done = torch.tensor([t + 1 == L for L in lens])
+        active = torch.tensor([t < L for L in lens])
+        s = torch.full((4, 82), float(t)); a = torch.zeros(4, 4); r = torch.arange(4.0)
+        rep.add(s, a, s + 1, r, done, store_mask=active)
+        if done.any():
+            rep.end_episodes(done)
+    assert rep.count == 3 and sorted(rep.ep_len[:3].tolist()) == [12, 30, 30]
+    st, ac, ns, rw, nd, w = rep.sample_batch_nstep(64)
+    assert st.shape == (64 * 25, 5, 82) and w.shape == (64 * 25,)
+    # windows are consecutive time steps and stay inside the episode
+    starts = st[:, 0, 0]
+    assert torch.equal(st[:, :, 0], starts.unsqueeze(1) + torch.arange(5.0))
+    W = w.view(64, 25)
+    # row counts per episode = ceiling = len - 5 (7 for the 12-step episode, 25 for the full ones)
+    assert set(W.sum(1).long().tolist()) <= {7, 25}
+    # windows_host: reference draw pattern (ceiling - 1 random + final)
+    wins = sample_windows_host([30, 12, 30], 5, 2, np.random.RandomState(0))
+    assert all(0 <= s <= L - 5 for (e, s), L in zip(wins, [[30, 12, 30][e] for e, _ in wins]))
