@@ -1,0 +1,87 @@
+"""CPU checks: the C-ABI library loads and exports every symbol include/kinova_sim.h declares (no compute
+without a GPU: ks_create must fail loudly), and the model compiler reproduces the known answers measured
+from the reference's STL/MJCF assets (SURVEY.md 8c "builder-generated pins")."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from kinovagrasping_amd import build as kb
+from kinovagrasping_amd import model_compiler as mc
+from kinovagrasping_amd import sim as ks
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    kb.build()
+    return ks.load_library()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    header = (ROOT / "include" / "kinova_sim.h").read_text()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(ks_[a-z_0-9]+)\s*\(", header))
+    assert {"ks_create", "ks_step", "ks_reset", "ks_load_model", "ks_get_state", "ks_destroy"} <= declared
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/kinova_sim.h but not exported"
+    assert declared == set(ks.EXPORTS)
+
+
+def test_config_struct_layout_and_defaults(lib):
+    cfg = ks.KsConfig()
+    lib.ks_default_config(C.byref(cfg))
+    assert C.sizeof(cfg) == 32
+    assert (cfg.frame_skip, cfg.horizon, cfg.precision) == (15, 30, 32)      # ENV:51, main_DDPGfD.py:384
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="needs a machine without a GPU")
+def test_no_cpu_path_fails_loudly(lib):
+    cfg = ks.KsConfig()
+    lib.ks_default_config(C.byref(cfg))
+    ctx = C.c_void_p()
+    assert lib.ks_create(C.byref(cfg), 0, C.byref(ctx)) == -2                # KS_ERR_NO_DEVICE
+    assert b"no CPU path" in lib.ks_last_error(None)
+    with pytest.raises(RuntimeError):
+        ks.KinovaSim(64, "CubeS")
+    cfg.n_envs = 0
+    assert lib.ks_create(C.byref(cfg), 0, C.byref(ctx)) == -1                # KS_ERR_INVALID
+
+
+def test_model_compiler_known_answers(assets_dir):
+    M = mc.read_blob(assets_dir / "CubeS.ksm")
+    info = M["mesh_info"]                                                    # volume, hull verts, planes, tris, simplices
+    np.testing.assert_allclose(info[:, 0], [5.5307e-4, 2.4029e-5, 1.2314e-5, 1.07651e-4], rtol=2e-4)
+    assert info[:, 3].astype(int).tolist() == [27908, 2710, 1942, 6344]
+    assert abs(info[0, 1] - 753) <= 2 and abs(info[1, 1] - 289) <= 8 and abs(info[2, 1] - 344) <= 8 and info[3, 1] == 24
+    np.testing.assert_allclose(M["geom_pos"][1], [1e-5, -4.03e-3, -5.969e-2], atol=2e-5)      # palm mesh centroid
+    np.testing.assert_allclose(M["geom_pos"][2], [0.02041, -0.00818, 0], atol=1e-5)
+    np.testing.assert_allclose(sorted(M["body_inertia"][9]), [1.870e-5, 8.568e-5, 8.568e-5], rtol=1e-3)
+    assert M["pairs"].shape == (30, 5) and (M["pairs"][0, :2] == [0, 8]).all() and M["pairs"][0, 2] == 0.3
+    assert M["body_mass"].tolist() == [0, 0, 0.727, 0.01, 0.01, 0.01, 0.01, 0.01, 0.01, 0.1]
+    # palm geom frame: link frame tilted ~5.4 deg about x (SURVEY hard part 6)
+    R = mc.quat_to_mat(M["geom_quat"][1])
+    assert abs(np.degrees(np.arccos(R[1, 1])) - 5.4) < 0.2 and R[0, 0] > 0.9999
+    # obs[33:36] = [s0, s1, 2*s2] of the object's AABB half extents (ENV:529, 706-746)
+    np.testing.assert_allclose(M["obj_size_obs"], [0.0167781, 0.0167781, 0.095875], rtol=1e-5)
+
+
+def test_euler_truncation_and_quaternion():
+    np.testing.assert_array_equal(mc.truncated_euler([-0.03600013, -1.57, 4.28785117e-05, 1.2345678]), [-0.03, -1.57, 0.0, 1.234])
+    # intrinsic xyz: (-1.57, 0, -1.57) maps link y -> world x, link z -> world y, link x -> world z
+    R = mc.quat_to_mat(mc.euler_to_quat([-np.pi / 2, 0, -np.pi / 2]))
+    np.testing.assert_allclose(R @ [0, 1, 0], [1, 0, 0], atol=1e-12)
+    np.testing.assert_allclose(R @ [0, 0, 1], [0, 1, 0], atol=1e-12)
+    np.testing.assert_allclose(R @ [1, 0, 0], [0, 0, 1], atol=1e-12)
+
+
+def test_all_shapes_have_blobs(assets_dir):
+    from kinovagrasping_amd import scenarios
+    for shape in scenarios.SHAPES:
+        M = mc.read_blob(assets_dir / f"{shape}.ksm")
+        assert M["mesh3_vert"].shape[1] == 3 and abs(M["body_mass"][9] - 0.1) < 1e-12
+        assert scenarios.start_coord_table(shape).shape[0] == 4499
