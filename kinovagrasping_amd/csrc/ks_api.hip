@@ -43,9 +43,26 @@ template <typename T> struct ColW {
     __device__ void operator()(int k, T v) const { base[(long)k * stride] = v; }
 };
 
-template <typename T, bool USE_LDS> __device__ __forceinline__ Scratch<T> lane_scratch(const Buffers<T>& b, int env, int N, T* lds) {
-    if constexpr (USE_LDS) return Scratch<T>{lds + threadIdx.x, WAVE};
-    else return Scratch<T>{b.gscratch + env, N};
+// Dynamic LDS layout of the stepping kernels: [hull vertex tables][per-lane scratch, lpw lanes].
+// Every thread of the (single-wave) workgroup helps to stage the hull tables from global memory; the
+// tables are then read with wave-uniform ds_read broadcasts.
+template <typename T> struct LdsScratch { using type = Scratch<T, KS_LDS T*>; };
+
+template <typename T> __device__ __forceinline__ Hulls<T> stage_hulls(const Model<T>& m, KS_LDS T* lds, int& used) {
+    Hulls<T> hu;
+    int off = 0;
+    for (int s = 0; s < 4; s++) {
+        const int n = m.mesh_nvert_pad[s] * 4;
+        const T* src = m.mesh_vert[s];
+        for (int i = threadIdx.x; i < n; i += WAVE) lds[off + i] = src[i];
+        hu.vert[s] = lds + off;
+        hu.nvert[s] = m.mesh_nvert[s];
+        hu.nvert_pad[s] = m.mesh_nvert_pad[s];
+        off += n;
+    }
+    used = off;
+    __syncthreads();
+    return hu;
 }
 
 template <typename T> __device__ __forceinline__ void load_state(const Buffers<T>& b, int env, int N, LaneState<T>& st) {
@@ -63,12 +80,16 @@ template <typename T> __device__ __forceinline__ void store_state(const Buffers<
 
 template <typename T, bool USE_LDS>
 __global__ __launch_bounds__(WAVE) void k_env_step(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ action, int N,
-                                                   int frame_skip, int iters) {
-    __shared__ T lds[USE_LDS ? SCR_TOTAL * WAVE : 1];
-    const int env = blockIdx.x * WAVE + threadIdx.x;
-    if (env >= N) return;
+                                                   int frame_skip, int iters, int lpw, int tap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    KS_LDS T* lds = (KS_LDS T*)smem;
     const Model<T>& m = *mp;
-    Scratch<T> scr = lane_scratch<T, USE_LDS>(b, env, N, lds);
+    int hull_words = 0;
+    const Hulls<T> hu = stage_hulls(m, lds, hull_words);
+    // lpw = envs per wave (<= 64): fewer envs per wave spread the batch over more CUs and shorten the
+    // "slowest lane" tails of the divergent collision / solver loops
+    const int env = blockIdx.x * lpw + threadIdx.x;
+    if ((int)threadIdx.x >= lpw || env >= N) return;
     LaneState<T> st;
     load_state(b, env, N, st);
     T hq[4], act[4];
@@ -76,20 +97,29 @@ __global__ __launch_bounds__(WAVE) void k_env_step(const Model<T>* __restrict__ 
     for (int i = 0; i < 4; i++) { hq[i] = b.hand_quat[(long)i * N + env]; act[i] = action[(long)i * N + env]; }
     int ncon = 0, status = 0;
     ColW<T> snap{b.snap + env, N};
-    lane_env_step(m, st, hq, act, scr, snap, frame_skip, iters, ncon, status);
+    if constexpr (USE_LDS) {
+        Scratch<T, KS_LDS T*> scr{lds + hull_words + threadIdx.x, lpw};
+        lane_env_step(m, hu, st, hq, act, scr, snap, frame_skip, iters, ncon, status);
+        for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
+    } else {
+        Scratch<T> scr{b.gscratch + env, N};
+        lane_env_step(m, hu, st, hq, act, scr, snap, frame_skip, iters, ncon, status);
+        for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
+    }
     store_state(b, env, N, st);
     b.ncon[env] = ncon;
     if (status) b.status[env] |= status;
-    for (int k = 0; k < ncon * CON_STRIDE; k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
 }
 
 template <typename T, bool USE_LDS>
-__global__ __launch_bounds__(WAVE) void k_substep(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ ctrl, int N, int iters) {
-    __shared__ T lds[USE_LDS ? SCR_TOTAL * WAVE : 1];
-    const int env = blockIdx.x * WAVE + threadIdx.x;
-    if (env >= N) return;
+__global__ __launch_bounds__(WAVE) void k_substep(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ ctrl, int N, int iters, int lpw, int tap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    KS_LDS T* lds = (KS_LDS T*)smem;
     const Model<T>& m = *mp;
-    Scratch<T> scr = lane_scratch<T, USE_LDS>(b, env, N, lds);
+    int hull_words = 0;
+    const Hulls<T> hu = stage_hulls(m, lds, hull_words);
+    const int env = blockIdx.x * lpw + threadIdx.x;
+    if ((int)threadIdx.x >= lpw || env >= N) return;
     LaneState<T> st;
     load_state(b, env, N, st);
     T hq[4], c[NU], R7[9];
@@ -99,20 +129,27 @@ __global__ __launch_bounds__(WAVE) void k_substep(const Model<T>* __restrict__ m
     for (int i = 0; i < NU; i++) c[i] = ctrl[(long)i * N + env];
     hand_rotation(hq, R7);
     int ncon = 0, status = 0;
-    mj_forward_step(m, st.qpos, st.qvel, st.warm, c, R7, scr, iters, true, ncon, status);
+    if constexpr (USE_LDS) {
+        Scratch<T, KS_LDS T*> scr{lds + hull_words + threadIdx.x, lpw};
+        mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, c, R7, scr, iters, true, ncon, status);
+        for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
+    } else {
+        Scratch<T> scr{b.gscratch + env, N};
+        mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, c, R7, scr, iters, true, ncon, status);
+        for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
+    }
     store_state(b, env, N, st);
     b.ncon[env] = ncon;
     if (status) b.status[env] |= status;
-    for (int k = 0; k < ncon * CON_STRIDE; k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
 }
 
 // (re)initialise flagged envs from their stored initial state
 template <typename T, bool USE_LDS> __global__ __launch_bounds__(WAVE) void k_reset(const Model<T>* __restrict__ mp, Buffers<T> b, int N) {
-    __shared__ T lds[USE_LDS ? SCR_TOTAL * WAVE : 1];
+    __shared__ T lds[SCR_CON * WAVE];       // forward kinematics only touches the body-pose part of the scratch
     const int env = blockIdx.x * WAVE + threadIdx.x;
     if (env >= N || !b.flag[env]) return;
     const Model<T>& m = *mp;
-    Scratch<T> scr = lane_scratch<T, USE_LDS>(b, env, N, lds);
+    Scratch<T, KS_LDS T*> scr{(KS_LDS T*)lds + threadIdx.x, WAVE};
     LaneState<T> st;
     T hq[4], q0[NQ];
     KS_UNROLL
@@ -272,10 +309,37 @@ template <typename T> struct Ctx : CtxBase {
             hm.m.mesh_plane[s] = d_plane[s];
         }
         HIPCHK(hipMemcpy(d_model, &hm.m, sizeof(Model<T>), hipMemcpyHostToDevice));
+        hull_words = 0;
+        for (int s = 0; s < 4; s++) hull_words += hm.m.mesh_nvert_pad[s] * 4;
+        int r = plan_launch();
+        if (r != KS_OK) return r;
         model_loaded = true;
         return KS_OK;
     }
     int blocks() const { return (cfg.n_envs + WAVE - 1) / WAVE; }
+    // envs per wave and dynamic LDS bytes of the stepping kernels
+    int lpw = WAVE;
+    size_t step_lds = 0;
+    int hull_words = 0;
+    int plan_launch() {
+        const size_t lds_max = 160 * 1024;
+        const size_t hull_bytes = (size_t)hull_words * sizeof(T);
+        const size_t per_lane = USE_LDS ? (size_t)SCR_TOTAL * sizeof(T) : 0;
+        int cap = USE_LDS ? (int)((lds_max - hull_bytes - 64) / per_lane) : WAVE;
+        if (cap > WAVE) cap = WAVE;
+        if (cap < 1) { error = "hull tables do not fit in LDS"; return KS_ERR_MODEL; }
+        int want = cfg.envs_per_wave;                       // explicit request (debug / tuning), else automatic
+        if (want <= 0) {
+            // spread the batch over the 256 CUs: 4096 envs -> 16 per wave, 8192 -> 32, more -> as many as fit
+            want = 16;
+            while (want < cap && (cfg.n_envs + want - 1) / want > 256) want *= 2;
+        }
+        lpw = want > cap ? cap : want;
+        step_lds = hull_bytes + per_lane * lpw;
+        HIPCHK(hipFuncSetAttribute((const void*)k_env_step<T, USE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_substep<T, USE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
+        return KS_OK;
+    }
     int post_reset(void* obs, hipStream_t s) {
         const int N = cfg.n_envs;
         hipLaunchKernelGGL((k_reset<T, USE_LDS>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N);
@@ -297,8 +361,8 @@ template <typename T> struct Ctx : CtxBase {
         const int N = cfg.n_envs;
         const bool timed = ev_used < NEV;
         if (timed) HIPCHK(hipEventRecord(ev0[ev_used], s));
-        hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, (const T*)action, N, cfg.frame_skip,
-                           cfg.solver_iterations);
+        hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3((N + lpw - 1) / lpw), dim3(WAVE), step_lds, s, d_model, b, (const T*)action, N,
+                           cfg.frame_skip, cfg.solver_iterations, lpw, cfg.contact_tap);
         if (timed) { HIPCHK(hipEventRecord(ev1[ev_used], s)); ev_used++; }
         hipLaunchKernelGGL((k_rays<T>), dim3(blocks(), NRAY), dim3(WAVE), 0, s, d_model, b, N, 0);
         hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0, cfg.horizon, cfg.auto_reset, cfg.obs_env_major,
@@ -309,7 +373,8 @@ template <typename T> struct Ctx : CtxBase {
     }
     int substep(const void* ctrl, hipStream_t s) override {
         if (!model_loaded) { error = "ks_substep before ks_load_model"; return KS_ERR_STATE; }
-        hipLaunchKernelGGL((k_substep<T, USE_LDS>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, (const T*)ctrl, cfg.n_envs, cfg.solver_iterations);
+        hipLaunchKernelGGL((k_substep<T, USE_LDS>), dim3((cfg.n_envs + lpw - 1) / lpw), dim3(WAVE), step_lds, s, d_model, b, (const T*)ctrl, cfg.n_envs,
+                           cfg.solver_iterations, lpw, cfg.contact_tap);
         HIPCHK(hipGetLastError());
         return KS_OK;
     }
@@ -365,6 +430,8 @@ void ks_default_config(ks_config* cfg) {
     cfg->precision = 32;
     cfg->auto_reset = 0;
     cfg->obs_env_major = 1;
+    cfg->envs_per_wave = 0;
+    cfg->contact_tap = 0;
 }
 
 const char* ks_last_error(const ks_ctx* ctx) { return ctx ? ctx->impl->error.c_str() : g_create_error.c_str(); }

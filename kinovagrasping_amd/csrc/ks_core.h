@@ -29,11 +29,25 @@ constexpr int CON_STRIDE = 20;
 //              14-16 J.a basis (n,t1,t2), 17-19 J.p basis
 constexpr int SCR_TOTAL = SCR_CON + NCON_MAX * CON_STRIDE;   // 576
 
-// Lane-interleaved scratch accessor: element k of this lane lives at base[k*stride].
-template <typename T> struct Scratch {
-    T* base;
+// Lane-interleaved scratch accessor: element k of this lane lives at base[k*stride].  P is the pointer
+// type: an address_space(3) pointer on the GPU (real ds_read / ds_write instead of flat accesses through
+// a generic pointer), a plain pointer for the fp64 / host instantiations.
+template <typename T, typename P = T*> struct Scratch {
+    P base;
     int stride;
-    KS_HD T& operator()(int k) const { return base[(long)k * stride]; }
+    struct Ref {
+        P p;
+        KS_HD operator T() const { return *p; }
+        KS_HD const Ref& operator=(T v) const { *p = v; return *this; }
+    };
+    KS_HD Ref operator()(int k) const { return Ref{base + k * stride}; }
+};
+
+// Convex-hull vertex tables as the collision code sees them: on the GPU they are staged in LDS once per
+// launch (wave-uniform ds_read broadcasts, no scalar-cache thrash, no per-lane 64-bit address math).
+template <typename T> struct Hulls {
+    KS_LDS const T* vert[4];   // [nvert_pad][4]
+    int nvert[4], nvert_pad[4];
 };
 
 template <typename T> struct LaneState {
@@ -244,7 +258,7 @@ template <typename T> struct Supp { T v[3], v1[3], v2[3]; };
 
 template <typename T> struct PairGeo {
     T R1[9], p1[3], R2[9], p2[3];
-    const T* V1; const T* V2;
+    KS_LDS const T* V1; KS_LDS const T* V2;
     int n1, n2;
     T half_margin;
 };
@@ -254,14 +268,14 @@ template <typename T> struct PairGeo {
 // selected vertex is the same as for the unpadded table).
 constexpr int HULL_CHUNK = 8;
 
-template <typename T> KS_HD void hull_support(const T* R, const T* p, const T* V, int n, const T* dir, T hm, T* out) {
+template <typename T> KS_HD void hull_support(const T* R, const T* p, KS_LDS const T* V, int n, const T* dir, T hm, T* out) {
     T ld[3];
     mulRtv(ld, R, dir);
     T best = -Lim<T>::big;
     int bi = 0;
     // The table index is wave-uniform -> scalar loads; HULL_CHUNK vertices are requested per
     // iteration so the loads overlap instead of paying one round trip per vertex.
-    const T* Vl = V;
+    KS_LDS const T* Vl = V;
 #ifdef KS_OLD_SUPPORT
     for (int i = 0; i < n; i++) {
         T d = V[4 * i] * ld[0] + V[4 * i + 1] * ld[1] + V[4 * i + 2] * ld[2];
@@ -698,7 +712,7 @@ KS_HD void add_contact(S scr, int& ncon, int& status, int b1, int b2, T mu, T di
 }
 
 // all contact pairs of the model (explicit pairs first, then the dynamic candidates), S4
-template <typename T, typename S> KS_FN void collision(const Model<T>& m, S scr, int& ncon, int& status) {
+template <typename T, typename S> KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, int& ncon, int& status) {
     ncon = 0;
     const T PLANE_MESH_TOL = T(0.3);
     for (int pi = 0; pi < m.npair; pi++) {
@@ -706,8 +720,8 @@ template <typename T, typename S> KS_FN void collision(const Model<T>& m, S scr,
         const T margin = m.pair_margin[pi], mu = m.pair_mu[pi];
         T R2[9], p2[3];
         geom_pose(m, scr, g2, R2, p2);
-        const int mesh2 = m.geom_mesh[g2], nv2 = m.mesh_nvert[mesh2];
-        const T* V2 = m.mesh_vert[mesh2];
+        const int mesh2 = m.geom_mesh[g2];
+        KS_LDS const T* V2 = hu.vert[mesh2];
         if (g1 == 0) {
             // ground plane z = 0 (normal +z) vs hull: deepest vertex, then up to 3 more within the
             // margin that are > 0.3*rbound from every accepted vertex
@@ -717,8 +731,8 @@ template <typename T, typename S> KS_FN void collision(const Model<T>& m, S scr,
             // exact cull: lowest point of the geom's bounding box (half extents geom_size about the
             // geom origin) is above the margin -> every hull vertex is too
             if (cdist - (kabs(ln[0]) * m.geom_size[g2][0] + kabs(ln[1]) * m.geom_size[g2][1] + kabs(ln[2]) * m.geom_size[g2][2]) > margin) continue;
-            const T* Vl = V2;
-            const int nv2p = m.mesh_nvert_pad[mesh2];  // padding rows repeat vertex 0: never a new minimum
+            KS_LDS const T* Vl = V2;
+            const int nv2p = hu.nvert_pad[mesh2];  // padding rows repeat vertex 0: never a new minimum
             int best = 0;
             T bd = Lim<T>::big;
             for (int i = 0; i < nv2p; i += HULL_CHUNK) {
@@ -786,8 +800,8 @@ template <typename T, typename S> KS_FN void collision(const Model<T>& m, S scr,
             for (int j = 0; j < 9; j++) pg.R2[j] = R2[j];
             copy3(pg.p2, p2);
             const int mesh1 = m.geom_mesh[g1];
-            pg.V1 = m.mesh_vert[mesh1]; pg.n1 = m.mesh_nvert_pad[mesh1];
-            pg.V2 = V2; pg.n2 = m.mesh_nvert_pad[mesh2];
+            pg.V1 = hu.vert[mesh1]; pg.n1 = hu.nvert_pad[mesh1];
+            pg.V2 = V2; pg.n2 = hu.nvert_pad[mesh2];
             pg.half_margin = T(0);
             T depth, dist, dir[3], pos[3];
             const int r = gjk_distance(pg, margin, &dist, dir, pos);
@@ -1132,8 +1146,17 @@ KS_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T
             alpha = next;
             if (stop) break;
         }
+        T amax = 0, dmax = 0;
         KS_UNROLL
-        for (int i = 0; i < NV; i++) a[i] += alpha * p[i];
+        for (int i = 0; i < NV; i++) {
+            const T da = alpha * p[i];
+            a[i] += da;
+            amax = kabs(a[i]) > amax ? kabs(a[i]) : amax;
+            dmax = kabs(da) > dmax ? kabs(da) : dmax;
+        }
+        // converged: the step just taken is below 1e-5 of the solution scale (Newton is quadratic, the
+        // next step would be far smaller); lanes that are done wait for the slowest lane of the wave
+        if (dmax <= T(1e-5) * (1 + amax)) break;
     }
     // constraint forces at the final a -> qfrc_c = J^T f
     KS_UNROLL
@@ -1179,14 +1202,14 @@ KS_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T
 
 // ---------------------------------------------------------------- one mj_step (forward + Euler)
 template <typename T, typename S>
-KS_HD void mj_forward_step(const Model<T>& m, T* qpos, T* qvel, T* warm, const T* ctrl, const T* R7, S scr, int solver_iterations,
+KS_HD void mj_forward_step(const Model<T>& m, const Hulls<T>& hu, T* qpos, T* qvel, T* warm, const T* ctrl, const T* R7, S scr, int solver_iterations,
                            bool integrate, int& ncon_out, int& status) {
     Kin<T> k;
     forward_kinematics(m, qpos, R7, k, scr);
     T Mh[81], Mo[36], qfrc[NV];
     smooth_dynamics(m, k, qvel, ctrl, Mh, Mo, qfrc);
     int ncon = 0;
-    collision(m, scr, ncon, status);
+    collision(m, hu, scr, ncon, status);
     ncon_out = ncon;
     if (!integrate) return;
     ScalarRows<T> rows;

@@ -9,10 +9,12 @@
 #define KS_HD __host__ __device__ __forceinline__
 #define KS_UNROLL _Pragma("unroll")
 #define KS_FN __host__ __device__ __attribute__((noinline))
+#define KS_LDS __attribute__((address_space(3)))
 #else
 #define KS_HD inline
 #define KS_UNROLL
 #define KS_FN inline
+#define KS_LDS
 #endif
 
 #include <math.h>

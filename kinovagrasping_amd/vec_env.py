@@ -68,8 +68,9 @@ class KinovaGripperVecEnv:
               obj_params=None, qpos=None, obj_coord_region=None, with_noise=False, env_ids=None):
         """Reset all envs (or `env_ids`).  start_pos: optional [n,3] object positions; otherwise rows are
         sampled from the no_noise start-coordinate table of the shape (ENV:1008-1054, SURVEY note N5).
-        Only the 'normal' hand pose has zero slide offsets (ENV:1288-1289); other orientations use the
-        env's no-noise constants for the quaternion and zero offsets."""
+        Slide offsets are zero for every orientation: determine_hand_location (ENV:1286-1307) multiplies by the
+        env's Tfw *before* it is first computed, and the training loop builds a fresh env (Tfw = zeros, ENV:114)
+        for every episode (main_DDPGfD.py:381), so the offsets it actually uses are 0."""
         self.set_with_grasp_reward(with_grasp)
         ids = np.arange(self.n_envs) if env_ids is None else np.asarray(env_ids)
         n = len(ids)

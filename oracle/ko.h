@@ -90,6 +90,7 @@ typedef struct {
     /* env layer bookkeeping */
     int mpr_calls, mpr_support_calls;
     double newton_last_grad;
+    int newton_iters_used;
 } ko_sim;
 
 /* ---- model ---- */

@@ -974,7 +974,15 @@ static void solve_newton(ko_sim *s) {
             if (fabs(next - alpha) <= 1e-14 * (1 + fabs(alpha))) { alpha = next; break; }
             alpha = next;
         }
-        for (int i = 0; i < KO_NV; i++) a[i] += alpha * p[i];
+        double amax = 0, dmax = 0;
+        for (int i = 0; i < KO_NV; i++) {
+            double da = alpha * p[i];
+            a[i] += da;
+            if (fabs(a[i]) > amax) amax = fabs(a[i]);
+            if (fabs(da) > dmax) dmax = fabs(da);
+        }
+        s->newton_iters_used = it + 1;
+        if (dmax <= 1e-5 * (1 + amax)) break; /* converged (same rule as the GPU kernel) */
     }
     /* outputs */
     memcpy(s->qacc, a, sizeof a);

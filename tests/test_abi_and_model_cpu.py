@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_config_struct_layout_and_defaults(lib):
     cfg = ks.KsConfig()
     lib.ks_default_config(C.byref(cfg))
-    assert C.sizeof(cfg) == 32
+    assert C.sizeof(cfg) == 48
     assert (cfg.frame_skip, cfg.horizon, cfg.precision) == (15, 30, 32)      # ENV:51, main_DDPGfD.py:384
 
 

@@ -9,10 +9,10 @@ n = 4096
 q0, hq = scenarios.config2_states(n)
 base = scenarios.config_actions(256, 30)
 acts = torch.as_tensor(np.tile(base, (1, 1, n // 256))).cuda()
-def run(npairs, iters, label):
+def run(npairs, iters, label, lpw=0):
     M2 = dict(M); M2['pairs'] = M['pairs'][:npairs].copy()
     p = pathlib.Path(tempfile.mktemp(suffix='.ksm')); mc.write_blob(M2, p); blob = p.read_bytes()
-    sim = KinovaSim(n, blob, auto_reset=True, horizon=30, solver_iterations=iters)
+    sim = KinovaSim(n, blob, auto_reset=True, horizon=30, solver_iterations=iters, envs_per_wave=lpw)
     sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
     for t in range(5): sim.step(acts[t])
     torch.cuda.synchronize(); sim.kernel_time(reset=True)
@@ -21,5 +21,5 @@ def run(npairs, iters, label):
     st = sim.get_state(); ncon = st['ncon'].float().mean().item()
     print(f"{label:40s} pairs {npairs:2d} iters {iters}  k_env_step {ms:8.3f} ms  mean ncon {ncon:.2f}", flush=True)
     sim.close()
-run(30, 6, 'all pairs'); run(15, 6, 'no hand-hand'); run(8, 6, 'no hand-ground'); run(1, 6, 'object-ground only')
-run(30, 1, 'all pairs, 1 newton'); run(1, 1, 'object-ground only, 1 newton'); run(30, 3, 'all pairs 3 newton')
+for lpw in (64, 32, 16, 8):
+    run(30, 6, f'all pairs lpw {lpw}', lpw)

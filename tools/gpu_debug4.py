@@ -10,7 +10,7 @@ cube = ko.OracleModel(blob)
 hq, rec = oracle_grasp_trajectory(cube, n_sub=215)
 idx = [200, 205, 210]
 n = len(idx)
-sim = KinovaSim(n, "CubeS", precision=32, solver_iterations=6)
+sim = KinovaSim(n, "CubeS", precision=32, solver_iterations=6, contact_tap=True)
 q0 = np.stack([rec[i][0][0] for i in idx], 1)
 sim.reset(torch.as_tensor(q0), torch.as_tensor(np.repeat(hq[:, None], n, 1)))
 sim.set_state(torch.as_tensor(q0), torch.as_tensor(np.stack([rec[i][0][1] for i in idx], 1)), torch.as_tensor(np.stack([rec[i][0][2] for i in idx], 1)))
