@@ -60,7 +60,20 @@ template <typename T> __device__ __forceinline__ Hulls<T> stage_hulls(const Mode
         hu.nvert_pad[s] = m.mesh_nvert_pad[s];
         off += n;
     }
-    used = off;
+    // adjacency (int32) behind the vertex tables; `used` stays in units of T
+    KS_LDS int* ilds = (KS_LDS int*)(lds + off);
+    int ioff = 0;
+    for (int s = 0; s < 4; s++) {
+        const int no = m.mesh_nvert[s] + 1, na = m.mesh_nadj[s];
+        for (int i = threadIdx.x; i < no; i += WAVE) ilds[ioff + i] = m.mesh_adj_off[s][i];
+        hu.adj_off[s] = ilds + ioff;
+        ioff += no;
+        for (int i = threadIdx.x; i < na; i += WAVE) ilds[ioff + i] = m.mesh_adj[s][i];
+        hu.adj[s] = ilds + ioff;
+        ioff += na;
+    }
+    const int iwords = (ioff * (int)sizeof(int) + (int)sizeof(T) - 1) / (int)sizeof(T);
+    used = off + ((iwords + 3) & ~3);
     __syncthreads();
     return hu;
 }
@@ -256,6 +269,8 @@ template <typename T> struct Ctx : CtxBase {
     Model<T>* d_model = nullptr;
     T* d_vert[4] = {nullptr, nullptr, nullptr, nullptr};
     T* d_plane[4] = {nullptr, nullptr, nullptr, nullptr};
+    int* d_adj_off[4] = {nullptr, nullptr, nullptr, nullptr};
+    int* d_adj[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> allocs;
     // HIP-event timing of k_env_step
     static constexpr int NEV = 512;
@@ -310,7 +325,23 @@ template <typename T> struct Ctx : CtxBase {
         }
         HIPCHK(hipMemcpy(d_model, &hm.m, sizeof(Model<T>), hipMemcpyHostToDevice));
         hull_words = 0;
-        for (int s = 0; s < 4; s++) hull_words += hm.m.mesh_nvert_pad[s] * 4;
+        int adj_ints = 0;
+        for (int s = 0; s < 4; s++) {
+            int r;
+            if ((r = alloc(&d_adj_off[s], hm.adj_off[s].size()))) return r;
+            if ((r = alloc(&d_adj[s], hm.adj[s].size()))) return r;
+            HIPCHK(hipMemcpy(d_adj_off[s], hm.adj_off[s].data(), hm.adj_off[s].size() * sizeof(int), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_adj[s], hm.adj[s].data(), hm.adj[s].size() * sizeof(int), hipMemcpyHostToDevice));
+            hm.m.mesh_adj_off[s] = d_adj_off[s];
+            hm.m.mesh_adj[s] = d_adj[s];
+            hull_words += hm.m.mesh_nvert_pad[s] * 4;
+            adj_ints += hm.m.mesh_nvert[s] + 1 + hm.m.mesh_nadj[s];
+        }
+        HIPCHK(hipMemcpy(d_model, &hm.m, sizeof(Model<T>), hipMemcpyHostToDevice));
+        {
+            const int iwords = (adj_ints * (int)sizeof(int) + (int)sizeof(T) - 1) / (int)sizeof(T);
+            hull_words += (iwords + 3) & ~3;
+        }
         int r = plan_launch();
         if (r != KS_OK) return r;
         model_loaded = true;

@@ -48,6 +48,8 @@ template <typename T, typename P = T*> struct Scratch {
 template <typename T> struct Hulls {
     KS_LDS const T* vert[4];   // [nvert_pad][4]
     int nvert[4], nvert_pad[4];
+    KS_LDS const int* adj_off[4];   // CSR adjacency of the hull graph (hill-climbing support queries)
+    KS_LDS const int* adj[4];
 };
 
 template <typename T> struct LaneState {
@@ -259,50 +261,51 @@ template <typename T> struct Supp { T v[3], v1[3], v2[3]; };
 template <typename T> struct PairGeo {
     T R1[9], p1[3], R2[9], p2[3];
     KS_LDS const T* V1; KS_LDS const T* V2;
+    KS_LDS const int* off1; KS_LDS const int* adj1;
+    KS_LDS const int* off2; KS_LDS const int* adj2;
     int n1, n2;
+    int hint1, hint2;          // last support vertex of each shape: start of the next hill climb
     T half_margin;
 };
 
 // Hull vertex tables are stored padded: stride 4 reals (x, y, z, 0) and the count rounded up to a
-// multiple of HULL_CHUNK with copies of vertex 0 (a copy never wins the strict `>` arg-max, so the
-// selected vertex is the same as for the unpadded table).
+// multiple of HULL_CHUNK with copies of vertex 0 (a copy never wins a strict arg-max / arg-min).
 constexpr int HULL_CHUNK = 8;
 
-template <typename T> KS_HD void hull_support(const T* R, const T* p, KS_LDS const T* V, int n, const T* dir, T hm, T* out) {
+// Support vertex of a convex hull along `dir` by hill climbing on the hull graph: from `hint`, move to
+// the best strictly-improving neighbour until none improves.  On a convex polytope a vertex without an
+// improving neighbour is a global maximiser, so this returns what the exhaustive scan of the oracle
+// returns (they can differ only between exactly tied vertices).  Visits O(sqrt(V)) vertices instead of
+// V (the palm hull has 754), and warm-started from the previous query usually only a handful.
+template <typename T>
+KS_HD void hull_support(const T* R, const T* p, KS_LDS const T* V, KS_LDS const int* off, KS_LDS const int* adj, int& hint, const T* dir,
+                        T hm, T* out) {
     T ld[3];
     mulRtv(ld, R, dir);
-    T best = -Lim<T>::big;
-    int bi = 0;
-    // The table index is wave-uniform -> scalar loads; HULL_CHUNK vertices are requested per
-    // iteration so the loads overlap instead of paying one round trip per vertex.
-    KS_LDS const T* Vl = V;
-#ifdef KS_OLD_SUPPORT
-    for (int i = 0; i < n; i++) {
-        T d = V[4 * i] * ld[0] + V[4 * i + 1] * ld[1] + V[4 * i + 2] * ld[2];
-        if (d > best) { best = d; bi = i; }
-    }
-#else
-    for (int i = 0; i < n; i += HULL_CHUNK) {
-        T vx[HULL_CHUNK], vy[HULL_CHUNK], vz[HULL_CHUNK];
-        KS_UNROLL
-        for (int j = 0; j < HULL_CHUNK; j++) { vx[j] = Vl[4 * (i + j)]; vy[j] = Vl[4 * (i + j) + 1]; vz[j] = Vl[4 * (i + j) + 2]; }
-        KS_UNROLL
-        for (int j = 0; j < HULL_CHUNK; j++) {
-            T d = vx[j] * ld[0] + vy[j] * ld[1] + vz[j] * ld[2];
-            if (d > best) { best = d; bi = i + j; }
+    int cur = hint;
+    T best = V[4 * cur] * ld[0] + V[4 * cur + 1] * ld[1] + V[4 * cur + 2] * ld[2];
+    for (int guard = 0; guard < 4096; guard++) {
+        const int e0 = off[cur], e1 = off[cur + 1];
+        int nxt = cur;
+        for (int e = e0; e < e1; e++) {
+            const int j = adj[e];
+            T d = V[4 * j] * ld[0] + V[4 * j + 1] * ld[1] + V[4 * j + 2] * ld[2];
+            if (d > best) { best = d; nxt = j; }
         }
+        if (nxt == cur) break;
+        cur = nxt;
     }
-#endif
-    T v[3] = {V[4 * bi], V[4 * bi + 1], V[4 * bi + 2]};
+    hint = cur;
+    T v[3] = {V[4 * cur], V[4 * cur + 1], V[4 * cur + 2]};
     mulRv(out, R, v);
     add3(out, out, p);
     addscl3(out, dir, hm);
 }
 
-template <typename T> KS_HD void mpr_support(const PairGeo<T>& g, const T* dir, Supp<T>& o) {
+template <typename T> KS_HD void mpr_support(PairGeo<T>& g, const T* dir, Supp<T>& o) {
     T nd[3] = {-dir[0], -dir[1], -dir[2]};
-    hull_support(g.R1, g.p1, g.V1, g.n1, dir, g.half_margin, o.v1);
-    hull_support(g.R2, g.p2, g.V2, g.n2, nd, g.half_margin, o.v2);
+    hull_support(g.R1, g.p1, g.V1, g.off1, g.adj1, g.hint1, dir, g.half_margin, o.v1);
+    hull_support(g.R2, g.p2, g.V2, g.off2, g.adj2, g.hint2, nd, g.half_margin, o.v2);
     sub3(o.v, o.v1, o.v2);
 }
 
@@ -404,7 +407,7 @@ KS_HD void find_pos(const Supp<T>& v0, const Supp<T>& v1, const Supp<T>& v2, con
 // Minkowski Portal Refinement penetration query (same decision structure as the oracle's
 // mpr_penetration / libccd's ccdMPRPenetration).  Returns true on overlap.
 template <typename T>
-KS_FN bool mpr_penetration(const PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir, T* pos) {
+KS_FN bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir, T* pos) {
     Supp<T> v0, v1, v2, v3, v4;
     T d[3], va[3], vb[3];
     copy3(v0.v1, g.p1);
@@ -495,10 +498,10 @@ template <typename T> struct Simplex {
     int n;
 };
 
-template <typename T> KS_HD void gjk_support(const PairGeo<T>& g, const T* dir, T* y, T* a, T* b) {
+template <typename T> KS_HD void gjk_support(PairGeo<T>& g, const T* dir, T* y, T* a, T* b) {
     T nd[3] = {-dir[0], -dir[1], -dir[2]};
-    hull_support(g.R1, g.p1, g.V1, g.n1, dir, T(0), a);
-    hull_support(g.R2, g.p2, g.V2, g.n2, nd, T(0), b);
+    hull_support(g.R1, g.p1, g.V1, g.off1, g.adj1, g.hint1, dir, T(0), a);
+    hull_support(g.R2, g.p2, g.V2, g.off2, g.adj2, g.hint2, nd, T(0), b);
     sub3(y, a, b);
 }
 
@@ -593,7 +596,7 @@ template <typename T> KS_HD bool gjk_closest(Simplex<T>& S, T* lam, T* v) {
 }
 
 // 0: separated by >= margin, 1: contact in the margin zone, 2: overlap (fall back to MPR)
-template <typename T> KS_FN int gjk_distance(const PairGeo<T>& g, T margin, T* dist, T* normal, T* pos) {
+template <typename T> KS_FN int gjk_distance(PairGeo<T>& g, T margin, T* dist, T* normal, T* pos) {
     Simplex<T> S;
     T lam[4] = {1, 0, 0, 0}, v[3], d[3];
     const T tol = T(1e-6);
@@ -732,16 +735,28 @@ template <typename T, typename S> KS_FN void collision(const Model<T>& m, const 
             // geom origin) is above the margin -> every hull vertex is too
             if (cdist - (kabs(ln[0]) * m.geom_size[g2][0] + kabs(ln[1]) * m.geom_size[g2][1] + kabs(ln[2]) * m.geom_size[g2][2]) > margin) continue;
             KS_LDS const T* Vl = V2;
-            const int nv2p = hu.nvert_pad[mesh2];  // padding rows repeat vertex 0: never a new minimum
+            const int nv2p = hu.nvert_pad[mesh2];
+            // deepest vertex = support vertex along -n, found by hill climbing (ties aside, the vertex the
+            // oracle's exhaustive scan finds); the full scan below only runs for geoms that do touch
             int best = 0;
-            T bd = Lim<T>::big;
-            for (int i = 0; i < nv2p; i += HULL_CHUNK) {
-                T dd[HULL_CHUNK];
-                KS_UNROLL
-                for (int j = 0; j < HULL_CHUNK; j++) dd[j] = cdist + Vl[4 * (i + j)] * ln[0] + Vl[4 * (i + j) + 1] * ln[1] + Vl[4 * (i + j) + 2] * ln[2];
-                KS_UNROLL
-                for (int j = 0; j < HULL_CHUNK; j++)
-                    if (dd[j] < bd) { bd = dd[j]; best = i + j; }
+            T bd;
+            {
+                KS_LDS const int* off = hu.adj_off[mesh2];
+                KS_LDS const int* adj = hu.adj[mesh2];
+                int cur = 0;
+                bd = cdist + Vl[0] * ln[0] + Vl[1] * ln[1] + Vl[2] * ln[2];
+                for (int guard = 0; guard < 4096; guard++) {
+                    const int e0 = off[cur], e1 = off[cur + 1];
+                    int nxt = cur;
+                    for (int e = e0; e < e1; e++) {
+                        const int j = adj[e];
+                        T d = cdist + Vl[4 * j] * ln[0] + Vl[4 * j + 1] * ln[1] + Vl[4 * j + 2] * ln[2];
+                        if (d < bd) { bd = d; nxt = j; }
+                    }
+                    if (nxt == cur) break;
+                    cur = nxt;
+                }
+                best = cur;
             }
             if (bd > margin) continue;
             T cv[4][3];
@@ -802,6 +817,9 @@ template <typename T, typename S> KS_FN void collision(const Model<T>& m, const 
             const int mesh1 = m.geom_mesh[g1];
             pg.V1 = hu.vert[mesh1]; pg.n1 = hu.nvert_pad[mesh1];
             pg.V2 = V2; pg.n2 = hu.nvert_pad[mesh2];
+            pg.off1 = hu.adj_off[mesh1]; pg.adj1 = hu.adj[mesh1];
+            pg.off2 = hu.adj_off[mesh2]; pg.adj2 = hu.adj[mesh2];
+            pg.hint1 = 0; pg.hint2 = 0;
             pg.half_margin = T(0);
             T depth, dist, dir[3], pos[3];
             const int r = gjk_distance(pg, margin, &dist, dir, pos);

@@ -42,6 +42,9 @@ template <typename T> struct Model {
     int mesh_nvert[4], mesh_nvert_pad[4], mesh_nplane[4];
     const T* mesh_vert[4];     // [nvert_pad][4] (x,y,z,0) in the geom frame; rows >= nvert repeat vertex 0
     const T* mesh_plane[4];    // [nplane][4]  n.x <= d
+    int mesh_nadj[4];
+    const int* mesh_adj_off[4];  // CSR vertex adjacency of the hull: [nvert+1]
+    const int* mesh_adj[4];      // [nadj] neighbour vertex ids, ascending
 };
 
 }  // namespace ks

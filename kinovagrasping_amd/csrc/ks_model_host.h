@@ -21,7 +21,7 @@ inline bool blob_find(const unsigned char* blob, size_t n, const char* name, Blo
     uint32_t ver, nrec;
     std::memcpy(&ver, blob + 4, 4);
     std::memcpy(&nrec, blob + 8, 4);
-    if (ver != 3) return false;
+    if (ver != 4) return false;
     size_t off = 16;
     for (uint32_t i = 0; i < nrec && off + 48 <= n; i++) {
         char nm[25] = {0};
@@ -45,6 +45,7 @@ inline bool blob_find(const unsigned char* blob, size_t n, const char* name, Blo
 template <typename T> struct HostModel {
     Model<T> m;
     std::vector<T> vert[4], plane[4];
+    std::vector<int> adj_off[4], adj[4];
     std::string error;
 };
 
@@ -76,7 +77,7 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
     Model<T>& m = hm.m;
     std::string& e = hm.error;
     BlobRec probe;
-    if (!blob_find(b, n, "opt", probe)) { e = "not a KSMB v3 model blob"; return false; }
+    if (!blob_find(b, n, "opt", probe)) { e = "not a KSMB v4 model blob"; return false; }
     double opt[11], body_pos[30], body_quat[40], body_mass[10], body_ipos[30], body_iquat[40], body_inertia[30];
     double geom_pos[27], geom_quat[36], geom_size[27], geom_rbound[9], site_pos[NSITE * 3], site_quat[NSITE * 4];
     double hl[6], binvw[20];
@@ -184,6 +185,17 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
         m.mesh_nplane[s] = (int)r.shape[0];
         m.mesh_vert[s] = hm.vert[s].data();
         m.mesh_plane[s] = hm.plane[s].data();
+        std::snprintf(nm, sizeof nm, "mesh%d_adj_off", s);
+        if (!blob_find(b, n, nm, r) || r.code != 1 || (int)r.count != m.mesh_nvert[s] + 1) { e = std::string("missing ") + nm; return false; }
+        hm.adj_off[s].resize(r.count);
+        std::memcpy(hm.adj_off[s].data(), r.data, r.count * 4);
+        std::snprintf(nm, sizeof nm, "mesh%d_adj", s);
+        if (!blob_find(b, n, nm, r) || r.code != 1 || (int)r.count != hm.adj_off[s].back()) { e = std::string("missing ") + nm; return false; }
+        hm.adj[s].resize(r.count);
+        std::memcpy(hm.adj[s].data(), r.data, r.count * 4);
+        m.mesh_nadj[s] = (int)r.count;
+        m.mesh_adj_off[s] = hm.adj_off[s].data();
+        m.mesh_adj[s] = hm.adj[s].data();
     }
     return true;
 }

@@ -28,7 +28,7 @@ from pathlib import Path
 import numpy as np
 
 MAGIC = b"KSMB"
-VERSION = 3
+VERSION = 4
 
 # fixed topology ------------------------------------------------------------------------------
 NQ, NV, NU = 16, 15, 9
@@ -213,6 +213,17 @@ class CompiledMesh:
         _, idx = np.unique(key, axis=0, return_index=True)
         self.planes = planes[np.sort(idx)]
         self.nsimplex = len(h2.simplices)
+        # vertex adjacency of the (triangulated) hull in CSR form, neighbours in ascending index order:
+        # lets the GPU do hill-climbing support queries instead of scanning every vertex
+        nbr = [set() for _ in range(len(self.verts))]
+        for tri_ in h2.simplices:
+            for a_ in tri_:
+                for b_ in tri_:
+                    if a_ != b_:
+                        nbr[a_].add(int(b_))
+        assert all(len(x) >= 3 for x in nbr)
+        self.adj_off = np.cumsum([0] + [len(x) for x in nbr]).astype(np.int32)
+        self.adj = np.concatenate([sorted(x) for x in nbr]).astype(np.int32)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -349,6 +360,8 @@ def compile_model(xml_path: Path) -> dict:
     for s, cm in enumerate(meshes):
         M[f"mesh{s}_vert"] = cm.verts
         M[f"mesh{s}_plane"] = cm.planes
+        M[f"mesh{s}_adj_off"] = cm.adj_off
+        M[f"mesh{s}_adj"] = cm.adj
     M["mesh_info"] = np.array([[cm.volume, len(cm.verts), len(cm.planes), cm.ntri, cm.nsimplex] for cm in meshes])
 
     # sites -------------------------------------------------------------------------------------

@@ -56,7 +56,7 @@ ko_model *ko_model_load(const void *vblob, size_t n) {
     if (n < 16 || memcmp(blob, "KSMB", 4) != 0) return NULL;
     uint32_t ver;
     memcpy(&ver, blob + 4, 4);
-    if (ver != 3) return NULL;
+    if (ver != 4) return NULL;
     ko_model *m = (ko_model *)calloc(1, sizeof(ko_model));
     double opt[11];
     int bad = 0;

@@ -61,6 +61,10 @@ def test_model_compiler_known_answers(assets_dir):
     np.testing.assert_allclose(M["geom_pos"][1], [1e-5, -4.03e-3, -5.969e-2], atol=2e-5)      # palm mesh centroid
     np.testing.assert_allclose(M["geom_pos"][2], [0.02041, -0.00818, 0], atol=1e-5)
     np.testing.assert_allclose(sorted(M["body_inertia"][9]), [1.870e-5, 8.568e-5, 8.568e-5], rtol=1e-3)
+    # hull adjacency (CSR): every vertex has >= 3 neighbours, symmetric
+    off, adj = M["mesh3_adj_off"], M["mesh3_adj"]
+    assert len(off) == 25 and off[-1] == len(adj) and (np.diff(off) >= 3).all()
+    assert all(i in adj[off[j]:off[j + 1]] for i in range(24) for j in adj[off[i]:off[i + 1]])
     assert M["pairs"].shape == (30, 5) and (M["pairs"][0, :2] == [0, 8]).all() and M["pairs"][0, 2] == 0.3
     assert M["body_mass"].tolist() == [0, 0, 0.727, 0.01, 0.01, 0.01, 0.01, 0.01, 0.01, 0.1]
     # palm geom frame: link frame tilted ~5.4 deg about x (SURVEY hard part 6)
