@@ -160,6 +160,13 @@ def main():
     if rank == 0:
         value = n * world * args.steps / dt
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/pmc_run.sh);
+        # the committed summary applies to the 4096-env workload only
+        traffic, traffic_note = None, "no PMC summary for this workload"
+        pmc = ROOT / "profiles" / "r01_pmc.json"
+        if pmc.exists() and n == 4096:
+            pj = json.loads(pmc.read_text())
+            traffic, traffic_note = pj["hbm_bytes_per_launch"], pj["note"]
         out = {
             "metric": "env-steps/sec (whole node) at 4096 envs/GPU", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -173,7 +180,8 @@ def main():
                        "learner_updates_timed": updates - upd0 if args.mode == "ddpg" else 0,
                        "parallelism": f"env-shard x{world}" + (" + grad all-reduce" if world > 1 and args.mode == "ddpg" else "")},
             "roofline": {"bound": "hbm", "kernel": "k_env_step", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_note": traffic_note,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "avg_launch_ms": round(kern_ms, 4), "launches_timed": launches,
                          "note": "algorithmic 768 B/env-step x envs per launch; the path is latency/VALU bound, not HBM bound (SURVEY 8d)"},
             "nonfinite_envs": bad,
