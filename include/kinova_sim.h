@@ -62,7 +62,7 @@ typedef struct {
     int32_t precision;          /* 32 or 64 */
     int32_t auto_reset;         /* 1: envs that finish are reset to their stored initial state inside ks_step */
     int32_t obs_env_major;      /* 0: obs[k*N+env], 1: obs[env*82+k] */
-    int32_t envs_per_wave;      /* 0 = automatic (spread the batch over the 256 CUs); else 1..64 */
+    int32_t envs_per_wave;      /* 0 = automatic (16: four lanes per env); else 1..16 */
     int32_t contact_tap;        /* 1: keep the per-contact records of the last substep for ks_get_state (parity) */
     int32_t reserved[3];
 } ks_config;

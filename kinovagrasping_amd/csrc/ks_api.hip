@@ -91,18 +91,23 @@ template <typename T> __device__ __forceinline__ void store_state(const Buffers<
     for (int i = 0; i < NV; i++) { b.qvel[(long)i * N + env] = st.qvel[i]; b.warm[(long)i * N + env] = st.warm[i]; }
 }
 
+constexpr int SUBS = 4;          // lanes per env (a DPP quad)
+constexpr int EPW_MAX = WAVE / SUBS;
+
 template <typename T, bool USE_LDS>
 __global__ __launch_bounds__(WAVE) void k_env_step(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ action, int N,
-                                                   int frame_skip, int iters, int lpw, int tap) {
+                                                   int frame_skip, int iters, int epw, int tap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KS_LDS T* lds = (KS_LDS T*)smem;
     const Model<T>& m = *mp;
     int hull_words = 0;
     const Hulls<T> hu = stage_hulls(m, lds, hull_words);
-    // lpw = envs per wave (<= 64): fewer envs per wave spread the batch over more CUs and shorten the
-    // "slowest lane" tails of the divergent collision / solver loops
-    const int env = blockIdx.x * lpw + threadIdx.x;
-    if ((int)threadIdx.x >= lpw || env >= N) return;
+    // epw envs per wave, SUBS lanes per env: the four lanes keep identical copies of the env state and
+    // split the per-pair (collision) and per-contact (solver) loops; per-env dynamic data is shared in LDS
+    const int e = threadIdx.x / SUBS;
+    const Team<SUBS> team{(int)threadIdx.x % SUBS};
+    const int env = blockIdx.x * epw + e;
+    if (e >= epw || env >= N) return;
     LaneState<T> st;
     load_state(b, env, N, st);
     T hq[4], act[4];
@@ -111,28 +116,33 @@ __global__ __launch_bounds__(WAVE) void k_env_step(const Model<T>* __restrict__ 
     int ncon = 0, status = 0;
     ColW<T> snap{b.snap + env, N};
     if constexpr (USE_LDS) {
-        Scratch<T, KS_LDS T*> scr{lds + hull_words + threadIdx.x, lpw};
-        lane_env_step(m, hu, st, hq, act, scr, snap, frame_skip, iters, ncon, status);
-        for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
+        Scratch<T, KS_LDS T*> scr{lds + hull_words + e, epw};
+        lane_env_step(m, hu, st, hq, act, scr, team, snap, frame_skip, iters, ncon, status);
+        if (team.sub == 0)
+            for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
     } else {
         Scratch<T> scr{b.gscratch + env, N};
-        lane_env_step(m, hu, st, hq, act, scr, snap, frame_skip, iters, ncon, status);
-        for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
+        lane_env_step(m, hu, st, hq, act, scr, team, snap, frame_skip, iters, ncon, status);
+        if (team.sub == 0)
+            for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
     }
+    if (status) atomicOr(&b.status[env], status);
+    if (team.sub != 0) return;
     store_state(b, env, N, st);
     b.ncon[env] = ncon;
-    if (status) b.status[env] |= status;
 }
 
 template <typename T, bool USE_LDS>
-__global__ __launch_bounds__(WAVE) void k_substep(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ ctrl, int N, int iters, int lpw, int tap) {
+__global__ __launch_bounds__(WAVE) void k_substep(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ ctrl, int N, int iters, int epw, int tap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KS_LDS T* lds = (KS_LDS T*)smem;
     const Model<T>& m = *mp;
     int hull_words = 0;
     const Hulls<T> hu = stage_hulls(m, lds, hull_words);
-    const int env = blockIdx.x * lpw + threadIdx.x;
-    if ((int)threadIdx.x >= lpw || env >= N) return;
+    const int e = threadIdx.x / SUBS;
+    const Team<SUBS> team{(int)threadIdx.x % SUBS};
+    const int env = blockIdx.x * epw + e;
+    if (e >= epw || env >= N) return;
     LaneState<T> st;
     load_state(b, env, N, st);
     T hq[4], c[NU], R7[9];
@@ -143,17 +153,20 @@ __global__ __launch_bounds__(WAVE) void k_substep(const Model<T>* __restrict__ m
     hand_rotation(hq, R7);
     int ncon = 0, status = 0;
     if constexpr (USE_LDS) {
-        Scratch<T, KS_LDS T*> scr{lds + hull_words + threadIdx.x, lpw};
-        mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, c, R7, scr, iters, true, ncon, status);
-        for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
+        Scratch<T, KS_LDS T*> scr{lds + hull_words + e, epw};
+        mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, c, R7, scr, team, iters, true, ncon, status);
+        if (team.sub == 0)
+            for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
     } else {
         Scratch<T> scr{b.gscratch + env, N};
-        mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, c, R7, scr, iters, true, ncon, status);
-        for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
+        mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, c, R7, scr, team, iters, true, ncon, status);
+        if (team.sub == 0)
+            for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
     }
+    if (status) atomicOr(&b.status[env], status);
+    if (team.sub != 0) return;
     store_state(b, env, N, st);
     b.ncon[env] = ncon;
-    if (status) b.status[env] |= status;
 }
 
 // (re)initialise flagged envs from their stored initial state
@@ -355,18 +368,13 @@ template <typename T> struct Ctx : CtxBase {
     int plan_launch() {
         const size_t lds_max = 160 * 1024;
         const size_t hull_bytes = (size_t)hull_words * sizeof(T);
-        const size_t per_lane = USE_LDS ? (size_t)SCR_TOTAL * sizeof(T) : 0;
-        int cap = USE_LDS ? (int)((lds_max - hull_bytes - 64) / per_lane) : WAVE;
-        if (cap > WAVE) cap = WAVE;
+        const size_t per_env = USE_LDS ? (size_t)SCR_TOTAL * sizeof(T) : 0;
+        int cap = USE_LDS ? (int)((lds_max - hull_bytes - 64) / per_env) : EPW_MAX;
+        if (cap > EPW_MAX) cap = EPW_MAX;
         if (cap < 1) { error = "hull tables do not fit in LDS"; return KS_ERR_MODEL; }
-        int want = cfg.envs_per_wave;                       // explicit request (debug / tuning), else automatic
-        if (want <= 0) {
-            // spread the batch over the 256 CUs: 4096 envs -> 16 per wave, 8192 -> 32, more -> as many as fit
-            want = 16;
-            while (want < cap && (cfg.n_envs + want - 1) / want > 256) want *= 2;
-        }
+        int want = cfg.envs_per_wave > 0 ? cfg.envs_per_wave : EPW_MAX;
         lpw = want > cap ? cap : want;
-        step_lds = hull_bytes + per_lane * lpw;
+        step_lds = hull_bytes + per_env * lpw;
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<T, USE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_substep<T, USE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
         return KS_OK;

@@ -27,7 +27,34 @@ constexpr int SCR_CON = SCR_BP + 8 * 12;
 constexpr int CON_STRIDE = 20;
 // per contact: 0-2 pos, 3-5 normal, 6 dist, 7 mu, 8 bodies (b1 + 16*b2), 9 R, 10-13 aref[4],
 //              14-16 J.a basis (n,t1,t2), 17-19 J.p basis
-constexpr int SCR_TOTAL = SCR_CON + NCON_MAX * CON_STRIDE;   // 576
+// collision staging: every lane of an env's team detects the contacts of its share of the pairs into its
+// own list (count + NSTAGE x (pair, pos3, normal3, dist, mu, bodies)); the lists are then merged in pair
+// order.  SCR_PC: contacts per pair.
+constexpr int NSTAGE = 16, STAGE_REC = 10, STAGE_STRIDE = 1 + NSTAGE * STAGE_REC, TEAM_MAX = 4;
+constexpr int SCR_PC = SCR_CON + NCON_MAX * CON_STRIDE;
+constexpr int SCR_STAGE = SCR_PC + NPAIR_MAX;
+constexpr int SCR_TOTAL = SCR_STAGE + TEAM_MAX * STAGE_STRIDE;   // 1252 per env
+
+// A team = the SUBS lanes that work on one env (SUBS = 4 on the GPU: the lanes of a DPP quad; 1 on the
+// host).  The lanes keep identical copies of the env state and split the per-pair / per-contact loops.
+template <int SUBS> struct Team {
+    int sub;
+    template <typename T> KS_HD T sum(T x) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (SUBS == 4) {
+            x += __shfl_xor(x, 1);
+            x += __shfl_xor(x, 2);
+        }
+#endif
+        return x;
+    }
+    // LDS writes of the team members become visible to each other (one wave: program order + a fence)
+    KS_HD void sync() const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (SUBS > 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+#endif
+    }
+};
 
 // Lane-interleaved scratch accessor: element k of this lane lives at base[k*stride].  P is the pointer
 // type: an address_space(3) pointer on the GPU (real ds_read / ds_write instead of flat accesses through
@@ -39,6 +66,7 @@ template <typename T, typename P = T*> struct Scratch {
         P p;
         KS_HD operator T() const { return *p; }
         KS_HD const Ref& operator=(T v) const { *p = v; return *this; }
+        KS_HD const Ref& operator=(const Ref& o) const { *p = T(*o.p); return *this; }   // element copy, not proxy copy
     };
     KS_HD Ref operator()(int k) const { return Ref{base + k * stride}; }
 };
@@ -67,7 +95,7 @@ template <typename T> struct Kin {
 
 // ---------------------------------------------------------------- S1 forward kinematics
 template <typename T, typename S>
-KS_HD void forward_kinematics(const Model<T>& m, const T* qpos, const T* R7, Kin<T>& k, S scr) {
+KS_HD void forward_kinematics(const Model<T>& m, const T* qpos, const T* R7, Kin<T>& k, S scr, bool write_poses = true) {
     KS_UNROLL
     for (int i = 0; i < 3; i++) mulRv(k.ax[i], R7, m.slide_axis[i]);
     KS_UNROLL
@@ -93,6 +121,7 @@ KS_HD void forward_kinematics(const Model<T>& m, const T* qpos, const T* R7, Kin
     quat2mat(k.Ro, q);
     copy3(k.po, &qpos[9]);
     // body poses -> scratch (runtime-indexed by collision / contact code)
+    if (!write_poses) return;
     KS_UNROLL
     for (int j = 0; j < 9; j++) scr(SCR_BP + j) = R7[j];
     KS_UNROLL
@@ -701,24 +730,28 @@ template <typename T> KS_HD void make_frame(const T* n, T* t1, T* t2) {
 }
 
 template <typename T, typename S>
-KS_HD void add_contact(S scr, int& ncon, int& status, int b1, int b2, T mu, T dist, const T* pos, const T* normal) {
-    if (ncon >= NCON_MAX) { status |= ST_CONTACT_OVERFLOW; return; }
-    int o = SCR_CON + ncon * CON_STRIDE;
+KS_HD void add_contact(S scr, int stage0, int& cnt, int& status, int pair, int b1, int b2, T mu, T dist, const T* pos, const T* normal) {
+    if (cnt >= NSTAGE) { status |= ST_CONTACT_OVERFLOW; return; }
+    int o = stage0 + 1 + cnt * STAGE_REC;
     T n[3] = {normal[0], normal[1], normal[2]};
     normalize3(n);
+    scr(o) = T(pair);
     KS_UNROLL
-    for (int i = 0; i < 3; i++) { scr(o + i) = pos[i]; scr(o + 3 + i) = n[i]; }
-    scr(o + 6) = dist;
-    scr(o + 7) = mu;
-    scr(o + 8) = T(b1 + 16 * b2);
-    ncon++;
+    for (int i = 0; i < 3; i++) { scr(o + 1 + i) = pos[i]; scr(o + 4 + i) = n[i]; }
+    scr(o + 7) = dist;
+    scr(o + 8) = mu;
+    scr(o + 9) = T(b1 + 16 * b2);
+    cnt++;
 }
 
-// all contact pairs of the model (explicit pairs first, then the dynamic candidates), S4
-template <typename T, typename S> KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, int& ncon, int& status) {
-    ncon = 0;
+template <typename T, typename S, int SUBS>
+KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> team, int& ncon, int& status) {
     const T PLANE_MESH_TOL = T(0.3);
-    for (int pi = 0; pi < m.npair; pi++) {
+    const int stage0 = SCR_STAGE + team.sub * STAGE_STRIDE;
+    int cnt = 0;
+    for (int pi = team.sub; pi < m.npair; pi += SUBS) {
+        const int cnt_before = cnt;
+        scr(SCR_PC + pi) = T(0);
         const int g1 = m.pair_g1[pi], g2 = m.pair_g2[pi];
         const T margin = m.pair_margin[pi], mu = m.pair_mu[pi];
         T R2[9], p2[3];
@@ -798,7 +831,7 @@ template <typename T, typename S> KS_FN void collision(const Model<T>& m, const 
                     mulRv(w, R2, cv[k]);
                     add3(w, w, p2);
                     w[2] -= T(0.5) * d;
-                    add_contact(scr, ncon, status, 0, m.geom_body[g2], mu, d, w, normal);
+                    add_contact(scr, stage0, cnt, status, pi, 0, m.geom_body[g2], mu, d, w, normal);
                 }
             }
         } else {
@@ -823,11 +856,31 @@ template <typename T, typename S> KS_FN void collision(const Model<T>& m, const 
             pg.half_margin = T(0);
             T depth, dist, dir[3], pos[3];
             const int r = gjk_distance(pg, margin, &dist, dir, pos);
-            if (r == 1) add_contact(scr, ncon, status, m.geom_body[g1], m.geom_body[g2], mu, dist, pos, dir);
+            if (r == 1) add_contact(scr, stage0, cnt, status, pi, m.geom_body[g1], m.geom_body[g2], mu, dist, pos, dir);
             else if (r == 2 && mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, dir, pos))
-                add_contact(scr, ncon, status, m.geom_body[g1], m.geom_body[g2], mu, -depth, pos, dir);
+                add_contact(scr, stage0, cnt, status, pi, m.geom_body[g1], m.geom_body[g2], mu, -depth, pos, dir);
         }
+        scr(SCR_PC + pi) = T(cnt - cnt_before);
     }
+    team.sync();
+    // merge the team's lists in pair order (= the oracle's contact order); contacts beyond NCON_MAX are dropped
+    int total = 0, mine = 0;
+    for (int pi = 0; pi < m.npair; pi++) {
+        const int c = (int)scr(SCR_PC + pi);
+        if (pi % SUBS == team.sub) {
+            for (int q = 0; q < c; q++) {
+                const int src = stage0 + 1 + (mine + q) * STAGE_REC, dst = SCR_CON + (total + q) * CON_STRIDE;
+                if (total + q < NCON_MAX) {
+                    KS_UNROLL
+                    for (int f = 0; f < 9; f++) scr(dst + f) = scr(src + 1 + f);
+                } else status |= ST_CONTACT_OVERFLOW;
+            }
+            mine += c;
+        }
+        total += c;
+    }
+    ncon = total < NCON_MAX ? total : NCON_MAX;
+    team.sync();
 }
 
 // ---------------------------------------------------------------- S5 constraint rows
@@ -911,8 +964,8 @@ template <typename T> struct ScalarRows {
     T lim_sign[6], lim_aref[6], lim_R[6];   // sign 0 = inactive; joints: slides 0-2, proximal hinges 3,5,7
 };
 
-template <typename T, typename S>
-KS_FN void make_constraints(const Model<T>& m, const Kin<T>& k, const T* qpos, const T* qvel, S scr, int ncon, ScalarRows<T>& r) {
+template <typename T, typename S, int SUBS>
+KS_FN void make_constraints(const Model<T>& m, const Kin<T>& k, const T* qpos, const T* qvel, S scr, Team<SUBS> team, int ncon, ScalarRows<T>& r) {
     KS_UNROLL
     for (int t = 0; t < 3; t++) {
         const T c0 = m.tendon_coef[t][0], c1 = m.tendon_coef[t][1];
@@ -939,7 +992,7 @@ KS_FN void make_constraints(const Model<T>& m, const Kin<T>& k, const T* qpos, c
         T R = (1 - imp) / imp * m.dof_invw[dof];
         r.lim_R[j] = R > T(1e-15) ? R : T(1e-15);
     }
-    for (int ci = 0; ci < ncon; ci++) {
+    for (int ci = team.sub; ci < ncon; ci += SUBS) {
         const int o = SCR_CON + ci * CON_STRIDE;
         T B[3][NV], dist, mu;
         contact_basis(k, scr, ci, B, dist, mu);
@@ -966,13 +1019,14 @@ KS_FN void make_constraints(const Model<T>& m, const Kin<T>& k, const T* qpos, c
         scr(o + 12) = -m.solref_b * (vb[0] + mu * vb[2]) + base;
         scr(o + 13) = -m.solref_b * (vb[0] - mu * vb[2]) + base;
     }
+    team.sync();
 }
 
 // ---------------------------------------------------------------- S6 Newton solver
 // cost of the constraint part + Gauss part at acceleration a (used for the warm-start choice)
-template <typename T, typename S>
+template <typename T, typename S, int SUBS>
 KS_HD T primal_cost(const Model<T>& m, const Kin<T>& k, const T* Mh, const T* Mo, const T* qacc_smooth, const ScalarRows<T>& r, S scr,
-                    int ncon, const T* a) {
+                    Team<SUBS> team, int ncon, const T* a) {
     T d[NV], Md[NV], c = 0;
     KS_UNROLL
     for (int i = 0; i < NV; i++) d[i] = a[i] - qacc_smooth[i];
@@ -990,7 +1044,8 @@ KS_HD T primal_cost(const Model<T>& m, const Kin<T>& k, const T* Mh, const T* Mo
         T x = r.lim_sign[j] * a[dof] - r.lim_aref[j];
         if (r.lim_sign[j] != 0 && x < 0) c += T(0.5) * x * x / r.lim_R[j];
     }
-    for (int ci = 0; ci < ncon; ci++) {
+    T cc = 0;
+    for (int ci = team.sub; ci < ncon; ci += SUBS) {
         const int o = SCR_CON + ci * CON_STRIDE;
         T R = scr(o + 9);
         if (R < 0) continue;
@@ -1006,19 +1061,19 @@ KS_HD T primal_cost(const Model<T>& m, const Kin<T>& k, const T* Mh, const T* Mo
         KS_UNROLL
         for (int kk = 0; kk < 4; kk++) {
             T x = xb[0] + ((kk & 1) ? -mu : mu) * xb[1 + (kk >> 1)] - scr(o + 10 + kk);
-            if (x < 0) c += T(0.5) * x * x / R;
+            if (x < 0) cc += T(0.5) * x * x / R;
         }
     }
-    return c;
+    return c + team.sum(cc);
 }
 
 // Solve for qacc.  Outputs a (qacc) and qfrc_c (J^T f).
-template <typename T, typename S>
+template <typename T, typename S, int SUBS>
 KS_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T* Mo, const T* qfrc_smooth, const T* qacc_smooth,
-                        const T* warm, const ScalarRows<T>& r, S scr, int ncon, int iterations, T* a, T* qfrc_c) {
+                        const T* warm, const ScalarRows<T>& r, S scr, Team<SUBS> team, int ncon, int iterations, T* a, T* qfrc_c) {
     {
-        T cw = primal_cost(m, k, Mh, Mo, qacc_smooth, r, scr, ncon, warm);
-        T cs = primal_cost(m, k, Mh, Mo, qacc_smooth, r, scr, ncon, qacc_smooth);
+        T cw = primal_cost(m, k, Mh, Mo, qacc_smooth, r, scr, team, ncon, warm);
+        T cs = primal_cost(m, k, Mh, Mo, qacc_smooth, r, scr, team, ncon, qacc_smooth);
         const bool use_warm = cw < cs;
         KS_UNROLL
         for (int i = 0; i < NV; i++) a[i] = use_warm ? warm[i] : qacc_smooth[i];
@@ -1026,12 +1081,15 @@ KS_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T
     for (int it = 0; it < iterations; it++) {
         T H[NV * NV], g[NV], Ma[NV];
         mul_M(Mh, Mo, a, Ma);
+        // the Gauss part and the scalar rows are accumulated on lane 0 of the team only; every lane adds the
+        // contacts it owns; the team sum below gives all lanes the complete g and H
+        const T lead = team.sub == 0 ? T(1) : T(0);
         KS_UNROLL
-        for (int i = 0; i < NV; i++) { Ma[i] -= qfrc_smooth[i]; g[i] = Ma[i]; }
+        for (int i = 0; i < NV; i++) { Ma[i] -= qfrc_smooth[i]; g[i] = lead * Ma[i]; }
         KS_UNROLL
         for (int i = 0; i < NV; i++) {
             KS_UNROLL
-            for (int j = 0; j <= i; j++) H[i * NV + j] = (i < 9 && j < 9) ? Mh[i * 9 + j] : ((i >= 9 && j >= 9) ? Mo[(i - 9) * 6 + (j - 9)] : T(0));
+            for (int j = 0; j <= i; j++) H[i * NV + j] = lead * ((i < 9 && j < 9) ? Mh[i * 9 + j] : ((i >= 9 && j >= 9) ? Mo[(i - 9) * 6 + (j - 9)] : T(0)));
         }
         // scalar rows
         T eq_x[3], lim_x[6];
@@ -1039,7 +1097,7 @@ KS_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T
         for (int t = 0; t < 3; t++) {
             const T c0 = m.tendon_coef[t][0], c1 = m.tendon_coef[t][1];
             const int ip = 3 + 2 * t, id = 4 + 2 * t;
-            T x = c0 * a[ip] + c1 * a[id] - r.eq_aref[t], D = T(1) / r.eq_R[t];
+            T x = c0 * a[ip] + c1 * a[id] - r.eq_aref[t], D = lead / r.eq_R[t];
             eq_x[t] = x;
             g[ip] += c0 * D * x; g[id] += c1 * D * x;
             H[ip * NV + ip] += D * c0 * c0; H[id * NV + ip] += D * c0 * c1; H[id * NV + id] += D * c1 * c1;
@@ -1050,13 +1108,13 @@ KS_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T
             T x = r.lim_sign[j] * a[dof] - r.lim_aref[j];
             lim_x[j] = x;
             if (r.lim_sign[j] != 0 && x < 0) {
-                T D = T(1) / r.lim_R[j];
+                T D = lead / r.lim_R[j];
                 g[dof] += r.lim_sign[j] * D * x;
                 H[dof * NV + dof] += D;
             }
         }
         // contacts: gradient + Hessian, basis values J.a cached in scratch
-        for (int ci = 0; ci < ncon; ci++) {
+        for (int ci = team.sub; ci < ncon; ci += SUBS) {
             const int o = SCR_CON + ci * CON_STRIDE;
             T R = scr(o + 9);
             if (R < 0) continue;
@@ -1097,6 +1155,14 @@ KS_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T
                 for (int j = 0; j <= i; j++) H[i * NV + j] += B[0][i] * W[0][j] + B[1][i] * W[1][j] + B[2][i] * W[2][j];
             }
         }
+        if constexpr (SUBS > 1) {
+            KS_UNROLL
+            for (int i = 0; i < NV; i++) {
+                g[i] = team.sum(g[i]);
+                KS_UNROLL
+                for (int j = 0; j <= i; j++) H[i * NV + j] = team.sum(H[i * NV + j]);
+            }
+        }
         // Newton direction
         chol_inplace<T, NV>(H);
         T ng[NV], p[NV], Mp[NV];
@@ -1112,7 +1178,7 @@ KS_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T
         for (int t = 0; t < 3; t++) eq_p[t] = m.tendon_coef[t][0] * p[3 + 2 * t] + m.tendon_coef[t][1] * p[4 + 2 * t];
         KS_UNROLL
         for (int j = 0; j < 6; j++) lim_p[j] = r.lim_sign[j] * p[j < 3 ? j : 3 + 2 * (j - 3)];
-        for (int ci = 0; ci < ncon; ci++) {
+        for (int ci = team.sub; ci < ncon; ci += SUBS) {
             const int o = SCR_CON + ci * CON_STRIDE;
             if (scr(o + 9) < 0) continue;
             T B[3][NV], dist, mu;
@@ -1128,18 +1194,18 @@ KS_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T
         // exact line search on phi'(alpha) (piecewise linear, increasing)
         T alpha = 0, lo = 0, hi = -1;
         for (int ls = 0; ls < 30; ls++) {
-            T d1 = pMa + alpha * pMp, d2 = pMp;
+            T d1 = lead * (pMa + alpha * pMp), d2 = lead * pMp;
             KS_UNROLL
             for (int t = 0; t < 3; t++) {
-                T x = eq_x[t] + alpha * eq_p[t], D = T(1) / r.eq_R[t];
+                T x = eq_x[t] + alpha * eq_p[t], D = lead / r.eq_R[t];
                 d1 += D * x * eq_p[t]; d2 += D * eq_p[t] * eq_p[t];
             }
             KS_UNROLL
             for (int j = 0; j < 6; j++) {
                 T x = lim_x[j] + alpha * lim_p[j];
-                if (r.lim_sign[j] != 0 && x < 0) { T D = T(1) / r.lim_R[j]; d1 += D * x * lim_p[j]; d2 += D * lim_p[j] * lim_p[j]; }
+                if (r.lim_sign[j] != 0 && x < 0) { T D = lead / r.lim_R[j]; d1 += D * x * lim_p[j]; d2 += D * lim_p[j] * lim_p[j]; }
             }
-            for (int ci = 0; ci < ncon; ci++) {
+            for (int ci = team.sub; ci < ncon; ci += SUBS) {
                 const int o = SCR_CON + ci * CON_STRIDE;
                 T R = scr(o + 9);
                 if (R < 0) continue;
@@ -1155,6 +1221,8 @@ KS_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T
                     if (x < 0) { d1 += D * x * jp; d2 += D * jp * jp; }
                 }
             }
+            d1 = team.sum(d1);
+            d2 = team.sum(d2);
             if (d2 < T(1e-15)) break;
             if (d1 < 0) lo = alpha; else hi = alpha;
             T next = alpha - d1 / d2;
@@ -1179,19 +1247,20 @@ KS_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T
     // constraint forces at the final a -> qfrc_c = J^T f
     KS_UNROLL
     for (int i = 0; i < NV; i++) qfrc_c[i] = 0;
+    const T lead = team.sub == 0 ? T(1) : T(0);
     KS_UNROLL
     for (int t = 0; t < 3; t++) {
         const T c0 = m.tendon_coef[t][0], c1 = m.tendon_coef[t][1];
-        T x = c0 * a[3 + 2 * t] + c1 * a[4 + 2 * t] - r.eq_aref[t], f = -x / r.eq_R[t];
+        T x = c0 * a[3 + 2 * t] + c1 * a[4 + 2 * t] - r.eq_aref[t], f = -lead * x / r.eq_R[t];
         qfrc_c[3 + 2 * t] += c0 * f; qfrc_c[4 + 2 * t] += c1 * f;
     }
     KS_UNROLL
     for (int j = 0; j < 6; j++) {
         const int dof = j < 3 ? j : 3 + 2 * (j - 3);
         T x = r.lim_sign[j] * a[dof] - r.lim_aref[j];
-        if (r.lim_sign[j] != 0 && x < 0) qfrc_c[dof] += r.lim_sign[j] * (-x / r.lim_R[j]);
+        if (r.lim_sign[j] != 0 && x < 0) qfrc_c[dof] += lead * r.lim_sign[j] * (-x / r.lim_R[j]);
     }
-    for (int ci = 0; ci < ncon; ci++) {
+    for (int ci = team.sub; ci < ncon; ci += SUBS) {
         const int o = SCR_CON + ci * CON_STRIDE;
         T R = scr(o + 9);
         if (R < 0) { scr(o + 14) = 0; scr(o + 15) = 0; scr(o + 16) = 0; continue; }
@@ -1216,22 +1285,29 @@ KS_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T
         KS_UNROLL
         for (int j = 0; j < NV; j++) qfrc_c[j] += B[0][j] * fn + B[1][j] * ft1 + B[2][j] * ft2;
     }
+    if constexpr (SUBS > 1) {
+        KS_UNROLL
+        for (int j = 0; j < NV; j++) qfrc_c[j] = team.sum(qfrc_c[j]);
+    }
+    team.sync();
 }
 
 // ---------------------------------------------------------------- one mj_step (forward + Euler)
-template <typename T, typename S>
-KS_HD void mj_forward_step(const Model<T>& m, const Hulls<T>& hu, T* qpos, T* qvel, T* warm, const T* ctrl, const T* R7, S scr, int solver_iterations,
-                           bool integrate, int& ncon_out, int& status) {
+template <typename T, typename S, int SUBS>
+KS_HD void mj_forward_step(const Model<T>& m, const Hulls<T>& hu, T* qpos, T* qvel, T* warm, const T* ctrl, const T* R7, S scr, Team<SUBS> team,
+                           int solver_iterations, bool integrate, int& ncon_out, int& status) {
     Kin<T> k;
-    forward_kinematics(m, qpos, R7, k, scr);
+    team.sync();                                   // the previous substep's readers of the body poses are done
+    forward_kinematics(m, qpos, R7, k, scr, team.sub == 0);
+    team.sync();
     T Mh[81], Mo[36], qfrc[NV];
     smooth_dynamics(m, k, qvel, ctrl, Mh, Mo, qfrc);
     int ncon = 0;
-    collision(m, hu, scr, ncon, status);
+    collision(m, hu, scr, team, ncon, status);
     ncon_out = ncon;
     if (!integrate) return;
     ScalarRows<T> rows;
-    make_constraints(m, k, qpos, qvel, scr, ncon, rows);
+    make_constraints(m, k, qpos, qvel, scr, team, ncon, rows);
     // qacc_smooth = M^-1 qfrc
     T Lh[81], Lo[36], qacc_s[NV];
     KS_UNROLL
@@ -1243,7 +1319,7 @@ KS_HD void mj_forward_step(const Model<T>& m, const Hulls<T>& hu, T* qpos, T* qv
     chol_solve<T, 9>(Lh, qfrc, qacc_s);
     chol_solve<T, 6>(Lo, qfrc + 9, qacc_s + 9);
     T a[NV], qfrc_c[NV];
-    solve_newton(m, k, Mh, Mo, qfrc, qacc_s, warm, rows, scr, ncon, solver_iterations, a, qfrc_c);
+    solve_newton(m, k, Mh, Mo, qfrc, qacc_s, warm, rows, scr, team, ncon, solver_iterations, a, qfrc_c);
     // S7 Euler with implicit joint damping: (M + h D) qacc' = qfrc_smooth + qfrc_constraint
     const T h = m.dt;
     KS_UNROLL

@@ -41,7 +41,7 @@ static int substep_t(const Model<T>& m, double* qpos, double* qvel, double* warm
     for (int i = 0; i < 4; i++) q4[i] = (T)hq[i];
     hand_rotation(q4, R7);
     int status = 0, nc = 0;
-    mj_forward_step(m, host_hulls(m), st.qpos, st.qvel, st.warm, c, R7, scr, iters, true, nc, status);
+    mj_forward_step(m, host_hulls(m), st.qpos, st.qvel, st.warm, c, R7, scr, Team<1>{0}, iters, true, nc, status);
     for (int i = 0; i < NQ; i++) qpos[i] = st.qpos[i];
     for (int i = 0; i < NV; i++) { qvel[i] = st.qvel[i]; warm[i] = st.warm[i]; }
     *ncon = nc;
@@ -67,7 +67,7 @@ static int env_step_t(const Model<T>& m, double* qpos, double* qvel, double* war
         for (int i = 0; i < NQ; i++) q0[i] = (T)qpos[i];
         lane_reset(m, st, q4, q0, scr, put);
     } else {
-        lane_env_step(m, host_hulls(m), st, q4, a4, scr, put, frame_skip, iters, nc, status);
+        lane_env_step(m, host_hulls(m), st, q4, a4, scr, Team<1>{0}, put, frame_skip, iters, nc, status);
     }
     Col<T> sc{snap.data(), 1};
     T rays[NRAY];

@@ -21,5 +21,5 @@ def run(npairs, iters, label, lpw=0):
     st = sim.get_state(); ncon = st['ncon'].float().mean().item()
     print(f"{label:40s} pairs {npairs:2d} iters {iters}  k_env_step {ms:8.3f} ms  mean ncon {ncon:.2f}", flush=True)
     sim.close()
-for lpw in (64, 32, 16, 8):
-    run(30, 6, f'all pairs lpw {lpw}', lpw)
+for lpw in (16, 8, 4):
+    run(30, 6, f'all pairs epw {lpw}', lpw)
