@@ -194,3 +194,26 @@ def test_full_size_properties():
     assert (prox - 2 * dist).abs().max().item() < 0.05
     # object quaternion stays normalised
     assert (qpos[12:16].norm(dim=0) - 1).abs().max().item() < 1e-5
+
+
+def test_naive_demonstrator_lifts_centred_cubes():
+    """Behavioural pin (SURVEY 8c-v): the naive controller lifts a centred CubeS within the 30-step horizon;
+    the reference's demonstrations succeed in 21-28 steps."""
+    from kinovagrasping_amd.demonstrators import run_naive_episodes
+    from kinovagrasping_amd.replay import DeviceEpisodeReplay
+    n = 64
+    q0 = np.zeros((16, n)); q0[12] = 1; q0[11] = 0.0654
+    q0[9] = np.linspace(-0.01, 0.01, n)            # object x across the palm centre
+    hq = np.repeat(scenarios.hand_quat_for("normal")[:, None], n, 1)
+    sim = _sim(n, "CubeS", horizon=30, auto_reset=False)
+    obs0 = sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+    rep = DeviceEpisodeReplay(n, capacity=128, device=sim.device)
+    out = run_naive_episodes(sim, obs0, rep)
+    torch.cuda.synchronize()
+    rate = out["success"].float().mean().item()
+    st = out["steps"][out["success"]].float()
+    print(f"naive controller: success {rate:.2f}, steps to lift min {st.min().item():.0f} mean {st.mean().item():.1f} max {st.max().item():.0f}")
+    assert rate >= 0.8
+    assert 18 <= st.mean().item() <= 30
+    assert rep.count == n and (rep.ep_reward[:n].sum(1) >= 50 * out["success"].float().cpu().to(rep.device)).all()
+    sim.close()
