@@ -217,3 +217,45 @@ def test_naive_demonstrator_lifts_centred_cubes():
     assert 18 <= st.mean().item() <= 30
     assert rep.count == n and (rep.ep_reward[:n].sum(1) >= 50 * out["success"].float().cpu().to(rep.device)).all()
     sim.close()
+
+
+def test_mixed_shape_batch_equals_per_shape_contexts(assets_dir):
+    """BASELINE config 5 plumbing: a mixed-object batch is bit-identical to running each shape alone, and each
+    block agrees with the oracle for its own shape."""
+    from kinovagrasping_amd.multi_shape import MultiShapeSim
+    shapes = ["CubeB", "CylinderS", "Cone1B", "Vase2S"]
+    per = 32
+    n = per * len(shapes)
+    rng = np.random.RandomState(5)
+    q0 = np.zeros((16, n)); q0[12] = 1
+    for k, sh in enumerate(shapes):
+        tab = scenarios.start_coord_table(sh)
+        q0[9:12, k * per:(k + 1) * per] = tab[rng.randint(0, len(tab), per)].T
+    hq = np.repeat(scenarios.hand_quat_for("normal")[:, None], n, 1)
+    acts = torch.as_tensor(scenarios.config_actions(n, 2, base_seed=77))
+    ms = MultiShapeSim(n, shapes)
+    obs_m = ms.reset(torch.as_tensor(q0), torch.as_tensor(hq)).clone()
+    for t in range(2):
+        om, rm, dm, im = ms.step(acts[t])
+    torch.cuda.synchronize()
+    qm = ms.get_state()["qpos"]
+    for k, sh in enumerate(shapes):
+        sl = slice(k * per, (k + 1) * per)
+        sim = _sim(per, sh)
+        o0 = sim.reset(torch.as_tensor(q0[:, sl]), torch.as_tensor(hq[:, sl]))
+        assert torch.equal(o0, obs_m[sl])
+        for t in range(2):
+            o1 = sim.step(acts[t][:, sl])[0]
+        torch.cuda.synchronize()
+        assert torch.equal(o1, om[sl]) and torch.equal(sim.get_state()["qpos"], qm[:, sl])
+        # oracle for this shape, first env of the block
+        model = ko.OracleModel((assets_dir / f"{sh}.ksm").read_bytes())
+        o = ko.OracleSim(model, hq[:, 0], solver_iterations=6)
+        o.env_reset(q0[:, k * per])
+        for t in range(2):
+            o.env_step(acts[t][:, k * per].numpy())
+        qo = o.view("qpos")
+        rel = np.abs(qm[:, k * per].double().cpu().numpy() - qo).max() / max(1e-3, np.abs(qo).max())
+        assert rel < 1e-4, (sh, rel)
+        sim.close()
+    ms.close()
