@@ -37,7 +37,7 @@ def cpu_baseline(n_cores: int, budget_s: float = 12.0):
     import numpy as np
     from kinovagrasping_amd import scenarios
     from oracle import ko_py as ko
-    model = ko.OracleModel((ROOT / "kinovagrasping_amd" / "assets" / "CubeS.ksm").read_bytes())
+    model = ko.OracleModel(scenarios.model_blob("CubeS"))
     q0, hq = scenarios.config2_states(n_cores)
     acts = scenarios.config_actions(n_cores, 30)
 

@@ -281,7 +281,9 @@ template <typename T> struct Ctx : CtxBase {
     Buffers<T> b{};
     Model<T>* d_model = nullptr;
     T* d_vert[4] = {nullptr, nullptr, nullptr, nullptr};
-    T* d_plane[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* d_tri[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* d_box[4] = {nullptr, nullptr, nullptr, nullptr};
+    int* d_lr[4] = {nullptr, nullptr, nullptr, nullptr};
     int* d_adj_off[4] = {nullptr, nullptr, nullptr, nullptr};
     int* d_adj[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> allocs;
@@ -330,11 +332,17 @@ template <typename T> struct Ctx : CtxBase {
         for (int s = 0; s < 4; s++) {
             int r;
             if ((r = alloc(&d_vert[s], hm.vert[s].size()))) return r;
-            if ((r = alloc(&d_plane[s], hm.plane[s].size()))) return r;
+            if ((r = alloc(&d_tri[s], hm.tri[s].size()))) return r;
+            if ((r = alloc(&d_box[s], hm.bvh_box[s].size()))) return r;
+            if ((r = alloc(&d_lr[s], hm.bvh_lr[s].size()))) return r;
             HIPCHK(hipMemcpy(d_vert[s], hm.vert[s].data(), hm.vert[s].size() * sizeof(T), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(d_plane[s], hm.plane[s].data(), hm.plane[s].size() * sizeof(T), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_tri[s], hm.tri[s].data(), hm.tri[s].size() * sizeof(float), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_box[s], hm.bvh_box[s].data(), hm.bvh_box[s].size() * sizeof(float), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_lr[s], hm.bvh_lr[s].data(), hm.bvh_lr[s].size() * sizeof(int), hipMemcpyHostToDevice));
             hm.m.mesh_vert[s] = d_vert[s];
-            hm.m.mesh_plane[s] = d_plane[s];
+            hm.m.mesh_tri[s] = d_tri[s];
+            hm.m.mesh_bvh_box[s] = d_box[s];
+            hm.m.mesh_bvh_lr[s] = d_lr[s];
         }
         HIPCHK(hipMemcpy(d_model, &hm.m, sizeof(Model<T>), hipMemcpyHostToDevice));
         hull_words = 0;

@@ -39,9 +39,12 @@ template <typename T> struct Model {
     T act[5];                  // kv_slide, gear_motor, ctrlrange_slide, kv_finger, ctrlrange_finger
     T dof_invw[NV], body_invw[NBODY], tendon_invw[3];
     T obj_size_obs[3];
-    int mesh_nvert[4], mesh_nvert_pad[4], mesh_nplane[4];
+    int mesh_nvert[4], mesh_nvert_pad[4], mesh_ntri[4], mesh_nnode[4];
     const T* mesh_vert[4];     // [nvert_pad][4] (x,y,z,0) in the geom frame; rows >= nvert repeat vertex 0
-    const T* mesh_plane[4];    // [nplane][4]  n.x <= d
+    // rangefinder geometry: the original mesh triangles (geom frame) under a bounding-volume hierarchy
+    const float* mesh_tri[4];      // [ntri][9], leaf ranges contiguous
+    const float* mesh_bvh_box[4];  // [nnode][6] min xyz, max xyz
+    const int* mesh_bvh_lr[4];     // [nnode][2] internal: (left, right); leaf: (first triangle, -count)
     int mesh_nadj[4];
     const int* mesh_adj_off[4];  // CSR vertex adjacency of the hull: [nvert+1]
     const int* mesh_adj[4];      // [nadj] neighbour vertex ids, ascending

@@ -21,14 +21,14 @@ inline bool blob_find(const unsigned char* blob, size_t n, const char* name, Blo
     uint32_t ver, nrec;
     std::memcpy(&ver, blob + 4, 4);
     std::memcpy(&nrec, blob + 8, 4);
-    if (ver != 4) return false;
+    if (ver != 5) return false;
     size_t off = 16;
     for (uint32_t i = 0; i < nrec && off + 48 <= n; i++) {
         char nm[25] = {0};
         std::memcpy(nm, blob + off, 24);
         uint32_t hdr[6];
         std::memcpy(hdr, blob + off + 24, 24);
-        size_t isz = hdr[0] == 1 ? 4 : 8, bytes = (size_t)hdr[1] * isz;
+        size_t isz = hdr[0] == 0 ? 8 : 4, bytes = (size_t)hdr[1] * isz;   // 0 = f64, 1 = i32, 2 = f32
         bytes += (8 - bytes % 8) % 8;
         if (off + 48 + bytes > n) return false;
         if (std::strcmp(nm, name) == 0) {
@@ -44,7 +44,9 @@ inline bool blob_find(const unsigned char* blob, size_t n, const char* name, Blo
 
 template <typename T> struct HostModel {
     Model<T> m;
-    std::vector<T> vert[4], plane[4];
+    std::vector<T> vert[4];
+    std::vector<float> tri[4], bvh_box[4];
+    std::vector<int> bvh_lr[4];
     std::vector<int> adj_off[4], adj[4];
     std::string error;
 };
@@ -77,7 +79,7 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
     Model<T>& m = hm.m;
     std::string& e = hm.error;
     BlobRec probe;
-    if (!blob_find(b, n, "opt", probe)) { e = "not a KSMB v4 model blob"; return false; }
+    if (!blob_find(b, n, "opt", probe)) { e = "not a KSMB v5 model blob (merge <shape>.ksm with hand_raymesh.kst: model_compiler.load_model_blob)"; return false; }
     double opt[11], body_pos[30], body_quat[40], body_mass[10], body_ipos[30], body_iquat[40], body_inertia[30];
     double geom_pos[27], geom_quat[36], geom_size[27], geom_rbound[9], site_pos[NSITE * 3], site_quat[NSITE * 4];
     double hl[6], binvw[20];
@@ -178,13 +180,24 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
             m.mesh_nvert[s] = nv;
             m.mesh_nvert_pad[s] = npad;
         }
-        std::snprintf(nm, sizeof nm, "mesh%d_plane", s);
-        if (!blob_find(b, n, nm, r) || r.code != 0) { e = std::string("missing ") + nm; return false; }
-        hm.plane[s].resize(r.count);
-        for (uint32_t i = 0; i < r.count; i++) { double v; std::memcpy(&v, r.data + 8 * i, 8); hm.plane[s][i] = (T)v; }
-        m.mesh_nplane[s] = (int)r.shape[0];
         m.mesh_vert[s] = hm.vert[s].data();
-        m.mesh_plane[s] = hm.plane[s].data();
+        {
+            BlobRec rt, rb, rl;
+            std::snprintf(nm, sizeof nm, "mesh%d_tri", s);
+            if (!blob_find(b, n, nm, rt) || rt.code != 2 || rt.shape[1] != 9) { e = std::string("missing ") + nm; return false; }
+            std::snprintf(nm, sizeof nm, "mesh%d_bvh_box", s);
+            if (!blob_find(b, n, nm, rb) || rb.code != 2 || rb.shape[1] != 6) { e = std::string("missing ") + nm; return false; }
+            std::snprintf(nm, sizeof nm, "mesh%d_bvh_lr", s);
+            if (!blob_find(b, n, nm, rl) || rl.code != 1 || rl.shape[0] != rb.shape[0]) { e = std::string("missing ") + nm; return false; }
+            hm.tri[s].resize(rt.count); std::memcpy(hm.tri[s].data(), rt.data, rt.count * 4);
+            hm.bvh_box[s].resize(rb.count); std::memcpy(hm.bvh_box[s].data(), rb.data, rb.count * 4);
+            hm.bvh_lr[s].resize(rl.count); std::memcpy(hm.bvh_lr[s].data(), rl.data, rl.count * 4);
+            m.mesh_ntri[s] = (int)rt.shape[0];
+            m.mesh_nnode[s] = (int)rb.shape[0];
+            m.mesh_tri[s] = hm.tri[s].data();
+            m.mesh_bvh_box[s] = hm.bvh_box[s].data();
+            m.mesh_bvh_lr[s] = hm.bvh_lr[s].data();
+        }
         std::snprintf(nm, sizeof nm, "mesh%d_adj_off", s);
         if (!blob_find(b, n, nm, r) || r.code != 1 || (int)r.count != m.mesh_nvert[s] + 1) { e = std::string("missing ") + nm; return false; }
         hm.adj_off[s].resize(r.count);

@@ -31,20 +31,73 @@ template <typename T, typename C> KS_HD void snap_body(C snap, int b, T* R, T* p
     for (int j = 0; j < 3; j++) p[j] = snap(o + 9 + j);
 }
 
-// ray vs convex hull given as face planes n.x <= d in the geom frame; -1 = miss
-template <typename T> KS_HD T ray_hull(const T* P, int np, const T* lp, const T* lv) {
-    T tin = -Lim<T>::big, tout = Lim<T>::big;
-    bool miss = false;
-    for (int i = 0; i < np; i++) {
-        const T nx = P[4 * i], ny = P[4 * i + 1], nz = P[4 * i + 2], d = P[4 * i + 3];
-        T den = nx * lv[0] + ny * lv[1] + nz * lv[2];
-        T num = d - (nx * lp[0] + ny * lp[1] + nz * lp[2]);
-        if (kabs(den) < T(1e-15)) { if (num < 0) miss = true; continue; }
-        T tt = num / den;
-        if (den < 0) { if (tt > tin) tin = tt; } else { if (tt < tout) tout = tt; }
+// slab test of a ray (origin o, direction d, reciprocal id) against an axis-aligned box; hit iff the
+// parametric overlap [t0, t1] intersects [0, tmax]
+template <typename T> KS_HD bool ray_box(const T* o, const T* d, const T* lo, const T* hi, T tmax) {
+    T t0 = 0, t1 = tmax;
+    KS_UNROLL
+    for (int a = 0; a < 3; a++) {
+        if (kabs(d[a]) < T(1e-15)) {
+            if (o[a] < lo[a] || o[a] > hi[a]) return false;
+        } else {
+            T ta = (lo[a] - o[a]) / d[a], tb = (hi[a] - o[a]) / d[a];
+            if (ta > tb) { T w = ta; ta = tb; tb = w; }
+            t0 = ta > t0 ? ta : t0;
+            t1 = tb < t1 ? tb : t1;
+            if (t0 > t1) return false;
+        }
     }
-    if (miss || tin > tout || tout < 0) return T(-1);
-    return tin >= 0 ? tin : tout;
+    return true;
+}
+
+// Ray vs mesh geom, MuJoCo's mj_rayMesh semantics: bounding-box pre-test (geom_size about the geom origin),
+// then the faces of the ORIGINAL triangle mesh, both orientations, nearest t >= 0 (-1 = miss).  The faces
+// are visited through a bounding-volume hierarchy; the boxes are float32-rounded outwards-safe because the
+// triangles they were built from are the same float32 values.
+template <typename T>
+KS_HD T ray_mesh(const float* tri, const float* box, const int* lr, const T* size, const T* lp, const T* lv) {
+    {
+        T lo[3] = {-size[0], -size[1], -size[2]}, hi[3] = {size[0], size[1], size[2]};
+        if (!ray_box(lp, lv, lo, hi, Lim<T>::big)) return T(-1);
+    }
+    T best = T(-1);
+    int stack[32], sp = 0, node = 0;
+    for (;;) {
+        T lo[3] = {T(box[6 * node]), T(box[6 * node + 1]), T(box[6 * node + 2])};
+        T hi[3] = {T(box[6 * node + 3]), T(box[6 * node + 4]), T(box[6 * node + 5])};
+        // small outward pad: the box test must never reject a triangle the exhaustive oracle would hit
+        KS_UNROLL
+        for (int a = 0; a < 3; a++) { lo[a] -= T(1e-6); hi[a] += T(1e-6); }
+        if (ray_box(lp, lv, lo, hi, best < 0 ? Lim<T>::big : best)) {
+            const int a = lr[2 * node], b = lr[2 * node + 1];
+            if (b < 0) {
+                for (int i = a; i < a - b; i++) {
+                    const float* v = &tri[9 * i];
+                    T v0[3] = {T(v[0]), T(v[1]), T(v[2])}, e1[3] = {T(v[3]) - v0[0], T(v[4]) - v0[1], T(v[5]) - v0[2]};
+                    T e2[3] = {T(v[6]) - v0[0], T(v[7]) - v0[1], T(v[8]) - v0[2]}, pv[3], tv[3], qv[3];
+                    cross3(pv, lv, e2);
+                    T det = dot3(e1, pv);
+                    if (kabs(det) < T(1e-30)) continue;
+                    T inv = T(1) / det;
+                    sub3(tv, lp, v0);
+                    T u = dot3(tv, pv) * inv;
+                    if (u < 0 || u > 1) continue;
+                    cross3(qv, tv, e1);
+                    T w = dot3(lv, qv) * inv;
+                    if (w < 0 || u + w > 1) continue;
+                    T tt = dot3(e2, qv) * inv;
+                    if (tt >= 0 && (best < 0 || tt < best)) best = tt;
+                }
+            } else {
+                if (sp < 31) stack[sp++] = b;
+                node = a;
+                continue;
+            }
+        }
+        if (sp == 0) break;
+        node = stack[--sp];
+    }
+    return best;
 }
 
 // one rangefinder: ray from site `si` along its +z, geoms of the site's own body excluded
@@ -72,17 +125,12 @@ template <typename T, typename C> KS_HD T rangefinder(const Model<T>& m, C snap,
         mulRR(Rg, R, m.geom_R[g]);
         mulRv(t, R, m.geom_pos[g]);
         add3(pg, p, t);
-        // bounding-sphere cull (conservative: a ray that misses the sphere misses the hull)
-        T oc[3];
-        sub3(oc, pg, pnt);
-        T tc = dot3(oc, vec), d2 = dot3(oc, oc) - tc * tc, rb = m.geom_rbound[g];
-        if (d2 > rb * rb || (tc < 0 && dot3(oc, oc) > rb * rb)) continue;
         T lp[3], lv[3];
         sub3(t, pnt, pg);
         mulRtv(lp, Rg, t);
         mulRtv(lv, Rg, vec);
         const int mesh = m.geom_mesh[g];
-        T d = ray_hull(m.mesh_plane[mesh], m.mesh_nplane[mesh], lp, lv);
+        T d = ray_mesh(m.mesh_tri[mesh], m.mesh_bvh_box[mesh], m.mesh_bvh_lr[mesh], m.geom_size[g], lp, lv);
         if (d >= 0 && (best < 0 || d < best)) best = d;
     }
     return best;

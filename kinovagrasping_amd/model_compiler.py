@@ -28,7 +28,7 @@ from pathlib import Path
 import numpy as np
 
 MAGIC = b"KSMB"
-VERSION = 4
+VERSION = 5
 
 # fixed topology ------------------------------------------------------------------------------
 NQ, NV, NU = 16, 15, 9
@@ -189,6 +189,38 @@ def principal_frame(I: np.ndarray):
     return ev, R
 
 
+def build_bvh(tri: np.ndarray, leaf: int = 4):
+    """Median-split BVH over triangles [n,3,3] (float32).  Returns (tri_reordered [n,9], box [nnode,6],
+    lr [nnode,2] int32): internal node -> (left, right) child ids; leaf -> (first triangle, -count)."""
+    cen = tri.mean(1)
+    order = np.arange(len(tri))
+    boxes, lr = [], []
+
+    def rec(lo, hi):
+        idx = order[lo:hi]
+        pts = tri[idx].reshape(-1, 3)
+        node = len(boxes)
+        boxes.append(np.concatenate([pts.min(0), pts.max(0)]))
+        lr.append([0, 0])
+        if hi - lo <= leaf:
+            lr[node] = [lo, -(hi - lo)]
+            return node
+        ext = cen[idx].max(0) - cen[idx].min(0)
+        ax = int(np.argmax(ext))
+        sub = idx[np.argsort(cen[idx, ax], kind="stable")]
+        order[lo:hi] = sub
+        mid = (lo + hi) // 2
+        left = rec(lo, mid)
+        right = rec(mid, hi)
+        lr[node] = [left, right]
+        return node
+
+    import sys
+    sys.setrecursionlimit(10000)
+    rec(0, len(tri))
+    return tri[order].reshape(-1, 9).astype(np.float32), np.array(boxes, dtype=np.float32), np.array(lr, dtype=np.int32)
+
+
 class CompiledMesh:
     def __init__(self, tri: np.ndarray, name: str):
         from scipy.spatial import ConvexHull
@@ -213,6 +245,12 @@ class CompiledMesh:
         _, idx = np.unique(key, axis=0, return_index=True)
         self.planes = planes[np.sort(idx)]
         self.nsimplex = len(h2.simplices)
+        # rangefinder geometry: the ORIGINAL triangles (MuJoCo ray-casts mesh faces, not the hull) in the geom
+        # frame, reordered so that the leaves of a median-split bounding-volume hierarchy are contiguous
+        tri_g = ((tri - self.com) @ self.R).astype(np.float32)
+        area = np.linalg.norm(np.cross(tri_g[:, 1] - tri_g[:, 0], tri_g[:, 2] - tri_g[:, 0]), axis=1)
+        tri_g = tri_g[area > 0]                      # zero-area triangles cannot be hit (Vase1S has 246)
+        self.tri, self.bvh_box, self.bvh_lr = build_bvh(tri_g)
         # vertex adjacency of the (triangulated) hull in CSR form, neighbours in ascending index order:
         # lets the GPU do hill-climbing support queries instead of scanning every vertex
         nbr = [set() for _ in range(len(self.verts))]
@@ -359,10 +397,12 @@ def compile_model(xml_path: Path) -> dict:
     M["geom_mesh"] = np.array(GEOM_MESH, dtype=np.int32)
     for s, cm in enumerate(meshes):
         M[f"mesh{s}_vert"] = cm.verts
-        M[f"mesh{s}_plane"] = cm.planes
+        M[f"mesh{s}_tri"] = cm.tri
+        M[f"mesh{s}_bvh_box"] = cm.bvh_box
+        M[f"mesh{s}_bvh_lr"] = cm.bvh_lr
         M[f"mesh{s}_adj_off"] = cm.adj_off
         M[f"mesh{s}_adj"] = cm.adj
-    M["mesh_info"] = np.array([[cm.volume, len(cm.verts), len(cm.planes), cm.ntri, cm.nsimplex] for cm in meshes])
+    M["mesh_info"] = np.array([[cm.volume, len(cm.verts), len(cm.planes), cm.ntri, cm.nsimplex] for cm in meshes], dtype=np.float64)
 
     # sites -------------------------------------------------------------------------------------
     site_pos = np.zeros((NSITE, 3))
@@ -503,28 +543,28 @@ def _invweights(M):
 
 
 # ---------------------------------------------------------------------------------------------
-def write_blob(M: dict, path: Path):
+def blob_bytes(M: dict) -> bytes:
+    """dtype codes: 0 = float64, 1 = int32, 2 = float32"""
     recs = []
     for name, arr in M.items():
         arr = np.ascontiguousarray(arr)
         if arr.dtype.kind in "iu":
-            arr = arr.astype("<i4")
-            code = 1
+            arr, code = arr.astype("<i4"), 1
+        elif arr.dtype == np.float32:
+            arr, code = arr.astype("<f4"), 2
         else:
-            arr = arr.astype("<f8")
-            code = 0
+            arr, code = arr.astype("<f8"), 0
         nb = name.encode()
         assert len(nb) < 24
         shape = list(arr.shape) + [0] * (4 - arr.ndim)
         hdr = nb.ljust(24, b"\0") + struct.pack("<II4I", code, arr.size, *shape)
         data = arr.tobytes()
-        pad = (-len(data)) % 8
-        recs.append(hdr + data + b"\0" * pad)
-    with open(path, "wb") as f:
-        f.write(MAGIC + struct.pack("<II", VERSION, len(recs)))
-        f.write(b"\0" * 4)
-        for r in recs:
-            f.write(r)
+        recs.append(hdr + data + b"\0" * ((-len(data)) % 8))
+    return MAGIC + struct.pack("<II", VERSION, len(recs)) + b"\0" * 4 + b"".join(recs)
+
+
+def write_blob(M: dict, path: Path):
+    Path(path).write_bytes(blob_bytes(M))
 
 
 def read_blob(path_or_bytes) -> dict:
@@ -538,13 +578,24 @@ def read_blob(path_or_bytes) -> dict:
         name = raw[off:off + 24].rstrip(b"\0").decode()
         code, size, s0, s1, s2, s3 = struct.unpack("<II4I", raw[off + 24:off + 48])
         off += 48
-        dt = "<i4" if code == 1 else "<f8"
-        isz = 4 if code == 1 else 8
+        dt = {0: "<f8", 1: "<i4", 2: "<f4"}[code]
+        isz = 8 if code == 0 else 4
         arr = np.frombuffer(raw[off:off + size * isz], dtype=dt).copy()
         shape = [s for s in (s0, s1, s2, s3) if s > 0]
         out[name] = arr.reshape(shape) if shape else arr.reshape(())
         off += size * isz + ((-size * isz) % 8)
     return out
+
+
+HAND_RAY_KEYS = [f"mesh{s}_{k}" for s in range(3) for k in ("tri", "bvh_box", "bvh_lr")]
+
+
+def load_model_blob(shape: str, assets: Path) -> bytes:
+    """Model blob as the loaders want it: <shape>.ksm plus the rangefinder triangle / BVH tables of the three
+    hand meshes, which are identical for every object and therefore stored once in hand_raymesh.kst."""
+    M = read_blob(Path(assets) / f"{shape}.ksm")
+    M.update(read_blob(Path(assets) / "hand_raymesh.kst"))
+    return blob_bytes(M)
 
 
 def load_coords_table(path: Path) -> np.ndarray:

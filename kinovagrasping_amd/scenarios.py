@@ -5,7 +5,7 @@ from pathlib import Path
 
 import numpy as np
 
-from .model_compiler import euler_to_quat, truncated_euler
+from .model_compiler import euler_to_quat, load_model_blob, truncated_euler
 
 ASSETS = Path(__file__).resolve().parent / "assets"
 
@@ -14,6 +14,11 @@ ORIENTATION_EULER = {"normal": (-1.57, 0.0, -1.57), "rotated": (-1.2, 0.0, 0.0),
 SHAPES = [s + z for s in ["Cube", "Cylinder", "Cube45", "Cone1", "Cone2", "Vase1", "Vase2"] for z in "SB"]  # README.md:59
 
 _tables = None
+
+
+def model_blob(shape: str) -> bytes:
+    """KSMB model blob of a shape (object .ksm merged with the shared hand ray-mesh tables)."""
+    return load_model_blob(shape, ASSETS)
 
 
 def start_coord_table(shape: str, orientation: str = "normal") -> np.ndarray:

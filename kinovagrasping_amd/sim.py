@@ -82,7 +82,11 @@ class KinovaSim:
         rc = self.lib.ks_create(C.byref(cfg), self.device.index, C.byref(self.ctx))
         if rc != 0:
             raise RuntimeError(f"ks_create failed ({rc}): {self.lib.ks_last_error(None).decode()}")
-        blob = model if isinstance(model, (bytes, bytearray)) else (ASSETS / f"{model}.ksm").read_bytes()
+        if isinstance(model, (bytes, bytearray)):
+            blob = model
+        else:
+            from .model_compiler import load_model_blob
+            blob = load_model_blob(model, ASSETS)
         self._check(self.lib.ks_load_model(self.ctx, bytes(blob), len(blob)))
         N, dt, dev = self.n_envs, self.dtype, self.device
         self.obs = torch.zeros((N, NOBS) if obs_env_major else (NOBS, N), dtype=dt, device=dev)

@@ -47,8 +47,8 @@ typedef struct {
     double dof_damping[KO_NV], dof_armature[KO_NV];
     double geom_pos[KO_NGEOM][3], geom_quat[KO_NGEOM][4], geom_size[KO_NGEOM][3], geom_rbound[KO_NGEOM];
     int geom_body[KO_NGEOM], geom_mesh[KO_NGEOM];
-    int mesh_nvert[4], mesh_nplane[4];
-    double *mesh_vert[4], *mesh_plane[4];
+    int mesh_nvert[4], mesh_ntri[4];
+    double *mesh_vert[4], *mesh_tri[4]; /* hull vertices [nvert][3]; original triangles [ntri][9], geom frame */
     double site_pos[KO_NSITE][3], site_quat[KO_NSITE][4];
     int site_body[KO_NSITE];
     int npair;
@@ -91,6 +91,7 @@ typedef struct {
     int mpr_calls, mpr_support_calls;
     double newton_last_grad;
     int newton_iters_used;
+    int rays_enabled; /* 0: skip the 17 rangefinders in ko_forward (only the last substep's values are ever read) */
 } ko_sim;
 
 /* ---- model ---- */

@@ -210,7 +210,11 @@ void ko_env_step(ko_sim *s, const double *action, int naction, int frame_skip, d
     double Tfw[16], wrist[3];
     ko_env_palm_transform(s->geom_xpos[1], s->geom_xmat[1], Tfw, wrist);
     ko_env_ctrl(Tfw, action, naction, s->ctrl);
-    for (int k = 0; k < frame_skip; k++) ko_step(s);
+    /* MuJoCo evaluates the 17 rangefinders every substep; only the last substep's values are read, so the
+     * oracle skips the rest (same result, the cpu_baseline is correspondingly generous to the CPU) */
+    int keep = s->rays_enabled;
+    for (int k = 0; k < frame_skip; k++) { s->rays_enabled = keep && (k == frame_skip - 1); ko_step(s); }
+    s->rays_enabled = keep;
     ko_env_inputs in;
     ko_env_inputs_from_sim(s, &in);
     ko_env_obs_local(&in, obs);

@@ -17,7 +17,7 @@ static const unsigned char *find_rec(const unsigned char *blob, size_t n, const 
     for (uint32_t i = 0; i < nrec && off + 48 <= n; i++) {
         rec_hdr h;
         memcpy(&h, blob + off, 48);
-        size_t isz = h.code == 1 ? 4 : 8;
+        size_t isz = h.code == 0 ? 8 : 4; /* 0 = f64, 1 = i32, 2 = f32 */
         size_t bytes = (size_t)h.count * isz;
         bytes += (8 - bytes % 8) % 8;
         if (strncmp(h.name, name, 24) == 0) {
@@ -56,7 +56,7 @@ ko_model *ko_model_load(const void *vblob, size_t n) {
     if (n < 16 || memcmp(blob, "KSMB", 4) != 0) return NULL;
     uint32_t ver;
     memcpy(&ver, blob + 4, 4);
-    if (ver != 4) return NULL;
+    if (ver != 5) return NULL;
     ko_model *m = (ko_model *)calloc(1, sizeof(ko_model));
     double opt[11];
     int bad = 0;
@@ -109,12 +109,12 @@ ko_model *ko_model_load(const void *vblob, size_t n) {
         m->mesh_nvert[s] = (int)h.shape[0];
         m->mesh_vert[s] = (double *)malloc((size_t)h.count * 8);
         memcpy(m->mesh_vert[s], p, (size_t)h.count * 8);
-        snprintf(nm, sizeof nm, "mesh%d_plane", s);
+        snprintf(nm, sizeof nm, "mesh%d_tri", s);
         p = find_rec(blob, n, nm, &h);
-        if (!p) { bad = 1; break; }
-        m->mesh_nplane[s] = (int)h.shape[0];
-        m->mesh_plane[s] = (double *)malloc((size_t)h.count * 8);
-        memcpy(m->mesh_plane[s], p, (size_t)h.count * 8);
+        if (!p || h.code != 2) { bad = 1; break; }
+        m->mesh_ntri[s] = (int)h.shape[0];
+        m->mesh_tri[s] = (double *)malloc((size_t)h.count * 8);
+        for (uint32_t i = 0; i < h.count; i++) { float f; memcpy(&f, p + 4 * i, 4); m->mesh_tri[s][i] = f; }
     }
     if (bad) {
         ko_model_free(m);
@@ -127,7 +127,7 @@ void ko_model_free(ko_model *m) {
     if (!m) return;
     for (int s = 0; s < 4; s++) {
         free(m->mesh_vert[s]);
-        free(m->mesh_plane[s]);
+        free(m->mesh_tri[s]);
     }
     free(m);
 }

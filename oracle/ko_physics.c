@@ -997,23 +997,45 @@ static void solve_newton(ko_sim *s) {
 }
 
 /* ------------------------------------------------------------------ S8 sensors */
-static double ray_hull(const ko_sim *s, int g, const double *pnt, const double *vec) {
+/* Ray vs mesh geom as MuJoCo's mj_rayMesh does it: bounding-box pre-test (geom_size about the geom
+ * origin), then EVERY face of the original triangle mesh (not the convex hull), both orientations;
+ * nearest intersection with t >= 0, -1 if none. */
+static double ray_mesh(const ko_sim *s, int g, const double *pnt, const double *vec) {
     const ko_model *m = s->m;
-    int mesh = m->geom_mesh[g], np = m->mesh_nplane[mesh];
-    const double *P = m->mesh_plane[mesh];
-    double lp[3], lv[3], t[3], tin = -1e300, tout = 1e300;
+    int mesh = m->geom_mesh[g], nt = m->mesh_ntri[mesh];
+    const double *T = m->mesh_tri[mesh], *e = m->geom_size[g];
+    double lp[3], lv[3], t[3];
     sub3(t, pnt, s->geom_xpos[g]);
     mulmatTvec3(lp, s->geom_xmat[g], t);
     mulmatTvec3(lv, s->geom_xmat[g], vec);
-    for (int i = 0; i < np; i++) {
-        const double *pl = &P[4 * i];
-        double den = dot3(pl, lv), num = pl[3] - dot3(pl, lp); /* n.(p + t v) <= d */
-        if (fabs(den) < MINVAL) { if (num < 0) return -1; continue; }
-        double tt = num / den;
-        if (den < 0) { if (tt > tin) tin = tt; } else { if (tt < tout) tout = tt; }
+    double t0 = 0, t1 = 1e300; /* slab test against the box */
+    for (int a = 0; a < 3; a++) {
+        if (fabs(lv[a]) < MINVAL) { if (fabs(lp[a]) > e[a]) return -1; continue; }
+        double ta = (-e[a] - lp[a]) / lv[a], tb = (e[a] - lp[a]) / lv[a];
+        if (ta > tb) { double w = ta; ta = tb; tb = w; }
+        if (ta > t0) t0 = ta;
+        if (tb < t1) t1 = tb;
+        if (t0 > t1) return -1;
     }
-    if (tin > tout || tout < 0) return -1;
-    return tin >= 0 ? tin : tout;
+    double best = -1;
+    for (int i = 0; i < nt; i++) {
+        const double *v0 = &T[9 * i], *v1 = v0 + 3, *v2 = v0 + 6;
+        double e1[3], e2[3], pv[3], tv[3], qv[3];
+        sub3(e1, v1, v0); sub3(e2, v2, v0);
+        cross3(pv, lv, e2);
+        double det = dot3(e1, pv);
+        if (fabs(det) < 1e-30) continue;
+        double inv = 1.0 / det;
+        sub3(tv, lp, v0);
+        double u = dot3(tv, pv) * inv;
+        if (u < 0 || u > 1) continue;
+        cross3(qv, tv, e1);
+        double v = dot3(lv, qv) * inv;
+        if (v < 0 || u + v > 1) continue;
+        double tt = dot3(e2, qv) * inv;
+        if (tt >= 0 && (best < 0 || tt < best)) best = tt;
+    }
+    return best;
 }
 
 static void sensors(ko_sim *s) {
@@ -1025,6 +1047,7 @@ static void sensors(ko_sim *s) {
         s->sensordata[6 + k] = s->qpos[4 + 2 * k];
     }
     /* rangefinders (XML:265-288): ray along site +z, geoms of the site's own body excluded */
+    if (!s->rays_enabled) return;
     for (int i = 0; i < KO_NSITE; i++) {
         const double *pnt = s->site_xpos[i];
         double vec[3] = {s->site_xmat[i][2], s->site_xmat[i][5], s->site_xmat[i][8]}, best = -1;
@@ -1039,7 +1062,7 @@ static void sensors(ko_sim *s) {
                         if (fabs(x) <= m->geom_size[0][0] && fabs(y) <= m->geom_size[0][1]) d = t;
                     }
                 }
-            } else d = ray_hull(s, g, pnt, vec);
+            } else d = ray_mesh(s, g, pnt, vec);
             if (d >= 0 && (best < 0 || d < best)) best = d;
         }
         s->sensordata[9 + i] = best;
@@ -1102,6 +1125,7 @@ ko_sim *ko_sim_new(const ko_model *m, const double hand_quat[4]) {
     s->solver = 0;
     s->solver_iterations = 8;
     s->ncon_max = KO_NCON_MAX;
+    s->rays_enabled = 1;
     s->qpos[12] = 1.0;
     return s;
 }

@@ -27,7 +27,7 @@ def _sim(*a, **k):
 
 @pytest.fixture(scope="module")
 def cube(assets_dir):
-    return ko.OracleModel((assets_dir / "CubeS.ksm").read_bytes())
+    return ko.OracleModel(scenarios.model_blob("CubeS"))
 
 
 def oracle_grasp_trajectory(model, n_sub=330, x0=0.0, y0=0.0, iters=6):
@@ -249,7 +249,7 @@ def test_mixed_shape_batch_equals_per_shape_contexts(assets_dir):
         torch.cuda.synchronize()
         assert torch.equal(o1, om[sl]) and torch.equal(sim.get_state()["qpos"], qm[:, sl])
         # oracle for this shape, first env of the block
-        model = ko.OracleModel((assets_dir / f"{sh}.ksm").read_bytes())
+        model = ko.OracleModel(scenarios.model_blob(sh))
         o = ko.OracleSim(model, hq[:, 0], solver_iterations=6)
         o.env_reset(q0[:, k * per])
         for t in range(2):

@@ -11,7 +11,7 @@ from tests.native_build import Lane
 
 @pytest.fixture(scope="module")
 def blob(assets_dir):
-    return (assets_dir / "CubeS.ksm").read_bytes()
+    return scenarios.model_blob("CubeS")
 
 
 def grasp_states(blob, n_sub=330, iters=6):
@@ -88,7 +88,7 @@ def test_env_step_and_observation(blob, prec, tol):
 def test_shapes_load_and_rest(assets_dir):
     """every README shape: kernel-source lane and oracle agree on a drop-and-rest run (fp64)"""
     for shape in ("CylinderB", "Cone1S", "Vase2B", "Cube45S"):
-        blob = (assets_dir / f"{shape}.ksm").read_bytes()
+        blob = scenarios.model_blob(shape)
         m = ko.OracleModel(blob)
         hq = scenarios.hand_quat_for("normal")
         o = ko.OracleSim(m, hq, solver_iterations=6)

@@ -19,6 +19,9 @@ def main():
     OUT.mkdir(exist_ok=True)
     for shape in SHAPES:
         M = mc.compile_model(KD / f"j2s7s300_end_effector_v1_{shape}.xml")
+        hand = {k: M.pop(k) for k in mc.HAND_RAY_KEYS}          # identical for every object: stored once
+        if shape == SHAPES[0]:
+            mc.write_blob(hand, OUT / "hand_raymesh.kst")
         mc.write_blob(M, OUT / f"{shape}.ksm")
         info = M["mesh_info"]
         print(shape, "hull verts", info[:, 1].astype(int), "planes", info[:, 2].astype(int),

@@ -103,13 +103,14 @@ def main():
 
     from oracle import ko_py as ko
     from kinovagrasping_amd import model_compiler as mc
+    from kinovagrasping_amd import scenarios as scenarios_mod
 
     rng = np.random.Generator(np.random.PCG64(20260930))
     cases = []
     orient = {"normal": [-1.57, 0, -1.57], "rotated": [-1.2, 0, 0], "top": [0, 0, 0]}
     shapes = ["CubeS", "CylinderB", "Cone1S", "Vase2B"]
     for shape in shapes:
-        blob = (REPO / "kinovagrasping_amd" / "assets" / f"{shape}.ksm").read_bytes()
+        blob = scenarios_mod.model_blob(shape)
         M = mc.read_blob(blob)
         om = ko.OracleModel(blob)
         for oname, eul in orient.items():

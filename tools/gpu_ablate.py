@@ -4,14 +4,14 @@ sys.path.insert(0, '.')
 from kinovagrasping_amd import model_compiler as mc, scenarios
 from kinovagrasping_amd.sim import KinovaSim
 import tempfile, pathlib
-M = mc.read_blob('kinovagrasping_amd/assets/CubeS.ksm')
+M = mc.read_blob(scenarios.model_blob('CubeS'))
 n = 4096
 q0, hq = scenarios.config2_states(n)
 base = scenarios.config_actions(256, 30)
 acts = torch.as_tensor(np.tile(base, (1, 1, n // 256))).cuda()
 def run(npairs, iters, label, lpw=0):
     M2 = dict(M); M2['pairs'] = M['pairs'][:npairs].copy()
-    p = pathlib.Path(tempfile.mktemp(suffix='.ksm')); mc.write_blob(M2, p); blob = p.read_bytes()
+    blob = mc.blob_bytes(M2)
     sim = KinovaSim(n, blob, auto_reset=True, horizon=30, solver_iterations=iters, envs_per_wave=lpw)
     sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
     for t in range(5): sim.step(acts[t])

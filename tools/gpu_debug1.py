@@ -5,7 +5,7 @@ from oracle import ko_py as ko
 from kinovagrasping_amd import scenarios
 from kinovagrasping_amd.sim import KinovaSim
 np.set_printoptions(precision=3, linewidth=200)
-cube = ko.OracleModel(open('kinovagrasping_amd/assets/CubeS.ksm','rb').read())
+cube = ko.OracleModel(__import__('kinovagrasping_amd.scenarios', fromlist=['x']).model_blob('CubeS'))
 hq, rec = oracle_grasp_trajectory(cube)
 for prec in (64, 32):
     eq, ev, ncon, onc = run_teacher_forced(prec, cube, rec, hq)

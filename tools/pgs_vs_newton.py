@@ -9,7 +9,7 @@ sys.path.insert(0, str(ROOT))
 from oracle import ko_py as ko
 from kinovagrasping_amd import scenarios
 
-blob = (ROOT / "kinovagrasping_amd/assets/CubeS.ksm").read_bytes()
+blob = scenarios.model_blob("CubeS")
 m = ko.OracleModel(blob)
 hq = scenarios.hand_quat_for("normal")
 s = ko.OracleSim(m, hq, solver_iterations=30)
