@@ -60,19 +60,19 @@ template <typename T> __device__ __forceinline__ Hulls<T> stage_hulls(const Mode
         hu.nvert_pad[s] = m.mesh_nvert_pad[s];
         off += n;
     }
-    // adjacency (int32) behind the vertex tables; `used` stays in units of T
-    KS_LDS int* ilds = (KS_LDS int*)(lds + off);
-    int ioff = 0;
+    // adjacency (uint16 chunk tables) behind the vertex tables; `used` stays in units of T
+    KS_LDS unsigned short* ulds = (KS_LDS unsigned short*)(lds + off);
+    int uoff = 0;
     for (int s = 0; s < 4; s++) {
-        const int no = m.mesh_nvert[s] + 1, na = m.mesh_nadj[s];
-        for (int i = threadIdx.x; i < no; i += WAVE) ilds[ioff + i] = m.mesh_adj_off[s][i];
-        hu.adj_off[s] = ilds + ioff;
-        ioff += no;
-        for (int i = threadIdx.x; i < na; i += WAVE) ilds[ioff + i] = m.mesh_adj[s][i];
-        hu.adj[s] = ilds + ioff;
-        ioff += na;
+        const int no = m.mesh_nvert[s] + 1, na = m.mesh_nchunk[s] * 4;
+        for (int i = threadIdx.x; i < no; i += WAVE) ulds[uoff + i] = m.mesh_adj_off[s][i];
+        hu.adj_off[s] = ulds + uoff;
+        uoff += (no + 3) & ~3;                       // keep the chunk tables 8-byte aligned
+        for (int i = threadIdx.x; i < na; i += WAVE) ulds[uoff + i] = m.mesh_adj[s][i];
+        hu.adj[s] = ulds + uoff;
+        uoff += na;
     }
-    const int iwords = (ioff * (int)sizeof(int) + (int)sizeof(T) - 1) / (int)sizeof(T);
+    const int iwords = (uoff * (int)sizeof(unsigned short) + (int)sizeof(T) - 1) / (int)sizeof(T);
     used = off + ((iwords + 3) & ~3);
     __syncthreads();
     return hu;
@@ -284,8 +284,8 @@ template <typename T> struct Ctx : CtxBase {
     float* d_tri[4] = {nullptr, nullptr, nullptr, nullptr};
     float* d_box[4] = {nullptr, nullptr, nullptr, nullptr};
     int* d_lr[4] = {nullptr, nullptr, nullptr, nullptr};
-    int* d_adj_off[4] = {nullptr, nullptr, nullptr, nullptr};
-    int* d_adj[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned short* d_adj_off[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned short* d_adj[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> allocs;
     // HIP-event timing of k_env_step
     static constexpr int NEV = 512;
@@ -351,16 +351,16 @@ template <typename T> struct Ctx : CtxBase {
             int r;
             if ((r = alloc(&d_adj_off[s], hm.adj_off[s].size()))) return r;
             if ((r = alloc(&d_adj[s], hm.adj[s].size()))) return r;
-            HIPCHK(hipMemcpy(d_adj_off[s], hm.adj_off[s].data(), hm.adj_off[s].size() * sizeof(int), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(d_adj[s], hm.adj[s].data(), hm.adj[s].size() * sizeof(int), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_adj_off[s], hm.adj_off[s].data(), hm.adj_off[s].size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_adj[s], hm.adj[s].data(), hm.adj[s].size() * sizeof(unsigned short), hipMemcpyHostToDevice));
             hm.m.mesh_adj_off[s] = d_adj_off[s];
             hm.m.mesh_adj[s] = d_adj[s];
             hull_words += hm.m.mesh_nvert_pad[s] * 4;
-            adj_ints += hm.m.mesh_nvert[s] + 1 + hm.m.mesh_nadj[s];
+            adj_ints += ((hm.m.mesh_nvert[s] + 1 + 3) & ~3) + hm.m.mesh_nchunk[s] * 4;
         }
         HIPCHK(hipMemcpy(d_model, &hm.m, sizeof(Model<T>), hipMemcpyHostToDevice));
         {
-            const int iwords = (adj_ints * (int)sizeof(int) + (int)sizeof(T) - 1) / (int)sizeof(T);
+            const int iwords = (adj_ints * (int)sizeof(unsigned short) + (int)sizeof(T) - 1) / (int)sizeof(T);
             hull_words += (iwords + 3) & ~3;
         }
         int r = plan_launch();

@@ -18,6 +18,10 @@
 #pragma once
 #include "ks_model.h"
 
+#ifndef KS_SOLVER_FN
+#define KS_SOLVER_FN KS_FN
+#endif
+
 namespace ks {
 
 // ---------------------------------------------------------------- scratch layout (units of T)
@@ -76,8 +80,8 @@ template <typename T, typename P = T*> struct Scratch {
 template <typename T> struct Hulls {
     KS_LDS const T* vert[4];   // [nvert_pad][4]
     int nvert[4], nvert_pad[4];
-    KS_LDS const int* adj_off[4];   // CSR adjacency of the hull graph (hill-climbing support queries)
-    KS_LDS const int* adj[4];
+    KS_LDS const unsigned short* adj_off[4];   // hull graph, 4-neighbour chunks (hill-climbing support queries)
+    KS_LDS const unsigned short* adj[4];
 };
 
 template <typename T> struct LaneState {
@@ -156,7 +160,7 @@ template <typename T, typename S> KS_HD void geom_pose(const Model<T>& m, S scr,
 // ---------------------------------------------------------------- S2+S3 smooth dynamics
 // Mh: hand 9x9 (row-major full, symmetric), Mo: object 6x6.  qfrc = passive - bias + actuator.
 template <typename T>
-KS_FN void smooth_dynamics(const Model<T>& m, const Kin<T>& k, const T* qvel, const T* ctrl, T* Mh, T* Mo, T* qfrc) {
+KS_SOLVER_FN void smooth_dynamics(const Model<T>& m, const Kin<T>& k, const T* qvel, const T* ctrl, T* Mh, T* Mo, T* qfrc) {
     KS_UNROLL
     for (int i = 0; i < 81; i++) Mh[i] = 0;
     KS_UNROLL
@@ -290,8 +294,8 @@ template <typename T> struct Supp { T v[3], v1[3], v2[3]; };
 template <typename T> struct PairGeo {
     T R1[9], p1[3], R2[9], p2[3];
     KS_LDS const T* V1; KS_LDS const T* V2;
-    KS_LDS const int* off1; KS_LDS const int* adj1;
-    KS_LDS const int* off2; KS_LDS const int* adj2;
+    KS_LDS const unsigned short* off1; KS_LDS const unsigned short* adj1;
+    KS_LDS const unsigned short* off2; KS_LDS const unsigned short* adj2;
     int n1, n2;
     int hint1, hint2;          // last support vertex of each shape: start of the next hill climb
     T half_margin;
@@ -307,19 +311,26 @@ constexpr int HULL_CHUNK = 8;
 // returns (they can differ only between exactly tied vertices).  Visits O(sqrt(V)) vertices instead of
 // V (the palm hull has 754), and warm-started from the previous query usually only a handful.
 template <typename T>
-KS_HD void hull_support(const T* R, const T* p, KS_LDS const T* V, KS_LDS const int* off, KS_LDS const int* adj, int& hint, const T* dir,
-                        T hm, T* out) {
+KS_HD void hull_support(const T* R, const T* p, KS_LDS const T* V, KS_LDS const unsigned short* off, KS_LDS const unsigned short* adj, int& hint,
+                        const T* dir, T hm, T* out) {
     T ld[3];
     mulRtv(ld, R, dir);
     int cur = hint;
     T best = V[4 * cur] * ld[0] + V[4 * cur + 1] * ld[1] + V[4 * cur + 2] * ld[2];
     for (int guard = 0; guard < 4096; guard++) {
-        const int e0 = off[cur], e1 = off[cur + 1];
+        const int c0 = off[cur], c1 = off[cur + 1];
         int nxt = cur;
-        for (int e = e0; e < e1; e++) {
-            const int j = adj[e];
-            T d = V[4 * j] * ld[0] + V[4 * j + 1] * ld[1] + V[4 * j + 2] * ld[2];
-            if (d > best) { best = d; nxt = j; }
+        for (int c = c0; c < c1; c++) {
+            // four neighbour ids in one read, their vertices fetched independently, then compared in order
+            int j[4];
+            T d[4];
+            KS_UNROLL
+            for (int q = 0; q < 4; q++) j[q] = adj[4 * c + q];
+            KS_UNROLL
+            for (int q = 0; q < 4; q++) d[q] = V[4 * j[q]] * ld[0] + V[4 * j[q] + 1] * ld[1] + V[4 * j[q] + 2] * ld[2];
+            KS_UNROLL
+            for (int q = 0; q < 4; q++)
+                if (d[q] > best) { best = d[q]; nxt = j[q]; }
         }
         if (nxt == cur) break;
         cur = nxt;
@@ -774,17 +785,23 @@ KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> te
             int best = 0;
             T bd;
             {
-                KS_LDS const int* off = hu.adj_off[mesh2];
-                KS_LDS const int* adj = hu.adj[mesh2];
+                KS_LDS const unsigned short* off = hu.adj_off[mesh2];
+                KS_LDS const unsigned short* adj = hu.adj[mesh2];
                 int cur = 0;
                 bd = cdist + Vl[0] * ln[0] + Vl[1] * ln[1] + Vl[2] * ln[2];
                 for (int guard = 0; guard < 4096; guard++) {
-                    const int e0 = off[cur], e1 = off[cur + 1];
+                    const int c0 = off[cur], c1 = off[cur + 1];
                     int nxt = cur;
-                    for (int e = e0; e < e1; e++) {
-                        const int j = adj[e];
-                        T d = cdist + Vl[4 * j] * ln[0] + Vl[4 * j + 1] * ln[1] + Vl[4 * j + 2] * ln[2];
-                        if (d < bd) { bd = d; nxt = j; }
+                    for (int c = c0; c < c1; c++) {
+                        int j[4];
+                        T d[4];
+                        KS_UNROLL
+                        for (int q = 0; q < 4; q++) j[q] = adj[4 * c + q];
+                        KS_UNROLL
+                        for (int q = 0; q < 4; q++) d[q] = cdist + Vl[4 * j[q]] * ln[0] + Vl[4 * j[q] + 1] * ln[1] + Vl[4 * j[q] + 2] * ln[2];
+                        KS_UNROLL
+                        for (int q = 0; q < 4; q++)
+                            if (d[q] < bd) { bd = d[q]; nxt = j[q]; }
                     }
                     if (nxt == cur) break;
                     cur = nxt;
@@ -965,7 +982,7 @@ template <typename T> struct ScalarRows {
 };
 
 template <typename T, typename S, int SUBS>
-KS_FN void make_constraints(const Model<T>& m, const Kin<T>& k, const T* qpos, const T* qvel, S scr, Team<SUBS> team, int ncon, ScalarRows<T>& r) {
+KS_SOLVER_FN void make_constraints(const Model<T>& m, const Kin<T>& k, const T* qpos, const T* qvel, S scr, Team<SUBS> team, int ncon, ScalarRows<T>& r) {
     KS_UNROLL
     for (int t = 0; t < 3; t++) {
         const T c0 = m.tendon_coef[t][0], c1 = m.tendon_coef[t][1];
@@ -1069,7 +1086,7 @@ KS_HD T primal_cost(const Model<T>& m, const Kin<T>& k, const T* Mh, const T* Mo
 
 // Solve for qacc.  Outputs a (qacc) and qfrc_c (J^T f).
 template <typename T, typename S, int SUBS>
-KS_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T* Mo, const T* qfrc_smooth, const T* qacc_smooth,
+KS_SOLVER_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T* Mo, const T* qfrc_smooth, const T* qacc_smooth,
                         const T* warm, const ScalarRows<T>& r, S scr, Team<SUBS> team, int ncon, int iterations, T* a, T* qfrc_c) {
     {
         T cw = primal_cost(m, k, Mh, Mo, qacc_smooth, r, scr, team, ncon, warm);

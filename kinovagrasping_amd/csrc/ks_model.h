@@ -45,9 +45,11 @@ template <typename T> struct Model {
     const float* mesh_tri[4];      // [ntri][9], leaf ranges contiguous
     const float* mesh_bvh_box[4];  // [nnode][6] min xyz, max xyz
     const int* mesh_bvh_lr[4];     // [nnode][2] internal: (left, right); leaf: (first triangle, -count)
-    int mesh_nadj[4];
-    const int* mesh_adj_off[4];  // CSR vertex adjacency of the hull: [nvert+1]
-    const int* mesh_adj[4];      // [nadj] neighbour vertex ids, ascending
+    // vertex adjacency of the hull graph in chunks of 4 neighbour ids (uint16, ascending, padded with the
+    // vertex itself, which never wins a strict comparison): one 8-byte read yields four neighbours
+    int mesh_nchunk[4];
+    const unsigned short* mesh_adj_off[4];  // [nvert+1] first chunk of every vertex
+    const unsigned short* mesh_adj[4];      // [nchunk][4]
 };
 
 }  // namespace ks

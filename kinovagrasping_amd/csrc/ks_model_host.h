@@ -47,7 +47,7 @@ template <typename T> struct HostModel {
     std::vector<T> vert[4];
     std::vector<float> tri[4], bvh_box[4];
     std::vector<int> bvh_lr[4];
-    std::vector<int> adj_off[4], adj[4];
+    std::vector<unsigned short> adj_off[4], adj[4];
     std::string error;
 };
 
@@ -198,15 +198,26 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
             m.mesh_bvh_box[s] = hm.bvh_box[s].data();
             m.mesh_bvh_lr[s] = hm.bvh_lr[s].data();
         }
-        std::snprintf(nm, sizeof nm, "mesh%d_adj_off", s);
-        if (!blob_find(b, n, nm, r) || r.code != 1 || (int)r.count != m.mesh_nvert[s] + 1) { e = std::string("missing ") + nm; return false; }
-        hm.adj_off[s].resize(r.count);
-        std::memcpy(hm.adj_off[s].data(), r.data, r.count * 4);
-        std::snprintf(nm, sizeof nm, "mesh%d_adj", s);
-        if (!blob_find(b, n, nm, r) || r.code != 1 || (int)r.count != hm.adj_off[s].back()) { e = std::string("missing ") + nm; return false; }
-        hm.adj[s].resize(r.count);
-        std::memcpy(hm.adj[s].data(), r.data, r.count * 4);
-        m.mesh_nadj[s] = (int)r.count;
+        {
+            BlobRec ro, ra;
+            std::snprintf(nm, sizeof nm, "mesh%d_adj_off", s);
+            if (!blob_find(b, n, nm, ro) || ro.code != 1 || (int)ro.count != m.mesh_nvert[s] + 1) { e = std::string("missing ") + nm; return false; }
+            std::snprintf(nm, sizeof nm, "mesh%d_adj", s);
+            if (!blob_find(b, n, nm, ra) || ra.code != 1) { e = std::string("missing ") + nm; return false; }
+            std::vector<int> off(ro.count), adj(ra.count);
+            std::memcpy(off.data(), ro.data, ro.count * 4);
+            std::memcpy(adj.data(), ra.data, ra.count * 4);
+            if ((int)ra.count != off.back() || m.mesh_nvert[s] > 65535) { e = std::string("bad adjacency ") + nm; return false; }
+            hm.adj_off[s].assign(1, 0);
+            hm.adj[s].clear();
+            for (int v = 0; v < m.mesh_nvert[s]; v++) {
+                for (int k = off[v]; k < off[v + 1]; k++) hm.adj[s].push_back((unsigned short)adj[k]);
+                while (hm.adj[s].size() % 4) hm.adj[s].push_back((unsigned short)v);          // pad with self
+                hm.adj_off[s].push_back((unsigned short)(hm.adj[s].size() / 4));
+            }
+            if (hm.adj[s].size() / 4 > 65535) { e = "hull graph too large for 16-bit chunk offsets"; return false; }
+            m.mesh_nchunk[s] = (int)(hm.adj[s].size() / 4);
+        }
         m.mesh_adj_off[s] = hm.adj_off[s].data();
         m.mesh_adj[s] = hm.adj[s].data();
     }
