@@ -27,7 +27,8 @@ namespace ks {
 // ---------------------------------------------------------------- scratch layout (units of T)
 // body poses b = 2..9: 12 each (R row-major 9, p 3)
 constexpr int SCR_BP = 0;
-constexpr int SCR_CON = SCR_BP + 8 * 12;
+constexpr int SCR_AX = SCR_BP + 8 * 12;      // world slide axes, 3 x 3
+constexpr int SCR_CON = SCR_AX + 9;
 constexpr int CON_STRIDE = 20;
 // per contact: 0-2 pos, 3-5 normal, 6 dist, 7 mu, 8 bodies (b1 + 16*b2), 9 R, 10-13 aref[4],
 //              14-16 J.a basis (n,t1,t2), 17-19 J.p basis
@@ -126,6 +127,8 @@ KS_HD void forward_kinematics(const Model<T>& m, const T* qpos, const T* R7, Kin
     copy3(k.po, &qpos[9]);
     // body poses -> scratch (runtime-indexed by collision / contact code)
     if (!write_poses) return;
+    KS_UNROLL
+    for (int j = 0; j < 9; j++) scr(SCR_AX + j) = k.ax[j / 3][j % 3];
     KS_UNROLL
     for (int j = 0; j < 9; j++) scr(SCR_BP + j) = R7[j];
     KS_UNROLL
@@ -912,7 +915,7 @@ template <typename T> KS_HD T impedance(const T* solimp, T x) {
 // Basis Jacobian of a contact, B[a][j] = frame_a . (Jp_b2(pos) - Jp_b1(pos))[:,j], rebuilt from
 // the contact geometry and the body poses in scratch (nothing per-contact is stored but 9 floats).
 template <typename T, typename S>
-KS_HD void contact_basis(const Kin<T>& k, S scr, int ci, T B[3][NV], T& dist, T& mu) {
+KS_HD void contact_basis(S scr, int ci, T B[3][NV], T& dist, T& mu) {
     const int o = SCR_CON + ci * CON_STRIDE;
     T pos[3] = {scr(o), scr(o + 1), scr(o + 2)};
     T fr[3][3];
@@ -927,6 +930,7 @@ KS_HD void contact_basis(const Kin<T>& k, S scr, int ci, T B[3][NV], T& dist, T&
         KS_UNROLL
         for (int j = 0; j < NV; j++) Jd[i][j] = 0;
     }
+    // kinematic data comes from the body poses in LDS (one ds_read each), not from the caller's stack
     KS_UNROLL
     for (int side = 0; side < 2; side++) {
         const int b = side == 0 ? (bb & 15) : (bb >> 4);
@@ -935,33 +939,43 @@ KS_HD void contact_basis(const Kin<T>& k, S scr, int ci, T B[3][NV], T& dist, T&
             KS_UNROLL
             for (int s = 0; s < 3; s++) {
                 KS_UNROLL
-                for (int i = 0; i < 3; i++) Jd[i][s] += sg * k.ax[s][i];
+                for (int i = 0; i < 3; i++) Jd[i][s] += sg * scr(SCR_AX + 3 * s + i);
             }
         }
-        KS_UNROLL
-        for (int f = 0; f < 3; f++) {
-            const int bP = 3 + 2 * f, bD = 4 + 2 * f;
-            if (b == bP || b == bD) {
-                T z[3] = {k.Rp[f][2], k.Rp[f][5], k.Rp[f][8]}, r[3], c[3];
-                sub3(r, pos, k.pp[f]);
+        if (b >= 3 && b <= 8) {
+            const int f = (b - 3) >> 1;                       // finger index
+            const int oP = SCR_BP + (1 + 2 * f) * 12, oD = oP + 12;
+            T z[3] = {scr(oP + 2), scr(oP + 5), scr(oP + 8)}, r[3], c[3], pp[3] = {scr(oP + 9), scr(oP + 10), scr(oP + 11)};
+            sub3(r, pos, pp);
+            cross3(c, z, r);
+            KS_UNROLL
+            for (int ff = 0; ff < 3; ff++) {
+                if (ff == f) {
+                    KS_UNROLL
+                    for (int i = 0; i < 3; i++) Jd[i][3 + 2 * ff] += sg * c[i];
+                }
+            }
+            if ((b - 3) & 1) {
+                T pd[3] = {scr(oD + 9), scr(oD + 10), scr(oD + 11)};
+                sub3(r, pos, pd);
                 cross3(c, z, r);
                 KS_UNROLL
-                for (int i = 0; i < 3; i++) Jd[i][3 + 2 * f] += sg * c[i];
-                if (b == bD) {
-                    sub3(r, pos, k.pd[f]);
-                    cross3(c, z, r);
-                    KS_UNROLL
-                    for (int i = 0; i < 3; i++) Jd[i][4 + 2 * f] += sg * c[i];
+                for (int ff = 0; ff < 3; ff++) {
+                    if (ff == f) {
+                        KS_UNROLL
+                        for (int i = 0; i < 3; i++) Jd[i][4 + 2 * ff] += sg * c[i];
+                    }
                 }
             }
         }
         if (b == 9) {
-            T r[3];
-            sub3(r, pos, k.po);
+            const int oO = SCR_BP + 7 * 12;
+            T r[3], po[3] = {scr(oO + 9), scr(oO + 10), scr(oO + 11)};
+            sub3(r, pos, po);
             KS_UNROLL
             for (int a = 0; a < 3; a++) {
                 Jd[a][9 + a] += sg;
-                T axv[3] = {k.Ro[a], k.Ro[3 + a], k.Ro[6 + a]}, c[3];
+                T axv[3] = {scr(oO + a), scr(oO + 3 + a), scr(oO + 6 + a)}, c[3];
                 cross3(c, axv, r);
                 KS_UNROLL
                 for (int i = 0; i < 3; i++) Jd[i][12 + a] += sg * c[i];
@@ -1012,7 +1026,7 @@ KS_SOLVER_FN void make_constraints(const Model<T>& m, const Kin<T>& k, const T* 
     for (int ci = team.sub; ci < ncon; ci += SUBS) {
         const int o = SCR_CON + ci * CON_STRIDE;
         T B[3][NV], dist, mu;
-        contact_basis(k, scr, ci, B, dist, mu);
+        contact_basis<T>(scr, ci, B, dist, mu);
         T vb[3];
         KS_UNROLL
         for (int a = 0; a < 3; a++) {
@@ -1067,7 +1081,7 @@ KS_HD T primal_cost(const Model<T>& m, const Kin<T>& k, const T* Mh, const T* Mo
         T R = scr(o + 9);
         if (R < 0) continue;
         T B[3][NV], dist, mu, xb[3];
-        contact_basis(k, scr, ci, B, dist, mu);
+        contact_basis<T>(scr, ci, B, dist, mu);
         KS_UNROLL
         for (int q = 0; q < 3; q++) {
             T v = 0;
@@ -1136,7 +1150,7 @@ KS_SOLVER_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, 
             T R = scr(o + 9);
             if (R < 0) continue;
             T B[3][NV], dist, mu, xb[3];
-            contact_basis(k, scr, ci, B, dist, mu);
+            contact_basis<T>(scr, ci, B, dist, mu);
             KS_UNROLL
             for (int q = 0; q < 3; q++) {
                 T v = 0;
@@ -1199,7 +1213,7 @@ KS_SOLVER_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, 
             const int o = SCR_CON + ci * CON_STRIDE;
             if (scr(o + 9) < 0) continue;
             T B[3][NV], dist, mu;
-            contact_basis(k, scr, ci, B, dist, mu);
+            contact_basis<T>(scr, ci, B, dist, mu);
             KS_UNROLL
             for (int q = 0; q < 3; q++) {
                 T v = 0;
@@ -1282,7 +1296,7 @@ KS_SOLVER_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, 
         T R = scr(o + 9);
         if (R < 0) { scr(o + 14) = 0; scr(o + 15) = 0; scr(o + 16) = 0; continue; }
         T B[3][NV], dist, mu, xb[3];
-        contact_basis(k, scr, ci, B, dist, mu);
+        contact_basis<T>(scr, ci, B, dist, mu);
         KS_UNROLL
         for (int q = 0; q < 3; q++) {
             T v = 0;
