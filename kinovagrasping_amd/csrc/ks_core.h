@@ -33,12 +33,16 @@ constexpr int CON_STRIDE = 20;
 // per contact: 0-2 pos, 3-5 normal, 6 dist, 7 mu, 8 bodies (b1 + 16*b2), 9 R, 10-13 aref[4],
 //              14-16 J.a basis (n,t1,t2), 17-19 J.p basis
 // collision staging: every lane of an env's team detects the contacts of its share of the pairs into its
-// own list (count + NSTAGE x (pair, pos3, normal3, dist, mu, bodies)); the lists are then merged in pair
-// order.  SCR_PC: contacts per pair.
-constexpr int NSTAGE = 16, STAGE_REC = 10, STAGE_STRIDE = 1 + NSTAGE * STAGE_REC, TEAM_MAX = 4;
+// own list of NSTAGE x (pos3, normal3, dist, mu, bodies) records; the lists are then merged in pair order
+// with the per-pair counts in SCR_PC.  NSTAGE = NCON_MAX: anything a lane finds beyond its 24th contact
+// could never make it into the merged, capped list either.
+constexpr int NSTAGE = NCON_MAX, STAGE_REC = 9, STAGE_STRIDE = NSTAGE * STAGE_REC, TEAM_MAX = 4;
 constexpr int SCR_PC = SCR_CON + NCON_MAX * CON_STRIDE;
 constexpr int SCR_STAGE = SCR_PC + NPAIR_MAX;
-constexpr int SCR_TOTAL = SCR_STAGE + TEAM_MAX * STAGE_STRIDE;   // 1252 per env
+// plane-hull contact selection: vertices within the margin, flood-filled from the deepest one
+constexpr int CAND_MAX = 24;
+constexpr int SCR_CAND = SCR_STAGE + TEAM_MAX * STAGE_STRIDE;
+constexpr int SCR_TOTAL = SCR_CAND + TEAM_MAX * CAND_MAX;
 
 // A team = the SUBS lanes that work on one env (SUBS = 4 on the GPU: the lanes of a DPP quad; 1 on the
 // host).  The lanes keep identical copies of the env state and split the per-pair / per-contact loops.
@@ -744,17 +748,16 @@ template <typename T> KS_HD void make_frame(const T* n, T* t1, T* t2) {
 }
 
 template <typename T, typename S>
-KS_HD void add_contact(S scr, int stage0, int& cnt, int& status, int pair, int b1, int b2, T mu, T dist, const T* pos, const T* normal) {
+KS_HD void add_contact(S scr, int stage0, int& cnt, int& status, int b1, int b2, T mu, T dist, const T* pos, const T* normal) {
     if (cnt >= NSTAGE) { status |= ST_CONTACT_OVERFLOW; return; }
-    int o = stage0 + 1 + cnt * STAGE_REC;
+    int o = stage0 + cnt * STAGE_REC;
     T n[3] = {normal[0], normal[1], normal[2]};
     normalize3(n);
-    scr(o) = T(pair);
     KS_UNROLL
-    for (int i = 0; i < 3; i++) { scr(o + 1 + i) = pos[i]; scr(o + 4 + i) = n[i]; }
-    scr(o + 7) = dist;
-    scr(o + 8) = mu;
-    scr(o + 9) = T(b1 + 16 * b2);
+    for (int i = 0; i < 3; i++) { scr(o + i) = pos[i]; scr(o + 3 + i) = n[i]; }
+    scr(o + 6) = dist;
+    scr(o + 7) = mu;
+    scr(o + 8) = T(b1 + 16 * b2);
     cnt++;
 }
 
@@ -817,6 +820,47 @@ KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> te
             cv[0][0] = V2[4 * best]; cv[0][1] = V2[4 * best + 1]; cv[0][2] = V2[4 * best + 2];
             T thr2 = PLANE_MESH_TOL * m.geom_rbound[g2];
             thr2 *= thr2;
+            // The oracle scans every vertex in index order and keeps those within the margin that are far enough
+            // from the ones already kept.  Pass A streams over the vertices and only collects the (few) indices
+            // within the margin - independent loads, no selection logic in the hot loop; pass B runs the greedy
+            // rule on that short ascending list.  More than CAND_MAX candidates (a large flat face lying on the
+            // ground) falls back to the one-pass scan.
+            const int cand0 = SCR_CAND + team.sub * CAND_MAX;
+            int ncand = 0;
+            bool overflow = false;
+            for (int i0 = 0; i0 < hu.nvert[mesh2]; i0 += HULL_CHUNK) {
+                T dd[HULL_CHUNK];
+                KS_UNROLL
+                for (int j = 0; j < HULL_CHUNK; j++) dd[j] = cdist + Vl[4 * (i0 + j)] * ln[0] + Vl[4 * (i0 + j) + 1] * ln[1] + Vl[4 * (i0 + j) + 2] * ln[2];
+                KS_UNROLL
+                for (int j = 0; j < HULL_CHUNK; j++) {
+                    if (dd[j] <= margin && i0 + j < hu.nvert[mesh2]) {
+                        if (ncand < CAND_MAX) scr(cand0 + ncand) = T(i0 + j); else overflow = true;
+                        ncand++;
+                    }
+                }
+            }
+            if (!overflow) {
+                for (int a = 0; a < ncand; a++) {
+                    const int i = (int)scr(cand0 + a);
+                    T v[3] = {Vl[4 * i], Vl[4 * i + 1], Vl[4 * i + 2]};
+                    bool ok = nc < 4;
+                    KS_UNROLL
+                    for (int k = 0; k < 4; k++) {
+                        if (k < nc) {
+                            T dv[3];
+                            sub3(dv, v, cv[k]);
+                            if (dot3(dv, dv) <= thr2) ok = false;
+                        }
+                    }
+                    if (ok) {
+                        KS_UNROLL
+                        for (int k = 0; k < 4; k++)
+                            if (k == nc) { cv[k][0] = v[0]; cv[k][1] = v[1]; cv[k][2] = v[2]; }
+                        nc++;
+                    }
+                }
+            } else
             for (int i0 = 0; i0 < nv2p; i0 += HULL_CHUNK) {
                 T vx[HULL_CHUNK], vy[HULL_CHUNK], vz[HULL_CHUNK];
                 KS_UNROLL
@@ -851,7 +895,7 @@ KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> te
                     mulRv(w, R2, cv[k]);
                     add3(w, w, p2);
                     w[2] -= T(0.5) * d;
-                    add_contact(scr, stage0, cnt, status, pi, 0, m.geom_body[g2], mu, d, w, normal);
+                    add_contact(scr, stage0, cnt, status, 0, m.geom_body[g2], mu, d, w, normal);
                 }
             }
         } else {
@@ -876,9 +920,9 @@ KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> te
             pg.half_margin = T(0);
             T depth, dist, dir[3], pos[3];
             const int r = gjk_distance(pg, margin, &dist, dir, pos);
-            if (r == 1) add_contact(scr, stage0, cnt, status, pi, m.geom_body[g1], m.geom_body[g2], mu, dist, pos, dir);
+            if (r == 1) add_contact(scr, stage0, cnt, status, m.geom_body[g1], m.geom_body[g2], mu, dist, pos, dir);
             else if (r == 2 && mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, dir, pos))
-                add_contact(scr, stage0, cnt, status, pi, m.geom_body[g1], m.geom_body[g2], mu, -depth, pos, dir);
+                add_contact(scr, stage0, cnt, status, m.geom_body[g1], m.geom_body[g2], mu, -depth, pos, dir);
         }
         scr(SCR_PC + pi) = T(cnt - cnt_before);
     }
@@ -889,10 +933,10 @@ KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> te
         const int c = (int)scr(SCR_PC + pi);
         if (pi % SUBS == team.sub) {
             for (int q = 0; q < c; q++) {
-                const int src = stage0 + 1 + (mine + q) * STAGE_REC, dst = SCR_CON + (total + q) * CON_STRIDE;
+                const int src = stage0 + (mine + q) * STAGE_REC, dst = SCR_CON + (total + q) * CON_STRIDE;
                 if (total + q < NCON_MAX) {
                     KS_UNROLL
-                    for (int f = 0; f < 9; f++) scr(dst + f) = scr(src + 1 + f);
+                    for (int f = 0; f < 9; f++) scr(dst + f) = scr(src + f);
                 } else status |= ST_CONTACT_OVERFLOW;
             }
             mine += c;

@@ -21,5 +21,5 @@ def run(npairs, iters, label, lpw=0):
     st = sim.get_state(); ncon = st['ncon'].float().mean().item()
     print(f"{label:40s} pairs {npairs:2d} iters {iters}  k_env_step {ms:8.3f} ms  mean ncon {ncon:.2f}", flush=True)
     sim.close()
-for lpw in (16, 8, 4):
-    run(30, 6, f'all pairs epw {lpw}', lpw)
+run(30, 6, 'all pairs'); run(15, 6, 'no hand-hand'); run(8, 6, 'no hand-ground'); run(1, 6, 'object-ground only')
+run(30, 2, 'all pairs, 2 newton'); run(1, 1, 'object-ground only, 1 newton'); run(30, 3, 'all pairs 3 newton')
