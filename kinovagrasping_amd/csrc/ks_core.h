@@ -43,6 +43,11 @@ constexpr int SCR_STAGE = SCR_PC + NPAIR_MAX;
 constexpr int CAND_MAX = 24;
 constexpr int SCR_CAND = SCR_STAGE + TEAM_MAX * STAGE_STRIDE;
 constexpr int SCR_TOTAL = SCR_CAND + TEAM_MAX * CAND_MAX;
+// The staging + candidate regions are dead once the contacts are merged: the solver reuses them as a cache of
+// the contact basis Jacobians (45 values per contact) so that they are built once per substep, not 2x per
+// Newton iteration; contacts that do not fit are rebuilt on the fly.
+constexpr int SCR_BCACHE = SCR_STAGE;
+constexpr int NBCACHE = (SCR_TOTAL - SCR_STAGE) / 45;
 
 // A team = the SUBS lanes that work on one env (SUBS = 4 on the GPU: the lanes of a DPP quad; 1 on the
 // host).  The lanes keep identical copies of the env state and split the per-pair / per-contact loops.
@@ -1033,6 +1038,21 @@ KS_HD void contact_basis(S scr, int ci, T B[3][NV], T& dist, T& mu) {
     }
 }
 
+// basis of contact ci: from the LDS cache when it has a slot (filled by make_constraints), else rebuilt
+template <typename T, typename S>
+KS_HD void contact_basis_cached(S scr, int ci, T B[3][NV], T& dist, T& mu) {
+    if (ci < NBCACHE) {
+        const int o = SCR_CON + ci * CON_STRIDE, c = SCR_BCACHE + ci * 45;
+        dist = scr(o + 6);
+        mu = scr(o + 7);
+        KS_UNROLL
+        for (int a = 0; a < 3; a++) {
+            KS_UNROLL
+            for (int j = 0; j < NV; j++) B[a][j] = scr(c + a * NV + j);
+        }
+    } else contact_basis<T>(scr, ci, B, dist, mu);
+}
+
 // Scalar (non-contact) rows kept in registers: 3 tendon equalities + up to 6 joint limits
 template <typename T> struct ScalarRows {
     T eq_aref[3], eq_R[3];
@@ -1071,6 +1091,13 @@ KS_SOLVER_FN void make_constraints(const Model<T>& m, const Kin<T>& k, const T* 
         const int o = SCR_CON + ci * CON_STRIDE;
         T B[3][NV], dist, mu;
         contact_basis<T>(scr, ci, B, dist, mu);
+        if (ci < NBCACHE) {
+            KS_UNROLL
+            for (int a = 0; a < 3; a++) {
+                KS_UNROLL
+                for (int jj = 0; jj < NV; jj++) scr(SCR_BCACHE + ci * 45 + a * NV + jj) = B[a][jj];
+            }
+        }
         T vb[3];
         KS_UNROLL
         for (int a = 0; a < 3; a++) {
@@ -1125,7 +1152,7 @@ KS_HD T primal_cost(const Model<T>& m, const Kin<T>& k, const T* Mh, const T* Mo
         T R = scr(o + 9);
         if (R < 0) continue;
         T B[3][NV], dist, mu, xb[3];
-        contact_basis<T>(scr, ci, B, dist, mu);
+        contact_basis_cached<T>(scr, ci, B, dist, mu);
         KS_UNROLL
         for (int q = 0; q < 3; q++) {
             T v = 0;
@@ -1194,7 +1221,7 @@ KS_SOLVER_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, 
             T R = scr(o + 9);
             if (R < 0) continue;
             T B[3][NV], dist, mu, xb[3];
-            contact_basis<T>(scr, ci, B, dist, mu);
+            contact_basis_cached<T>(scr, ci, B, dist, mu);
             KS_UNROLL
             for (int q = 0; q < 3; q++) {
                 T v = 0;
@@ -1257,7 +1284,7 @@ KS_SOLVER_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, 
             const int o = SCR_CON + ci * CON_STRIDE;
             if (scr(o + 9) < 0) continue;
             T B[3][NV], dist, mu;
-            contact_basis<T>(scr, ci, B, dist, mu);
+            contact_basis_cached<T>(scr, ci, B, dist, mu);
             KS_UNROLL
             for (int q = 0; q < 3; q++) {
                 T v = 0;
@@ -1340,7 +1367,7 @@ KS_SOLVER_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, 
         T R = scr(o + 9);
         if (R < 0) { scr(o + 14) = 0; scr(o + 15) = 0; scr(o + 16) = 0; continue; }
         T B[3][NV], dist, mu, xb[3];
-        contact_basis<T>(scr, ci, B, dist, mu);
+        contact_basis_cached<T>(scr, ci, B, dist, mu);
         KS_UNROLL
         for (int q = 0; q < 3; q++) {
             T v = 0;
