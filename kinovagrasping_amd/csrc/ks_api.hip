@@ -54,7 +54,7 @@ template <typename T> __device__ __forceinline__ Hulls<T> stage_hulls(const Mode
     for (int s = 0; s < 4; s++) {
         const int n = m.mesh_nvert_pad[s] * 4;
         const T* src = m.mesh_vert[s];
-        for (int i = threadIdx.x; i < n; i += WAVE) lds[off + i] = src[i];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) lds[off + i] = src[i];
         hu.vert[s] = lds + off;
         hu.nvert[s] = m.mesh_nvert[s];
         hu.nvert_pad[s] = m.mesh_nvert_pad[s];
@@ -65,10 +65,10 @@ template <typename T> __device__ __forceinline__ Hulls<T> stage_hulls(const Mode
     int uoff = 0;
     for (int s = 0; s < 4; s++) {
         const int no = m.mesh_nvert[s] + 1, na = m.mesh_nchunk[s] * 4;
-        for (int i = threadIdx.x; i < no; i += WAVE) ulds[uoff + i] = m.mesh_adj_off[s][i];
+        for (int i = threadIdx.x; i < no; i += blockDim.x) ulds[uoff + i] = m.mesh_adj_off[s][i];
         hu.adj_off[s] = ulds + uoff;
         uoff += (no + 3) & ~3;                       // keep the chunk tables 8-byte aligned
-        for (int i = threadIdx.x; i < na; i += WAVE) ulds[uoff + i] = m.mesh_adj[s][i];
+        for (int i = threadIdx.x; i < na; i += blockDim.x) ulds[uoff + i] = m.mesh_adj[s][i];
         hu.adj[s] = ulds + uoff;
         uoff += na;
     }
@@ -91,19 +91,20 @@ template <typename T> __device__ __forceinline__ void store_state(const Buffers<
     for (int i = 0; i < NV; i++) { b.qvel[(long)i * N + env] = st.qvel[i]; b.warm[(long)i * N + env] = st.warm[i]; }
 }
 
-constexpr int SUBS = 4;          // lanes per env (a DPP quad)
-constexpr int EPW_MAX = WAVE / SUBS;
+constexpr int SUBS = 16;         // lanes per env (a DPP row)
+constexpr int WG = 256;          // stepping workgroup: four waves, one per SIMD of the CU, sharing the hull tables in LDS
+constexpr int EPW_MAX = WG / SUBS;
 
 template <typename T, bool USE_LDS>
-__global__ __launch_bounds__(WAVE) void k_env_step(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ action, int N,
+__global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ action, int N,
                                                    int frame_skip, int iters, int epw, int tap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KS_LDS T* lds = (KS_LDS T*)smem;
     const Model<T>& m = *mp;
     int hull_words = 0;
     const Hulls<T> hu = stage_hulls(m, lds, hull_words);
-    // epw envs per wave, SUBS lanes per env: the four lanes keep identical copies of the env state and
-    // split the per-pair (collision) and per-contact (solver) loops; per-env dynamic data is shared in LDS
+    // epw envs per workgroup, SUBS lanes per env: the lanes of a team keep identical copies of the env state and
+    // split the vertex scans / per-pair (collision) and per-contact (solver) loops; per-env dynamic data is shared in LDS
     const int e = threadIdx.x / SUBS;
     const Team<SUBS> team{(int)threadIdx.x % SUBS};
     const int env = blockIdx.x * epw + e;
@@ -115,9 +116,23 @@ __global__ __launch_bounds__(WAVE) void k_env_step(const Model<T>* __restrict__ 
     for (int i = 0; i < 4; i++) { hq[i] = b.hand_quat[(long)i * N + env]; act[i] = action[(long)i * N + env]; }
     int ncon = 0, status = 0;
     ColW<T> snap{b.snap + env, N};
+#ifdef KS_STAMP
+    float prof[24];
+    for (int k = 0; k < 24; k++) prof[k] = 0;
+    const long long tk0 = clock64();
+#else
+    float* prof = nullptr;
+#endif
     if constexpr (USE_LDS) {
-        Scratch<T, KS_LDS T*> scr{lds + hull_words + e, epw};
-        lane_env_step(m, hu, st, hq, act, scr, team, snap, frame_skip, iters, ncon, status);
+        ScratchC<T, KS_LDS T*> scr{lds + ((hull_words >> 2) << 2) + e * SCR_TOTAL};
+        lane_env_step(m, hu, st, hq, act, scr, team, snap, frame_skip, iters, ncon, status, prof);
+#ifdef KS_STAMP
+        // diagnostic build only: per-phase cycle sums of this lane go to the contact tap buffer
+        prof[6] = (float)(clock64() - tk0);
+        prof[7] = (float)ncon;
+        if (tap) for (int k = 0; k < 24; k++) b.contact[(long)(k + 24 * team.sub) * N + env] = (T)prof[k];
+        tap = 0;
+#endif
         if (team.sub == 0)
             for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
     } else {
@@ -133,7 +148,7 @@ __global__ __launch_bounds__(WAVE) void k_env_step(const Model<T>* __restrict__ 
 }
 
 template <typename T, bool USE_LDS>
-__global__ __launch_bounds__(WAVE) void k_substep(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ ctrl, int N, int iters, int epw, int tap) {
+__global__ __launch_bounds__(WG) void k_substep(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ ctrl, int N, int iters, int epw, int tap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KS_LDS T* lds = (KS_LDS T*)smem;
     const Model<T>& m = *mp;
@@ -153,7 +168,7 @@ __global__ __launch_bounds__(WAVE) void k_substep(const Model<T>* __restrict__ m
     hand_rotation(hq, R7);
     int ncon = 0, status = 0;
     if constexpr (USE_LDS) {
-        Scratch<T, KS_LDS T*> scr{lds + hull_words + e, epw};
+        ScratchC<T, KS_LDS T*> scr{lds + ((hull_words >> 2) << 2) + e * SCR_TOTAL};
         mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, c, R7, scr, team, iters, true, ncon, status);
         if (team.sub == 0)
             for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
@@ -408,7 +423,7 @@ template <typename T> struct Ctx : CtxBase {
         const int N = cfg.n_envs;
         const bool timed = ev_used < NEV;
         if (timed) HIPCHK(hipEventRecord(ev0[ev_used], s));
-        hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3((N + lpw - 1) / lpw), dim3(WAVE), step_lds, s, d_model, b, (const T*)action, N,
+        hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3((N + lpw - 1) / lpw), dim3(WG), step_lds, s, d_model, b, (const T*)action, N,
                            cfg.frame_skip, cfg.solver_iterations, lpw, cfg.contact_tap);
         if (timed) { HIPCHK(hipEventRecord(ev1[ev_used], s)); ev_used++; }
         hipLaunchKernelGGL((k_rays<T>), dim3(blocks(), NRAY), dim3(WAVE), 0, s, d_model, b, N, 0);
@@ -420,7 +435,7 @@ template <typename T> struct Ctx : CtxBase {
     }
     int substep(const void* ctrl, hipStream_t s) override {
         if (!model_loaded) { error = "ks_substep before ks_load_model"; return KS_ERR_STATE; }
-        hipLaunchKernelGGL((k_substep<T, USE_LDS>), dim3((cfg.n_envs + lpw - 1) / lpw), dim3(WAVE), step_lds, s, d_model, b, (const T*)ctrl, cfg.n_envs,
+        hipLaunchKernelGGL((k_substep<T, USE_LDS>), dim3((cfg.n_envs + lpw - 1) / lpw), dim3(WG), step_lds, s, d_model, b, (const T*)ctrl, cfg.n_envs,
                            cfg.solver_iterations, lpw, cfg.contact_tap);
         HIPCHK(hipGetLastError());
         return KS_OK;

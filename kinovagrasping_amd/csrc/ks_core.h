@@ -16,6 +16,9 @@
 //
 // The code is KS_HD so the same source is lane-checked on the CPU against the fp64 oracle.
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "ks_model.h"
 
 #ifndef KS_SOLVER_FN
@@ -27,40 +30,95 @@ namespace ks {
 // ---------------------------------------------------------------- scratch layout (units of T)
 // body poses b = 2..9: 12 each (R row-major 9, p 3)
 constexpr int SCR_BP = 0;
-constexpr int SCR_AX = SCR_BP + 8 * 12;      // world slide axes, 3 x 3
-constexpr int SCR_CON = SCR_AX + 9;
+constexpr int SCR_AX = SCR_BP + 8 * 12;      // world slide axes, 3 x 3 (+3 pad: every region starts on a 16-byte boundary)
+constexpr int SCR_CON = SCR_AX + 12;
 constexpr int CON_STRIDE = 20;
 // per contact: 0-2 pos, 3-5 normal, 6 dist, 7 mu, 8 bodies (b1 + 16*b2), 9 R, 10-13 aref[4],
 //              14-16 J.a basis (n,t1,t2), 17-19 J.p basis
-// collision staging: every lane of an env's team detects the contacts of its share of the pairs into its
-// own list of NSTAGE x (pos3, normal3, dist, mu, bodies) records; the lists are then merged in pair order
-// with the per-pair counts in SCR_PC.  NSTAGE = NCON_MAX: anything a lane finds beyond its 24th contact
-// could never make it into the merged, capped list either.
-constexpr int NSTAGE = NCON_MAX, STAGE_REC = 9, STAGE_STRIDE = NSTAGE * STAGE_REC, TEAM_MAX = 4;
+// collision staging: contacts are detected pair by pair into per-pair slots of (pos3, normal3, dist, mu,
+// bodies) records - 4 slots for a plane pair, 1 for a hull pair, assigned in pair order - and then merged
+// in pair order with the per-pair counts in SCR_PC.
+constexpr int NSTAGE = 96, STAGE_REC = 9;
 constexpr int SCR_PC = SCR_CON + NCON_MAX * CON_STRIDE;
 constexpr int SCR_STAGE = SCR_PC + NPAIR_MAX;
-// plane-hull contact selection: vertices within the margin, flood-filled from the deepest one
-constexpr int CAND_MAX = 24;
-constexpr int SCR_CAND = SCR_STAGE + TEAM_MAX * STAGE_STRIDE;
-constexpr int SCR_TOTAL = SCR_CAND + TEAM_MAX * CAND_MAX;
+// plane-hull contact selection: indices of the vertices within the margin, ascending (one list per env)
+constexpr int CAND_MAX = 96;
+constexpr int SCR_CAND = SCR_STAGE + NSTAGE * STAGE_REC;
+constexpr int SCR_TOTAL = SCR_CAND + CAND_MAX;
 // The staging + candidate regions are dead once the contacts are merged: the solver reuses them as a cache of
 // the contact basis Jacobians (45 values per contact) so that they are built once per substep, not 2x per
 // Newton iteration; contacts that do not fit are rebuilt on the fly.
 constexpr int SCR_BCACHE = SCR_STAGE;
-constexpr int NBCACHE = (SCR_TOTAL - SCR_STAGE) / 45;
+constexpr int BC_STRIDE = 48;                 // 3 x 15 values, padded to whole 16-byte vectors
+constexpr int NBCACHE = (SCR_TOTAL - SCR_STAGE) / BC_STRIDE;
+static_assert(SCR_CON % 4 == 0 && SCR_STAGE % 4 == 0 && SCR_TOTAL % 4 == 0 && CON_STRIDE % 4 == 0, "16-byte aligned scratch regions");
 
-// A team = the SUBS lanes that work on one env (SUBS = 4 on the GPU: the lanes of a DPP quad; 1 on the
-// host).  The lanes keep identical copies of the env state and split the per-pair / per-contact loops.
+// A team = the SUBS lanes that work on one env (SUBS = 16 on the GPU: one DPP row; 1 on the host).  The
+// lanes keep identical copies of the env state; they share the plane-hull vertex scans and split the
+// per-pair / per-contact loops.  Teams are aligned groups of lanes of one wave.
 template <int SUBS> struct Team {
     int sub;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // x + (x of the lane this one is paired with under the DPP control word): one v_add_f32_dpp
+    template <int CTRL> static __device__ __forceinline__ float dpp_add(float x) {
+        return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+    }
+#endif
     template <typename T> KS_HD T sum(T x) const {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (SUBS == 4) {
-            x += __shfl_xor(x, 1);
-            x += __shfl_xor(x, 2);
+        if constexpr (sizeof(T) == 4) {
+            // row_ror:8, row_ror:4 fold the four quads of the row; quad_perm [1,0,3,2], [2,3,0,1] the quad
+            if constexpr (SUBS >= 16) x = dpp_add<0x128>(x);
+            if constexpr (SUBS >= 8) x = dpp_add<0x124>(x);
+            if constexpr (SUBS >= 4) x = dpp_add<0x4E>(x);
+            if constexpr (SUBS >= 2) x = dpp_add<0xB1>(x);
+            static_assert(SUBS == 1 || SUBS == 4 || SUBS == 16, "team sizes: 1, 4 or 16 lanes");
+        } else {
+            if constexpr (SUBS >= 16) x += __shfl_xor(x, 8);
+            if constexpr (SUBS >= 8) x += __shfl_xor(x, 4);
+            if constexpr (SUBS >= 4) x += __shfl_xor(x, 2);
+            if constexpr (SUBS >= 2) x += __shfl_xor(x, 1);
         }
 #endif
         return x;
+    }
+    // x of team lane SRC (a compile-time lane: one DPP row_newbcast mov)
+    template <int SRC, typename T> KS_HD T bcast(T x) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (SUBS == 1) return x;
+        else if constexpr (sizeof(T) == 4) {
+            static_assert(SUBS == 16, "row broadcast needs a full DPP row");
+            return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + SRC, 0xf, 0xf, false));
+        } else return __shfl(x, SRC, SUBS);
+#else
+        return x;
+#endif
+    }
+    // smallest d over the team, lowest index among equal values; every lane gets the result
+    template <typename T> KS_HD void argmin(T& d, int& i) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        KS_UNROLL
+        for (int mask = SUBS / 2; mask >= 1; mask >>= 1) {
+            const T od = __shfl_xor(d, mask);
+            const int oi = __shfl_xor(i, mask);
+            if (od < d || (od == d && oi < i)) { d = od; i = oi; }
+        }
+#endif
+    }
+    // exclusive prefix sum of x over the team's lanes (lane order), team total in `total`
+    KS_HD int scan(int x, int& total) const {
+        int incl = x;
+#if defined(__HIP_DEVICE_COMPILE__)
+        KS_UNROLL
+        for (int d = 1; d < SUBS; d <<= 1) {
+            const int o = __shfl_up(incl, d, SUBS);
+            if (sub >= d) incl += o;
+        }
+        total = __shfl(incl, SUBS - 1, SUBS);
+#else
+        total = incl;
+#endif
+        return incl - x;
     }
     // LDS writes of the team members become visible to each other (one wave: program order + a fence)
     KS_HD void sync() const {
@@ -83,6 +141,21 @@ template <typename T, typename P = T*> struct Scratch {
         KS_HD const Ref& operator=(const Ref& o) const { *p = T(*o.p); return *this; }   // element copy, not proxy copy
     };
     KS_HD Ref operator()(int k) const { return Ref{base + k * stride}; }
+};
+
+// Contiguous scratch accessor: element k of this env lives at base[k] (the env's private block).  Used for the
+// LDS scratch of the stepping kernels: the 16 lanes of a team read the same addresses (LDS broadcast), adjacent
+// elements merge into ds_read_b64 / b128, and with a block size of 12 (mod 32) words the four teams of a wave
+// hit disjoint bank groups.
+template <typename T, typename P = T*> struct ScratchC {
+    P base;
+    struct Ref {
+        P p;
+        KS_HD operator T() const { return *p; }
+        KS_HD const Ref& operator=(T v) const { *p = v; return *this; }
+        KS_HD const Ref& operator=(const Ref& o) const { *p = T(*o.p); return *this; }
+    };
+    KS_HD Ref operator()(int k) const { return Ref{base + k}; }
 };
 
 // Convex-hull vertex tables as the collision code sees them: on the GPU they are staged in LDS once per
@@ -752,10 +825,18 @@ template <typename T> KS_HD void make_frame(const T* n, T* t1, T* t2) {
     cross3(t2, n, t1);
 }
 
+#if defined(KS_STAMP) && defined(__HIP_DEVICE_COMPILE__)
+#define KS_T0 long long t0_ = clock64();
+#define KS_TICK(i) { long long t1_ = clock64(); if (prof) prof[i] += (float)(t1_ - t0_); t0_ = t1_; }
+#else
+#define KS_T0
+#define KS_TICK(i)
+#endif
+
+// One staged contact record of pair slot `slot` (record index, see SCR_STAGE)
 template <typename T, typename S>
-KS_HD void add_contact(S scr, int stage0, int& cnt, int& status, int b1, int b2, T mu, T dist, const T* pos, const T* normal) {
-    if (cnt >= NSTAGE) { status |= ST_CONTACT_OVERFLOW; return; }
-    int o = stage0 + cnt * STAGE_REC;
+KS_HD void stage_contact(S scr, int slot, int b1, int b2, T mu, T dist, const T* pos, const T* normal) {
+    const int o = SCR_STAGE + slot * STAGE_REC;
     T n[3] = {normal[0], normal[1], normal[2]};
     normalize3(n);
     KS_UNROLL
@@ -763,193 +844,198 @@ KS_HD void add_contact(S scr, int stage0, int& cnt, int& status, int b1, int b2,
     scr(o + 6) = dist;
     scr(o + 7) = mu;
     scr(o + 8) = T(b1 + 16 * b2);
-    cnt++;
+}
+
+// greedy plane-hull selection rule of the oracle applied to vertex v (cv/nc: accepted so far)
+template <typename T> KS_HD void plane_pick(const T* v, T thr2, T cv[4][3], int& nc) {
+    bool ok = nc < 4;
+    KS_UNROLL
+    for (int k = 0; k < 4; k++) {
+        if (k < nc) {
+            T dv[3];
+            sub3(dv, v, cv[k]);
+            if (dot3(dv, dv) <= thr2) ok = false;
+        }
+    }
+    if (ok) {
+        KS_UNROLL
+        for (int k = 0; k < 4; k++)
+            if (k == nc) { cv[k][0] = v[0]; cv[k][1] = v[1]; cv[k][2] = v[2]; }
+        nc++;
+    }
+}
+
+// Ground plane z = 0 (normal +z) vs the hull of geom g2, worked on by the WHOLE team: deepest vertex, then up
+// to 3 more within the margin that are > 0.3*rbound from every accepted vertex (index order).  Every lane
+// scans a contiguous slice of the vertex table; the team then agrees on the deepest vertex and on the
+// ascending list of vertices within the margin, and every lane runs the (short) greedy rule on that list.
+// Returns the number of contacts staged at record `slot`.
+template <typename T, typename S, int SUBS>
+KS_HD int collide_plane_hull(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> team, int g2, T margin, T mu, int slot) {
+    const T PLANE_MESH_TOL = T(0.3);
+    T R2[9], p2[3];
+    geom_pose(m, scr, g2, R2, p2);
+    const T cdist = p2[2];
+    if (cdist > m.geom_rbound[g2] + margin) return 0;
+    const T ln[3] = {R2[6], R2[7], R2[8]};          // R2^T e_z
+    // exact cull: lowest point of the geom's bounding box (half extents geom_size about the geom origin) is
+    // above the margin -> every hull vertex is too
+    if (cdist - (kabs(ln[0]) * m.geom_size[g2][0] + kabs(ln[1]) * m.geom_size[g2][1] + kabs(ln[2]) * m.geom_size[g2][2]) > margin) return 0;
+    const int mesh2 = m.geom_mesh[g2];
+    KS_LDS const T* V = hu.vert[mesh2];
+    const int nv = hu.nvert[mesh2];
+    // slices are whole HULL_CHUNKs; rows past nv are padding (copies of vertex 0) and never counted
+    const int len = ((nv + SUBS * HULL_CHUNK - 1) / (SUBS * HULL_CHUNK)) * HULL_CHUNK;
+    const int i_lo = team.sub * len, i_hi = (i_lo + len < nv) ? i_lo + len : nv;
+    T bd = T(1e30);
+    int best = nv, mine = 0;
+    for (int i0 = i_lo; i0 < i_hi; i0 += HULL_CHUNK) {
+        T dd[HULL_CHUNK];
+        KS_UNROLL
+        for (int j = 0; j < HULL_CHUNK; j++) dd[j] = cdist + V[4 * (i0 + j)] * ln[0] + V[4 * (i0 + j) + 1] * ln[1] + V[4 * (i0 + j) + 2] * ln[2];
+        KS_UNROLL
+        for (int j = 0; j < HULL_CHUNK; j++) {
+            if (i0 + j < i_hi) {
+                if (dd[j] < bd) { bd = dd[j]; best = i0 + j; }
+                if (dd[j] <= margin) mine++;
+            }
+        }
+    }
+    team.argmin(bd, best);
+    if (bd > margin) return 0;
+    int total = 0;
+    const int first = team.scan(mine, total);
+    T cv[4][3];
+    int nc = 1;
+    cv[0][0] = V[4 * best]; cv[0][1] = V[4 * best + 1]; cv[0][2] = V[4 * best + 2];
+    T thr2 = PLANE_MESH_TOL * m.geom_rbound[g2];
+    thr2 *= thr2;
+    if (total <= CAND_MAX) {
+        int w = first;
+        for (int i0 = i_lo; i0 < i_hi && mine > 0; i0 += HULL_CHUNK) {
+            T dd[HULL_CHUNK];
+            KS_UNROLL
+            for (int j = 0; j < HULL_CHUNK; j++) dd[j] = cdist + V[4 * (i0 + j)] * ln[0] + V[4 * (i0 + j) + 1] * ln[1] + V[4 * (i0 + j) + 2] * ln[2];
+            KS_UNROLL
+            for (int j = 0; j < HULL_CHUNK; j++)
+                if (i0 + j < i_hi && dd[j] <= margin) scr(SCR_CAND + w++) = T(i0 + j);
+        }
+        team.sync();
+        for (int a = 0; a < total && nc < 4; a++) {
+            const int i = (int)scr(SCR_CAND + a);
+            const T v[3] = {V[4 * i], V[4 * i + 1], V[4 * i + 2]};
+            plane_pick(v, thr2, cv, nc);
+        }
+        team.sync();                                  // the list is reused by the next plane pair
+    } else {
+        // a large flat face lies on the ground: every lane runs the one-pass rule over the whole table
+        for (int i = 0; i < nv && nc < 4; i++) {
+            const T v[3] = {V[4 * i], V[4 * i + 1], V[4 * i + 2]};
+            if (cdist + dot3(v, ln) <= margin) plane_pick(v, thr2, cv, nc);
+        }
+    }
+    if (team.sub == 0) {
+        const T normal[3] = {0, 0, 1};
+        KS_UNROLL
+        for (int k = 0; k < 4; k++) {
+            if (k < nc) {
+                T d = cdist + dot3(cv[k], ln), w[3];
+                mulRv(w, R2, cv[k]);
+                add3(w, w, p2);
+                w[2] -= T(0.5) * d;
+                stage_contact(scr, slot + k, 0, m.geom_body[g2], mu, d, w, normal);
+            }
+        }
+    }
+    return nc;
+}
+
+// hull vs hull (one lane): bounding spheres, exact OBB test, GJK distance for the margin zone, MPR on overlap
+template <typename T, typename S>
+KS_HD int collide_hull_hull(const Model<T>& m, const Hulls<T>& hu, S scr, int g1, int g2, T margin, T mu, int slot) {
+    PairGeo<T> pg;
+    geom_pose(m, scr, g1, pg.R1, pg.p1);
+    geom_pose(m, scr, g2, pg.R2, pg.p2);
+    T t[3];
+    sub3(t, pg.p1, pg.p2);
+    const T bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin;
+    if (dot3(t, t) > bound * bound) return 0;
+#ifndef KS_NO_OBB
+    if (obb_separated(pg.R1, pg.p1, m.geom_size[g1], pg.R2, pg.p2, m.geom_size[g2], margin)) return 0;
+#endif
+    const int mesh1 = m.geom_mesh[g1], mesh2 = m.geom_mesh[g2];
+    pg.V1 = hu.vert[mesh1]; pg.n1 = hu.nvert_pad[mesh1];
+    pg.V2 = hu.vert[mesh2]; pg.n2 = hu.nvert_pad[mesh2];
+    pg.off1 = hu.adj_off[mesh1]; pg.adj1 = hu.adj[mesh1];
+    pg.off2 = hu.adj_off[mesh2]; pg.adj2 = hu.adj[mesh2];
+    pg.hint1 = 0; pg.hint2 = 0;
+    pg.half_margin = T(0);
+    T depth, dist, dir[3], pos[3];
+    const int r = gjk_distance(pg, margin, &dist, dir, pos);
+    if (r == 1) { stage_contact(scr, slot, m.geom_body[g1], m.geom_body[g2], mu, dist, pos, dir); return 1; }
+    if (r == 2 && mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, dir, pos)) {
+        stage_contact(scr, slot, m.geom_body[g1], m.geom_body[g2], mu, -depth, pos, dir);
+        return 1;
+    }
+    return 0;
 }
 
 template <typename T, typename S, int SUBS>
-KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> team, int& ncon, int& status) {
-    const T PLANE_MESH_TOL = T(0.3);
-    const int stage0 = SCR_STAGE + team.sub * STAGE_STRIDE;
-    int cnt = 0;
-    for (int pi = team.sub; pi < m.npair; pi += SUBS) {
-        const int cnt_before = cnt;
-        scr(SCR_PC + pi) = T(0);
-        const int g1 = m.pair_g1[pi], g2 = m.pair_g2[pi];
-        const T margin = m.pair_margin[pi], mu = m.pair_mu[pi];
-        T R2[9], p2[3];
-        geom_pose(m, scr, g2, R2, p2);
-        const int mesh2 = m.geom_mesh[g2];
-        KS_LDS const T* V2 = hu.vert[mesh2];
-        if (g1 == 0) {
-            // ground plane z = 0 (normal +z) vs hull: deepest vertex, then up to 3 more within the
-            // margin that are > 0.3*rbound from every accepted vertex
-            const T cdist = p2[2];
-            if (cdist > m.geom_rbound[g2] + margin) continue;
-            T ln[3] = {R2[6], R2[7], R2[8]};          // R2^T e_z
-            // exact cull: lowest point of the geom's bounding box (half extents geom_size about the
-            // geom origin) is above the margin -> every hull vertex is too
-            if (cdist - (kabs(ln[0]) * m.geom_size[g2][0] + kabs(ln[1]) * m.geom_size[g2][1] + kabs(ln[2]) * m.geom_size[g2][2]) > margin) continue;
-            KS_LDS const T* Vl = V2;
-            const int nv2p = hu.nvert_pad[mesh2];
-            // deepest vertex = support vertex along -n, found by hill climbing (ties aside, the vertex the
-            // oracle's exhaustive scan finds); the full scan below only runs for geoms that do touch
-            int best = 0;
-            T bd;
-            {
-                KS_LDS const unsigned short* off = hu.adj_off[mesh2];
-                KS_LDS const unsigned short* adj = hu.adj[mesh2];
-                int cur = 0;
-                bd = cdist + Vl[0] * ln[0] + Vl[1] * ln[1] + Vl[2] * ln[2];
-                for (int guard = 0; guard < 4096; guard++) {
-                    const int c0 = off[cur], c1 = off[cur + 1];
-                    int nxt = cur;
-                    for (int c = c0; c < c1; c++) {
-                        int j[4];
-                        T d[4];
-                        KS_UNROLL
-                        for (int q = 0; q < 4; q++) j[q] = adj[4 * c + q];
-                        KS_UNROLL
-                        for (int q = 0; q < 4; q++) d[q] = cdist + Vl[4 * j[q]] * ln[0] + Vl[4 * j[q] + 1] * ln[1] + Vl[4 * j[q] + 2] * ln[2];
-                        KS_UNROLL
-                        for (int q = 0; q < 4; q++)
-                            if (d[q] < bd) { bd = d[q]; nxt = j[q]; }
-                    }
-                    if (nxt == cur) break;
-                    cur = nxt;
-                }
-                best = cur;
-            }
-            if (bd > margin) continue;
-            T cv[4][3];
-            int nc = 1;
-            cv[0][0] = V2[4 * best]; cv[0][1] = V2[4 * best + 1]; cv[0][2] = V2[4 * best + 2];
-            T thr2 = PLANE_MESH_TOL * m.geom_rbound[g2];
-            thr2 *= thr2;
-            // The oracle scans every vertex in index order and keeps those within the margin that are far enough
-            // from the ones already kept.  Pass A streams over the vertices and only collects the (few) indices
-            // within the margin - independent loads, no selection logic in the hot loop; pass B runs the greedy
-            // rule on that short ascending list.  More than CAND_MAX candidates (a large flat face lying on the
-            // ground) falls back to the one-pass scan.
-            const int cand0 = SCR_CAND + team.sub * CAND_MAX;
-            int ncand = 0;
-            bool overflow = false;
-            for (int i0 = 0; i0 < hu.nvert[mesh2]; i0 += HULL_CHUNK) {
-                T dd[HULL_CHUNK];
-                KS_UNROLL
-                for (int j = 0; j < HULL_CHUNK; j++) dd[j] = cdist + Vl[4 * (i0 + j)] * ln[0] + Vl[4 * (i0 + j) + 1] * ln[1] + Vl[4 * (i0 + j) + 2] * ln[2];
-                KS_UNROLL
-                for (int j = 0; j < HULL_CHUNK; j++) {
-                    if (dd[j] <= margin && i0 + j < hu.nvert[mesh2]) {
-                        if (ncand < CAND_MAX) scr(cand0 + ncand) = T(i0 + j); else overflow = true;
-                        ncand++;
-                    }
-                }
-            }
-            if (!overflow) {
-                for (int a = 0; a < ncand; a++) {
-                    const int i = (int)scr(cand0 + a);
-                    T v[3] = {Vl[4 * i], Vl[4 * i + 1], Vl[4 * i + 2]};
-                    bool ok = nc < 4;
-                    KS_UNROLL
-                    for (int k = 0; k < 4; k++) {
-                        if (k < nc) {
-                            T dv[3];
-                            sub3(dv, v, cv[k]);
-                            if (dot3(dv, dv) <= thr2) ok = false;
-                        }
-                    }
-                    if (ok) {
-                        KS_UNROLL
-                        for (int k = 0; k < 4; k++)
-                            if (k == nc) { cv[k][0] = v[0]; cv[k][1] = v[1]; cv[k][2] = v[2]; }
-                        nc++;
-                    }
-                }
-            } else
-            for (int i0 = 0; i0 < nv2p; i0 += HULL_CHUNK) {
-                T vx[HULL_CHUNK], vy[HULL_CHUNK], vz[HULL_CHUNK];
-                KS_UNROLL
-                for (int j = 0; j < HULL_CHUNK; j++) { vx[j] = Vl[4 * (i0 + j)]; vy[j] = Vl[4 * (i0 + j) + 1]; vz[j] = Vl[4 * (i0 + j) + 2]; }
-                KS_UNROLL
-                for (int j = 0; j < HULL_CHUNK; j++) {
-                    T v[3] = {vx[j], vy[j], vz[j]};
-                    T d = cdist + dot3(v, ln);
-                    // padding rows duplicate vertex 0, which is either chosen already or rejected again
-                    bool ok = (d <= margin) && (nc < 4);
-                    KS_UNROLL
-                    for (int k = 0; k < 4; k++) {
-                        if (k < nc) {
-                            T dv[3];
-                            sub3(dv, v, cv[k]);
-                            if (dot3(dv, dv) <= thr2) ok = false;
-                        }
-                    }
-                    if (ok) {
-                        KS_UNROLL
-                        for (int k = 0; k < 4; k++)
-                            if (k == nc) { cv[k][0] = v[0]; cv[k][1] = v[1]; cv[k][2] = v[2]; }
-                        nc++;
-                    }
-                }
-            }
-            const T normal[3] = {0, 0, 1};
-            KS_UNROLL
-            for (int k = 0; k < 4; k++) {
-                if (k < nc) {
-                    T d = cdist + dot3(cv[k], ln), w[3];
-                    mulRv(w, R2, cv[k]);
-                    add3(w, w, p2);
-                    w[2] -= T(0.5) * d;
-                    add_contact(scr, stage0, cnt, status, 0, m.geom_body[g2], mu, d, w, normal);
-                }
-            }
-        } else {
-            PairGeo<T> pg;
-            geom_pose(m, scr, g1, pg.R1, pg.p1);
-            T t[3];
-            sub3(t, pg.p1, p2);
-            T bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin;
-            if (dot3(t, t) > bound * bound) continue;
-#ifndef KS_NO_OBB
-            if (obb_separated(pg.R1, pg.p1, m.geom_size[g1], R2, p2, m.geom_size[g2], margin)) continue;
-#endif
-            KS_UNROLL
-            for (int j = 0; j < 9; j++) pg.R2[j] = R2[j];
-            copy3(pg.p2, p2);
-            const int mesh1 = m.geom_mesh[g1];
-            pg.V1 = hu.vert[mesh1]; pg.n1 = hu.nvert_pad[mesh1];
-            pg.V2 = V2; pg.n2 = hu.nvert_pad[mesh2];
-            pg.off1 = hu.adj_off[mesh1]; pg.adj1 = hu.adj[mesh1];
-            pg.off2 = hu.adj_off[mesh2]; pg.adj2 = hu.adj[mesh2];
-            pg.hint1 = 0; pg.hint2 = 0;
-            pg.half_margin = T(0);
-            T depth, dist, dir[3], pos[3];
-            const int r = gjk_distance(pg, margin, &dist, dir, pos);
-            if (r == 1) add_contact(scr, stage0, cnt, status, m.geom_body[g1], m.geom_body[g2], mu, dist, pos, dir);
-            else if (r == 2 && mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, dir, pos))
-                add_contact(scr, stage0, cnt, status, m.geom_body[g1], m.geom_body[g2], mu, -depth, pos, dir);
+KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> team, int& ncon, int& status, float* prof = nullptr) {
+    KS_T0
+    // plane pairs: the whole team on one pair at a time (team-uniform control flow)
+    int slot = 0;
+    for (int pi = 0; pi < m.npair; pi++) {
+        const bool plane = m.pair_g1[pi] == 0;
+        const int need = plane ? 4 : 1;
+        if (plane) {
+            int c = 0;
+            if (slot + need <= NSTAGE) c = collide_plane_hull(m, hu, scr, team, m.pair_g2[pi], m.pair_margin[pi], m.pair_mu[pi], slot);
+            else status |= ST_CONTACT_OVERFLOW;
+            if (team.sub == 0) scr(SCR_PC + pi) = T(c);
         }
-        scr(SCR_PC + pi) = T(cnt - cnt_before);
+        slot += need;
     }
+    KS_TICK(8)
+    // hull pairs: dealt round-robin to the lanes of the team
+    slot = 0;
+    int hk = 0;
+    for (int pi = 0; pi < m.npair; pi++) {
+        const bool plane = m.pair_g1[pi] == 0;
+        const int need = plane ? 4 : 1;
+        if (!plane) {
+            if (hk % SUBS == team.sub) {
+                int c = 0;
+                if (slot + need <= NSTAGE) c = collide_hull_hull(m, hu, scr, m.pair_g1[pi], m.pair_g2[pi], m.pair_margin[pi], m.pair_mu[pi], slot);
+                else status |= ST_CONTACT_OVERFLOW;
+                scr(SCR_PC + pi) = T(c);
+            }
+            hk++;
+        }
+        slot += need;
+    }
+    KS_TICK(9)
     team.sync();
-    // merge the team's lists in pair order (= the oracle's contact order); contacts beyond NCON_MAX are dropped
-    int total = 0, mine = 0;
+    // merge the staged records in pair order (= the oracle's contact order); contacts beyond NCON_MAX are dropped
+    int total = 0;
+    slot = 0;
     for (int pi = 0; pi < m.npair; pi++) {
         const int c = (int)scr(SCR_PC + pi);
         if (pi % SUBS == team.sub) {
             for (int q = 0; q < c; q++) {
-                const int src = stage0 + (mine + q) * STAGE_REC, dst = SCR_CON + (total + q) * CON_STRIDE;
+                const int src = SCR_STAGE + (slot + q) * STAGE_REC, dst = SCR_CON + (total + q) * CON_STRIDE;
                 if (total + q < NCON_MAX) {
                     KS_UNROLL
                     for (int f = 0; f < 9; f++) scr(dst + f) = scr(src + f);
                 } else status |= ST_CONTACT_OVERFLOW;
             }
-            mine += c;
         }
         total += c;
+        slot += m.pair_g1[pi] == 0 ? 4 : 1;
     }
     ncon = total < NCON_MAX ? total : NCON_MAX;
     team.sync();
+    KS_TICK(10)
 }
 
 // ---------------------------------------------------------------- S5 constraint rows
@@ -1038,11 +1124,15 @@ KS_HD void contact_basis(S scr, int ci, T B[3][NV], T& dist, T& mu) {
     }
 }
 
+// out-of-line rebuild for the (rare) contacts beyond the cache: keeps the solver's code size down
+template <typename T, typename S>
+KS_FN void contact_basis_rebuild(S scr, int ci, T B[3][NV], T& dist, T& mu) { contact_basis<T>(scr, ci, B, dist, mu); }
+
 // basis of contact ci: from the LDS cache when it has a slot (filled by make_constraints), else rebuilt
 template <typename T, typename S>
 KS_HD void contact_basis_cached(S scr, int ci, T B[3][NV], T& dist, T& mu) {
     if (ci < NBCACHE) {
-        const int o = SCR_CON + ci * CON_STRIDE, c = SCR_BCACHE + ci * 45;
+        const int o = SCR_CON + ci * CON_STRIDE, c = SCR_BCACHE + ci * BC_STRIDE;
         dist = scr(o + 6);
         mu = scr(o + 7);
         KS_UNROLL
@@ -1050,7 +1140,32 @@ KS_HD void contact_basis_cached(S scr, int ci, T B[3][NV], T& dist, T& mu) {
             KS_UNROLL
             for (int j = 0; j < NV; j++) B[a][j] = scr(c + a * NV + j);
         }
-    } else contact_basis<T>(scr, ci, B, dist, mu);
+    } else {
+        // only the temporary escapes to the out-of-line call: B itself stays promotable to registers
+        T tmp[3][NV];
+        contact_basis_rebuild<T>(scr, ci, tmp, dist, mu);
+        KS_UNROLL
+        for (int a = 0; a < 3; a++) {
+            KS_UNROLL
+            for (int j = 0; j < NV; j++) B[a][j] = tmp[a][j];
+        }
+    }
+}
+
+// column i (3 values: normal, tangent1, tangent2 rows) of the basis Jacobian of contact ci
+template <typename T, typename S>
+KS_HD void contact_basis_column(S scr, int ci, int i, T b[3]) {
+    if (ci < NBCACHE) {
+        const int c = SCR_BCACHE + ci * BC_STRIDE;
+        const int ii = i < NV ? i : 0;
+        KS_UNROLL
+        for (int a = 0; a < 3; a++) b[a] = i < NV ? T(scr(c + a * NV + ii)) : T(0);
+    } else {
+        T B[3][NV], dist, mu;
+        contact_basis_rebuild<T>(scr, ci, B, dist, mu);
+        KS_UNROLL
+        for (int a = 0; a < 3; a++) b[a] = pick(B[a], i);
+    }
 }
 
 // Scalar (non-contact) rows kept in registers: 3 tendon equalities + up to 6 joint limits
@@ -1095,7 +1210,7 @@ KS_SOLVER_FN void make_constraints(const Model<T>& m, const Kin<T>& k, const T* 
             KS_UNROLL
             for (int a = 0; a < 3; a++) {
                 KS_UNROLL
-                for (int jj = 0; jj < NV; jj++) scr(SCR_BCACHE + ci * 45 + a * NV + jj) = B[a][jj];
+                for (int jj = 0; jj < NV; jj++) scr(SCR_BCACHE + ci * BC_STRIDE + a * NV + jj) = B[a][jj];
             }
         }
         T vb[3];
@@ -1125,202 +1240,338 @@ KS_SOLVER_FN void make_constraints(const Model<T>& m, const Kin<T>& k, const T* 
 }
 
 // ---------------------------------------------------------------- S6 Newton solver
-// cost of the constraint part + Gauss part at acceleration a (used for the warm-start choice)
-template <typename T, typename S, int SUBS>
-KS_HD T primal_cost(const Model<T>& m, const Kin<T>& k, const T* Mh, const T* Mo, const T* qacc_smooth, const ScalarRows<T>& r, S scr,
-                    Team<SUBS> team, int ncon, const T* a) {
-    T d[NV], Md[NV], c = 0;
-    KS_UNROLL
-    for (int i = 0; i < NV; i++) d[i] = a[i] - qacc_smooth[i];
-    mul_M(Mh, Mo, d, Md);
-    KS_UNROLL
-    for (int i = 0; i < NV; i++) c += T(0.5) * d[i] * Md[i];
-    KS_UNROLL
-    for (int t = 0; t < 3; t++) {
-        T x = m.tendon_coef[t][0] * a[3 + 2 * t] + m.tendon_coef[t][1] * a[4 + 2 * t] - r.eq_aref[t];
-        c += T(0.5) * x * x / r.eq_R[t];
-    }
-    KS_UNROLL
-    for (int j = 0; j < 6; j++) {
-        const int dof = j < 3 ? j : 3 + 2 * (j - 3);
-        T x = r.lim_sign[j] * a[dof] - r.lim_aref[j];
-        if (r.lim_sign[j] != 0 && x < 0) c += T(0.5) * x * x / r.lim_R[j];
-    }
-    T cc = 0;
-    for (int ci = team.sub; ci < ncon; ci += SUBS) {
-        const int o = SCR_CON + ci * CON_STRIDE;
-        T R = scr(o + 9);
-        if (R < 0) continue;
-        T B[3][NV], dist, mu, xb[3];
-        contact_basis_cached<T>(scr, ci, B, dist, mu);
-        KS_UNROLL
-        for (int q = 0; q < 3; q++) {
-            T v = 0;
-            KS_UNROLL
-            for (int j = 0; j < NV; j++) v += B[q][j] * a[j];
-            xb[q] = v;
-        }
-        KS_UNROLL
-        for (int kk = 0; kk < 4; kk++) {
-            T x = xb[0] + ((kk & 1) ? -mu : mu) * xb[1 + (kk >> 1)] - scr(o + 10 + kk);
-            if (x < 0) cc += T(0.5) * x * x / R;
-        }
-    }
-    return c + team.sum(cc);
-}
+// line-search step tolerance (relative): fp32 stops at 1e-5 - the piecewise-linear derivative is evaluated with
+// ~1e-6 relative noise near its root, chasing machine precision only burns iterations; the Newton exit test
+// bounds what an inexact step can cost.  fp64 keeps the oracle's setting.
+template <typename T> KS_HD constexpr T LS_RTOL() { return sizeof(T) == 4 ? T(1e-5) : T(4.8e-16); }
 
-// Solve for qacc.  Outputs a (qacc) and qfrc_c (J^T f).
+// Compile-time loop: f(std::integral_constant<int, 0>) ... f(<N-1>); the DPP broadcasts need constant lanes.
+template <typename F, int... Is> KS_HD void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F> KS_HD void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// Newton's method on the primal problem  min_a 1/2 (a-a0)^T M (a-a0) + sum_rows s(J a - aref),  ROW-DISTRIBUTED over
+// the team: row i of the 15x15 Hessian H = M + J^T D J (and entry i of the gradient, of M a, of the Cholesky
+// factor, of the search direction) lives in team lane i % SUBS, slot i / SUBS.  With SUBS = 16 every lane holds
+// ONE row (15 registers) instead of a private copy of the whole matrix; columns of the factor travel with DPP
+// row broadcasts, dot products with DPP row sums.  With SUBS = 1 (host lane check, oracle-equivalent) a lane
+// owns all rows and the same code is the serial algorithm.  Contacts are owned by lane ci % SUBS: the owner
+// evaluates the pyramid rows (J.a, active set, forces) and publishes 5 numbers per contact in LDS; every lane
+// then adds the contact's contribution to its own row from the cached basis Jacobian.
+// Vectors a, p (and the small inputs) are replicated in every lane.
+// Outputs a (qacc) and qfrc_c (J^T f), both replicated.
 template <typename T, typename S, int SUBS>
-KS_SOLVER_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, const T* Mo, const T* qfrc_smooth, const T* qacc_smooth,
-                        const T* warm, const ScalarRows<T>& r, S scr, Team<SUBS> team, int ncon, int iterations, T* a, T* qfrc_c) {
-    {
-        T cw = primal_cost(m, k, Mh, Mo, qacc_smooth, r, scr, team, ncon, warm);
-        T cs = primal_cost(m, k, Mh, Mo, qacc_smooth, r, scr, team, ncon, qacc_smooth);
-        const bool use_warm = cw < cs;
+KS_SOLVER_FN void solve_newton(const Model<T>& m, const T* Mh, const T* Mo, const T* qfrc_smooth, const T* qacc_smooth, const T* warm,
+                               const ScalarRows<T>& rows_in, S scr, Team<SUBS> team, int ncon, int iterations, T* a_out, T* qfrc_c,
+                               float* prof = nullptr) {
+    static_assert(SUBS == 1 || SUBS == 16, "row distribution: one lane or one DPP row per env");
+    constexpr int RPL = (NV + SUBS - 1) / SUBS;         // rows per lane
+    constexpr int CPL = (NCON_MAX + SUBS - 1) / SUBS;   // contacts per lane
+    KS_T0
+    const ScalarRows<T> r = rows_in;
+    T tc0[3], tc1[3], eqD[3], limD[6];
+    KS_UNROLL
+    for (int t = 0; t < 3; t++) { tc0[t] = m.tendon_coef[t][0]; tc1[t] = m.tendon_coef[t][1]; eqD[t] = T(1) / r.eq_R[t]; }
+    KS_UNROLL
+    for (int j = 0; j < 6; j++) limD[j] = T(1) / r.lim_R[j];
+    const T lead = team.sub == 0 ? T(1) : T(0);
+    // own rows of M (block diagonal: hand 9x9, object 6x6) and own entries of the smooth force
+    T Mrow[RPL][NV], qs[RPL];
+    int row[RPL];
+    KS_UNROLL
+    for (int rr = 0; rr < RPL; rr++) {
+        const int i = team.sub + rr * SUBS;
+        row[rr] = i;
+        qs[rr] = i < NV ? qfrc_smooth[i] : T(0);
         KS_UNROLL
-        for (int i = 0; i < NV; i++) a[i] = use_warm ? warm[i] : qacc_smooth[i];
-    }
-    for (int it = 0; it < iterations; it++) {
-        T H[NV * NV], g[NV], Ma[NV];
-        mul_M(Mh, Mo, a, Ma);
-        // the Gauss part and the scalar rows are accumulated on lane 0 of the team only; every lane adds the
-        // contacts it owns; the team sum below gives all lanes the complete g and H
-        const T lead = team.sub == 0 ? T(1) : T(0);
-        KS_UNROLL
-        for (int i = 0; i < NV; i++) { Ma[i] -= qfrc_smooth[i]; g[i] = lead * Ma[i]; }
-        KS_UNROLL
-        for (int i = 0; i < NV; i++) {
-            KS_UNROLL
-            for (int j = 0; j <= i; j++) H[i * NV + j] = lead * ((i < 9 && j < 9) ? Mh[i * 9 + j] : ((i >= 9 && j >= 9) ? Mo[(i - 9) * 6 + (j - 9)] : T(0)));
+        for (int j = 0; j < NV; j++) {
+            T v = 0;
+            if (j < 9) { if (i < 9) v = Mh[i * 9 + j]; }
+            else if (i >= 9 && i < NV) v = Mo[(i - 9) * 6 + (j - 9)];
+            Mrow[rr][j] = v;
         }
-        // scalar rows
-        T eq_x[3], lim_x[6];
+    }
+    T a[NV], a0[NV];
+    KS_UNROLL
+    for (int j = 0; j < NV; j++) a0[j] = qacc_smooth[j];
+
+    // cost at x (replicated): Gauss part by rows, scalar rows on the lead lane, contacts by their owners
+    auto cost = [&](const T* x) -> T {
+        T d[NV], c = 0;
+        KS_UNROLL
+        for (int j = 0; j < NV; j++) d[j] = x[j] - a0[j];
+        KS_UNROLL
+        for (int rr = 0; rr < RPL; rr++) {
+            T md = 0;
+            KS_UNROLL
+            for (int j = 0; j < NV; j++) md += Mrow[rr][j] * d[j];
+            c += T(0.5) * pick(d, row[rr]) * md;
+        }
+        T cs = 0;
         KS_UNROLL
         for (int t = 0; t < 3; t++) {
-            const T c0 = m.tendon_coef[t][0], c1 = m.tendon_coef[t][1];
-            const int ip = 3 + 2 * t, id = 4 + 2 * t;
-            T x = c0 * a[ip] + c1 * a[id] - r.eq_aref[t], D = lead / r.eq_R[t];
-            eq_x[t] = x;
-            g[ip] += c0 * D * x; g[id] += c1 * D * x;
-            H[ip * NV + ip] += D * c0 * c0; H[id * NV + ip] += D * c0 * c1; H[id * NV + id] += D * c1 * c1;
+            T xx = tc0[t] * x[3 + 2 * t] + tc1[t] * x[4 + 2 * t] - r.eq_aref[t];
+            cs += T(0.5) * xx * xx * eqD[t];
         }
         KS_UNROLL
         for (int j = 0; j < 6; j++) {
             const int dof = j < 3 ? j : 3 + 2 * (j - 3);
-            T x = r.lim_sign[j] * a[dof] - r.lim_aref[j];
-            lim_x[j] = x;
-            if (r.lim_sign[j] != 0 && x < 0) {
-                T D = lead / r.lim_R[j];
-                g[dof] += r.lim_sign[j] * D * x;
-                H[dof * NV + dof] += D;
+            T xx = r.lim_sign[j] * x[dof] - r.lim_aref[j];
+            if (r.lim_sign[j] != 0 && xx < 0) cs += T(0.5) * xx * xx * limD[j];
+        }
+        c += lead * cs;
+        KS_UNROLL
+        for (int q = 0; q < CPL; q++) {
+            const int ci = team.sub + q * SUBS;
+            if (ci < ncon) {
+                const int o = SCR_CON + ci * CON_STRIDE;
+                const T R = scr(o + 9);
+                if (R >= 0) {
+                    T B[3][NV], dist, mu, xb[3];
+                    contact_basis_cached<T>(scr, ci, B, dist, mu);
+                    KS_UNROLL
+                    for (int b = 0; b < 3; b++) {
+                        T v = 0;
+                        KS_UNROLL
+                        for (int j = 0; j < NV; j++) v += B[b][j] * x[j];
+                        xb[b] = v;
+                    }
+                    const T D = T(1) / R;
+                    KS_UNROLL
+                    for (int kk = 0; kk < 4; kk++) {
+                        T xx = xb[0] + ((kk & 1) ? -mu : mu) * xb[1 + (kk >> 1)] - scr(o + 10 + kk);
+                        if (xx < 0) c += T(0.5) * xx * xx * D;
+                    }
+                }
             }
         }
-        // contacts: gradient + Hessian, basis values J.a cached in scratch
-        for (int ci = team.sub; ci < ncon; ci += SUBS) {
-            const int o = SCR_CON + ci * CON_STRIDE;
-            T R = scr(o + 9);
-            if (R < 0) continue;
-            T B[3][NV], dist, mu, xb[3];
-            contact_basis_cached<T>(scr, ci, B, dist, mu);
-            KS_UNROLL
-            for (int q = 0; q < 3; q++) {
-                T v = 0;
-                KS_UNROLL
-                for (int j = 0; j < NV; j++) v += B[q][j] * a[j];
-                xb[q] = v;
-                scr(o + 14 + q) = v;
-            }
-            const T D = T(1) / R;
-            T act[4], y[4];
-            KS_UNROLL
-            for (int kk = 0; kk < 4; kk++) {
-                T x = xb[0] + ((kk & 1) ? -mu : mu) * xb[1 + (kk >> 1)] - scr(o + 10 + kk);
-                act[kk] = x < 0 ? T(1) : T(0);
-                y[kk] = D * x * act[kk];
-            }
-            const T gn = y[0] + y[1] + y[2] + y[3], gt1 = mu * (y[0] - y[1]), gt2 = mu * (y[2] - y[3]);
-            const T Cnn = D * (act[0] + act[1] + act[2] + act[3]);
-            const T Cn1 = D * mu * (act[0] - act[1]), Cn2 = D * mu * (act[2] - act[3]);
-            const T C11 = D * mu * mu * (act[0] + act[1]), C22 = D * mu * mu * (act[2] + act[3]);
-            if (Cnn == 0) continue;
-            T W[3][NV];
-            KS_UNROLL
-            for (int j = 0; j < NV; j++) {
-                g[j] += B[0][j] * gn + B[1][j] * gt1 + B[2][j] * gt2;
-                W[0][j] = Cnn * B[0][j] + Cn1 * B[1][j] + Cn2 * B[2][j];
-                W[1][j] = Cn1 * B[0][j] + C11 * B[1][j];
-                W[2][j] = Cn2 * B[0][j] + C22 * B[2][j];
-            }
-            KS_UNROLL
-            for (int i = 0; i < NV; i++) {
-                KS_UNROLL
-                for (int j = 0; j <= i; j++) H[i * NV + j] += B[0][i] * W[0][j] + B[1][i] * W[1][j] + B[2][i] * W[2][j];
+        return team.sum(c);
+    };
+    {
+        T w[NV];
+        KS_UNROLL
+        for (int j = 0; j < NV; j++) w[j] = warm[j];
+        const T cw = cost(w), cs = cost(a0);
+        const bool use_warm = cw < cs;
+        KS_UNROLL
+        for (int j = 0; j < NV; j++) a[j] = use_warm ? w[j] : a0[j];
+    }
+    KS_TICK(13)
+    T xb[CPL][3], pb[CPL][3];
+    for (int it = 0; it < iterations; it++) {
+#ifdef KS_STAMP
+        if (prof) prof[21] += 1.f;
+#endif
+        // --- contact owners: pyramid rows at a, published as (gn, gt1, gt2, active mask, D) in slots 14..18
+        KS_UNROLL
+        for (int q = 0; q < CPL; q++) {
+            const int ci = team.sub + q * SUBS;
+            if (ci < ncon) {
+                const int o = SCR_CON + ci * CON_STRIDE;
+                const T R = scr(o + 9);
+                T gn = 0, gt1 = 0, gt2 = 0, D = 0;
+                int mask = 0;
+                if (R >= 0) {
+                    T B[3][NV], dist, mu;
+                    contact_basis_cached<T>(scr, ci, B, dist, mu);
+                    KS_UNROLL
+                    for (int b = 0; b < 3; b++) {
+                        T v = 0;
+                        KS_UNROLL
+                        for (int j = 0; j < NV; j++) v += B[b][j] * a[j];
+                        xb[q][b] = v;
+                    }
+                    D = T(1) / R;
+                    T y[4];
+                    KS_UNROLL
+                    for (int kk = 0; kk < 4; kk++) {
+                        T xx = xb[q][0] + ((kk & 1) ? -mu : mu) * xb[q][1 + (kk >> 1)] - scr(o + 10 + kk);
+                        const bool act = xx < 0;
+                        mask |= act ? (1 << kk) : 0;
+                        y[kk] = act ? D * xx : T(0);
+                    }
+                    gn = y[0] + y[1] + y[2] + y[3]; gt1 = mu * (y[0] - y[1]); gt2 = mu * (y[2] - y[3]);
+                }
+                scr(o + 14) = gn; scr(o + 15) = gt1; scr(o + 16) = gt2; scr(o + 17) = T(mask); scr(o + 18) = D;
             }
         }
-        if constexpr (SUBS > 1) {
+        team.sync();
+        // --- own rows: gradient and Hessian
+        T H[RPL][NV], g[RPL], Ma[RPL];
+        KS_UNROLL
+        for (int rr = 0; rr < RPL; rr++) {
+            const int i = row[rr];
+            T v = 0;
             KS_UNROLL
-            for (int i = 0; i < NV; i++) {
-                g[i] = team.sum(g[i]);
-                KS_UNROLL
-                for (int j = 0; j <= i; j++) H[i * NV + j] = team.sum(H[i * NV + j]);
-            }
-        }
-        // Newton direction
-        chol_inplace<T, NV>(H);
-        T ng[NV], p[NV], Mp[NV];
-        KS_UNROLL
-        for (int i = 0; i < NV; i++) ng[i] = -g[i];
-        chol_solve<T, NV>(H, ng, p);
-        mul_M(Mh, Mo, p, Mp);
-        T pMa = 0, pMp = 0;
-        KS_UNROLL
-        for (int i = 0; i < NV; i++) { pMa += p[i] * Ma[i]; pMp += p[i] * Mp[i]; }
-        T eq_p[3], lim_p[6];
-        KS_UNROLL
-        for (int t = 0; t < 3; t++) eq_p[t] = m.tendon_coef[t][0] * p[3 + 2 * t] + m.tendon_coef[t][1] * p[4 + 2 * t];
-        KS_UNROLL
-        for (int j = 0; j < 6; j++) lim_p[j] = r.lim_sign[j] * p[j < 3 ? j : 3 + 2 * (j - 3)];
-        for (int ci = team.sub; ci < ncon; ci += SUBS) {
-            const int o = SCR_CON + ci * CON_STRIDE;
-            if (scr(o + 9) < 0) continue;
-            T B[3][NV], dist, mu;
-            contact_basis_cached<T>(scr, ci, B, dist, mu);
-            KS_UNROLL
-            for (int q = 0; q < 3; q++) {
-                T v = 0;
-                KS_UNROLL
-                for (int j = 0; j < NV; j++) v += B[q][j] * p[j];
-                scr(o + 17 + q) = v;
-            }
-        }
-        // exact line search on phi'(alpha) (piecewise linear, increasing)
-        T alpha = 0, lo = 0, hi = -1;
-        for (int ls = 0; ls < 30; ls++) {
-            T d1 = lead * (pMa + alpha * pMp), d2 = lead * pMp;
+            for (int j = 0; j < NV; j++) { v += Mrow[rr][j] * a[j]; H[rr][j] = Mrow[rr][j]; }
+            Ma[rr] = v - qs[rr];
+            g[rr] = Ma[rr];
             KS_UNROLL
             for (int t = 0; t < 3; t++) {
-                T x = eq_x[t] + alpha * eq_p[t], D = lead / r.eq_R[t];
-                d1 += D * x * eq_p[t]; d2 += D * eq_p[t] * eq_p[t];
+                const int ip = 3 + 2 * t, id = 4 + 2 * t;
+                const T xx = tc0[t] * a[ip] + tc1[t] * a[id] - r.eq_aref[t];
+                const T ci_ = (i == ip) ? tc0[t] : ((i == id) ? tc1[t] : T(0));   // J[t][i]
+                g[rr] += ci_ * eqD[t] * xx;
+                H[rr][ip] += ci_ * eqD[t] * tc0[t];
+                H[rr][id] += ci_ * eqD[t] * tc1[t];
             }
             KS_UNROLL
             for (int j = 0; j < 6; j++) {
-                T x = lim_x[j] + alpha * lim_p[j];
-                if (r.lim_sign[j] != 0 && x < 0) { T D = lead / r.lim_R[j]; d1 += D * x * lim_p[j]; d2 += D * lim_p[j] * lim_p[j]; }
+                const int dof = j < 3 ? j : 3 + 2 * (j - 3);
+                const T xx = r.lim_sign[j] * a[dof] - r.lim_aref[j];
+                if (i == dof && r.lim_sign[j] != 0 && xx < 0) {
+                    g[rr] += r.lim_sign[j] * limD[j] * xx;
+                    H[rr][dof] += limD[j];
+                }
             }
-            for (int ci = team.sub; ci < ncon; ci += SUBS) {
-                const int o = SCR_CON + ci * CON_STRIDE;
-                T R = scr(o + 9);
-                if (R < 0) continue;
-                const T D = T(1) / R, mu = scr(o + 7);
-                T xb[3], pb[3];
+        }
+        for (int ci = 0; ci < ncon; ci++) {
+            const int o = SCR_CON + ci * CON_STRIDE;
+            const int mask = (int)scr(o + 17);
+            if (mask == 0) continue;
+            const T gn = scr(o + 14), gt1 = scr(o + 15), gt2 = scr(o + 16), D = scr(o + 18);
+            T B[3][NV], dist, mu;
+            contact_basis_cached<T>(scr, ci, B, dist, mu);
+            const T a0_ = (mask & 1) ? T(1) : T(0), a1_ = (mask & 2) ? T(1) : T(0), a2_ = (mask & 4) ? T(1) : T(0), a3_ = (mask & 8) ? T(1) : T(0);
+            const T Cnn = D * (a0_ + a1_ + a2_ + a3_);
+            const T Cn1 = D * mu * (a0_ - a1_), Cn2 = D * mu * (a2_ - a3_);
+            const T C11 = D * mu * mu * (a0_ + a1_), C22 = D * mu * mu * (a2_ + a3_);
+            KS_UNROLL
+            for (int rr = 0; rr < RPL; rr++) {
+                const int i = row[rr];
+                T bc[3];
+                contact_basis_column<T>(scr, ci, i, bc);
+                const T b0 = bc[0], b1 = bc[1], b2 = bc[2];
+                g[rr] += b0 * gn + b1 * gt1 + b2 * gt2;
+                const T u0 = Cnn * b0 + Cn1 * b1 + Cn2 * b2, u1 = Cn1 * b0 + C11 * b1, u2 = Cn2 * b0 + C22 * b2;
                 KS_UNROLL
-                for (int q = 0; q < 3; q++) { xb[q] = scr(o + 14 + q); pb[q] = scr(o + 17 + q); }
+                for (int j = 0; j < NV; j++) H[rr][j] += u0 * B[0][j] + u1 * B[1][j] + u2 * B[2][j];
+            }
+        }
+        KS_TICK(14)
+        // --- Cholesky H = L L^T, right-looking, column k of L in register k of the row owners
+        T rd[RPL];
+        KS_UNROLL
+        for (int rr = 0; rr < RPL; rr++) rd[rr] = 0;
+        static_for<NV>([&](auto kc) {
+            constexpr int k = decltype(kc)::value, ko = k % SUBS, ks = k / SUBS;
+            T piv = team.template bcast<ko>(H[ks][k]);
+            piv = piv > T(1e-15) ? piv : T(1e-15);
+            const T rp = krsqrt(piv);
+            KS_UNROLL
+            for (int rr = 0; rr < RPL; rr++) {
+                H[rr][k] *= rp;
+                if (row[rr] == k) rd[rr] = rp;
+            }
+            static_for<NV - 1 - k>([&](auto jc) {
+                constexpr int j = k + 1 + decltype(jc)::value, jo = j % SUBS, js = j / SUBS;
+                const T Ljk = team.template bcast<jo>(H[js][k]);
                 KS_UNROLL
-                for (int kk = 0; kk < 4; kk++) {
-                    const T sm = (kk & 1) ? -mu : mu;
-                    T jp = pb[0] + sm * pb[1 + (kk >> 1)];
-                    T x = xb[0] + sm * xb[1 + (kk >> 1)] - scr(o + 10 + kk) + alpha * jp;
-                    if (x < 0) { d1 += D * x * jp; d2 += D * jp * jp; }
+                for (int rr = 0; rr < RPL; rr++) H[rr][j] -= H[rr][k] * Ljk;
+            });
+        });
+        KS_TICK(15)
+        // --- L y = -g (forward), L^T x = y (backward): x = Newton direction, entry i in the owner of row i
+        T bb[RPL], y[RPL], x[RPL];
+        KS_UNROLL
+        for (int rr = 0; rr < RPL; rr++) { bb[rr] = -g[rr]; y[rr] = 0; x[rr] = 0; }
+        static_for<NV>([&](auto kc) {
+            constexpr int k = decltype(kc)::value, ko = k % SUBS, ks = k / SUBS;
+            const T yk = team.template bcast<ko>(bb[ks] * rd[ks]);
+            KS_UNROLL
+            for (int rr = 0; rr < RPL; rr++) {
+                if (row[rr] == k) y[rr] = yk;
+                bb[rr] -= H[rr][k] * yk;
+            }
+        });
+        static_for<NV>([&](auto kc) {
+            constexpr int i0 = NV - 1 - decltype(kc)::value;
+            T part = 0;
+            KS_UNROLL
+            for (int rr = 0; rr < RPL; rr++) part += (row[rr] > i0 && row[rr] < NV) ? H[rr][i0] * x[rr] : T(0);
+            const T sacc = team.sum(part);
+            KS_UNROLL
+            for (int rr = 0; rr < RPL; rr++)
+                if (row[rr] == i0) x[rr] = (y[rr] - sacc) * rd[rr];
+        });
+        T p[NV];
+        static_for<NV>([&](auto kc) {
+            constexpr int k = decltype(kc)::value, ko = k % SUBS, ks = k / SUBS;
+            p[k] = team.template bcast<ko>(x[ks]);
+        });
+        KS_TICK(16)
+        // --- line search data
+        T pMa = 0, pMp = 0;
+        KS_UNROLL
+        for (int rr = 0; rr < RPL; rr++) {
+            T mp = 0;
+            KS_UNROLL
+            for (int j = 0; j < NV; j++) mp += Mrow[rr][j] * p[j];
+            pMa += x[rr] * Ma[rr];
+            pMp += x[rr] * mp;
+        }
+        pMa = team.sum(pMa);
+        pMp = team.sum(pMp);
+        T eq_x[3], eq_p[3], lim_x[6], lim_p[6];
+        KS_UNROLL
+        for (int t = 0; t < 3; t++) {
+            eq_x[t] = tc0[t] * a[3 + 2 * t] + tc1[t] * a[4 + 2 * t] - r.eq_aref[t];
+            eq_p[t] = tc0[t] * p[3 + 2 * t] + tc1[t] * p[4 + 2 * t];
+        }
+        KS_UNROLL
+        for (int j = 0; j < 6; j++) {
+            const int dof = j < 3 ? j : 3 + 2 * (j - 3);
+            lim_x[j] = r.lim_sign[j] * a[dof] - r.lim_aref[j];
+            lim_p[j] = r.lim_sign[j] * p[dof];
+        }
+        KS_UNROLL
+        for (int q = 0; q < CPL; q++) {
+            const int ci = team.sub + q * SUBS;
+            if (ci < ncon && scr(SCR_CON + ci * CON_STRIDE + 9) >= 0) {
+                T B[3][NV], dist, mu;
+                contact_basis_cached<T>(scr, ci, B, dist, mu);
+                KS_UNROLL
+                for (int b = 0; b < 3; b++) {
+                    T v = 0;
+                    KS_UNROLL
+                    for (int j = 0; j < NV; j++) v += B[b][j] * p[j];
+                    pb[q][b] = v;
+                }
+            }
+        }
+        KS_TICK(17)
+        // --- exact line search on phi'(alpha) (piecewise linear, increasing)
+        T alpha = 0, lo = 0, hi = -1;
+        for (int ls = 0; ls < 30; ls++) {
+#ifdef KS_STAMP
+            if (prof) prof[22] += 1.f;
+#endif
+            T d1 = pMa + alpha * pMp, d2 = pMp;
+            KS_UNROLL
+            for (int t = 0; t < 3; t++) {
+                T xx = eq_x[t] + alpha * eq_p[t];
+                d1 += eqD[t] * xx * eq_p[t]; d2 += eqD[t] * eq_p[t] * eq_p[t];
+            }
+            KS_UNROLL
+            for (int j = 0; j < 6; j++) {
+                T xx = lim_x[j] + alpha * lim_p[j];
+                if (r.lim_sign[j] != 0 && xx < 0) { d1 += limD[j] * xx * lim_p[j]; d2 += limD[j] * lim_p[j] * lim_p[j]; }
+            }
+            d1 *= lead; d2 *= lead;
+            KS_UNROLL
+            for (int q = 0; q < CPL; q++) {
+                const int ci = team.sub + q * SUBS;
+                if (ci < ncon) {
+                    const int o = SCR_CON + ci * CON_STRIDE;
+                    const T D = scr(o + 18), mu = scr(o + 7);
+                    if (scr(o + 9) >= 0) {
+                        KS_UNROLL
+                        for (int kk = 0; kk < 4; kk++) {
+                            const T sm = (kk & 1) ? -mu : mu;
+                            const T jp = pb[q][0] + sm * pb[q][1 + (kk >> 1)];
+                            const T xx = xb[q][0] + sm * xb[q][1 + (kk >> 1)] - scr(o + 10 + kk) + alpha * jp;
+                            if (xx < 0) { d1 += D * xx * jp; d2 += D * jp * jp; }
+                        }
+                    }
                 }
             }
             d1 = team.sum(d1);
@@ -1330,86 +1581,118 @@ KS_SOLVER_FN void solve_newton(const Model<T>& m, const Kin<T>& k, const T* Mh, 
             T next = alpha - d1 / d2;
             if (hi >= 0 && (next < lo || next > hi)) next = T(0.5) * (lo + hi);
             if (next < lo) next = lo;
-            const bool stop = kabs(next - alpha) <= T(1e-14) * (1 + kabs(alpha)) || kabs(next - alpha) <= T(4) * T(sizeof(T) == 4 ? 6e-8 : 1.2e-16) * kabs(alpha);
+            const bool stop = kabs(next - alpha) <= LS_RTOL<T>() * kabs(alpha) || kabs(next - alpha) <= T(1e-14) * (1 + kabs(alpha));
             alpha = next;
             if (stop) break;
         }
+        KS_TICK(18)
         T amax = 0, dmax = 0;
         KS_UNROLL
-        for (int i = 0; i < NV; i++) {
-            const T da = alpha * p[i];
-            a[i] += da;
-            amax = kabs(a[i]) > amax ? kabs(a[i]) : amax;
+        for (int j = 0; j < NV; j++) {
+            const T da = alpha * p[j];
+            a[j] += da;
+            amax = kabs(a[j]) > amax ? kabs(a[j]) : amax;
             dmax = kabs(da) > dmax ? kabs(da) : dmax;
         }
+        team.sync();                                   // slots 14..18 are rewritten by the next iteration
         // converged: the step just taken is below 1e-5 of the solution scale (Newton is quadratic, the
-        // next step would be far smaller); lanes that are done wait for the slowest lane of the wave
+        // next step would be far smaller); lanes that are done wait for the slowest env of the wave
         if (dmax <= T(1e-5) * (1 + amax)) break;
     }
-    // constraint forces at the final a -> qfrc_c = J^T f
+    KS_TICK(19)
+    // --- constraint forces at the final a: owners publish (fn, ft1, ft2) in slots 14..16 (also the parity tap)
     KS_UNROLL
-    for (int i = 0; i < NV; i++) qfrc_c[i] = 0;
-    const T lead = team.sub == 0 ? T(1) : T(0);
-    KS_UNROLL
-    for (int t = 0; t < 3; t++) {
-        const T c0 = m.tendon_coef[t][0], c1 = m.tendon_coef[t][1];
-        T x = c0 * a[3 + 2 * t] + c1 * a[4 + 2 * t] - r.eq_aref[t], f = -lead * x / r.eq_R[t];
-        qfrc_c[3 + 2 * t] += c0 * f; qfrc_c[4 + 2 * t] += c1 * f;
-    }
-    KS_UNROLL
-    for (int j = 0; j < 6; j++) {
-        const int dof = j < 3 ? j : 3 + 2 * (j - 3);
-        T x = r.lim_sign[j] * a[dof] - r.lim_aref[j];
-        if (r.lim_sign[j] != 0 && x < 0) qfrc_c[dof] += lead * r.lim_sign[j] * (-x / r.lim_R[j]);
-    }
-    for (int ci = team.sub; ci < ncon; ci += SUBS) {
-        const int o = SCR_CON + ci * CON_STRIDE;
-        T R = scr(o + 9);
-        if (R < 0) { scr(o + 14) = 0; scr(o + 15) = 0; scr(o + 16) = 0; continue; }
-        T B[3][NV], dist, mu, xb[3];
-        contact_basis_cached<T>(scr, ci, B, dist, mu);
-        KS_UNROLL
-        for (int q = 0; q < 3; q++) {
-            T v = 0;
-            KS_UNROLL
-            for (int j = 0; j < NV; j++) v += B[q][j] * a[j];
-            xb[q] = v;
+    for (int q = 0; q < CPL; q++) {
+        const int ci = team.sub + q * SUBS;
+        if (ci < ncon) {
+            const int o = SCR_CON + ci * CON_STRIDE;
+            const T R = scr(o + 9);
+            T fn = 0, ft1 = 0, ft2 = 0;
+            if (R >= 0) {
+                T B[3][NV], dist, mu, xf[3];
+                contact_basis_cached<T>(scr, ci, B, dist, mu);
+                KS_UNROLL
+                for (int b = 0; b < 3; b++) {
+                    T v = 0;
+                    KS_UNROLL
+                    for (int j = 0; j < NV; j++) v += B[b][j] * a[j];
+                    xf[b] = v;
+                }
+                const T D = T(1) / R;
+                T f[4];
+                KS_UNROLL
+                for (int kk = 0; kk < 4; kk++) {
+                    T xx = xf[0] + ((kk & 1) ? -mu : mu) * xf[1 + (kk >> 1)] - scr(o + 10 + kk);
+                    f[kk] = xx < 0 ? -xx * D : T(0);
+                }
+                fn = f[0] + f[1] + f[2] + f[3]; ft1 = mu * (f[0] - f[1]); ft2 = mu * (f[2] - f[3]);
+            }
+            scr(o + 14) = fn; scr(o + 15) = ft1; scr(o + 16) = ft2;
         }
-        T f[4];
-        KS_UNROLL
-        for (int kk = 0; kk < 4; kk++) {
-            T x = xb[0] + ((kk & 1) ? -mu : mu) * xb[1 + (kk >> 1)] - scr(o + 10 + kk);
-            f[kk] = x < 0 ? -x / R : T(0);
-        }
-        const T fn = f[0] + f[1] + f[2] + f[3], ft1 = mu * (f[0] - f[1]), ft2 = mu * (f[2] - f[3]);
-        // contact force in the contact frame (normal, tangent1, tangent2): parity tap
-        scr(o + 14) = fn; scr(o + 15) = ft1; scr(o + 16) = ft2;
-        KS_UNROLL
-        for (int j = 0; j < NV; j++) qfrc_c[j] += B[0][j] * fn + B[1][j] * ft1 + B[2][j] * ft2;
-    }
-    if constexpr (SUBS > 1) {
-        KS_UNROLL
-        for (int j = 0; j < NV; j++) qfrc_c[j] = team.sum(qfrc_c[j]);
     }
     team.sync();
+    // qfrc_c = J^T f by rows, then replicated
+    T qc[RPL];
+    KS_UNROLL
+    for (int rr = 0; rr < RPL; rr++) {
+        const int i = row[rr];
+        T v = 0;
+        KS_UNROLL
+        for (int t = 0; t < 3; t++) {
+            const int ip = 3 + 2 * t, id = 4 + 2 * t;
+            const T xx = tc0[t] * a[ip] + tc1[t] * a[id] - r.eq_aref[t];
+            const T ci_ = (i == ip) ? tc0[t] : ((i == id) ? tc1[t] : T(0));
+            v -= ci_ * xx * eqD[t];
+        }
+        KS_UNROLL
+        for (int j = 0; j < 6; j++) {
+            const int dof = j < 3 ? j : 3 + 2 * (j - 3);
+            const T xx = r.lim_sign[j] * a[dof] - r.lim_aref[j];
+            if (i == dof && r.lim_sign[j] != 0 && xx < 0) v -= r.lim_sign[j] * xx * limD[j];
+        }
+        qc[rr] = v;
+    }
+    for (int ci = 0; ci < ncon; ci++) {
+        const int o = SCR_CON + ci * CON_STRIDE;
+        const T fn = scr(o + 14), ft1 = scr(o + 15), ft2 = scr(o + 16);
+        if (fn == 0) continue;
+        KS_UNROLL
+        for (int rr = 0; rr < RPL; rr++) {
+            T b[3];
+            contact_basis_column<T>(scr, ci, row[rr], b);
+            qc[rr] += b[0] * fn + b[1] * ft1 + b[2] * ft2;
+        }
+    }
+    static_for<NV>([&](auto kc) {
+        constexpr int k = decltype(kc)::value, ko = k % SUBS, ks = k / SUBS;
+        qfrc_c[k] = team.template bcast<ko>(qc[ks]);
+    });
+    KS_UNROLL
+    for (int j = 0; j < NV; j++) a_out[j] = a[j];
+    team.sync();
+    KS_TICK(20)
 }
 
 // ---------------------------------------------------------------- one mj_step (forward + Euler)
 template <typename T, typename S, int SUBS>
 KS_HD void mj_forward_step(const Model<T>& m, const Hulls<T>& hu, T* qpos, T* qvel, T* warm, const T* ctrl, const T* R7, S scr, Team<SUBS> team,
-                           int solver_iterations, bool integrate, int& ncon_out, int& status) {
+                           int solver_iterations, bool integrate, int& ncon_out, int& status, float* prof = nullptr) {
     Kin<T> k;
+    KS_T0
     team.sync();                                   // the previous substep's readers of the body poses are done
     forward_kinematics(m, qpos, R7, k, scr, team.sub == 0);
     team.sync();
     T Mh[81], Mo[36], qfrc[NV];
     smooth_dynamics(m, k, qvel, ctrl, Mh, Mo, qfrc);
+    KS_TICK(0)
     int ncon = 0;
-    collision(m, hu, scr, team, ncon, status);
+    collision(m, hu, scr, team, ncon, status, prof);
+    KS_TICK(1)
     ncon_out = ncon;
     if (!integrate) return;
     ScalarRows<T> rows;
     make_constraints(m, k, qpos, qvel, scr, team, ncon, rows);
+    KS_TICK(2)
     // qacc_smooth = M^-1 qfrc
     T Lh[81], Lo[36], qacc_s[NV];
     KS_UNROLL
@@ -1421,7 +1704,9 @@ KS_HD void mj_forward_step(const Model<T>& m, const Hulls<T>& hu, T* qpos, T* qv
     chol_solve<T, 9>(Lh, qfrc, qacc_s);
     chol_solve<T, 6>(Lo, qfrc + 9, qacc_s + 9);
     T a[NV], qfrc_c[NV];
-    solve_newton(m, k, Mh, Mo, qfrc, qacc_s, warm, rows, scr, team, ncon, solver_iterations, a, qfrc_c);
+    KS_TICK(3)
+    solve_newton(m, Mh, Mo, qfrc, qacc_s, warm, rows, scr, team, ncon, solver_iterations, a, qfrc_c, prof);
+    KS_TICK(4)
     // S7 Euler with implicit joint damping: (M + h D) qacc' = qfrc_smooth + qfrc_constraint
     const T h = m.dt;
     KS_UNROLL
@@ -1458,6 +1743,7 @@ KS_HD void mj_forward_step(const Model<T>& m, const Hulls<T>& hu, T* qpos, T* qv
     }
     quatnormalize(&qpos[12]);
     if (!finite) status |= ST_NONFINITE;
+    KS_TICK(5)
 }
 
 }  // namespace ks

@@ -28,7 +28,7 @@ template <typename T, typename S, typename SnapW> KS_HD void write_snapshot(S sc
 // The snapshot is what mj_forward saw at the START of the last substep.
 template <typename T, typename S, typename SnapW, int SUBS>
 KS_HD void lane_env_step(const Model<T>& m, const Hulls<T>& hu, LaneState<T>& st, const T* hand_quat, const T* act4, S scr, Team<SUBS> team,
-                         SnapW snap_put, int frame_skip, int solver_iterations, int& ncon, int& status) {
+                         SnapW snap_put, int frame_skip, int solver_iterations, int& ncon, int& status, float* prof = nullptr) {
     T R7[9], Rpalm[9], T3[9], wrist[3], ctrl[NU];
     hand_rotation(hand_quat, R7);
     mulRR(Rpalm, R7, m.geom_R[1]);
@@ -39,7 +39,7 @@ KS_HD void lane_env_step(const Model<T>& m, const Hulls<T>& hu, LaneState<T>& st
         T jq[9];
         KS_UNROLL
         for (int j = 0; j < 9; j++) jq[j] = st.qpos[j];
-        mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, ctrl, R7, scr, team, solver_iterations, true, ncon, status);
+        mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, ctrl, R7, scr, team, solver_iterations, true, ncon, status, prof);
         if (sub == frame_skip - 1 && team.sub == 0) write_snapshot<T>(scr, jq, snap_put);
     }
 }

@@ -27,6 +27,15 @@ template <> struct Lim<double> { static constexpr double minval = 1e-300; static
 
 KS_HD float ksqrt(float x) { return sqrtf(x); }
 KS_HD double ksqrt(double x) { return sqrt(x); }
+// reciprocal square root: the hardware v_rsq_f32 (1 ulp) in fp32 device code
+KS_HD float krsqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __frsqrt_rn(x);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
+KS_HD double krsqrt(double x) { return 1.0 / sqrt(x); }
 KS_HD float kabs(float x) { return fabsf(x); }
 KS_HD double kabs(double x) { return fabs(x); }
 KS_HD float ksin(float x) { return sinf(x); }
@@ -124,6 +133,14 @@ template <typename T, int N> KS_HD void chol_inplace(T* A) {
         }
     }
 }
+// element i (runtime) of a register array: a select chain, never a dynamically indexed (scratch) array
+template <typename T, int N> KS_HD T pick(const T (&v)[N], int i) {
+    T out = 0;
+    KS_UNROLL
+    for (int j = 0; j < N; j++) out = (j == i) ? v[j] : out;
+    return out;
+}
+
 // x = (L L^T)^-1 b, L from chol_inplace (lower triangle of A)
 template <typename T, int N> KS_HD void chol_solve(const T* L, const T* b, T* x) {
     T y[N];

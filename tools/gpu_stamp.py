@@ -1,0 +1,26 @@
+"""Dev tool (diagnostic build -DKS_STAMP): per-phase cycle shares of k_env_step."""
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+from kinovagrasping_amd import scenarios
+from kinovagrasping_amd.sim import KinovaSim
+n = 4096
+q0, hq = scenarios.config2_states(n)
+base = scenarios.config_actions(256, 30)
+acts = torch.as_tensor(np.tile(base, (1, 1, n // 256))).cuda()
+sim = KinovaSim(n, "CubeS", auto_reset=True, horizon=30, contact_tap=True)
+sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+names = ["fk+dyn", "collision", "constraints", "chol M", "newton", "euler", "total", "ncon", "c:plane pairs", "c:hull pairs", "c:merge", "-", "-", "n:warm cost", "n:H assembly", "n:team reduce", "n:chol+solve", "n:p proj", "n:linesearch", "n:update", "n:forces", "#newton iters", "#ls iters", "-"]
+acc = np.zeros((24,))
+accmax = np.zeros((24,))
+for t in range(30):
+    sim.step(acts[t])
+    st = sim.get_state(contacts=True)
+    torch.cuda.synchronize()
+    prof = st["contact"].reshape(-1, n)[:384].cpu().numpy().reshape(16, 24, n)   # [sub][phase][env]
+    # a wave's time is set by its slowest lane: take the max over the 4 envs x 16 lanes of every wave
+    w = prof.transpose(1, 0, 2).reshape(24, 16, n // 4, 4)
+    acc += prof.mean(axis=(0, 2))
+    accmax += w.max(axis=(1, 3)).mean(axis=1)
+print("phase            mean-lane cycles   wave-max cycles (avg over waves)   share of wave-max total")
+for i, nm in enumerate(names):
+    print(f"{nm:14s} {acc[i]/30:14.0f} {accmax[i]/30:18.0f} {accmax[i]/accmax[6]*100 if i != 6 and i != 7 else 0:10.1f}%")
