@@ -48,6 +48,17 @@ template <typename T> struct ColW {
 // tables are then read with wave-uniform ds_read broadcasts.
 template <typename T> struct LdsScratch { using type = Scratch<T, KS_LDS T*>; };
 
+// The model constants (about 3 KB) are copied to the head of LDS as well: the physics stages are out-of-line
+// device functions that reach the model through a generic reference, and a flat load that resolves to LDS costs
+// a fraction of one that goes to L2.  Returns the words (of T) used; visibility comes with stage_hulls' barrier.
+template <typename T> constexpr int model_words() { return (int)((sizeof(Model<T>) + 15) / 16 * 16 / sizeof(T)); }
+template <typename T> __device__ __forceinline__ const Model<T>* stage_model(const Model<T>* __restrict__ mp, KS_LDS T* lds) {
+    const unsigned* src = (const unsigned*)mp;
+    KS_LDS unsigned* dst = (KS_LDS unsigned*)lds;
+    for (int i = threadIdx.x; i < (int)(sizeof(Model<T>) / 4); i += blockDim.x) dst[i] = src[i];
+    return (const Model<T>*)lds;
+}
+
 template <typename T> __device__ __forceinline__ Hulls<T> stage_hulls(const Model<T>& m, KS_LDS T* lds, int& used) {
     Hulls<T> hu;
     int off = 0;
@@ -100,9 +111,11 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
                                                    int frame_skip, int iters, int epw, int tap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KS_LDS T* lds = (KS_LDS T*)smem;
-    const Model<T>& m = *mp;
+    const Model<T>* ml = mp;
+    if constexpr (USE_LDS) { ml = stage_model(mp, lds); lds += model_words<T>(); }
+    const Model<T>& m = *ml;
     int hull_words = 0;
-    const Hulls<T> hu = stage_hulls(m, lds, hull_words);
+    const Hulls<T> hu = stage_hulls(*mp, lds, hull_words);
     // epw envs per workgroup, SUBS lanes per env: the lanes of a team keep identical copies of the env state and
     // split the vertex scans / per-pair (collision) and per-contact (solver) loops; per-env dynamic data is shared in LDS
     const int e = threadIdx.x / SUBS;
@@ -151,9 +164,11 @@ template <typename T, bool USE_LDS>
 __global__ __launch_bounds__(WG) void k_substep(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ ctrl, int N, int iters, int epw, int tap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KS_LDS T* lds = (KS_LDS T*)smem;
-    const Model<T>& m = *mp;
+    const Model<T>* ml = mp;
+    if constexpr (USE_LDS) { ml = stage_model(mp, lds); lds += model_words<T>(); }
+    const Model<T>& m = *ml;
     int hull_words = 0;
-    const Hulls<T> hu = stage_hulls(m, lds, hull_words);
+    const Hulls<T> hu = stage_hulls(*mp, lds, hull_words);
     const int e = threadIdx.x / SUBS;
     const Team<SUBS> team{(int)threadIdx.x % SUBS};
     const int env = blockIdx.x * epw + e;
@@ -390,7 +405,7 @@ template <typename T> struct Ctx : CtxBase {
     int hull_words = 0;
     int plan_launch() {
         const size_t lds_max = 160 * 1024;
-        const size_t hull_bytes = (size_t)hull_words * sizeof(T);
+        const size_t hull_bytes = (size_t)hull_words * sizeof(T) + (USE_LDS ? (size_t)model_words<T>() * sizeof(T) : 0);
         const size_t per_env = USE_LDS ? (size_t)SCR_TOTAL * sizeof(T) : 0;
         int cap = USE_LDS ? (int)((lds_max - hull_bytes - 64) / per_env) : EPW_MAX;
         if (cap > EPW_MAX) cap = EPW_MAX;

@@ -1523,10 +1523,16 @@ KS_SOLVER_FN void solve_newton(const Model<T>& m, const T* Mh, const T* Mo, cons
             lim_x[j] = r.lim_sign[j] * a[dof] - r.lim_aref[j];
             lim_p[j] = r.lim_sign[j] * p[dof];
         }
+        // rows of the owned contacts along the search line: x(alpha) = rx + alpha * rj, weight rD (0 = not a row)
+        T rx[CPL][4], rj[CPL][4], rD[CPL];
         KS_UNROLL
         for (int q = 0; q < CPL; q++) {
             const int ci = team.sub + q * SUBS;
+            rD[q] = 0;
+            KS_UNROLL
+            for (int kk = 0; kk < 4; kk++) { rx[q][kk] = 0; rj[q][kk] = 0; }
             if (ci < ncon && scr(SCR_CON + ci * CON_STRIDE + 9) >= 0) {
+                const int o = SCR_CON + ci * CON_STRIDE;
                 T B[3][NV], dist, mu;
                 contact_basis_cached<T>(scr, ci, B, dist, mu);
                 KS_UNROLL
@@ -1535,6 +1541,13 @@ KS_SOLVER_FN void solve_newton(const Model<T>& m, const T* Mh, const T* Mo, cons
                     KS_UNROLL
                     for (int j = 0; j < NV; j++) v += B[b][j] * p[j];
                     pb[q][b] = v;
+                }
+                rD[q] = scr(o + 18);
+                KS_UNROLL
+                for (int kk = 0; kk < 4; kk++) {
+                    const T sm = (kk & 1) ? -mu : mu;
+                    rj[q][kk] = pb[q][0] + sm * pb[q][1 + (kk >> 1)];
+                    rx[q][kk] = xb[q][0] + sm * xb[q][1 + (kk >> 1)] - scr(o + 10 + kk);
                 }
             }
         }
@@ -1545,33 +1558,24 @@ KS_SOLVER_FN void solve_newton(const Model<T>& m, const T* Mh, const T* Mo, cons
 #ifdef KS_STAMP
             if (prof) prof[22] += 1.f;
 #endif
-            T d1 = pMa + alpha * pMp, d2 = pMp;
+            T d1 = pMa + alpha * pMp, d2 = pMp, mag = kabs(pMa) + kabs(alpha * pMp);
             KS_UNROLL
             for (int t = 0; t < 3; t++) {
-                T xx = eq_x[t] + alpha * eq_p[t];
-                d1 += eqD[t] * xx * eq_p[t]; d2 += eqD[t] * eq_p[t] * eq_p[t];
+                const T xx = eq_x[t] + alpha * eq_p[t], w = eqD[t] * eq_p[t];
+                d1 += w * xx; d2 += w * eq_p[t]; mag += kabs(w * xx);
             }
             KS_UNROLL
             for (int j = 0; j < 6; j++) {
-                T xx = lim_x[j] + alpha * lim_p[j];
-                if (r.lim_sign[j] != 0 && xx < 0) { d1 += limD[j] * xx * lim_p[j]; d2 += limD[j] * lim_p[j] * lim_p[j]; }
+                const T xx = lim_x[j] + alpha * lim_p[j], w = limD[j] * lim_p[j];
+                if (r.lim_sign[j] != 0 && xx < 0) { d1 += w * xx; d2 += w * lim_p[j]; mag += kabs(w * xx); }
             }
-            d1 *= lead; d2 *= lead;
+            d1 *= lead; d2 *= lead; mag *= lead;
             KS_UNROLL
             for (int q = 0; q < CPL; q++) {
-                const int ci = team.sub + q * SUBS;
-                if (ci < ncon) {
-                    const int o = SCR_CON + ci * CON_STRIDE;
-                    const T D = scr(o + 18), mu = scr(o + 7);
-                    if (scr(o + 9) >= 0) {
-                        KS_UNROLL
-                        for (int kk = 0; kk < 4; kk++) {
-                            const T sm = (kk & 1) ? -mu : mu;
-                            const T jp = pb[q][0] + sm * pb[q][1 + (kk >> 1)];
-                            const T xx = xb[q][0] + sm * xb[q][1 + (kk >> 1)] - scr(o + 10 + kk) + alpha * jp;
-                            if (xx < 0) { d1 += D * xx * jp; d2 += D * jp * jp; }
-                        }
-                    }
+                KS_UNROLL
+                for (int kk = 0; kk < 4; kk++) {
+                    const T xx = rx[q][kk] + alpha * rj[q][kk], w = rD[q] * rj[q][kk];
+                    if (xx < 0) { d1 += w * xx; d2 += w * rj[q][kk]; mag += kabs(w * xx); }
                 }
             }
             d1 = team.sum(d1);
@@ -1581,7 +1585,9 @@ KS_SOLVER_FN void solve_newton(const Model<T>& m, const T* Mh, const T* Mo, cons
             T next = alpha - d1 / d2;
             if (hi >= 0 && (next < lo || next > hi)) next = T(0.5) * (lo + hi);
             if (next < lo) next = lo;
-            const bool stop = kabs(next - alpha) <= LS_RTOL<T>() * kabs(alpha) || kabs(next - alpha) <= T(1e-14) * (1 + kabs(alpha));
+            bool stop = kabs(next - alpha) <= LS_RTOL<T>() * kabs(alpha) || kabs(next - alpha) <= T(1e-14) * (1 + kabs(alpha));
+            // fp32: the derivative is below the rounding noise of its own terms - alpha cannot be resolved further
+            if constexpr (sizeof(T) == 4) stop = stop || kabs(d1) <= T(2e-6) * team.sum(mag);
             alpha = next;
             if (stop) break;
         }
