@@ -21,10 +21,6 @@
 
 #include "ks_model.h"
 
-#ifndef KS_SOLVER_FN
-#define KS_SOLVER_FN KS_FN
-#endif
-
 namespace ks {
 
 // ---------------------------------------------------------------- scratch layout (units of T)
@@ -41,16 +37,25 @@ constexpr int CON_STRIDE = 20;
 constexpr int NSTAGE = 96, STAGE_REC = 9;
 constexpr int SCR_PC = SCR_CON + NCON_MAX * CON_STRIDE;
 constexpr int SCR_STAGE = SCR_PC + NPAIR_MAX;
-// plane-hull contact selection: indices of the vertices within the margin, ascending (one list per env)
+// plane-hull contact selection: indices of the vertices within the margin, ascending (one list per env).  The
+// list lives in the contact slots, which are only written by the merge that follows the detection.
 constexpr int CAND_MAX = 96;
-constexpr int SCR_CAND = SCR_STAGE + NSTAGE * STAGE_REC;
-constexpr int SCR_TOTAL = SCR_CAND + CAND_MAX;
+constexpr int SCR_CAND = SCR_CON;
+// smooth dynamics of the substep, written by the role lanes (fingers, object, slides) and read by row:
+// hand mass matrix 9x9, object mass matrix 6x6, qfrc_smooth (slide entries without the finger links' bias),
+// per-finger bias on the three slides
+constexpr int SCR_MH = SCR_STAGE + NSTAGE * STAGE_REC;
+constexpr int SCR_MO = SCR_MH + 81;
+constexpr int SCR_QF = SCR_MO + 36;
+constexpr int SCR_SB = SCR_QF + NV;
+constexpr int SCR_TOTAL = ((SCR_SB + 9 + 3) / 4) * 4;
+static_assert(CAND_MAX <= NCON_MAX * CON_STRIDE, "candidate list fits in the contact slots");
 // The staging + candidate regions are dead once the contacts are merged: the solver reuses them as a cache of
 // the contact basis Jacobians (45 values per contact) so that they are built once per substep, not 2x per
 // Newton iteration; contacts that do not fit are rebuilt on the fly.
 constexpr int SCR_BCACHE = SCR_STAGE;
 constexpr int BC_STRIDE = 48;                 // 3 x 15 values, padded to whole 16-byte vectors
-constexpr int NBCACHE = (SCR_TOTAL - SCR_STAGE) / BC_STRIDE;
+constexpr int NBCACHE = (SCR_MH - SCR_STAGE) / BC_STRIDE;
 static_assert(SCR_CON % 4 == 0 && SCR_STAGE % 4 == 0 && SCR_TOTAL % 4 == 0 && CON_STRIDE % 4 == 0, "16-byte aligned scratch regions");
 
 // A team = the SUBS lanes that work on one env (SUBS = 16 on the GPU: one DPP row; 1 on the host).  The
@@ -242,134 +247,169 @@ template <typename T, typename S> KS_HD void geom_pose(const Model<T>& m, S scr,
     add3(p, pb, t);
 }
 
-// ---------------------------------------------------------------- S2+S3 smooth dynamics
-// Mh: hand 9x9 (row-major full, symmetric), Mo: object 6x6.  qfrc = passive - bias + actuator.
-template <typename T>
-KS_SOLVER_FN void smooth_dynamics(const Model<T>& m, const Kin<T>& k, const T* qvel, const T* ctrl, T* Mh, T* Mo, T* qfrc) {
+// ---------------------------------------------------------------- S1-S3 by role lanes
+// Forward kinematics + smooth dynamics of one substep, split over the team by ROLE: lanes 0-2 one finger each
+// (proximal + distal link), lane 3 the object, lane 4 the slides / link_7.  Every role writes its body poses
+// (SCR_BP / SCR_AX) and its part of the mass matrix and of qfrc_smooth = passive - bias + actuator into the
+// env's LDS block; consumers read them by row (load_dynamics_row).  With SUBS = 1 one lane plays all roles.
+template <typename T, typename S, int SUBS>
+KS_FN void dynamics_rows(const Model<T>& m, const T* qpos, const T* qvel, const T* ctrl, const T* R7, S scr, Team<SUBS> team) {
+    // entries no role writes (finger-finger cross terms, hand-object) stay zero
+    for (int k = team.sub; k < 81 + 36; k += SUBS) scr(SCR_MH + k) = T(0);
+    team.sync();
+    T ax[3][3], p7[3];
     KS_UNROLL
-    for (int i = 0; i < 81; i++) Mh[i] = 0;
+    for (int i = 0; i < 3; i++) mulRv(ax[i], R7, m.slide_axis[i]);
     KS_UNROLL
-    for (int i = 0; i < 36; i++) Mo[i] = 0;
-    T bias[NV];
-    KS_UNROLL
-    for (int i = 0; i < NV; i++) bias[i] = 0;
+    for (int i = 0; i < 3; i++) p7[i] = m.l7_pos[i] + ax[0][i] * qpos[0] + ax[1][i] * qpos[1] + ax[2][i] * qpos[2];
     const T g = -m.gravity_z;   // a_com - gravity = a_com + (0,0,g)
-    // link_7 and total hand mass on the slides
-    T mt = m.mass[2];
-    KS_UNROLL
-    for (int b = 3; b <= 8; b++) mt += m.mass[b];
-    KS_UNROLL
-    for (int i = 0; i < 3; i++) {
-        KS_UNROLL
-        for (int j = 0; j < 3; j++) Mh[i * 9 + j] = mt * dot3(k.ax[i], k.ax[j]);
-        bias[i] += m.mass[2] * g * k.ax[i][2];
-    }
-    KS_UNROLL
-    for (int f = 0; f < 3; f++) {
-        const int hp = 3 + 2 * f, hd = 4 + 2 * f, bP = 3 + 2 * f, bD = 4 + 2 * f;
-        const T mP = m.mass[bP], mD = m.mass[bD];
-        T z[3] = {k.Rp[f][2], k.Rp[f][5], k.Rp[f][8]};
-        T rPP[3], rDD[3], rDP[3], t[3];
-        mulRv(rPP, k.Rp[f], m.ipos[bP]);
-        mulRv(rDD, k.Rd[f], m.ipos[bD]);
-        sub3(t, k.pd[f], k.pp[f]);
-        add3(rDP, t, rDD);
-        T jP[3], jDp[3], jDd[3];
-        cross3(jP, z, rPP);
-        cross3(jDp, z, rDP);
-        cross3(jDd, z, rDD);
-        Mh[hp * 9 + hp] = mP * dot3(jP, jP) + mD * dot3(jDp, jDp) + m.izz[bP] + m.izz[bD];
-        Mh[hp * 9 + hd] = Mh[hd * 9 + hp] = mD * dot3(jDp, jDd) + m.izz[bD];
-        Mh[hd * 9 + hd] = mD * dot3(jDd, jDd) + m.izz[bD];
-        T sP[3] = {mP * jP[0] + mD * jDp[0], mP * jP[1] + mD * jDp[1], mP * jP[2] + mD * jDp[2]};
-        KS_UNROLL
-        for (int i = 0; i < 3; i++) {
-            Mh[i * 9 + hp] = Mh[hp * 9 + i] = dot3(k.ax[i], sP);
-            Mh[i * 9 + hd] = Mh[hd * 9 + i] = mD * dot3(k.ax[i], jDd);
-        }
-        // velocity-product accelerations of the two COMs (planar chain about z):
-        // a = w x (w x r) = -w^2 * r_perp
-        T wP = qvel[hp], wD = qvel[hp] + qvel[hd];
-        T aP[3], aD[3], u[3], zs[3];
-        scl3(zs, z, wP);
-        cross3(u, zs, rPP); cross3(aP, zs, u);
-        cross3(u, zs, t); cross3(aD, zs, u);           // distal origin
-        scl3(zs, z, wD);
-        cross3(u, zs, rDD); cross3(u, zs, u);
-        add3(aD, aD, u);
-        aP[2] += g; aD[2] += g;
-        T FP[3], FD[3];
-        scl3(FP, aP, mP);
-        scl3(FD, aD, mD);
-        KS_UNROLL
-        for (int i = 0; i < 3; i++) bias[i] += dot3(k.ax[i], FP) + dot3(k.ax[i], FD);
-        bias[hp] += dot3(jP, FP) + dot3(jDp, FD);
-        bias[hd] += dot3(jDd, FD);
-    }
-    // object (free joint: linear world, angular body frame)
-    {
-        const T mo = m.mass[9];
-        T c[3];
-        mulRv(c, k.Ro, m.ipos[9]);
-        KS_UNROLL
-        for (int i = 0; i < 3; i++) Mo[i * 6 + i] = mo;
-        T cb[3] = {m.ipos[9][0], m.ipos[9][1], m.ipos[9][2]};
-        T cc = dot3(cb, cb);
-        KS_UNROLL
-        for (int a = 0; a < 3; a++) {
-            T e[3] = {T(a == 0), T(a == 1), T(a == 2)}, ec[3], w[3];
-            cross3(ec, e, cb);
-            mulRv(w, k.Ro, ec);                        // R_a x c (world)
+    for (int role = team.sub; role < 5; role += SUBS) {
+        if (role < 3) {
+            const int f = role, hp = 3 + 2 * f, hd = 4 + 2 * f, bP = hp, bD = hd;
+            T Rp[9], pp[3], Rd[9], pd[3];
+            {
+                T Rb[9], Rz[9], t[3];
+                mulRR(Rb, R7, m.fbase_R[f]);
+                T a = qpos[hp], c = kcos(a), sn = ksin(a);
+                Rz[0] = c; Rz[1] = -sn; Rz[2] = 0; Rz[3] = sn; Rz[4] = c; Rz[5] = 0; Rz[6] = 0; Rz[7] = 0; Rz[8] = 1;
+                mulRR(Rp, Rb, Rz);
+                mulRv(t, R7, m.fbase_pos[f]);
+                add3(pp, p7, t);
+                mulRR(Rb, Rp, m.ftip_R[f]);
+                a = qpos[hd]; c = kcos(a); sn = ksin(a);
+                Rz[0] = c; Rz[1] = -sn; Rz[3] = sn; Rz[4] = c;
+                mulRR(Rd, Rb, Rz);
+                mulRv(t, Rp, m.ftip_pos[f]);
+                add3(pd, pp, t);
+            }
+            const int o1 = SCR_BP + (1 + 2 * f) * 12, o2 = o1 + 12;
             KS_UNROLL
-            for (int i = 0; i < 3; i++) Mo[i * 6 + 3 + a] = Mo[(3 + a) * 6 + i] = mo * w[i];
+            for (int j = 0; j < 9; j++) { scr(o1 + j) = Rp[j]; scr(o2 + j) = Rd[j]; }
             KS_UNROLL
-            for (int b = 0; b < 3; b++) Mo[(3 + a) * 6 + 3 + b] = m.obj_Ib[a * 3 + b] + mo * ((a == b ? cc : T(0)) - cb[a] * cb[b]);
+            for (int j = 0; j < 3; j++) { scr(o1 + 9 + j) = pp[j]; scr(o2 + 9 + j) = pd[j]; }
+            const T mP = m.mass[bP], mD = m.mass[bD];
+            const T z[3] = {Rp[2], Rp[5], Rp[8]};
+            T rPP[3], rDD[3], rDP[3], t[3];
+            mulRv(rPP, Rp, m.ipos[bP]);
+            mulRv(rDD, Rd, m.ipos[bD]);
+            sub3(t, pd, pp);
+            add3(rDP, t, rDD);
+            T jP[3], jDp[3], jDd[3];
+            cross3(jP, z, rPP);
+            cross3(jDp, z, rDP);
+            cross3(jDd, z, rDD);
+            scr(SCR_MH + hp * 9 + hp) = mP * dot3(jP, jP) + mD * dot3(jDp, jDp) + m.izz[bP] + m.izz[bD] + m.armature[hp];
+            const T mpd = mD * dot3(jDp, jDd) + m.izz[bD];
+            scr(SCR_MH + hp * 9 + hd) = mpd;
+            scr(SCR_MH + hd * 9 + hp) = mpd;
+            scr(SCR_MH + hd * 9 + hd) = mD * dot3(jDd, jDd) + m.izz[bD] + m.armature[hd];
+            const T sP[3] = {mP * jP[0] + mD * jDp[0], mP * jP[1] + mD * jDp[1], mP * jP[2] + mD * jDp[2]};
+            KS_UNROLL
+            for (int i = 0; i < 3; i++) {
+                const T cp = dot3(ax[i], sP), cd = mD * dot3(ax[i], jDd);
+                scr(SCR_MH + i * 9 + hp) = cp; scr(SCR_MH + hp * 9 + i) = cp;
+                scr(SCR_MH + i * 9 + hd) = cd; scr(SCR_MH + hd * 9 + i) = cd;
+            }
+            // velocity-product accelerations of the two COMs (planar chain about z): a = w x (w x r)
+            const T qvp = qvel[hp], qvd = qvel[hd];
+            const T wP = qvp, wD = qvp + qvd;
+            T aP[3], aD[3], u[3], zs[3];
+            scl3(zs, z, wP);
+            cross3(u, zs, rPP); cross3(aP, zs, u);
+            cross3(u, zs, t); cross3(aD, zs, u);           // distal origin
+            scl3(zs, z, wD);
+            cross3(u, zs, rDD); cross3(u, zs, u);
+            add3(aD, aD, u);
+            aP[2] += g; aD[2] += g;
+            T FP[3], FD[3];
+            scl3(FP, aP, mP);
+            scl3(FD, aD, mD);
+            KS_UNROLL
+            for (int i = 0; i < 3; i++) scr(SCR_SB + 3 * f + i) = dot3(ax[i], FP) + dot3(ax[i], FD);
+            const T bias_p = dot3(jP, FP) + dot3(jDp, FD), bias_d = dot3(jDd, FD);
+            scr(SCR_QF + hp) = -m.damping[hp] * qvp - bias_p + m.act[3] * (clampT(ctrl[6 + f], -m.act[4], m.act[4]) - qvp);
+            scr(SCR_QF + hd) = -m.damping[hd] * qvd - bias_d;
+        } else if (role == 3) {
+            // object (free joint: linear world, angular body frame)
+            T q[4] = {qpos[12], qpos[13], qpos[14], qpos[15]}, Ro[9];
+            quatnormalize(q);
+            quat2mat(Ro, q);
+            KS_UNROLL
+            for (int j = 0; j < 9; j++) scr(SCR_BP + 7 * 12 + j) = Ro[j];
+            KS_UNROLL
+            for (int j = 0; j < 3; j++) scr(SCR_BP + 7 * 12 + 9 + j) = qpos[9 + j];
+            const T mo = m.mass[9];
+            T c[3];
+            mulRv(c, Ro, m.ipos[9]);
+            KS_UNROLL
+            for (int i = 0; i < 3; i++) scr(SCR_MO + i * 6 + i) = mo + m.armature[9 + i];
+            const T cb[3] = {m.ipos[9][0], m.ipos[9][1], m.ipos[9][2]};
+            const T cc = dot3(cb, cb);
+            KS_UNROLL
+            for (int a = 0; a < 3; a++) {
+                T e[3] = {T(a == 0), T(a == 1), T(a == 2)}, ec[3], w[3];
+                cross3(ec, e, cb);
+                mulRv(w, Ro, ec);                        // R_a x c (world)
+                KS_UNROLL
+                for (int i = 0; i < 3; i++) { scr(SCR_MO + i * 6 + 3 + a) = mo * w[i]; scr(SCR_MO + (3 + a) * 6 + i) = mo * w[i]; }
+                KS_UNROLL
+                for (int b = 0; b < 3; b++)
+                    scr(SCR_MO + (3 + a) * 6 + 3 + b) = m.obj_Ib[a * 3 + b] + mo * ((a == b ? cc : T(0)) - cb[a] * cb[b]) + (a == b ? m.armature[12 + a] : T(0));
+            }
+            // bias: F = m (w x (w x c) + g e_z), T = w x I w ; angular rows in the body frame
+            T wl[3] = {qvel[12], qvel[13], qvel[14]}, w[3], u[3], ac[3];
+            mulRv(w, Ro, wl);
+            cross3(u, w, c); cross3(ac, w, u);
+            ac[2] += g;
+            T F[3];
+            scl3(F, ac, mo);
+            T Iwl[3], tl[3];
+            mulRv(Iwl, m.obj_Ib, wl);
+            cross3(tl, wl, Iwl);
+            T cF[3], cFl[3];
+            cross3(cF, c, F);
+            mulRtv(cFl, Ro, cF);
+            KS_UNROLL
+            for (int i = 0; i < 3; i++) {
+                scr(SCR_QF + 9 + i) = -m.damping[9 + i] * qvel[9 + i] - F[i];
+                scr(SCR_QF + 12 + i) = -m.damping[12 + i] * qvel[12 + i] - (cFl[i] + tl[i]);
+            }
+        } else {
+            // slides: link_7 pose, world slide axes, 3x3 slide block, slide forces without the finger links' bias
+            KS_UNROLL
+            for (int j = 0; j < 9; j++) { scr(SCR_AX + j) = ax[j / 3][j % 3]; scr(SCR_BP + j) = R7[j]; }
+            KS_UNROLL
+            for (int j = 0; j < 3; j++) scr(SCR_BP + 9 + j) = p7[j];
+            T mt = m.mass[2];
+            KS_UNROLL
+            for (int b = 3; b <= 8; b++) mt += m.mass[b];
+            KS_UNROLL
+            for (int i = 0; i < 3; i++) {
+                KS_UNROLL
+                for (int j = 0; j < 3; j++) scr(SCR_MH + i * 9 + j) = mt * dot3(ax[i], ax[j]) + (i == j ? m.armature[i] : T(0));
+                scr(SCR_QF + i) = -m.damping[i] * qvel[i] - m.mass[2] * g * ax[i][2] +
+                                  m.act[0] * (clampT(ctrl[2 * i], -m.act[2], m.act[2]) - qvel[i]) + m.act[1] * ctrl[2 * i + 1];
+            }
         }
-        // bias: F = m (w x (w x c) + g e_z), T = w x I w (world) ; angular rows in the body frame
-        T wl[3] = {qvel[12], qvel[13], qvel[14]}, w[3], u[3], ac[3];
-        mulRv(w, k.Ro, wl);
-        cross3(u, w, c); cross3(ac, w, u);
-        ac[2] += g;
-        T F[3];
-        scl3(F, ac, mo);
-        T Iwl[3], tl[3];
-        mulRv(Iwl, m.obj_Ib, wl);
-        cross3(tl, wl, Iwl);                            // body frame torque w x I w
-        T cF[3], cFl[3];
-        cross3(cF, c, F);
-        mulRtv(cFl, k.Ro, cF);
-        KS_UNROLL
-        for (int i = 0; i < 3; i++) { bias[9 + i] = F[i]; bias[12 + i] = cFl[i] + tl[i]; }
     }
-    KS_UNROLL
-    for (int i = 0; i < 9; i++) Mh[i * 9 + i] += m.armature[i];
-    KS_UNROLL
-    for (int i = 0; i < 6; i++) Mo[i * 6 + i] += m.armature[9 + i];
-    // passive (joint damping) + actuation (XML:214-222)
-    KS_UNROLL
-    for (int i = 0; i < NV; i++) qfrc[i] = -m.damping[i] * qvel[i] - bias[i];
-    KS_UNROLL
-    for (int j = 0; j < 3; j++) {
-        qfrc[j] += m.act[0] * (clampT(ctrl[2 * j], -m.act[2], m.act[2]) - qvel[j]) + m.act[1] * ctrl[2 * j + 1];
-        qfrc[3 + 2 * j] += m.act[3] * (clampT(ctrl[6 + j], -m.act[4], m.act[4]) - qvel[3 + 2 * j]);
-    }
+    team.sync();
 }
 
-// y = M x  (block diagonal)
-template <typename T> KS_HD void mul_M(const T* Mh, const T* Mo, const T* x, T* y) {
+// row i of the block-diagonal mass matrix and entry i of qfrc_smooth from the env's LDS block (i >= NV: zeros)
+template <typename T, typename S>
+KS_HD void load_dynamics_row(S scr, int i, T (&Mrow)[NV], T& qs) {
     KS_UNROLL
-    for (int i = 0; i < 9; i++) {
-        T v = 0;
+    for (int j = 0; j < NV; j++) Mrow[j] = 0;
+    qs = 0;
+    if (i < 9) {
         KS_UNROLL
-        for (int j = 0; j < 9; j++) v += Mh[i * 9 + j] * x[j];
-        y[i] = v;
-    }
-    KS_UNROLL
-    for (int i = 0; i < 6; i++) {
-        T v = 0;
+        for (int j = 0; j < 9; j++) Mrow[j] = scr(SCR_MH + i * 9 + j);
+        qs = scr(SCR_QF + i);
+        if (i < 3) qs -= T(scr(SCR_SB + i)) + T(scr(SCR_SB + 3 + i)) + T(scr(SCR_SB + 6 + i));
+    } else if (i < NV) {
         KS_UNROLL
-        for (int j = 0; j < 6; j++) v += Mo[i * 6 + j] * x[9 + j];
-        y[9 + i] = v;
+        for (int j = 0; j < 6; j++) Mrow[9 + j] = scr(SCR_MO + (i - 9) * 6 + j);
+        qs = scr(SCR_QF + i);
     }
 }
 
@@ -1175,7 +1215,7 @@ template <typename T> struct ScalarRows {
 };
 
 template <typename T, typename S, int SUBS>
-KS_SOLVER_FN void make_constraints(const Model<T>& m, const Kin<T>& k, const T* qpos, const T* qvel, S scr, Team<SUBS> team, int ncon, ScalarRows<T>& r) {
+KS_HD void make_constraints(const Model<T>& m, const T* qpos, const T* qvel, S scr, Team<SUBS> team, int ncon, ScalarRows<T>& r) {
     KS_UNROLL
     for (int t = 0; t < 3; t++) {
         const T c0 = m.tendon_coef[t][0], c1 = m.tendon_coef[t][1];
@@ -1249,6 +1289,66 @@ template <typename T> KS_HD constexpr T LS_RTOL() { return sizeof(T) == 4 ? T(1e
 template <typename F, int... Is> KS_HD void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, typename F> KS_HD void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+// ---- row-distributed dense kernels (row i in team lane i % SUBS, slot i / SUBS)
+// In-place Cholesky A = L L^T, right-looking: afterwards register k of a row owner holds L[row][k] (k <= row),
+// rd = 1 / L[row][row].  Pivots are clamped like the oracle's.
+template <typename T, int SUBS, int RPL>
+KS_HD void rows_cholesky(Team<SUBS> team, const int (&row)[RPL], T (&H)[RPL][NV], T (&rd)[RPL]) {
+    KS_UNROLL
+    for (int rr = 0; rr < RPL; rr++) rd[rr] = 0;
+    static_for<NV>([&](auto kc) {
+        constexpr int k = decltype(kc)::value, ko = k % SUBS, ks = k / SUBS;
+        T piv = team.template bcast<ko>(H[ks][k]);
+        piv = piv > T(1e-15) ? piv : T(1e-15);
+        const T rp = krsqrt(piv);
+        KS_UNROLL
+        for (int rr = 0; rr < RPL; rr++) {
+            H[rr][k] *= rp;
+            if (row[rr] == k) rd[rr] = rp;
+        }
+        static_for<NV - 1 - k>([&](auto jc) {
+            constexpr int j = k + 1 + decltype(jc)::value, jo = j % SUBS, js = j / SUBS;
+            const T Ljk = team.template bcast<jo>(H[js][k]);
+            KS_UNROLL
+            for (int rr = 0; rr < RPL; rr++) H[rr][j] -= H[rr][k] * Ljk;
+        });
+    });
+}
+// x = (L L^T)^-1 b with b, x distributed by row
+template <typename T, int SUBS, int RPL>
+KS_HD void rows_solve(Team<SUBS> team, const int (&row)[RPL], const T (&L)[RPL][NV], const T (&rd)[RPL], const T (&b)[RPL], T (&x)[RPL]) {
+    T bb[RPL], y[RPL];
+    KS_UNROLL
+    for (int rr = 0; rr < RPL; rr++) { bb[rr] = b[rr]; y[rr] = 0; x[rr] = 0; }
+    static_for<NV>([&](auto kc) {
+        constexpr int k = decltype(kc)::value, ko = k % SUBS, ks = k / SUBS;
+        const T yk = team.template bcast<ko>(bb[ks] * rd[ks]);
+        KS_UNROLL
+        for (int rr = 0; rr < RPL; rr++) {
+            if (row[rr] == k) y[rr] = yk;
+            bb[rr] -= L[rr][k] * yk;
+        }
+    });
+    static_for<NV>([&](auto kc) {
+        constexpr int i0 = NV - 1 - decltype(kc)::value;
+        T part = 0;
+        KS_UNROLL
+        for (int rr = 0; rr < RPL; rr++) part += (row[rr] > i0 && row[rr] < NV) ? L[rr][i0] * x[rr] : T(0);
+        const T sacc = team.sum(part);
+        KS_UNROLL
+        for (int rr = 0; rr < RPL; rr++)
+            if (row[rr] == i0) x[rr] = (y[rr] - sacc) * rd[rr];
+    });
+}
+// every lane gets the whole vector
+template <typename T, int SUBS, int RPL>
+KS_HD void rows_replicate(Team<SUBS> team, const T (&x)[RPL], T (&out)[NV]) {
+    static_for<NV>([&](auto kc) {
+        constexpr int k = decltype(kc)::value, ko = k % SUBS, ks = k / SUBS;
+        out[k] = team.template bcast<ko>(x[ks]);
+    });
+}
+
 // Newton's method on the primal problem  min_a 1/2 (a-a0)^T M (a-a0) + sum_rows s(J a - aref),  ROW-DISTRIBUTED over
 // the team: row i of the 15x15 Hessian H = M + J^T D J (and entry i of the gradient, of M a, of the Cholesky
 // factor, of the search direction) lives in team lane i % SUBS, slot i / SUBS.  With SUBS = 16 every lane holds
@@ -1258,16 +1358,18 @@ template <int N, typename F> KS_HD void static_for(F&& f) { static_for_impl(f, s
 // evaluates the pyramid rows (J.a, active set, forces) and publishes 5 numbers per contact in LDS; every lane
 // then adds the contact's contribution to its own row from the cached basis Jacobian.
 // Vectors a, p (and the small inputs) are replicated in every lane.
-// Outputs a (qacc) and qfrc_c (J^T f), both replicated.
+// The stage also builds the constraint rows (S5), solves M qacc_smooth = qfrc_smooth and finishes with the
+// semi-implicit Euler update (S7): everything that needs the mass matrix by rows lives in one function.
 template <typename T, typename S, int SUBS>
-KS_SOLVER_FN void solve_newton(const Model<T>& m, const T* Mh, const T* Mo, const T* qfrc_smooth, const T* qacc_smooth, const T* warm,
-                               const ScalarRows<T>& rows_in, S scr, Team<SUBS> team, int ncon, int iterations, T* a_out, T* qfrc_c,
-                               float* prof = nullptr) {
+KS_FN void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm, S scr, Team<SUBS> team, int ncon, int iterations, int& status,
+                            float* prof = nullptr) {
     static_assert(SUBS == 1 || SUBS == 16, "row distribution: one lane or one DPP row per env");
     constexpr int RPL = (NV + SUBS - 1) / SUBS;         // rows per lane
     constexpr int CPL = (NCON_MAX + SUBS - 1) / SUBS;   // contacts per lane
     KS_T0
-    const ScalarRows<T> r = rows_in;
+    ScalarRows<T> r;
+    make_constraints(m, qpos, qvel, scr, team, ncon, r);
+    KS_TICK(2)
     T tc0[3], tc1[3], eqD[3], limD[6];
     KS_UNROLL
     for (int t = 0; t < 3; t++) { tc0[t] = m.tendon_coef[t][0]; tc1[t] = m.tendon_coef[t][1]; eqD[t] = T(1) / r.eq_R[t]; }
@@ -1279,20 +1381,23 @@ KS_SOLVER_FN void solve_newton(const Model<T>& m, const T* Mh, const T* Mo, cons
     int row[RPL];
     KS_UNROLL
     for (int rr = 0; rr < RPL; rr++) {
-        const int i = team.sub + rr * SUBS;
-        row[rr] = i;
-        qs[rr] = i < NV ? qfrc_smooth[i] : T(0);
-        KS_UNROLL
-        for (int j = 0; j < NV; j++) {
-            T v = 0;
-            if (j < 9) { if (i < 9) v = Mh[i * 9 + j]; }
-            else if (i >= 9 && i < NV) v = Mo[(i - 9) * 6 + (j - 9)];
-            Mrow[rr][j] = v;
-        }
+        row[rr] = team.sub + rr * SUBS;
+        load_dynamics_row<T>(scr, row[rr], Mrow[rr], qs[rr]);
     }
+    // qacc_smooth = M^-1 qfrc_smooth
     T a[NV], a0[NV];
-    KS_UNROLL
-    for (int j = 0; j < NV; j++) a0[j] = qacc_smooth[j];
+    {
+        T L[RPL][NV], rd[RPL], x[RPL];
+        KS_UNROLL
+        for (int rr = 0; rr < RPL; rr++) {
+            KS_UNROLL
+            for (int j = 0; j < NV; j++) L[rr][j] = Mrow[rr][j];
+        }
+        rows_cholesky(team, row, L, rd);
+        rows_solve(team, row, L, rd, qs, x);
+        rows_replicate(team, x, a0);
+    }
+    KS_TICK(3)
 
     // cost at x (replicated): Gauss part by rows, scalar rows on the lead lane, contacts by their owners
     auto cost = [&](const T* x) -> T {
@@ -1448,56 +1553,14 @@ KS_SOLVER_FN void solve_newton(const Model<T>& m, const T* Mh, const T* Mo, cons
             }
         }
         KS_TICK(14)
-        // --- Cholesky H = L L^T, right-looking, column k of L in register k of the row owners
-        T rd[RPL];
+        // --- Newton direction: H p = -g
+        T rd[RPL], ng[RPL], x[RPL], p[NV];
         KS_UNROLL
-        for (int rr = 0; rr < RPL; rr++) rd[rr] = 0;
-        static_for<NV>([&](auto kc) {
-            constexpr int k = decltype(kc)::value, ko = k % SUBS, ks = k / SUBS;
-            T piv = team.template bcast<ko>(H[ks][k]);
-            piv = piv > T(1e-15) ? piv : T(1e-15);
-            const T rp = krsqrt(piv);
-            KS_UNROLL
-            for (int rr = 0; rr < RPL; rr++) {
-                H[rr][k] *= rp;
-                if (row[rr] == k) rd[rr] = rp;
-            }
-            static_for<NV - 1 - k>([&](auto jc) {
-                constexpr int j = k + 1 + decltype(jc)::value, jo = j % SUBS, js = j / SUBS;
-                const T Ljk = team.template bcast<jo>(H[js][k]);
-                KS_UNROLL
-                for (int rr = 0; rr < RPL; rr++) H[rr][j] -= H[rr][k] * Ljk;
-            });
-        });
+        for (int rr = 0; rr < RPL; rr++) ng[rr] = -g[rr];
+        rows_cholesky(team, row, H, rd);
         KS_TICK(15)
-        // --- L y = -g (forward), L^T x = y (backward): x = Newton direction, entry i in the owner of row i
-        T bb[RPL], y[RPL], x[RPL];
-        KS_UNROLL
-        for (int rr = 0; rr < RPL; rr++) { bb[rr] = -g[rr]; y[rr] = 0; x[rr] = 0; }
-        static_for<NV>([&](auto kc) {
-            constexpr int k = decltype(kc)::value, ko = k % SUBS, ks = k / SUBS;
-            const T yk = team.template bcast<ko>(bb[ks] * rd[ks]);
-            KS_UNROLL
-            for (int rr = 0; rr < RPL; rr++) {
-                if (row[rr] == k) y[rr] = yk;
-                bb[rr] -= H[rr][k] * yk;
-            }
-        });
-        static_for<NV>([&](auto kc) {
-            constexpr int i0 = NV - 1 - decltype(kc)::value;
-            T part = 0;
-            KS_UNROLL
-            for (int rr = 0; rr < RPL; rr++) part += (row[rr] > i0 && row[rr] < NV) ? H[rr][i0] * x[rr] : T(0);
-            const T sacc = team.sum(part);
-            KS_UNROLL
-            for (int rr = 0; rr < RPL; rr++)
-                if (row[rr] == i0) x[rr] = (y[rr] - sacc) * rd[rr];
-        });
-        T p[NV];
-        static_for<NV>([&](auto kc) {
-            constexpr int k = decltype(kc)::value, ko = k % SUBS, ks = k / SUBS;
-            p[k] = team.template bcast<ko>(x[ks]);
-        });
+        rows_solve(team, row, H, rd, ng, x);
+        rows_replicate(team, x, p);
         KS_TICK(16)
         // --- line search data
         T pMa = 0, pMp = 0;
@@ -1669,87 +1732,64 @@ KS_SOLVER_FN void solve_newton(const Model<T>& m, const T* Mh, const T* Mo, cons
             qc[rr] += b[0] * fn + b[1] * ft1 + b[2] * ft2;
         }
     }
-    static_for<NV>([&](auto kc) {
-        constexpr int k = decltype(kc)::value, ko = k % SUBS, ks = k / SUBS;
-        qfrc_c[k] = team.template bcast<ko>(qc[ks]);
-    });
-    KS_UNROLL
-    for (int j = 0; j < NV; j++) a_out[j] = a[j];
-    team.sync();
     KS_TICK(20)
+    // --- S7 Euler with implicit joint damping: (M + h D) qacc' = qfrc_smooth + qfrc_constraint, by rows
+    const T h = m.dt;
+    T qa[NV];
+    {
+        T L[RPL][NV], rd[RPL], f[RPL], x[RPL];
+        KS_UNROLL
+        for (int rr = 0; rr < RPL; rr++) {
+            const T hd = row[rr] < NV ? h * m.damping[row[rr] < NV ? row[rr] : 0] : T(0);
+            KS_UNROLL
+            for (int j = 0; j < NV; j++) L[rr][j] = Mrow[rr][j] + (j == row[rr] ? hd : T(0));
+            f[rr] = qs[rr] + qc[rr];
+        }
+        rows_cholesky(team, row, L, rd);
+        rows_solve(team, row, L, rd, f, x);
+        rows_replicate(team, x, qa);
+    }
+    KS_UNROLL
+    for (int i = 0; i < NV; i++) warm[i] = a[i];
+    bool finite = true;
+    T qv[NV];
+    KS_UNROLL
+    for (int i = 0; i < NV; i++) {
+        qv[i] = qvel[i] + h * qa[i];
+        qvel[i] = qv[i];
+        finite = finite && (qv[i] == qv[i]) && kabs(qv[i]) < T(1e10);
+    }
+    KS_UNROLL
+    for (int i = 0; i < 12; i++) qpos[i] += h * qv[i];
+    T w[3] = {qv[12], qv[13], qv[14]}, quat[4] = {qpos[12], qpos[13], qpos[14], qpos[15]};
+    const T ang = norm3(w) * h;
+    if (ang > T(1e-15)) {
+        normalize3(w);
+        const T sa = ksin(T(0.5) * ang), dq[4] = {kcos(T(0.5) * ang), w[0] * sa, w[1] * sa, w[2] * sa};
+        quatmul(quat, quat, dq);
+    }
+    quatnormalize(quat);
+    KS_UNROLL
+    for (int i = 0; i < 4; i++) qpos[12 + i] = quat[i];
+    if (!finite) status |= ST_NONFINITE;
+    team.sync();
+    KS_TICK(5)
 }
 
 // ---------------------------------------------------------------- one mj_step (forward + Euler)
 template <typename T, typename S, int SUBS>
 KS_HD void mj_forward_step(const Model<T>& m, const Hulls<T>& hu, T* qpos, T* qvel, T* warm, const T* ctrl, const T* R7, S scr, Team<SUBS> team,
                            int solver_iterations, bool integrate, int& ncon_out, int& status, float* prof = nullptr) {
-    Kin<T> k;
     KS_T0
     team.sync();                                   // the previous substep's readers of the body poses are done
-    forward_kinematics(m, qpos, R7, k, scr, team.sub == 0);
-    team.sync();
-    T Mh[81], Mo[36], qfrc[NV];
-    smooth_dynamics(m, k, qvel, ctrl, Mh, Mo, qfrc);
+    dynamics_rows(m, qpos, qvel, ctrl, R7, scr, team);
     KS_TICK(0)
     int ncon = 0;
     collision(m, hu, scr, team, ncon, status, prof);
     KS_TICK(1)
     ncon_out = ncon;
     if (!integrate) return;
-    ScalarRows<T> rows;
-    make_constraints(m, k, qpos, qvel, scr, team, ncon, rows);
-    KS_TICK(2)
-    // qacc_smooth = M^-1 qfrc
-    T Lh[81], Lo[36], qacc_s[NV];
-    KS_UNROLL
-    for (int i = 0; i < 81; i++) Lh[i] = Mh[i];
-    KS_UNROLL
-    for (int i = 0; i < 36; i++) Lo[i] = Mo[i];
-    chol_inplace<T, 9>(Lh);
-    chol_inplace<T, 6>(Lo);
-    chol_solve<T, 9>(Lh, qfrc, qacc_s);
-    chol_solve<T, 6>(Lo, qfrc + 9, qacc_s + 9);
-    T a[NV], qfrc_c[NV];
-    KS_TICK(3)
-    solve_newton(m, Mh, Mo, qfrc, qacc_s, warm, rows, scr, team, ncon, solver_iterations, a, qfrc_c, prof);
-    KS_TICK(4)
-    // S7 Euler with implicit joint damping: (M + h D) qacc' = qfrc_smooth + qfrc_constraint
-    const T h = m.dt;
-    KS_UNROLL
-    for (int i = 0; i < NV; i++) warm[i] = a[i];
-    KS_UNROLL
-    for (int i = 0; i < 81; i++) Lh[i] = Mh[i];
-    KS_UNROLL
-    for (int i = 0; i < 36; i++) Lo[i] = Mo[i];
-    KS_UNROLL
-    for (int i = 0; i < 9; i++) Lh[i * 9 + i] += h * m.damping[i];
-    KS_UNROLL
-    for (int i = 0; i < 6; i++) Lo[i * 6 + i] += h * m.damping[9 + i];
-    T f[NV], qa[NV];
-    KS_UNROLL
-    for (int i = 0; i < NV; i++) f[i] = qfrc[i] + qfrc_c[i];
-    chol_inplace<T, 9>(Lh);
-    chol_inplace<T, 6>(Lo);
-    chol_solve<T, 9>(Lh, f, qa);
-    chol_solve<T, 6>(Lo, f + 9, qa + 9);
-    bool finite = true;
-    KS_UNROLL
-    for (int i = 0; i < NV; i++) {
-        qvel[i] += h * qa[i];
-        finite = finite && (qvel[i] == qvel[i]) && kabs(qvel[i]) < T(1e10);
-    }
-    KS_UNROLL
-    for (int i = 0; i < 12; i++) qpos[i] += h * qvel[i];
-    T w[3] = {qvel[12], qvel[13], qvel[14]};
-    T ang = norm3(w) * h;
-    if (ang > T(1e-15)) {
-        normalize3(w);
-        T sa = ksin(T(0.5) * ang), dq[4] = {kcos(T(0.5) * ang), w[0] * sa, w[1] * sa, w[2] * sa};
-        quatmul(&qpos[12], &qpos[12], dq);
-    }
-    quatnormalize(&qpos[12]);
-    if (!finite) status |= ST_NONFINITE;
-    KS_TICK(5)
+    constrained_step(m, qpos, qvel, warm, scr, team, ncon, solver_iterations, status, prof);
 }
 
 }  // namespace ks
