@@ -51,13 +51,17 @@ template <typename T> struct LdsScratch { using type = Scratch<T, KS_LDS T*>; };
 // The model constants (about 3 KB) are copied to the head of LDS as well: the physics stages are out-of-line
 // device functions that reach the model through a generic reference, and a flat load that resolves to LDS costs
 // a fraction of one that goes to L2.  Returns the words (of T) used; visibility comes with stage_hulls' barrier.
-template <typename T> constexpr int model_words() { return (int)((sizeof(Model<T>) + 15) / 16 * 16 / sizeof(T)); }
+constexpr int HULLS_BYTES = 256;   // the Hulls descriptor (LDS pointers, counts) sits behind the model copy
+template <typename T> constexpr int model_words() { return (int)(((sizeof(Model<T>) + 15) / 16 * 16 + HULLS_BYTES) / sizeof(T)); }
 template <typename T> __device__ __forceinline__ const Model<T>* stage_model(const Model<T>* __restrict__ mp, KS_LDS T* lds) {
     const unsigned* src = (const unsigned*)mp;
     KS_LDS unsigned* dst = (KS_LDS unsigned*)lds;
     for (int i = threadIdx.x; i < (int)(sizeof(Model<T>) / 4); i += blockDim.x) dst[i] = src[i];
     return (const Model<T>*)lds;
 }
+
+// size of a PairRec in DEVICE code (LDS pointers are 4 bytes there; the host pass of this file sees 8)
+template <typename T> constexpr int pair_rec_bytes() { return sizeof(T) == 4 ? 96 : 144; }
 
 template <typename T> __device__ __forceinline__ Hulls<T> stage_hulls(const Model<T>& m, KS_LDS T* lds, int& used) {
     Hulls<T> hu;
@@ -85,6 +89,14 @@ template <typename T> __device__ __forceinline__ Hulls<T> stage_hulls(const Mode
     }
     const int iwords = (uoff * (int)sizeof(unsigned short) + (int)sizeof(T) - 1) / (int)sizeof(T);
     used = off + ((iwords + 3) & ~3);
+    // pair records behind the adjacency tables, one thread per pair
+    hulls_set_pairs(m, hu);
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(sizeof(PairRec<T>) == pair_rec_bytes<T>(), "device size of a pair record");
+#endif
+    hu.pair = (KS_LDS const PairRec<T>*)(lds + used);
+    if ((int)threadIdx.x < m.npair) fill_pair_rec(m, hu, threadIdx.x, *(PairRec<T>*)(hu.pair + threadIdx.x));
+    used += NPAIR_MAX * pair_rec_bytes<T>() / (int)sizeof(T);
     __syncthreads();
     return hu;
 }
@@ -115,7 +127,17 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
     if constexpr (USE_LDS) { ml = stage_model(mp, lds); lds += model_words<T>(); }
     const Model<T>& m = *ml;
     int hull_words = 0;
-    const Hulls<T> hu = stage_hulls(*mp, lds, hull_words);
+    const Hulls<T> hu_reg = stage_hulls(*mp, lds, hull_words);
+    const Hulls<T>* hup = &hu_reg;
+    if constexpr (USE_LDS) {
+        // the out-of-line stages reach the descriptor through a generic reference as well: keep it in LDS
+        static_assert(sizeof(Hulls<T>) <= HULLS_BYTES, "Hulls descriptor slot");
+        Hulls<T>* slot = (Hulls<T>*)(smem + (sizeof(Model<T>) + 15) / 16 * 16);
+        if (threadIdx.x == 0) *slot = hu_reg;
+        __syncthreads();
+        hup = slot;
+    }
+    const Hulls<T>& hu = *hup;
     // epw envs per workgroup, SUBS lanes per env: the lanes of a team keep identical copies of the env state and
     // split the vertex scans / per-pair (collision) and per-contact (solver) loops; per-env dynamic data is shared in LDS
     const int e = threadIdx.x / SUBS;
@@ -168,7 +190,17 @@ __global__ __launch_bounds__(WG) void k_substep(const Model<T>* __restrict__ mp,
     if constexpr (USE_LDS) { ml = stage_model(mp, lds); lds += model_words<T>(); }
     const Model<T>& m = *ml;
     int hull_words = 0;
-    const Hulls<T> hu = stage_hulls(*mp, lds, hull_words);
+    const Hulls<T> hu_reg = stage_hulls(*mp, lds, hull_words);
+    const Hulls<T>* hup = &hu_reg;
+    if constexpr (USE_LDS) {
+        // the out-of-line stages reach the descriptor through a generic reference as well: keep it in LDS
+        static_assert(sizeof(Hulls<T>) <= HULLS_BYTES, "Hulls descriptor slot");
+        Hulls<T>* slot = (Hulls<T>*)(smem + (sizeof(Model<T>) + 15) / 16 * 16);
+        if (threadIdx.x == 0) *slot = hu_reg;
+        __syncthreads();
+        hup = slot;
+    }
+    const Hulls<T>& hu = *hup;
     const int e = threadIdx.x / SUBS;
     const Team<SUBS> team{(int)threadIdx.x % SUBS};
     const int env = blockIdx.x * epw + e;
@@ -392,6 +424,7 @@ template <typename T> struct Ctx : CtxBase {
         {
             const int iwords = (adj_ints * (int)sizeof(unsigned short) + (int)sizeof(T) - 1) / (int)sizeof(T);
             hull_words += (iwords + 3) & ~3;
+            hull_words += NPAIR_MAX * pair_rec_bytes<T>() / (int)sizeof(T);
         }
         int r = plan_launch();
         if (r != KS_OK) return r;

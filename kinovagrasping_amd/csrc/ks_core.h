@@ -34,7 +34,7 @@ constexpr int CON_STRIDE = 20;
 // collision staging: contacts are detected pair by pair into per-pair slots of (pos3, normal3, dist, mu,
 // bodies) records - 4 slots for a plane pair, 1 for a hull pair, assigned in pair order - and then merged
 // in pair order with the per-pair counts in SCR_PC.
-constexpr int NSTAGE = 96, STAGE_REC = 9;
+constexpr int NSTAGE = 85, STAGE_REC = 9, STAGE_WORDS = 768;   // 85 x 9 = 765 <= 768 = 16 cached bases
 constexpr int SCR_PC = SCR_CON + NCON_MAX * CON_STRIDE;
 constexpr int SCR_STAGE = SCR_PC + NPAIR_MAX;
 // plane-hull contact selection: indices of the vertices within the margin, ascending (one list per env).  The
@@ -44,11 +44,13 @@ constexpr int SCR_CAND = SCR_CON;
 // smooth dynamics of the substep, written by the role lanes (fingers, object, slides) and read by row:
 // hand mass matrix 9x9, object mass matrix 6x6, qfrc_smooth (slide entries without the finger links' bias),
 // per-finger bias on the three slides
-constexpr int SCR_MH = SCR_STAGE + NSTAGE * STAGE_REC;
+constexpr int SCR_MH = SCR_STAGE + STAGE_WORDS;
+static_assert(NSTAGE * STAGE_REC <= STAGE_WORDS, "staging records fit");
 constexpr int SCR_MO = SCR_MH + 81;
 constexpr int SCR_QF = SCR_MO + 36;
 constexpr int SCR_SB = SCR_QF + NV;
-constexpr int SCR_TOTAL = ((SCR_SB + 9 + 3) / 4) * 4;
+constexpr int SCR_GP = ((SCR_SB + 9 + 3) / 4) * 4;   // world poses of geoms 1..8 (R row-major 9, p 3), refreshed every substep
+constexpr int SCR_TOTAL = SCR_GP + (NGEOM - 1) * 12;
 static_assert(CAND_MAX <= NCON_MAX * CON_STRIDE, "candidate list fits in the contact slots");
 // The staging + candidate regions are dead once the contacts are merged: the solver reuses them as a cache of
 // the contact basis Jacobians (45 values per contact) so that they are built once per substep, not 2x per
@@ -165,12 +167,64 @@ template <typename T, typename P = T*> struct ScratchC {
 
 // Convex-hull vertex tables as the collision code sees them: on the GPU they are staged in LDS once per
 // launch (wave-uniform ds_read broadcasts, no scalar-cache thrash, no per-lane 64-bit address math).
+// Everything the narrow phase needs to know about one collision pair, gathered once per launch into one 96-byte
+// LDS record: a pair costs one burst of ds_read_b128 instead of a chain of dependent model lookups.
+template <typename T> struct alignas(16) PairRec {
+    int g1, g2;
+    T margin, mu;
+    T rbound1, size1[3];
+    T rbound2, size2[3];
+    int body1, body2;
+    int n1, n2;                // padded hull vertex counts; n2 of a plane pair is the true count
+    int slot, pad_;            // first staging record of the pair (4 per plane pair, 1 per hull pair, pair order)
+    KS_LDS const T* V1; KS_LDS const T* V2;
+    KS_LDS const unsigned short* off1; KS_LDS const unsigned short* adj1;
+    KS_LDS const unsigned short* off2; KS_LDS const unsigned short* adj2;
+};
+
 template <typename T> struct Hulls {
     KS_LDS const T* vert[4];   // [nvert_pad][4]
     int nvert[4], nvert_pad[4];
     KS_LDS const unsigned short* adj_off[4];   // hull graph, 4-neighbour chunks (hill-climbing support queries)
     KS_LDS const unsigned short* adj[4];
+    unsigned plane_mask;   // bit pi set: pair pi is ground plane vs hull (pair_g1 == 0)
+    int npair, nhull;
+    KS_LDS const PairRec<T>* pair;             // [npair]
+    unsigned char hull_pi[NPAIR_MAX];          // pair index of the k-th hull-hull pair
 };
+template <typename T> KS_HD unsigned plane_pair_mask(const Model<T>& m) {
+    unsigned mask = 0;
+    for (int pi = 0; pi < m.npair; pi++) mask |= (m.pair_g1[pi] == 0) ? (1u << pi) : 0u;
+    return mask;
+}
+// pair bookkeeping of the descriptor (mask, counts, hull pair list); `pair` is set by the caller
+template <typename T> KS_HD void hulls_set_pairs(const Model<T>& m, Hulls<T>& hu) {
+    hu.plane_mask = plane_pair_mask(m);
+    hu.npair = m.npair;
+    hu.nhull = 0;
+    for (int pi = 0; pi < m.npair; pi++)
+        if (!((hu.plane_mask >> pi) & 1u)) hu.hull_pi[hu.nhull++] = (unsigned char)pi;
+}
+template <typename T> KS_HD void fill_pair_rec(const Model<T>& m, const Hulls<T>& hu, int pi, PairRec<T>& r) {
+    const int g1 = m.pair_g1[pi], g2 = m.pair_g2[pi];
+    r.g1 = g1; r.g2 = g2; r.margin = m.pair_margin[pi]; r.mu = m.pair_mu[pi];
+    int slot = 0;
+    for (int j = 0; j < pi; j++) slot += ((hu.plane_mask >> j) & 1u) ? 4 : 1;
+    r.slot = slot; r.pad_ = 0;
+    r.rbound1 = m.geom_rbound[g1]; r.rbound2 = m.geom_rbound[g2];
+    for (int k = 0; k < 3; k++) { r.size1[k] = m.geom_size[g1][k]; r.size2[k] = m.geom_size[g2][k]; }
+    r.body1 = m.geom_body[g1]; r.body2 = m.geom_body[g2];
+    const int mesh2 = m.geom_mesh[g2];
+    r.V2 = hu.vert[mesh2]; r.off2 = hu.adj_off[mesh2]; r.adj2 = hu.adj[mesh2];
+    if (g1 == 0) {
+        r.n1 = 0; r.n2 = hu.nvert[mesh2];
+        r.V1 = r.V2; r.off1 = r.off2; r.adj1 = r.adj2;
+    } else {
+        const int mesh1 = m.geom_mesh[g1];
+        r.n1 = hu.nvert_pad[mesh1]; r.n2 = hu.nvert_pad[mesh2];
+        r.V1 = hu.vert[mesh1]; r.off1 = hu.adj_off[mesh1]; r.adj1 = hu.adj[mesh1];
+    }
+}
 
 template <typename T> struct LaneState {
     T qpos[NQ], qvel[NV], warm[NV];
@@ -245,6 +299,15 @@ template <typename T, typename S> KS_HD void geom_pose(const Model<T>& m, S scr,
     mulRR(R, Rb, m.geom_R[g]);
     mulRv(t, Rb, m.geom_pos[g]);
     add3(p, pb, t);
+}
+
+// world pose of geom g (1..8) as stored by dynamics_rows
+template <typename T, typename S> KS_HD void geom_pose_cached(S scr, int g, T* R, T* p) {
+    const int o = SCR_GP + (g - 1) * 12;
+    KS_UNROLL
+    for (int j = 0; j < 9; j++) R[j] = scr(o + j);
+    KS_UNROLL
+    for (int j = 0; j < 3; j++) p[j] = scr(o + 9 + j);
 }
 
 // ---------------------------------------------------------------- S1-S3 by role lanes
@@ -391,6 +454,17 @@ KS_FN void dynamics_rows(const Model<T>& m, const T* qpos, const T* qvel, const 
                                   m.act[0] * (clampT(ctrl[2 * i], -m.act[2], m.act[2]) - qvel[i]) + m.act[1] * ctrl[2 * i + 1];
             }
         }
+    }
+    team.sync();
+    // world poses of the collision geoms, one geom per lane
+    for (int g = 1 + team.sub; g < NGEOM; g += SUBS) {
+        T R[9], p[3];
+        geom_pose(m, scr, g, R, p);
+        const int o = SCR_GP + (g - 1) * 12;
+        KS_UNROLL
+        for (int j = 0; j < 9; j++) scr(o + j) = R[j];
+        KS_UNROLL
+        for (int j = 0; j < 3; j++) scr(o + 9 + j) = p[j];
     }
     team.sync();
 }
@@ -911,19 +985,22 @@ template <typename T> KS_HD void plane_pick(const T* v, T thr2, T cv[4][3], int&
 // ascending list of vertices within the margin, and every lane runs the (short) greedy rule on that list.
 // Returns the number of contacts staged at record `slot`.
 template <typename T, typename S, int SUBS>
-KS_HD int collide_plane_hull(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> team, int g2, T margin, T mu, int slot) {
+KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* prp) {
+    KS_LDS const PairRec<T>& pr = *prp;
     const T PLANE_MESH_TOL = T(0.3);
+    const int g2 = pr.g2, slot = pr.slot;
+    const T margin = pr.margin, mu = pr.mu, rbound = pr.rbound2;
+    const T size[3] = {pr.size2[0], pr.size2[1], pr.size2[2]};
+    KS_LDS const T* V = pr.V2;
+    const int nv = pr.n2, body2 = pr.body2;
     T R2[9], p2[3];
-    geom_pose(m, scr, g2, R2, p2);
+    geom_pose_cached(scr, g2, R2, p2);
     const T cdist = p2[2];
-    if (cdist > m.geom_rbound[g2] + margin) return 0;
+    if (cdist > rbound + margin) return 0;
     const T ln[3] = {R2[6], R2[7], R2[8]};          // R2^T e_z
     // exact cull: lowest point of the geom's bounding box (half extents geom_size about the geom origin) is
     // above the margin -> every hull vertex is too
-    if (cdist - (kabs(ln[0]) * m.geom_size[g2][0] + kabs(ln[1]) * m.geom_size[g2][1] + kabs(ln[2]) * m.geom_size[g2][2]) > margin) return 0;
-    const int mesh2 = m.geom_mesh[g2];
-    KS_LDS const T* V = hu.vert[mesh2];
-    const int nv = hu.nvert[mesh2];
+    if (cdist - (kabs(ln[0]) * size[0] + kabs(ln[1]) * size[1] + kabs(ln[2]) * size[2]) > margin) return 0;
     // slices are whole HULL_CHUNKs; rows past nv are padding (copies of vertex 0) and never counted
     const int len = ((nv + SUBS * HULL_CHUNK - 1) / (SUBS * HULL_CHUNK)) * HULL_CHUNK;
     const int i_lo = team.sub * len, i_hi = (i_lo + len < nv) ? i_lo + len : nv;
@@ -948,7 +1025,7 @@ KS_HD int collide_plane_hull(const Model<T>& m, const Hulls<T>& hu, S scr, Team<
     T cv[4][3];
     int nc = 1;
     cv[0][0] = V[4 * best]; cv[0][1] = V[4 * best + 1]; cv[0][2] = V[4 * best + 2];
-    T thr2 = PLANE_MESH_TOL * m.geom_rbound[g2];
+    T thr2 = PLANE_MESH_TOL * rbound;
     thr2 *= thr2;
     if (total <= CAND_MAX) {
         int w = first;
@@ -983,7 +1060,7 @@ KS_HD int collide_plane_hull(const Model<T>& m, const Hulls<T>& hu, S scr, Team<
                 mulRv(w, R2, cv[k]);
                 add3(w, w, p2);
                 w[2] -= T(0.5) * d;
-                stage_contact(scr, slot + k, 0, m.geom_body[g2], mu, d, w, normal);
+                stage_contact(scr, slot + k, 0, body2, mu, d, w, normal);
             }
         }
     }
@@ -992,29 +1069,30 @@ KS_HD int collide_plane_hull(const Model<T>& m, const Hulls<T>& hu, S scr, Team<
 
 // hull vs hull (one lane): bounding spheres, exact OBB test, GJK distance for the margin zone, MPR on overlap
 template <typename T, typename S>
-KS_HD int collide_hull_hull(const Model<T>& m, const Hulls<T>& hu, S scr, int g1, int g2, T margin, T mu, int slot) {
+KS_HD int collide_hull_hull(const Model<T>& m, S scr, KS_LDS const PairRec<T>* prp) {
+    KS_LDS const PairRec<T>& pr = *prp;
     PairGeo<T> pg;
-    geom_pose(m, scr, g1, pg.R1, pg.p1);
-    geom_pose(m, scr, g2, pg.R2, pg.p2);
+    // the whole record first: one burst of LDS reads, one wait
+    const int g1 = pr.g1, g2 = pr.g2, slot = pr.slot, body1 = pr.body1, body2 = pr.body2;
+    const T margin = pr.margin, mu = pr.mu, bound = pr.rbound1 + pr.rbound2 + margin;
+    const T size1[3] = {pr.size1[0], pr.size1[1], pr.size1[2]}, size2[3] = {pr.size2[0], pr.size2[1], pr.size2[2]};
+    pg.V1 = pr.V1; pg.n1 = pr.n1; pg.off1 = pr.off1; pg.adj1 = pr.adj1;
+    pg.V2 = pr.V2; pg.n2 = pr.n2; pg.off2 = pr.off2; pg.adj2 = pr.adj2;
+    geom_pose_cached(scr, g1, pg.R1, pg.p1);
+    geom_pose_cached(scr, g2, pg.R2, pg.p2);
     T t[3];
     sub3(t, pg.p1, pg.p2);
-    const T bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin;
     if (dot3(t, t) > bound * bound) return 0;
 #ifndef KS_NO_OBB
-    if (obb_separated(pg.R1, pg.p1, m.geom_size[g1], pg.R2, pg.p2, m.geom_size[g2], margin)) return 0;
+    if (obb_separated(pg.R1, pg.p1, size1, pg.R2, pg.p2, size2, margin)) return 0;
 #endif
-    const int mesh1 = m.geom_mesh[g1], mesh2 = m.geom_mesh[g2];
-    pg.V1 = hu.vert[mesh1]; pg.n1 = hu.nvert_pad[mesh1];
-    pg.V2 = hu.vert[mesh2]; pg.n2 = hu.nvert_pad[mesh2];
-    pg.off1 = hu.adj_off[mesh1]; pg.adj1 = hu.adj[mesh1];
-    pg.off2 = hu.adj_off[mesh2]; pg.adj2 = hu.adj[mesh2];
     pg.hint1 = 0; pg.hint2 = 0;
     pg.half_margin = T(0);
     T depth, dist, dir[3], pos[3];
     const int r = gjk_distance(pg, margin, &dist, dir, pos);
-    if (r == 1) { stage_contact(scr, slot, m.geom_body[g1], m.geom_body[g2], mu, dist, pos, dir); return 1; }
+    if (r == 1) { stage_contact(scr, slot, body1, body2, mu, dist, pos, dir); return 1; }
     if (r == 2 && mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, dir, pos)) {
-        stage_contact(scr, slot, m.geom_body[g1], m.geom_body[g2], mu, -depth, pos, dir);
+        stage_contact(scr, slot, body1, body2, mu, -depth, pos, dir);
         return 1;
     }
     return 0;
@@ -1023,56 +1101,59 @@ KS_HD int collide_hull_hull(const Model<T>& m, const Hulls<T>& hu, S scr, int g1
 template <typename T, typename S, int SUBS>
 KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> team, int& ncon, int& status, float* prof = nullptr) {
     KS_T0
+    const unsigned plane_mask = hu.plane_mask;
+    const int npair = hu.npair, nhull = hu.nhull;
+    KS_LDS const PairRec<T>* pairs = hu.pair;
     // plane pairs: the whole team on one pair at a time (team-uniform control flow)
-    int slot = 0;
-    for (int pi = 0; pi < m.npair; pi++) {
-        const bool plane = m.pair_g1[pi] == 0;
-        const int need = plane ? 4 : 1;
-        if (plane) {
-            int c = 0;
-            if (slot + need <= NSTAGE) c = collide_plane_hull(m, hu, scr, team, m.pair_g2[pi], m.pair_margin[pi], m.pair_mu[pi], slot);
-            else status |= ST_CONTACT_OVERFLOW;
-            if (team.sub == 0) scr(SCR_PC + pi) = T(c);
-        }
-        slot += need;
+    for (unsigned mk = plane_mask; mk != 0; mk &= mk - 1) {
+        const int pi = kctz(mk);
+        int c = 0;
+        if (pairs[pi].slot + 4 <= NSTAGE) c = collide_plane_hull(scr, team, pairs + pi);
+        else status |= ST_CONTACT_OVERFLOW;
+        if (team.sub == 0) scr(SCR_PC + pi) = T(c);
     }
     KS_TICK(8)
     // hull pairs: dealt round-robin to the lanes of the team
-    slot = 0;
-    int hk = 0;
-    for (int pi = 0; pi < m.npair; pi++) {
-        const bool plane = m.pair_g1[pi] == 0;
-        const int need = plane ? 4 : 1;
-        if (!plane) {
-            if (hk % SUBS == team.sub) {
-                int c = 0;
-                if (slot + need <= NSTAGE) c = collide_hull_hull(m, hu, scr, m.pair_g1[pi], m.pair_g2[pi], m.pair_margin[pi], m.pair_mu[pi], slot);
-                else status |= ST_CONTACT_OVERFLOW;
-                scr(SCR_PC + pi) = T(c);
-            }
-            hk++;
-        }
-        slot += need;
+    for (int hk = team.sub; hk < nhull; hk += SUBS) {
+        const int pi = hu.hull_pi[hk];
+        int c = 0;
+        if (pairs[pi].slot + 1 <= NSTAGE) c = collide_hull_hull(m, scr, pairs + pi);
+        else status |= ST_CONTACT_OVERFLOW;
+        scr(SCR_PC + pi) = T(c);
     }
     KS_TICK(9)
     team.sync();
-    // merge the staged records in pair order (= the oracle's contact order); contacts beyond NCON_MAX are dropped
+    // merge the staged records in pair order (= the oracle's contact order); contacts beyond NCON_MAX are dropped.
+    // Every lane reads all per-pair counts at once and copies the records of the pairs pi = sub (mod SUBS).
+    T cnt[NPAIR_MAX];
+    KS_UNROLL
+    for (int j = 0; j < NPAIR_MAX; j++) cnt[j] = scr(SCR_PC + j);
     int total = 0;
-    slot = 0;
-    for (int pi = 0; pi < m.npair; pi++) {
-        const int c = (int)scr(SCR_PC + pi);
-        if (pi % SUBS == team.sub) {
-            for (int q = 0; q < c; q++) {
-                const int src = SCR_STAGE + (slot + q) * STAGE_REC, dst = SCR_CON + (total + q) * CON_STRIDE;
-                if (total + q < NCON_MAX) {
+    int before[(NPAIR_MAX + SUBS - 1) / SUBS];
+    KS_UNROLL
+    for (int q = 0; q < (NPAIR_MAX + SUBS - 1) / SUBS; q++) before[q] = 0;
+    KS_UNROLL
+    for (int j = 0; j < NPAIR_MAX; j++) {
+        const int c = j < npair ? (int)cnt[j] : 0;
+        KS_UNROLL
+        for (int q = 0; q < (NPAIR_MAX + SUBS - 1) / SUBS; q++) before[q] += (j < team.sub + q * SUBS) ? c : 0;
+        total += c;
+    }
+    KS_UNROLL
+    for (int q = 0; q < (NPAIR_MAX + SUBS - 1) / SUBS; q++) {
+        const int pi = team.sub + q * SUBS;
+        if (pi < npair) {
+            const int c = (int)scr(SCR_PC + pi), slot = pairs[pi].slot;
+            for (int k = 0; k < c; k++) {
+                const int src = SCR_STAGE + (slot + k) * STAGE_REC, dst = SCR_CON + (before[q] + k) * CON_STRIDE;
+                if (before[q] + k < NCON_MAX) {
                     KS_UNROLL
                     for (int f = 0; f < 9; f++) scr(dst + f) = scr(src + f);
-                } else status |= ST_CONTACT_OVERFLOW;
+                }
             }
         }
-        total += c;
-        slot += m.pair_g1[pi] == 0 ? 4 : 1;
     }
+    if (total > NCON_MAX) status |= ST_CONTACT_OVERFLOW;
     ncon = total < NCON_MAX ? total : NCON_MAX;
     team.sync();
     KS_TICK(10)

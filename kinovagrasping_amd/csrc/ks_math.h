@@ -27,6 +27,7 @@ template <> struct Lim<double> { static constexpr double minval = 1e-300; static
 
 KS_HD float ksqrt(float x) { return sqrtf(x); }
 KS_HD double ksqrt(double x) { return sqrt(x); }
+KS_HD int kctz(unsigned x) { return __builtin_ctz(x); }
 // reciprocal square root: the hardware v_rsq_f32 (1 ulp) in fp32 device code
 KS_HD float krsqrt(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
