@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--mode", choices=["ddpg", "sim"], default="ddpg")
     ap.add_argument("--hidden", type=int, nargs=2, default=[256, 256])
     ap.add_argument("--serial-learner", action="store_true", help="run the learner update after the sim step instead of beside it")
+    ap.add_argument("--eager", action="store_true", help="launch the rollout / learner ops one by one instead of replaying HIP graphs")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -108,37 +109,50 @@ def main():
         from kinovagrasping_amd.replay import DeviceEpisodeReplay
         from kinovagrasping_amd.rollout import RolloutEngine
         torch.manual_seed(2)                                   # reference default seed (main_DDPGfD.py:884): identical replicas
-        policy = DDPGfD(82, 4, 0.8, 5, batch_size=64, hidden=tuple(args.hidden), device=dev)
-        gen = torch.Generator(device=dev).manual_seed(2 + rank)
+        policy = DDPGfD(82, 4, 0.8, 5, batch_size=64, hidden=tuple(args.hidden), device=dev, capturable=not args.eager)
+        torch.manual_seed(2 + rank)                            # exploration noise / window sampling differ per rank
         replay = DeviceEpisodeReplay(n, capacity=max(4 * n, 1024), horizon=30, device=dev)
-        eng = RolloutEngine(sim, policy, replay, expl_noise=0.1, generator=gen)
-        eng.start(obs0)
+        if not args.eager:
+            # rollout ops and the DDPGfD update replayed as HIP graphs; the simulator is launched between them and
+            # the learner graph runs on a second stream beside the simulator kernel (kinovagrasping_amd/pipeline.py)
+            from kinovagrasping_amd.pipeline import GraphedTrainer
+            eng = RolloutEngine(sim, policy, replay, expl_noise=0.1)
+            eng.start(obs0)
+            trainer = GraphedTrainer(sim, policy, replay, eng, batch_episodes=64, overlap=not args.serial_learner)
+            trainer.capture()
 
-        # The sim kernel keeps 64 of the 256 CUs busy (one wave per 64 envs); the learner update runs on a
-        # second HIP stream beside it.  Ordering: the update starts after the actor forward of this step was
-        # enqueued and finishes before the replay is written / the next actor forward reads the weights.
-        main, side = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
-        lgen = torch.Generator(device=dev).manual_seed(1002 + rank)
+            def step_fn(t):
+                nonlocal updates
+                trainer.step()
+                updates = trainer.updates
+        else:
+            gen = torch.Generator(device=dev).manual_seed(2 + rank)
+            eng = RolloutEngine(sim, policy, replay, expl_noise=0.1, generator=gen)
+            eng.start(obs0)
+            main, side = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+            lgen = torch.Generator(device=dev).manual_seed(1002 + rank)
+            acted = torch.cuda.Event()
+            steps_done = 0
 
-        acted = torch.cuda.Event()
+            def learner_update():
+                nonlocal updates
+                if steps_done < 31:                    # every env has finished an episode by step 30
+                    return
+                side.wait_event(acted)                 # weights are free once this step's actor forward is done
+                with torch.cuda.stream(side), torch.enable_grad():
+                    st, ac, ns, rw, nd, w = replay.sample_batch_nstep(64, generator=lgen)
+                    policy.train_on_batch(st, ac, ns, rw, w)
+                updates += 1
 
-        def learner_update():
-            nonlocal updates
-            if replay.count < 2:
-                return
-            side.wait_event(acted)                 # weights are free once this step's actor forward is done
-            with torch.cuda.stream(side), torch.enable_grad():   # called from inside the no_grad rollout step
-                st, ac, ns, rw, nd, w = replay.sample_batch_nstep(64, generator=lgen)
-                policy.train_on_batch(st, ac, ns, rw, w)
-            updates += 1
-
-        def step_fn(t):
-            if args.serial_learner:
-                eng.step()
-                learner_update()
-                main.wait_stream(side)
-            else:
-                eng.step(after_act=lambda: acted.record(main), after_launch=learner_update, before_store=lambda: main.wait_stream(side))
+            def step_fn(t):
+                nonlocal steps_done
+                if args.serial_learner:
+                    eng.step()
+                    learner_update()
+                    main.wait_stream(side)
+                else:
+                    eng.step(after_act=lambda: acted.record(main), after_launch=learner_update, before_store=lambda: main.wait_stream(side))
+                steps_done += 1
 
     for t in range(args.warmup):
         step_fn(t)
@@ -178,6 +192,7 @@ def main():
                                     "metric's env count); sim kernels only"),
                        "mode": args.mode, "envs_per_gpu": n, "frame_skip": 15, "solver": "newton x6", "hidden": list(args.hidden),
                        "learner_updates_timed": updates - upd0 if args.mode == "ddpg" else 0,
+                       "launch": ("eager" if args.eager else "hip-graphs") if args.mode == "ddpg" else "direct",
                        "parallelism": f"env-shard x{world}" + (" + grad all-reduce" if world > 1 and args.mode == "ddpg" else "")},
             "roofline": {"bound": "hbm", "kernel": "k_env_step", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_note": traffic_note,

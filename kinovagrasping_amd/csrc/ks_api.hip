@@ -164,7 +164,6 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
 #ifdef KS_STAMP
         // diagnostic build only: per-phase cycle sums of this lane go to the contact tap buffer
         prof[6] = (float)(clock64() - tk0);
-        prof[7] = (float)ncon;
         if (tap) for (int k = 0; k < 24; k++) b.contact[(long)(k + 24 * team.sub) * N + env] = (T)prof[k];
         tap = 0;
 #endif

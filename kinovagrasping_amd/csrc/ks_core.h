@@ -71,6 +71,12 @@ template <int SUBS> struct Team {
         return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
     }
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    // x of the lane selected by the DPP control word (32-bit types)
+    template <int CTRL, typename T> static __device__ __forceinline__ T dpp_get(T x) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+    }
+#endif
     template <typename T> KS_HD T sum(T x) const {
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (sizeof(T) == 4) {
@@ -104,11 +110,22 @@ template <int SUBS> struct Team {
     // smallest d over the team, lowest index among equal values; every lane gets the result
     template <typename T> KS_HD void argmin(T& d, int& i) const {
 #if defined(__HIP_DEVICE_COMPILE__)
-        KS_UNROLL
-        for (int mask = SUBS / 2; mask >= 1; mask >>= 1) {
-            const T od = __shfl_xor(d, mask);
-            const int oi = __shfl_xor(i, mask);
-            if (od < d || (od == d && oi < i)) { d = od; i = oi; }
+        if constexpr (sizeof(T) == 4 && SUBS == 16) {
+            // two DPP butterflies: the minimum, then the lowest index among the lanes that hold it
+            T dm = d;
+            dm = kmin(dm, dpp_get<0x128>(dm)); dm = kmin(dm, dpp_get<0x124>(dm));
+            dm = kmin(dm, dpp_get<0x4E>(dm)); dm = kmin(dm, dpp_get<0xB1>(dm));
+            int c = (d == dm) ? i : 0x7fffffff;
+            c = kmin(c, dpp_get<0x128>(c)); c = kmin(c, dpp_get<0x124>(c));
+            c = kmin(c, dpp_get<0x4E>(c)); c = kmin(c, dpp_get<0xB1>(c));
+            d = dm; i = c;
+        } else {
+            KS_UNROLL
+            for (int mask = SUBS / 2; mask >= 1; mask >>= 1) {
+                const T od = __shfl_xor(d, mask);
+                const int oi = __shfl_xor(i, mask);
+                if (od < d || (od == d && oi < i)) { d = od; i = oi; }
+            }
         }
 #endif
     }
@@ -116,16 +133,38 @@ template <int SUBS> struct Team {
     KS_HD int scan(int x, int& total) const {
         int incl = x;
 #if defined(__HIP_DEVICE_COMPILE__)
-        KS_UNROLL
-        for (int d = 1; d < SUBS; d <<= 1) {
-            const int o = __shfl_up(incl, d, SUBS);
-            if (sub >= d) incl += o;
+        if constexpr (SUBS == 16) {
+            // row_shr:1,2,4,8 with zero fill
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
+            total = __builtin_amdgcn_update_dpp(0, incl, 0x15F, 0xf, 0xf, false);
+        } else {
+            KS_UNROLL
+            for (int d = 1; d < SUBS; d <<= 1) {
+                const int o = __shfl_up(incl, d, SUBS);
+                if (sub >= d) incl += o;
+            }
+            total = __shfl(incl, SUBS - 1, SUBS);
         }
-        total = __shfl(incl, SUBS - 1, SUBS);
 #else
         total = incl;
 #endif
         return incl - x;
+    }
+    // bit k set: team lane k voted true
+    KS_HD unsigned ballot(bool pred) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (SUBS == 1) return pred ? 1u : 0u;
+        else {
+            const unsigned long long b = __ballot(pred);
+            const int base = (int)(__lane_id() & ~(SUBS - 1));
+            return (unsigned)(b >> base) & ((1u << SUBS) - 1u);
+        }
+#else
+        return pred ? 1u : 0u;
+#endif
     }
     // LDS writes of the team members become visible to each other (one wave: program order + a fence)
     KS_HD void sync() const {
@@ -191,6 +230,8 @@ template <typename T> struct Hulls {
     int npair, nhull;
     KS_LDS const PairRec<T>* pair;             // [npair]
     unsigned char hull_pi[NPAIR_MAX];          // pair index of the k-th hull-hull pair
+    int nplane;
+    unsigned char plane_pi[NPAIR_MAX];         // pair index of the k-th plane pair
 };
 template <typename T> KS_HD unsigned plane_pair_mask(const Model<T>& m) {
     unsigned mask = 0;
@@ -202,8 +243,11 @@ template <typename T> KS_HD void hulls_set_pairs(const Model<T>& m, Hulls<T>& hu
     hu.plane_mask = plane_pair_mask(m);
     hu.npair = m.npair;
     hu.nhull = 0;
-    for (int pi = 0; pi < m.npair; pi++)
-        if (!((hu.plane_mask >> pi) & 1u)) hu.hull_pi[hu.nhull++] = (unsigned char)pi;
+    hu.nplane = 0;
+    for (int pi = 0; pi < m.npair; pi++) {
+        if ((hu.plane_mask >> pi) & 1u) hu.plane_pi[hu.nplane++] = (unsigned char)pi;
+        else hu.hull_pi[hu.nhull++] = (unsigned char)pi;
+    }
 }
 template <typename T> KS_HD void fill_pair_rec(const Model<T>& m, const Hulls<T>& hu, int pi, PairRec<T>& r) {
     const int g1 = m.pair_g1[pi], g2 = m.pair_g2[pi];
@@ -979,13 +1023,26 @@ template <typename T> KS_HD void plane_pick(const T* v, T thr2, T cv[4][3], int&
     }
 }
 
+// The two culls of a plane pair (bounding sphere, exact box-vs-plane): false = no vertex can be within the margin
+template <typename T, typename S>
+KS_HD bool plane_may_touch(S scr, KS_LDS const PairRec<T>* prp) {
+    KS_LDS const PairRec<T>& pr = *prp;
+    const T margin = pr.margin, rbound = pr.rbound2;
+    const T size[3] = {pr.size2[0], pr.size2[1], pr.size2[2]};
+    const int o = SCR_GP + (pr.g2 - 1) * 12;
+    const T ln[3] = {scr(o + 6), scr(o + 7), scr(o + 8)}, cdist = scr(o + 11);
+    if (cdist > rbound + margin) return false;
+    return !(cdist - (kabs(ln[0]) * size[0] + kabs(ln[1]) * size[1] + kabs(ln[2]) * size[2]) > margin);
+}
+
 // Ground plane z = 0 (normal +z) vs the hull of geom g2, worked on by the WHOLE team: deepest vertex, then up
 // to 3 more within the margin that are > 0.3*rbound from every accepted vertex (index order).  Every lane
 // scans a contiguous slice of the vertex table; the team then agrees on the deepest vertex and on the
 // ascending list of vertices within the margin, and every lane runs the (short) greedy rule on that list.
 // Returns the number of contacts staged at record `slot`.
 template <typename T, typename S, int SUBS>
-KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* prp) {
+KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* prp, float* prof = nullptr) {
+    KS_T0
     KS_LDS const PairRec<T>& pr = *prp;
     const T PLANE_MESH_TOL = T(0.3);
     const int g2 = pr.g2, slot = pr.slot;
@@ -1018,10 +1075,12 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
             }
         }
     }
+    KS_TICK(12)
     team.argmin(bd, best);
     if (bd > margin) return 0;
     int total = 0;
     const int first = team.scan(mine, total);
+    KS_TICK(4)
     T cv[4][3];
     int nc = 1;
     cv[0][0] = V[4 * best]; cv[0][1] = V[4 * best + 1]; cv[0][2] = V[4 * best + 2];
@@ -1038,6 +1097,7 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
                 if (i0 + j < i_hi && dd[j] <= margin) scr(SCR_CAND + w++) = T(i0 + j);
         }
         team.sync();
+        KS_TICK(7)
         for (int a = 0; a < total && nc < 4; a++) {
             const int i = (int)scr(SCR_CAND + a);
             const T v[3] = {V[4 * i], V[4 * i + 1], V[4 * i + 2]};
@@ -1051,6 +1111,7 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
             if (cdist + dot3(v, ln) <= margin) plane_pick(v, thr2, cv, nc);
         }
     }
+    KS_TICK(23)
     if (team.sub == 0) {
         const T normal[3] = {0, 0, 1};
         KS_UNROLL
@@ -1104,12 +1165,25 @@ KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> te
     const unsigned plane_mask = hu.plane_mask;
     const int npair = hu.npair, nhull = hu.nhull;
     KS_LDS const PairRec<T>* pairs = hu.pair;
-    // plane pairs: the whole team on one pair at a time (team-uniform control flow)
-    for (unsigned mk = plane_mask; mk != 0; mk &= mk - 1) {
-        const int pi = kctz(mk);
-        int c = 0;
-        if (pairs[pi].slot + 4 <= NSTAGE) c = collide_plane_hull(scr, team, pairs + pi);
-        else status |= ST_CONTACT_OVERFLOW;
+    // plane pairs, culls: one pair per lane; the survivors (typically just the object) are then scanned by the
+    // whole team, one pair at a time (team-uniform control flow)
+    const int nplane = hu.nplane;
+    unsigned live = 0;
+    for (int k0 = 0; k0 < nplane; k0 += SUBS) {
+        const int k = k0 + team.sub;
+        bool pass = false;
+        if (k < nplane) {
+            const int pi = hu.plane_pi[k];
+            if (pairs[pi].slot + 4 <= NSTAGE) pass = plane_may_touch(scr, pairs + pi);
+            else status |= ST_CONTACT_OVERFLOW;
+            if (!pass) scr(SCR_PC + pi) = T(0);
+        }
+        live |= team.ballot(pass) << k0;
+    }
+    KS_TICK(11)
+    for (unsigned mk = live; mk != 0; mk &= mk - 1) {
+        const int pi = hu.plane_pi[kctz(mk)];
+        const int c = collide_plane_hull(scr, team, pairs + pi, prof);
         if (team.sub == 0) scr(SCR_PC + pi) = T(c);
     }
     KS_TICK(8)

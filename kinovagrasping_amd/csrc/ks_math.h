@@ -27,6 +27,9 @@ template <> struct Lim<double> { static constexpr double minval = 1e-300; static
 
 KS_HD float ksqrt(float x) { return sqrtf(x); }
 KS_HD double ksqrt(double x) { return sqrt(x); }
+KS_HD float kmin(float a, float b) { return a < b ? a : b; }
+KS_HD double kmin(double a, double b) { return a < b ? a : b; }
+KS_HD int kmin(int a, int b) { return a < b ? a : b; }
 KS_HD int kctz(unsigned x) { return __builtin_ctz(x); }
 // reciprocal square root: the hardware v_rsq_f32 (1 ulp) in fp32 device code
 KS_HD float krsqrt(float x) {

@@ -58,14 +58,18 @@ class Critic(nn.Module):
 
 class DDPGfD:
     def __init__(self, state_dim=82, action_dim=4, max_action=0.8, n=5, discount=0.995, tau=0.0005, batch_size=64,
-                 hidden=(400, 300), device="cpu", process_group=None):
+                 hidden=(400, 300), device="cpu", process_group=None, capturable=False):
         self.device = torch.device(device)
         self.actor = Actor(state_dim, action_dim, max_action, hidden).to(self.device)
         self.actor_target = copy.deepcopy(self.actor)
-        self.actor_optimizer = torch.optim.Adam(self.actor.parameters(), lr=1e-4)
+        # capturable: optimizer state and the update counter live on the device, so that a whole update can be
+        # captured in a HIP graph (pipeline.GraphedTrainer); the arithmetic is the same
+        self.capturable = bool(capturable)
+        self.actor_optimizer = torch.optim.Adam(self.actor.parameters(), lr=1e-4, capturable=self.capturable)
         self.critic = Critic(state_dim, action_dim, hidden).to(self.device)
         self.critic_target = copy.deepcopy(self.critic)
-        self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), weight_decay=1e-4)
+        self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), weight_decay=1e-4, capturable=self.capturable)
+        self._it_dev = torch.zeros((), dtype=torch.long, device=self.device)
         self.discount, self.tau, self.n = discount, tau, n
         self.network_repl_freq = 10
         self.total_it = 0
@@ -105,8 +109,27 @@ class DDPGfD:
         """One DDPGfD update on already-sampled n-step windows: state/next_state [R, n, 82],
         action [R, n, 4], reward [R, n].  `weight` [R] (optional, 0/1) masks padding rows so that
         fixed-shape device batches keep the reference's per-row means.  Returns the four losses
-        (actor, critic, critic_L1, critic_LN) as 0-d tensors (no host sync)."""
-        self.total_it += 1
+        (actor, critic, critic_L1, critic_LN) as 0-d tensors (no host sync).
+
+        The update is three phases with a gradient exchange after the first two (`phase_critic`,
+        `phase_actor`, `phase_targets`); pipeline.GraphedTrainer captures the phases in HIP graphs and runs the
+        exchanges between them."""
+        losses_c = self.phase_critic(state, action, next_state, reward, weight)
+        self._allreduce_grads(list(self.critic.parameters()))
+        actor_loss = self.phase_actor(state, weight)
+        self._allreduce_grads(list(self.actor.parameters()))
+        self.phase_targets()
+        return (actor_loss,) + losses_c
+
+    @staticmethod
+    def _mean(x, per_row, weight):
+        if weight is None:
+            return x.mean()
+        w = weight.view(-1, *([1] * (x.dim() - 1)))
+        return (x * w).sum() / (w.sum() * per_row)
+
+    def phase_critic(self, state, action, next_state, reward, weight=None):
+        """targets + critic loss + backward (DDPGfD.py:256-330).  Returns (critic, L1, LN) losses."""
         reward = reward.unsqueeze(-1)
         with torch.no_grad():
             target_Q = self.critic_target(next_state[:, 0], self.actor_target(next_state[:, 0]))
@@ -117,34 +140,39 @@ class DDPGfD:
             for i in range(self.n):
                 n_step_return += (self.discount ** i) * reward[:, i].squeeze(-1)
             target_QN = (n_step_return + (self.discount ** self.n) * target_critic_val.squeeze(-1)).unsqueeze(-1)
-
-        def mean(x, per_row):
-            if weight is None:
-                return x.mean()
-            w = weight.view(-1, *([1] * (x.dim() - 1)))
-            return (x * w).sum() / (w.sum() * per_row)
-
         current_Q = self.critic(state[:, 0], action[:, 0])
-        critic_L1 = mean((current_Q - target_Q) ** 2, 1)
-        critic_LN = mean((current_Q - target_QN) ** 2, 1)
+        critic_L1 = self._mean((current_Q - target_Q) ** 2, 1, weight)
+        critic_LN = self._mean((current_Q - target_QN) ** 2, 1, weight)
         critic_loss = critic_L1 + 0.5 * critic_LN
         self.critic_optimizer.zero_grad()
         critic_loss.backward()
-        self._allreduce_grads(list(self.critic.parameters()))
-        self.critic_optimizer.step()
+        return critic_loss.detach(), critic_L1.detach(), critic_LN.detach()
 
-        actor_loss = -mean(self.critic(state, self.actor(state)), state.shape[1])
+    def phase_actor(self, state, weight=None):
+        """critic step, then actor loss + backward (DDPGfD.py:331-352)"""
+        self.critic_optimizer.step()
+        actor_loss = -self._mean(self.critic(state, self.actor(state)), state.shape[1], weight)
         self.actor_optimizer.zero_grad()
         actor_loss.backward()
-        self._allreduce_grads(list(self.actor.parameters()))
-        self.actor_optimizer.step()
+        return actor_loss.detach()
 
-        if self.total_it % self.network_repl_freq == 0:
-            with torch.no_grad():
-                for net, tgt in ((self.critic, self.critic_target), (self.actor, self.actor_target)):
+    def phase_targets(self):
+        """actor step + soft target update on every 10th call (DDPGfD.py:353-366)"""
+        self.actor_optimizer.step()
+        self.total_it += 1
+        pairs = ((self.critic, self.critic_target), (self.actor, self.actor_target))
+        with torch.no_grad():
+            if self.capturable:
+                # device-side gate: tau on every network_repl_freq-th call, else 0 (same arithmetic when it fires)
+                self._it_dev += 1
+                gate = (self._it_dev % self.network_repl_freq == 0).to(torch.float32) * self.tau
+                for net, tgt in pairs:
+                    for p, tp in zip(net.parameters(), tgt.parameters()):
+                        tp.copy_(torch.where(gate > 0, gate * p + (1 - gate) * tp, tp))
+            elif self.total_it % self.network_repl_freq == 0:
+                for net, tgt in pairs:
                     for p, tp in zip(net.parameters(), tgt.parameters()):
                         tp.copy_(self.tau * p + (1 - self.tau) * tp)
-        return actor_loss.detach(), critic_loss.detach(), critic_L1.detach(), critic_LN.detach()
 
     def train_batch(self, episode_step, expert_replay_buffer, replay_buffer, num_trajectories=5, prob=0.3):
         """Reference signature (DDPGfD.py:219): samples agent (1-prob) / expert (prob) episodes from

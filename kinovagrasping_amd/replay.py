@@ -53,71 +53,91 @@ class HostEpisodeReplay:
 
 class DeviceEpisodeReplay:
     """Fixed-shape episode ring on the GPU: [capacity, horizon, ...] plus per-episode lengths.
-    Envs append to their own open episode; a finished episode is committed to the ring (FIFO)."""
+    Envs append to their own open episode; a finished episode is committed to the ring (FIFO).
+
+    Every method is a fixed sequence of fixed-shape device ops - no host synchronisation, no data-dependent
+    shapes - so a whole rollout step can be captured in a HIP graph.  Masked rows are handled with
+    torch.where; episodes that are not committed are copied to a trash row behind the ring."""
 
     def __init__(self, n_envs, capacity, horizon=30, state_dim=82, action_dim=4, n_steps=5, device="cuda"):
         self.n_envs, self.capacity, self.horizon, self.n_steps = n_envs, capacity, horizon, n_steps
         self.device = torch.device(device)
         z = lambda *s: torch.zeros(*s, device=self.device)
-        self.ep_state, self.ep_next = z(capacity, horizon, state_dim), z(capacity, horizon, state_dim)
-        self.ep_action, self.ep_reward, self.ep_not_done = z(capacity, horizon, action_dim), z(capacity, horizon), z(capacity, horizon)
-        self.ep_len = torch.zeros(capacity, dtype=torch.long, device=self.device)
-        self.count, self.head = 0, 0                      # committed episodes, next ring slot
+        rows = capacity + 1                                # row `capacity` is the trash row
+        self.ep_state, self.ep_next = z(rows, horizon, state_dim), z(rows, horizon, state_dim)
+        self.ep_action, self.ep_reward, self.ep_not_done = z(rows, horizon, action_dim), z(rows, horizon), z(rows, horizon)
+        self.ep_len = torch.zeros(rows, dtype=torch.long, device=self.device)
+        self._count = torch.zeros((), dtype=torch.long, device=self.device)   # committed episodes
+        self._head = torch.zeros((), dtype=torch.long, device=self.device)    # next ring slot
         self.cur_state, self.cur_next = z(n_envs, horizon, state_dim), z(n_envs, horizon, state_dim)
         self.cur_action, self.cur_reward, self.cur_not_done = z(n_envs, horizon, action_dim), z(n_envs, horizon), z(n_envs, horizon)
         self.cur_len = torch.zeros(n_envs, dtype=torch.long, device=self.device)
         self._env_ar = torch.arange(n_envs, device=self.device)
+        self._all = torch.ones(n_envs, dtype=torch.bool, device=self.device)
+        self._row = torch.arange(horizon - n_steps, device=self.device).unsqueeze(0)
+        self._win = torch.arange(n_steps, device=self.device)
+
+    @property
+    def count(self):
+        """committed episodes (host read: synchronises)"""
+        return int(self._count)
+
+    @property
+    def head(self):
+        return int(self._head)
 
     def add(self, state, action, next_state, reward, done, store_mask=None):
         """Append one transition per env (where store_mask is True; utils.py:34-64)."""
-        m = torch.ones(self.n_envs, dtype=torch.bool, device=self.device) if store_mask is None else store_mask
-        t = self.cur_len.clamp(max=self.horizon - 1)
-        idx = self._env_ar[m]
-        tt = t[m]
-        self.cur_state[idx, tt] = state[m]
-        self.cur_next[idx, tt] = next_state[m]
-        self.cur_action[idx, tt] = action[m]
-        self.cur_reward[idx, tt] = reward[m]
-        self.cur_not_done[idx, tt] = 1.0 - done[m].float()
-        self.cur_len[idx] = tt + 1
+        m = self._all if store_mask is None else store_mask
+        ar, t = self._env_ar, self.cur_len.clamp(max=self.horizon - 1)
+        mc = m.unsqueeze(1)
+        self.cur_state[ar, t] = torch.where(mc, state, self.cur_state[ar, t])
+        self.cur_next[ar, t] = torch.where(mc, next_state, self.cur_next[ar, t])
+        self.cur_action[ar, t] = torch.where(mc, action, self.cur_action[ar, t])
+        self.cur_reward[ar, t] = torch.where(m, reward, self.cur_reward[ar, t])
+        self.cur_not_done[ar, t] = torch.where(m, 1.0 - done.float(), self.cur_not_done[ar, t])
+        self.cur_len.copy_(torch.where(m, t + 1, self.cur_len))
 
     def replace_last(self, env_mask, reward):
         """utils.py:309-343: overwrite the last stored transition of the open episode with the lift outcome."""
-        idx = self._env_ar[env_mask & (self.cur_len > 0)]
-        last = self.cur_len[idx] - 1
-        self.cur_reward[idx, last] = reward[idx]
-        self.cur_not_done[idx, last] = 0.0
+        m = env_mask & (self.cur_len > 0)
+        ar, last = self._env_ar, (self.cur_len - 1).clamp(min=0)
+        self.cur_reward[ar, last] = torch.where(m, reward, self.cur_reward[ar, last])
+        self.cur_not_done[ar, last] = torch.where(m, torch.zeros_like(reward), self.cur_not_done[ar, last])
 
     def end_episodes(self, env_mask):
-        """Commit the open episodes of `env_mask` envs; episodes with len - n <= 1 are dropped
-        (main_DDPGfD.py:469-471)."""
+        """Commit the open episodes of `env_mask` envs in env order; episodes with len - n <= 1 are dropped
+        (main_DDPGfD.py:469-471).  Returns the number committed as a 0-d device tensor."""
         keep = env_mask & (self.cur_len - self.n_steps > 1)
-        idx = self._env_ar[keep]
-        k = int(idx.numel())
-        if k:
-            slots = (self.head + torch.arange(k, device=self.device)) % self.capacity
-            self.ep_state[slots], self.ep_next[slots] = self.cur_state[idx], self.cur_next[idx]
-            self.ep_action[slots], self.ep_reward[slots], self.ep_not_done[slots] = self.cur_action[idx], self.cur_reward[idx], self.cur_not_done[idx]
-            self.ep_len[slots] = self.cur_len[idx]
-            self.head = (self.head + k) % self.capacity
-            self.count = min(self.capacity, self.count + k)
-        self.cur_len[env_mask] = 0
+        rank = torch.cumsum(keep.long(), 0) - 1
+        slots = torch.where(keep, (self._head + rank) % self.capacity, torch.full_like(rank, self.capacity))
+        self.ep_state.index_copy_(0, slots, self.cur_state)
+        self.ep_next.index_copy_(0, slots, self.cur_next)
+        self.ep_action.index_copy_(0, slots, self.cur_action)
+        self.ep_reward.index_copy_(0, slots, self.cur_reward)
+        self.ep_not_done.index_copy_(0, slots, self.cur_not_done)
+        self.ep_len.index_copy_(0, slots, self.cur_len)
+        k = keep.sum()
+        self._head.copy_((self._head + k) % self.capacity)
+        self._count.copy_((self._count + k).clamp(max=self.capacity))
+        self.cur_len.copy_(torch.where(env_mask, torch.zeros_like(self.cur_len), self.cur_len))
         return k
 
     def sample_batch_nstep(self, batch_size, generator=None):
         """Fixed-shape batch: batch_size episodes x (horizon - n) window rows, padding rows have weight 0.
         Returns state [R,n,S], action [R,n,A], next_state [R,n,S], reward [R,n], not_done [R,n], weight [R]."""
         n, W = self.n_steps, self.horizon - self.n_steps
-        hi = max(1, self.count - 1)                        # newest episode excluded (utils.py:259)
-        ep = torch.randint(hi, (batch_size,), device=self.device, generator=generator)
+        hi = (self._count - 1).clamp(min=1)                # newest episode excluded (utils.py:259)
+        ue = torch.rand(batch_size, device=self.device, generator=generator)
+        ep = torch.minimum((ue * hi).long(), hi - 1)
         ceiling = (self.ep_len[ep] - n).clamp(min=1)       # [B]
-        row = torch.arange(W, device=self.device).unsqueeze(0)              # [1,W]
+        row = self._row                                                      # [1,W]
         u = torch.rand(batch_size, W, device=self.device, generator=generator)
         start = (u * ceiling.unsqueeze(1)).long().clamp(max=self.horizon - n)
         start = torch.where(row == (ceiling.unsqueeze(1) - 1), ceiling.unsqueeze(1).expand(-1, W), start)
         start = start.clamp(max=self.horizon - n)
         weight = (row < ceiling.unsqueeze(1)).float().reshape(-1)
-        t = start.unsqueeze(-1) + torch.arange(n, device=self.device)        # [B,W,n]
+        t = start.unsqueeze(-1) + self._win                                  # [B,W,n]
         e = ep.view(-1, 1, 1).expand(-1, W, n)
         g = lambda x: x[e, t].reshape(batch_size * W, n, *x.shape[2:])
         return g(self.ep_state), g(self.ep_action), g(self.ep_next), g(self.ep_reward), g(self.ep_not_done), weight

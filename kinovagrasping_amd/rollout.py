@@ -25,11 +25,15 @@ SKIP_NUM_TS = 6                         # main_DDPGfD.py:418
 def check_grasp(f_dist_old: torch.Tensor, f_dist_new: torch.Tensor) -> torch.Tensor:
     """Batched expert_data.check_grasp: inputs [N, 8] = obs[:, 9:17]; True where the summed |dx| of the
     three distal fingertips per substep is below 2e-4."""
-    d = (f_dist_old[:, (0, 3, 6)] - f_dist_new[:, (0, 3, 6)]).abs() / 15.0
+    d = (f_dist_old[:, 0:7:3] - f_dist_new[:, 0:7:3]).abs() / 15.0     # x of the three fingertips (columns 0, 3, 6)
     return d.sum(1) < 0.0002
 
 
 class RolloutEngine:
+    """State lives in fixed tensors that are updated in place and every op has a fixed shape, so `pre()` (action
+    selection) and `post()` (replay + bookkeeping) can each be captured in a HIP graph (pipeline.GraphedTrainer);
+    `step()` is the plain eager sequence pre -> sim -> post."""
+
     def __init__(self, sim, policy, replay=None, expl_noise=0.1, max_action=0.8, generator=None):
         self.sim, self.policy, self.replay = sim, policy, replay
         self.n = sim.n_envs
@@ -40,62 +44,76 @@ class RolloutEngine:
         self.lift_action = torch.tensor(LIFT_ACTION, device=dev).expand(self.n, 4)
         self.t = torch.zeros(self.n, dtype=torch.long, device=dev)           # steps taken in the episode
         self.ready = torch.zeros(self.n, dtype=torch.bool, device=dev)       # ready_for_lift (latched)
-        self.prev_obs = None
-        self.obs = None
+        self.lifting = torch.zeros(self.n, dtype=torch.bool, device=dev)     # ready at the time of the action
+        self.has_prev = torch.zeros(self.n, dtype=torch.bool, device=dev)
+        self.obs = torch.zeros(self.n, 82, device=dev)
+        self.prev_obs = torch.zeros(self.n, 82, device=dev)
+        self.action = torch.zeros(self.n, 4, device=dev)
+        self.action_t = torch.zeros(4, self.n, device=dev)                   # field-major copy for ks_step
+        self.reward_out = torch.zeros(self.n, device=dev)
+        self.done_out = torch.zeros(self.n, dtype=torch.bool, device=dev)
         self.episodes_done = 0
         self.lift_success = 0
 
     def start(self, obs):
         """obs [N, 82]: observations returned by the reset"""
-        self.obs = obs.clone()
-        self.prev_obs = None
+        self.obs.copy_(obs)
+        self.prev_obs.copy_(obs)
+        self.has_prev.zero_()
         self.t.zero_()
         self.ready.zero_()
 
     @torch.no_grad()
-    def act(self):
+    def pre(self):
+        """Action selection for every env -> self.action [N,4] / self.action_t [4,N]."""
         timestep = self.t + 1                                              # main_DDPGfD.py:425
-        if self.prev_obs is not None:
-            chk = check_grasp(self.prev_obs[:, 9:17], self.obs[:, 9:17]) & (timestep >= SKIP_NUM_TS) & self.has_prev
-            self.ready |= chk
+        chk = check_grasp(self.prev_obs[:, 9:17], self.obs[:, 9:17]) & (timestep >= SKIP_NUM_TS) & self.has_prev
+        self.ready |= chk
         a = self.policy.actor(self.obs)
         noise = torch.randn(a.shape, device=a.device, generator=self.gen) * self.sigma
         a = (a + noise).clamp_(0.0, self.max_action)
-        return torch.where(self.ready.unsqueeze(1), self.lift_action, a)
+        self.action.copy_(torch.where(self.ready.unsqueeze(1), self.lift_action, a))
+        self.action_t.copy_(self.action.t())
+        self.lifting.copy_(self.ready)
+
+    def act(self):
+        self.pre()
+        return self.action
 
     @torch.no_grad()
+    def post(self):
+        """Consume the sim's output buffers: replay writes and per-env bookkeeping for the next step."""
+        sim = self.sim
+        obs, reward = sim.obs, sim.reward
+        done_b = sim.done != 0
+        state, lifting = self.obs, self.lifting
+        # the transition's next_state is the terminal observation for envs that just finished
+        next_state = torch.where(done_b.unsqueeze(1), sim.final_obs, obs) if sim.cfg.auto_reset else obs
+        if self.replay is not None:
+            self.replay.add(state, self.action, next_state, reward, done_b, store_mask=~lifting)
+            self.replay.replace_last(done_b & lifting, reward)
+            self.replay.end_episodes(done_b)
+        # bookkeeping for the next step (auto-reset envs start a new episode)
+        self.prev_obs.copy_(torch.where(done_b.unsqueeze(1), obs, state))
+        self.has_prev.copy_(~done_b)
+        self.obs.copy_(obs)
+        self.t.copy_(torch.where(done_b, torch.zeros_like(self.t), self.t + 1))
+        self.ready &= ~done_b
+        self.reward_out.copy_(reward)
+        self.done_out.copy_(done_b)
+
     def step(self, after_act=None, after_launch=None, before_store=None):
         """One env-step for every env.  Returns (reward, done) of the step.  Hooks for running the learner
         beside the sim kernel on a second stream: `after_act()` right after the actor forward has been
         enqueued (record an event there), `after_launch()` right after the sim kernels have been enqueued
         (enqueue the update there), `before_store()` before the replay is written."""
-        if self.prev_obs is None:
-            self.has_prev = torch.zeros(self.n, dtype=torch.bool, device=self.obs.device)
-            self.prev_obs = self.obs.clone()
-        action = self.act()
+        self.pre()
         if after_act is not None:
             after_act()
-        lifting = self.ready.clone()
-        state = self.obs
-        obs, reward, done, info = self.sim.step(action.t().contiguous())
+        self.sim.step(self.action_t)
         if after_launch is not None:
             after_launch()
         if before_store is not None:
             before_store()
-        done_b = done != 0
-        # the transition's next_state is the terminal observation for envs that just finished
-        next_state = torch.where(done_b.unsqueeze(1), self.sim.final_obs, obs) if self.sim.cfg.auto_reset else obs
-        if self.replay is not None:
-            self.replay.add(state, action, next_state, reward, done_b, store_mask=~lifting)
-            ended_lifting = done_b & lifting
-            if ended_lifting.any():
-                self.replay.replace_last(ended_lifting, reward)
-            if done_b.any():
-                self.replay.end_episodes(done_b)
-        # bookkeeping for the next step (auto-reset envs start a new episode)
-        self.prev_obs = torch.where(done_b.unsqueeze(1), obs, state)
-        self.has_prev = ~done_b
-        self.obs = obs.clone()
-        self.t = torch.where(done_b, torch.zeros_like(self.t), self.t + 1)
-        self.ready &= ~done_b
-        return reward, done_b
+        self.post()
+        return self.reward_out, self.done_out

@@ -9,7 +9,7 @@ base = scenarios.config_actions(256, 30)
 acts = torch.as_tensor(np.tile(base, (1, 1, n // 256))).cuda()
 sim = KinovaSim(n, "CubeS", auto_reset=True, horizon=30, contact_tap=True)
 sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
-names = ["fk+dyn", "collision", "constraints", "chol M", "newton", "euler", "total", "ncon", "c:plane pairs", "c:hull pairs", "c:merge", "-", "-", "n:warm cost", "n:H assembly", "n:team reduce", "n:chol+solve", "n:p proj", "n:linesearch", "n:update", "n:forces", "#newton iters", "#ls iters", "-"]
+names = ["fk+dyn", "collision", "constraints", "chol M", "p:scan->argmin+scan", "euler", "total", "p:cand list", "c:plane pairs", "c:hull pairs", "c:merge", "p:culls", "p:rec+pose+slice scan", "n:warm cost", "n:H assembly", "n:team reduce", "n:chol+solve", "n:p proj", "n:linesearch", "n:update", "n:forces", "#newton iters", "#ls iters", "p:greedy"]
 acc = np.zeros((24,))
 accmax = np.zeros((24,))
 for t in range(30):
