@@ -1,0 +1,76 @@
+/* include/kinova_rollout.h -- C ABI of the batched rollout / replay kernels in libkinova_sim.so.
+ *
+ * The reference drives ONE env from Python and keeps its replay in Python lists; for N envs in lock step the same
+ * bookkeeping is a handful of per-env elementwise rules.  Each entry point below is one kernel launch that replaces
+ * the loop body named beside it (reference root /root/reference/gym-kinova-gripper):
+ *
+ *   kr_select_action    main_DDPGfD.py:425-451  check_grasp latch (expert_data.py:559-593), exploration noise,
+ *                                               clip, scripted lift action
+ *   kr_store_transition main_DDPGfD.py:443-471  replay_buffer.add (utils.py:34-64) for envs that are not lifting,
+ *                                               replace (utils.py:309-343) when an episode ends during the lift,
+ *                                               per-episode counters; decides which episodes are kept (len-n > 1)
+ *   kr_rank_episodes    utils.py:66-90          FIFO slot of every kept episode (env order)
+ *   kr_commit_episodes  utils.py:66-90          copy the kept open episodes into the episode ring
+ *   kr_advance_ring     utils.py:66-90          ring head / count, open-episode lengths of finished envs
+ *   kr_sample_windows   utils.py:240-306        sample_batch_nstep: per sampled episode, ceiling-1 uniform window
+ *                                               starts + the final window, as ONE fixed-shape padded batch
+ *
+ * Conventions: all pointers are DEVICE pointers owned by the caller (PyTorch tensors); bool arrays are one byte per
+ * element; counters are int64; float data is fp32, row-major; every call is asynchronous on `stream` (hipStream_t
+ * as void*) and does no host synchronisation, so sequences of them can be captured in a HIP graph.
+ * Return value: 0, or a negative ks_status (kinova_sim.h).
+ */
+#ifndef KINOVA_ROLLOUT_H
+#define KINOVA_ROLLOUT_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KR_STATE_DIM 82
+#define KR_ACTION_DIM 4
+
+/* action selection for n envs.  obs/prev_obs [n,82], has_prev/ready/lifting bool [n], t int64 [n] (steps taken in
+ * the episode), actor_out [n,4] = pi(obs), noise [n,4] ~ N(0,1).  ready is updated in place (latched),
+ * action [n,4], action_t [4,n] (the layout ks_step takes) and lifting (= ready at the time of the action) are written. */
+int kr_select_action(int32_t n, const float *obs, const float *prev_obs, const uint8_t *has_prev, const int64_t *t, uint8_t *ready,
+                     const float *actor_out, const float *noise, float sigma, float max_action, int32_t skip_steps,
+                     float *action, float *action_t, uint8_t *lifting, void *stream);
+
+/* replay write + bookkeeping after ks_step.  sim_obs/sim_final_obs [n,82], sim_reward [n], sim_done uint8 [n]
+ * (non-zero = finished), auto_reset as in ks_config.  Engine state (in/out): obs (the state the action was taken
+ * in; becomes the new observation), prev_obs, has_prev, t, ready; lifting/action from kr_select_action.
+ * Open episodes (in/out): cur_state/cur_next [n,H,82], cur_action [n,H,4], cur_reward/cur_not_done [n,H],
+ * cur_len int64 [n].  Outputs: reward_out [n], done_out bool [n], keep bool [n] (finished AND len - n_steps > 1). */
+int kr_store_transition(int32_t n, int32_t horizon, int32_t n_steps, int32_t auto_reset, int32_t with_replay,
+                        const float *sim_obs, const float *sim_final_obs, const float *sim_reward, const uint8_t *sim_done,
+                        float *obs, float *prev_obs, uint8_t *has_prev, int64_t *t, uint8_t *ready, const uint8_t *lifting,
+                        const float *action, float *cur_state, float *cur_next, float *cur_action, float *cur_reward,
+                        float *cur_not_done, int64_t *cur_len, float *reward_out, uint8_t *done_out, uint8_t *keep, void *stream);
+
+/* rank [n] int64: number of kept episodes among envs 0..i (inclusive); total int64 [1] */
+int kr_rank_episodes(int32_t n, const uint8_t *keep, int64_t *rank, int64_t *total, void *stream);
+
+/* ring rows ep_* [capacity(+), H, ...], ep_len int64; kept env i goes to slot (head + rank[i] - 1) % capacity */
+int kr_commit_episodes(int32_t n, int32_t horizon, int32_t capacity, const uint8_t *keep, const int64_t *rank, const int64_t *head,
+                       const float *cur_state, const float *cur_next, const float *cur_action, const float *cur_reward,
+                       const float *cur_not_done, const int64_t *cur_len, float *ep_state, float *ep_next, float *ep_action,
+                       float *ep_reward, float *ep_not_done, int64_t *ep_len, void *stream);
+
+/* head = (head + total) % capacity, count = min(capacity, count + total), cur_len[i] = 0 where ended[i] */
+int kr_advance_ring(int32_t n, int32_t capacity, const int64_t *total, int64_t *head, int64_t *count, const uint8_t *ended,
+                    int64_t *cur_len, void *stream);
+
+/* n-step window batch: B episodes x W = horizon - n_steps rows.  u_ep [B], u_start [B,W] uniform in [0,1).
+ * Outputs state/next_state [B*W,n_steps,82], action [B*W,n_steps,4], reward/not_done [B*W,n_steps], weight [B*W]
+ * (1 for real windows, 0 for padding rows). */
+int kr_sample_windows(int32_t batch, int32_t horizon, int32_t n_steps, const int64_t *count, const int64_t *ep_len, const float *u_ep,
+                      const float *u_start, const float *ep_state, const float *ep_next, const float *ep_action, const float *ep_reward,
+                      const float *ep_not_done, float *state, float *action, float *next_state, float *reward, float *not_done,
+                      float *weight, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

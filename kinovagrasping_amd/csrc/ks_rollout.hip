@@ -1,0 +1,254 @@
+// ks_rollout.hip -- batched rollout / replay bookkeeping kernels (C ABI: include/kinova_rollout.h).
+//
+// Every kernel is HBM-streaming elementwise work on struct-of-rows tensors owned by PyTorch: one wavefront per
+// env (or per sampled window row), lanes across the 82 observation columns, so that row reads/writes are
+// coalesced 256-byte bursts.  No LDS, no atomics; the only cross-env step (FIFO ranks of the kept episodes) is a
+// single-block scan.  The torch implementations in rollout.py / replay.py are the checkers of these kernels.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "../../include/kinova_rollout.h"
+#include "../../include/kinova_sim.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int S = KR_STATE_DIM, A = KR_ACTION_DIM;
+
+// scripted lift: wrist_lift_velocity, finger_lift_velocity x3 (main_DDPGfD.py:945-947)
+__device__ __forceinline__ float lift_action(int k) { return k == 0 ? 0.6f : 0.5f; }
+
+__global__ __launch_bounds__(256) void k_select_action(int n, const float* __restrict__ obs, const float* __restrict__ prev_obs,
+                                                       const uint8_t* __restrict__ has_prev, const int64_t* __restrict__ t, uint8_t* ready,
+                                                       const float* __restrict__ actor_out, const float* __restrict__ noise, float sigma,
+                                                       float max_action, int skip_steps, float* __restrict__ action,
+                                                       float* __restrict__ action_t, uint8_t* __restrict__ lifting) {
+    // no fma contraction in this kernel: the products are rounded before the sums, bit-identical to the torch expressions
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // check_grasp on obs[9:17]: x of the three distal fingertips (columns 9, 12, 15), per substep (frame_skip 15)
+    const float* o = obs + (long)i * S;
+    const float* p = prev_obs + (long)i * S;
+    float d = fabsf(p[9] - o[9]) / 15.0f;
+    d += fabsf(p[12] - o[12]) / 15.0f;
+    d += fabsf(p[15] - o[15]) / 15.0f;
+    const bool chk = d < 0.0002f && (t[i] + 1 >= skip_steps) && has_prev[i] != 0;
+    const bool rdy = ready[i] != 0 || chk;
+    ready[i] = rdy;
+    lifting[i] = rdy;
+#pragma unroll
+    for (int k = 0; k < A; k++) {
+        float a = actor_out[(long)i * A + k] + noise[(long)i * A + k] * sigma;
+        a = fminf(fmaxf(a, 0.0f), max_action);
+        a = rdy ? lift_action(k) : a;
+        action[(long)i * A + k] = a;
+        action_t[(long)k * n + i] = a;
+    }
+}
+
+// one wave per env
+__global__ __launch_bounds__(WAVE) void k_store_transition(int n, int H, int n_steps, int auto_reset, int with_replay,
+                                                           const float* __restrict__ sim_obs, const float* __restrict__ sim_final,
+                                                           const float* __restrict__ sim_reward, const uint8_t* __restrict__ sim_done,
+                                                           float* obs, float* prev_obs, uint8_t* has_prev, int64_t* t, uint8_t* ready,
+                                                           const uint8_t* __restrict__ lifting, const float* __restrict__ action,
+                                                           float* cur_state, float* cur_next, float* cur_action, float* cur_reward,
+                                                           float* cur_not_done, int64_t* cur_len, float* reward_out, uint8_t* done_out,
+                                                           uint8_t* keep) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n) return;
+    const bool done = sim_done[i] != 0, lift = lifting[i] != 0;
+    const float rew = sim_reward[i];
+    const bool store = with_replay && !lift;
+    const long len0 = with_replay ? cur_len[i] : 0;
+    const long tt = len0 < H - 1 ? len0 : H - 1;
+    const long row = ((long)i * H + tt);
+    for (int c = lane; c < S; c += WAVE) {
+        const float so = sim_obs[(long)i * S + c];
+        const float st = obs[(long)i * S + c];
+        const float nx = (done && auto_reset) ? sim_final[(long)i * S + c] : so;
+        if (store) { cur_state[row * S + c] = st; cur_next[row * S + c] = nx; }
+        prev_obs[(long)i * S + c] = done ? so : st;
+        obs[(long)i * S + c] = so;
+    }
+    if (store && lane < A) cur_action[row * A + lane] = action[(long)i * A + lane];
+    if (lane == 0) {
+        long len1 = len0;
+        if (store) {
+            cur_reward[row] = rew;
+            cur_not_done[row] = done ? 0.0f : 1.0f;
+            len1 = tt + 1;
+        }
+        if (with_replay) {
+            // the episode ended during the scripted lift: the last stored transition carries the outcome
+            if (done && lift && len1 > 0) {
+                cur_reward[(long)i * H + len1 - 1] = rew;
+                cur_not_done[(long)i * H + len1 - 1] = 0.0f;
+            }
+            cur_len[i] = len1;
+            keep[i] = done && (len1 - n_steps > 1);
+        }
+        has_prev[i] = !done;
+        t[i] = done ? 0 : t[i] + 1;
+        ready[i] = (ready[i] != 0) && !done;
+        reward_out[i] = rew;
+        done_out[i] = done;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_rank_episodes(int n, const uint8_t* __restrict__ keep, int64_t* __restrict__ rank, int64_t* total) {
+    using Scan = hipcub::BlockScan<int, 1024>;
+    __shared__ typename Scan::TempStorage tmp;
+    const int per = (n + 1023) / 1024, i0 = threadIdx.x * per, i1 = min(i0 + per, n);
+    int local = 0;
+    for (int i = i0; i < i1; i++) local += keep[i] != 0;
+    int before = 0, all = 0;
+    Scan(tmp).ExclusiveSum(local, before, all);
+    for (int i = i0; i < i1; i++) {
+        before += keep[i] != 0;
+        rank[i] = before;
+    }
+    if (threadIdx.x == 0) total[0] = all;
+}
+
+// one wave per env; only kept envs move data
+__global__ __launch_bounds__(WAVE) void k_commit_episodes(int n, int H, int capacity, const uint8_t* __restrict__ keep,
+                                                          const int64_t* __restrict__ rank, const int64_t* __restrict__ head,
+                                                          const float* __restrict__ cur_state, const float* __restrict__ cur_next,
+                                                          const float* __restrict__ cur_action, const float* __restrict__ cur_reward,
+                                                          const float* __restrict__ cur_not_done, const int64_t* __restrict__ cur_len,
+                                                          float* ep_state, float* ep_next, float* ep_action, float* ep_reward,
+                                                          float* ep_not_done, int64_t* ep_len) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n || keep[i] == 0) return;
+    const long slot = (head[0] + rank[i] - 1) % capacity;
+    const long src = (long)i * H, dst = slot * H;
+    for (int k = lane; k < H * S; k += WAVE) {
+        ep_state[dst * S + k] = cur_state[src * S + k];
+        ep_next[dst * S + k] = cur_next[src * S + k];
+    }
+    for (int k = lane; k < H * A; k += WAVE) ep_action[dst * A + k] = cur_action[src * A + k];
+    for (int k = lane; k < H; k += WAVE) {
+        ep_reward[dst + k] = cur_reward[src + k];
+        ep_not_done[dst + k] = cur_not_done[src + k];
+    }
+    if (lane == 0) ep_len[slot] = cur_len[i];
+}
+
+__global__ __launch_bounds__(256) void k_advance_ring(int n, int capacity, const int64_t* __restrict__ total, int64_t* head, int64_t* count,
+                                                      const uint8_t* __restrict__ ended, int64_t* cur_len) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        const long k = total[0];
+        head[0] = (head[0] + k) % capacity;
+        const long c = count[0] + k;
+        count[0] = c < capacity ? c : capacity;
+    }
+    if (i < n && ended[i] != 0) cur_len[i] = 0;
+}
+
+// one wave per window row (b, w)
+__global__ __launch_bounds__(WAVE) void k_sample_windows(int B, int H, int n_steps, const int64_t* __restrict__ count,
+                                                         const int64_t* __restrict__ ep_len, const float* __restrict__ u_ep,
+                                                         const float* __restrict__ u_start, const float* __restrict__ ep_state,
+                                                         const float* __restrict__ ep_next, const float* __restrict__ ep_action,
+                                                         const float* __restrict__ ep_reward, const float* __restrict__ ep_not_done,
+                                                         float* __restrict__ state, float* __restrict__ action, float* __restrict__ next_state,
+                                                         float* __restrict__ reward, float* __restrict__ not_done, float* __restrict__ weight) {
+    const int W = H - n_steps;
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= B * W) return;
+    const int b = r / W, w = r % W;
+    long hi = count[0] - 1;                    // the newest episode is never sampled (utils.py:259)
+    hi = hi > 1 ? hi : 1;
+    long ep = (long)(u_ep[b] * (float)hi);
+    ep = ep < hi - 1 ? ep : hi - 1;
+    long ceiling = ep_len[ep] - n_steps;
+    ceiling = ceiling > 1 ? ceiling : 1;
+    long start = (long)(u_start[(long)b * W + w] * (float)ceiling);
+    start = start < H - n_steps ? start : H - n_steps;
+    if (w == ceiling - 1) start = ceiling;     // the final window of the episode (utils.py:283-301)
+    start = start < H - n_steps ? start : H - n_steps;
+    const long src = ep * H + start, dst = (long)r * n_steps;
+    for (int k = lane; k < n_steps * S; k += WAVE) {
+        state[dst * S + k] = ep_state[src * S + k];
+        next_state[dst * S + k] = ep_next[src * S + k];
+    }
+    for (int k = lane; k < n_steps * A; k += WAVE) action[dst * A + k] = ep_action[src * A + k];
+    if (lane < n_steps) {
+        reward[dst + lane] = ep_reward[src + lane];
+        not_done[dst + lane] = ep_not_done[src + lane];
+    }
+    if (lane == 0) weight[r] = w < ceiling ? 1.0f : 0.0f;
+}
+
+inline int launched() { return hipGetLastError() == hipSuccess ? KS_OK : KS_ERR_HIP; }
+
+}  // namespace
+
+extern "C" {
+
+int kr_select_action(int32_t n, const float* obs, const float* prev_obs, const uint8_t* has_prev, const int64_t* t, uint8_t* ready,
+                     const float* actor_out, const float* noise, float sigma, float max_action, int32_t skip_steps, float* action,
+                     float* action_t, uint8_t* lifting, void* stream) {
+    if (n <= 0 || !obs || !prev_obs || !has_prev || !t || !ready || !actor_out || !noise || !action || !action_t || !lifting) return KS_ERR_INVALID;
+    hipLaunchKernelGGL(k_select_action, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, obs, prev_obs, has_prev, t, ready, actor_out,
+                       noise, sigma, max_action, skip_steps, action, action_t, lifting);
+    return launched();
+}
+
+int kr_store_transition(int32_t n, int32_t horizon, int32_t n_steps, int32_t auto_reset, int32_t with_replay, const float* sim_obs,
+                        const float* sim_final_obs, const float* sim_reward, const uint8_t* sim_done, float* obs, float* prev_obs,
+                        uint8_t* has_prev, int64_t* t, uint8_t* ready, const uint8_t* lifting, const float* action, float* cur_state,
+                        float* cur_next, float* cur_action, float* cur_reward, float* cur_not_done, int64_t* cur_len, float* reward_out,
+                        uint8_t* done_out, uint8_t* keep, void* stream) {
+    if (n <= 0 || !sim_obs || !sim_reward || !sim_done || !obs || !prev_obs || !has_prev || !t || !ready || !lifting || !reward_out || !done_out)
+        return KS_ERR_INVALID;
+    if (auto_reset && !sim_final_obs) return KS_ERR_INVALID;
+    if (with_replay && (!action || !cur_state || !cur_next || !cur_action || !cur_reward || !cur_not_done || !cur_len || !keep)) return KS_ERR_INVALID;
+    hipLaunchKernelGGL(k_store_transition, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, n, horizon, n_steps, auto_reset, with_replay, sim_obs,
+                       sim_final_obs, sim_reward, sim_done, obs, prev_obs, has_prev, t, ready, lifting, action, cur_state, cur_next, cur_action,
+                       cur_reward, cur_not_done, cur_len, reward_out, done_out, keep);
+    return launched();
+}
+
+int kr_rank_episodes(int32_t n, const uint8_t* keep, int64_t* rank, int64_t* total, void* stream) {
+    if (n <= 0 || !keep || !rank || !total) return KS_ERR_INVALID;
+    hipLaunchKernelGGL(k_rank_episodes, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, keep, rank, total);
+    return launched();
+}
+
+int kr_commit_episodes(int32_t n, int32_t horizon, int32_t capacity, const uint8_t* keep, const int64_t* rank, const int64_t* head,
+                       const float* cur_state, const float* cur_next, const float* cur_action, const float* cur_reward,
+                       const float* cur_not_done, const int64_t* cur_len, float* ep_state, float* ep_next, float* ep_action, float* ep_reward,
+                       float* ep_not_done, int64_t* ep_len, void* stream) {
+    if (n <= 0 || capacity <= 0 || !keep || !rank || !head || !cur_state || !cur_next || !cur_action || !cur_reward || !cur_not_done || !cur_len ||
+        !ep_state || !ep_next || !ep_action || !ep_reward || !ep_not_done || !ep_len)
+        return KS_ERR_INVALID;
+    hipLaunchKernelGGL(k_commit_episodes, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, n, horizon, capacity, keep, rank, head, cur_state, cur_next,
+                       cur_action, cur_reward, cur_not_done, cur_len, ep_state, ep_next, ep_action, ep_reward, ep_not_done, ep_len);
+    return launched();
+}
+
+int kr_advance_ring(int32_t n, int32_t capacity, const int64_t* total, int64_t* head, int64_t* count, const uint8_t* ended, int64_t* cur_len,
+                    void* stream) {
+    if (n <= 0 || capacity <= 0 || !total || !head || !count || !ended || !cur_len) return KS_ERR_INVALID;
+    hipLaunchKernelGGL(k_advance_ring, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, capacity, total, head, count, ended, cur_len);
+    return launched();
+}
+
+int kr_sample_windows(int32_t batch, int32_t horizon, int32_t n_steps, const int64_t* count, const int64_t* ep_len, const float* u_ep,
+                      const float* u_start, const float* ep_state, const float* ep_next, const float* ep_action, const float* ep_reward,
+                      const float* ep_not_done, float* state, float* action, float* next_state, float* reward, float* not_done, float* weight,
+                      void* stream) {
+    if (batch <= 0 || horizon <= n_steps || n_steps <= 0 || n_steps > WAVE || !count || !ep_len || !u_ep || !u_start || !ep_state || !ep_next ||
+        !ep_action || !ep_reward || !ep_not_done || !state || !action || !next_state || !reward || !not_done || !weight)
+        return KS_ERR_INVALID;
+    hipLaunchKernelGGL(k_sample_windows, dim3(batch * (horizon - n_steps)), dim3(WAVE), 0, (hipStream_t)stream, batch, horizon, n_steps, count,
+                       ep_len, u_ep, u_start, ep_state, ep_next, ep_action, ep_reward, ep_not_done, state, action, next_state, reward, not_done,
+                       weight);
+    return launched();
+}
+
+}  // extern "C"

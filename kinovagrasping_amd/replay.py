@@ -76,6 +76,22 @@ class DeviceEpisodeReplay:
         self._all = torch.ones(n_envs, dtype=torch.bool, device=self.device)
         self._row = torch.arange(horizon - n_steps, device=self.device).unsqueeze(0)
         self._win = torch.arange(n_steps, device=self.device)
+        # on a GPU the bookkeeping runs as the kr_* kernels of libkinova_sim.so (include/kinova_rollout.h), one launch
+        # per method instead of a dozen torch ops; the torch code below is the same arithmetic (and their checker)
+        self.native = self.device.type == "cuda"
+        if self.native:
+            from . import sim as _sim
+            self._lib, self._ptr = _sim.load_library(), _sim._ptr
+            self._rank = torch.zeros(n_envs, dtype=torch.long, device=self.device)
+            self._total = torch.zeros(1, dtype=torch.long, device=self.device)
+
+    def _stream(self):
+        import ctypes
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc})")
 
     @property
     def count(self):
@@ -109,6 +125,8 @@ class DeviceEpisodeReplay:
         """Commit the open episodes of `env_mask` envs in env order; episodes with len - n <= 1 are dropped
         (main_DDPGfD.py:469-471).  Returns the number committed as a 0-d device tensor."""
         keep = env_mask & (self.cur_len - self.n_steps > 1)
+        if self.native:
+            return self.commit_native(keep, env_mask)
         rank = torch.cumsum(keep.long(), 0) - 1
         slots = torch.where(keep, (self._head + rank) % self.capacity, torch.full_like(rank, self.capacity))
         self.ep_state.index_copy_(0, slots, self.cur_state)
@@ -123,16 +141,41 @@ class DeviceEpisodeReplay:
         self.cur_len.copy_(torch.where(env_mask, torch.zeros_like(self.cur_len), self.cur_len))
         return k
 
-    def sample_batch_nstep(self, batch_size, generator=None):
+    def commit_native(self, keep, ended):
+        """rank -> commit -> advance with the kr_* kernels; keep / ended: bool [n_envs]"""
+        L, P, st = self._lib, self._ptr, self._stream()
+        self._check(L.kr_rank_episodes(self.n_envs, P(keep), P(self._rank), P(self._total), st), "kr_rank_episodes")
+        self._check(L.kr_commit_episodes(self.n_envs, self.horizon, self.capacity, P(keep), P(self._rank), P(self._head), P(self.cur_state),
+                                         P(self.cur_next), P(self.cur_action), P(self.cur_reward), P(self.cur_not_done), P(self.cur_len),
+                                         P(self.ep_state), P(self.ep_next), P(self.ep_action), P(self.ep_reward), P(self.ep_not_done),
+                                         P(self.ep_len), st), "kr_commit_episodes")
+        self._check(L.kr_advance_ring(self.n_envs, self.capacity, P(self._total), P(self._head), P(self._count), P(ended), P(self.cur_len), st),
+                    "kr_advance_ring")
+        return self._total[0]
+
+    def sample_batch_nstep(self, batch_size, generator=None, uniforms=None):
         """Fixed-shape batch: batch_size episodes x (horizon - n) window rows, padding rows have weight 0.
-        Returns state [R,n,S], action [R,n,A], next_state [R,n,S], reward [R,n], not_done [R,n], weight [R]."""
+        Returns state [R,n,S], action [R,n,A], next_state [R,n,S], reward [R,n], not_done [R,n], weight [R].
+        `uniforms` (optional, tests): the batch_size + batch_size*W numbers in [0,1) to use instead of torch.rand."""
         n, W = self.n_steps, self.horizon - self.n_steps
+        if self.native:
+            u = torch.rand(batch_size * (W + 1), device=self.device, generator=generator) if uniforms is None else uniforms.contiguous()
+            R, dev = batch_size * W, self.device
+            S, A = self.ep_state.shape[2], self.ep_action.shape[2]
+            out = (torch.empty(R, n, S, device=dev), torch.empty(R, n, A, device=dev), torch.empty(R, n, S, device=dev),
+                   torch.empty(R, n, device=dev), torch.empty(R, n, device=dev), torch.empty(R, device=dev))
+            P = self._ptr
+            self._check(self._lib.kr_sample_windows(batch_size, self.horizon, n, P(self._count), P(self.ep_len), P(u), P(u[batch_size:]),
+                                                    P(self.ep_state), P(self.ep_next), P(self.ep_action), P(self.ep_reward),
+                                                    P(self.ep_not_done), P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(out[4]), P(out[5]),
+                                                    self._stream()), "kr_sample_windows")
+            return out
         hi = (self._count - 1).clamp(min=1)                # newest episode excluded (utils.py:259)
-        ue = torch.rand(batch_size, device=self.device, generator=generator)
+        ue = torch.rand(batch_size, device=self.device, generator=generator) if uniforms is None else uniforms[:batch_size]
         ep = torch.minimum((ue * hi).long(), hi - 1)
         ceiling = (self.ep_len[ep] - n).clamp(min=1)       # [B]
         row = self._row                                                      # [1,W]
-        u = torch.rand(batch_size, W, device=self.device, generator=generator)
+        u = torch.rand(batch_size, W, device=self.device, generator=generator) if uniforms is None else uniforms[batch_size:].view(batch_size, W)
         start = (u * ceiling.unsqueeze(1)).long().clamp(max=self.horizon - n)
         start = torch.where(row == (ceiling.unsqueeze(1) - 1), ceiling.unsqueeze(1).expand(-1, W), start)
         start = start.clamp(max=self.horizon - n)

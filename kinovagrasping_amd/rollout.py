@@ -54,6 +54,17 @@ class RolloutEngine:
         self.done_out = torch.zeros(self.n, dtype=torch.bool, device=dev)
         self.episodes_done = 0
         self.lift_success = 0
+        # on a GPU the per-env rules run as two kernels of libkinova_sim.so (include/kinova_rollout.h); the torch
+        # code in pre() / post() is the same arithmetic and the checker of those kernels
+        self.native = dev.type == "cuda" and (replay is None or getattr(replay, "native", False))
+        if self.native:
+            from . import sim as _sim
+            self._lib, self._ptr = _sim.load_library(), _sim._ptr
+            self._keep = torch.zeros(self.n, dtype=torch.bool, device=dev)
+
+    def _stream(self):
+        import ctypes
+        return ctypes.c_void_p(torch.cuda.current_stream(self.sim.device).cuda_stream)
 
     def start(self, obs):
         """obs [N, 82]: observations returned by the reset"""
@@ -66,6 +77,16 @@ class RolloutEngine:
     @torch.no_grad()
     def pre(self):
         """Action selection for every env -> self.action [N,4] / self.action_t [4,N]."""
+        if self.native:
+            a = self.policy.actor(self.obs).contiguous()
+            noise = torch.randn(a.shape, device=a.device, generator=self.gen)
+            P = self._ptr
+            rc = self._lib.kr_select_action(self.n, P(self.obs), P(self.prev_obs), P(self.has_prev), P(self.t), P(self.ready), P(a), P(noise),
+                                            self.sigma, self.max_action, SKIP_NUM_TS, P(self.action), P(self.action_t), P(self.lifting),
+                                            self._stream())
+            if rc != 0:
+                raise RuntimeError(f"kr_select_action failed ({rc})")
+            return
         timestep = self.t + 1                                              # main_DDPGfD.py:425
         chk = check_grasp(self.prev_obs[:, 9:17], self.obs[:, 9:17]) & (timestep >= SKIP_NUM_TS) & self.has_prev
         self.ready |= chk
@@ -84,6 +105,20 @@ class RolloutEngine:
     def post(self):
         """Consume the sim's output buffers: replay writes and per-env bookkeeping for the next step."""
         sim = self.sim
+        if self.native:
+            rp, P = self.replay, self._ptr
+            N = lambda *a: [None] * len(a) if rp is None else list(a)
+            cur = N("cur_state", "cur_next", "cur_action", "cur_reward", "cur_not_done", "cur_len")
+            cur = [None if c is None else P(getattr(rp, c)) for c in cur]
+            rc = self._lib.kr_store_transition(self.n, rp.horizon if rp else 1, rp.n_steps if rp else 0, int(sim.cfg.auto_reset), int(rp is not None),
+                                               P(sim.obs), P(sim.final_obs), P(sim.reward), P(sim.done), P(self.obs), P(self.prev_obs),
+                                               P(self.has_prev), P(self.t), P(self.ready), P(self.lifting), P(self.action), *cur,
+                                               P(self.reward_out), P(self.done_out), P(self._keep), self._stream())
+            if rc != 0:
+                raise RuntimeError(f"kr_store_transition failed ({rc})")
+            if rp is not None:
+                rp.commit_native(self._keep, self.done_out)
+            return
         obs, reward = sim.obs, sim.reward
         done_b = sim.done != 0
         state, lifting = self.obs, self.lifting

@@ -23,6 +23,9 @@ class KsConfig(C.Structure):
 
 EXPORTS = ["ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_load_model", "ks_reset", "ks_step",
            "ks_get_state", "ks_set_state", "ks_substep", "ks_kernel_time", "ks_version"]
+# include/kinova_rollout.h
+ROLLOUT_EXPORTS = ["kr_select_action", "kr_store_transition", "kr_rank_episodes", "kr_commit_episodes", "kr_advance_ring",
+                   "kr_sample_windows"]
 
 _lib = None
 
@@ -51,6 +54,13 @@ def load_library(path: Path | None = None):
     L.ks_set_state.argtypes = [vp, vp, vp, vp, vp]
     L.ks_substep.argtypes = [vp, vp, vp]
     L.ks_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    i32, f32 = C.c_int32, C.c_float
+    L.kr_select_action.argtypes = [i32] + [vp] * 7 + [f32, f32, i32] + [vp] * 4
+    L.kr_store_transition.argtypes = [i32] * 5 + [vp] * 21
+    L.kr_rank_episodes.argtypes = [i32, vp, vp, vp, vp]
+    L.kr_commit_episodes.argtypes = [i32, i32, i32] + [vp] * 16
+    L.kr_advance_ring.argtypes = [i32, i32] + [vp] * 6
+    L.kr_sample_windows.argtypes = [i32, i32, i32] + [vp] * 16
     _lib = L
     return L
 

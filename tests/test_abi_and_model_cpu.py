@@ -30,6 +30,12 @@ def test_every_declared_symbol_is_exported(lib):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/kinova_sim.h but not exported"
     assert declared == set(ks.EXPORTS)
+    # the rollout / replay kernels (include/kinova_rollout.h)
+    header = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "kinova_rollout.h").read_text(), flags=re.S)
+    declared = set(re.findall(r"\b(kr_[a-z_0-9]+)\s*\(", header))
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/kinova_rollout.h but not exported"
+    assert declared == set(ks.ROLLOUT_EXPORTS)
 
 
 def test_config_struct_layout_and_defaults(lib):

@@ -259,3 +259,65 @@ def test_mixed_shape_batch_equals_per_shape_contexts(assets_dir):
         assert rel < 1e-4, (sh, rel)
         sim.close()
     ms.close()
+
+
+def test_rollout_kernels_equal_torch_bookkeeping():
+    """The kr_* kernels (include/kinova_rollout.h) against the torch implementation of the same rules
+    (RolloutEngine.pre/post, DeviceEpisodeReplay) on identical synthetic sim outputs: every piece of engine /
+    replay state and a sampled batch must be bit-identical."""
+    from types import SimpleNamespace
+    from kinovagrasping_amd.replay import DeviceEpisodeReplay
+    from kinovagrasping_amd.rollout import RolloutEngine
+    dev = torch.device("cuda", 0)
+    n, T = 193, 75
+    g = torch.Generator(device=dev).manual_seed(5)
+
+    class FakeSim:
+        def __init__(self):
+            self.n_envs, self.device = n, dev
+            self.cfg = SimpleNamespace(auto_reset=1)
+            self.obs = torch.zeros(n, 82, device=dev); self.final_obs = torch.zeros(n, 82, device=dev)
+            self.reward = torch.zeros(n, device=dev); self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
+
+    W1 = torch.randn(82, 4, device=dev, generator=g) * 0.05
+    policy = SimpleNamespace(actor=lambda o: 0.8 * torch.sigmoid(o @ W1))
+    engines = []
+    for native in (True, False):
+        sim = FakeSim()
+        rep = DeviceEpisodeReplay(n, capacity=256, horizon=30, device=dev)
+        rep.native = native
+        eng = RolloutEngine(sim, policy, rep, expl_noise=0.1, generator=torch.Generator(device=dev).manual_seed(11))
+        eng.native = native
+        engines.append((sim, rep, eng))
+    obs0 = torch.randn(n, 82, device=dev, generator=g) * 0.1
+    for _, _, eng in engines:
+        eng.start(obs0)
+    age = torch.zeros(n, dtype=torch.long, device=dev)
+    for step in range(T):
+        # synthetic sim outputs: fingertips freeze for some envs (check_grasp fires), episodes end at random or at 30
+        nobs = torch.randn(n, 82, device=dev, generator=g) * 0.1
+        frozen = torch.rand(n, device=dev, generator=g) < 0.3
+        nobs[:, 9:17] = torch.where(frozen.unsqueeze(1), engines[0][2].obs[:, 9:17], nobs[:, 9:17])
+        fin = torch.randn(n, 82, device=dev, generator=g)
+        rew = torch.rand(n, device=dev, generator=g) * 50
+        age += 1
+        done = (torch.rand(n, device=dev, generator=g) < 0.04) | (age >= 30)
+        age = torch.where(done, torch.zeros_like(age), age)
+        for sim, rep, eng in engines:
+            eng.pre()
+            sim.obs.copy_(nobs); sim.final_obs.copy_(fin); sim.reward.copy_(rew); sim.done.copy_(done.to(torch.uint8) * 3)
+            eng.post()
+        (sa, ra, ea), (sb, rb, eb) = engines
+        for name in ("obs", "prev_obs", "has_prev", "t", "ready", "lifting", "action", "action_t", "reward_out", "done_out"):
+            assert torch.equal(getattr(ea, name), getattr(eb, name)), (step, name)
+        for name in ("cur_state", "cur_next", "cur_action", "cur_reward", "cur_not_done", "cur_len", "_head", "_count"):
+            assert torch.equal(getattr(ra, name), getattr(rb, name)), (step, name)
+        assert torch.equal(ra.ep_len[:ra.capacity], rb.ep_len[:rb.capacity]), step      # the row behind the ring is torch's trash row
+    (sa, ra, ea), (sb, rb, eb) = engines
+    assert ra.count > 100 and ea.lifting.any()
+    cap = ra.capacity
+    for name in ("ep_state", "ep_next", "ep_action", "ep_reward", "ep_not_done"):
+        assert torch.equal(getattr(ra, name)[:cap], getattr(rb, name)[:cap]), name
+    u = torch.rand(64 * 26, device=dev, generator=g)
+    for x, y in zip(ra.sample_batch_nstep(64, uniforms=u), rb.sample_batch_nstep(64, uniforms=u)):
+        assert torch.equal(x, y)
