@@ -56,12 +56,26 @@ class Critic(nn.Module):
         return self.l3(q)
 
 
+def _flatten_parameters(module: nn.Module) -> torch.Tensor:
+    """Re-home the parameters of `module` as views into ONE flat fp32 buffer (returned): the soft target update is
+    then a single elementwise expression per network instead of one per tensor."""
+    params = list(module.parameters())
+    flat = torch.cat([p.data.reshape(-1) for p in params])
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.data = flat[off:off + n].view_as(p)
+        off += n
+    return flat
+
+
 class DDPGfD:
     def __init__(self, state_dim=82, action_dim=4, max_action=0.8, n=5, discount=0.995, tau=0.0005, batch_size=64,
                  hidden=(400, 300), device="cpu", process_group=None, capturable=False):
         self.device = torch.device(device)
         self.actor = Actor(state_dim, action_dim, max_action, hidden).to(self.device)
         self.actor_target = copy.deepcopy(self.actor)
+        self._flat_params = {}
         # capturable: optimizer state and the update counter live on the device, so that a whole update can be
         # captured in a HIP graph (pipeline.GraphedTrainer); the arithmetic is the same
         self.capturable = bool(capturable)
@@ -70,7 +84,10 @@ class DDPGfD:
         self.critic_target = copy.deepcopy(self.critic)
         self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), weight_decay=1e-4, capturable=self.capturable)
         self._it_dev = torch.zeros((), dtype=torch.long, device=self.device)
+        for name in ("actor", "actor_target", "critic", "critic_target"):
+            self._flat_params[name] = _flatten_parameters(getattr(self, name))
         self.discount, self.tau, self.n = discount, tau, n
+        self._disc = torch.tensor([discount ** i for i in range(n)], dtype=torch.float32, device=self.device)
         self.network_repl_freq = 10
         self.total_it = 0
         self.batch_size = batch_size
@@ -132,14 +149,13 @@ class DDPGfD:
         """targets + critic loss + backward (DDPGfD.py:256-330).  Returns (critic, L1, LN) losses."""
         reward = reward.unsqueeze(-1)
         with torch.no_grad():
-            target_Q = self.critic_target(next_state[:, 0], self.actor_target(next_state[:, 0]))
-            target_Q = reward[:, 0] + self.discount * target_Q
-            target_action = self.actor_target(next_state[:, -1])
-            target_critic_val = self.critic_target(next_state[:, -1], target_action)
-            n_step_return = torch.zeros(reward.shape[0], device=reward.device)
-            for i in range(self.n):
-                n_step_return += (self.discount ** i) * reward[:, i].squeeze(-1)
-            target_QN = (n_step_return + (self.discount ** self.n) * target_critic_val.squeeze(-1)).unsqueeze(-1)
+            # both target evaluations (1-step: next_state[:, 0], n-step: next_state[:, -1]) in one pass of the target nets
+            R = reward.shape[0]
+            nx = torch.cat([next_state[:, 0], next_state[:, -1]], 0)
+            tq = self.critic_target(nx, self.actor_target(nx))
+            target_Q = reward[:, 0] + self.discount * tq[:R]
+            n_step_return = (reward.squeeze(-1) * self._disc).sum(1)
+            target_QN = (n_step_return + (self.discount ** self.n) * tq[R:].squeeze(-1)).unsqueeze(-1)
         current_Q = self.critic(state[:, 0], action[:, 0])
         critic_L1 = self._mean((current_Q - target_Q) ** 2, 1, weight)
         critic_LN = self._mean((current_Q - target_QN) ** 2, 1, weight)
@@ -151,28 +167,33 @@ class DDPGfD:
     def phase_actor(self, state, weight=None):
         """critic step, then actor loss + backward (DDPGfD.py:331-352)"""
         self.critic_optimizer.step()
+        # the critic is only a differentiable function here: no weight gradients for it (the reference computes and
+        # discards them)
+        for p in self.critic.parameters():
+            p.requires_grad_(False)
         actor_loss = -self._mean(self.critic(state, self.actor(state)), state.shape[1], weight)
         self.actor_optimizer.zero_grad()
         actor_loss.backward()
+        for p in self.critic.parameters():
+            p.requires_grad_(True)
         return actor_loss.detach()
 
     def phase_targets(self):
         """actor step + soft target update on every 10th call (DDPGfD.py:353-366)"""
         self.actor_optimizer.step()
         self.total_it += 1
-        pairs = ((self.critic, self.critic_target), (self.actor, self.actor_target))
+        fp = self._flat_params
+        pairs = ((fp["critic"], fp["critic_target"]), (fp["actor"], fp["actor_target"]))
         with torch.no_grad():
             if self.capturable:
                 # device-side gate: tau on every network_repl_freq-th call, else 0 (same arithmetic when it fires)
                 self._it_dev += 1
-                gate = (self._it_dev % self.network_repl_freq == 0).to(torch.float32) * self.tau
-                for net, tgt in pairs:
-                    for p, tp in zip(net.parameters(), tgt.parameters()):
-                        tp.copy_(torch.where(gate > 0, gate * p + (1 - gate) * tp, tp))
+                fire = self._it_dev % self.network_repl_freq == 0
+                for p, tp in pairs:
+                    tp.copy_(torch.where(fire, self.tau * p + (1 - self.tau) * tp, tp))
             elif self.total_it % self.network_repl_freq == 0:
-                for net, tgt in pairs:
-                    for p, tp in zip(net.parameters(), tgt.parameters()):
-                        tp.copy_(self.tau * p + (1 - self.tau) * tp)
+                for p, tp in pairs:
+                    tp.copy_(self.tau * p + (1 - self.tau) * tp)
 
     def train_batch(self, episode_step, expert_replay_buffer, replay_buffer, num_trajectories=5, prob=0.3):
         """Reference signature (DDPGfD.py:219): samples agent (1-prob) / expert (prob) episodes from
