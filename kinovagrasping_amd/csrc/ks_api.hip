@@ -4,7 +4,7 @@
 //   k_env_step   15 x mj_step per launch; per-lane dynamic state in LDS (144 KB / wave), model tables
 //                through wave-uniform scalar loads.  THE dominant kernel.
 //   k_reset      state <- stored initial state for flagged envs, kinematics -> snapshot
-//   k_rays       17 rangefinder rays, one (env, ray) per lane: grid (N/64, 17)
+//   k_rays       17 rangefinder rays x 8 mesh geoms, one (env, ray, geom) per lane: grid (N/8, 17)
 //   k_obs        82-d observation, reward, termination, time limit, auto-reset flagging
 //   k_substep    one mj_step with explicit controls (parity tap)
 // No CPU fallback exists in this library.
@@ -262,12 +262,26 @@ __global__ void k_store_init(Buffers<T> b, const int32_t* __restrict__ env_ids, 
     b.flag[env] = 1;
 }
 
-// one (env, ray) per lane; the ray index is uniform per workgroup so hull tables stay scalar loads
+// one (env, ray, geom) per lane: eight envs per wave, the eight mesh geoms of an env in adjacent lanes (lane 0 of the
+// group also takes the ground plane), nearest hit by a 3-step butterfly.  The ray index is uniform per workgroup.
+constexpr int RAY_ENVS = WAVE / (NGEOM - 1);
+static_assert(NGEOM - 1 == 8, "k_rays: eight mesh geoms per env, one per lane");
 template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model<T>* __restrict__ mp, Buffers<T> b, int N, int masked) {
-    const int env = blockIdx.x * WAVE + threadIdx.x, ray = blockIdx.y;
-    if (env >= N || (masked && !b.flag[env])) return;
-    Col<T> snap{b.snap + env, N};
-    b.rays[(long)ray * N + env] = rangefinder(*mp, snap, ray);
+    const int g = 1 + (threadIdx.x & 7);
+    const int env = blockIdx.x * RAY_ENVS + (threadIdx.x >> 3), ray = blockIdx.y;
+    const bool live = env < N && !(masked && !b.flag[env]);
+    T best = T(-1);
+    if (live) {
+        const Model<T>& m = *mp;
+        Col<T> snap{b.snap + env, N};
+        T pnt[3], vec[3];
+        const int sb = ray_origin(m, snap, ray, pnt, vec);
+        if (g == 1) best = ray_ground(m, pnt, vec);
+        if (m.geom_body[g] != sb) best = ray_nearer(best, ray_geom(m, snap, g, pnt, vec));
+    }
+    KS_UNROLL
+    for (int mask = 1; mask < 8; mask <<= 1) best = ray_nearer(best, (T)__shfl_xor(best, mask));
+    if (live && g == 1) b.rays[(long)ray * N + env] = best;
 }
 
 // mode 0: after a step (reward / done / time limit / auto-reset flagging); mode 1: after a reset
@@ -452,7 +466,7 @@ template <typename T> struct Ctx : CtxBase {
     int post_reset(void* obs, hipStream_t s) {
         const int N = cfg.n_envs;
         hipLaunchKernelGGL((k_reset<T, USE_LDS>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N);
-        hipLaunchKernelGGL((k_rays<T>), dim3(blocks(), NRAY), dim3(WAVE), 0, s, d_model, b, N, 1);
+        hipLaunchKernelGGL((k_rays<T>), dim3((N + RAY_ENVS - 1) / RAY_ENVS, NRAY), dim3(WAVE), 0, s, d_model, b, N, 1);
         hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 1, cfg.horizon, cfg.auto_reset, cfg.obs_env_major,
                            (T*)obs, (T*)nullptr, (uint8_t*)nullptr, (T*)nullptr, (T*)nullptr);
         HIPCHK(hipGetLastError());
@@ -473,7 +487,7 @@ template <typename T> struct Ctx : CtxBase {
         hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3((N + lpw - 1) / lpw), dim3(WG), step_lds, s, d_model, b, (const T*)action, N,
                            cfg.frame_skip, cfg.solver_iterations, lpw, cfg.contact_tap);
         if (timed) { HIPCHK(hipEventRecord(ev1[ev_used], s)); ev_used++; }
-        hipLaunchKernelGGL((k_rays<T>), dim3(blocks(), NRAY), dim3(WAVE), 0, s, d_model, b, N, 0);
+        hipLaunchKernelGGL((k_rays<T>), dim3((N + RAY_ENVS - 1) / RAY_ENVS, NRAY), dim3(WAVE), 0, s, d_model, b, N, 0);
         hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0, cfg.horizon, cfg.auto_reset, cfg.obs_env_major,
                            (T*)obs, (T*)reward, done, (T*)info, (T*)final_obs);
         HIPCHK(hipGetLastError());

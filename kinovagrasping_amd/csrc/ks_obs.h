@@ -31,29 +31,38 @@ template <typename T, typename C> KS_HD void snap_body(C snap, int b, T* R, T* p
     for (int j = 0; j < 3; j++) p[j] = snap(o + 9 + j);
 }
 
-// slab test of a ray (origin o, direction d, reciprocal id) against an axis-aligned box; hit iff the
-// parametric overlap [t0, t1] intersects [0, tmax]
-template <typename T> KS_HD bool ray_box(const T* o, const T* d, const T* lo, const T* hi, T tmax) {
+// slab test of a ray (origin o, direction d) against an axis-aligned box: entry parameter t0 >= 0 when the
+// parametric overlap [t0, t1] intersects [0, tmax], -1 when the box is missed
+template <typename T> KS_HD T ray_box_entry(const T* o, const T* d, const T* lo, const T* hi, T tmax) {
     T t0 = 0, t1 = tmax;
     KS_UNROLL
     for (int a = 0; a < 3; a++) {
         if (kabs(d[a]) < T(1e-15)) {
-            if (o[a] < lo[a] || o[a] > hi[a]) return false;
+            if (o[a] < lo[a] || o[a] > hi[a]) return T(-1);
         } else {
             T ta = (lo[a] - o[a]) / d[a], tb = (hi[a] - o[a]) / d[a];
             if (ta > tb) { T w = ta; ta = tb; tb = w; }
             t0 = ta > t0 ? ta : t0;
             t1 = tb < t1 ? tb : t1;
-            if (t0 > t1) return false;
+            if (t0 > t1) return T(-1);
         }
     }
-    return true;
+    return t0;
+}
+template <typename T> KS_HD bool ray_box(const T* o, const T* d, const T* lo, const T* hi, T tmax) { return ray_box_entry(o, d, lo, hi, tmax) >= 0; }
+
+// entry parameter of BVH node `node` (float32 box, padded outwards by 1e-6: the box test must never reject a
+// triangle the exhaustive oracle would hit)
+template <typename T> KS_HD T bvh_node_entry(const float* box, int node, const T* lp, const T* lv, T tmax) {
+    T lo[3] = {T(box[6 * node]) - T(1e-6), T(box[6 * node + 1]) - T(1e-6), T(box[6 * node + 2]) - T(1e-6)};
+    T hi[3] = {T(box[6 * node + 3]) + T(1e-6), T(box[6 * node + 4]) + T(1e-6), T(box[6 * node + 5]) + T(1e-6)};
+    return ray_box_entry(lp, lv, lo, hi, tmax);
 }
 
 // Ray vs mesh geom, MuJoCo's mj_rayMesh semantics: bounding-box pre-test (geom_size about the geom origin),
 // then the faces of the ORIGINAL triangle mesh, both orientations, nearest t >= 0 (-1 = miss).  The faces
-// are visited through a bounding-volume hierarchy; the boxes are float32-rounded outwards-safe because the
-// triangles they were built from are the same float32 values.
+// are visited through a bounding-volume hierarchy, nearer child first, so that the nearest hit found so far
+// prunes the rest; the result is the minimum over all faces, exactly what the exhaustive oracle computes.
 template <typename T>
 KS_HD T ray_mesh(const float* tri, const float* box, const int* lr, const T* size, const T* lp, const T* lv) {
     {
@@ -61,77 +70,102 @@ KS_HD T ray_mesh(const float* tri, const float* box, const int* lr, const T* siz
         if (!ray_box(lp, lv, lo, hi, Lim<T>::big)) return T(-1);
     }
     T best = T(-1);
+    if (bvh_node_entry(box, 0, lp, lv, Lim<T>::big) < 0) return best;
     int stack[32], sp = 0, node = 0;
+    T stack_t[32];
     for (;;) {
-        T lo[3] = {T(box[6 * node]), T(box[6 * node + 1]), T(box[6 * node + 2])};
-        T hi[3] = {T(box[6 * node + 3]), T(box[6 * node + 4]), T(box[6 * node + 5])};
-        // small outward pad: the box test must never reject a triangle the exhaustive oracle would hit
-        KS_UNROLL
-        for (int a = 0; a < 3; a++) { lo[a] -= T(1e-6); hi[a] += T(1e-6); }
-        if (ray_box(lp, lv, lo, hi, best < 0 ? Lim<T>::big : best)) {
-            const int a = lr[2 * node], b = lr[2 * node + 1];
-            if (b < 0) {
-                for (int i = a; i < a - b; i++) {
-                    const float* v = &tri[9 * i];
-                    T v0[3] = {T(v[0]), T(v[1]), T(v[2])}, e1[3] = {T(v[3]) - v0[0], T(v[4]) - v0[1], T(v[5]) - v0[2]};
-                    T e2[3] = {T(v[6]) - v0[0], T(v[7]) - v0[1], T(v[8]) - v0[2]}, pv[3], tv[3], qv[3];
-                    cross3(pv, lv, e2);
-                    T det = dot3(e1, pv);
-                    if (kabs(det) < T(1e-30)) continue;
-                    T inv = T(1) / det;
-                    sub3(tv, lp, v0);
-                    T u = dot3(tv, pv) * inv;
-                    if (u < 0 || u > 1) continue;
-                    cross3(qv, tv, e1);
-                    T w = dot3(lv, qv) * inv;
-                    if (w < 0 || u + w > 1) continue;
-                    T tt = dot3(e2, qv) * inv;
-                    if (tt >= 0 && (best < 0 || tt < best)) best = tt;
-                }
-            } else {
-                if (sp < 31) stack[sp++] = b;
-                node = a;
-                continue;
+        const int a = lr[2 * node], b = lr[2 * node + 1];
+        bool descend = false;
+        if (b < 0) {
+            for (int i = a; i < a - b; i++) {
+                const float* v = &tri[9 * i];
+                T v0[3] = {T(v[0]), T(v[1]), T(v[2])}, e1[3] = {T(v[3]) - v0[0], T(v[4]) - v0[1], T(v[5]) - v0[2]};
+                T e2[3] = {T(v[6]) - v0[0], T(v[7]) - v0[1], T(v[8]) - v0[2]}, pv[3], tv[3], qv[3];
+                cross3(pv, lv, e2);
+                T det = dot3(e1, pv);
+                if (kabs(det) < T(1e-30)) continue;
+                T inv = T(1) / det;
+                sub3(tv, lp, v0);
+                T u = dot3(tv, pv) * inv;
+                if (u < 0 || u > 1) continue;
+                cross3(qv, tv, e1);
+                T w = dot3(lv, qv) * inv;
+                if (w < 0 || u + w > 1) continue;
+                T tt = dot3(e2, qv) * inv;
+                if (tt >= 0 && (best < 0 || tt < best)) best = tt;
+            }
+        } else {
+            // both children tested at once (independent loads); the farther one waits on the stack with its entry t
+            const T tmax = best < 0 ? Lim<T>::big : best;
+            const T ta = bvh_node_entry(box, a, lp, lv, tmax), tb = bvh_node_entry(box, b, lp, lv, tmax);
+            if (ta >= 0 && tb >= 0) {
+                const bool a_first = ta <= tb;
+                if (sp < 32) { stack[sp] = a_first ? b : a; stack_t[sp] = a_first ? tb : ta; sp++; }
+                node = a_first ? a : b;
+                descend = true;
+            } else if (ta >= 0 || tb >= 0) {
+                node = ta >= 0 ? a : b;
+                descend = true;
             }
         }
-        if (sp == 0) break;
-        node = stack[--sp];
+        if (descend) continue;
+        // next stacked node whose entry is still in front of the nearest hit
+        bool found = false;
+        while (sp > 0) {
+            sp--;
+            if (best < 0 || stack_t[sp] <= best) { node = stack[sp]; found = true; break; }
+        }
+        if (!found) break;
     }
     return best;
 }
 
-// one rangefinder: ray from site `si` along its +z, geoms of the site's own body excluded
-template <typename T, typename C> KS_HD T rangefinder(const Model<T>& m, C snap, int si) {
-    T Rb[9], pb[3], pnt[3], vec[3], t[3];
+// ---- one rangefinder = ray from site `si` along its +z against the ground plane and the 8 mesh geoms (those of the
+// site's own body excluded), nearest hit.  The three pieces below are what the serial loop (rangefinder) and the
+// one-geom-per-lane kernel (k_rays) share; the minimum over geoms does not depend on the order.
+template <typename T, typename C> KS_HD int ray_origin(const Model<T>& m, C snap, int si, T* pnt, T* vec) {
+    T Rb[9], pb[3], t[3];
     const int sb = m.site_body[si];
     snap_body<T>(snap, sb, Rb, pb);
     mulRv(t, Rb, m.site_pos[si]);
     add3(pnt, pb, t);
     mulRv(vec, Rb, m.site_z[si]);
-    T best = T(-1);
-    // ground plane z = 0 with finite half-size (XML:148)
+    return sb;
+}
+// ground plane z = 0 with finite half-size (XML:148); -1 = miss
+template <typename T> KS_HD T ray_ground(const Model<T>& m, const T* pnt, const T* vec) {
     if (kabs(vec[2]) > T(1e-15)) {
         T tt = -pnt[2] / vec[2];
         if (tt >= 0) {
             T x = pnt[0] + tt * vec[0], y = pnt[1] + tt * vec[1];
-            if (kabs(x) <= m.geom_size[0][0] && kabs(y) <= m.geom_size[0][1]) best = tt;
+            if (kabs(x) <= m.geom_size[0][0] && kabs(y) <= m.geom_size[0][1]) return tt;
         }
     }
+    return T(-1);
+}
+template <typename T, typename C> KS_HD T ray_geom(const Model<T>& m, C snap, int g, const T* pnt, const T* vec) {
+    T R[9], p[3], Rg[9], pg[3], t[3];
+    snap_body<T>(snap, m.geom_body[g], R, p);
+    mulRR(Rg, R, m.geom_R[g]);
+    mulRv(t, R, m.geom_pos[g]);
+    add3(pg, p, t);
+    T lp[3], lv[3];
+    sub3(t, pnt, pg);
+    mulRtv(lp, Rg, t);
+    mulRtv(lv, Rg, vec);
+    const int mesh = m.geom_mesh[g];
+    return ray_mesh(m.mesh_tri[mesh], m.mesh_bvh_box[mesh], m.mesh_bvh_lr[mesh], m.geom_size[g], lp, lv);
+}
+// nearer of two ray results (-1 = miss)
+template <typename T> KS_HD T ray_nearer(T a, T b) { return (b >= 0 && (a < 0 || b < a)) ? b : a; }
+
+template <typename T, typename C> KS_HD T rangefinder(const Model<T>& m, C snap, int si) {
+    T pnt[3], vec[3];
+    const int sb = ray_origin(m, snap, si, pnt, vec);
+    T best = ray_ground(m, pnt, vec);
     for (int g = 1; g < NGEOM; g++) {
-        const int gb = m.geom_body[g];
-        if (gb == sb) continue;
-        T R[9], p[3], Rg[9], pg[3];
-        snap_body<T>(snap, gb, R, p);
-        mulRR(Rg, R, m.geom_R[g]);
-        mulRv(t, R, m.geom_pos[g]);
-        add3(pg, p, t);
-        T lp[3], lv[3];
-        sub3(t, pnt, pg);
-        mulRtv(lp, Rg, t);
-        mulRtv(lv, Rg, vec);
-        const int mesh = m.geom_mesh[g];
-        T d = ray_mesh(m.mesh_tri[mesh], m.mesh_bvh_box[mesh], m.mesh_bvh_lr[mesh], m.geom_size[g], lp, lv);
-        if (d >= 0 && (best < 0 || d < best)) best = d;
+        if (m.geom_body[g] == sb) continue;
+        best = ray_nearer(best, ray_geom(m, snap, g, pnt, vec));
     }
     return best;
 }
