@@ -1058,28 +1058,28 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     // exact cull: lowest point of the geom's bounding box (half extents geom_size about the geom origin) is
     // above the margin -> every hull vertex is too
     if (cdist - (kabs(ln[0]) * size[0] + kabs(ln[1]) * size[1] + kabs(ln[2]) * size[2]) > margin) return 0;
-    // slices are whole HULL_CHUNKs; rows past nv are padding (copies of vertex 0) and never counted
-    const int len = ((nv + SUBS * HULL_CHUNK - 1) / (SUBS * HULL_CHUNK)) * HULL_CHUNK;
-    const int i_lo = team.sub * len, i_hi = (i_lo + len < nv) ? i_lo + len : nv;
+    // One pass, SUBS consecutive vertices per round (lane k takes vertex base + k: adjacent lanes read adjacent
+    // 16-byte rows, no LDS bank conflicts).  Every lane tracks the deepest vertex it saw; the vertices within the
+    // margin are appended to the candidate list in index order through a team ballot.
     T bd = T(1e30);
-    int best = nv, mine = 0;
-    for (int i0 = i_lo; i0 < i_hi; i0 += HULL_CHUNK) {
-        T dd[HULL_CHUNK];
-        KS_UNROLL
-        for (int j = 0; j < HULL_CHUNK; j++) dd[j] = cdist + V[4 * (i0 + j)] * ln[0] + V[4 * (i0 + j) + 1] * ln[1] + V[4 * (i0 + j) + 2] * ln[2];
-        KS_UNROLL
-        for (int j = 0; j < HULL_CHUNK; j++) {
-            if (i0 + j < i_hi) {
-                if (dd[j] < bd) { bd = dd[j]; best = i0 + j; }
-                if (dd[j] <= margin) mine++;
-            }
+    int best = nv, total = 0;
+    for (int base = 0; base < nv; base += SUBS) {
+        const int i = base + team.sub;
+        const bool in = i < nv;
+        const int ii = in ? i : 0;
+        const T d = cdist + V[4 * ii] * ln[0] + V[4 * ii + 1] * ln[1] + V[4 * ii + 2] * ln[2];
+        if (in && d < bd) { bd = d; best = i; }
+        const bool cand = in && d <= margin;
+        const unsigned votes = team.ballot(cand);
+        if (cand) {
+            const int pos = total + kpopc(votes & ((1u << team.sub) - 1u));
+            if (pos < CAND_MAX) scr(SCR_CAND + pos) = T(i);
         }
+        total += kpopc(votes);
     }
     KS_TICK(12)
     team.argmin(bd, best);
     if (bd > margin) return 0;
-    int total = 0;
-    const int first = team.scan(mine, total);
     KS_TICK(4)
     T cv[4][3];
     int nc = 1;
@@ -1087,15 +1087,6 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     T thr2 = PLANE_MESH_TOL * rbound;
     thr2 *= thr2;
     if (total <= CAND_MAX) {
-        int w = first;
-        for (int i0 = i_lo; i0 < i_hi && mine > 0; i0 += HULL_CHUNK) {
-            T dd[HULL_CHUNK];
-            KS_UNROLL
-            for (int j = 0; j < HULL_CHUNK; j++) dd[j] = cdist + V[4 * (i0 + j)] * ln[0] + V[4 * (i0 + j) + 1] * ln[1] + V[4 * (i0 + j) + 2] * ln[2];
-            KS_UNROLL
-            for (int j = 0; j < HULL_CHUNK; j++)
-                if (i0 + j < i_hi && dd[j] <= margin) scr(SCR_CAND + w++) = T(i0 + j);
-        }
         team.sync();
         KS_TICK(7)
         for (int a = 0; a < total && nc < 4; a++) {
@@ -1809,6 +1800,19 @@ KS_FN void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm, S scr,
             alpha = next;
             if (stop) break;
         }
+        // Did any row change sides between a and a + alpha p?  If not, the cost is one quadratic on the whole step,
+        // the exact line search landed on its minimiser and that is the solution: no confirming iteration needed.
+        T flips = 0;
+        KS_UNROLL
+        for (int j = 0; j < 6; j++)
+            if (r.lim_sign[j] != 0 && ((lim_x[j] < 0) != (lim_x[j] + alpha * lim_p[j] < 0))) flips += lead;
+        KS_UNROLL
+        for (int q = 0; q < CPL; q++) {
+            KS_UNROLL
+            for (int kk = 0; kk < 4; kk++)
+                if (rD[q] != 0 && ((rx[q][kk] < 0) != (rx[q][kk] + alpha * rj[q][kk] < 0))) flips += T(1);
+        }
+        flips = team.sum(flips);
         KS_TICK(18)
         T amax = 0, dmax = 0;
         KS_UNROLL
@@ -1821,7 +1825,7 @@ KS_FN void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm, S scr,
         team.sync();                                   // slots 14..18 are rewritten by the next iteration
         // converged: the step just taken is below 1e-5 of the solution scale (Newton is quadratic, the
         // next step would be far smaller); lanes that are done wait for the slowest env of the wave
-        if (dmax <= T(1e-5) * (1 + amax)) break;
+        if (dmax <= T(1e-5) * (1 + amax) || flips == 0) break;
     }
     KS_TICK(19)
     // --- constraint forces at the final a: owners publish (fn, ft1, ft2) in slots 14..16 (also the parity tap)

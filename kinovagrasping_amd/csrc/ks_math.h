@@ -31,6 +31,7 @@ KS_HD float kmin(float a, float b) { return a < b ? a : b; }
 KS_HD double kmin(double a, double b) { return a < b ? a : b; }
 KS_HD int kmin(int a, int b) { return a < b ? a : b; }
 KS_HD int kctz(unsigned x) { return __builtin_ctz(x); }
+KS_HD int kpopc(unsigned x) { return __builtin_popcount(x); }
 // reciprocal square root: the hardware v_rsq_f32 (1 ulp) in fp32 device code
 KS_HD float krsqrt(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
