@@ -114,6 +114,20 @@ template <typename T> __device__ __forceinline__ void store_state(const Buffers<
     for (int i = 0; i < NV; i++) { b.qvel[(long)i * N + env] = st.qvel[i]; b.warm[(long)i * N + env] = st.warm[i]; }
 }
 
+// team versions: the env state lives in the env's LDS block, every lane moves a share of the 46 values
+template <typename T, int SUBS_> __device__ __forceinline__ void load_state_team(const Buffers<T>& b, int env, int N, T* st, int sub) {
+    for (int i = sub; i < NQ + 2 * NV; i += SUBS_)
+        st[i] = i < NQ ? b.qpos[(long)i * N + env] : (i < NQ + NV ? b.qvel[(long)(i - NQ) * N + env] : b.warm[(long)(i - NQ - NV) * N + env]);
+}
+template <typename T, int SUBS_> __device__ __forceinline__ void store_state_team(const Buffers<T>& b, int env, int N, const T* st, int sub) {
+    for (int i = sub; i < NQ + 2 * NV; i += SUBS_) {
+        if (i < NQ) b.qpos[(long)i * N + env] = st[i];
+        else if (i < NQ + NV) b.qvel[(long)(i - NQ) * N + env] = st[i];
+        else b.warm[(long)(i - NQ - NV) * N + env] = st[i];
+    }
+}
+static_assert(sizeof(LaneState<float>) == (NQ + 2 * NV) * sizeof(float), "LaneState is qpos | qvel | warm, packed");
+
 constexpr int SUBS = 16;         // lanes per env (a DPP row)
 constexpr int WG = 256;          // stepping workgroup: four waves, one per SIMD of the CU, sharing the hull tables in LDS
 constexpr int EPW_MAX = WG / SUBS;
@@ -144,8 +158,6 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
     const Team<SUBS> team{(int)threadIdx.x % SUBS};
     const int env = blockIdx.x * epw + e;
     if (e >= epw || env >= N) return;
-    LaneState<T> st;
-    load_state(b, env, N, st);
     T hq[4], act[4];
     KS_UNROLL
     for (int i = 0; i < 4; i++) { hq[i] = b.hand_quat[(long)i * N + env]; act[i] = action[(long)i * N + env]; }
@@ -159,8 +171,13 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
     float* prof = nullptr;
 #endif
     if constexpr (USE_LDS) {
-        ScratchC<T, KS_LDS T*> scr{lds + ((hull_words >> 2) << 2) + e * SCR_TOTAL};
-        lane_env_step(m, hu, st, hq, act, scr, team, snap, frame_skip, iters, ncon, status, prof);
+        KS_LDS T* blk = lds + ((hull_words >> 2) << 2) + e * SCR_TOTAL;
+        ScratchC<T, KS_LDS T*> scr{blk};
+        // state and per-step constants in the env's LDS block, reached through generic pointers
+        T* stp = (T*)(blk + SCR_STATE);
+        load_state_team<T, SUBS>(b, env, N, stp, team.sub);
+        team.sync();
+        lane_env_step(m, hu, *(LaneState<T>*)stp, hq, act, scr, team, snap, frame_skip, iters, ncon, status, prof, stp + NQ + 2 * NV);
 #ifdef KS_STAMP
         // diagnostic build only: per-phase cycle sums of this lane go to the contact tap buffer
         prof[6] = (float)(clock64() - tk0);
@@ -169,16 +186,20 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
 #endif
         if (team.sub == 0)
             for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
+        team.sync();
+        store_state_team<T, SUBS>(b, env, N, stp, team.sub);
     } else {
+        LaneState<T> st;
+        load_state(b, env, N, st);
         Scratch<T> scr{b.gscratch + env, N};
         lane_env_step(m, hu, st, hq, act, scr, team, snap, frame_skip, iters, ncon, status);
-        if (team.sub == 0)
+        if (team.sub == 0) {
             for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
+            store_state(b, env, N, st);
+        }
     }
     if (status) atomicOr(&b.status[env], status);
-    if (team.sub != 0) return;
-    store_state(b, env, N, st);
-    b.ncon[env] = ncon;
+    if (team.sub == 0) b.ncon[env] = ncon;
 }
 
 template <typename T, bool USE_LDS>

@@ -34,7 +34,7 @@ constexpr int CON_STRIDE = 20;
 // collision staging: contacts are detected pair by pair into per-pair slots of (pos3, normal3, dist, mu,
 // bodies) records - 4 slots for a plane pair, 1 for a hull pair, assigned in pair order - and then merged
 // in pair order with the per-pair counts in SCR_PC.
-constexpr int NSTAGE = 85, STAGE_REC = 9, STAGE_WORDS = 768;   // 85 x 9 = 765 <= 768 = 16 cached bases
+constexpr int NSTAGE = 80, STAGE_REC = 9, STAGE_WORDS = 720;   // 80 x 9 = 720 = 15 cached bases
 constexpr int SCR_PC = SCR_CON + NCON_MAX * CON_STRIDE;
 constexpr int SCR_STAGE = SCR_PC + NPAIR_MAX;
 // plane-hull contact selection: indices of the vertices within the margin, ascending (one list per env).  The
@@ -50,7 +50,11 @@ constexpr int SCR_MO = SCR_MH + 81;
 constexpr int SCR_QF = SCR_MO + 36;
 constexpr int SCR_SB = SCR_QF + NV;
 constexpr int SCR_GP = ((SCR_SB + 9 + 3) / 4) * 4;   // world poses of geoms 1..8 (R row-major 9, p 3), refreshed every substep
-constexpr int SCR_TOTAL = SCR_GP + (NGEOM - 1) * 12;
+// the env's state and per-step constants (GPU: the stepping kernel keeps them here instead of in per-lane
+// registers / stack, the stages reach them through generic pointers): LaneState (qpos 16, qvel 15, warm 15),
+// hand rotation 9, controls 9
+constexpr int SCR_STATE = SCR_GP + (NGEOM - 1) * 12;
+constexpr int SCR_TOTAL = SCR_STATE + 64;
 static_assert(CAND_MAX <= NCON_MAX * CON_STRIDE, "candidate list fits in the contact slots");
 // The staging + candidate regions are dead once the contacts are merged: the solver reuses them as a cache of
 // the contact basis Jacobians (45 values per contact) so that they are built once per substep, not 2x per
