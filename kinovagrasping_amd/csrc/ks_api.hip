@@ -164,9 +164,10 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
     int ncon = 0, status = 0;
     ColW<T> snap{b.snap + env, N};
 #ifdef KS_STAMP
-    float prof[24];
-    for (int k = 0; k < 24; k++) prof[k] = 0;
+    float prof[30];
+    for (int k = 0; k < 30; k++) prof[k] = 0;
     const long long tk0 = clock64();
+    const long long wk0 = wall_clock64();
 #else
     float* prof = nullptr;
 #endif
@@ -181,7 +182,12 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
 #ifdef KS_STAMP
         // diagnostic build only: per-phase cycle sums of this lane go to the contact tap buffer
         prof[6] = (float)(clock64() - tk0);
-        if (tap) for (int k = 0; k < 24; k++) b.contact[(long)(k + 24 * team.sub) * N + env] = (T)prof[k];
+        // wall clock (100 MHz) of the stepping loop's start / end, modulo 2^22 ticks, and the hardware id (CU / SE / XCC)
+        prof[13] = (float)(wk0 & 0x3fffff);
+        prof[14] = (float)(wall_clock64() & 0x3fffff);
+        prof[19] = (float)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) & 0xffffff);
+        prof[20] = (float)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf);
+        if (tap) for (int k = 0; k < 30; k++) b.contact[(long)(k + 30 * team.sub) * N + env] = (T)prof[k];
         tap = 0;
 #endif
         if (team.sub == 0)
@@ -236,11 +242,13 @@ __global__ __launch_bounds__(WG) void k_substep(const Model<T>* __restrict__ mp,
     int ncon = 0, status = 0;
     if constexpr (USE_LDS) {
         ScratchC<T, KS_LDS T*> scr{lds + ((hull_words >> 2) << 2) + e * SCR_TOTAL};
+        reset_pair_words<T>(scr, team);
         mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, c, R7, scr, team, iters, true, ncon, status);
         if (team.sub == 0)
             for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
     } else {
         Scratch<T> scr{b.gscratch + env, N};
+        reset_pair_words<T>(scr, team);
         mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, c, R7, scr, team, iters, true, ncon, status);
         if (team.sub == 0)
             for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);

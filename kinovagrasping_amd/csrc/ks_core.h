@@ -546,6 +546,9 @@ template <typename T> struct PairGeo {
     int n1, n2;
     int hint1, hint2;          // last support vertex of each shape: start of the next hill climb
     T half_margin;
+#ifdef KS_STAMP_HULL
+    int cnt_support, cnt_steps;
+#endif
 };
 
 // Hull vertex tables are stored padded: stride 4 reals (x, y, z, 0) and the count rounded up to a
@@ -591,8 +594,14 @@ KS_HD void hull_support(const T* R, const T* p, KS_LDS const T* V, KS_LDS const 
 
 template <typename T> KS_HD void mpr_support(PairGeo<T>& g, const T* dir, Supp<T>& o) {
     T nd[3] = {-dir[0], -dir[1], -dir[2]};
+#ifdef KS_STAMP_HULL
+    const int h1_ = g.hint1, h2_ = g.hint2;
+#endif
     hull_support(g.R1, g.p1, g.V1, g.off1, g.adj1, g.hint1, dir, g.half_margin, o.v1);
     hull_support(g.R2, g.p2, g.V2, g.off2, g.adj2, g.hint2, nd, g.half_margin, o.v2);
+#ifdef KS_STAMP_HULL
+    g.cnt_support += 2; g.cnt_steps += (h1_ != g.hint1) + (h2_ != g.hint2);
+#endif
     sub3(o.v, o.v1, o.v2);
 }
 
@@ -1124,10 +1133,18 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
 }
 
 // hull vs hull (one lane): bounding spheres, exact OBB test, GJK distance for the margin zone, MPR on overlap
+// Hull pairs keep the support vertices their last GJK / MPR query ended on as the hill-climbing start of the next
+// substep (two 10-bit vertex ids packed above the 3-bit contact count in the pair's SCR_PC word): the climb is
+// then a handful of steps instead of a walk across the hull.  The support vertex found does not depend on the start.
+constexpr int PC_COUNT_MASK = 7, PC_HINT_BITS = 10, PC_HINT_MAX = (1 << PC_HINT_BITS) - 1;
+KS_HD int pc_pack(int count, int h1, int h2) { return count + 8 * (h1 + (1 << PC_HINT_BITS) * h2); }
+
 template <typename T, typename S>
-KS_HD int collide_hull_hull(const Model<T>& m, S scr, KS_LDS const PairRec<T>* prp) {
+KS_HD int collide_hull_hull(const Model<T>& m, S scr, KS_LDS const PairRec<T>* prp, int packed_in, int& h1_out, int& h2_out, float* prof = nullptr) {
     KS_LDS const PairRec<T>& pr = *prp;
     PairGeo<T> pg;
+    h1_out = (packed_in >> 3) & PC_HINT_MAX;
+    h2_out = (packed_in >> (3 + PC_HINT_BITS)) & PC_HINT_MAX;
     // the whole record first: one burst of LDS reads, one wait
     const int g1 = pr.g1, g2 = pr.g2, slot = pr.slot, body1 = pr.body1, body2 = pr.body2;
     const T margin = pr.margin, mu = pr.mu, bound = pr.rbound1 + pr.rbound2 + margin;
@@ -1142,16 +1159,40 @@ KS_HD int collide_hull_hull(const Model<T>& m, S scr, KS_LDS const PairRec<T>* p
 #ifndef KS_NO_OBB
     if (obb_separated(pg.R1, pg.p1, size1, pg.R2, pg.p2, size2, margin)) return 0;
 #endif
-    pg.hint1 = 0; pg.hint2 = 0;
+    // hints are only meaningful when they index the pair's own hulls (always, unless a hull has > 1024 vertices)
+    pg.hint1 = h1_out < pg.n1 ? h1_out : 0;
+    pg.hint2 = h2_out < pg.n2 ? h2_out : 0;
     pg.half_margin = T(0);
+#ifdef KS_STAMP_HULL
+    pg.cnt_support = 0; pg.cnt_steps = 0;
+#endif
     T depth, dist, dir[3], pos[3];
     const int r = gjk_distance(pg, margin, &dist, dir, pos);
+#ifdef KS_STAMP_HULL
+    if (prof) { prof[24] += 1.f; prof[25] += (float)pg.cnt_support; if (r == 2) prof[26] += 1.f; }
+    const int sup_gjk = pg.cnt_support;
+#endif
+    h1_out = pg.hint1 & PC_HINT_MAX; h2_out = pg.hint2 & PC_HINT_MAX;
     if (r == 1) { stage_contact(scr, slot, body1, body2, mu, dist, pos, dir); return 1; }
-    if (r == 2 && mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, dir, pos)) {
-        stage_contact(scr, slot, body1, body2, mu, -depth, pos, dir);
-        return 1;
+    if (r == 2) {
+        const bool hit = mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, dir, pos);
+        h1_out = pg.hint1 & PC_HINT_MAX; h2_out = pg.hint2 & PC_HINT_MAX;
+#ifdef KS_STAMP_HULL
+        if (prof) prof[27] += (float)(pg.cnt_support - sup_gjk);
+#endif
+        if (hit) {
+            stage_contact(scr, slot, body1, body2, mu, -depth, pos, dir);
+            return 1;
+        }
     }
     return 0;
+}
+
+// the per-pair words (contact count + support hints) must start from zero once per launch: the hints of a fresh
+// LDS block are garbage
+template <typename T, typename S, int SUBS> KS_HD void reset_pair_words(S scr, Team<SUBS> team) {
+    for (int k = team.sub; k < NPAIR_MAX; k += SUBS) scr(SCR_PC + k) = T(0);
+    team.sync();
 }
 
 template <typename T, typename S, int SUBS>
@@ -1185,10 +1226,10 @@ KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> te
     // hull pairs: dealt round-robin to the lanes of the team
     for (int hk = team.sub; hk < nhull; hk += SUBS) {
         const int pi = hu.hull_pi[hk];
-        int c = 0;
-        if (pairs[pi].slot + 1 <= NSTAGE) c = collide_hull_hull(m, scr, pairs + pi);
+        int c = 0, h1 = 0, h2 = 0;
+        if (pairs[pi].slot + 1 <= NSTAGE) c = collide_hull_hull(m, scr, pairs + pi, (int)scr(SCR_PC + pi), h1, h2, prof);
         else status |= ST_CONTACT_OVERFLOW;
-        scr(SCR_PC + pi) = T(c);
+        scr(SCR_PC + pi) = T(pc_pack(c, h1, h2));
     }
     KS_TICK(9)
     team.sync();
@@ -1203,7 +1244,7 @@ KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> te
     for (int q = 0; q < (NPAIR_MAX + SUBS - 1) / SUBS; q++) before[q] = 0;
     KS_UNROLL
     for (int j = 0; j < NPAIR_MAX; j++) {
-        const int c = j < npair ? (int)cnt[j] : 0;
+        const int c = j < npair ? ((int)cnt[j] & PC_COUNT_MASK) : 0;
         KS_UNROLL
         for (int q = 0; q < (NPAIR_MAX + SUBS - 1) / SUBS; q++) before[q] += (j < team.sub + q * SUBS) ? c : 0;
         total += c;
@@ -1212,7 +1253,7 @@ KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> te
     for (int q = 0; q < (NPAIR_MAX + SUBS - 1) / SUBS; q++) {
         const int pi = team.sub + q * SUBS;
         if (pi < npair) {
-            const int c = (int)scr(SCR_PC + pi), slot = pairs[pi].slot;
+            const int c = (int)scr(SCR_PC + pi) & PC_COUNT_MASK, slot = pairs[pi].slot;
             for (int k = 0; k < c; k++) {
                 const int src = SCR_STAGE + (slot + k) * STAGE_REC, dst = SCR_CON + (before[q] + k) * CON_STRIDE;
                 if (before[q] + k < NCON_MAX) {

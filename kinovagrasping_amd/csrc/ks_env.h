@@ -39,6 +39,7 @@ KS_HD void lane_env_step(const Model<T>& m, const Hulls<T>& hu, LaneState<T>& st
     const T zero3[3] = {0, 0, 0};
     palm_transform(Rpalm, zero3, T3, wrist);     // only the rotation feeds the controls
     action_to_ctrl(T3, act4, ctrl);
+    reset_pair_words<T>(scr, team);
     for (int sub = 0; sub < frame_skip; sub++) {
         T jq[9];
         KS_UNROLL

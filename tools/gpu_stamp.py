@@ -16,7 +16,7 @@ for t in range(30):
     sim.step(acts[t])
     st = sim.get_state(contacts=True)
     torch.cuda.synchronize()
-    prof = st["contact"].reshape(-1, n)[:384].cpu().numpy().reshape(16, 24, n)   # [sub][phase][env]
+    prof = st["contact"].reshape(-1, n)[:480].cpu().numpy().reshape(16, 30, n)[:, :24]   # [sub][phase][env]
     # a wave's time is set by its slowest lane: take the max over the 4 envs x 16 lanes of every wave
     w = prof.transpose(1, 0, 2).reshape(24, 16, n // 4, 4)
     acc += prof.mean(axis=(0, 2))

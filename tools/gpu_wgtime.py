@@ -1,0 +1,39 @@
+"""Dev tool (diagnostic build -DKS_STAMP): when does each workgroup of k_env_step run, and on which CU?"""
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+from kinovagrasping_amd import scenarios
+from kinovagrasping_amd.sim import KinovaSim
+n = 4096
+q0, hq = scenarios.config2_states(n)
+base = scenarios.config_actions(256, 30)
+acts = torch.as_tensor(np.tile(base, (1, 1, n // 256))).cuda()
+sim = KinovaSim(n, "CubeS", auto_reset=True, horizon=30, contact_tap=True)
+sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+for t in range(12):
+    sim.step(acts[t])
+    st = sim.get_state(contacts=True)
+    torch.cuda.synchronize()
+    prof = st["contact"].reshape(-1, n)[:480].cpu().numpy().reshape(16, 30, n)[0]   # lane 0 of every env
+    start, end, hw, xcc = prof[13], prof[14], prof[19].astype(np.int64), prof[20].astype(np.int64)
+    wg = np.arange(n) // 16
+    s0 = start.min()
+    d = (end - start) % (1 << 22)
+    st_rel = (start - s0) % (1 << 22)
+    if t >= 10:
+        print(f"step {t}: per-env loop duration (100MHz ticks) min {d.min():.0f} mean {d.mean():.0f} max {d.max():.0f};  start spread max {st_rel.max():.0f};  last end {((end - s0) % (1<<22)).max():.0f}")
+        cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
+        key = xcc * 1000 + se * 100 + sh * 20 + cu
+        uniq, cnt = np.unique(key[::16], return_counts=True)
+        print("  distinct (xcc,se,sh,cu) used by the 256 workgroups:", len(uniq), " max WGs on one CU:", cnt.max())
+        late = st_rel[::16] > 0.25 * d.mean()
+        print("  workgroups starting late (> 25% of a loop):", int(late.sum()))
+    if t == 11:
+        full = st["contact"].reshape(-1, n)[:480].cpu().numpy().reshape(16, 30, n)
+        names = {0: "fk+dyn", 1: "collision", 2: "constraints", 3: "chol M", 5: "euler", 8: "c:plane", 9: "c:hull", 10: "c:merge", 14: "(end)", 15: "n:chol", 16: "n:solve", 17: "n:pproj", 18: "n:ls", 21: "#newton", 22: "#ls"}
+        order = np.argsort(-d)
+        st2 = sim.get_state()
+        nc = st2["ncon"].cpu().numpy()
+        for rank in (0, 1, 2, 3, n // 2, n - 1):
+            e = order[rank]
+            p = full[:, :, e].max(0)
+            print(f"  env {e} (rank {rank}) duration {d[e]:.0f} ticks, ncon(last) {nc[e]}, total cyc {p[6]:.0f}: " + ", ".join(f"{names[k]} {p[k]:.0f}" for k in (0, 1, 8, 9, 10, 2, 3, 5, 21, 22)) + f" | gjk calls {full[:, 24, e].sum():.0f} gjk supports {full[:, 25, e].sum():.0f} mpr calls {full[:, 26, e].sum():.0f} mpr supports {full[:, 27, e].sum():.0f}; per-lane max gjk sup {full[:, 25, e].max():.0f} mpr sup {full[:, 27, e].max():.0f}")
