@@ -70,6 +70,26 @@ int kr_sample_windows(int32_t batch, int32_t horizon, int32_t n_steps, const int
                       const float *ep_not_done, float *state, float *action, float *next_state, float *reward, float *not_done,
                       float *weight, void *stream);
 
+/* ---- learner glue (DDPGfD.train_batch, DDPGfD.py:219-367): the elementwise steps between the GEMMs, one launch each
+ *
+ *   kr_critic_grad   targets + dLoss/dQ of the critic loss L1 + 0.5 LN with masked row means (DDPGfD.py:256-330):
+ *                      target_Q  = r[:,0] + discount * tq1,   target_QN = sum_i discount^i r[:,i] + discount^n * tqn
+ *                      dq = w / sum(w) * (2 (q - target_Q) + 0.5 * 2 (q - target_QN));  losses[0..2] = (loss, L1, LN)
+ *   kr_relu_backward g = (z > 0) ? g : 0 in place (z = the ReLU OUTPUT of the layer)
+ *   kr_sigmoid_scale_backward  g *= a (1 - a / max_action)  for a = max_action * sigmoid(z)   (DDPGfD.py:32)
+ *   kr_adam_step     torch.optim.Adam (lr, betas, eps, weight_decay as L2 added to the gradient) on a flat parameter buffer;
+ *                      step is a device counter that the caller has already incremented
+ *   kr_soft_update   target = tau * p + (1 - tau) * target on every `freq`-th value of the device counter `it`
+ *                      (DDPGfD.py:360-366), else unchanged
+ */
+int kr_critic_grad(int32_t rows, int32_t n_steps, const float *q, const float *tq1, const float *tqn, const float *reward,
+                   const float *weight, const float *weight_sum, float discount, float *dq, float *losses, void *stream);
+int kr_relu_backward(int64_t count, const float *act, float *grad, void *stream);
+int kr_sigmoid_scale_backward(int64_t count, const float *a, float max_action, float *grad, void *stream);
+int kr_adam_step(int64_t count, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *step, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, void *stream);
+int kr_soft_update(int64_t count, const float *param, float *target, float tau, const int64_t *it, int32_t freq, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

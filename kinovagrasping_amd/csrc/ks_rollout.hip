@@ -183,6 +183,70 @@ __global__ __launch_bounds__(WAVE) void k_sample_windows(int B, int H, int n_ste
     if (lane == 0) weight[r] = w < ceiling ? 1.0f : 0.0f;
 }
 
+// ---- learner glue: plain grid-stride elementwise kernels, no fma contraction where the torch expression has none
+__global__ __launch_bounds__(256) void k_critic_grad(int R, int n, const float* __restrict__ q, const float* __restrict__ tq1,
+                                                     const float* __restrict__ tqn, const float* __restrict__ reward,
+                                                     const float* __restrict__ weight, const float* __restrict__ wsum, float discount,
+                                                     float* __restrict__ dq, float* losses) {
+#pragma clang fp contract(off)
+    // single workgroup: the batch is a few thousand rows; the three masked means are block reductions
+    using Reduce = hipcub::BlockReduce<float, 256>;
+    __shared__ typename Reduce::TempStorage tmp;
+    const float inv = 1.0f / wsum[0];
+    float l1 = 0, ln = 0;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const float t1 = reward[(long)r * n] + discount * tq1[r];
+        float ret = 0, g = 1.0f;
+        for (int i = 0; i < n; i++) { ret += g * reward[(long)r * n + i]; g *= discount; }
+        const float tn = ret + g * tqn[r];
+        const float w = weight ? weight[r] : 1.0f, e1 = q[r] - t1, en = q[r] - tn;
+        l1 += w * e1 * e1;
+        ln += w * en * en;
+        dq[r] = w * inv * (2.0f * e1 + 0.5f * 2.0f * en);
+    }
+    l1 = Reduce(tmp).Sum(l1);
+    __syncthreads();
+    ln = Reduce(tmp).Sum(ln);
+    if (threadIdx.x == 0) { losses[1] = l1 * inv; losses[2] = ln * inv; losses[0] = l1 * inv + 0.5f * (ln * inv); }
+}
+
+__global__ __launch_bounds__(256) void k_relu_backward(long count, const float* __restrict__ act, float* __restrict__ grad) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) grad[i] = act[i] > 0.0f ? grad[i] : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_sigmoid_scale_backward(long count, const float* __restrict__ a, float max_action, float* __restrict__ grad) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) grad[i] *= a[i] * (1.0f - a[i] / max_action);
+}
+
+__global__ __launch_bounds__(256) void k_adam_step(long count, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, const int64_t* __restrict__ step, float lr, float b1, float b2,
+                                                   float eps, float wd) {
+#pragma clang fp contract(off)
+    // torch.optim.Adam, single-tensor formulation: bias corrections from the (already incremented) device step
+    const float t = (float)step[0];
+    const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+    const float step_size = lr / bc1, bc2s = sqrtf(bc2);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) {
+        float gi = g[i];
+        if (wd != 0.0f) gi = gi + wd * p[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);            // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2s + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_soft_update(long count, const float* __restrict__ p, float* __restrict__ tp, float tau,
+                                                     const int64_t* __restrict__ it, int freq) {
+#pragma clang fp contract(off)
+    if (it[0] % freq != 0) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) tp[i] = tau * p[i] + (1.0f - tau) * tp[i];
+}
+
+inline int grid_for(long count) { long b = (count + 255) / 256; return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
+
 inline int launched() { return hipGetLastError() == hipSuccess ? KS_OK : KS_ERR_HIP; }
 
 }  // namespace
@@ -248,6 +312,40 @@ int kr_sample_windows(int32_t batch, int32_t horizon, int32_t n_steps, const int
     hipLaunchKernelGGL(k_sample_windows, dim3(batch * (horizon - n_steps)), dim3(WAVE), 0, (hipStream_t)stream, batch, horizon, n_steps, count,
                        ep_len, u_ep, u_start, ep_state, ep_next, ep_action, ep_reward, ep_not_done, state, action, next_state, reward, not_done,
                        weight);
+    return launched();
+}
+
+int kr_critic_grad(int32_t rows, int32_t n_steps, const float* q, const float* tq1, const float* tqn, const float* reward, const float* weight,
+                   const float* weight_sum, float discount, float* dq, float* losses, void* stream) {
+    if (rows <= 0 || n_steps <= 0 || !q || !tq1 || !tqn || !reward || !weight_sum || !dq || !losses) return KS_ERR_INVALID;
+    hipLaunchKernelGGL(k_critic_grad, dim3(1), dim3(256), 0, (hipStream_t)stream, rows, n_steps, q, tq1, tqn, reward, weight, weight_sum, discount, dq,
+                       losses);
+    return launched();
+}
+
+int kr_relu_backward(int64_t count, const float* act, float* grad, void* stream) {
+    if (count <= 0 || !act || !grad) return KS_ERR_INVALID;
+    hipLaunchKernelGGL(k_relu_backward, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, (long)count, act, grad);
+    return launched();
+}
+
+int kr_sigmoid_scale_backward(int64_t count, const float* a, float max_action, float* grad, void* stream) {
+    if (count <= 0 || !a || !grad) return KS_ERR_INVALID;
+    hipLaunchKernelGGL(k_sigmoid_scale_backward, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, (long)count, a, max_action, grad);
+    return launched();
+}
+
+int kr_adam_step(int64_t count, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* step, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, void* stream) {
+    if (count <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !step) return KS_ERR_INVALID;
+    hipLaunchKernelGGL(k_adam_step, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, (long)count, param, grad, exp_avg, exp_avg_sq, step, lr,
+                       beta1, beta2, eps, weight_decay);
+    return launched();
+}
+
+int kr_soft_update(int64_t count, const float* param, float* target, float tau, const int64_t* it, int32_t freq, void* stream) {
+    if (count <= 0 || freq <= 0 || !param || !target || !it) return KS_ERR_INVALID;
+    hipLaunchKernelGGL(k_soft_update, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, (long)count, param, target, tau, it, freq);
     return launched();
 }
 

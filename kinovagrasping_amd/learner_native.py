@@ -1,0 +1,182 @@
+"""DDPGfD update without autograd: explicit forward / backward GEMMs (PyTorch -> hipBLASLt, matrix cores) with the
+elementwise steps between them as single kernels of libkinova_sim.so (include/kinova_rollout.h).
+
+The eager update (ddpgfd.DDPGfD.train_on_batch: autograd + torch.optim.Adam) is ~180 kernel launches of a few
+microseconds each for two 3-layer MLPs - on MI355X the launches, not the arithmetic, are the cost.  This module does
+the same update in ~75 launches:
+
+  * forward layers are addmm with the ReLU fused in the GEMM epilogue (torch._addmm_activation);
+  * weight gradients are written by the GEMMs straight into one flat gradient buffer per network
+    (torch.mm(..., out=view)), bias gradients by column sums;
+  * targets + critic loss gradient, ReLU / sigmoid backward, Adam and the soft target update are one kernel each
+    (kr_critic_grad, kr_relu_backward, kr_sigmoid_scale_backward, kr_adam_step, kr_soft_update);
+  * with world_size > 1 the flat gradient buffers are all-reduced directly (no pack / unpack).
+
+Same arithmetic as DDPGfD.py:219-367 of the reference (critic loss L1 + 0.5 LN on masked row means, actor loss
+-mean Q(s, pi(s)) over all n-step rows, Adam lr 1e-4 / default lr + weight_decay 1e-4, soft target update every 10th
+call); tests/test_gpu_parity.py checks it against the autograd implementation.  The three `phase_*` methods mirror
+DDPGfD.phase_* so that pipeline.GraphedTrainer can capture them and run the gradient exchange between them.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import sim as _sim
+
+
+class _Net:
+    """views of one MLP's flat parameter buffer + a flat gradient buffer of the same layout + Adam state"""
+
+    def __init__(self, module, flat):
+        self.flat = flat
+        self.grad = torch.zeros_like(flat)
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.W, self.b, self.gW, self.gb = [], [], [], []
+        off = 0
+        for name in ("l1", "l2", "l3"):
+            lin = getattr(module, name)
+            for p, dst_p, dst_g in ((lin.weight, self.W, self.gW), (lin.bias, self.b, self.gb)):
+                n = p.numel()
+                assert p.data.data_ptr() == flat[off:off + n].data_ptr(), "parameters must be views of the flat buffer, in order"
+                dst_p.append(p.data)
+                dst_g.append(self.grad[off:off + n].view_as(p))
+                off += n
+        assert off == flat.numel()
+
+
+class NativeDDPGfDUpdate:
+    def __init__(self, policy):
+        assert policy.device.type == "cuda", "the learner glue kernels are GPU only"
+        self.p = policy
+        self.lib = _sim.load_library()
+        fp = policy._flat_params
+        self.critic, self.actor = _Net(policy.critic, fp["critic"]), _Net(policy.actor, fp["actor"])
+        self.critic_t, self.actor_t = _Net(policy.critic_target, fp["critic_target"]), _Net(policy.actor_target, fp["actor_target"])
+        self.it = torch.zeros(1, dtype=torch.long, device=policy.device)      # updates done (Adam step of both nets)
+        self.losses = torch.zeros(3, device=policy.device)                   # critic loss, L1, LN of the last update
+        ao, co = policy.actor_optimizer.param_groups[0], policy.critic_optimizer.param_groups[0]
+        self.hyper_a = (ao["lr"], ao["betas"][0], ao["betas"][1], ao["eps"], ao["weight_decay"])
+        self.hyper_c = (co["lr"], co["betas"][0], co["betas"][1], co["eps"], co["weight_decay"])
+
+    # -- helpers ------------------------------------------------------------------------------------------------------
+    def _st(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.p.device).cuda_stream)
+
+    @staticmethod
+    def _chk(rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc})")
+
+    @staticmethod
+    def _lin_relu(net, k, x):
+        return torch._addmm_activation(net.b[k], x, net.W[k].t())
+
+    def _actor_forward(self, net, x):
+        h1 = self._lin_relu(net, 0, x)
+        h2 = self._lin_relu(net, 1, h1)
+        a = torch.addmm(net.b[2], h2, net.W[2].t()).sigmoid_().mul_(self.p.max_action)
+        return h1, h2, a
+
+    def _relu_bwd(self, act, grad):
+        self._chk(self.lib.kr_relu_backward(grad.numel(), _sim._ptr(act), _sim._ptr(grad), self._st()), "kr_relu_backward")
+
+    def _adam(self, net, hyper):
+        lr, b1, b2, eps, wd = hyper
+        P = _sim._ptr
+        self._chk(self.lib.kr_adam_step(net.flat.numel(), P(net.flat), P(net.grad), P(net.exp_avg), P(net.exp_avg_sq), P(self.it), lr, b1, b2,
+                                        eps, wd, self._st()), "kr_adam_step")
+
+    def _weight_grads(self, net, x, h1, h2, dz3):
+        """dz3: gradient at the last layer's pre-activation; fills net.grad, returns nothing"""
+        torch.mm(dz3.t(), h2, out=net.gW[2])
+        torch.sum(dz3, 0, out=net.gb[2])
+        dh2 = torch.mm(dz3, net.W[2])
+        self._relu_bwd(h2, dh2)
+        torch.mm(dh2.t(), h1, out=net.gW[1])
+        torch.sum(dh2, 0, out=net.gb[1])
+        dh1 = torch.mm(dh2, net.W[1])
+        self._relu_bwd(h1, dh1)
+        torch.mm(dh1.t(), x, out=net.gW[0])
+        torch.sum(dh1, 0, out=net.gb[0])
+
+    # -- the three phases ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def phase_critic(self, state, action, next_state, reward, weight=None):
+        """targets, critic forward, loss gradient, critic weight gradients -> self.critic.grad"""
+        pol, P = self.p, _sim._ptr
+        self.it += 1
+        R = reward.shape[0]
+        if weight is None:
+            weight = torch.ones(R, device=reward.device)
+        self.weight, self.wsum = weight, weight.sum().reshape(1)
+        # both target evaluations (1-step: next_state[:, 0], n-step: next_state[:, -1]) in one pass of the target nets
+        nx = torch.cat([next_state[:, 0], next_state[:, -1]], 0)
+        _, _, ta = self._actor_forward(self.actor_t, nx)
+        ct = self.critic_t
+        tq = torch.addmm(ct.b[2], self._lin_relu(ct, 1, self._lin_relu(ct, 0, torch.cat([nx, ta], 1))), ct.W[2].t())
+        x0 = torch.cat([state[:, 0], action[:, 0]], 1)
+        c = self.critic
+        h1 = self._lin_relu(c, 0, x0)
+        h2 = self._lin_relu(c, 1, h1)
+        q = torch.addmm(c.b[2], h2, c.W[2].t())
+        dq = torch.empty_like(q)
+        reward = reward.contiguous()
+        self._chk(self.lib.kr_critic_grad(R, pol.n, P(q), P(tq), P(tq[R:]), P(reward), P(weight), P(self.wsum), pol.discount, P(dq), P(self.losses),
+                                          self._st()), "kr_critic_grad")
+        self._weight_grads(c, x0, h1, h2, dq)
+        return self.losses[0], self.losses[1], self.losses[2]
+
+    @torch.no_grad()
+    def phase_actor(self, state, weight=None):
+        """critic Adam step, then the actor loss -mean_w Q(s, pi(s)) over all n-step rows -> self.actor.grad"""
+        pol, P = self.p, _sim._ptr
+        self._adam(self.critic, self.hyper_c)
+        n = state.shape[1]
+        sa = state.reshape(-1, state.shape[2])
+        a_, c = self.actor, self.critic
+        ha1, ha2, a = self._actor_forward(a_, sa)
+        hc1 = self._lin_relu(c, 0, torch.cat([sa, a], 1))
+        hc2 = self._lin_relu(c, 1, hc1)
+        # d(-sum_r w_r sum_k Q_rk / (sum(w) n)) / dQ_rk
+        dq = (self.weight / (self.wsum * (-float(n)))).repeat_interleave(n).unsqueeze(1)
+        dh2 = torch.mm(dq, c.W[2])
+        self._relu_bwd(hc2, dh2)
+        dh1 = torch.mm(dh2, c.W[1])
+        self._relu_bwd(hc1, dh1)
+        da = torch.mm(dh1, c.W[0][:, sa.shape[1]:])                       # only the action columns of the critic's first layer
+        self._chk(self.lib.kr_sigmoid_scale_backward(da.numel(), P(a), pol.max_action, P(da), self._st()), "kr_sigmoid_scale_backward")
+        self._weight_grads(a_, sa, ha1, ha2, da)
+        return None
+
+    @torch.no_grad()
+    def phase_targets(self):
+        """actor Adam step + soft target update on every network_repl_freq-th update"""
+        pol, P = self.p, _sim._ptr
+        self._adam(self.actor, self.hyper_a)
+        pol.total_it += 1
+        for net, tgt in ((self.critic, self.critic_t), (self.actor, self.actor_t)):
+            self._chk(self.lib.kr_soft_update(net.flat.numel(), P(net.flat), P(tgt.flat), pol.tau, P(self.it), pol.network_repl_freq, self._st()),
+                      "kr_soft_update")
+
+    def allreduce(self, net):
+        """average the flat gradient buffer of `net` ("critic" / "actor") over the process group (RCCL), in place"""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        world = dist.get_world_size(self.p.process_group)
+        if world == 1:
+            return
+        g = getattr(self, net).grad
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.p.process_group)
+        g.div_(world)
+
+    def train_on_batch(self, state, action, next_state, reward, weight=None):
+        losses = self.phase_critic(state, action, next_state, reward, weight)
+        self.allreduce("critic")
+        self.phase_actor(state, weight)
+        self.allreduce("actor")
+        self.phase_targets()
+        return losses

@@ -7,9 +7,10 @@ physics kernel takes on the device.  GraphedTrainer captures them once into HIP 
     g_pre    action selection (check_grasp, actor forward, exploration noise, scripted lift)
     ks_step  the simulator (libkinova_sim, launched directly on the stream - not part of a graph)
     g_post   replay writes + episode bookkeeping
-    g_learn  window sampling + one DDPGfD update; with world_size > 1 it is three graphs (critic backward |
-             critic step + actor backward | actor step + targets) with the flat-buffer gradient all-reduce
-             (RCCL) issued between them - collectives stay outside the captures.
+    g_learn  window sampling + one DDPGfD update (learner_native: explicit GEMMs + fused glue kernels); with
+             world_size > 1 it is three graphs (critic backward | critic step + actor backward | actor step +
+             targets) with the all-reduce of the flat gradient buffer (RCCL) issued between them - collectives stay
+             outside the captures.
 
 The learner graphs run on a second stream beside the simulator kernel: they read the replay as it was before this
 step's writes and update the weights after this step's actor forward.
@@ -21,7 +22,6 @@ import torch
 
 class GraphedTrainer:
     def __init__(self, sim, policy, replay, engine, batch_episodes=64, overlap=True, learn_after=31):
-        assert policy.capturable, "DDPGfD(capturable=True) is required for graph capture"
         assert engine.gen is None, "graph capture uses the default CUDA generator"
         self.sim, self.policy, self.replay, self.eng = sim, policy, replay, engine
         self.batch_episodes, self.overlap, self.learn_after = batch_episodes, overlap, learn_after
@@ -40,6 +40,9 @@ class GraphedTrainer:
         self.g_pre = self.g_post = None
         self.g_learn = []
         self.losses = None
+        # the update itself: explicit GEMMs + fused glue kernels (learner_native), same arithmetic as policy.train_on_batch
+        from .learner_native import NativeDDPGfDUpdate
+        self.native = NativeDDPGfDUpdate(policy)
 
     # -- learner phases on the static batch -------------------------------------------------------------
     def _sample(self):
@@ -48,21 +51,20 @@ class GraphedTrainer:
     def _phase1(self):
         self._sample()
         st, ac, ns, rw, nd, w = self.batch
-        self.loss_c = self.policy.phase_critic(st, ac, ns, rw, w)
+        self.loss_c = self.native.phase_critic(st, ac, ns, rw, w)
 
     def _phase2(self):
-        self.loss_a = self.policy.phase_actor(self.batch[0], self.batch[5])
+        self.native.phase_actor(self.batch[0], self.batch[5])
 
     def _phase3(self):
-        self.policy.phase_targets()
+        self.native.phase_targets()
 
     def _learn_eager(self):
-        with torch.enable_grad():
-            self._phase1()
-            self.policy._allreduce_grads(list(self.policy.critic.parameters()))
-            self._phase2()
-            self.policy._allreduce_grads(list(self.policy.actor.parameters()))
-            self._phase3()
+        self._phase1()
+        self.native.allreduce("critic")
+        self._phase2()
+        self.native.allreduce("actor")
+        self._phase3()
 
     def capture(self, warmup_steps=3):
         """Run `warmup_steps` eager steps (allocator / autotune warm-up, as torch.cuda.graphs requires) and capture."""
@@ -89,7 +91,7 @@ class GraphedTrainer:
         pool = None
         for grp in groups:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool), torch.enable_grad():
+            with torch.cuda.graph(g, pool=pool):
                 for p in grp:
                     p()
             pool = g.pool()
@@ -100,11 +102,10 @@ class GraphedTrainer:
         if not self.distributed:
             self.g_learn[0].replay()
         else:
-            pol = self.policy
             self.g_learn[0].replay()
-            pol._allreduce_grads(list(pol.critic.parameters()))
+            self.native.allreduce("critic")
             self.g_learn[1].replay()
-            pol._allreduce_grads(list(pol.actor.parameters()))
+            self.native.allreduce("actor")
             self.g_learn[2].replay()
         self.updates += 1
 

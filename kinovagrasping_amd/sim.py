@@ -25,7 +25,7 @@ EXPORTS = ["ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_
            "ks_get_state", "ks_set_state", "ks_substep", "ks_kernel_time", "ks_version"]
 # include/kinova_rollout.h
 ROLLOUT_EXPORTS = ["kr_select_action", "kr_store_transition", "kr_rank_episodes", "kr_commit_episodes", "kr_advance_ring",
-                   "kr_sample_windows"]
+                   "kr_sample_windows", "kr_critic_grad", "kr_relu_backward", "kr_sigmoid_scale_backward", "kr_adam_step", "kr_soft_update"]
 
 _lib = None
 
@@ -61,6 +61,12 @@ def load_library(path: Path | None = None):
     L.kr_commit_episodes.argtypes = [i32, i32, i32] + [vp] * 16
     L.kr_advance_ring.argtypes = [i32, i32] + [vp] * 6
     L.kr_sample_windows.argtypes = [i32, i32, i32] + [vp] * 16
+    i64 = C.c_int64
+    L.kr_critic_grad.argtypes = [i32, i32] + [vp] * 6 + [f32, vp, vp, vp]
+    L.kr_relu_backward.argtypes = [i64, vp, vp, vp]
+    L.kr_sigmoid_scale_backward.argtypes = [i64, vp, f32, vp, vp]
+    L.kr_adam_step.argtypes = [i64, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, vp]
+    L.kr_soft_update.argtypes = [i64, vp, vp, f32, vp, i32, vp]
     _lib = L
     return L
 

@@ -321,3 +321,37 @@ def test_rollout_kernels_equal_torch_bookkeeping():
     u = torch.rand(64 * 26, device=dev, generator=g)
     for x, y in zip(ra.sample_batch_nstep(64, uniforms=u), rb.sample_batch_nstep(64, uniforms=u)):
         assert torch.equal(x, y)
+
+
+def test_native_learner_update_equals_autograd_update():
+    """learner_native (explicit GEMMs + kr_* glue kernels) against DDPGfD.train_on_batch (autograd + torch.optim.Adam):
+    same losses and the same parameters / targets after several updates on masked fixed-shape batches."""
+    from kinovagrasping_amd.ddpgfd import DDPGfD
+    from kinovagrasping_amd.learner_native import NativeDDPGfDUpdate
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(7)
+    pa = DDPGfD(82, 4, 0.8, 5, hidden=(256, 256), device=dev)
+    torch.manual_seed(7)
+    pb = DDPGfD(82, 4, 0.8, 5, hidden=(256, 256), device=dev)
+    nat = NativeDDPGfDUpdate(pb)
+    g = torch.Generator(device=dev).manual_seed(3)
+    R, n = 320, 5
+    for it in range(12):                      # crosses the soft target update of the 10th call
+        st = torch.randn(R, n, 82, device=dev, generator=g) * 0.3
+        ns = torch.randn(R, n, 82, device=dev, generator=g) * 0.3
+        ac = torch.rand(R, n, 4, device=dev, generator=g) * 0.8
+        rw = torch.rand(R, n, device=dev, generator=g) * 5
+        w = (torch.rand(R, device=dev, generator=g) < 0.8).float()
+        la = pa.train_on_batch(st, ac, ns, rw, w)
+        lb = nat.train_on_batch(st, ac, ns, rw, w)
+        for x, y in zip(la[1:], lb):
+            assert abs(x.item() - y.item()) <= 2e-4 * max(1.0, abs(x.item())), (it, x.item(), y.item())
+    for name in ("critic", "actor", "critic_target", "actor_target"):
+        a, b = pa._flat_params[name], pb._flat_params[name]
+        err = (a - b).abs().max().item()
+        print(f"{name}: max |autograd - native| after 12 updates = {err:.2e} (max |param| {a.abs().max().item():.2f})")
+        # Adam moves every entry by ~lr per update whatever the gradient's size, so entries whose gradient is rounding
+        # noise may drift apart by a fraction of lr * updates; the bound is 10 % of that path length
+        lr = 1e-3 if name.startswith("critic") else 1e-4
+        assert err <= 0.1 * lr * 12, name
+    assert (pa._flat_params["critic_target"] - pa._flat_params["critic"]).abs().max().item() > 0
