@@ -80,11 +80,16 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(1, int(os.environ.get("KS_VISIBLE_GPUS", "1000000")))
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # backend nccl = RCCL over xGMI; KS_DIST_BACKEND=gloo lets two ranks share one GPU (plumbing check only)
+        backend = os.environ.get("KS_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     n = args.envs_per_gpu
     dev = torch.device("cuda", local_rank)
     # envs shard by global index: rank r owns envs [r*n, (r+1)*n); no data-path collective in the sim

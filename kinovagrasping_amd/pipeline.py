@@ -81,17 +81,19 @@ class GraphedTrainer:
         self.main.wait_stream(s)
         torch.cuda.synchronize(self.dev)
         self.g_pre = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_pre):
+        # thread_local: other threads (the RCCL watchdog of torch.distributed) keep issuing HIP calls during a capture
+        mode = dict(capture_error_mode="thread_local")
+        with torch.cuda.graph(self.g_pre, **mode):
             eng.pre()
         self.g_post = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_post):
+        with torch.cuda.graph(self.g_post, **mode):
             eng.post()
         phases = [self._phase1, self._phase2, self._phase3]
         groups = [[p] for p in phases] if self.distributed else [phases]
         pool = None
         for grp in groups:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, **mode):
                 for p in grp:
                     p()
             pool = g.pool()

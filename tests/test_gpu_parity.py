@@ -355,3 +355,37 @@ def test_native_learner_update_equals_autograd_update():
         lr = 1e-3 if name.startswith("critic") else 1e-4
         assert err <= 0.1 * lr * 12, name
     assert (pa._flat_params["critic_target"] - pa._flat_params["critic"]).abs().max().item() > 0
+
+
+def test_graphed_trainer_runs_rollout_and_updates():
+    """pipeline.GraphedTrainer end to end on 256 envs: the HIP-graph replay of pre / sim / learner / post advances
+    episodes, fills the replay, updates both networks and keeps everything finite."""
+    from kinovagrasping_amd.ddpgfd import DDPGfD
+    from kinovagrasping_amd.pipeline import GraphedTrainer
+    from kinovagrasping_amd.replay import DeviceEpisodeReplay
+    from kinovagrasping_amd.rollout import RolloutEngine
+    n = 256
+    q0, hq = scenarios.config2_states(n)
+    sim = _sim(n, "CubeS", horizon=30, auto_reset=True)
+    obs0 = sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+    torch.manual_seed(2)
+    policy = DDPGfD(82, 4, 0.8, 5, batch_size=64, hidden=(256, 256), device=sim.device)
+    w0 = policy._flat_params["actor"].clone(), policy._flat_params["critic"].clone(), policy._flat_params["critic_target"].clone()
+    replay = DeviceEpisodeReplay(n, capacity=1024, horizon=30, device=sim.device)
+    eng = RolloutEngine(sim, policy, replay, expl_noise=0.1)
+    eng.start(obs0)
+    tr = GraphedTrainer(sim, policy, replay, eng, batch_episodes=16)
+    tr.capture()
+    ep_done = 0
+    for _ in range(70):
+        rew, done = tr.step()
+        ep_done += int(done.sum())
+    torch.cuda.synchronize()
+    assert tr.updates >= 35 and ep_done >= 2 * n
+    assert replay.count >= n                               # every env committed at least one episode
+    for w_before, name in zip(w0, ("actor", "critic", "critic_target")):
+        w = policy._flat_params[name]
+        assert torch.isfinite(w).all() and (w - w_before).abs().max().item() > 0, name
+    assert torch.isfinite(tr.native.losses).all()
+    assert (sim.get_state()["status"] & 2).sum().item() == 0
+    sim.close()
