@@ -12,6 +12,7 @@
  *   ks_step                  <- KinovaGripper_Env.step: action->ctrl, 15 x sim.step(),
  *                               _get_obs(), _get_reward()                           ENV:1495-1552
  *                               + gym TimeLimit (max_episode_steps)                 gym_kinova_gripper/__init__.py:3-7, main_DDPGfD.py:384
+ *   ks_set_env_params        <- (none: the reference edits geom mass / pair friction in the XML; config-5 extension)
  *   ks_get_state/ks_set_state<- sim.data.qpos / qvel / qacc_warmstart, sim.data.ncon,
  *                               contact forces (parity taps)                        ENV:109, 347-353
  *
@@ -95,6 +96,11 @@ int ks_step(ks_ctx *ctx, const void *action, void *obs, void *reward, uint8_t *d
  * status: int32 [N] sticky bit flags (1 contact overflow, 2 non-finite state). */
 int ks_get_state(ks_ctx *ctx, void *qpos, void *qvel, void *qacc_warmstart, void *contact, int32_t *ncon, int32_t *status, void *stream);
 int ks_set_state(ks_ctx *ctx, const void *qpos, const void *qvel, const void *qacc_warmstart, void *stream);
+
+/* Per-env domain randomisation (BASELINE config 5; an extension: the reference fixes the object's mass at 0.1 kg,
+ * XML:153, and the object-hand friction at 1, XML:160-166).  obj_mass [N] (kg; the inertia scales with it), obj_mu [N]
+ * (friction of the seven object-hand pairs); either pointer may be NULL = leave as is.  Defaults are the model's. */
+int ks_set_env_params(ks_ctx *ctx, const void *obj_mass, const void *obj_mu, void *stream);
 
 /* Advance by ONE mj_step with explicit controls ctrl [9, N] (no observation); parity testing. */
 int ks_substep(ks_ctx *ctx, const void *ctrl, void *stream);

@@ -10,6 +10,7 @@
 // No CPU fallback exists in this library.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -33,6 +34,7 @@ template <typename T> struct Buffers {
     T *rays;                      // [17][N]
     T *contact;                   // [NCON_MAX*CON_STRIDE][N] parity tap (last substep)
     T *gscratch;                  // [SCR_TOTAL][N] (fp64 contexts only; fp32 uses LDS)
+    T *envp;                      // [2][N] per-env object mass, object-hand friction (config 5 randomisation)
     int32_t *ncon, *status, *step_count;
     uint8_t *flag;                // envs to (re)initialise
 };
@@ -128,6 +130,12 @@ template <typename T, int SUBS_> __device__ __forceinline__ void store_state_tea
 }
 static_assert(sizeof(LaneState<float>) == (NQ + 2 * NV) * sizeof(float), "LaneState is qpos | qvel | warm, packed");
 
+// per-env randomised parameters -> the env's scratch block
+template <typename T, typename S, int SUBS_> __device__ __forceinline__ void load_env_params(S scr, Team<SUBS_> team, const Buffers<T>& b, int env, int N) {
+    if (team.sub == 0) { scr(SCR_ENVP) = b.envp[env]; scr(SCR_ENVP + 1) = b.envp[(long)N + env]; }
+    team.sync();
+}
+
 constexpr int SUBS = 16;         // lanes per env (a DPP row)
 constexpr int WG = 256;          // stepping workgroup: four waves, one per SIMD of the CU, sharing the hull tables in LDS
 constexpr int EPW_MAX = WG / SUBS;
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
         // state and per-step constants in the env's LDS block, reached through generic pointers
         T* stp = (T*)(blk + SCR_STATE);
         load_state_team<T, SUBS>(b, env, N, stp, team.sub);
-        team.sync();
+        load_env_params(scr, team, b, env, N);
         lane_env_step(m, hu, *(LaneState<T>*)stp, hq, act, scr, team, snap, frame_skip, iters, ncon, status, prof, stp + NQ + 2 * NV);
 #ifdef KS_STAMP
         // diagnostic build only: per-phase cycle sums of this lane go to the contact tap buffer
@@ -198,6 +206,7 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
         LaneState<T> st;
         load_state(b, env, N, st);
         Scratch<T> scr{b.gscratch + env, N};
+        load_env_params(scr, team, b, env, N);
         lane_env_step(m, hu, st, hq, act, scr, team, snap, frame_skip, iters, ncon, status);
         if (team.sub == 0) {
             for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
@@ -242,12 +251,14 @@ __global__ __launch_bounds__(WG) void k_substep(const Model<T>* __restrict__ mp,
     int ncon = 0, status = 0;
     if constexpr (USE_LDS) {
         ScratchC<T, KS_LDS T*> scr{lds + ((hull_words >> 2) << 2) + e * SCR_TOTAL};
+        load_env_params(scr, team, b, env, N);
         reset_pair_words<T>(scr, team);
         mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, c, R7, scr, team, iters, true, ncon, status);
         if (team.sub == 0)
             for (int k = 0; k < (tap ? ncon * CON_STRIDE : 0); k++) b.contact[(long)k * N + env] = scr(SCR_CON + k);
     } else {
         Scratch<T> scr{b.gscratch + env, N};
+        load_env_params(scr, team, b, env, N);
         reset_pair_words<T>(scr, team);
         mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, c, R7, scr, team, iters, true, ncon, status);
         if (team.sub == 0)
@@ -367,6 +378,7 @@ struct CtxBase {
     virtual int step(const void* action, void* obs, void* reward, uint8_t* done, void* info, void* final_obs, hipStream_t s) = 0;
     virtual int get_state(void* qpos, void* qvel, void* warm, void* contact, int32_t* ncon, int32_t* status, hipStream_t s) = 0;
     virtual int set_state(const void* qpos, const void* qvel, const void* warm, hipStream_t s) = 0;
+    virtual int set_env_params(const void* mass, const void* mu, hipStream_t s) = 0;
     virtual int substep(const void* ctrl, hipStream_t s) = 0;
     virtual int kernel_time(int reset, double* avg_ms, int64_t* launches) = 0;
 };
@@ -416,6 +428,7 @@ template <typename T> struct Ctx : CtxBase {
         if ((r = alloc(&b.rays, NRAY * N))) return r;
         if ((r = alloc(&b.contact, (size_t)NCON_MAX * CON_STRIDE * N))) return r;
         if (!USE_LDS && (r = alloc(&b.gscratch, (size_t)SCR_TOTAL * N))) return r;
+        if ((r = alloc(&b.envp, (size_t)2 * N))) return r;
         if ((r = alloc(&b.ncon, N))) return r;
         if ((r = alloc(&b.status, N))) return r;
         if ((r = alloc(&b.step_count, N))) return r;
@@ -467,6 +480,14 @@ template <typename T> struct Ctx : CtxBase {
             const int iwords = (adj_ints * (int)sizeof(unsigned short) + (int)sizeof(T) - 1) / (int)sizeof(T);
             hull_words += (iwords + 3) & ~3;
             hull_words += NPAIR_MAX * pair_rec_bytes<T>() / (int)sizeof(T);
+        }
+        {
+            // nominal per-env parameters until ks_set_env_params says otherwise
+            T mass, mu;
+            nominal_env_params(hm.m, mass, mu);
+            std::vector<T> ep(2 * (size_t)cfg.n_envs, mu);
+            std::fill(ep.begin(), ep.begin() + cfg.n_envs, mass);
+            HIPCHK(hipMemcpy(b.envp, ep.data(), ep.size() * sizeof(T), hipMemcpyHostToDevice));
         }
         int r = plan_launch();
         if (r != KS_OK) return r;
@@ -545,6 +566,13 @@ template <typename T> struct Ctx : CtxBase {
         if (qpos) HIPCHK(hipMemcpyAsync(b.qpos, qpos, NQ * N * sizeof(T), hipMemcpyDefault, s));
         if (qvel) HIPCHK(hipMemcpyAsync(b.qvel, qvel, NV * N * sizeof(T), hipMemcpyDefault, s));
         if (warm) HIPCHK(hipMemcpyAsync(b.warm, warm, NV * N * sizeof(T), hipMemcpyDefault, s));
+        return KS_OK;
+    }
+    int set_env_params(const void* mass, const void* mu, hipStream_t s) override {
+        if (!model_loaded) { error = "ks_set_env_params before ks_load_model"; return KS_ERR_STATE; }
+        const size_t N = cfg.n_envs;
+        if (mass) HIPCHK(hipMemcpyAsync(b.envp, mass, N * sizeof(T), hipMemcpyDefault, s));
+        if (mu) HIPCHK(hipMemcpyAsync(b.envp + N, mu, N * sizeof(T), hipMemcpyDefault, s));
         return KS_OK;
     }
     int kernel_time(int reset, double* avg_ms, int64_t* launches) override {
@@ -635,6 +663,10 @@ int ks_get_state(ks_ctx* ctx, void* qpos, void* qvel, void* warm, void* contact,
 int ks_set_state(ks_ctx* ctx, const void* qpos, const void* qvel, const void* warm, void* stream) {
     if (!ctx) return KS_ERR_INVALID;
     return ctx->impl->set_state(qpos, qvel, warm, (hipStream_t)stream);
+}
+int ks_set_env_params(ks_ctx* ctx, const void* obj_mass, const void* obj_mu, void* stream) {
+    if (!ctx) return KS_ERR_INVALID;
+    return ctx->impl->set_env_params(obj_mass, obj_mu, (hipStream_t)stream);
 }
 int ks_substep(ks_ctx* ctx, const void* ctrl, void* stream) {
     if (!ctx) return KS_ERR_INVALID;

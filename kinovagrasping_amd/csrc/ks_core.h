@@ -27,6 +27,8 @@ namespace ks {
 // body poses b = 2..9: 12 each (R row-major 9, p 3)
 constexpr int SCR_BP = 0;
 constexpr int SCR_AX = SCR_BP + 8 * 12;      // world slide axes, 3 x 3 (+3 pad: every region starts on a 16-byte boundary)
+// per-env randomised parameters (BASELINE config 5): object mass, object-hand friction - in the padding
+constexpr int SCR_ENVP = SCR_AX + 9;
 constexpr int SCR_CON = SCR_AX + 12;
 constexpr int CON_STRIDE = 20;
 // per contact: 0-2 pos, 3-5 normal, 6 dist, 7 mu, 8 bodies (b1 + 16*b2), 9 R, 10-13 aref[4],
@@ -219,7 +221,8 @@ template <typename T> struct alignas(16) PairRec {
     T rbound2, size2[3];
     int body1, body2;
     int n1, n2;                // padded hull vertex counts; n2 of a plane pair is the true count
-    int slot, pad_;            // first staging record of the pair (4 per plane pair, 1 per hull pair, pair order)
+    int slot, obj_hand;        // first staging record of the pair (4 per plane pair, 1 per hull pair, pair order);
+                               // obj_hand: object vs hand geom - the pair whose friction may be set per env
     KS_LDS const T* V1; KS_LDS const T* V2;
     KS_LDS const unsigned short* off1; KS_LDS const unsigned short* adj1;
     KS_LDS const unsigned short* off2; KS_LDS const unsigned short* adj2;
@@ -258,7 +261,7 @@ template <typename T> KS_HD void fill_pair_rec(const Model<T>& m, const Hulls<T>
     r.g1 = g1; r.g2 = g2; r.margin = m.pair_margin[pi]; r.mu = m.pair_mu[pi];
     int slot = 0;
     for (int j = 0; j < pi; j++) slot += ((hu.plane_mask >> j) & 1u) ? 4 : 1;
-    r.slot = slot; r.pad_ = 0;
+    r.slot = slot; r.obj_hand = (g1 != 0 && g2 == NGEOM - 1) ? 1 : 0;
     r.rbound1 = m.geom_rbound[g1]; r.rbound2 = m.geom_rbound[g2];
     for (int k = 0; k < 3; k++) { r.size1[k] = m.geom_size[g1][k]; r.size2[k] = m.geom_size[g2][k]; }
     r.body1 = m.geom_body[g1]; r.body2 = m.geom_body[g2];
@@ -347,6 +350,14 @@ template <typename T, typename S> KS_HD void geom_pose(const Model<T>& m, S scr,
     mulRR(R, Rb, m.geom_R[g]);
     mulRv(t, Rb, m.geom_pos[g]);
     add3(p, pb, t);
+}
+
+// nominal values of the per-env parameters: the model's object mass and the friction of its object-hand pairs
+template <typename T> KS_HD void nominal_env_params(const Model<T>& m, T& mass, T& mu) {
+    mass = m.mass[NBODY - 1];
+    mu = T(1);
+    for (int pi = 0; pi < m.npair; pi++)
+        if (m.pair_g1[pi] != 0 && m.pair_g2[pi] == NGEOM - 1) { mu = m.pair_mu[pi]; break; }
 }
 
 // world pose of geom g (1..8) as stored by dynamics_rows
@@ -449,7 +460,7 @@ KS_FN void dynamics_rows(const Model<T>& m, const T* qpos, const T* qvel, const 
             for (int j = 0; j < 9; j++) scr(SCR_BP + 7 * 12 + j) = Ro[j];
             KS_UNROLL
             for (int j = 0; j < 3; j++) scr(SCR_BP + 7 * 12 + 9 + j) = qpos[9 + j];
-            const T mo = m.mass[9];
+            const T mo = scr(SCR_ENVP), ms = mo / m.mass[9];   // per-env mass; the inertia scales with it
             T c[3];
             mulRv(c, Ro, m.ipos[9]);
             KS_UNROLL
@@ -465,7 +476,7 @@ KS_FN void dynamics_rows(const Model<T>& m, const T* qpos, const T* qvel, const 
                 for (int i = 0; i < 3; i++) { scr(SCR_MO + i * 6 + 3 + a) = mo * w[i]; scr(SCR_MO + (3 + a) * 6 + i) = mo * w[i]; }
                 KS_UNROLL
                 for (int b = 0; b < 3; b++)
-                    scr(SCR_MO + (3 + a) * 6 + 3 + b) = m.obj_Ib[a * 3 + b] + mo * ((a == b ? cc : T(0)) - cb[a] * cb[b]) + (a == b ? m.armature[12 + a] : T(0));
+                    scr(SCR_MO + (3 + a) * 6 + 3 + b) = ms * m.obj_Ib[a * 3 + b] + mo * ((a == b ? cc : T(0)) - cb[a] * cb[b]) + (a == b ? m.armature[12 + a] : T(0));
             }
             // bias: F = m (w x (w x c) + g e_z), T = w x I w ; angular rows in the body frame
             T wl[3] = {qvel[12], qvel[13], qvel[14]}, w[3], u[3], ac[3];
@@ -476,6 +487,7 @@ KS_FN void dynamics_rows(const Model<T>& m, const T* qpos, const T* qvel, const 
             scl3(F, ac, mo);
             T Iwl[3], tl[3];
             mulRv(Iwl, m.obj_Ib, wl);
+            scl3(Iwl, Iwl, ms);
             cross3(tl, wl, Iwl);
             T cF[3], cFl[3];
             cross3(cF, c, F);
@@ -1147,7 +1159,7 @@ KS_HD int collide_hull_hull(const Model<T>& m, S scr, KS_LDS const PairRec<T>* p
     h2_out = (packed_in >> (3 + PC_HINT_BITS)) & PC_HINT_MAX;
     // the whole record first: one burst of LDS reads, one wait
     const int g1 = pr.g1, g2 = pr.g2, slot = pr.slot, body1 = pr.body1, body2 = pr.body2;
-    const T margin = pr.margin, mu = pr.mu, bound = pr.rbound1 + pr.rbound2 + margin;
+    const T margin = pr.margin, mu = pr.obj_hand ? T(scr(SCR_ENVP + 1)) : pr.mu, bound = pr.rbound1 + pr.rbound2 + margin;
     const T size1[3] = {pr.size1[0], pr.size1[1], pr.size1[2]}, size2[3] = {pr.size2[0], pr.size2[1], pr.size2[2]};
     pg.V1 = pr.V1; pg.n1 = pr.n1; pg.off1 = pr.off1; pg.adj1 = pr.adj1;
     pg.V2 = pr.V2; pg.n2 = pr.n2; pg.off2 = pr.off2; pg.adj2 = pr.adj2;
@@ -1456,7 +1468,10 @@ KS_HD void make_constraints(const Model<T>& m, const T* qpos, const T* qvel, S s
         const T margin = m.pair_margin[0];   // one margin for every pair of this model (XML:40)
         T rr = dist - margin;
         T imp = impedance(m.solimp, rr);
-        T w = m.body_invw[bb & 15] + m.body_invw[bb >> 4];
+        // the object's inverse weight follows its per-env mass
+        const T wobj = m.body_invw[NBODY - 1] * (m.mass[NBODY - 1] + m.armature[9]) / (T(scr(SCR_ENVP)) + m.armature[9]);
+        const int cb1 = bb & 15, cb2 = bb >> 4;
+        T w = (cb1 == NBODY - 1 ? wobj : m.body_invw[cb1]) + (cb2 == NBODY - 1 ? wobj : m.body_invw[cb2]);
         T diag = (w + mu * mu * w) * 2 * mu * mu / m.impratio;
         T R = (1 - imp) / imp * diag;
         // rows with dist >= margin are inactive: flag with R < 0

@@ -4,8 +4,8 @@ on separate HIP streams, presented as one batch.
 The reference swaps the object by loading a different MJCF per episode (kinova_gripper_env.py:986-1005,
 Latin-square queue ENV:895-964); here env i keeps the shape `shapes[i * len(shapes) // N]` for its whole
 life, which is the in-memory replacement SURVEY.md section 2 row 17 describes.  Per-env object mass /
-friction randomisation (an extension beyond the reference) is not implemented: every
-env uses the nominal 0.1 kg, mu = 1 of the XML.
+object-hand friction (an extension beyond the reference, SURVEY 8d config 5: mass ~ U[0.05, 0.15] kg,
+mu ~ U[0.5, 1.0]) go through `set_env_params` (ks_set_env_params); `scenarios.config5_env_params` draws them.
 """
 from __future__ import annotations
 
@@ -53,6 +53,12 @@ class MultiShapeSim:
         self.final_obs = torch.cat([s.final_obs for s in self.sims], 0)
         return (torch.cat([x[0] for x in outs], 0), torch.cat([x[1] for x in outs], 0), torch.cat([x[2] for x in outs], 0),
                 torch.cat([x[3] for x in outs], 1))
+
+    def set_env_params(self, obj_mass=None, obj_mu=None):
+        """per-env object mass [N] and object-hand friction [N] (None = leave as is)"""
+        o = self.offsets
+        for i, sim in enumerate(self.sims):
+            sim.set_env_params(None if obj_mass is None else obj_mass[o[i]:o[i + 1]], None if obj_mu is None else obj_mu[o[i]:o[i + 1]])
 
     def get_state(self):
         sts = [s.get_state() for s in self.sims]

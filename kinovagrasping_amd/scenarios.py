@@ -56,6 +56,13 @@ def config2_states(n_envs: int, shape: str = "CubeS"):
     return q, hq
 
 
+def config5_env_params(n_envs: int, seed: int = 5):
+    """BASELINE config 5 domain randomisation: object mass ~ U[0.05, 0.15] kg and finger-object
+    friction ~ U[0.5, 1.0] per env, Generator(PCG64(seed)); returns (mass [N], mu [N]) float64."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.uniform(0.05, 0.15, n_envs), rng.uniform(0.5, 1.0, n_envs)
+
+
 def config_actions(n_envs: int, n_steps: int = 30, base_seed: int = 1000) -> np.ndarray:
     """Per-env action streams Generator(PCG64(base_seed + i)).uniform(-0.8, 0.8, (n_steps, 4)) as
     float32; returns [n_steps, 4, N].  (Config 1 is base_seed=0 with one env.)"""

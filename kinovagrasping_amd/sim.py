@@ -22,7 +22,7 @@ class KsConfig(C.Structure):
 
 
 EXPORTS = ["ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_load_model", "ks_reset", "ks_step",
-           "ks_get_state", "ks_set_state", "ks_substep", "ks_kernel_time", "ks_version"]
+           "ks_get_state", "ks_set_state", "ks_set_env_params", "ks_substep", "ks_kernel_time", "ks_version"]
 # include/kinova_rollout.h
 ROLLOUT_EXPORTS = ["kr_select_action", "kr_store_transition", "kr_rank_episodes", "kr_commit_episodes", "kr_advance_ring",
                    "kr_sample_windows", "kr_critic_grad", "kr_relu_backward", "kr_sigmoid_scale_backward", "kr_adam_step", "kr_soft_update"]
@@ -52,6 +52,7 @@ def load_library(path: Path | None = None):
     L.ks_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.ks_get_state.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.ks_set_state.argtypes = [vp, vp, vp, vp, vp]
+    L.ks_set_env_params.argtypes = [vp, vp, vp, vp]
     L.ks_substep.argtypes = [vp, vp, vp]
     L.ks_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     i32, f32 = C.c_int32, C.c_float
@@ -167,6 +168,15 @@ class KinovaSim:
     def set_state(self, qpos=None, qvel=None, qacc_warmstart=None):
         ts = [None if t is None else t.to(self.device, self.dtype).contiguous() for t in (qpos, qvel, qacc_warmstart)]
         self._check(self.lib.ks_set_state(self.ctx, _ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def set_env_params(self, obj_mass=None, obj_mu=None):
+        """Per-env object mass [N] (kg) and object-hand friction [N] (BASELINE config 5); None leaves a parameter as is."""
+        ts = [None if t is None else torch.as_tensor(t).to(self.device, self.dtype).contiguous() for t in (obj_mass, obj_mu)]
+        for t in ts:
+            if t is not None and t.numel() != self.n_envs:
+                raise ValueError("set_env_params: one value per env")
+        self._check(self.lib.ks_set_env_params(self.ctx, _ptr(ts[0]), _ptr(ts[1]), self._stream()))
         torch.cuda.current_stream(self.device).synchronize()
 
     def kernel_time(self, reset: bool = False):

@@ -92,6 +92,10 @@ typedef struct {
     double newton_last_grad;
     int newton_iters_used;
     int rays_enabled; /* 0: skip the 17 rangefinders in ko_forward (only the last substep's values are ever read) */
+    /* per-env domain randomisation (BASELINE config 5; an extension - the reference fixes mass 0.1 and mu 1):
+     * obj_mass > 0 replaces the object's mass (inertia scales with it, its body_invweight0 by
+     * (m0 + armature) / (m + armature)); obj_mu > 0 replaces the friction of the object-hand pairs. */
+    double obj_mass, obj_mu;
 } ko_sim;
 
 /* ---- model ---- */

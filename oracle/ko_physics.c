@@ -177,8 +177,19 @@ static void jac_point(const ko_sim *s, int body, const double *x, double Jp[3][K
     }
 }
 
+/* mass of body b and the factor on its inertia: the object's may be replaced per sim (config 5) */
+static double body_mass_of(const ko_sim *s, int b) { return (b == KO_NBODY - 1 && s->obj_mass > 0) ? s->obj_mass : s->m->body_mass[b]; }
+static double inertia_scale_of(const ko_sim *s, int b) { return body_mass_of(s, b) / s->m->body_mass[b]; }
+static double body_invweight_of(const ko_sim *s, int b) {
+    const ko_model *m = s->m;
+    double w = m->body_invweight0[b][0];
+    if (b == KO_NBODY - 1 && s->obj_mass > 0) w *= (m->body_mass[b] + m->dof_armature[9]) / (s->obj_mass + m->dof_armature[9]);
+    return w;
+}
+
 static void world_inertia(const ko_sim *s, int b, double Iw[9]) {
-    const double *Ri = s->ximat[b], *d = s->m->body_inertia[b];
+    const double *Ri = s->ximat[b], *d0 = s->m->body_inertia[b];
+    const double sc = inertia_scale_of(s, b), d[3] = {d0[0] * sc, d0[1] * sc, d0[2] * sc};
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++)
             Iw[3 * i + j] = Ri[3 * i] * d[0] * Ri[3 * j] + Ri[3 * i + 1] * d[1] * Ri[3 * j + 1] + Ri[3 * i + 2] * d[2] * Ri[3 * j + 2];
@@ -197,7 +208,7 @@ static void mass_matrix(ko_sim *s) {
             for (int j = 0; j < KO_NV; j++) {
                 double acc = 0;
                 for (int r = 0; r < 3; r++) {
-                    acc += m->body_mass[b] * Jp[r][i] * Jp[r][j];
+                    acc += body_mass_of(s, b) * Jp[r][i] * Jp[r][j];
                     acc += Jr[r][i] * (Iw[3 * r] * Jr[0][j] + Iw[3 * r + 1] * Jr[1][j] + Iw[3 * r + 2] * Jr[2][j]);
                 }
                 s->M[i][j] += acc;
@@ -271,7 +282,7 @@ static void bias_forces(ko_sim *s) {
         add3(ac, a0[b], t);
         add3(ac, ac, u);
         ac[2] -= m->gravity_z; /* a_com - g */
-        scl3(F, ac, m->body_mass[b]);
+        scl3(F, ac, body_mass_of(s, b));
         mulmatvec3(T, Iw, alpha[b]);
         mulmatvec3(Iwv, Iw, w[b]);
         cross3(t, w[b], Iwv);
@@ -657,6 +668,7 @@ static void add_contact(ko_sim *s, int g1, int g2, const double *pair, double di
     ko_contact *c = &s->contact[s->ncon++];
     c->dist = dist; c->geom1 = g1; c->geom2 = g2;
     c->mu[0] = pair[2]; c->mu[1] = pair[3]; c->margin = pair[4];
+    if (s->obj_mu > 0 && g1 != 0 && g2 == KO_NGEOM - 1) c->mu[0] = c->mu[1] = s->obj_mu; /* object-hand pairs */
     copy3(c->pos, pos);
     copy3(c->frame, normal);
     make_frame(c->frame);
@@ -795,7 +807,7 @@ static void make_constraint(ko_sim *s) {
             for (int j = 0; j < KO_NV; j++)
                 Jd[a][j] = c->frame[3 * a] * (Jp2[0][j] - Jp1[0][j]) + c->frame[3 * a + 1] * (Jp2[1][j] - Jp1[1][j]) +
                            c->frame[3 * a + 2] * (Jp2[2][j] - Jp1[2][j]);
-        double w = m->body_invweight0[b1][0] + m->body_invweight0[b2][0], mu = c->mu[0];
+        double w = body_invweight_of(s, b1) + body_invweight_of(s, b2), mu = c->mu[0];
         double diag = (w + mu * mu * w) * 2 * mu * mu / m->impratio;
         for (int k = 0; k < 4; k++) {
             double sgn = (k & 1) ? -1.0 : 1.0, muk = c->mu[k >> 1];

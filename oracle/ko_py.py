@@ -37,6 +37,7 @@ class Sim(C.Structure):
         ("qfrc_bias", d * NV), ("qfrc_passive", d * NV), ("qfrc_actuator", d * NV), ("qfrc_constraint", d * NV),
         ("qacc_smooth", d * NV), ("qacc", d * NV),
         ("mpr_calls", C.c_int), ("mpr_support_calls", C.c_int), ("newton_last_grad", d), ("newton_iters_used", C.c_int), ("rays_enabled", C.c_int),
+        ("obj_mass", d), ("obj_mu", d),
     ]
 
 

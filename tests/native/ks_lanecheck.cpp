@@ -38,6 +38,7 @@ static int substep_t(const Model<T>& m, double* qpos, double* qvel, double* warm
                      double* con) {
     std::vector<T> scrbuf(SCR_TOTAL, T(0));
     Scratch<T> scr{scrbuf.data(), 1};
+    { T mass, mu; nominal_env_params(m, mass, mu); scr(SCR_ENVP) = mass; scr(SCR_ENVP + 1) = mu; }
     LaneState<T> st;
     T c[NU], q4[4], R7[9];
     for (int i = 0; i < NQ; i++) st.qpos[i] = (T)qpos[i];
@@ -60,6 +61,7 @@ static int env_step_t(const Model<T>& m, double* qpos, double* qvel, double* war
                       double* obs, double* reward, int* done, double* rays_out, int do_reset) {
     std::vector<T> scrbuf(SCR_TOTAL, T(0)), snap(SNAP_TOTAL, T(0));
     Scratch<T> scr{scrbuf.data(), 1};
+    { T mass, mu; nominal_env_params(m, mass, mu); scr(SCR_ENVP) = mass; scr(SCR_ENVP + 1) = mu; }
     LaneState<T> st;
     T q4[4], a4[4];
     for (int i = 0; i < NQ; i++) st.qpos[i] = (T)qpos[i];

@@ -220,8 +220,8 @@ def test_naive_demonstrator_lifts_centred_cubes():
 
 
 def test_mixed_shape_batch_equals_per_shape_contexts(assets_dir):
-    """BASELINE config 5 plumbing: a mixed-object batch is bit-identical to running each shape alone, and each
-    block agrees with the oracle for its own shape."""
+    """BASELINE config 5 plumbing: a mixed-object batch with per-env randomised object mass / friction is bit-identical
+    to running each shape alone, and each block agrees with the oracle for its own shape and parameters."""
     from kinovagrasping_amd.multi_shape import MultiShapeSim
     shapes = ["CubeB", "CylinderS", "Cone1B", "Vase2S"]
     per = 32
@@ -233,7 +233,9 @@ def test_mixed_shape_batch_equals_per_shape_contexts(assets_dir):
         q0[9:12, k * per:(k + 1) * per] = tab[rng.randint(0, len(tab), per)].T
     hq = np.repeat(scenarios.hand_quat_for("normal")[:, None], n, 1)
     acts = torch.as_tensor(scenarios.config_actions(n, 2, base_seed=77))
+    mass, mu = scenarios.config5_env_params(n)
     ms = MultiShapeSim(n, shapes)
+    ms.set_env_params(mass, mu)
     obs_m = ms.reset(torch.as_tensor(q0), torch.as_tensor(hq)).clone()
     for t in range(2):
         om, rm, dm, im = ms.step(acts[t])
@@ -242,6 +244,7 @@ def test_mixed_shape_batch_equals_per_shape_contexts(assets_dir):
     for k, sh in enumerate(shapes):
         sl = slice(k * per, (k + 1) * per)
         sim = _sim(per, sh)
+        sim.set_env_params(mass[sl], mu[sl])
         o0 = sim.reset(torch.as_tensor(q0[:, sl]), torch.as_tensor(hq[:, sl]))
         assert torch.equal(o0, obs_m[sl])
         for t in range(2):
@@ -251,6 +254,7 @@ def test_mixed_shape_batch_equals_per_shape_contexts(assets_dir):
         # oracle for this shape, first env of the block
         model = ko.OracleModel(scenarios.model_blob(sh))
         o = ko.OracleSim(model, hq[:, 0], solver_iterations=6)
+        o.s.obj_mass, o.s.obj_mu = mass[k * per], mu[k * per]
         o.env_reset(q0[:, k * per])
         for t in range(2):
             o.env_step(acts[t][:, k * per].numpy())
@@ -389,3 +393,53 @@ def test_graphed_trainer_runs_rollout_and_updates():
     assert torch.isfinite(tr.native.losses).all()
     assert (sim.get_state()["status"] & 2).sum().item() == 0
     sim.close()
+
+
+def test_randomised_mass_and_friction_match_oracle(cube):
+    """BASELINE config 5 extension: per-env object mass U[0.05, 0.15] kg and object-hand friction U[0.5, 1.0]
+    (ks_set_env_params) against the oracle with the same overrides: a closing + lifting grasp, teacher-forced one
+    substep at a time so that every state along the way is compared (fp64 kernels: algorithm-exact; fp32: product)."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    n_env = 6
+    masses, mus = rng.uniform(0.05, 0.15, n_env), rng.uniform(0.5, 1.0, n_env)
+    hq = scenarios.hand_quat_for("normal")
+    recs, env_of = [], []
+    for e in range(n_env):
+        s = ko.OracleSim(cube, hq, solver_iterations=6)
+        s.s.obj_mass, s.s.obj_mu = masses[e], mus[e]
+        q0 = np.zeros(16); q0[9:12] = [0.01 * (e - 2), 0.0, 0.0654]; q0[12] = 1
+        s.env_reset(q0)
+        ctrl = np.zeros(9); ctrl[5] = 0.2932; ctrl[6:9] = 0.5
+        for i in range(330):
+            if i == 250:
+                ctrl[4] = 0.5
+            before = (s.view("qpos").copy(), s.view("qvel").copy(), s.view("qacc_warmstart").copy())
+            s.step(ctrl)
+            if i % 3 == 0:
+                recs.append((before, ctrl.copy(), (s.view("qpos").copy(), s.view("qvel").copy()), s.s.ncon))
+                env_of.append(e)
+    n = len(recs)
+    env_of = np.array(env_of)
+    assert max(r[3] for r in recs) >= 4                      # the grasps do make finger contacts
+    for precision, tol_med, tol_p99 in ((64, 1e-10, 1e-8), (32, 5e-7, 2e-4)):
+        sim = _sim(n, "CubeS", precision=precision, solver_iterations=6)
+        q0 = np.stack([r[0][0] for r in recs], 1)
+        sim.reset(torch.as_tensor(q0), torch.as_tensor(np.repeat(hq[:, None], n, 1)))
+        sim.set_env_params(masses[env_of], mus[env_of])
+        sim.set_state(torch.as_tensor(q0), torch.as_tensor(np.stack([r[0][1] for r in recs], 1)), torch.as_tensor(np.stack([r[0][2] for r in recs], 1)))
+        sim.substep(torch.as_tensor(np.stack([r[1] for r in recs], 1)))
+        st = sim.get_state()
+        torch.cuda.synchronize()
+        eq = np.abs(st["qpos"].double().cpu().numpy() - np.stack([r[2][0] for r in recs], 1)).max(0)
+        print(f"randomised mass/mu, precision {precision}: one-step |dqpos| median {np.median(eq):.2e} p99 {np.percentile(eq, 99):.2e} max {eq.max():.2e}")
+        assert np.median(eq) <= tol_med and np.percentile(eq, 99) <= tol_p99
+        # the overrides matter: the same states stepped with nominal parameters differ from the oracle where there is contact
+        if precision == 64:
+            sim2 = _sim(n, "CubeS", precision=64, solver_iterations=6)
+            sim2.reset(torch.as_tensor(q0), torch.as_tensor(np.repeat(hq[:, None], n, 1)))
+            sim2.set_state(torch.as_tensor(q0), torch.as_tensor(np.stack([r[0][1] for r in recs], 1)), torch.as_tensor(np.stack([r[0][2] for r in recs], 1)))
+            sim2.substep(torch.as_tensor(np.stack([r[1] for r in recs], 1)))
+            e2 = np.abs(sim2.get_state()["qpos"].double().cpu().numpy() - np.stack([r[2][0] for r in recs], 1)).max(0)
+            assert e2.max() > 100 * max(eq.max(), 1e-12)
+            sim2.close()
+        sim.close()
