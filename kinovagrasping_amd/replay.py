@@ -26,6 +26,55 @@ def sample_windows_host(ep_lens, n_steps: int, batch_size: int, rng=np.random):
     return out
 
 
+# ---- the reference's on-disk replay bundle (utils.py:345-390): a directory of .npy files, each the pickled
+# nested list the buffer holds in memory - state / action / next_state / reward / not_done: one list per episode
+# (+ the empty list of the episode being filled), episodes: [first, last] timestep counters per episode,
+# episodes_info: [max_episode, size, episodes_count, replay_ep_num], orientation_indexes.
+_BUNDLE_FIELDS = ("state", "action", "next_state", "reward", "not_done")
+
+
+def _object_rows(rows):
+    out = np.empty(len(rows), dtype=object)
+    for i, r in enumerate(rows):
+        out[i] = r
+    return out
+
+
+def save_reference_bundle(dirpath, episodes, max_episode=10000, orientation_indexes=None):
+    """Write episodes (list of dicts with the five _BUNDLE_FIELDS, each [L, ...] array) in the layout
+    ReplayBuffer_Queue.save_replay_buffer produces, readable by store_saved_data_into_replay (utils.py:367-400)."""
+    from pathlib import Path
+    d = Path(dirpath)
+    d.mkdir(parents=True, exist_ok=True)
+    for f in _BUNDLE_FIELDS:
+        rows = []
+        for ep in episodes:
+            a = np.asarray(ep[f])
+            rows.append([np.asarray(x, dtype=np.float64) if a.ndim > 1 else float(x) for x in a])
+        rows.append([])                                         # the open episode
+        np.save(d / f, _object_rows(rows), allow_pickle=True)
+    lens = [len(np.asarray(ep["reward"])) for ep in episodes]
+    np.save(d / "episodes", _object_rows([[0, n] for n in lens] + [[]]), allow_pickle=True)
+    np.save(d / "episodes_info", np.array([max_episode, sum(lens), len(lens), len(lens)]))
+    np.save(d / "orientation_indexes", _object_rows(list(orientation_indexes) if orientation_indexes is not None else []), allow_pickle=True)
+
+
+def load_reference_bundle(dirpath):
+    """Read a bundle written by the reference (or by save_reference_bundle): list of episode dicts of float32 arrays
+    (empty trailing episodes dropped) + the episodes_info vector."""
+    from pathlib import Path
+    d = Path(dirpath)
+    cols = {f: np.load(d / (f + ".npy"), allow_pickle=True) for f in _BUNDLE_FIELDS}
+    n = len(cols["reward"])
+    episodes = []
+    for i in range(n):
+        if len(cols["reward"][i]) == 0:
+            continue
+        episodes.append({f: np.asarray([np.asarray(x, dtype=np.float32) for x in cols[f][i]], dtype=np.float32) for f in _BUNDLE_FIELDS})
+    info = np.load(d / "episodes_info.npy", allow_pickle=True)
+    return episodes, np.asarray(info, dtype=np.int64)
+
+
 class HostEpisodeReplay:
     """Flat-array host replay with the reference's sampler; used for expert data and parity tests."""
 
@@ -43,6 +92,21 @@ class HostEpisodeReplay:
     @property
     def replay_ep_num(self):
         return len(self.lens)
+
+    def episodes(self):
+        return [dict(state=self.state[i], action=self.action[i], next_state=self.next_state[i], reward=self.reward[i], not_done=self.not_done[i])
+                for i in range(len(self.lens))]
+
+    def save(self, dirpath, max_episode=10000):
+        """the reference's replay bundle (utils.py:345-365)"""
+        save_reference_bundle(dirpath, self.episodes(), max_episode)
+
+    def load(self, dirpath):
+        """append the episodes of a reference replay bundle (utils.py:367-400)"""
+        eps, info = load_reference_bundle(dirpath)
+        for ep in eps:
+            self.add_episode_arrays(ep["state"], ep["action"], ep["next_state"], ep["reward"], ep["not_done"])
+        return info
 
     def sample_batch_nstep(self, batch_size, num_ts_from_ep=5, rng=np.random):
         wins = sample_windows_host(self.lens, self.n_steps, batch_size, rng)
@@ -140,6 +204,36 @@ class DeviceEpisodeReplay:
         self._count.copy_((self._count + k).clamp(max=self.capacity))
         self.cur_len.copy_(torch.where(env_mask, torch.zeros_like(self.cur_len), self.cur_len))
         return k
+
+    def host_episodes(self):
+        """committed episodes, oldest first, as numpy dicts (synchronises)"""
+        cnt, head = self.count, self.head
+        first = (head - cnt) % self.capacity
+        out = []
+        for k in range(cnt):
+            s = (first + k) % self.capacity
+            L = int(self.ep_len[s])
+            out.append(dict(state=self.ep_state[s, :L].cpu().numpy(), action=self.ep_action[s, :L].cpu().numpy(),
+                            next_state=self.ep_next[s, :L].cpu().numpy(), reward=self.ep_reward[s, :L].cpu().numpy(),
+                            not_done=self.ep_not_done[s, :L].cpu().numpy()))
+        return out
+
+    def save(self, dirpath, max_episode=None):
+        """the reference's replay bundle (utils.py:345-365)"""
+        save_reference_bundle(dirpath, self.host_episodes(), self.capacity if max_episode is None else max_episode)
+
+    def load(self, dirpath):
+        """append the episodes of a reference replay bundle to the ring (episodes longer than the horizon are cut)"""
+        eps, info = load_reference_bundle(dirpath)
+        for ep in eps:
+            L = min(len(ep["reward"]), self.horizon)
+            s = int(self._head)
+            for name, key in (("ep_state", "state"), ("ep_next", "next_state"), ("ep_action", "action"), ("ep_reward", "reward"), ("ep_not_done", "not_done")):
+                getattr(self, name)[s, :L] = torch.as_tensor(ep[key][:L]).to(self.device)
+            self.ep_len[s] = L
+            self._head.copy_((self._head + 1) % self.capacity)
+            self._count.copy_((self._count + 1).clamp(max=self.capacity))
+        return info
 
     def commit_native(self, keep, ended):
         """rank -> commit -> advance with the kr_* kernels; keep / ended: bool [n_envs]"""

@@ -443,3 +443,29 @@ def test_randomised_mass_and_friction_match_oracle(cube):
             assert e2.max() > 100 * max(eq.max(), 1e-12)
             sim2.close()
         sim.close()
+
+
+def test_scripted_demonstrators_grasp_across_the_start_table():
+    """Behavioural pin for the expert-data generators: naive, position-dependent and combined
+    controllers on 512 CubeS starts spread over the no-noise table; the reference reports most demonstrations
+    succeeding within 21-28 steps."""
+    from kinovagrasping_amd.demonstrators import run_controller_episodes
+    from kinovagrasping_amd.replay import DeviceEpisodeReplay
+    n = 512
+    tab = scenarios.start_coord_table("CubeS")
+    idx = np.linspace(0, len(tab) - 1, n).astype(int)
+    q0 = np.zeros((16, n)); q0[12] = 1; q0[9:12] = tab[idx].T
+    hq = np.repeat(scenarios.hand_quat_for("normal")[:, None], n, 1)
+    rates = {}
+    for mode in ("naive", "position-dependent", "combined"):
+        sim = _sim(n, "CubeS", horizon=30, auto_reset=False)
+        obs0 = sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+        rep = DeviceEpisodeReplay(n, capacity=n, device=sim.device)
+        out = run_controller_episodes(sim, obs0, rep, mode=mode)
+        torch.cuda.synchronize()
+        rates[mode] = out["success"].float().mean().item()
+        st = out["steps"][out["success"]].float()
+        print(f"{mode:20s} success {rates[mode]:.2f}  steps to lift mean {st.mean().item():.1f}")
+        assert rep.count == n
+        sim.close()
+    assert min(rates.values()) >= 0.6 and rates["combined"] >= 0.8

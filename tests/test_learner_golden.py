@@ -1,5 +1,7 @@
 """Learner path (L1-L4) against golden vectors produced by the reference's own DDPGfD.py / utils.py
 (tools/gen_golden_learner.py -> tests/golden/learner.npz).  CPU, fp32, 400-300 widths (reference)."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -122,3 +124,59 @@ def test_device_replay_ring_and_sampling_distribution():
     # windows_host: reference draw pattern (ceiling - 1 random + final)
     wins = sample_windows_host([30, 12, 30], 5, 2, np.random.RandomState(0))
     assert all(0 <= s <= L - 5 for (e, s), L in zip(wins, [[30, 12, 30][e] for e, _ in wins]))
+
+
+def test_scripted_controllers_match_reference_known_answers():
+    """demonstrators.controller_action against expert_data.get_action (naive / position-dependent / combined) on the
+    600 cases of tests/golden/controllers.npz (tools/gen_golden_controllers.py ran the reference itself)."""
+    from kinovagrasping_amd.demonstrators import controller_action
+    g = np.load(Path(__file__).resolve().parent / "golden" / "controllers.npz")
+    n = len(g["obs21"])
+    obs = torch.zeros(n, 82, dtype=torch.float64)
+    for col, key in ((21, "obs21"), (78, "obs78"), (79, "obs79"), (81, "obs81")):
+        obs[:, col] = torch.as_tensor(g[key])
+    init_x, init_dot, lift = torch.as_tensor(g["init21"]), torch.as_tensor(g["init81"]), torch.as_tensor(g["lift"])
+    for mode, key in (("naive", "action_naive"), ("position-dependent", "action_position_dependent"), ("combined", "action_combined")):
+        a = controller_action(mode, obs, init_x, init_dot, lift).numpy()
+        err = np.abs(a - g[key]).max()
+        assert err < 1e-12, (mode, err, int(np.abs(a - g[key]).max(1).argmax()))
+    # the PD branches are all exercised
+    assert len(np.unique(np.round(g["action_position_dependent"][:, 1:], 6))) > 10
+
+
+def test_replay_bundle_format_reads_reference_files_and_round_trips(tmp_path):
+    """On-disk replay bundle (utils.py:345-400): tests/golden/replay_bundle/ was written by the reference's own
+    ReplayBuffer_Queue.save_replay_buffer (tools/gen_golden_replay_bundle.py, which also checked that the reference reads
+    OUR bundles); our reader recovers the episodes, our writer reproduces the same files' content."""
+    from kinovagrasping_amd.replay import load_reference_bundle, save_reference_bundle
+    gdir = Path(__file__).resolve().parent / "golden"
+    exp = np.load(gdir / "replay_bundle_expected.npz")
+    eps, info = load_reference_bundle(gdir / "replay_bundle")
+    assert info.tolist() == exp["info"].tolist() == [100, 49, 3, 3]
+    assert [len(e["reward"]) for e in eps] == [7, 30, 12]
+    for i, e in enumerate(eps):
+        for k, v in e.items():
+            np.testing.assert_allclose(v, exp[f"ep{i}_{k}"], rtol=0, atol=1e-6)
+    # host replay: load -> sample -> save -> load again
+    rep = HostEpisodeReplay()
+    rep.load(gdir / "replay_bundle")
+    assert rep.replay_ep_num == 3
+    st, ac, ns, rw, nd = rep.sample_batch_nstep(4, rng=np.random.RandomState(1))
+    assert st.shape[1:] == (5, 82)
+    rep.save(tmp_path / "b", max_episode=100)
+    eps2, info2 = load_reference_bundle(tmp_path / "b")
+    assert info2.tolist() == [100, 49, 3, 3]
+    for a, b in zip(eps, eps2):
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k])
+    for f in ("state", "reward", "episodes"):
+        ours, ref = np.load(tmp_path / "b" / f"{f}.npy", allow_pickle=True), np.load(gdir / "replay_bundle" / f"{f}.npy", allow_pickle=True)
+        assert ours.dtype == ref.dtype == object and [len(x) for x in ours] == [len(x) for x in ref]
+    # device ring (CPU tensors here): load the bundle, save it back
+    dev = DeviceEpisodeReplay(n_envs=2, capacity=8, horizon=30, device="cpu")
+    dev.load(gdir / "replay_bundle")
+    assert dev.count == 3 and dev.ep_len[:3].tolist() == [7, 30, 12]
+    dev.save(tmp_path / "c")
+    eps3, _ = load_reference_bundle(tmp_path / "c")
+    for a, b in zip(eps, eps3):
+        np.testing.assert_array_equal(a["state"], b["state"])
