@@ -469,3 +469,32 @@ def test_scripted_demonstrators_grasp_across_the_start_table():
         assert rep.count == n
         sim.close()
     assert min(rates.values()) >= 0.6 and rates["combined"] >= 0.8
+
+
+def test_reference_trained_policy_grasps_in_this_simulator():
+    """End-to-end behavioural cross-check: a 400-300 actor the reference authors trained on real
+    MuJoCo (policies/rl_exp_pretrain_no_grasp_2_7_2021/pre_DDPGfD_kinovaGrip_02_05_21_2324_actor; weights committed as
+    tests/golden/ref_policy_cubes_actor.npz) evaluated with evaluate.eval_policy on 512 CubeS starts of the reference's
+    no-noise table.  tools/eval_reference_policies.py ran all thirteen 82-d checkpoints of the reference through the CPU
+    oracle: they are pre-training snapshots of very uneven quality (0 - 0.88 success); the two best reach 0.88 here."""
+    from pathlib import Path
+    from kinovagrasping_amd.ddpgfd import DDPGfD
+    from kinovagrasping_amd.evaluate import eval_policy
+    n = 512
+    tab = scenarios.start_coord_table("CubeS")
+    idx = np.linspace(0, len(tab) - 1, n).astype(int)
+    q0 = np.zeros((16, n)); q0[12] = 1; q0[9:12] = tab[idx].T
+    hq = np.repeat(scenarios.hand_quat_for("normal")[:, None], n, 1)
+    sim = _sim(n, "CubeS", horizon=30, auto_reset=False)
+    obs0 = sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+    pol = DDPGfD(82, 4, 0.8, 5, hidden=(400, 300), device=sim.device)
+    w = np.load(Path(__file__).resolve().parent / "golden" / "ref_policy_cubes_actor.npz")
+    pol.actor.load_state_dict({k.replace("_", ".", 1): torch.as_tensor(w[k]) for k in w.files})
+    out = eval_policy(sim, pol, obs0)
+    rate = out["num_success"] / n
+    print(f"reference-trained actor in this sim: success {rate:.2f}, avg reward {out['avg_reward']:.1f}, "
+          f"mean steps of successes {out['steps'][out['success']].float().mean().item():.1f}")
+    assert len(out["success_coords"]["x"]) + len(out["fail_coords"]["x"]) == n
+    assert abs(out["avg_rewards"]["lift_reward"] - 50 * rate) < 1e-3 and out["avg_rewards"]["finger_reward"] == 0
+    assert rate >= 0.7
+    sim.close()

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Dev-only behavioural cross-check (needs /root/reference): evaluate every 82-d reference actor checkpoint with the
+fp64 CPU oracle on a few dozen CubeS starts (eval_policy semantics: deterministic policy, check_grasp lift trigger,
+scripted lift) and print the success rates.  The reference policies were trained on real MuJoCo observations."""
+import glob
+import sys
+from concurrent.futures import ProcessPoolExecutor
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(REPO))
+
+
+def episode(args):
+    f, row = args
+    from kinovagrasping_amd import scenarios
+    from kinovagrasping_amd.ddpgfd import Actor
+    from oracle import ko_py as ko
+    torch.set_num_threads(1)
+    sd = torch.load(f, map_location="cpu", weights_only=True)
+    actor = Actor(82, 4, 0.8, (400, 300))
+    actor.load_state_dict(sd)
+    m = ko.OracleModel(scenarios.model_blob("CubeS"))
+    tab = scenarios.start_coord_table("CubeS")
+    s = ko.OracleSim(m, scenarios.hand_quat_for("normal"), solver_iterations=6)
+    q = np.zeros(16); q[9:12] = tab[row]; q[12] = 1
+    obs = np.array(s.env_reset(q))
+    prev, ready, acts = None, False, []
+    for t in range(30):
+        if prev is not None and t + 1 >= 6 and not ready:
+            d = np.abs(prev[[9, 12, 15]] - obs[[9, 12, 15]]) / 15.0
+            ready = d.sum() < 0.0002
+        with torch.no_grad():
+            a = actor(torch.tensor(obs, dtype=torch.float32)[None])[0].numpy()
+        acts.append(a)
+        act = np.array([0.6, 0.5, 0.5, 0.5]) if ready else a
+        prev = obs
+        obs, r, done, info = s.env_step(act)
+        obs = np.array(obs)
+        if done:
+            return 1, t + 1, np.mean(acts, 0)
+    return 0, 30, np.mean(acts, 0)
+
+
+def main():
+    files = [f for f in sorted(glob.glob("/root/reference/gym-kinova-gripper/policies/**/*_actor", recursive=True))
+             if torch.load(f, map_location="cpu", weights_only=True)["l1.weight"].shape[1] == 82]
+    rows = np.linspace(0, 4400, 24).astype(int)
+    with ProcessPoolExecutor(8) as ex:
+        for f in files:
+            res = list(ex.map(episode, [(f, int(r)) for r in rows]))
+            ok = np.array([r[0] for r in res]); st = np.array([r[1] for r in res]); am = np.mean([r[2] for r in res], 0)
+            print(f"{f.split('policies/')[1]:90s} success {ok.mean():.2f}  steps(ok) {st[ok == 1].mean() if ok.any() else float('nan'):.1f}  mean policy action {am.round(2)}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
