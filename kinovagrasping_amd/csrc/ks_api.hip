@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -89,6 +90,10 @@ template <typename T> __device__ __forceinline__ Hulls<T> stage_hulls(const Mode
         hu.adj[s] = ulds + uoff;
         uoff += na;
     }
+    // coarse support tables [4][SUPPORT_DIRS] behind the adjacency
+    for (int i = threadIdx.x; i < 4 * SUPPORT_DIRS; i += blockDim.x) ulds[uoff + i] = m.mesh_dirtab[i];
+    hu.dirtab = ulds + uoff;
+    uoff += 4 * SUPPORT_DIRS;
     const int iwords = (uoff * (int)sizeof(unsigned short) + (int)sizeof(T) - 1) / (int)sizeof(T);
     used = off + ((iwords + 3) & ~3);
     // pair records behind the adjacency tables, one thread per pair
@@ -402,6 +407,7 @@ template <typename T> struct Ctx : CtxBase {
     int* d_lr[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned short* d_adj_off[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned short* d_adj[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned short* d_dirtab = nullptr;
     std::vector<void*> allocs;
     // HIP-event timing of k_env_step
     static constexpr int NEV = 512;
@@ -475,6 +481,13 @@ template <typename T> struct Ctx : CtxBase {
             hull_words += hm.m.mesh_nvert_pad[s] * 4;
             adj_ints += ((hm.m.mesh_nvert[s] + 1 + 3) & ~3) + hm.m.mesh_nchunk[s] * 4;
         }
+        adj_ints += 4 * SUPPORT_DIRS;
+        {
+            int r;
+            if ((r = alloc(&d_dirtab, hm.dirtab.size()))) return r;
+            HIPCHK(hipMemcpy(d_dirtab, hm.dirtab.data(), hm.dirtab.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+            hm.m.mesh_dirtab = d_dirtab;
+        }
         HIPCHK(hipMemcpy(d_model, &hm.m, sizeof(Model<T>), hipMemcpyHostToDevice));
         {
             const int iwords = (adj_ints * (int)sizeof(unsigned short) + (int)sizeof(T) - 1) / (int)sizeof(T);
@@ -509,6 +522,7 @@ template <typename T> struct Ctx : CtxBase {
         int want = cfg.envs_per_wave > 0 ? cfg.envs_per_wave : EPW_MAX;
         lpw = want > cap ? cap : want;
         step_lds = hull_bytes + per_env * lpw;
+        if (getenv("KS_DEBUG")) fprintf(stderr, "[ks] stepping kernel: %d envs per workgroup, LDS %zu B (tables %zu B, %zu B per env), limit %zu\n", lpw, step_lds, hull_bytes, per_env, lds_max);
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<T, USE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_substep<T, USE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
         return KS_OK;

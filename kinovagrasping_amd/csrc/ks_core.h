@@ -222,7 +222,8 @@ template <typename T> struct alignas(16) PairRec {
     int body1, body2;
     int n1, n2;                // padded hull vertex counts; n2 of a plane pair is the true count
     int slot, obj_hand;        // first staging record of the pair (4 per plane pair, 1 per hull pair, pair order);
-                               // obj_hand: object vs hand geom - the pair whose friction may be set per env
+                               // obj_hand: bit 0 = object vs hand geom (the pair whose friction may be set per env),
+                               // bits 4-7 / 8-11 = mesh ids of the two geoms
     KS_LDS const T* V1; KS_LDS const T* V2;
     KS_LDS const unsigned short* off1; KS_LDS const unsigned short* adj1;
     KS_LDS const unsigned short* off2; KS_LDS const unsigned short* adj2;
@@ -236,6 +237,7 @@ template <typename T> struct Hulls {
     unsigned plane_mask;   // bit pi set: pair pi is ground plane vs hull (pair_g1 == 0)
     int npair, nhull;
     KS_LDS const PairRec<T>* pair;             // [npair]
+    KS_LDS const unsigned short* dirtab;       // [4][SUPPORT_DIRS] coarse support tables
     unsigned char hull_pi[NPAIR_MAX];          // pair index of the k-th hull-hull pair
     int nplane;
     unsigned char plane_pi[NPAIR_MAX];         // pair index of the k-th plane pair
@@ -261,7 +263,8 @@ template <typename T> KS_HD void fill_pair_rec(const Model<T>& m, const Hulls<T>
     r.g1 = g1; r.g2 = g2; r.margin = m.pair_margin[pi]; r.mu = m.pair_mu[pi];
     int slot = 0;
     for (int j = 0; j < pi; j++) slot += ((hu.plane_mask >> j) & 1u) ? 4 : 1;
-    r.slot = slot; r.obj_hand = (g1 != 0 && g2 == NGEOM - 1) ? 1 : 0;
+    r.slot = slot;
+    r.obj_hand = ((g1 != 0 && g2 == NGEOM - 1) ? 1 : 0) | ((g1 != 0 ? m.geom_mesh[g1] : 0) << 4) | (m.geom_mesh[g2] << 8);
     r.rbound1 = m.geom_rbound[g1]; r.rbound2 = m.geom_rbound[g2];
     for (int k = 0; k < 3; k++) { r.size1[k] = m.geom_size[g1][k]; r.size2[k] = m.geom_size[g2][k]; }
     r.body1 = m.geom_body[g1]; r.body2 = m.geom_body[g2];
@@ -555,6 +558,7 @@ template <typename T> struct PairGeo {
     KS_LDS const T* V1; KS_LDS const T* V2;
     KS_LDS const unsigned short* off1; KS_LDS const unsigned short* adj1;
     KS_LDS const unsigned short* off2; KS_LDS const unsigned short* adj2;
+    KS_LDS const unsigned short* dir1; KS_LDS const unsigned short* dir2;   // coarse support tables of the two hulls
     int n1, n2;
     int hint1, hint2;          // last support vertex of each shape: start of the next hill climb
     T half_margin;
@@ -573,12 +577,26 @@ constexpr int HULL_CHUNK = 8;
 // returns (they can differ only between exactly tied vertices).  Visits O(sqrt(V)) vertices instead of
 // V (the palm hull has 754), and warm-started from the previous query usually only a handful.
 template <typename T>
-KS_HD void hull_support(const T* R, const T* p, KS_LDS const T* V, KS_LDS const unsigned short* off, KS_LDS const unsigned short* adj, int& hint,
-                        const T* dir, T hm, T* out) {
+KS_HD void hull_support(const T* R, const T* p, KS_LDS const T* V, KS_LDS const unsigned short* off, KS_LDS const unsigned short* adj,
+                        KS_LDS const unsigned short* dirtab, int& hint, const T* dir, T hm, T* out) {
     T ld[3];
     mulRtv(ld, R, dir);
+    // start from the better of: the previous support vertex, the table's support vertex of the direction's sign pattern
+    // (a component counts when it is > 0.4 |ld|, i.e. ld_i |ld_i| > 0.16 |ld|^2)
+    const T n2 = T(0.16) * (ld[0] * ld[0] + ld[1] * ld[1] + ld[2] * ld[2]);
+    int cls = 0;
+    KS_UNROLL
+    for (int i = 0; i < 3; i++) {
+        const T sq = ld[i] * kabs(ld[i]);
+        cls = cls * 3 + (sq > n2 ? 2 : (sq < -n2 ? 0 : 1));
+    }
+    const int tab = dirtab[cls];
     int cur = hint;
     T best = V[4 * cur] * ld[0] + V[4 * cur + 1] * ld[1] + V[4 * cur + 2] * ld[2];
+    {
+        const T bt = V[4 * tab] * ld[0] + V[4 * tab + 1] * ld[1] + V[4 * tab + 2] * ld[2];
+        if (bt > best) { best = bt; cur = tab; }
+    }
     for (int guard = 0; guard < 4096; guard++) {
         const int c0 = off[cur], c1 = off[cur + 1];
         int nxt = cur;
@@ -609,8 +627,8 @@ template <typename T> KS_HD void mpr_support(PairGeo<T>& g, const T* dir, Supp<T
 #ifdef KS_STAMP_HULL
     const int h1_ = g.hint1, h2_ = g.hint2;
 #endif
-    hull_support(g.R1, g.p1, g.V1, g.off1, g.adj1, g.hint1, dir, g.half_margin, o.v1);
-    hull_support(g.R2, g.p2, g.V2, g.off2, g.adj2, g.hint2, nd, g.half_margin, o.v2);
+    hull_support(g.R1, g.p1, g.V1, g.off1, g.adj1, g.dir1, g.hint1, dir, g.half_margin, o.v1);
+    hull_support(g.R2, g.p2, g.V2, g.off2, g.adj2, g.dir2, g.hint2, nd, g.half_margin, o.v2);
 #ifdef KS_STAMP_HULL
     g.cnt_support += 2; g.cnt_steps += (h1_ != g.hint1) + (h2_ != g.hint2);
 #endif
@@ -808,8 +826,8 @@ template <typename T> struct Simplex {
 
 template <typename T> KS_HD void gjk_support(PairGeo<T>& g, const T* dir, T* y, T* a, T* b) {
     T nd[3] = {-dir[0], -dir[1], -dir[2]};
-    hull_support(g.R1, g.p1, g.V1, g.off1, g.adj1, g.hint1, dir, T(0), a);
-    hull_support(g.R2, g.p2, g.V2, g.off2, g.adj2, g.hint2, nd, T(0), b);
+    hull_support(g.R1, g.p1, g.V1, g.off1, g.adj1, g.dir1, g.hint1, dir, T(0), a);
+    hull_support(g.R2, g.p2, g.V2, g.off2, g.adj2, g.dir2, g.hint2, nd, T(0), b);
     sub3(y, a, b);
 }
 
@@ -1152,17 +1170,21 @@ constexpr int PC_COUNT_MASK = 7, PC_HINT_BITS = 10, PC_HINT_MAX = (1 << PC_HINT_
 KS_HD int pc_pack(int count, int h1, int h2) { return count + 8 * (h1 + (1 << PC_HINT_BITS) * h2); }
 
 template <typename T, typename S>
-KS_HD int collide_hull_hull(const Model<T>& m, S scr, KS_LDS const PairRec<T>* prp, int packed_in, int& h1_out, int& h2_out, float* prof = nullptr) {
+KS_HD int collide_hull_hull(const Model<T>& m, KS_LDS const unsigned short* dirtab, S scr, KS_LDS const PairRec<T>* prp, int packed_in, int& h1_out,
+                            int& h2_out, float* prof = nullptr) {
     KS_LDS const PairRec<T>& pr = *prp;
     PairGeo<T> pg;
     h1_out = (packed_in >> 3) & PC_HINT_MAX;
     h2_out = (packed_in >> (3 + PC_HINT_BITS)) & PC_HINT_MAX;
     // the whole record first: one burst of LDS reads, one wait
     const int g1 = pr.g1, g2 = pr.g2, slot = pr.slot, body1 = pr.body1, body2 = pr.body2;
-    const T margin = pr.margin, mu = pr.obj_hand ? T(scr(SCR_ENVP + 1)) : pr.mu, bound = pr.rbound1 + pr.rbound2 + margin;
+    const int flags = pr.obj_hand;
+    const T margin = pr.margin, mu = (flags & 1) ? T(scr(SCR_ENVP + 1)) : pr.mu, bound = pr.rbound1 + pr.rbound2 + margin;
     const T size1[3] = {pr.size1[0], pr.size1[1], pr.size1[2]}, size2[3] = {pr.size2[0], pr.size2[1], pr.size2[2]};
     pg.V1 = pr.V1; pg.n1 = pr.n1; pg.off1 = pr.off1; pg.adj1 = pr.adj1;
     pg.V2 = pr.V2; pg.n2 = pr.n2; pg.off2 = pr.off2; pg.adj2 = pr.adj2;
+    pg.dir1 = dirtab + SUPPORT_DIRS * ((flags >> 4) & 15);
+    pg.dir2 = dirtab + SUPPORT_DIRS * ((flags >> 8) & 15);
     geom_pose_cached(scr, g1, pg.R1, pg.p1);
     geom_pose_cached(scr, g2, pg.R2, pg.p2);
     T t[3];
@@ -1213,6 +1235,7 @@ KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> te
     const unsigned plane_mask = hu.plane_mask;
     const int npair = hu.npair, nhull = hu.nhull;
     KS_LDS const PairRec<T>* pairs = hu.pair;
+    KS_LDS const unsigned short* dirtab = hu.dirtab;
     // plane pairs, culls: one pair per lane; the survivors (typically just the object) are then scanned by the
     // whole team, one pair at a time (team-uniform control flow)
     const int nplane = hu.nplane;
@@ -1239,7 +1262,7 @@ KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> te
     for (int hk = team.sub; hk < nhull; hk += SUBS) {
         const int pi = hu.hull_pi[hk];
         int c = 0, h1 = 0, h2 = 0;
-        if (pairs[pi].slot + 1 <= NSTAGE) c = collide_hull_hull(m, scr, pairs + pi, (int)scr(SCR_PC + pi), h1, h2, prof);
+        if (pairs[pi].slot + 1 <= NSTAGE) c = collide_hull_hull(m, dirtab, scr, pairs + pi, (int)scr(SCR_PC + pi), h1, h2, prof);
         else status |= ST_CONTACT_OVERFLOW;
         scr(SCR_PC + pi) = T(pc_pack(c, h1, h2));
     }

@@ -10,6 +10,7 @@ constexpr int NQ = 16, NV = 15, NU = 9, NBODY = 10, NGEOM = 9, NSITE = 17, NSENS
 constexpr int NPAIR_MAX = 32;
 constexpr int NCON_MAX = 24;   // contacts kept per env per substep (oracle: KO_NCON_MAX)
 constexpr int NRAY = 17;
+constexpr int SUPPORT_DIRS = 28;   // 27 sign patterns, padded to an even count
 
 // status bits reported per env
 constexpr int ST_CONTACT_OVERFLOW = 1, ST_NONFINITE = 2;
@@ -50,6 +51,9 @@ template <typename T> struct Model {
     int mesh_nchunk[4];
     const unsigned short* mesh_adj_off[4];  // [nvert+1] first chunk of every vertex
     const unsigned short* mesh_adj[4];      // [nchunk][4]
+    // support vertex of every hull for the 27 directions {-1,0,1}^3 (entry 13 = zero direction, unused): where a
+    // hill climb towards an arbitrary direction starts, [4][SUPPORT_DIRS]
+    const unsigned short* mesh_dirtab;
 };
 
 }  // namespace ks
