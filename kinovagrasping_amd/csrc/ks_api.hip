@@ -90,10 +90,6 @@ template <typename T> __device__ __forceinline__ Hulls<T> stage_hulls(const Mode
         hu.adj[s] = ulds + uoff;
         uoff += na;
     }
-    // coarse support tables [4][SUPPORT_DIRS] behind the adjacency
-    for (int i = threadIdx.x; i < 4 * SUPPORT_DIRS; i += blockDim.x) ulds[uoff + i] = m.mesh_dirtab[i];
-    hu.dirtab = ulds + uoff;
-    uoff += 4 * SUPPORT_DIRS;
     const int iwords = (uoff * (int)sizeof(unsigned short) + (int)sizeof(T) - 1) / (int)sizeof(T);
     used = off + ((iwords + 3) & ~3);
     // pair records behind the adjacency tables, one thread per pair
@@ -481,7 +477,6 @@ template <typename T> struct Ctx : CtxBase {
             hull_words += hm.m.mesh_nvert_pad[s] * 4;
             adj_ints += ((hm.m.mesh_nvert[s] + 1 + 3) & ~3) + hm.m.mesh_nchunk[s] * 4;
         }
-        adj_ints += 4 * SUPPORT_DIRS;
         {
             int r;
             if ((r = alloc(&d_dirtab, hm.dirtab.size()))) return r;

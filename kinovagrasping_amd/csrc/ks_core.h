@@ -237,7 +237,6 @@ template <typename T> struct Hulls {
     unsigned plane_mask;   // bit pi set: pair pi is ground plane vs hull (pair_g1 == 0)
     int npair, nhull;
     KS_LDS const PairRec<T>* pair;             // [npair]
-    KS_LDS const unsigned short* dirtab;       // [4][SUPPORT_DIRS] coarse support tables
     unsigned char hull_pi[NPAIR_MAX];          // pair index of the k-th hull-hull pair
     int nplane;
     unsigned char plane_pi[NPAIR_MAX];         // pair index of the k-th plane pair
@@ -558,7 +557,7 @@ template <typename T> struct PairGeo {
     KS_LDS const T* V1; KS_LDS const T* V2;
     KS_LDS const unsigned short* off1; KS_LDS const unsigned short* adj1;
     KS_LDS const unsigned short* off2; KS_LDS const unsigned short* adj2;
-    KS_LDS const unsigned short* dir1; KS_LDS const unsigned short* dir2;   // coarse support tables of the two hulls
+    const unsigned short* dir1; const unsigned short* dir2;   // cube-map support start tables of the two hulls (global memory)
     int n1, n2;
     int hint1, hint2;          // last support vertex of each shape: start of the next hill climb
     T half_margin;
@@ -578,19 +577,23 @@ constexpr int HULL_CHUNK = 8;
 // V (the palm hull has 754), and warm-started from the previous query usually only a handful.
 template <typename T>
 KS_HD void hull_support(const T* R, const T* p, KS_LDS const T* V, KS_LDS const unsigned short* off, KS_LDS const unsigned short* adj,
-                        KS_LDS const unsigned short* dirtab, int& hint, const T* dir, T hm, T* out) {
+                        const unsigned short* dirtab, int& hint, const T* dir, T hm, T* out) {
     T ld[3];
     mulRtv(ld, R, dir);
-    // start from the better of: the previous support vertex, the table's support vertex of the direction's sign pattern
-    // (a component counts when it is > 0.4 |ld|, i.e. ld_i |ld_i| > 0.16 |ld|^2)
-    const T n2 = T(0.16) * (ld[0] * ld[0] + ld[1] * ld[1] + ld[2] * ld[2]);
-    int cls = 0;
-    KS_UNROLL
-    for (int i = 0; i < 3; i++) {
-        const T sq = ld[i] * kabs(ld[i]);
-        cls = cls * 3 + (sq > n2 ? 2 : (sq < -n2 ? 0 : 1));
+    // start from the better of: the previous support vertex, the support vertex of the cube-map cell the direction
+    // falls in (one L1/L2-resident load; the climb from there is a step or two)
+    int tab;
+    {
+        const T ax = kabs(ld[0]), ay = kabs(ld[1]), az = kabs(ld[2]);
+        const int axis = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+        const T major = axis == 0 ? ld[0] : (axis == 1 ? ld[1] : ld[2]);
+        const T cu = axis == 0 ? ld[1] : (axis == 1 ? ld[2] : ld[0]), cv = axis == 0 ? ld[2] : (axis == 1 ? ld[0] : ld[1]);
+        const T inv = T(0.5 * SUPPORT_R) / (kabs(major) > T(1e-30) ? kabs(major) : T(1e-30));
+        int iu = (int)(cu * inv + T(0.5 * SUPPORT_R)), iv = (int)(cv * inv + T(0.5 * SUPPORT_R));
+        iu = iu < 0 ? 0 : (iu > SUPPORT_R - 1 ? SUPPORT_R - 1 : iu);
+        iv = iv < 0 ? 0 : (iv > SUPPORT_R - 1 ? SUPPORT_R - 1 : iv);
+        tab = dirtab[((2 * axis + (major < 0 ? 1 : 0)) * SUPPORT_R + iu) * SUPPORT_R + iv];
     }
-    const int tab = dirtab[cls];
     int cur = hint;
     T best = V[4 * cur] * ld[0] + V[4 * cur + 1] * ld[1] + V[4 * cur + 2] * ld[2];
     {
@@ -828,6 +831,9 @@ template <typename T> KS_HD void gjk_support(PairGeo<T>& g, const T* dir, T* y, 
     T nd[3] = {-dir[0], -dir[1], -dir[2]};
     hull_support(g.R1, g.p1, g.V1, g.off1, g.adj1, g.dir1, g.hint1, dir, T(0), a);
     hull_support(g.R2, g.p2, g.V2, g.off2, g.adj2, g.dir2, g.hint2, nd, T(0), b);
+#ifdef KS_STAMP_HULL
+    g.cnt_support += 2;
+#endif
     sub3(y, a, b);
 }
 
@@ -1170,7 +1176,7 @@ constexpr int PC_COUNT_MASK = 7, PC_HINT_BITS = 10, PC_HINT_MAX = (1 << PC_HINT_
 KS_HD int pc_pack(int count, int h1, int h2) { return count + 8 * (h1 + (1 << PC_HINT_BITS) * h2); }
 
 template <typename T, typename S>
-KS_HD int collide_hull_hull(const Model<T>& m, KS_LDS const unsigned short* dirtab, S scr, KS_LDS const PairRec<T>* prp, int packed_in, int& h1_out,
+KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S scr, KS_LDS const PairRec<T>* prp, int packed_in, int& h1_out,
                             int& h2_out, float* prof = nullptr) {
     KS_LDS const PairRec<T>& pr = *prp;
     PairGeo<T> pg;
@@ -1183,8 +1189,8 @@ KS_HD int collide_hull_hull(const Model<T>& m, KS_LDS const unsigned short* dirt
     const T size1[3] = {pr.size1[0], pr.size1[1], pr.size1[2]}, size2[3] = {pr.size2[0], pr.size2[1], pr.size2[2]};
     pg.V1 = pr.V1; pg.n1 = pr.n1; pg.off1 = pr.off1; pg.adj1 = pr.adj1;
     pg.V2 = pr.V2; pg.n2 = pr.n2; pg.off2 = pr.off2; pg.adj2 = pr.adj2;
-    pg.dir1 = dirtab + SUPPORT_DIRS * ((flags >> 4) & 15);
-    pg.dir2 = dirtab + SUPPORT_DIRS * ((flags >> 8) & 15);
+    pg.dir1 = dirtab + SUPPORT_CELLS * ((flags >> 4) & 15);
+    pg.dir2 = dirtab + SUPPORT_CELLS * ((flags >> 8) & 15);
     geom_pose_cached(scr, g1, pg.R1, pg.p1);
     geom_pose_cached(scr, g2, pg.R2, pg.p2);
     T t[3];
@@ -1235,7 +1241,7 @@ KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> te
     const unsigned plane_mask = hu.plane_mask;
     const int npair = hu.npair, nhull = hu.nhull;
     KS_LDS const PairRec<T>* pairs = hu.pair;
-    KS_LDS const unsigned short* dirtab = hu.dirtab;
+    const unsigned short* dirtab = m.mesh_dirtab;
     // plane pairs, culls: one pair per lane; the survivors (typically just the object) are then scanned by the
     // whole team, one pair at a time (team-uniform control flow)
     const int nplane = hu.nplane;

@@ -10,7 +10,7 @@ constexpr int NQ = 16, NV = 15, NU = 9, NBODY = 10, NGEOM = 9, NSITE = 17, NSENS
 constexpr int NPAIR_MAX = 32;
 constexpr int NCON_MAX = 24;   // contacts kept per env per substep (oracle: KO_NCON_MAX)
 constexpr int NRAY = 17;
-constexpr int SUPPORT_DIRS = 28;   // 27 sign patterns, padded to an even count
+constexpr int SUPPORT_R = 16, SUPPORT_CELLS = 6 * SUPPORT_R * SUPPORT_R;   // cube-map resolution of the support start tables
 
 // status bits reported per env
 constexpr int ST_CONTACT_OVERFLOW = 1, ST_NONFINITE = 2;
@@ -51,8 +51,8 @@ template <typename T> struct Model {
     int mesh_nchunk[4];
     const unsigned short* mesh_adj_off[4];  // [nvert+1] first chunk of every vertex
     const unsigned short* mesh_adj[4];      // [nchunk][4]
-    // support vertex of every hull for the 27 directions {-1,0,1}^3 (entry 13 = zero direction, unused): where a
-    // hill climb towards an arbitrary direction starts, [4][SUPPORT_DIRS]
+    // support vertex of every hull for the centre direction of every cell of a cube map (6 faces x R x R): where a
+    // hill climb towards an arbitrary direction starts, [4][SUPPORT_CELLS]; global memory (12 KB, L1/L2 resident)
     const unsigned short* mesh_dirtab;
 };
 

@@ -48,7 +48,7 @@ template <typename T> struct HostModel {
     std::vector<float> tri[4], bvh_box[4];
     std::vector<int> bvh_lr[4];
     std::vector<unsigned short> adj_off[4], adj[4];
-    std::vector<unsigned short> dirtab;     // [4][SUPPORT_DIRS]
+    std::vector<unsigned short> dirtab;     // [4][SUPPORT_CELLS]
     std::string error;
 };
 
@@ -222,11 +222,15 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
         m.mesh_adj_off[s] = hm.adj_off[s].data();
         m.mesh_adj[s] = hm.adj[s].data();
     }
-    // support vertices along the 27 coarse directions (exhaustive scans, once per model)
-    hm.dirtab.assign(4 * SUPPORT_DIRS, 0);
+    // support vertex of the centre direction of every cube-map cell (exhaustive scans, once per model)
+    hm.dirtab.assign(4 * SUPPORT_CELLS, 0);
     for (int s = 0; s < 4; s++)
-        for (int d = 0; d < 27; d++) {
-            const double dir[3] = {(double)(d / 9 - 1), (double)((d / 3) % 3 - 1), (double)(d % 3 - 1)};
+        for (int c = 0; c < SUPPORT_CELLS; c++) {
+            const int face = c / (SUPPORT_R * SUPPORT_R), iu = (c / SUPPORT_R) % SUPPORT_R, iv = c % SUPPORT_R, axis = face >> 1;
+            double dir[3];
+            dir[axis] = (face & 1) ? -1.0 : 1.0;
+            dir[(axis + 1) % 3] = (iu + 0.5) * 2.0 / SUPPORT_R - 1.0;
+            dir[(axis + 2) % 3] = (iv + 0.5) * 2.0 / SUPPORT_R - 1.0;
             double best = -1e300;
             int arg = 0;
             for (int v = 0; v < m.mesh_nvert[s]; v++) {
@@ -234,7 +238,7 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
                 const double val = dir[0] * (double)p[0] + dir[1] * (double)p[1] + dir[2] * (double)p[2];
                 if (val > best) { best = val; arg = v; }
             }
-            hm.dirtab[s * SUPPORT_DIRS + d] = (unsigned short)arg;
+            hm.dirtab[s * SUPPORT_CELLS + c] = (unsigned short)arg;
         }
     m.mesh_dirtab = hm.dirtab.data();
     return true;

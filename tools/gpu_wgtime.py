@@ -9,8 +9,10 @@ base = scenarios.config_actions(256, 30)
 acts = torch.as_tensor(np.tile(base, (1, 1, n // 256))).cuda()
 sim = KinovaSim(n, "CubeS", auto_reset=True, horizon=30, contact_tap=True)
 sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
-for t in range(12):
-    sim.step(acts[t])
+closing = torch.tensor([0.0, 0.5, 0.5, 0.5], device="cuda").repeat(n, 1).t().contiguous()
+MODE = sys.argv[1] if len(sys.argv) > 1 else "random"
+for t in range(22 if MODE == "grasp" else 12):
+    sim.step(closing if MODE == "grasp" else acts[t])
     st = sim.get_state(contacts=True)
     torch.cuda.synchronize()
     prof = st["contact"].reshape(-1, n)[:480].cpu().numpy().reshape(16, 30, n)[0]   # lane 0 of every env
@@ -19,7 +21,7 @@ for t in range(12):
     s0 = start.min()
     d = (end - start) % (1 << 22)
     st_rel = (start - s0) % (1 << 22)
-    if t >= 10:
+    if t >= (10 if MODE != 'grasp' else 8) and (MODE != 'grasp' or t % 3 == 0 or t == 21):
         print(f"step {t}: per-env loop duration (100MHz ticks) min {d.min():.0f} mean {d.mean():.0f} max {d.max():.0f};  start spread max {st_rel.max():.0f};  last end {((end - s0) % (1<<22)).max():.0f}")
         cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
         key = xcc * 1000 + se * 100 + sh * 20 + cu
@@ -27,7 +29,7 @@ for t in range(12):
         print("  distinct (xcc,se,sh,cu) used by the 256 workgroups:", len(uniq), " max WGs on one CU:", cnt.max())
         late = st_rel[::16] > 0.25 * d.mean()
         print("  workgroups starting late (> 25% of a loop):", int(late.sum()))
-    if t == 11:
+    if t == (11 if MODE != 'grasp' else 21):
         full = st["contact"].reshape(-1, n)[:480].cpu().numpy().reshape(16, 30, n)
         names = {0: "fk+dyn", 1: "collision", 2: "constraints", 3: "chol M", 5: "euler", 8: "c:plane", 9: "c:hull", 10: "c:merge", 14: "(end)", 15: "n:chol", 16: "n:solve", 17: "n:pproj", 18: "n:ls", 21: "#newton", 22: "#ls"}
         order = np.argsort(-d)
