@@ -563,6 +563,7 @@ template <typename T> struct PairGeo {
     T half_margin;
 #ifdef KS_STAMP_HULL
     int cnt_support, cnt_steps;
+    long long t_sup, t_clo;
 #endif
 };
 
@@ -824,15 +825,29 @@ KS_FN bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir,
 // newest vertex last); every slot access is static so nothing spills to scratch memory.
 template <typename T> struct Simplex {
     T y[4][3], a[4][3], b[4][3];
+    int ia[4], ib[4];          // hull vertex ids of a / b
     int n;
 };
 
+// What a lane remembers of a hull pair's last GJK query: the vertex ids of the final simplex (<= 3 points).  The next
+// substep starts GJK from that simplex - the poses have barely moved, so it is usually still the closest feature and
+// the query ends after one confirming support instead of ~10 iterations.  Lane-private (the pair -> lane dealing is
+// fixed), lives in the stepping kernel's frame across the substeps of a launch.
+struct GjkWarm {
+    int n;
+    int ia[3], ib[3];
+};
+
 template <typename T> KS_HD void gjk_support(PairGeo<T>& g, const T* dir, T* y, T* a, T* b) {
+#if defined(KS_STAMP_HULL) && defined(__HIP_DEVICE_COMPILE__)
+    const long long ts0 = clock64();
+#endif
     T nd[3] = {-dir[0], -dir[1], -dir[2]};
     hull_support(g.R1, g.p1, g.V1, g.off1, g.adj1, g.dir1, g.hint1, dir, T(0), a);
     hull_support(g.R2, g.p2, g.V2, g.off2, g.adj2, g.dir2, g.hint2, nd, T(0), b);
-#ifdef KS_STAMP_HULL
+#if defined(KS_STAMP_HULL) && defined(__HIP_DEVICE_COMPILE__)
     g.cnt_support += 2;
+    g.t_sup += clock64() - ts0;
 #endif
     sub3(y, a, b);
 }
@@ -866,6 +881,9 @@ template <typename T> KS_HD void swap_slots(Simplex<T>& S, T* l, int i, int j, b
         t = S.b[i][c]; S.b[i][c] = doit ? S.b[j][c] : t; S.b[j][c] = doit ? t : S.b[j][c];
     }
     T t = l[i]; l[i] = doit ? l[j] : t; l[j] = doit ? t : l[j];
+    int k;
+    k = S.ia[i]; S.ia[i] = doit ? S.ia[j] : k; S.ia[j] = doit ? k : S.ia[j];
+    k = S.ib[i]; S.ib[i] = doit ? S.ib[j] : k; S.ib[j] = doit ? k : S.ib[j];
 }
 
 // closest point on the simplex; reduces it to the supporting sub-simplex (stable compaction),
@@ -928,30 +946,71 @@ template <typename T> KS_HD bool gjk_closest(Simplex<T>& S, T* lam, T* v) {
 }
 
 // 0: separated by >= margin, 1: contact in the margin zone, 2: overlap (fall back to MPR)
-template <typename T> KS_FN int gjk_distance(PairGeo<T>& g, T margin, T* dist, T* normal, T* pos) {
+template <typename T> KS_HD void hull_point(const T* R, const T* p, KS_LDS const T* V, int i, T* out) {
+    const T v[3] = {V[4 * i], V[4 * i + 1], V[4 * i + 2]};
+    mulRv(out, R, v);
+    add3(out, out, p);
+}
+
+template <typename T> KS_HD void gjk_remember(GjkWarm* ws, const Simplex<T>& S) {
+    if (ws == nullptr) return;
+    ws->n = S.n < 3 ? S.n : 3;
+    KS_UNROLL
+    for (int i = 0; i < 3; i++) { ws->ia[i] = S.ia[i]; ws->ib[i] = S.ib[i]; }
+}
+
+template <typename T> KS_FN int gjk_distance(PairGeo<T>& g, T margin, T* dist, T* normal, T* pos, GjkWarm* ws = nullptr) {
     Simplex<T> S;
     T lam[4] = {1, 0, 0, 0}, v[3], d[3];
     const T tol = T(1e-6);
     KS_UNROLL
     for (int i = 0; i < 4; i++) {
+        S.ia[i] = 0; S.ib[i] = 0;
         KS_UNROLL
         for (int c = 0; c < 3; c++) { S.y[i][c] = 0; S.a[i][c] = 0; S.b[i][c] = 0; }
     }
-    sub3(d, g.p2, g.p1);
-    if (dot3(d, d) < T(1e-15)) { d[0] = 1; d[1] = 0; d[2] = 0; }
-    gjk_support(g, d, S.y[0], S.a[0], S.b[0]);
-    S.n = 1;
-    copy3(v, S.y[0]);
+    bool warm = false;
+    if (ws != nullptr && ws->n > 0) {
+        // the previous query's simplex at the current poses
+        S.n = ws->n;
+        KS_UNROLL
+        for (int i = 0; i < 3; i++) {
+            if (i < S.n) {
+                S.ia[i] = ws->ia[i]; S.ib[i] = ws->ib[i];
+                hull_point(g.R1, g.p1, g.V1, S.ia[i], S.a[i]);
+                hull_point(g.R2, g.p2, g.V2, S.ib[i], S.b[i]);
+                sub3(S.y[i], S.a[i], S.b[i]);
+            }
+        }
+        const bool inside = gjk_closest(S, lam, v);
+        const T vv0 = dot3(v, v);
+        warm = !inside && vv0 == vv0 && vv0 > T(1e-24);             // a degenerate or swallowed simplex -> cold start
+        if (warm) { g.hint1 = S.ia[0]; g.hint2 = S.ib[0]; }
+    }
+    if (!warm) {
+        KS_UNROLL
+        for (int i = 0; i < 4; i++) {
+            KS_UNROLL
+            for (int c = 0; c < 3; c++) { S.y[i][c] = 0; S.a[i][c] = 0; S.b[i][c] = 0; }
+        }
+        lam[0] = 1; lam[1] = 0; lam[2] = 0; lam[3] = 0;
+        sub3(d, g.p2, g.p1);
+        if (dot3(d, d) < T(1e-15)) { d[0] = 1; d[1] = 0; d[2] = 0; }
+        gjk_support(g, d, S.y[0], S.a[0], S.b[0]);
+        S.ia[0] = g.hint1; S.ib[0] = g.hint2;
+        S.n = 1;
+        copy3(v, S.y[0]);
+    }
     for (int it = 0; it < 48; it++) {
         T vv = dot3(v, v);
-        if (vv < T(1e-24)) return 2;
+        if (vv < T(1e-24)) { gjk_remember(ws, S); return 2; }
         T nd[3] = {-v[0], -v[1], -v[2]}, w[3], wa[3], wb[3];
         gjk_support(g, nd, w, wa, wb);
         T vw = dot3(v, w);
 #ifdef KS_DEBUG_GJK
         printf("  gjk[%d] it %d n %d vv %.9g vw %.9g |v| %.9g\n", (int)sizeof(T), it, S.n, (double)vv, (double)vw, (double)ksqrt(vv));
 #endif
-        if (vw > 0 && vw * vw >= margin * margin * vv) return 0;
+        if (vw > 0 && vw * vw >= margin * margin * vv) { gjk_remember(ws, S); return 0; }
         if (vv - vw <= tol * vv) break;
         bool dup = false;
         KS_UNROLL
@@ -962,9 +1021,16 @@ template <typename T> KS_FN int gjk_distance(PairGeo<T>& g, T margin, T* dist, T
         T plam[4] = {lam[0], lam[1], lam[2], lam[3]}, pv[3] = {v[0], v[1], v[2]};
         KS_UNROLL
         for (int i = 0; i < 4; i++)
-            if (i == S.n) { copy3(S.y[i], w); copy3(S.a[i], wa); copy3(S.b[i], wb); }
+            if (i == S.n) { copy3(S.y[i], w); copy3(S.a[i], wa); copy3(S.b[i], wb); S.ia[i] = g.hint1; S.ib[i] = g.hint2; }
         S.n++;
-        if (gjk_closest(S, lam, v)) return 2;
+#if defined(KS_STAMP_HULL) && defined(__HIP_DEVICE_COMPILE__)
+        const long long tc0 = clock64();
+        const bool inside_ = gjk_closest(S, lam, v);
+        g.t_clo += clock64() - tc0;
+        if (inside_) { gjk_remember(ws, S); return 2; }
+#else
+        if (gjk_closest(S, lam, v)) { gjk_remember(ws, S); return 2; }
+#endif
         if (dot3(v, v) >= vv) {
             copy3(v, pv);
             S = prev;
@@ -972,6 +1038,7 @@ template <typename T> KS_FN int gjk_distance(PairGeo<T>& g, T margin, T* dist, T
             break;
         }
     }
+    gjk_remember(ws, S);
     T dd = norm3(v);
     if (dd < T(1e-12)) return 2;
     if (dd >= margin) return 0;
@@ -1177,7 +1244,7 @@ KS_HD int pc_pack(int count, int h1, int h2) { return count + 8 * (h1 + (1 << PC
 
 template <typename T, typename S>
 KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S scr, KS_LDS const PairRec<T>* prp, int packed_in, int& h1_out,
-                            int& h2_out, float* prof = nullptr) {
+                            int& h2_out, GjkWarm* ws, float* prof = nullptr) {
     KS_LDS const PairRec<T>& pr = *prp;
     PairGeo<T> pg;
     h1_out = (packed_in >> 3) & PC_HINT_MAX;
@@ -1204,12 +1271,12 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
     pg.hint2 = h2_out < pg.n2 ? h2_out : 0;
     pg.half_margin = T(0);
 #ifdef KS_STAMP_HULL
-    pg.cnt_support = 0; pg.cnt_steps = 0;
+    pg.cnt_support = 0; pg.cnt_steps = 0; pg.t_sup = 0; pg.t_clo = 0;
 #endif
     T depth, dist, dir[3], pos[3];
-    const int r = gjk_distance(pg, margin, &dist, dir, pos);
+    const int r = gjk_distance(pg, margin, &dist, dir, pos, ws);
 #ifdef KS_STAMP_HULL
-    if (prof) { prof[24] += 1.f; prof[25] += (float)pg.cnt_support; if (r == 2) prof[26] += 1.f; }
+    if (prof) { prof[24] += 1.f; prof[25] += (float)pg.cnt_support; if (r == 2) prof[26] += 1.f; prof[28] += (float)pg.t_sup; prof[29] += (float)pg.t_clo; }
     const int sup_gjk = pg.cnt_support;
 #endif
     h1_out = pg.hint1 & PC_HINT_MAX; h2_out = pg.hint2 & PC_HINT_MAX;
@@ -1236,7 +1303,8 @@ template <typename T, typename S, int SUBS> KS_HD void reset_pair_words(S scr, T
 }
 
 template <typename T, typename S, int SUBS>
-KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> team, int& ncon, int& status, float* prof = nullptr) {
+KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> team, int& ncon, int& status, GjkWarm* warm = nullptr,
+                     float* prof = nullptr) {
     KS_T0
     const unsigned plane_mask = hu.plane_mask;
     const int npair = hu.npair, nhull = hu.nhull;
@@ -1268,7 +1336,7 @@ KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> te
     for (int hk = team.sub; hk < nhull; hk += SUBS) {
         const int pi = hu.hull_pi[hk];
         int c = 0, h1 = 0, h2 = 0;
-        if (pairs[pi].slot + 1 <= NSTAGE) c = collide_hull_hull(m, dirtab, scr, pairs + pi, (int)scr(SCR_PC + pi), h1, h2, prof);
+        if (pairs[pi].slot + 1 <= NSTAGE) c = collide_hull_hull(m, dirtab, scr, pairs + pi, (int)scr(SCR_PC + pi), h1, h2, warm ? warm + hk / SUBS : nullptr, prof);
         else status |= ST_CONTACT_OVERFLOW;
         scr(SCR_PC + pi) = T(pc_pack(c, h1, h2));
     }
@@ -2027,13 +2095,13 @@ KS_FN void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm, S scr,
 // ---------------------------------------------------------------- one mj_step (forward + Euler)
 template <typename T, typename S, int SUBS>
 KS_HD void mj_forward_step(const Model<T>& m, const Hulls<T>& hu, T* qpos, T* qvel, T* warm, const T* ctrl, const T* R7, S scr, Team<SUBS> team,
-                           int solver_iterations, bool integrate, int& ncon_out, int& status, float* prof = nullptr) {
+                           int solver_iterations, bool integrate, int& ncon_out, int& status, float* prof = nullptr, GjkWarm* gjk_warm = nullptr) {
     KS_T0
     team.sync();                                   // the previous substep's readers of the body poses are done
     dynamics_rows(m, qpos, qvel, ctrl, R7, scr, team);
     KS_TICK(0)
     int ncon = 0;
-    collision(m, hu, scr, team, ncon, status, prof);
+    collision(m, hu, scr, team, ncon, status, gjk_warm, prof);
     KS_TICK(1)
     ncon_out = ncon;
     if (!integrate) return;

@@ -29,7 +29,7 @@ template <typename T, typename S, typename SnapW> KS_HD void write_snapshot(S sc
 template <typename T, typename S, typename SnapW, int SUBS>
 KS_HD void lane_env_step(const Model<T>& m, const Hulls<T>& hu, LaneState<T>& st, const T* hand_quat, const T* act4, S scr, Team<SUBS> team,
                          SnapW snap_put, int frame_skip, int solver_iterations, int& ncon, int& status, float* prof = nullptr,
-                         T* ws = nullptr) {
+                         T* ws = nullptr, GjkWarm* warm = nullptr) {
     // ws (optional, 18 reals shared by the team): where the per-step constants live; the GPU passes LDS
     T Rpalm[9], T3[9], wrist[3], R7_[9], ctrl_[NU];
     T* R7 = ws ? ws : R7_;
@@ -44,7 +44,7 @@ KS_HD void lane_env_step(const Model<T>& m, const Hulls<T>& hu, LaneState<T>& st
         T jq[9];
         KS_UNROLL
         for (int j = 0; j < 9; j++) jq[j] = st.qpos[j];
-        mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, ctrl, R7, scr, team, solver_iterations, true, ncon, status, prof);
+        mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, ctrl, R7, scr, team, solver_iterations, true, ncon, status, prof, warm);
         if (sub == frame_skip - 1 && team.sub == 0) write_snapshot<T>(scr, jq, snap_put);
     }
 }

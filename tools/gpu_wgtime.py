@@ -38,4 +38,4 @@ for t in range(22 if MODE == "grasp" else 12):
         for rank in (0, 1, 2, 3, n // 2, n - 1):
             e = order[rank]
             p = full[:, :, e].max(0)
-            print(f"  env {e} (rank {rank}) duration {d[e]:.0f} ticks, ncon(last) {nc[e]}, total cyc {p[6]:.0f}: " + ", ".join(f"{names[k]} {p[k]:.0f}" for k in (0, 1, 8, 9, 10, 2, 3, 5, 21, 22)) + f" | gjk calls {full[:, 24, e].sum():.0f} gjk supports {full[:, 25, e].sum():.0f} mpr calls {full[:, 26, e].sum():.0f} mpr supports {full[:, 27, e].sum():.0f}; per-lane max gjk sup {full[:, 25, e].max():.0f} mpr sup {full[:, 27, e].max():.0f}")
+            print(f"  env {e} (rank {rank}) duration {d[e]:.0f} ticks, ncon(last) {nc[e]}, total cyc {p[6]:.0f}: " + ", ".join(f"{names[k]} {p[k]:.0f}" for k in (0, 1, 8, 9, 10, 2, 3, 5, 21, 22)) + f" | gjk calls {full[:, 24, e].sum():.0f} gjk supports {full[:, 25, e].sum():.0f} mpr calls {full[:, 26, e].sum():.0f} mpr supports {full[:, 27, e].sum():.0f}; per-lane max gjk sup {full[:, 25, e].max():.0f} mpr sup {full[:, 27, e].max():.0f}; busiest lane: support cycles {full[:, 28, e].max():.0f} closest cycles {full[:, 29, e].max():.0f}")
