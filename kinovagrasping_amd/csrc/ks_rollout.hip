@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void k_adam_step(long count, float* __restrict
                                                    float eps, float wd) {
 #pragma clang fp contract(off)
     // torch.optim.Adam, single-tensor formulation: bias corrections from the (already incremented) device step
+    if (step[0] <= 0) return;                 // no update has produced gradients yet
     const float t = (float)step[0];
     const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
     const float step_size = lr / bc1, bc2s = sqrtf(bc2);
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void k_adam_step(long count, float* __restrict
 __global__ __launch_bounds__(256) void k_soft_update(long count, const float* __restrict__ p, float* __restrict__ tp, float tau,
                                                      const int64_t* __restrict__ it, int freq) {
 #pragma clang fp contract(off)
-    if (it[0] % freq != 0) return;
+    if (it[0] <= 0 || it[0] % freq != 0) return;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) tp[i] = tau * p[i] + (1.0f - tau) * tp[i];
 }
 

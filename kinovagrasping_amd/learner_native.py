@@ -152,6 +152,13 @@ class NativeDDPGfDUpdate:
         return None
 
     @torch.no_grad()
+    def phase_head(self):
+        """Pipelined form of phase_targets: applied at the START of the next update (pipeline.GraphedTrainer), so that
+        the actor's weights change at one known, early point of every update instead of at its end.  A no-op before the
+        first update (device counter 0)."""
+        self.phase_targets()
+
+    @torch.no_grad()
     def phase_targets(self):
         """actor Adam step + soft target update on every network_repl_freq-th update"""
         pol, P = self.p, _sim._ptr

@@ -7,13 +7,18 @@ physics kernel takes on the device.  GraphedTrainer captures them once into HIP 
     g_pre    action selection (check_grasp, actor forward, exploration noise, scripted lift)
     ks_step  the simulator (libkinova_sim, launched directly on the stream - not part of a graph)
     g_post   replay writes + episode bookkeeping
-    g_learn  window sampling + one DDPGfD update (learner_native: explicit GEMMs + fused glue kernels); with
-             world_size > 1 it is three graphs (critic backward | critic step + actor backward | actor step +
-             targets) with the all-reduce of the flat gradient buffer (RCCL) issued between them - collectives stay
-             outside the captures.
+    g_head   actor Adam + soft target update (previous update's gradients), window sampling
+    g_learn  the body of one DDPGfD update (learner_native: explicit GEMMs + fused glue kernels); with
+             world_size > 1 it is two graphs (critic backward | critic step + actor backward) with the all-reduce of
+             the flat gradient buffers (RCCL) issued after each - collectives stay outside the captures.
 
-The learner graphs run on a second stream beside the simulator kernel: they read the replay as it was before this
-step's writes and update the weights after this step's actor forward.
+The learner runs on a second stream as a one-step software pipeline.  Each update is a short HEAD (the actor's Adam
+step + soft target update for the gradients of the PREVIOUS update, then the window sampling) and a BODY (targets,
+critic backward + Adam, actor backward).  The rollout only waits for the head - a few launches that need no LDS and
+finish while the simulator kernel is still running - so replay writes and the next actor forward never wait for the
+GEMMs, which can only get CUs once simulator workgroups retire (the stepping kernel holds all of every CU's LDS).
+The actor therefore acts with weights that lag the learner by one update; the reference's own loop acts with a policy
+that is a whole episode old (100 updates at the end of each episode, main_DDPGfD.py:466-486).
 """
 from __future__ import annotations
 
@@ -37,6 +42,7 @@ class GraphedTrainer:
         self.main = torch.cuda.current_stream(self.dev)
         self.side = torch.cuda.Stream(self.dev)
         self.acted = torch.cuda.Event()
+        self.head_done = torch.cuda.Event()
         self.g_pre = self.g_post = None
         self.g_learn = []
         self.losses = None
@@ -48,23 +54,23 @@ class GraphedTrainer:
     def _sample(self):
         self.batch = self.replay.sample_batch_nstep(self.batch_episodes)
 
-    def _phase1(self):
+    def _head(self):
+        self.native.phase_head()
         self._sample()
+
+    def _phase1(self):
         st, ac, ns, rw, nd, w = self.batch
         self.loss_c = self.native.phase_critic(st, ac, ns, rw, w)
 
     def _phase2(self):
         self.native.phase_actor(self.batch[0], self.batch[5])
 
-    def _phase3(self):
-        self.native.phase_targets()
-
     def _learn_eager(self):
+        self._head()
         self._phase1()
         self.native.allreduce("critic")
         self._phase2()
         self.native.allreduce("actor")
-        self._phase3()
 
     def capture(self, warmup_steps=3):
         """Run `warmup_steps` eager steps (allocator / autotune warm-up, as torch.cuda.graphs requires) and capture."""
@@ -88,9 +94,12 @@ class GraphedTrainer:
         self.g_post = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_post, **mode):
             eng.post()
-        phases = [self._phase1, self._phase2, self._phase3]
+        self.g_head = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_head, **mode):
+            self._head()
+        phases = [self._phase1, self._phase2]
         groups = [[p] for p in phases] if self.distributed else [phases]
-        pool = None
+        pool = self.g_head.pool()
         for grp in groups:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, **mode):
@@ -100,7 +109,7 @@ class GraphedTrainer:
             self.g_learn.append(g)
         torch.cuda.synchronize(self.dev)
 
-    def _learn(self):
+    def _body(self):
         if not self.distributed:
             self.g_learn[0].replay()
         else:
@@ -108,7 +117,6 @@ class GraphedTrainer:
             self.native.allreduce("critic")
             self.g_learn[1].replay()
             self.native.allreduce("actor")
-            self.g_learn[2].replay()
         self.updates += 1
 
     def step(self):
@@ -121,12 +129,15 @@ class GraphedTrainer:
         self.sim.step(self.eng.action_t)
         if learn:
             if self.overlap:
-                side.wait_event(self.acted)        # weights are free once this step's actor forward is done
+                side.wait_event(self.acted)        # the actor's weights are free once this step's forward is done
                 with torch.cuda.stream(side):
-                    self._learn()
-                main.wait_stream(side)             # the update read the replay before this step's writes
+                    self.g_head.replay()
+                    self.head_done.record(side)
+                    self._body()
+                main.wait_event(self.head_done)    # windows sampled, actor weights settled: the body runs on its own
             else:
-                self._learn()
+                self.g_head.replay()
+                self._body()
         self.g_post.replay()
         self.steps += 1
         return self.eng.reward_out, self.eng.done_out
