@@ -12,8 +12,10 @@ sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
 names = ["fk+dyn", "collision", "constraints", "chol M", "p:scan->argmin+scan", "euler", "total", "p:cand list", "c:plane pairs", "c:hull pairs", "c:merge", "p:culls", "p:rec+pose+slice scan", "n:warm cost", "n:H assembly", "n:team reduce", "n:chol+solve", "n:p proj", "n:linesearch", "n:update", "n:forces", "#newton iters", "#ls iters", "p:greedy"]
 acc = np.zeros((24,))
 accmax = np.zeros((24,))
+MODE = sys.argv[1] if len(sys.argv) > 1 else 'random'
+closing = torch.tensor([0.0, 0.5, 0.5, 0.5], device='cuda').repeat(n, 1).t().contiguous()
 for t in range(30):
-    sim.step(acts[t])
+    sim.step(closing if MODE == 'grasp' else acts[t])
     st = sim.get_state(contacts=True)
     torch.cuda.synchronize()
     prof = st["contact"].reshape(-1, n)[:480].cpu().numpy().reshape(16, 30, n)[:, :24]   # [sub][phase][env]
