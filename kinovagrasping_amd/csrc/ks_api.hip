@@ -195,11 +195,13 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
 #ifdef KS_STAMP
         // diagnostic build only: per-phase cycle sums of this lane go to the contact tap buffer
         prof[6] = (float)(clock64() - tk0);
+#ifdef KS_STAMP_WG
         // wall clock (100 MHz) of the stepping loop's start / end, modulo 2^22 ticks, and the hardware id (CU / SE / XCC)
         prof[13] = (float)(wk0 & 0x3fffff);
         prof[14] = (float)(wall_clock64() & 0x3fffff);
         prof[19] = (float)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) & 0xffffff);
         prof[20] = (float)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf);
+#endif
         if (tap) for (int k = 0; k < 30; k++) b.contact[(long)(k + 30 * team.sub) * N + env] = (T)prof[k];
         tap = 0;
 #endif

@@ -604,16 +604,18 @@ KS_HD void hull_support(const T* R, const T* p, KS_LDS const T* V, KS_LDS const 
     for (int guard = 0; guard < 4096; guard++) {
         const int c0 = off[cur], c1 = off[cur + 1];
         int nxt = cur;
-        for (int c = c0; c < c1; c++) {
-            // four neighbour ids in one read, their vertices fetched independently, then compared in order
-            int j[4];
-            T d[4];
+        for (int c = c0; c < c1; c += 2) {
+            // two chunks (eight neighbour ids) per round: both id reads are issued together, then the eight vertices, then
+            // the comparisons in list order; a vertex with <= 4 neighbours left reads its last chunk twice (no effect)
+            const int cb = c + 1 < c1 ? c + 1 : c;
+            int j[8];
+            T d[8];
             KS_UNROLL
-            for (int q = 0; q < 4; q++) j[q] = adj[4 * c + q];
+            for (int q = 0; q < 4; q++) { j[q] = adj[4 * c + q]; j[4 + q] = adj[4 * cb + q]; }
             KS_UNROLL
-            for (int q = 0; q < 4; q++) d[q] = V[4 * j[q]] * ld[0] + V[4 * j[q] + 1] * ld[1] + V[4 * j[q] + 2] * ld[2];
+            for (int q = 0; q < 8; q++) d[q] = V[4 * j[q]] * ld[0] + V[4 * j[q] + 1] * ld[1] + V[4 * j[q] + 2] * ld[2];
             KS_UNROLL
-            for (int q = 0; q < 4; q++)
+            for (int q = 0; q < 8; q++)
                 if (d[q] > best) { best = d[q]; nxt = j[q]; }
         }
         if (nxt == cur) break;

@@ -1,4 +1,4 @@
-"""Dev tool (diagnostic build -DKS_STAMP): when does each workgroup of k_env_step run, and on which CU?"""
+"""Dev tool (diagnostic build -DKS_STAMP -DKS_STAMP_WG [-DKS_STAMP_HULL]): when does each workgroup of k_env_step run, and on which CU?"""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from kinovagrasping_amd import scenarios
