@@ -75,6 +75,16 @@ class GraphedTrainer:
     def capture(self, warmup_steps=3):
         """Run `warmup_steps` eager steps (allocator / autotune warm-up, as torch.cuda.graphs requires) and capture."""
         eng, sim = self.eng, self.sim
+        # The learner's GEMMs are small and skinny (M = 1600 / 8000 rows, N, K <= 256): let PyTorch's TunableOp time the
+        # hipBLASLt / rocBLAS candidates for each shape during the eager warm-up and keep the fastest; tuning is
+        # switched off again before the captures (the selections stay in use).  KS_TUNABLEOP=0 skips it.
+        import os
+        tune = os.environ.get("KS_TUNABLEOP", "1") != "0" and hasattr(torch.cuda, "tunable")
+        if tune:
+            torch.cuda.tunable.enable(True)
+            torch.cuda.tunable.tuning_enable(True)
+            torch.cuda.tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "ks_tunableop.csv"))
+            torch.cuda.tunable.set_max_tuning_duration(15)
         s = torch.cuda.Stream(self.dev)
         s.wait_stream(self.main)
         with torch.cuda.stream(s):
@@ -86,6 +96,8 @@ class GraphedTrainer:
                 self.steps += 1
         self.main.wait_stream(s)
         torch.cuda.synchronize(self.dev)
+        if tune:
+            torch.cuda.tunable.tuning_enable(False)
         self.g_pre = torch.cuda.CUDAGraph()
         # thread_local: other threads (the RCCL watchdog of torch.distributed) keep issuing HIP calls during a capture
         mode = dict(capture_error_mode="thread_local")
