@@ -44,7 +44,8 @@ template <typename T> struct Model {
     const T* mesh_vert[4];     // [nvert_pad][4] (x,y,z,0) in the geom frame; rows >= nvert repeat vertex 0
     // rangefinder geometry: the original mesh triangles (geom frame) under a bounding-volume hierarchy
     const float* mesh_tri[4];      // [ntri][9], leaf ranges contiguous
-    const float* mesh_bvh_box[4];  // [nnode][6] min xyz, max xyz
+    const float* mesh_bvh_box[4];  // [nnode][16] wide nodes: child A box (min xyz, max xyz), child B box, child ids
+                                   // (int bits; leaf: first triangle, -count), 2 pad
     const int* mesh_bvh_lr[4];     // [nnode][2] internal: (left, right); leaf: (first triangle, -count)
     // vertex adjacency of the hull graph in chunks of 4 neighbour ids (uint16, ascending, padded with the
     // vertex itself, which never wins a strict comparison): one 8-byte read yields four neighbours

@@ -191,8 +191,25 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
             std::snprintf(nm, sizeof nm, "mesh%d_bvh_lr", s);
             if (!blob_find(b, n, nm, rl) || rl.code != 1 || rl.shape[0] != rb.shape[0]) { e = std::string("missing ") + nm; return false; }
             hm.tri[s].resize(rt.count); std::memcpy(hm.tri[s].data(), rt.data, rt.count * 4);
-            hm.bvh_box[s].resize(rb.count); std::memcpy(hm.bvh_box[s].data(), rb.data, rb.count * 4);
             hm.bvh_lr[s].resize(rl.count); std::memcpy(hm.bvh_lr[s].data(), rl.data, rl.count * 4);
+            // wide nodes for the traversal: one 64-byte record per node = the boxes of BOTH children (12 floats) + the two
+            // child ids (leaf: first triangle, -count) as int bit patterns + padding -> one visit = one cache line
+            {
+                std::vector<float> nb(rb.count);
+                std::memcpy(nb.data(), rb.data, rb.count * 4);
+                const int nn = (int)(rl.count / 2);
+                hm.bvh_box[s].assign((size_t)nn * 16, 0.0f);
+                for (int i = 0; i < nn; i++) {
+                    const int a = hm.bvh_lr[s][2 * i], b = hm.bvh_lr[s][2 * i + 1];
+                    float* w = &hm.bvh_box[s][(size_t)i * 16];
+                    if (b >= 0) {
+                        std::memcpy(w, &nb[6 * (size_t)a], 24);
+                        std::memcpy(w + 6, &nb[6 * (size_t)b], 24);
+                    }
+                    std::memcpy(w + 12, &a, 4);
+                    std::memcpy(w + 13, &b, 4);
+                }
+            }
             m.mesh_ntri[s] = (int)rt.shape[0];
             m.mesh_nnode[s] = (int)rb.shape[0];
             m.mesh_tri[s] = hm.tri[s].data();

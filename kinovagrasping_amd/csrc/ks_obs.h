@@ -8,6 +8,8 @@
 // reference never calls sim.forward() after its 15th sim.step(), so everything the observation
 // reads lags qpos by one substep) -- the "snapshot".  KS_HD: lane-checked on the CPU too.
 #pragma once
+#include <string.h>
+
 #include "ks_model.h"
 
 namespace ks {
@@ -51,30 +53,42 @@ template <typename T> KS_HD T ray_box_entry(const T* o, const T* d, const T* lo,
 }
 template <typename T> KS_HD bool ray_box(const T* o, const T* d, const T* lo, const T* hi, T tmax) { return ray_box_entry(o, d, lo, hi, tmax) >= 0; }
 
-// entry parameter of BVH node `node` (float32 box, padded outwards by 1e-6: the box test must never reject a
-// triangle the exhaustive oracle would hit)
-template <typename T> KS_HD T bvh_node_entry(const float* box, int node, const T* lp, const T* lv, T tmax) {
-    T lo[3] = {T(box[6 * node]) - T(1e-6), T(box[6 * node + 1]) - T(1e-6), T(box[6 * node + 2]) - T(1e-6)};
-    T hi[3] = {T(box[6 * node + 3]) + T(1e-6), T(box[6 * node + 4]) + T(1e-6), T(box[6 * node + 5]) + T(1e-6)};
+// entry parameter of a float32 box (6 values: min xyz, max xyz), padded outwards by 1e-6: the box test must never reject
+// a triangle the exhaustive oracle would hit
+template <typename T> KS_HD T bvh_box_entry(const float* bx, const T* lp, const T* lv, T tmax) {
+    T lo[3] = {T(bx[0]) - T(1e-6), T(bx[1]) - T(1e-6), T(bx[2]) - T(1e-6)};
+    T hi[3] = {T(bx[3]) + T(1e-6), T(bx[4]) + T(1e-6), T(bx[5]) + T(1e-6)};
     return ray_box_entry(lp, lv, lo, hi, tmax);
+}
+KS_HD int float_bits(float f) {
+    int i;
+#if defined(__HIP_DEVICE_COMPILE__)
+    i = __float_as_int(f);
+#else
+    memcpy(&i, &f, 4);
+#endif
+    return i;
 }
 
 // Ray vs mesh geom, MuJoCo's mj_rayMesh semantics: bounding-box pre-test (geom_size about the geom origin),
 // then the faces of the ORIGINAL triangle mesh, both orientations, nearest t >= 0 (-1 = miss).  The faces
-// are visited through a bounding-volume hierarchy, nearer child first, so that the nearest hit found so far
-// prunes the rest; the result is the minimum over all faces, exactly what the exhaustive oracle computes.
+// are visited through a bounding-volume hierarchy of wide nodes (one 64-byte record holds both children's boxes),
+// nearer child first, so that the nearest hit found so far prunes the rest; the result is the minimum over all
+// faces, exactly what the exhaustive oracle computes.
 template <typename T>
-KS_HD T ray_mesh(const float* tri, const float* box, const int* lr, const T* size, const T* lp, const T* lv) {
+KS_HD T ray_mesh(const float* tri, const float* wnode, const T* size, const T* lp, const T* lv) {
     {
         T lo[3] = {-size[0], -size[1], -size[2]}, hi[3] = {size[0], size[1], size[2]};
         if (!ray_box(lp, lv, lo, hi, Lim<T>::big)) return T(-1);
     }
     T best = T(-1);
-    if (bvh_node_entry(box, 0, lp, lv, Lim<T>::big) < 0) return best;
     int stack[32], sp = 0, node = 0;
     T stack_t[32];
     for (;;) {
-        const int a = lr[2 * node], b = lr[2 * node + 1];
+        float w[16];
+        KS_UNROLL
+        for (int i = 0; i < 16; i++) w[i] = wnode[16 * (long)node + i];
+        const int a = float_bits(w[12]), b = float_bits(w[13]);
         bool descend = false;
         if (b < 0) {
             for (int i = a; i < a - b; i++) {
@@ -89,15 +103,15 @@ KS_HD T ray_mesh(const float* tri, const float* box, const int* lr, const T* siz
                 T u = dot3(tv, pv) * inv;
                 if (u < 0 || u > 1) continue;
                 cross3(qv, tv, e1);
-                T w = dot3(lv, qv) * inv;
-                if (w < 0 || u + w > 1) continue;
+                T ww = dot3(lv, qv) * inv;
+                if (ww < 0 || u + ww > 1) continue;
                 T tt = dot3(e2, qv) * inv;
                 if (tt >= 0 && (best < 0 || tt < best)) best = tt;
             }
         } else {
-            // both children tested at once (independent loads); the farther one waits on the stack with its entry t
+            // both children's boxes are in the record; the farther one waits on the stack with its entry t
             const T tmax = best < 0 ? Lim<T>::big : best;
-            const T ta = bvh_node_entry(box, a, lp, lv, tmax), tb = bvh_node_entry(box, b, lp, lv, tmax);
+            const T ta = bvh_box_entry(w, lp, lv, tmax), tb = bvh_box_entry(w + 6, lp, lv, tmax);
             if (ta >= 0 && tb >= 0) {
                 const bool a_first = ta <= tb;
                 if (sp < 32) { stack[sp] = a_first ? b : a; stack_t[sp] = a_first ? tb : ta; sp++; }
@@ -154,7 +168,7 @@ template <typename T, typename C> KS_HD T ray_geom(const Model<T>& m, C snap, in
     mulRtv(lp, Rg, t);
     mulRtv(lv, Rg, vec);
     const int mesh = m.geom_mesh[g];
-    return ray_mesh(m.mesh_tri[mesh], m.mesh_bvh_box[mesh], m.mesh_bvh_lr[mesh], m.geom_size[g], lp, lv);
+    return ray_mesh(m.mesh_tri[mesh], m.mesh_bvh_box[mesh], m.geom_size[g], lp, lv);
 }
 // nearer of two ray results (-1 = miss)
 template <typename T> KS_HD T ray_nearer(T a, T b) { return (b >= 0 && (a < 0 || b < a)) ? b : a; }
