@@ -311,6 +311,20 @@ __global__ void k_store_init(Buffers<T> b, const int32_t* __restrict__ env_ids, 
 
 // one (env, ray, geom) per lane: eight envs per wave, the eight mesh geoms of an env in adjacent lanes (lane 0 of the
 // group also takes the ground plane), nearest hit by a 3-step butterfly.  The ray index is uniform per workgroup.
+// pruning distance shared by the eight lanes of one (env, ray): the minimum of their nearest hits so far, published in
+// LDS (lanes that have left the traversal keep their final value there; a stale read only prunes less).
+template <typename T> struct GroupBound {
+    KS_LDS T* group;   // the eight published distances of this (env, ray)
+    int me;
+    __device__ T operator()(T best) const {
+        if (best >= 0 && best < group[me]) group[me] = best;
+        T b = group[0];
+        KS_UNROLL
+        for (int k = 1; k < 8; k++) { const T o = group[k]; b = o < b ? o : b; }
+        return b;
+    }
+};
+
 constexpr int RAY_ENVS = WAVE / (NGEOM - 1);
 static_assert(NGEOM - 1 == 8, "k_rays: eight mesh geoms per env, one per lane");
 template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model<T>* __restrict__ mp, Buffers<T> b, int N, int masked) {
@@ -318,13 +332,19 @@ template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model
     const int env = blockIdx.x * RAY_ENVS + (threadIdx.x >> 3), ray = blockIdx.y;
     const bool live = env < N && !(masked && !b.flag[env]);
     T best = T(-1);
+    __shared__ T pub[WAVE];
+    pub[threadIdx.x] = Lim<T>::big;
     if (live) {
         const Model<T>& m = *mp;
         Col<T> snap{b.snap + env, N};
         T pnt[3], vec[3];
         const int sb = ray_origin(m, snap, ray, pnt, vec);
-        if (g == 1) best = ray_ground(m, pnt, vec);
-        if (m.geom_body[g] != sb) best = ray_nearer(best, ray_geom(m, snap, g, pnt, vec));
+        if (g == 1) {
+            best = ray_ground(m, pnt, vec);
+            if (best >= 0) pub[threadIdx.x] = best;
+        }
+        if (m.geom_body[g] != sb)
+            best = ray_nearer(best, ray_geom(m, snap, g, pnt, vec, GroupBound<T>{(KS_LDS T*)pub + (threadIdx.x & ~7), (int)(threadIdx.x & 7)}));
     }
     KS_UNROLL
     for (int mask = 1; mask < 8; mask <<= 1) best = ray_nearer(best, (T)__shfl_xor(best, mask));

@@ -75,8 +75,16 @@ KS_HD int float_bits(float f) {
 // are visited through a bounding-volume hierarchy of wide nodes (one 64-byte record holds both children's boxes),
 // nearer child first, so that the nearest hit found so far prunes the rest; the result is the minimum over all
 // faces, exactly what the exhaustive oracle computes.
-template <typename T>
-KS_HD T ray_mesh(const float* tri, const float* wnode, const T* size, const T* lp, const T* lv) {
+// `bound(best)`: the pruning distance for the traversal, given this lane's nearest hit so far (-1 = none).  The serial
+// code passes its own hit through; k_rays takes the minimum over the lanes that cast the SAME ray at the other geoms -
+// a near hit on the object prunes the walk through the 28 000-triangle palm behind it.  The minimum over geoms of the
+// nearest hits is unchanged by that.
+struct OwnBound {
+    template <typename T> KS_HD T operator()(T best) const { return best < 0 ? Lim<T>::big : best; }
+};
+
+template <typename T, typename Bound = OwnBound>
+KS_HD T ray_mesh(const float* tri, const float* wnode, const T* size, const T* lp, const T* lv, Bound bound = Bound()) {
     {
         T lo[3] = {-size[0], -size[1], -size[2]}, hi[3] = {size[0], size[1], size[2]};
         if (!ray_box(lp, lv, lo, hi, Lim<T>::big)) return T(-1);
@@ -110,7 +118,7 @@ KS_HD T ray_mesh(const float* tri, const float* wnode, const T* size, const T* l
             }
         } else {
             // both children's boxes are in the record; the farther one waits on the stack with its entry t
-            const T tmax = best < 0 ? Lim<T>::big : best;
+            const T tmax = bound(best);
             const T ta = bvh_box_entry(w, lp, lv, tmax), tb = bvh_box_entry(w + 6, lp, lv, tmax);
             if (ta >= 0 && tb >= 0) {
                 const bool a_first = ta <= tb;
@@ -157,7 +165,7 @@ template <typename T> KS_HD T ray_ground(const Model<T>& m, const T* pnt, const 
     }
     return T(-1);
 }
-template <typename T, typename C> KS_HD T ray_geom(const Model<T>& m, C snap, int g, const T* pnt, const T* vec) {
+template <typename T, typename C, typename Bound = OwnBound> KS_HD T ray_geom(const Model<T>& m, C snap, int g, const T* pnt, const T* vec, Bound bound = Bound()) {
     T R[9], p[3], Rg[9], pg[3], t[3];
     snap_body<T>(snap, m.geom_body[g], R, p);
     mulRR(Rg, R, m.geom_R[g]);
@@ -168,7 +176,7 @@ template <typename T, typename C> KS_HD T ray_geom(const Model<T>& m, C snap, in
     mulRtv(lp, Rg, t);
     mulRtv(lv, Rg, vec);
     const int mesh = m.geom_mesh[g];
-    return ray_mesh(m.mesh_tri[mesh], m.mesh_bvh_box[mesh], m.geom_size[g], lp, lv);
+    return ray_mesh(m.mesh_tri[mesh], m.mesh_bvh_box[mesh], m.geom_size[g], lp, lv, bound);
 }
 // nearer of two ray results (-1 = miss)
 template <typename T> KS_HD T ray_nearer(T a, T b) { return (b >= 0 && (a < 0 || b < a)) ? b : a; }
