@@ -83,7 +83,7 @@ class GraphedTrainer:
         if tune:
             torch.cuda.tunable.enable(True)
             torch.cuda.tunable.tuning_enable(True)
-            torch.cuda.tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "ks_tunableop.csv"))
+            torch.cuda.tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "ks_tunableop.csv"), insert_device_ordinal=True)
             torch.cuda.tunable.set_max_tuning_duration(15)
         s = torch.cuda.Stream(self.dev)
         s.wait_stream(self.main)
