@@ -56,6 +56,48 @@ def config2_states(n_envs: int, shape: str = "CubeS"):
     return q, hq
 
 
+def latin_square_object_keys(shape_keys, max_elements: int):
+    """Object schedule of KinovaGripper_Env.Generate_Latin_Square (kinova_gripper_env.py:895-964): cyclic rotations of
+    the key list - rows keys[k:] + keys[:k] for k = n, n-1, ..., 0 (n = len - 1), repeated - cut at max_elements.
+    Episodes take their object from the END of the list (get_object pops, kinova_gripper_env.py:986-989)."""
+    keys = list(shape_keys)
+    n = len(keys) - 1
+    out = []
+    while len(out) < max_elements:
+        for k in range(n, -1, -1):
+            row = keys[k:] + keys[:k]
+            out.extend(row[:max_elements - len(out)])
+            if len(out) >= max_elements:
+                break
+    return out
+
+
+def episode_objects(shape_keys, n_episodes: int):
+    """shape of episode 0, 1, ... as the reference's reset() sees them: the Latin-square list popped from its end"""
+    return latin_square_object_keys(shape_keys, n_episodes)[::-1]
+
+
+def select_orientation(shape: str, hand_orientation: str, rng=np.random) -> str:
+    """KinovaGripper_Env.select_orienation (kinova_gripper_env.py:1180-1222) with the same np.random draws: 'normal'
+    unless hand_orientation == 'random'; RBowl shapes never normal, Lemon shapes never rotated; thresholds 0.333 / 0.667."""
+    t = 0.330
+    if "RBowl" in shape:
+        if hand_orientation == "random":
+            t = rng.uniform(0.333, 1)
+    elif "Lemon" in shape:
+        if hand_orientation == "random":
+            c1 = rng.uniform(0, 0.333)
+            c2 = rng.uniform(0.667, 1)
+            t = rng.choice([c1, c2])
+    elif hand_orientation == "random":
+        t = rng.rand()
+    if t < 0.333:
+        return "normal"
+    if t > 0.667:
+        return "top"
+    return "rotated"
+
+
 def config5_env_params(n_envs: int, seed: int = 5):
     """BASELINE config 5 domain randomisation: object mass ~ U[0.05, 0.15] kg and finger-object
     friction ~ U[0.5, 1.0] per env, Generator(PCG64(seed)); returns (mass [N], mu [N]) float64."""

@@ -180,3 +180,19 @@ def test_replay_bundle_format_reads_reference_files_and_round_trips(tmp_path):
     eps3, _ = load_reference_bundle(tmp_path / "c")
     for a, b in zip(eps, eps3):
         np.testing.assert_array_equal(a["state"], b["state"])
+
+
+def test_object_schedule_and_orientation_selection_match_reference():
+    """scenarios.latin_square_object_keys / select_orientation against the reference's Generate_Latin_Square and
+    select_orienation (tests/golden/schedule.npz, tools/gen_golden_schedule.py)."""
+    from kinovagrasping_amd import scenarios
+    g = np.load(Path(__file__).resolve().parent / "golden" / "schedule.npz")
+    for tag in "abcd":
+        keys, n = [str(k) for k in g[f"ls_{tag}_keys"]], int(g[f"ls_{tag}_n"])
+        want = [str(k) for k in g[f"ls_{tag}_out"]]
+        assert scenarios.latin_square_object_keys(keys, n) == want, tag
+        assert scenarios.episode_objects(keys, n) == want[::-1]
+    rng = np.random.RandomState(123)          # the generator seeded np.random with 123
+    got = [scenarios.select_orientation(str(s), str(h), rng) for s, h in zip(g["or_shapes"], g["or_modes"])]
+    assert got == [str(o) for o in g["or_out"]]
+    assert set(got[:120]) == {"normal", "rotated", "top"} and set(got[120:]) == {"normal"}
