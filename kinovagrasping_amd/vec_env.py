@@ -58,11 +58,11 @@ class KinovaGripperVecEnv:
 
     # -- reset ------------------------------------------------------------------------------------
     def select_orienation(self, hand_orientation: str):
-        """ENV:1180-1222 for ordinary shapes: 'random' draws uniformly, thresholds 0.333 / 0.667."""
-        if hand_orientation != "random":
-            return hand_orientation if hand_orientation in scenarios.ORIENTATION_EULER else "normal"
-        t = self.np_random.rand()
-        return "normal" if t < 0.333 else ("top" if t > 0.667 else "rotated")
+        """ENV:1180-1222 (scenarios.select_orientation, pinned by tests/golden/schedule.npz); a fixed class name
+        ('normal' / 'rotated' / 'top') is taken as is."""
+        if hand_orientation in scenarios.ORIENTATION_EULER:
+            return hand_orientation
+        return scenarios.select_orientation(self.random_shape, hand_orientation, self.np_random)
 
     def reset(self, shape_keys=None, hand_orientation="normal", with_grasp=False, env_name="env", mode="train", start_pos=None,
               obj_params=None, qpos=None, obj_coord_region=None, with_noise=False, env_ids=None):
