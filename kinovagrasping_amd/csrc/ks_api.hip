@@ -138,8 +138,12 @@ template <typename T, typename S, int SUBS_> __device__ __forceinline__ void loa
 }
 
 constexpr int SUBS = 16;         // lanes per env (a DPP row)
-constexpr int WG = 256;          // stepping workgroup: four waves, one per SIMD of the CU, sharing the hull tables in LDS
-constexpr int EPW_MAX = WG / SUBS;
+#ifndef KS_LANE_STRIDE
+#define KS_LANE_STRIDE 16
+#endif
+constexpr int LANE_STRIDE = KS_LANE_STRIDE;   // lanes reserved per env (16 = teams packed; 32 = every second DPP row idle: 2 envs per wave)
+constexpr int WG = 16 * LANE_STRIDE;          // stepping workgroup: 16 envs sharing the hull tables in LDS
+constexpr int EPW_MAX = WG / LANE_STRIDE;
 
 template <typename T, bool USE_LDS>
 __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ action, int N,
@@ -163,10 +167,10 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
     const Hulls<T>& hu = *hup;
     // epw envs per workgroup, SUBS lanes per env: the lanes of a team keep identical copies of the env state and
     // split the vertex scans / per-pair (collision) and per-contact (solver) loops; per-env dynamic data is shared in LDS
-    const int e = threadIdx.x / SUBS;
-    const Team<SUBS> team{(int)threadIdx.x % SUBS};
+    const int e = threadIdx.x / LANE_STRIDE;
+    const Team<SUBS> team{(int)threadIdx.x % LANE_STRIDE};
     const int env = blockIdx.x * epw + e;
-    if (e >= epw || env >= N) return;
+    if (team.sub >= SUBS || e >= epw || env >= N) return;
     T hq[4], act[4];
     KS_UNROLL
     for (int i = 0; i < 4; i++) { hq[i] = b.hand_quat[(long)i * N + env]; act[i] = action[(long)i * N + env]; }
@@ -243,10 +247,10 @@ __global__ __launch_bounds__(WG) void k_substep(const Model<T>* __restrict__ mp,
         hup = slot;
     }
     const Hulls<T>& hu = *hup;
-    const int e = threadIdx.x / SUBS;
-    const Team<SUBS> team{(int)threadIdx.x % SUBS};
+    const int e = threadIdx.x / LANE_STRIDE;
+    const Team<SUBS> team{(int)threadIdx.x % LANE_STRIDE};
     const int env = blockIdx.x * epw + e;
-    if (e >= epw || env >= N) return;
+    if (team.sub >= SUBS || e >= epw || env >= N) return;
     LaneState<T> st;
     load_state(b, env, N, st);
     T hq[4], c[NU], R7[9];
