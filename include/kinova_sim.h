@@ -63,7 +63,8 @@ typedef struct {
     int32_t precision;          /* 32 or 64 */
     int32_t auto_reset;         /* 1: envs that finish are reset to their stored initial state inside ks_step */
     int32_t obs_env_major;      /* 0: obs[k*N+env], 1: obs[env*82+k] */
-    int32_t envs_per_wave;      /* 0 = automatic (16: four lanes per env); else 1..16 */
+    int32_t envs_per_wave;      /* envs per stepping workgroup (256 threads = 16 lanes per env): 0 = automatic (16,
+                                   or fewer when the model's hull tables leave less LDS); else 1..16 */
     int32_t contact_tap;        /* 1: keep the per-contact records of the last substep for ks_get_state (parity) */
     int32_t reserved[3];
 } ks_config;
@@ -92,7 +93,7 @@ int ks_reset(ks_ctx *ctx, const int32_t *env_ids, int32_t n, const void *qpos0, 
 int ks_step(ks_ctx *ctx, const void *action, void *obs, void *reward, uint8_t *done, void *info, void *final_obs, void *stream);
 
 /* Parity taps; any pointer may be NULL.  contact: [KS_NCON_MAX*KS_CONTACT_STRIDE, N] records of the
- * last substep (pos3 normal3 dist mu bodies R aref4 force3(normal,t1,t2) Jp3; needs cfg.contact_tap), ncon: int32 [N],
+ * last substep (pos3 normal3 dist mu bodies R aref4 force3(normal,t1,t2) active-row-mask D spare; needs cfg.contact_tap), ncon: int32 [N],
  * status: int32 [N] sticky bit flags (1 contact overflow, 2 non-finite state). */
 int ks_get_state(ks_ctx *ctx, void *qpos, void *qvel, void *qacc_warmstart, void *contact, int32_t *ncon, int32_t *status, void *stream);
 int ks_set_state(ks_ctx *ctx, const void *qpos, const void *qvel, const void *qacc_warmstart, void *stream);
