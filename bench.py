@@ -159,14 +159,19 @@ def main():
                     eng.step(after_act=lambda: acted.record(main), after_launch=learner_update, before_store=lambda: main.wait_stream(side))
                 steps_done += 1
 
-    for t in range(args.warmup):
+    # ddpg mode: the learner only has data once every env has finished an episode (30 steps) - if the requested warm-up is
+    # shorter, prime the replay first so that EVERY timed step carries a learner update (nothing skipped in the timed region)
+    priming = max(0, 36 - args.warmup) if args.mode == "ddpg" else 0
+    for t in range(priming):
         step_fn(t)
+    for t in range(args.warmup):
+        step_fn(priming + t)
     barrier()
     sim.kernel_time(reset=True)
     upd0 = updates
     t0 = time.perf_counter()
     for t in range(args.steps):
-        step_fn(args.warmup + t)
+        step_fn(priming + args.warmup + t)
     barrier()
     dt = time.perf_counter() - t0
     kern_ms, launches = sim.kernel_time()
@@ -196,7 +201,7 @@ def main():
                                    (f"{n} envs/GPU CubeS normal-pose grasp sim, PCG64(1000+i) random-action rollout (BASELINE config 2 at the "
                                     "metric's env count); sim kernels only"),
                        "mode": args.mode, "envs_per_gpu": n, "frame_skip": 15, "solver": "newton x6", "hidden": list(args.hidden),
-                       "learner_updates_timed": updates - upd0 if args.mode == "ddpg" else 0,
+                       "learner_updates_timed": updates - upd0 if args.mode == "ddpg" else 0, "priming_steps": priming,
                        "launch": ("eager" if args.eager else "hip-graphs") if args.mode == "ddpg" else "direct",
                        "parallelism": f"env-shard x{world}" + (" + grad all-reduce" if world > 1 and args.mode == "ddpg" else "")},
             "roofline": {"bound": "hbm", "kernel": "k_env_step", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
