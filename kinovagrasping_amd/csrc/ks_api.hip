@@ -194,7 +194,7 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
         // what this lane remembers of its hull pairs' GJK queries, across the substeps of the launch
         GjkWarm gw[(NPAIR_MAX + SUBS - 1) / SUBS];
         KS_UNROLL
-        for (int q = 0; q < (NPAIR_MAX + SUBS - 1) / SUBS; q++) gw[q].n = 0;
+        for (int q = 0; q < (NPAIR_MAX + SUBS - 1) / SUBS; q++) { gw[q].n = 0; gw[q].mn = 0; }
         lane_env_step(m, hu, *(LaneState<T>*)stp, hq, act, scr, team, snap, frame_skip, iters, ncon, status, prof, stp + NQ + 2 * NV, gw);
 #ifdef KS_STAMP
         // diagnostic build only: per-phase cycle sums of this lane go to the contact tap buffer

@@ -550,7 +550,10 @@ KS_HD void load_dynamics_row(S scr, int i, T (&Mrow)[NV], T& qs) {
 }
 
 // ---------------------------------------------------------------- S4 collision
-template <typename T> struct Supp { T v[3], v1[3], v2[3]; };
+template <typename T> struct Supp {
+    T v[3], v1[3], v2[3];
+    int i1, i2;                // hull vertex ids of v1 / v2 (support points only)
+};
 
 template <typename T> struct PairGeo {
     T R1[9], p1[3], R2[9], p2[3];
@@ -635,6 +638,7 @@ template <typename T> KS_HD void mpr_support(PairGeo<T>& g, const T* dir, Supp<T
 #endif
     hull_support(g.R1, g.p1, g.V1, g.off1, g.adj1, g.dir1, g.hint1, dir, g.half_margin, o.v1);
     hull_support(g.R2, g.p2, g.V2, g.off2, g.adj2, g.dir2, g.hint2, nd, g.half_margin, o.v2);
+    o.i1 = g.hint1; o.i2 = g.hint2;
 #ifdef KS_STAMP_HULL
     g.cnt_support += 2; g.cnt_steps += (h1_ != g.hint1) + (h2_ != g.hint2);
 #endif
@@ -664,6 +668,7 @@ KS_HD bool portal_reach_tol(const Supp<T>& v1, const Supp<T>& v2, const Supp<T>&
 template <typename T> KS_HD void assign(Supp<T>& d, const Supp<T>& s) {
     KS_UNROLL
     for (int i = 0; i < 3; i++) { d.v[i] = s.v[i]; d.v1[i] = s.v1[i]; d.v2[i] = s.v2[i]; }
+    d.i1 = s.i1; d.i2 = s.i2;
 }
 
 template <typename T>
@@ -738,14 +743,54 @@ KS_HD void find_pos(const Supp<T>& v0, const Supp<T>& v1, const Supp<T>& v2, con
 
 // Minkowski Portal Refinement penetration query (same decision structure as the oracle's
 // mpr_penetration / libccd's ccdMPRPenetration).  Returns true on overlap.
+// What a lane remembers of a hull pair's last narrow-phase queries (lane-private: the pair -> lane dealing is fixed;
+// lives in the stepping kernel's frame across the substeps of a launch).
+//   GJK: the vertex ids of the final simplex (<= 3 points).  The next substep starts GJK from that simplex - the poses
+//        have barely moved, so it is usually still the closest feature and the query ends after one confirming support
+//        instead of ~10 iterations.
+//   MPR: the vertex ids of the final portal.  While the origin ray still passes through it, the next query skips the
+//        portal discovery and refines from there (a few supports instead of ~22).
+struct GjkWarm {
+    int n;
+    int ia[3], ib[3];
+    int mn;                    // 3: MPR portal ids valid
+    int ma[3], mb[3];
+};
+
+template <typename T> KS_HD void hull_point(const T* R, const T* p, KS_LDS const T* V, int i, T* out) {
+    const T v[3] = {V[4 * i], V[4 * i + 1], V[4 * i + 2]};
+    mulRv(out, R, v);
+    add3(out, out, p);
+}
+
 template <typename T>
-KS_FN bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir, T* pos) {
+KS_FN bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir, T* pos, GjkWarm* ws = nullptr) {
     Supp<T> v0, v1, v2, v3, v4;
     T d[3], va[3], vb[3];
     copy3(v0.v1, g.p1);
     copy3(v0.v2, g.p2);
     sub3(v0.v, v0.v1, v0.v2);
     if (vec_is_zero(v0.v)) v0.v[0] += T(1e-5);
+    v0.i1 = 0; v0.i2 = 0;
+    bool have_portal = false;
+    if (ws != nullptr && ws->mn == 3) {
+        // the previous query's portal at the current poses: still a portal if the origin ray (from v0 through the
+        // origin) passes through the triangle, i.e. the origin is on the inner side of the three planes (v0, vi, vj)
+        Supp<T>* vs[3] = {&v1, &v2, &v3};
+        KS_UNROLL
+        for (int k = 0; k < 3; k++) {
+            vs[k]->i1 = ws->ma[k]; vs[k]->i2 = ws->mb[k];
+            hull_point(g.R1, g.p1, g.V1, ws->ma[k], vs[k]->v1);
+            hull_point(g.R2, g.p2, g.V2, ws->mb[k], vs[k]->v2);
+            sub3(vs[k]->v, vs[k]->v1, vs[k]->v2);
+        }
+        T c13[3], c32[3], c21[3], e1[3], e2[3], nn[3];
+        cross3(c13, v1.v, v3.v); cross3(c32, v3.v, v2.v); cross3(c21, v2.v, v1.v);
+        sub3(e1, v2.v, v1.v); sub3(e2, v3.v, v1.v); cross3(nn, e1, e2);
+        have_portal = dot3(c13, v0.v) >= 0 && dot3(c32, v0.v) >= 0 && dot3(c21, v0.v) >= 0 && dot3(nn, nn) > T(1e-24);
+        ws->mn = 0;
+    }
+    if (!have_portal) {
     scl3(d, v0.v, T(-1));
     normalize3(d);
     mpr_support(g, d, v1);
@@ -794,6 +839,8 @@ KS_FN bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir,
         cross3(d, va, vb);
         normalize3(d);
     }
+    }   // portal discovery
+    T dt;
     for (int it = 0;; it++) {
         if (it > 100) return false;
         portal_dir(v1, v2, v3, d);
@@ -815,6 +862,10 @@ KS_FN bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir,
             copy3(dir, wit);
             normalize3(dir);
             find_pos(v0, v1, v2, v3, pos);
+            if (ws != nullptr) {
+                ws->mn = 3;
+                ws->ma[0] = v1.i1; ws->mb[0] = v1.i2; ws->ma[1] = v2.i1; ws->mb[1] = v2.i2; ws->ma[2] = v3.i1; ws->mb[2] = v3.i2;
+            }
             return true;
         }
         expand_portal(v0, v1, v2, v3, v4);
@@ -829,15 +880,6 @@ template <typename T> struct Simplex {
     T y[4][3], a[4][3], b[4][3];
     int ia[4], ib[4];          // hull vertex ids of a / b
     int n;
-};
-
-// What a lane remembers of a hull pair's last GJK query: the vertex ids of the final simplex (<= 3 points).  The next
-// substep starts GJK from that simplex - the poses have barely moved, so it is usually still the closest feature and
-// the query ends after one confirming support instead of ~10 iterations.  Lane-private (the pair -> lane dealing is
-// fixed), lives in the stepping kernel's frame across the substeps of a launch.
-struct GjkWarm {
-    int n;
-    int ia[3], ib[3];
 };
 
 template <typename T> KS_HD void gjk_support(PairGeo<T>& g, const T* dir, T* y, T* a, T* b) {
@@ -948,12 +990,6 @@ template <typename T> KS_HD bool gjk_closest(Simplex<T>& S, T* lam, T* v) {
 }
 
 // 0: separated by >= margin, 1: contact in the margin zone, 2: overlap (fall back to MPR)
-template <typename T> KS_HD void hull_point(const T* R, const T* p, KS_LDS const T* V, int i, T* out) {
-    const T v[3] = {V[4 * i], V[4 * i + 1], V[4 * i + 2]};
-    mulRv(out, R, v);
-    add3(out, out, p);
-}
-
 template <typename T> KS_HD void gjk_remember(GjkWarm* ws, const Simplex<T>& S) {
     if (ws == nullptr) return;
     ws->n = S.n < 3 ? S.n : 3;
@@ -1284,7 +1320,7 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
     h1_out = pg.hint1 & PC_HINT_MAX; h2_out = pg.hint2 & PC_HINT_MAX;
     if (r == 1) { stage_contact(scr, slot, body1, body2, mu, dist, pos, dir); return 1; }
     if (r == 2) {
-        const bool hit = mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, dir, pos);
+        const bool hit = mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, dir, pos, ws);
         h1_out = pg.hint1 & PC_HINT_MAX; h2_out = pg.hint2 & PC_HINT_MAX;
 #ifdef KS_STAMP_HULL
         if (prof) prof[27] += (float)(pg.cnt_support - sup_gjk);
