@@ -1217,19 +1217,28 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     // margin are appended to the candidate list in index order through a team ballot.
     T bd = T(1e30);
     int best = nv, total = 0;
-    for (int base = 0; base < nv; base += SUBS) {
-        const int i = base + team.sub;
-        const bool in = i < nv;
-        const int ii = in ? i : 0;
-        const T d = cdist + V[4 * ii] * ln[0] + V[4 * ii + 1] * ln[1] + V[4 * ii + 2] * ln[2];
-        if (in && d < bd) { bd = d; best = i; }
-        const bool cand = in && d <= margin;
-        const unsigned votes = team.ballot(cand);
-        if (cand) {
-            const int pos = total + kpopc(votes & ((1u << team.sub) - 1u));
-            if (pos < CAND_MAX) scr(SCR_CAND + pos) = T(i);
+    for (int base0 = 0; base0 < nv; base0 += 4 * SUBS) {
+        // four rounds at a time: the four vertex reads are issued together (one LDS latency), the ballots follow in order
+        T dd[4];
+        KS_UNROLL
+        for (int u = 0; u < 4; u++) {
+            const int i = base0 + u * SUBS + team.sub, ii = i < nv ? i : 0;
+            dd[u] = cdist + V[4 * ii] * ln[0] + V[4 * ii + 1] * ln[1] + V[4 * ii + 2] * ln[2];
         }
-        total += kpopc(votes);
+        KS_UNROLL
+        for (int u = 0; u < 4; u++) {
+            const int i = base0 + u * SUBS + team.sub;
+            const bool in = i < nv;
+            const T d = dd[u];
+            if (in && d < bd) { bd = d; best = i; }
+            const bool cand = in && d <= margin;
+            const unsigned votes = team.ballot(cand);
+            if (cand) {
+                const int pos = total + kpopc(votes & ((1u << team.sub) - 1u));
+                if (pos < CAND_MAX) scr(SCR_CAND + pos) = T(i);
+            }
+            total += kpopc(votes);
+        }
     }
     KS_TICK(12)
     team.argmin(bd, best);
