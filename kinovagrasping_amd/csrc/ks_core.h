@@ -39,10 +39,6 @@ constexpr int CON_STRIDE = 20;
 constexpr int NSTAGE = 80, STAGE_REC = 9, STAGE_WORDS = 720;   // 80 x 9 = 720 = 15 cached bases
 constexpr int SCR_PC = SCR_CON + NCON_MAX * CON_STRIDE;
 constexpr int SCR_STAGE = SCR_PC + NPAIR_MAX;
-// plane-hull contact selection: indices of the vertices within the margin, ascending (one list per env).  The
-// list lives in the contact slots, which are only written by the merge that follows the detection.
-constexpr int CAND_MAX = 96;
-constexpr int SCR_CAND = SCR_CON;
 // smooth dynamics of the substep, written by the role lanes (fingers, object, slides) and read by row:
 // hand mass matrix 9x9, object mass matrix 6x6, qfrc_smooth (slide entries without the finger links' bias),
 // per-finger bias on the three slides
@@ -57,8 +53,7 @@ constexpr int SCR_GP = ((SCR_SB + 9 + 3) / 4) * 4;   // world poses of geoms 1..
 // hand rotation 9, controls 9
 constexpr int SCR_STATE = SCR_GP + (NGEOM - 1) * 12;
 constexpr int SCR_TOTAL = SCR_STATE + 64;
-static_assert(CAND_MAX <= NCON_MAX * CON_STRIDE, "candidate list fits in the contact slots");
-// The staging + candidate regions are dead once the contacts are merged: the solver reuses them as a cache of
+// The staging region is dead once the contacts are merged: the solver reuses them as a cache of
 // the contact basis Jacobians (45 values per contact) so that they are built once per substep, not 2x per
 // Newton iteration; contacts that do not fit are rebuilt on the fly.
 constexpr int SCR_BCACHE = SCR_STAGE;
@@ -1158,25 +1153,6 @@ KS_HD void stage_contact(S scr, int slot, int b1, int b2, T mu, T dist, const T*
     scr(o + 8) = T(b1 + 16 * b2);
 }
 
-// greedy plane-hull selection rule of the oracle applied to vertex v (cv/nc: accepted so far)
-template <typename T> KS_HD void plane_pick(const T* v, T thr2, T cv[4][3], int& nc) {
-    bool ok = nc < 4;
-    KS_UNROLL
-    for (int k = 0; k < 4; k++) {
-        if (k < nc) {
-            T dv[3];
-            sub3(dv, v, cv[k]);
-            if (dot3(dv, dv) <= thr2) ok = false;
-        }
-    }
-    if (ok) {
-        KS_UNROLL
-        for (int k = 0; k < 4; k++)
-            if (k == nc) { cv[k][0] = v[0]; cv[k][1] = v[1]; cv[k][2] = v[2]; }
-        nc++;
-    }
-}
-
 // The two culls of a plane pair (bounding sphere, exact box-vs-plane): false = no vertex can be within the margin
 template <typename T, typename S>
 KS_HD bool plane_may_touch(S scr, KS_LDS const PairRec<T>* prp) {
@@ -1190,9 +1166,9 @@ KS_HD bool plane_may_touch(S scr, KS_LDS const PairRec<T>* prp) {
 }
 
 // Ground plane z = 0 (normal +z) vs the hull of geom g2, worked on by the WHOLE team: deepest vertex, then up
-// to 3 more within the margin that are > 0.3*rbound from every accepted vertex (index order).  Every lane
-// scans a contiguous slice of the vertex table; the team then agrees on the deepest vertex and on the
-// ascending list of vertices within the margin, and every lane runs the (short) greedy rule on that list.
+// to 3 more within the margin that are > 0.3*rbound from every accepted vertex (index order).  The lanes
+// scan the vertex table SUBS rows at a time; the team then agrees on the deepest vertex and on the
+// vertices the oracle's greedy index-order rule accepts (see pass 2 below).
 // Returns the number of contacts staged at record `slot`.
 template <typename T, typename S, int SUBS>
 KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* prp, float* prof = nullptr) {
@@ -1212,13 +1188,11 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     // exact cull: lowest point of the geom's bounding box (half extents geom_size about the geom origin) is
     // above the margin -> every hull vertex is too
     if (cdist - (kabs(ln[0]) * size[0] + kabs(ln[1]) * size[1] + kabs(ln[2]) * size[2]) > margin) return 0;
-    // One pass, SUBS consecutive vertices per round (lane k takes vertex base + k: adjacent lanes read adjacent
-    // 16-byte rows, no LDS bank conflicts).  Every lane tracks the deepest vertex it saw; the vertices within the
-    // margin are appended to the candidate list in index order through a team ballot.
+    // Pass 1, SUBS consecutive vertices per round (lane k takes vertex base + k: adjacent lanes read adjacent
+    // 16-byte rows, no LDS bank conflicts), four rounds of reads in flight: the deepest vertex.
     T bd = T(1e30);
-    int best = nv, total = 0;
+    int best = nv;
     for (int base0 = 0; base0 < nv; base0 += 4 * SUBS) {
-        // four rounds at a time: the four vertex reads are issued together (one LDS latency), the ballots follow in order
         T dd[4];
         KS_UNROLL
         for (int u = 0; u < 4; u++) {
@@ -1228,16 +1202,7 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
         KS_UNROLL
         for (int u = 0; u < 4; u++) {
             const int i = base0 + u * SUBS + team.sub;
-            const bool in = i < nv;
-            const T d = dd[u];
-            if (in && d < bd) { bd = d; best = i; }
-            const bool cand = in && d <= margin;
-            const unsigned votes = team.ballot(cand);
-            if (cand) {
-                const int pos = total + kpopc(votes & ((1u << team.sub) - 1u));
-                if (pos < CAND_MAX) scr(SCR_CAND + pos) = T(i);
-            }
-            total += kpopc(votes);
+            if (i < nv && dd[u] < bd) { bd = dd[u]; best = i; }
         }
     }
     KS_TICK(12)
@@ -1249,21 +1214,41 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     cv[0][0] = V[4 * best]; cv[0][1] = V[4 * best + 1]; cv[0][2] = V[4 * best + 2];
     T thr2 = PLANE_MESH_TOL * rbound;
     thr2 *= thr2;
-    if (total <= CAND_MAX) {
-        team.sync();
-        KS_TICK(7)
-        for (int a = 0; a < total && nc < 4; a++) {
-            const int i = (int)scr(SCR_CAND + a);
-            const T v[3] = {V[4 * i], V[4 * i + 1], V[4 * i + 2]};
-            plane_pick(v, thr2, cv, nc);
+    // Pass 2: the oracle's greedy rule is ONE walk over the vertex indices that accepts a vertex when it is within
+    // the margin and far from everything accepted before it, so the k-th accepted vertex is the first acceptable
+    // index after the (k-1)-th.  The team looks for it SUBS indices at a time (a ballot per round, lowest lane =
+    // lowest index) and resumes behind it: at most nv/SUBS + 3 rounds in total, however many vertices lie within
+    // the margin (a palm lying flat on the ground has hundreds).
+    int start = 0;
+    while (nc < 4 && start < nv) {
+        int found = -1;
+        for (int base = start; base < nv; base += 2 * SUBS) {
+            T v[2][3];
+            bool ok[2];
+            KS_UNROLL
+            for (int u = 0; u < 2; u++) {
+                const int i = base + u * SUBS + team.sub, ii = i < nv ? i : 0;
+                v[u][0] = V[4 * ii]; v[u][1] = V[4 * ii + 1]; v[u][2] = V[4 * ii + 2];
+                ok[u] = i < nv && cdist + v[u][0] * ln[0] + v[u][1] * ln[1] + v[u][2] * ln[2] <= margin;
+                KS_UNROLL
+                for (int k = 0; k < 3; k++) {
+                    if (k < nc) {
+                        T dv[3];
+                        sub3(dv, v[u], cv[k]);
+                        if (dot3(dv, dv) <= thr2) ok[u] = false;
+                    }
+                }
+            }
+            const unsigned v0 = team.ballot(ok[0]), v1 = team.ballot(ok[1]);
+            if (v0) { found = base + kctz(v0); break; }
+            if (v1) { found = base + SUBS + kctz(v1); break; }
         }
-        team.sync();                                  // the list is reused by the next plane pair
-    } else {
-        // a large flat face lies on the ground: every lane runs the one-pass rule over the whole table
-        for (int i = 0; i < nv && nc < 4; i++) {
-            const T v[3] = {V[4 * i], V[4 * i + 1], V[4 * i + 2]};
-            if (cdist + dot3(v, ln) <= margin) plane_pick(v, thr2, cv, nc);
-        }
+        if (found < 0) break;
+        KS_UNROLL
+        for (int k = 1; k < 4; k++)
+            if (k == nc) { cv[k][0] = V[4 * found]; cv[k][1] = V[4 * found + 1]; cv[k][2] = V[4 * found + 2]; }
+        nc++;
+        start = found + 1;
     }
     KS_TICK(23)
     if (team.sub == 0) {
