@@ -92,6 +92,8 @@ def main():
             dist.init_process_group(backend)
     n = args.envs_per_gpu
     dev = torch.device("cuda", local_rank)
+    if os.environ.get("KS_EXP_MAIN_PRIO"):
+        torch.cuda.set_stream(torch.cuda.Stream(dev, priority=int(os.environ["KS_EXP_MAIN_PRIO"])))
     # envs shard by global index: rank r owns envs [r*n, (r+1)*n); no data-path collective in the sim
     q0_all, hq_all = scenarios.config2_states(n * world)
     q0, hq = q0_all[:, rank * n:(rank + 1) * n], hq_all[:, rank * n:(rank + 1) * n]
@@ -172,6 +174,7 @@ def main():
     t0 = time.perf_counter()
     for t in range(args.steps):
         step_fn(priming + args.warmup + t)
+    t_issue = time.perf_counter() - t0                 # host time to issue the timed steps (before the device catches up)
     barrier()
     dt = time.perf_counter() - t0
     kern_ms, launches = sim.kernel_time()
@@ -210,6 +213,7 @@ def main():
                          "avg_launch_ms": round(kern_ms, 4), "launches_timed": launches,
                          "note": "algorithmic 768 B/env-step x envs per launch; the path is latency/VALU bound, not HBM bound (SURVEY 8d)"},
             "nonfinite_envs": bad,
+            "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 4),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)

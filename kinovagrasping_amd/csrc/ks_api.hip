@@ -478,6 +478,13 @@ template <typename T> struct Ctx : CtxBase {
     int load_model(const void* blob, size_t n) override {
         HostModel<T> hm;
         if (!parse_model<T>(blob, n, hm)) { error = "ks_load_model: " + hm.error; return KS_ERR_MODEL; }
+        {
+            // the stepping kernel gives every lane of an env's team at most two hull pairs (ks_core.h, collision)
+            const unsigned planes = plane_pair_mask(hm.m);
+            int nh = 0;
+            for (int pi = 0; pi < hm.m.npair; pi++) nh += ((planes >> pi) & 1u) ? 0 : 1;
+            if (nh > 2 * SUBS) { error = "ks_load_model: more than 32 hull-hull contact pairs"; return KS_ERR_MODEL; }
+        }
         for (int s = 0; s < 4; s++) {
             int r;
             if ((r = alloc(&d_vert[s], hm.vert[s].size()))) return r;

@@ -1274,30 +1274,45 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
 constexpr int PC_COUNT_MASK = 7, PC_HINT_BITS = 10, PC_HINT_MAX = (1 << PC_HINT_BITS) - 1;
 KS_HD int pc_pack(int count, int h1, int h2) { return count + 8 * (h1 + (1 << PC_HINT_BITS) * h2); }
 
+// The two culls of a hull pair (bounding spheres, exact OBB test): false = the hulls are further apart than the margin
+template <typename T, typename S>
+KS_HD bool hull_pair_may_touch(S scr, KS_LDS const PairRec<T>* prp) {
+    KS_LDS const PairRec<T>& pr = *prp;
+    const int g1 = pr.g1, g2 = pr.g2;
+    const T margin = pr.margin, bound = pr.rbound1 + pr.rbound2 + margin;
+    const T size1[3] = {pr.size1[0], pr.size1[1], pr.size1[2]}, size2[3] = {pr.size2[0], pr.size2[1], pr.size2[2]};
+    T R1[9], p1[3], R2[9], p2[3], t[3];
+    geom_pose_cached(scr, g1, R1, p1);
+    geom_pose_cached(scr, g2, R2, p2);
+    sub3(t, p1, p2);
+    if (dot3(t, t) > bound * bound) return false;
+#ifndef KS_NO_OBB
+    if (obb_separated(R1, p1, size1, R2, p2, size2, margin)) return false;
+#endif
+    return true;
+}
+
+// narrow phase of a hull pair that passed hull_pair_may_touch
 template <typename T, typename S>
 KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S scr, KS_LDS const PairRec<T>* prp, int packed_in, int& h1_out,
                             int& h2_out, GjkWarm* ws, float* prof = nullptr) {
     KS_LDS const PairRec<T>& pr = *prp;
     PairGeo<T> pg;
+#ifdef KS_STAMP_HULL
+    const long long th0 = clock64();
+#endif
     h1_out = (packed_in >> 3) & PC_HINT_MAX;
     h2_out = (packed_in >> (3 + PC_HINT_BITS)) & PC_HINT_MAX;
     // the whole record first: one burst of LDS reads, one wait
     const int g1 = pr.g1, g2 = pr.g2, slot = pr.slot, body1 = pr.body1, body2 = pr.body2;
     const int flags = pr.obj_hand;
-    const T margin = pr.margin, mu = (flags & 1) ? T(scr(SCR_ENVP + 1)) : pr.mu, bound = pr.rbound1 + pr.rbound2 + margin;
-    const T size1[3] = {pr.size1[0], pr.size1[1], pr.size1[2]}, size2[3] = {pr.size2[0], pr.size2[1], pr.size2[2]};
+    const T margin = pr.margin, mu = (flags & 1) ? T(scr(SCR_ENVP + 1)) : pr.mu;
     pg.V1 = pr.V1; pg.n1 = pr.n1; pg.off1 = pr.off1; pg.adj1 = pr.adj1;
     pg.V2 = pr.V2; pg.n2 = pr.n2; pg.off2 = pr.off2; pg.adj2 = pr.adj2;
     pg.dir1 = dirtab + SUPPORT_CELLS * ((flags >> 4) & 15);
     pg.dir2 = dirtab + SUPPORT_CELLS * ((flags >> 8) & 15);
     geom_pose_cached(scr, g1, pg.R1, pg.p1);
     geom_pose_cached(scr, g2, pg.R2, pg.p2);
-    T t[3];
-    sub3(t, pg.p1, pg.p2);
-    if (dot3(t, t) > bound * bound) return 0;
-#ifndef KS_NO_OBB
-    if (obb_separated(pg.R1, pg.p1, size1, pg.R2, pg.p2, size2, margin)) return 0;
-#endif
     // hints are only meaningful when they index the pair's own hulls (always, unless a hull has > 1024 vertices)
     pg.hint1 = h1_out < pg.n1 ? h1_out : 0;
     pg.hint2 = h2_out < pg.n2 ? h2_out : 0;
@@ -1306,19 +1321,18 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
     pg.cnt_support = 0; pg.cnt_steps = 0; pg.t_sup = 0; pg.t_clo = 0;
 #endif
     T depth, dist, dir[3], pos[3];
+#ifdef KS_STAMP_HULL
+    const long long th1 = clock64();
+#endif
     const int r = gjk_distance(pg, margin, &dist, dir, pos, ws);
 #ifdef KS_STAMP_HULL
-    if (prof) { prof[24] += 1.f; prof[25] += (float)pg.cnt_support; if (r == 2) prof[26] += 1.f; prof[28] += (float)pg.t_sup; prof[29] += (float)pg.t_clo; }
-    const int sup_gjk = pg.cnt_support;
+    if (prof) { prof[24] += 1.f; prof[25] += (float)pg.cnt_support; prof[26] += (float)(th1 - th0); prof[27] += (float)(clock64() - th1); prof[28] += (float)pg.t_sup; prof[29] += (float)pg.t_clo; }
 #endif
     h1_out = pg.hint1 & PC_HINT_MAX; h2_out = pg.hint2 & PC_HINT_MAX;
     if (r == 1) { stage_contact(scr, slot, body1, body2, mu, dist, pos, dir); return 1; }
     if (r == 2) {
         const bool hit = mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, dir, pos, ws);
         h1_out = pg.hint1 & PC_HINT_MAX; h2_out = pg.hint2 & PC_HINT_MAX;
-#ifdef KS_STAMP_HULL
-        if (prof) prof[27] += (float)(pg.cnt_support - sup_gjk);
-#endif
         if (hit) {
             stage_contact(scr, slot, body1, body2, mu, -depth, pos, dir);
             return 1;
@@ -1364,13 +1378,47 @@ KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> te
         if (team.sub == 0) scr(SCR_PC + pi) = T(c);
     }
     KS_TICK(8)
-    // hull pairs: dealt round-robin to the lanes of the team
-    for (int hk = team.sub; hk < nhull; hk += SUBS) {
-        const int pi = hu.hull_pi[hk];
-        int c = 0, h1 = 0, h2 = 0;
-        if (pairs[pi].slot + 1 <= NSTAGE) c = collide_hull_hull(m, dirtab, scr, pairs + pi, (int)scr(SCR_PC + pi), h1, h2, warm ? warm + hk / SUBS : nullptr, prof);
-        else status |= ST_CONTACT_OVERFLOW;
-        scr(SCR_PC + pi) = T(pc_pack(c, h1, h2));
+    // Hull pairs.  Every lane owns up to two of them (pair `sub`, and - the last lanes - one of the nhull - SUBS pairs
+    // beyond the first SUBS), culls both, and then runs the narrow phase in two passes: pass A takes the lane's first
+    // live pair, pass B the second one of a lane whose pairs are BOTH live.  A narrow phase is a few thousand dependent
+    // instructions and the wave waits for its slowest lane, so what matters is the number of passes that have any
+    // work in them: pass B is empty unless one lane of the wave has two live pairs at once (round-robin dealing ran
+    // two full passes whenever a pair of the second round was live anywhere in the wave).  nhull <= 2 SUBS is checked
+    // when the model is loaded.
+    if constexpr (SUBS == 1) {
+        for (int hk = 0; hk < nhull; hk++) {
+            const int pi = hu.hull_pi[hk], word = (int)scr(SCR_PC + pi);
+            int c = 0, h1 = (word >> 3) & PC_HINT_MAX, h2 = (word >> (3 + PC_HINT_BITS)) & PC_HINT_MAX;
+            if (pairs[pi].slot + 1 > NSTAGE) status |= ST_CONTACT_OVERFLOW;
+            else if (hull_pair_may_touch(scr, pairs + pi)) c = collide_hull_hull(m, dirtab, scr, pairs + pi, word, h1, h2, warm ? warm + hk : nullptr, prof);
+            scr(SCR_PC + pi) = T(pc_pack(c, h1, h2));
+        }
+    } else {
+        const int n2 = nhull > SUBS ? nhull - SUBS : 0;
+        int pi_[2] = {0, 0}, word_[2] = {0, 0};
+        bool live_[2] = {false, false}, have_[2];
+        have_[0] = team.sub < nhull;
+        have_[1] = team.sub >= SUBS - n2;
+        KS_UNROLL
+        for (int r = 0; r < 2; r++) {
+            if (have_[r]) {
+                pi_[r] = hu.hull_pi[r == 0 ? team.sub : team.sub + n2];
+                word_[r] = (int)scr(SCR_PC + pi_[r]);
+                if (pairs[pi_[r]].slot + 1 <= NSTAGE) live_[r] = hull_pair_may_touch(scr, pairs + pi_[r]);
+                else status |= ST_CONTACT_OVERFLOW;
+                if (!live_[r]) scr(SCR_PC + pi_[r]) = T(word_[r] & ~PC_COUNT_MASK);     // no contact, hints kept
+            }
+        }
+        KS_UNROLL
+        for (int pass = 0; pass < 2; pass++) {
+            const bool go = pass == 0 ? (live_[0] || live_[1]) : (live_[0] && live_[1]);
+            if (go) {
+                const int r = (pass == 0 && live_[0]) ? 0 : 1;
+                int h1 = 0, h2 = 0;
+                const int c = collide_hull_hull(m, dirtab, scr, pairs + pi_[r], word_[r], h1, h2, warm ? warm + r : nullptr, prof);
+                scr(SCR_PC + pi_[r]) = T(pc_pack(c, h1, h2));
+            }
+        }
     }
     KS_TICK(9)
     team.sync();

@@ -11,8 +11,38 @@ sim = KinovaSim(n, "CubeS", auto_reset=True, horizon=30, contact_tap=True)
 sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
 closing = torch.tensor([0.0, 0.5, 0.5, 0.5], device="cuda").repeat(n, 1).t().contiguous()
 MODE = sys.argv[1] if len(sys.argv) > 1 else "random"
-for t in range(22 if MODE == "grasp" else 12):
-    sim.step(closing if MODE == "grasp" else acts[t])
+eng = None
+if MODE.startswith("policy"):
+    # the bench's rollout (config 3): untrained actor + exploration noise + scripted lift; "policy:K" reports step K
+    from kinovagrasping_amd.ddpgfd import DDPGfD
+    from kinovagrasping_amd.rollout import RolloutEngine
+    torch.manual_seed(2)
+    policy = DDPGfD(82, 4, 0.8, 5, batch_size=64, hidden=(256, 256), device=torch.device("cuda", 0))
+    sim.close()
+    sim = KinovaSim(n, "CubeS", auto_reset=True, horizon=30, contact_tap=True)
+    obs0 = sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+    LAST = int(MODE.split(":")[1]) if ":" in MODE else 45
+    if MODE.startswith("policy-train"):
+        # ... with the learner of the bench running (the actor changes as it is trained)
+        from kinovagrasping_amd.replay import DeviceEpisodeReplay
+        from kinovagrasping_amd.pipeline import GraphedTrainer
+        policy = DDPGfD(82, 4, 0.8, 5, batch_size=64, hidden=(256, 256), device=torch.device("cuda", 0), capturable=True)
+        replay = DeviceEpisodeReplay(n, capacity=4 * n, horizon=30, device=torch.device("cuda", 0))
+        eng = RolloutEngine(sim, policy, replay, expl_noise=0.1)
+        eng.start(obs0)
+        trainer = GraphedTrainer(sim, policy, replay, eng, batch_episodes=64, overlap=False)
+        trainer.capture()
+        eng.step = trainer.step
+    else:
+        eng = RolloutEngine(sim, policy, None, expl_noise=0.1)
+        eng.start(obs0)
+    MODE = "policy"
+NSTEP = {"grasp": 22, "random": 12}.get(MODE, 0) or LAST + 1
+for t in range(NSTEP):
+    if eng is not None:
+        eng.step()
+    else:
+        sim.step(closing if MODE == "grasp" else acts[t])
     st = sim.get_state(contacts=True)
     torch.cuda.synchronize()
     prof = st["contact"].reshape(-1, n)[:480].cpu().numpy().reshape(16, 30, n)[0]   # lane 0 of every env
@@ -21,7 +51,7 @@ for t in range(22 if MODE == "grasp" else 12):
     s0 = start.min()
     d = (end - start) % (1 << 22)
     st_rel = (start - s0) % (1 << 22)
-    if t >= (10 if MODE != 'grasp' else 8) and (MODE != 'grasp' or t % 3 == 0 or t == 21):
+    if (MODE == "random" and t >= 10) or (MODE == "grasp" and t >= 8 and (t % 3 == 0 or t == 21)) or (MODE == "policy" and (t % 5 == 0 or t == NSTEP - 1)):
         print(f"step {t}: per-env loop duration (100MHz ticks) min {d.min():.0f} mean {d.mean():.0f} max {d.max():.0f};  start spread max {st_rel.max():.0f};  last end {((end - s0) % (1<<22)).max():.0f}")
         cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
         key = xcc * 1000 + se * 100 + sh * 20 + cu
@@ -29,7 +59,7 @@ for t in range(22 if MODE == "grasp" else 12):
         print("  distinct (xcc,se,sh,cu) used by the 256 workgroups:", len(uniq), " max WGs on one CU:", cnt.max())
         late = st_rel[::16] > 0.25 * d.mean()
         print("  workgroups starting late (> 25% of a loop):", int(late.sum()))
-    if t == (11 if MODE != 'grasp' else 21):
+    if t == NSTEP - 1:
         full = st["contact"].reshape(-1, n)[:480].cpu().numpy().reshape(16, 30, n)
         names = {0: "fk+dyn", 1: "collision", 2: "constraints", 3: "chol M", 5: "euler", 8: "c:plane", 9: "c:hull", 10: "c:merge", 14: "(end)", 15: "n:chol", 16: "n:solve", 17: "n:pproj", 18: "n:ls", 21: "#newton", 22: "#ls"}
         order = np.argsort(-d)
@@ -38,4 +68,4 @@ for t in range(22 if MODE == "grasp" else 12):
         for rank in (0, 1, 2, 3, n // 2, n - 1):
             e = order[rank]
             p = full[:, :, e].max(0)
-            print(f"  env {e} (rank {rank}) duration {d[e]:.0f} ticks, ncon(last) {nc[e]}, total cyc {p[6]:.0f}: " + ", ".join(f"{names[k]} {p[k]:.0f}" for k in (0, 1, 8, 9, 10, 2, 3, 5, 21, 22)) + f" | gjk calls {full[:, 24, e].sum():.0f} gjk supports {full[:, 25, e].sum():.0f} mpr calls {full[:, 26, e].sum():.0f} mpr supports {full[:, 27, e].sum():.0f}; per-lane max gjk sup {full[:, 25, e].max():.0f} mpr sup {full[:, 27, e].max():.0f}; busiest lane: support cycles {full[:, 28, e].max():.0f} closest cycles {full[:, 29, e].max():.0f}")
+            print(f"  env {e} (rank {rank}) duration {d[e]:.0f} ticks, ncon(last) {nc[e]}, total cyc {p[6]:.0f}: " + ", ".join(f"{names[k]} {p[k]:.0f}" for k in (0, 1, 8, 9, 10, 2, 3, 5, 21, 22)) + f" | gjk calls {full[:, 24, e].sum():.0f} gjk supports {full[:, 25, e].sum():.0f} busiest lane: pre-GJK cycles {full[:, 26, e].max():.0f} gjk_distance cycles {full[:, 27, e].max():.0f} gjk sup {full[:, 25, e].max():.0f} gjk calls {full[:, 24, e].max():.0f}; support cycles {full[:, 28, e].max():.0f} closest cycles {full[:, 29, e].max():.0f}")
