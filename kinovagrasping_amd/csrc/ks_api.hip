@@ -337,6 +337,7 @@ template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model
     const bool live = env < N && !(masked && !b.flag[env]);
     T best = T(-1);
     __shared__ T pub[WAVE];
+    __shared__ unsigned stk[RAY_STACK * WAVE];
     pub[threadIdx.x] = Lim<T>::big;
     if (live) {
         const Model<T>& m = *mp;
@@ -348,7 +349,8 @@ template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model
             if (best >= 0) pub[threadIdx.x] = best;
         }
         if (m.geom_body[g] != sb)
-            best = ray_nearer(best, ray_geom(m, snap, g, pnt, vec, GroupBound<T>{(KS_LDS T*)pub + (threadIdx.x & ~7), (int)(threadIdx.x & 7)}));
+            best = ray_nearer(best, ray_geom(m, snap, g, pnt, vec, GroupBound<T>{(KS_LDS T*)pub + (threadIdx.x & ~7), (int)(threadIdx.x & 7)},
+                                              LdsStack<T>{(KS_LDS unsigned*)stk + threadIdx.x, WAVE}));
     }
     KS_UNROLL
     for (int mask = 1; mask < 8; mask <<= 1) best = ray_nearer(best, (T)__shfl_xor(best, mask));

@@ -8,6 +8,7 @@ namespace ks {
 
 constexpr int NQ = 16, NV = 15, NU = 9, NBODY = 10, NGEOM = 9, NSITE = 17, NSENSOR = 26, NOBS = 82;
 constexpr int NPAIR_MAX = 32;
+constexpr int RAY_STACK = 16;   // depth bound of the ray-casting hierarchies (ks_obs.h: ray_mesh), checked at load
 constexpr int NCON_MAX = 24;   // contacts kept per env per substep (oracle: KO_NCON_MAX)
 constexpr int NRAY = 17;
 constexpr int SUPPORT_R = 16, SUPPORT_CELLS = 6 * SUPPORT_R * SUPPORT_R;   // cube-map resolution of the support start tables

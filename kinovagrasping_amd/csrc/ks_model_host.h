@@ -198,6 +198,20 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
                 std::vector<float> nb(rb.count);
                 std::memcpy(nb.data(), rb.data, rb.count * 4);
                 const int nn = (int)(rl.count / 2);
+                {
+                    // limits of the traversal (ks_obs.h): 16-bit node ids, at most RAY_STACK pending far children
+                    std::vector<int> depth(nn, 0);
+                    int deepest = nn > 0 ? 1 : 0;
+                    if (nn > 0) depth[0] = 1;
+                    for (int i = 0; i < nn; i++) {       // children follow their parent in the node order
+                        const int a = hm.bvh_lr[s][2 * i], b = hm.bvh_lr[s][2 * i + 1];
+                        if (b < 0) continue;
+                        if (a <= i || b <= i || a >= nn || b >= nn) { hm.error = "ray hierarchy: child ids out of order"; return false; }
+                        depth[a] = depth[b] = depth[i] + 1;
+                        if (depth[a] > deepest) deepest = depth[a];
+                    }
+                    if (nn > 65535 || deepest > RAY_STACK + 1) { hm.error = "ray hierarchy too large (nodes > 65535 or depth > 17)"; return false; }
+                }
                 hm.bvh_box[s].assign((size_t)nn * 16, 0.0f);
                 for (int i = 0; i < nn; i++) {
                     const int a = hm.bvh_lr[s][2 * i], b = hm.bvh_lr[s][2 * i + 1];

@@ -69,6 +69,15 @@ KS_HD int float_bits(float f) {
 #endif
     return i;
 }
+KS_HD float bits_float(int i) {
+    float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    f = __int_as_float(i);
+#else
+    memcpy(&f, &i, 4);
+#endif
+    return f;
+}
 
 // Ray vs mesh geom, MuJoCo's mj_rayMesh semantics: bounding-box pre-test (geom_size about the geom origin),
 // then the faces of the ORIGINAL triangle mesh, both orientations, nearest t >= 0 (-1 = miss).  The faces
@@ -83,15 +92,50 @@ struct OwnBound {
     template <typename T> KS_HD T operator()(T best) const { return best < 0 ? Lim<T>::big : best; }
 };
 
-template <typename T, typename Bound = OwnBound>
-KS_HD T ray_mesh(const float* tri, const float* wnode, const T* size, const T* lp, const T* lv, Bound bound = Bound()) {
+// Traversal stack of ray_mesh: the far child of a node waits here with its entry parameter.  RAY_STACK bounds the depth
+// of the hierarchy (checked when the model is loaded).  LocalStack keeps it in the lane's own registers / stack frame
+// (serial code, host); k_rays keeps it in LDS (LdsStack) so that the kernel needs half the VGPRs and twice the waves
+// fit on a SIMD - the walk is a chain of dependent L2 reads, and occupancy is what hides them.
+template <typename T> struct LocalStack {
+    int node[RAY_STACK];
+    T t[RAY_STACK];
+    int sp = 0;
+    KS_HD void push(int n, T tt) { if (sp < RAY_STACK) { node[sp] = n; t[sp] = tt; sp++; } }
+    KS_HD bool pop(int& n, T& tt) { if (sp == 0) return false; sp--; n = node[sp]; tt = t[sp]; return true; }
+};
+// one 32-bit word per entry, lane-interleaved (entry k of lane l at base[k * stride]): node id in the low 16 bits
+// (< 65536 nodes, checked at load), the entry parameter as the top 16 bits of its float32 pattern minus one unit -
+// always below the true value, so an entry is never pruned that the exact value would keep
+template <typename T> struct LdsStack {
+    KS_LDS unsigned* base;
+    int stride;
+    int sp = 0;
+    KS_HD void push(int n, T tt) {
+        if (sp < RAY_STACK) {
+            unsigned b = (unsigned)float_bits((float)tt);
+            b = b >= 0x10000u ? b - 0x10000u : 0u;
+            base[sp * stride] = (b & 0xffff0000u) | (unsigned)n;
+            sp++;
+        }
+    }
+    KS_HD bool pop(int& n, T& tt) {
+        if (sp == 0) return false;
+        sp--;
+        const unsigned w = base[sp * stride];
+        n = (int)(w & 0xffffu);
+        tt = (T)bits_float((int)(w & 0xffff0000u));
+        return true;
+    }
+};
+
+template <typename T, typename Bound = OwnBound, typename Stack = LocalStack<T>>
+KS_HD T ray_mesh(const float* tri, const float* wnode, const T* size, const T* lp, const T* lv, Bound bound = Bound(), Stack stack = Stack()) {
     {
         T lo[3] = {-size[0], -size[1], -size[2]}, hi[3] = {size[0], size[1], size[2]};
         if (!ray_box(lp, lv, lo, hi, Lim<T>::big)) return T(-1);
     }
     T best = T(-1);
-    int stack[32], sp = 0, node = 0;
-    T stack_t[32];
+    int node = 0;
     for (;;) {
         float w[16];
         KS_UNROLL
@@ -122,7 +166,7 @@ KS_HD T ray_mesh(const float* tri, const float* wnode, const T* size, const T* l
             const T ta = bvh_box_entry(w, lp, lv, tmax), tb = bvh_box_entry(w + 6, lp, lv, tmax);
             if (ta >= 0 && tb >= 0) {
                 const bool a_first = ta <= tb;
-                if (sp < 32) { stack[sp] = a_first ? b : a; stack_t[sp] = a_first ? tb : ta; sp++; }
+                stack.push(a_first ? b : a, a_first ? tb : ta);
                 node = a_first ? a : b;
                 descend = true;
             } else if (ta >= 0 || tb >= 0) {
@@ -133,9 +177,10 @@ KS_HD T ray_mesh(const float* tri, const float* wnode, const T* size, const T* l
         if (descend) continue;
         // next stacked node whose entry is still in front of the nearest hit
         bool found = false;
-        while (sp > 0) {
-            sp--;
-            if (best < 0 || stack_t[sp] <= best) { node = stack[sp]; found = true; break; }
+        int pn;
+        T pt;
+        while (stack.pop(pn, pt)) {
+            if (best < 0 || pt <= best) { node = pn; found = true; break; }
         }
         if (!found) break;
     }
@@ -165,7 +210,8 @@ template <typename T> KS_HD T ray_ground(const Model<T>& m, const T* pnt, const 
     }
     return T(-1);
 }
-template <typename T, typename C, typename Bound = OwnBound> KS_HD T ray_geom(const Model<T>& m, C snap, int g, const T* pnt, const T* vec, Bound bound = Bound()) {
+template <typename T, typename C, typename Bound = OwnBound, typename Stack = LocalStack<T>>
+KS_HD T ray_geom(const Model<T>& m, C snap, int g, const T* pnt, const T* vec, Bound bound = Bound(), Stack stack = Stack()) {
     T R[9], p[3], Rg[9], pg[3], t[3];
     snap_body<T>(snap, m.geom_body[g], R, p);
     mulRR(Rg, R, m.geom_R[g]);
@@ -176,7 +222,7 @@ template <typename T, typename C, typename Bound = OwnBound> KS_HD T ray_geom(co
     mulRtv(lp, Rg, t);
     mulRtv(lv, Rg, vec);
     const int mesh = m.geom_mesh[g];
-    return ray_mesh(m.mesh_tri[mesh], m.mesh_bvh_box[mesh], m.geom_size[g], lp, lv, bound);
+    return ray_mesh(m.mesh_tri[mesh], m.mesh_bvh_box[mesh], m.geom_size[g], lp, lv, bound, stack);
 }
 // nearer of two ray results (-1 = miss)
 template <typename T> KS_HD T ray_nearer(T a, T b) { return (b >= 0 && (a < 0 || b < a)) ? b : a; }
