@@ -574,25 +574,25 @@ constexpr int HULL_CHUNK = 8;
 // improving neighbour is a global maximiser, so this returns what the exhaustive scan of the oracle
 // returns (they can differ only between exactly tied vertices).  Visits O(sqrt(V)) vertices instead of
 // V (the palm hull has 754), and warm-started from the previous query usually only a handful.
+
+// cube-map cell of a (hull-frame) direction: index into the hull's support start table
+template <typename T> KS_HD int support_cell(const T* ld) {
+    const T ax = kabs(ld[0]), ay = kabs(ld[1]), az = kabs(ld[2]);
+    const int axis = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+    const T major = axis == 0 ? ld[0] : (axis == 1 ? ld[1] : ld[2]);
+    const T cu = axis == 0 ? ld[1] : (axis == 1 ? ld[2] : ld[0]), cv = axis == 0 ? ld[2] : (axis == 1 ? ld[0] : ld[1]);
+    const T inv = T(0.5 * SUPPORT_R) / (kabs(major) > T(1e-30) ? kabs(major) : T(1e-30));
+    int iu = (int)(cu * inv + T(0.5 * SUPPORT_R)), iv = (int)(cv * inv + T(0.5 * SUPPORT_R));
+    iu = iu < 0 ? 0 : (iu > SUPPORT_R - 1 ? SUPPORT_R - 1 : iu);
+    iv = iv < 0 ? 0 : (iv > SUPPORT_R - 1 ? SUPPORT_R - 1 : iv);
+    return ((2 * axis + (major < 0 ? 1 : 0)) * SUPPORT_R + iu) * SUPPORT_R + iv;
+}
+
+// the climb: from the better of `hint` (the previous support vertex) and `tab` (the support vertex of the cube-map cell
+// the direction falls in) to the support vertex along the hull-frame direction ld
 template <typename T>
-KS_HD void hull_support(const T* R, const T* p, KS_LDS const T* V, KS_LDS const unsigned short* off, KS_LDS const unsigned short* adj,
-                        const unsigned short* dirtab, int& hint, const T* dir, T hm, T* out) {
-    T ld[3];
-    mulRtv(ld, R, dir);
-    // start from the better of: the previous support vertex, the support vertex of the cube-map cell the direction
-    // falls in (one L1/L2-resident load; the climb from there is a step or two)
-    int tab;
-    {
-        const T ax = kabs(ld[0]), ay = kabs(ld[1]), az = kabs(ld[2]);
-        const int axis = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
-        const T major = axis == 0 ? ld[0] : (axis == 1 ? ld[1] : ld[2]);
-        const T cu = axis == 0 ? ld[1] : (axis == 1 ? ld[2] : ld[0]), cv = axis == 0 ? ld[2] : (axis == 1 ? ld[0] : ld[1]);
-        const T inv = T(0.5 * SUPPORT_R) / (kabs(major) > T(1e-30) ? kabs(major) : T(1e-30));
-        int iu = (int)(cu * inv + T(0.5 * SUPPORT_R)), iv = (int)(cv * inv + T(0.5 * SUPPORT_R));
-        iu = iu < 0 ? 0 : (iu > SUPPORT_R - 1 ? SUPPORT_R - 1 : iu);
-        iv = iv < 0 ? 0 : (iv > SUPPORT_R - 1 ? SUPPORT_R - 1 : iv);
-        tab = dirtab[((2 * axis + (major < 0 ? 1 : 0)) * SUPPORT_R + iu) * SUPPORT_R + iv];
-    }
+KS_HD void hull_climb(const T* R, const T* p, KS_LDS const T* V, KS_LDS const unsigned short* off, KS_LDS const unsigned short* adj, int tab, int& hint,
+                      const T* ld, const T* dir, T hm, T* out) {
     int cur = hint;
     T best = V[4 * cur] * ld[0] + V[4 * cur + 1] * ld[1] + V[4 * cur + 2] * ld[2];
     {
@@ -626,13 +626,24 @@ KS_HD void hull_support(const T* R, const T* p, KS_LDS const T* V, KS_LDS const 
     addscl3(out, dir, hm);
 }
 
+// Support points of BOTH hulls of a pair along dir / -dir.  The two cube-map reads (global memory, L2 resident, ~10x
+// the latency of an LDS round) are issued first, back to back, so that the second one is in flight while the first
+// hull is climbed.
+template <typename T> KS_HD void pair_support(PairGeo<T>& g, const T* dir, T hm, T* out1, T* out2) {
+    const T nd[3] = {-dir[0], -dir[1], -dir[2]};
+    T ld1[3], ld2[3];
+    mulRtv(ld1, g.R1, dir);
+    mulRtv(ld2, g.R2, nd);
+    const int tab1 = g.dir1[support_cell(ld1)], tab2 = g.dir2[support_cell(ld2)];
+    hull_climb(g.R1, g.p1, g.V1, g.off1, g.adj1, tab1, g.hint1, ld1, dir, hm, out1);
+    hull_climb(g.R2, g.p2, g.V2, g.off2, g.adj2, tab2, g.hint2, ld2, nd, hm, out2);
+}
+
 template <typename T> KS_HD void mpr_support(PairGeo<T>& g, const T* dir, Supp<T>& o) {
-    T nd[3] = {-dir[0], -dir[1], -dir[2]};
 #ifdef KS_STAMP_HULL
     const int h1_ = g.hint1, h2_ = g.hint2;
 #endif
-    hull_support(g.R1, g.p1, g.V1, g.off1, g.adj1, g.dir1, g.hint1, dir, g.half_margin, o.v1);
-    hull_support(g.R2, g.p2, g.V2, g.off2, g.adj2, g.dir2, g.hint2, nd, g.half_margin, o.v2);
+    pair_support(g, dir, g.half_margin, o.v1, o.v2);
     o.i1 = g.hint1; o.i2 = g.hint2;
 #ifdef KS_STAMP_HULL
     g.cnt_support += 2; g.cnt_steps += (h1_ != g.hint1) + (h2_ != g.hint2);
@@ -881,9 +892,7 @@ template <typename T> KS_HD void gjk_support(PairGeo<T>& g, const T* dir, T* y, 
 #if defined(KS_STAMP_HULL) && defined(__HIP_DEVICE_COMPILE__)
     const long long ts0 = clock64();
 #endif
-    T nd[3] = {-dir[0], -dir[1], -dir[2]};
-    hull_support(g.R1, g.p1, g.V1, g.off1, g.adj1, g.dir1, g.hint1, dir, T(0), a);
-    hull_support(g.R2, g.p2, g.V2, g.off2, g.adj2, g.dir2, g.hint2, nd, T(0), b);
+    pair_support(g, dir, T(0), a, b);
 #if defined(KS_STAMP_HULL) && defined(__HIP_DEVICE_COMPILE__)
     g.cnt_support += 2;
     g.t_sup += clock64() - ts0;
