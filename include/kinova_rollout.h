@@ -90,6 +90,31 @@ int kr_adam_step(int64_t count, float *param, const float *grad, float *exp_avg,
                  float beta1, float beta2, float eps, float weight_decay, void *stream);
 int kr_soft_update(int64_t count, const float *param, float *target, float tau, const int64_t *it, int32_t freq, void *stream);
 
+/* ---- fused 3-layer MLP forward on the matrix cores (fp32 MFMA): Actor.forward (DDPGfD.py:29-32) and
+ * Critic.forward (DDPGfD.py:47-50) as ONE launch each:
+ *     out[n,out_dim] = f(W3 relu(W2 relu(W1 x + b1) + b2) + b3),   f = identity (KR_ACT_NONE) or scale * sigmoid
+ * x = the first in_a columns from xa ([n, >= in_a], row stride lda) followed by in_b columns from xb (row stride ldb;
+ * in_b = 0: xb unused) - the critic's cat([state, action], 1) without materialising it.  Weights in torch.nn.Linear
+ * layout (W [out][in] row-major, b [out]).  Limits: in_a + in_b <= 96, out_dim <= 4, hidden widths 256-256 (BASELINE),
+ * 400-300 (reference), 128-128, 64-64; any other width returns KS_ERR_INVALID and the caller keeps its GEMM path. */
+#define KR_ACT_NONE 0
+#define KR_ACT_SIGMOID 1
+int kr_mlp3_forward(int32_t n, int32_t in_a, int32_t in_b, int32_t h1, int32_t h2, int32_t out_dim, const float *xa, int32_t lda,
+                    const float *xb, int32_t ldb, const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
+                    const float *b3, int32_t act, float scale, float *out, void *stream);
+
+/* Actor forward + exploration noise + kr_select_action in ONE launch (main_DDPGfD.py:424-451): the epilogue of the
+ * fused MLP applies the selection rule to its own output.  obs .. ready and action .. lifting as in kr_select_action;
+ * W1 .. b3 the actor (82 -> h1 -> h2 -> 4).  Noise: either `noise` [n,4] ~ N(0,1) (then rng_state = NULL), or
+ * noise = NULL and rng_state = int64[2] on the device, zero-initialised by the caller: the kernel draws
+ * Philox4x32-10 / Box-Muller normals keyed by (seed, rng_state[0], env) and advances rng_state[0] by one per launch
+ * (rng_state[1] is its scratch word) - no host-side generator state, so the launch replays from a HIP graph.
+ * actor_out [n,4] (optional, may be NULL) receives pi(obs). */
+int kr_actor_select(int32_t n, int32_t h1, int32_t h2, const float *obs, const float *prev_obs, const uint8_t *has_prev, const int64_t *t,
+                    uint8_t *ready, const float *W1, const float *b1, const float *W2, const float *b2, const float *W3, const float *b3,
+                    const float *noise, uint64_t seed, int64_t *rng_state, float sigma, float max_action, int32_t skip_steps,
+                    float *actor_out, float *action, float *action_t, uint8_t *lifting, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

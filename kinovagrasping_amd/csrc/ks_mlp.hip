@@ -1,0 +1,229 @@
+// ks_mlp.hip -- fused 3-layer MLP forward on the matrix cores (C ABI: include/kinova_rollout.h, kr_mlp3_forward).
+//
+// The reference's actor and critic (DDPGfD.py:17-50) are  out = f(W3 relu(W2 relu(W1 x + b1) + b2) + b3)  with
+// 82 / 86 inputs, two hidden layers (256-256 in BASELINE, 400-300 in the reference) and 4 / 1 outputs.  As three
+// library GEMMs + bias/activation kernels that is 8-11 launches of a few microseconds each, on the critical path of
+// every env-step (the action of step t+1 needs the observation of step t).  Here it is ONE launch:
+//
+//   * a workgroup (4 waves, one per SIMD) owns 16 batch rows and computes all three layers for them; the activations
+//     never leave the CU (LDS), the weights (<= 0.7 MB, L2 resident) stream through the MFMA A operand;
+//   * exact fp32 on v_mfma_f32_16x16x4_f32, in the TRANSPOSED orientation  H^T = W X^T : A = W (16 output features x
+//     4 k), B = X^T (4 k x 16 batch rows), D = 16 features x 16 rows.  A lane of D holds features 4q..4q+3 (q = lane>>4)
+//     of batch row n = lane&15 - exactly the 4 k-values the same lane must supply as the B operand of the next
+//     layer's four MFMAs of a 16-wide k-step.  So a layer's output quad is stored as one float4 at [tile*4 + q][n] and
+//     read back from the same slot: no transposes, no bank conflicts (16 consecutive float4 per quarter wave);
+//   * the four waves split the output tiles of layers 1 and 2 and the k-steps of layer 3 (partial sums through LDS).
+//
+// Arithmetic: every output is a k-ordered fp32 fma chain (MFMA f32 is bitwise an fmaf chain), so results differ
+// from the library GEMMs only by summation order (~1e-7 relative); tests/test_gpu_parity.py checks against torch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/kinova_rollout.h"
+#include "../../include/kinova_sim.h"
+#include "ks_select.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ROWS = 16;        // batch rows per workgroup (the N of the MFMA)
+constexpr int KS_IN_MAX = 6;    // input k-steps: in_dim <= 96
+
+// 4 consecutive weights W[row][k .. k+3] (zero beyond the matrix): one 16-byte load when the row is 16-byte aligned
+template <bool VEC> __device__ __forceinline__ f32x4 load_w4(const float* __restrict__ W, int row, int nrow, int k, int K) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row >= nrow) return v;
+    const float* p = W + (long)row * K + k;
+    if (VEC && k + 3 < K) return *(const f32x4*)p;
+    if (k < K) v.x = p[0];
+    if (k + 1 < K) v.y = p[1];
+    if (k + 2 < K) v.z = p[2];
+    if (k + 3 < K) v.w = p[3];
+    return v;
+}
+
+__device__ __forceinline__ f32x4 mfma4(f32x4 a, f32x4 b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+}
+
+// bias + ReLU on an output quad (features f .. f+3, zero beyond nfeat)
+__device__ __forceinline__ f32x4 bias_relu(f32x4 acc, const float* __restrict__ bias, int f, int nfeat) {
+    f32x4 r;
+    r.x = f < nfeat ? fmaxf(acc.x + bias[f], 0.f) : 0.f;
+    r.y = f + 1 < nfeat ? fmaxf(acc.y + bias[f + 1], 0.f) : 0.f;
+    r.z = f + 2 < nfeat ? fmaxf(acc.z + bias[f + 2], 0.f) : 0.f;
+    r.w = f + 3 < nfeat ? fmaxf(acc.w + bias[f + 3], 0.f) : 0.f;
+    return r;
+}
+
+// Epilogue of the fused actor + action-selection launch (kr_actor_select): everything k_select_action takes, plus the
+// noise source (a tensor of N(0,1) draws, or the in-kernel counter-based generator keyed by (seed, rng_state[0], env))
+struct SelectArgs {
+    const float* obs; const float* prev_obs; const uint8_t* has_prev; const int64_t* t; uint8_t* ready;
+    const float* noise; unsigned long long seed; int64_t* rng_state;
+    float sigma, max_action; int skip_steps;
+    float* action; float* action_t; uint8_t* lifting;
+};
+
+// NT1 / NT2: 16-feature tiles of the two hidden layers.  x is [n][ldx] with the first in_a columns from xa and, when
+// xb != nullptr, the next in_b columns from xb ([n][ldb]) - the critic's cat([state, action]) without materialising it.
+template <int NT1, int NT2, bool VEC, bool SEL>
+__global__ __launch_bounds__(256) void k_mlp3(int n, int in_a, int in_b, int h1, int h2, int out_dim, const float* __restrict__ xa, int lda,
+                                              const float* __restrict__ xb, int ldb, const float* __restrict__ W1, const float* __restrict__ b1,
+                                              const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ W3,
+                                              const float* __restrict__ b3, int act, float scale, float* __restrict__ out, SelectArgs sel) {
+    __shared__ f32x4 H1[NT1 * 4][ROWS];
+    __shared__ f32x4 H2[NT2 * 4][ROWS];
+    __shared__ f32x4 P[4][ROWS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nn = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * ROWS + nn;
+    const bool row_ok = row < n;
+    const int in_dim = in_a + in_b;
+    unsigned long long rng_step = 0;
+    if (SEL && sel.rng_state) rng_step = (unsigned long long)sel.rng_state[0];      // read by every workgroup before any of them finishes
+
+    // layer 1: the wave's copy of the 16 input rows as B operands (k = 16 s + 4 q + j)
+    f32x4 bx[KS_IN_MAX];
+#pragma unroll
+    for (int s = 0; s < KS_IN_MAX; s++) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = 16 * s + 4 * q + j;
+            float x = 0.f;
+            if (row_ok && k < in_a) x = xa[(long)row * lda + k];
+            else if (row_ok && k < in_dim) x = xb[(long)row * ldb + (k - in_a)];
+            v[j] = x;
+        }
+        bx[s] = f32x4{v[0], v[1], v[2], v[3]};
+    }
+    const int ks1 = (in_dim + 15) >> 4;
+    for (int t = wave; t < NT1; t += 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS_IN_MAX; s++)
+            if (s < ks1) acc = mfma4(load_w4<false>(W1, t * 16 + nn, h1, 16 * s + 4 * q, in_dim), bx[s], acc);
+        H1[t * 4 + q][nn] = bias_relu(acc, b1, t * 16 + 4 * q, h1);
+    }
+    __syncthreads();
+
+    // layer 2: K = h1, one k-step per tile of H1
+    for (int t = wave; t < NT2; t += 4) {
+        f32x4 w[NT1];
+#pragma unroll
+        for (int s = 0; s < NT1; s++) w[s] = load_w4<VEC>(W2, t * 16 + nn, h2, 16 * s + 4 * q, h1);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};      // two chains: the MFMA's dependent latency is 40 cycles, its issue 32
+#pragma unroll
+        for (int s = 0; s < NT1; s++) {
+            if (s & 1) acc1 = mfma4(w[s], H1[s * 4 + q][nn], acc1);
+            else acc0 = mfma4(w[s], H1[s * 4 + q][nn], acc0);
+        }
+        H2[t * 4 + q][nn] = bias_relu(acc0 + acc1, b2, t * 16 + 4 * q, h2);
+    }
+    __syncthreads();
+
+    // layer 3: out_dim <= 4 outputs = rows 0..3 of ONE tile (quarter q = 0); the waves split the k-steps
+    {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s = wave; s < NT2; s += 4) acc = mfma4(load_w4<VEC>(W3, nn, out_dim, 16 * s + 4 * q, h2), H2[s * 4 + q][nn], acc);
+        if (q == 0) P[wave][nn] = acc;
+    }
+    __syncthreads();
+    if (wave == 0 && q == 0 && row_ok) {
+        const f32x4 z4 = P[0][nn] + P[1][nn] + P[2][nn] + P[3][nn];
+        const float z[4] = {z4.x, z4.y, z4.z, z4.w};
+        float y[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < out_dim; i++) {
+            y[i] = z[i] + b3[i];
+            if (act == KR_ACT_SIGMOID) y[i] = scale / (1.f + __expf(-y[i]));
+            if (out) out[(long)row * out_dim + i] = y[i];
+        }
+        if (SEL) {
+            float nz[4];
+            if (sel.noise) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) nz[k] = sel.noise[(long)row * 4 + k];
+            } else {
+                krsel::normal4(sel.seed, rng_step, (uint32_t)row, nz);
+            }
+            krsel::select_one(row, n, y, nz, sel.obs, sel.prev_obs, sel.has_prev, sel.t, sel.ready, sel.sigma, sel.max_action, sel.skip_steps,
+                              sel.action, sel.action_t, sel.lifting);
+        }
+    }
+    if (SEL && sel.rng_state) {
+        // the LAST workgroup to finish advances the step counter: every workgroup has read it by then
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const unsigned ticket = atomicAdd((unsigned*)(sel.rng_state + 1), 1u);
+            if (ticket == gridDim.x - 1) {
+                sel.rng_state[1] = 0;
+                sel.rng_state[0] = (int64_t)(rng_step + 1);
+            }
+        }
+    }
+}
+
+template <int NT1, int NT2, bool SEL>
+int launch(int n, int in_a, int in_b, int h1, int h2, int out_dim, const float* xa, int lda, const float* xb, int ldb, const float* W1,
+           const float* b1, const float* W2, const float* b2, const float* W3, const float* b3, int act, float scale, float* out,
+           const SelectArgs& sel, hipStream_t s) {
+    const bool vec = (h1 % 4 == 0) && (h2 % 4 == 0) && ((uintptr_t)W2 % 16 == 0) && ((uintptr_t)W3 % 16 == 0);
+    const dim3 grid((n + ROWS - 1) / ROWS), block(256);
+    if (vec)
+        hipLaunchKernelGGL((k_mlp3<NT1, NT2, true, SEL>), grid, block, 0, s, n, in_a, in_b, h1, h2, out_dim, xa, lda, xb, ldb, W1, b1, W2, b2, W3, b3,
+                           act, scale, out, sel);
+    else
+        hipLaunchKernelGGL((k_mlp3<NT1, NT2, false, SEL>), grid, block, 0, s, n, in_a, in_b, h1, h2, out_dim, xa, lda, xb, ldb, W1, b1, W2, b2, W3, b3,
+                           act, scale, out, sel);
+    return hipGetLastError() == hipSuccess ? KS_OK : KS_ERR_HIP;
+}
+
+
+template <bool SEL>
+int dispatch(int n, int in_a, int in_b, int h1, int h2, int out_dim, const float* xa, int lda, const float* xb, int ldb, const float* W1,
+             const float* b1, const float* W2, const float* b2, const float* W3, const float* b3, int act, float scale, float* out,
+             const SelectArgs& sel, hipStream_t s) {
+    const int nt1 = (h1 + 15) / 16, nt2 = (h2 + 15) / 16;
+#define KR_MLP_CASE(A, B) \
+    if (nt1 == A && nt2 == B) return launch<A, B, SEL>(n, in_a, in_b, h1, h2, out_dim, xa, lda, xb, ldb, W1, b1, W2, b2, W3, b3, act, scale, out, sel, s);
+    KR_MLP_CASE(16, 16)      // 256-256 (BASELINE)
+    KR_MLP_CASE(25, 19)      // 400-300 (reference, DDPGfD.py:19-23)
+    KR_MLP_CASE(8, 8)        // 128-128
+    KR_MLP_CASE(4, 4)        // 64-64 (tests)
+#undef KR_MLP_CASE
+    return KS_ERR_INVALID;   // other widths: the caller keeps its GEMM path
+}
+
+}  // namespace
+
+extern "C" {
+
+int kr_mlp3_forward(int32_t n, int32_t in_a, int32_t in_b, int32_t h1, int32_t h2, int32_t out_dim, const float* xa, int32_t lda,
+                    const float* xb, int32_t ldb, const float* W1, const float* b1, const float* W2, const float* b2,
+                    const float* W3, const float* b3, int32_t act, float scale, float* out, void* stream) {
+    if (n <= 0) return KS_OK;
+    if (!xa || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out || in_a <= 0 || in_b < 0 || (in_b > 0 && !xb)) return KS_ERR_INVALID;
+    if (in_a + in_b > 16 * KS_IN_MAX || out_dim < 1 || out_dim > 4 || h1 < 1 || h2 < 1) return KS_ERR_INVALID;
+    if (act != KR_ACT_NONE && act != KR_ACT_SIGMOID) return KS_ERR_INVALID;
+    return dispatch<false>(n, in_a, in_b, h1, h2, out_dim, xa, lda, xb, ldb, W1, b1, W2, b2, W3, b3, act, scale, out, SelectArgs{}, (hipStream_t)stream);
+}
+
+int kr_actor_select(int32_t n, int32_t h1, int32_t h2, const float* obs, const float* prev_obs, const uint8_t* has_prev, const int64_t* t,
+                    uint8_t* ready, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
+                    const float* noise, uint64_t seed, int64_t* rng_state, float sigma, float max_action, int32_t skip_steps, float* actor_out,
+                    float* action, float* action_t, uint8_t* lifting, void* stream) {
+    if (n <= 0) return KS_OK;
+    if (!obs || !prev_obs || !has_prev || !t || !ready || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !action || !action_t || !lifting) return KS_ERR_INVALID;
+    if ((noise == nullptr) == (rng_state == nullptr) || h1 < 1 || h2 < 1) return KS_ERR_INVALID;     // exactly one noise source
+    SelectArgs sel{obs, prev_obs, has_prev, t, ready, noise, (unsigned long long)seed, rng_state, sigma, max_action, skip_steps, action, action_t, lifting};
+    return dispatch<true>(n, KR_STATE_DIM, 0, h1, h2, KR_ACTION_DIM, obs, KR_STATE_DIM, nullptr, 0, W1, b1, W2, b2, W3, b3, KR_ACT_SIGMOID, max_action,
+                          actor_out, sel, (hipStream_t)stream);
+}
+
+}  // extern "C"

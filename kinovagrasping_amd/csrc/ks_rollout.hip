@@ -9,42 +9,24 @@
 
 #include "../../include/kinova_rollout.h"
 #include "../../include/kinova_sim.h"
+#include "ks_select.h"
 
 namespace {
 
 constexpr int WAVE = 64;
 constexpr int S = KR_STATE_DIM, A = KR_ACTION_DIM;
 
-// scripted lift: wrist_lift_velocity, finger_lift_velocity x3 (main_DDPGfD.py:945-947)
-__device__ __forceinline__ float lift_action(int k) { return k == 0 ? 0.6f : 0.5f; }
-
 __global__ __launch_bounds__(256) void k_select_action(int n, const float* __restrict__ obs, const float* __restrict__ prev_obs,
                                                        const uint8_t* __restrict__ has_prev, const int64_t* __restrict__ t, uint8_t* ready,
                                                        const float* __restrict__ actor_out, const float* __restrict__ noise, float sigma,
                                                        float max_action, int skip_steps, float* __restrict__ action,
                                                        float* __restrict__ action_t, uint8_t* __restrict__ lifting) {
-    // no fma contraction in this kernel: the products are rounded before the sums, bit-identical to the torch expressions
-#pragma clang fp contract(off)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    // check_grasp on obs[9:17]: x of the three distal fingertips (columns 9, 12, 15), per substep (frame_skip 15)
-    const float* o = obs + (long)i * S;
-    const float* p = prev_obs + (long)i * S;
-    float d = fabsf(p[9] - o[9]) / 15.0f;
-    d += fabsf(p[12] - o[12]) / 15.0f;
-    d += fabsf(p[15] - o[15]) / 15.0f;
-    const bool chk = d < 0.0002f && (t[i] + 1 >= skip_steps) && has_prev[i] != 0;
-    const bool rdy = ready[i] != 0 || chk;
-    ready[i] = rdy;
-    lifting[i] = rdy;
+    float pi[A], nz[A];
 #pragma unroll
-    for (int k = 0; k < A; k++) {
-        float a = actor_out[(long)i * A + k] + noise[(long)i * A + k] * sigma;
-        a = fminf(fmaxf(a, 0.0f), max_action);
-        a = rdy ? lift_action(k) : a;
-        action[(long)i * A + k] = a;
-        action_t[(long)k * n + i] = a;
-    }
+    for (int k = 0; k < A; k++) { pi[k] = actor_out[(long)i * A + k]; nz[k] = noise[(long)i * A + k]; }
+    krsel::select_one(i, n, pi, nz, obs, prev_obs, has_prev, t, ready, sigma, max_action, skip_steps, action, action_t, lifting);
 }
 
 // one wave per env

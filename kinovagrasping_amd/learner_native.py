@@ -23,6 +23,7 @@ import ctypes
 
 import torch
 
+from . import mlp as _mlp
 from . import sim as _sim
 
 
@@ -60,6 +61,8 @@ class NativeDDPGfDUpdate:
         ao, co = policy.actor_optimizer.param_groups[0], policy.critic_optimizer.param_groups[0]
         self.hyper_a = (ao["lr"], ao["betas"][0], ao["betas"][1], ao["eps"], ao["weight_decay"])
         self.hyper_c = (co["lr"], co["betas"][0], co["betas"][1], co["eps"], co["weight_decay"])
+        self.fused_targets = (_mlp.supported(list(zip(self.actor_t.W, self.actor_t.b)), self.actor_t.W[0].shape[1])
+                              and _mlp.supported(list(zip(self.critic_t.W, self.critic_t.b)), self.critic_t.W[0].shape[1]))
 
     # -- helpers ------------------------------------------------------------------------------------------------------
     def _st(self):
@@ -114,9 +117,14 @@ class NativeDDPGfDUpdate:
         self.weight, self.wsum = weight, weight.sum().reshape(1)
         # both target evaluations (1-step: next_state[:, 0], n-step: next_state[:, -1]) in one pass of the target nets
         nx = torch.cat([next_state[:, 0], next_state[:, -1]], 0)
-        _, _, ta = self._actor_forward(self.actor_t, nx)
-        ct = self.critic_t
-        tq = torch.addmm(ct.b[2], self._lin_relu(ct, 1, self._lin_relu(ct, 0, torch.cat([nx, ta], 1))), ct.W[2].t())
+        if self.fused_targets:
+            # forward-only networks: one fused fp32-MFMA launch each (mlp.mlp3_forward) instead of 3 GEMMs + glue
+            ta = _mlp.mlp3_forward(list(zip(self.actor_t.W, self.actor_t.b)), nx, act=_mlp.ACT_SIGMOID, scale=pol.max_action)
+            tq = _mlp.mlp3_forward(list(zip(self.critic_t.W, self.critic_t.b)), nx, ta, act=_mlp.ACT_NONE)
+        else:
+            _, _, ta = self._actor_forward(self.actor_t, nx)
+            ct = self.critic_t
+            tq = torch.addmm(ct.b[2], self._lin_relu(ct, 1, self._lin_relu(ct, 0, torch.cat([nx, ta], 1))), ct.W[2].t())
         x0 = torch.cat([state[:, 0], action[:, 0]], 1)
         c = self.critic
         h1 = self._lin_relu(c, 0, x0)

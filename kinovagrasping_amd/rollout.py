@@ -34,7 +34,10 @@ class RolloutEngine:
     selection) and `post()` (replay + bookkeeping) can each be captured in a HIP graph (pipeline.GraphedTrainer);
     `step()` is the plain eager sequence pre -> sim -> post."""
 
-    def __init__(self, sim, policy, replay=None, expl_noise=0.1, max_action=0.8, generator=None):
+    def __init__(self, sim, policy, replay=None, expl_noise=0.1, max_action=0.8, generator=None, device_noise=None):
+        """device_noise: draw the exploration noise inside the fused actor kernel (counter-based Philox keyed by
+        torch.initial_seed(), a device step counter and the env index) instead of with torch.randn.  Default: on when no
+        torch generator is given and the actor is a 3-layer MLP the fused kernel supports."""
         self.sim, self.policy, self.replay = sim, policy, replay
         self.n = sim.n_envs
         dev = sim.device
@@ -61,6 +64,9 @@ class RolloutEngine:
             from . import sim as _sim
             self._lib, self._ptr = _sim.load_library(), _sim._ptr
             self._keep = torch.zeros(self.n, dtype=torch.bool, device=dev)
+        self.device_noise = (generator is None) if device_noise is None else bool(device_noise)
+        self.noise_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        self.rng_state = torch.zeros(2, dtype=torch.long, device=dev)        # [launch counter, scratch] of kr_actor_select
 
     def _stream(self):
         import ctypes
@@ -78,6 +84,19 @@ class RolloutEngine:
     def pre(self):
         """Action selection for every env -> self.action [N,4] / self.action_t [4,N]."""
         if self.native:
+            layers = self._fused_actor_layers()
+            if layers is not None:
+                # actor forward + noise + selection rule: one launch (kr_actor_select, csrc/ks_mlp.hip)
+                (w1, b1), (w2, b2), (w3, b3) = layers
+                P = self._ptr
+                noise = None if self.device_noise else torch.randn(self.n, 4, device=self.obs.device, generator=self.gen)
+                rc = self._lib.kr_actor_select(self.n, w1.shape[0], w2.shape[0], P(self.obs), P(self.prev_obs), P(self.has_prev), P(self.t),
+                                               P(self.ready), P(w1), P(b1), P(w2), P(b2), P(w3), P(b3), P(noise), self.noise_seed,
+                                               P(self.rng_state) if noise is None else None, self.sigma, self.max_action, SKIP_NUM_TS, None,
+                                               P(self.action), P(self.action_t), P(self.lifting), self._stream())
+                if rc != 0:
+                    raise RuntimeError(f"kr_actor_select failed ({rc})")
+                return
             a = self.policy.actor(self.obs).contiguous()
             noise = torch.randn(a.shape, device=a.device, generator=self.gen)
             P = self._ptr
@@ -96,6 +115,17 @@ class RolloutEngine:
         self.action.copy_(torch.where(self.ready.unsqueeze(1), self.lift_action, a))
         self.action_t.copy_(self.action.t())
         self.lifting.copy_(self.ready)
+
+    def _fused_actor_layers(self):
+        """the actor's (weight, bias) x 3 when it is the reference's 3-layer MLP at a width the fused kernel supports
+        (max_action * sigmoid output), else None"""
+        actor = self.policy.actor
+        if not all(hasattr(actor, k) for k in ("l1", "l2", "l3")):
+            return None
+        from . import mlp
+        layers = mlp.layers_of(actor)
+        ok = mlp.supported(layers, self.obs.shape[1]) and layers[2][0].shape[0] == 4 and float(getattr(actor, "max_action", -1.0)) == float(self.max_action)
+        return layers if ok else None
 
     def act(self):
         self.pre()

@@ -573,3 +573,93 @@ def test_vec_env_keeps_the_reference_interface():
     with pytest.raises(NotImplementedError):
         env.set_with_grasp_reward(True)
     env.close()
+
+
+def test_fused_mlp_forward_matches_torch():
+    """kr_mlp3_forward (fp32 MFMA, one launch) against the torch modules it replaces: the actor (82 -> h1 -> h2 -> 4,
+    0.8 * sigmoid) and the critic on cat([state, action]) (86 -> h1 -> h2 -> 1), at the BASELINE widths (256-256), the
+    reference's (400-300) and a small one, for batch sizes that are not multiples of the 16-row tile, with the inputs
+    read through row-strided views.  Same fp32 arithmetic, different summation order: 2e-5 absolute."""
+    from kinovagrasping_amd import mlp
+    from kinovagrasping_amd.ddpgfd import Actor, Critic
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for hidden in ((256, 256), (400, 300), (64, 64)):
+        torch.manual_seed(11)
+        actor, critic = Actor(82, 4, 0.8, hidden).to(dev), Critic(82, 4, hidden).to(dev)
+        for net in (actor, critic):             # biases away from zero, weights large enough to exercise the ReLUs
+            for p in net.parameters():
+                p.data.add_(0.05 * torch.randn(p.shape, generator=g).to(dev))
+        for n in (1, 37, 1000, 4096):
+            wide = torch.randn(n, 100, generator=g).to(dev)
+            s, a = wide[:, :82], (0.8 * torch.rand(n, 4, generator=g)).to(dev)
+            with torch.no_grad():
+                ref_a, ref_q = actor(s), critic(s, a)
+            out_a = mlp.mlp3_forward(mlp.layers_of(actor), s, act=mlp.ACT_SIGMOID, scale=0.8)
+            out_q = mlp.mlp3_forward(mlp.layers_of(critic), s, a, act=mlp.ACT_NONE)
+            assert out_a.shape == ref_a.shape and out_q.shape == ref_q.shape
+            assert (out_a - ref_a).abs().max().item() < 2e-5, (hidden, n, (out_a - ref_a).abs().max().item())
+            assert (out_q - ref_q).abs().max().item() < 2e-5 * max(1.0, ref_q.abs().max().item()), (hidden, n, (out_q - ref_q).abs().max().item())
+    # unsupported widths are refused, not silently mis-computed
+    odd = Actor(82, 4, 0.8, (200, 100)).to(dev)
+    assert not mlp.supported(mlp.layers_of(odd), 82)
+    with pytest.raises(RuntimeError):
+        mlp.mlp3_forward(mlp.layers_of(odd), torch.zeros(4, 82, device=dev), act=mlp.ACT_SIGMOID, scale=0.8)
+
+
+def test_fused_actor_select_equals_separate_kernels():
+    """kr_actor_select (actor forward + noise + selection rule in one launch) against kr_mlp3_forward followed by
+    kr_select_action on the same noise tensor: bit-identical actions and latches.  With its in-kernel generator: the
+    same seed and counter give the same draws, the counter advances by one per launch, and the draws are N(0,1)
+    (mean, variance, 4th moment over 2e5 samples; per-column independence through the correlation matrix)."""
+    import ctypes
+    from kinovagrasping_amd import mlp, sim as ks
+    from kinovagrasping_amd.ddpgfd import Actor
+    dev = torch.device("cuda", 0)
+    lib, P = ks.load_library(), ks._ptr
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    torch.manual_seed(3)
+    n = 5000
+    actor = Actor(82, 4, 0.8, (256, 256)).to(dev)
+    (w1, b1), (w2, b2), (w3, b3) = mlp.layers_of(actor)
+    obs, prev = torch.randn(n, 82, device=dev), torch.randn(n, 82, device=dev)
+    prev[: n // 2, 9:16:3] = obs[: n // 2, 9:16:3]                # fingertips at rest: check_grasp fires
+    has_prev = torch.rand(n, device=dev) < 0.8
+    t = torch.randint(0, 30, (n,), device=dev)
+    noise = torch.randn(n, 4, device=dev)
+
+    def fresh():
+        return (torch.rand(n, device=dev) < 0.1, torch.zeros(n, 4, device=dev), torch.zeros(4, n, device=dev), torch.zeros(n, dtype=torch.bool, device=dev))
+
+    r1, a1, at1, l1 = fresh()
+    r2 = r1.clone(); _, a2, at2, l2 = fresh()
+    pi = mlp.mlp3_forward(mlp.layers_of(actor), obs, act=mlp.ACT_SIGMOID, scale=0.8)
+    assert lib.kr_select_action(n, P(obs), P(prev), P(has_prev), P(t), P(r1), P(pi), P(noise), 0.08, 0.8, 6, P(a1), P(at1), P(l1), st) == 0
+    pi2 = torch.zeros(n, 4, device=dev)
+    assert lib.kr_actor_select(n, 256, 256, P(obs), P(prev), P(has_prev), P(t), P(r2), P(w1), P(b1), P(w2), P(b2), P(w3), P(b3), P(noise), 0, None,
+                               0.08, 0.8, 6, P(pi2), P(a2), P(at2), P(l2), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(pi, pi2) and torch.equal(a1, a2) and torch.equal(at1, at2) and torch.equal(l1, l2) and torch.equal(r1, r2)
+    assert l1.any() and not l1.all()
+    # in-kernel noise: zero the actor so that action = clip(0.4 + sigma * z) and recover z (sigma small enough not to clip)
+    for p in actor.parameters():
+        p.data.zero_()
+    zs = []
+    rng = torch.zeros(2, dtype=torch.long, device=dev)
+    nobody = torch.zeros(n, dtype=torch.bool, device=dev)
+    for rep in range(40):
+        r, a, at, l = nobody.clone(), torch.zeros(n, 4, device=dev), torch.zeros(4, n, device=dev), nobody.clone()
+        assert lib.kr_actor_select(n, 256, 256, P(obs), P(prev), P(nobody), P(t), P(r), P(w1), P(b1), P(w2), P(b2), P(w3), P(b3), None, 1234, P(rng),
+                                   0.01, 0.8, 6, None, P(a), P(at), P(l), st) == 0
+        zs.append((a - 0.4) / 0.01)
+        assert int(rng[0].item()) == rep + 1 and int(rng[1].item()) == 0
+    z = torch.cat(zs, 0).double()
+    assert abs(z.mean().item()) < 0.01 and abs(z.var().item() - 1.0) < 0.02 and abs((z ** 4).mean().item() - 3.0) < 0.1
+    c = torch.corrcoef(z.t())
+    assert (c - torch.eye(4, device=dev, dtype=torch.double)).abs().max().item() < 0.01
+    assert not torch.equal(zs[0], zs[1])                       # a new draw every launch
+    rng2 = torch.zeros(2, dtype=torch.long, device=dev)
+    a_again = torch.zeros(n, 4, device=dev)
+    assert lib.kr_actor_select(n, 256, 256, P(obs), P(prev), P(nobody), P(t), P(nobody.clone()), P(w1), P(b1), P(w2), P(b2), P(w3), P(b3), None, 1234,
+                               P(rng2), 0.01, 0.8, 6, None, P(a_again), P(torch.zeros(4, n, device=dev)), P(nobody.clone()), st) == 0
+    assert torch.equal((a_again - 0.4) / 0.01, zs[0])          # same (seed, counter, env) -> same draw
