@@ -92,8 +92,6 @@ def main():
             dist.init_process_group(backend)
     n = args.envs_per_gpu
     dev = torch.device("cuda", local_rank)
-    if os.environ.get("KS_EXP_MAIN_PRIO"):
-        torch.cuda.set_stream(torch.cuda.Stream(dev, priority=int(os.environ["KS_EXP_MAIN_PRIO"])))
     # envs shard by global index: rank r owns envs [r*n, (r+1)*n); no data-path collective in the sim
     q0_all, hq_all = scenarios.config2_states(n * world)
     q0, hq = q0_all[:, rank * n:(rank + 1) * n], hq_all[:, rank * n:(rank + 1) * n]

@@ -96,12 +96,14 @@ int kr_soft_update(int64_t count, const float *param, float *target, float tau, 
  * x = the first in_a columns from xa ([n, >= in_a], row stride lda) followed by in_b columns from xb (row stride ldb;
  * in_b = 0: xb unused) - the critic's cat([state, action], 1) without materialising it.  Weights in torch.nn.Linear
  * layout (W [out][in] row-major, b [out]).  Limits: in_a + in_b <= 96, out_dim <= 4, hidden widths 256-256 (BASELINE),
- * 400-300 (reference), 128-128, 64-64; any other width returns KS_ERR_INVALID and the caller keeps its GEMM path. */
+ * 400-300 (reference), 128-128, 64-64; any other width returns KS_ERR_INVALID and the caller keeps its GEMM path.
+ * h1_out [n,h1] / h2_out [n,h2] (optional, NULL to skip): the hidden activations (after the ReLU), which the backward
+ * pass of a training step needs; they require h % 4 == 0 and 16-byte aligned buffers. */
 #define KR_ACT_NONE 0
 #define KR_ACT_SIGMOID 1
 int kr_mlp3_forward(int32_t n, int32_t in_a, int32_t in_b, int32_t h1, int32_t h2, int32_t out_dim, const float *xa, int32_t lda,
                     const float *xb, int32_t ldb, const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
-                    const float *b3, int32_t act, float scale, float *out, void *stream);
+                    const float *b3, int32_t act, float scale, float *out, float *h1_out, float *h2_out, void *stream);
 
 /* Actor forward + exploration noise + kr_select_action in ONE launch (main_DDPGfD.py:424-451): the epilogue of the
  * fused MLP applies the selection rule to its own output.  obs .. ready and action .. lifting as in kr_select_action;

@@ -12,7 +12,7 @@
 //     of batch row n = lane&15 - exactly the 4 k-values the same lane must supply as the B operand of the next
 //     layer's four MFMAs of a 16-wide k-step.  So a layer's output quad is stored as one float4 at [tile*4 + q][n] and
 //     read back from the same slot: no transposes, no bank conflicts (16 consecutive float4 per quarter wave);
-//   * the four waves split the output tiles of layers 1 and 2 and the k-steps of layer 3 (partial sums through LDS).
+//   * the waves split the output tiles of layers 1 and 2 and the k-steps of layer 3 (partial sums through LDS).
 //
 // Arithmetic: every output is a k-ordered fp32 fma chain (MFMA f32 is bitwise an fmaf chain), so results differ
 // from the library GEMMs only by summation order (~1e-7 relative); tests/test_gpu_parity.py checks against torch.
@@ -29,6 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROWS = 16;        // batch rows per workgroup (the N of the MFMA)
 constexpr int KS_IN_MAX = 6;    // input k-steps: in_dim <= 96
+constexpr int NW = 4;           // waves per workgroup (one per SIMD)
 
 // 4 consecutive weights W[row][k .. k+3] (zero beyond the matrix): one 16-byte load when the row is 16-byte aligned
 template <bool VEC> __device__ __forceinline__ f32x4 load_w4(const float* __restrict__ W, int row, int nrow, int k, int K) {
@@ -73,13 +74,14 @@ struct SelectArgs {
 // NT1 / NT2: 16-feature tiles of the two hidden layers.  x is [n][ldx] with the first in_a columns from xa and, when
 // xb != nullptr, the next in_b columns from xb ([n][ldb]) - the critic's cat([state, action]) without materialising it.
 template <int NT1, int NT2, bool VEC, bool SEL>
-__global__ __launch_bounds__(256) void k_mlp3(int n, int in_a, int in_b, int h1, int h2, int out_dim, const float* __restrict__ xa, int lda,
+__global__ __launch_bounds__(64 * NW) void k_mlp3(int n, int in_a, int in_b, int h1, int h2, int out_dim, const float* __restrict__ xa, int lda,
                                               const float* __restrict__ xb, int ldb, const float* __restrict__ W1, const float* __restrict__ b1,
                                               const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ W3,
-                                              const float* __restrict__ b3, int act, float scale, float* __restrict__ out, SelectArgs sel) {
+                                              const float* __restrict__ b3, int act, float scale, float* __restrict__ out, float* __restrict__ h1_out,
+                                              float* __restrict__ h2_out, SelectArgs sel) {
     __shared__ f32x4 H1[NT1 * 4][ROWS];
     __shared__ f32x4 H2[NT2 * 4][ROWS];
-    __shared__ f32x4 P[4][ROWS];
+    __shared__ f32x4 P[NW][ROWS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nn = lane & 15, q = lane >> 4;
     const int row = blockIdx.x * ROWS + nn;
     const bool row_ok = row < n;
@@ -102,40 +104,69 @@ __global__ __launch_bounds__(256) void k_mlp3(int n, int in_a, int in_b, int h1,
         }
         bx[s] = f32x4{v[0], v[1], v[2], v[3]};
     }
-    const int ks1 = (in_dim + 15) >> 4;
-    for (int t = wave; t < NT1; t += 4) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // Weights stream from L2 (~1.5 us per dependent read at one wave per SIMD): every tile's weights are requested one
+    // tile ahead of the MFMAs that use them, and the first tile of a layer while the previous layer is still computing.
+    f32x4 w2[NT1];
 #pragma unroll
-        for (int s = 0; s < KS_IN_MAX; s++)
-            if (s < ks1) acc = mfma4(load_w4<false>(W1, t * 16 + nn, h1, 16 * s + 4 * q, in_dim), bx[s], acc);
-        H1[t * 4 + q][nn] = bias_relu(acc, b1, t * 16 + 4 * q, h1);
+    for (int s = 0; s < NT1; s++) w2[s] = load_w4<VEC>(W2, wave * 16 + nn, wave < NT2 ? h2 : 0, 16 * s + 4 * q, h1);
+    {
+        f32x4 w1[KS_IN_MAX];
+#pragma unroll
+        for (int s = 0; s < KS_IN_MAX; s++) w1[s] = load_w4<false>(W1, wave * 16 + nn, wave < NT1 ? h1 : 0, 16 * s + 4 * q, in_dim);
+        for (int t = wave; t < NT1; t += NW) {
+            f32x4 wn[KS_IN_MAX];
+#pragma unroll
+            for (int s = 0; s < KS_IN_MAX; s++) wn[s] = load_w4<false>(W1, (t + NW) * 16 + nn, t + NW < NT1 ? h1 : 0, 16 * s + 4 * q, in_dim);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains: the MFMA's dependent latency is 40 cycles, its issue 32
+#pragma unroll
+            for (int s = 0; s < KS_IN_MAX; s++) {       // k beyond in_dim: both operands are zero
+                if (s & 1) acc1 = mfma4(w1[s], bx[s], acc1);
+                else acc0 = mfma4(w1[s], bx[s], acc0);
+            }
+            const f32x4 hq = bias_relu(acc0 + acc1, b1, t * 16 + 4 * q, h1);
+            H1[t * 4 + q][nn] = hq;
+            if (h1_out && row_ok && t * 16 + 4 * q < h1) *(f32x4*)(h1_out + (long)row * h1 + t * 16 + 4 * q) = hq;   // h1 % 4 == 0 (checked by the host)
+#pragma unroll
+            for (int s = 0; s < KS_IN_MAX; s++) w1[s] = wn[s];
+        }
     }
     __syncthreads();
 
     // layer 2: K = h1, one k-step per tile of H1
-    for (int t = wave; t < NT2; t += 4) {
-        f32x4 w[NT1];
+    f32x4 w3[(NT2 + NW - 1) / NW];
 #pragma unroll
-        for (int s = 0; s < NT1; s++) w[s] = load_w4<VEC>(W2, t * 16 + nn, h2, 16 * s + 4 * q, h1);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};      // two chains: the MFMA's dependent latency is 40 cycles, its issue 32
+    for (int j = 0; j < (NT2 + NW - 1) / NW; j++) w3[j] = load_w4<VEC>(W3, nn, out_dim, 16 * (wave + NW * j) + 4 * q, h2);
+    for (int t = wave; t < NT2; t += NW) {
+        f32x4 wn[NT1];
+#pragma unroll
+        for (int s = 0; s < NT1; s++) wn[s] = load_w4<VEC>(W2, (t + NW) * 16 + nn, t + NW < NT2 ? h2 : 0, 16 * s + 4 * q, h1);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < NT1; s++) {
-            if (s & 1) acc1 = mfma4(w[s], H1[s * 4 + q][nn], acc1);
-            else acc0 = mfma4(w[s], H1[s * 4 + q][nn], acc0);
+            if (s & 1) acc1 = mfma4(w2[s], H1[s * 4 + q][nn], acc1);
+            else acc0 = mfma4(w2[s], H1[s * 4 + q][nn], acc0);
         }
-        H2[t * 4 + q][nn] = bias_relu(acc0 + acc1, b2, t * 16 + 4 * q, h2);
+        const f32x4 hq = bias_relu(acc0 + acc1, b2, t * 16 + 4 * q, h2);
+        H2[t * 4 + q][nn] = hq;
+        if (h2_out && row_ok && t * 16 + 4 * q < h2) *(f32x4*)(h2_out + (long)row * h2 + t * 16 + 4 * q) = hq;
+#pragma unroll
+        for (int s = 0; s < NT1; s++) w2[s] = wn[s];
     }
     __syncthreads();
 
     // layer 3: out_dim <= 4 outputs = rows 0..3 of ONE tile (quarter q = 0); the waves split the k-steps
     {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int s = wave; s < NT2; s += 4) acc = mfma4(load_w4<VEC>(W3, nn, out_dim, 16 * s + 4 * q, h2), H2[s * 4 + q][nn], acc);
+#pragma unroll
+        for (int j = 0; j < (NT2 + NW - 1) / NW; j++)
+            if (wave + NW * j < NT2) acc = mfma4(w3[j], H2[(wave + NW * j) * 4 + q][nn], acc);
         if (q == 0) P[wave][nn] = acc;
     }
     __syncthreads();
     if (wave == 0 && q == 0 && row_ok) {
-        const f32x4 z4 = P[0][nn] + P[1][nn] + P[2][nn] + P[3][nn];
+        f32x4 z4 = P[0][nn];
+#pragma unroll
+        for (int w = 1; w < NW; w++) z4 += P[w][nn];
         const float z[4] = {z4.x, z4.y, z4.z, z4.w};
         float y[4] = {0.f, 0.f, 0.f, 0.f};
         for (int i = 0; i < out_dim; i++) {
@@ -172,15 +203,15 @@ __global__ __launch_bounds__(256) void k_mlp3(int n, int in_a, int in_b, int h1,
 template <int NT1, int NT2, bool SEL>
 int launch(int n, int in_a, int in_b, int h1, int h2, int out_dim, const float* xa, int lda, const float* xb, int ldb, const float* W1,
            const float* b1, const float* W2, const float* b2, const float* W3, const float* b3, int act, float scale, float* out,
-           const SelectArgs& sel, hipStream_t s) {
+           float* h1_out, float* h2_out, const SelectArgs& sel, hipStream_t s) {
     const bool vec = (h1 % 4 == 0) && (h2 % 4 == 0) && ((uintptr_t)W2 % 16 == 0) && ((uintptr_t)W3 % 16 == 0);
-    const dim3 grid((n + ROWS - 1) / ROWS), block(256);
+    const dim3 grid((n + ROWS - 1) / ROWS), block(64 * NW);
     if (vec)
         hipLaunchKernelGGL((k_mlp3<NT1, NT2, true, SEL>), grid, block, 0, s, n, in_a, in_b, h1, h2, out_dim, xa, lda, xb, ldb, W1, b1, W2, b2, W3, b3,
-                           act, scale, out, sel);
+                           act, scale, out, h1_out, h2_out, sel);
     else
         hipLaunchKernelGGL((k_mlp3<NT1, NT2, false, SEL>), grid, block, 0, s, n, in_a, in_b, h1, h2, out_dim, xa, lda, xb, ldb, W1, b1, W2, b2, W3, b3,
-                           act, scale, out, sel);
+                           act, scale, out, h1_out, h2_out, sel);
     return hipGetLastError() == hipSuccess ? KS_OK : KS_ERR_HIP;
 }
 
@@ -188,10 +219,10 @@ int launch(int n, int in_a, int in_b, int h1, int h2, int out_dim, const float* 
 template <bool SEL>
 int dispatch(int n, int in_a, int in_b, int h1, int h2, int out_dim, const float* xa, int lda, const float* xb, int ldb, const float* W1,
              const float* b1, const float* W2, const float* b2, const float* W3, const float* b3, int act, float scale, float* out,
-             const SelectArgs& sel, hipStream_t s) {
+             float* h1_out, float* h2_out, const SelectArgs& sel, hipStream_t s) {
     const int nt1 = (h1 + 15) / 16, nt2 = (h2 + 15) / 16;
 #define KR_MLP_CASE(A, B) \
-    if (nt1 == A && nt2 == B) return launch<A, B, SEL>(n, in_a, in_b, h1, h2, out_dim, xa, lda, xb, ldb, W1, b1, W2, b2, W3, b3, act, scale, out, sel, s);
+    if (nt1 == A && nt2 == B) return launch<A, B, SEL>(n, in_a, in_b, h1, h2, out_dim, xa, lda, xb, ldb, W1, b1, W2, b2, W3, b3, act, scale, out, h1_out, h2_out, sel, s);
     KR_MLP_CASE(16, 16)      // 256-256 (BASELINE)
     KR_MLP_CASE(25, 19)      // 400-300 (reference, DDPGfD.py:19-23)
     KR_MLP_CASE(8, 8)        // 128-128
@@ -206,12 +237,13 @@ extern "C" {
 
 int kr_mlp3_forward(int32_t n, int32_t in_a, int32_t in_b, int32_t h1, int32_t h2, int32_t out_dim, const float* xa, int32_t lda,
                     const float* xb, int32_t ldb, const float* W1, const float* b1, const float* W2, const float* b2,
-                    const float* W3, const float* b3, int32_t act, float scale, float* out, void* stream) {
+                    const float* W3, const float* b3, int32_t act, float scale, float* out, float* h1_out, float* h2_out, void* stream) {
     if (n <= 0) return KS_OK;
+    if (((h1_out && (h1 % 4 || (uintptr_t)h1_out % 16)) || (h2_out && (h2 % 4 || (uintptr_t)h2_out % 16)))) return KS_ERR_INVALID;
     if (!xa || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out || in_a <= 0 || in_b < 0 || (in_b > 0 && !xb)) return KS_ERR_INVALID;
     if (in_a + in_b > 16 * KS_IN_MAX || out_dim < 1 || out_dim > 4 || h1 < 1 || h2 < 1) return KS_ERR_INVALID;
     if (act != KR_ACT_NONE && act != KR_ACT_SIGMOID) return KS_ERR_INVALID;
-    return dispatch<false>(n, in_a, in_b, h1, h2, out_dim, xa, lda, xb, ldb, W1, b1, W2, b2, W3, b3, act, scale, out, SelectArgs{}, (hipStream_t)stream);
+    return dispatch<false>(n, in_a, in_b, h1, h2, out_dim, xa, lda, xb, ldb, W1, b1, W2, b2, W3, b3, act, scale, out, h1_out, h2_out, SelectArgs{}, (hipStream_t)stream);
 }
 
 int kr_actor_select(int32_t n, int32_t h1, int32_t h2, const float* obs, const float* prev_obs, const uint8_t* has_prev, const int64_t* t,
@@ -223,7 +255,7 @@ int kr_actor_select(int32_t n, int32_t h1, int32_t h2, const float* obs, const f
     if ((noise == nullptr) == (rng_state == nullptr) || h1 < 1 || h2 < 1) return KS_ERR_INVALID;     // exactly one noise source
     SelectArgs sel{obs, prev_obs, has_prev, t, ready, noise, (unsigned long long)seed, rng_state, sigma, max_action, skip_steps, action, action_t, lifting};
     return dispatch<true>(n, KR_STATE_DIM, 0, h1, h2, KR_ACTION_DIM, obs, KR_STATE_DIM, nullptr, 0, W1, b1, W2, b2, W3, b3, KR_ACT_SIGMOID, max_action,
-                          actor_out, sel, (hipStream_t)stream);
+                          actor_out, nullptr, nullptr, sel, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -25,9 +25,10 @@ def supported(layers, in_dim: int) -> bool:
 
 
 def mlp3_forward(layers, xa: torch.Tensor, xb: torch.Tensor | None = None, act: int = ACT_NONE, scale: float = 1.0,
-                 out: torch.Tensor | None = None) -> torch.Tensor:
+                 out: torch.Tensor | None = None, h1_out: torch.Tensor | None = None, h2_out: torch.Tensor | None = None) -> torch.Tensor:
     """out[n, out_dim] = f(W3 relu(W2 relu(W1 [xa | xb] + b1) + b2) + b3) on the current stream.  xa / xb: fp32 [n, *]
-    with unit column stride (row stride free: slices of wider tensors are fine)."""
+    with unit column stride (row stride free: slices of wider tensors are fine).  h1_out [n, h1] / h2_out [n, h2]
+    (contiguous, optional) receive the hidden activations for a backward pass."""
     (w1, b1), (w2, b2), (w3, b3) = layers
     n, in_a = xa.shape
     in_b = 0 if xb is None else xb.shape[1]
@@ -36,9 +37,11 @@ def mlp3_forward(layers, xa: torch.Tensor, xb: torch.Tensor | None = None, act: 
     if out is None:
         out = torch.empty(n, w3.shape[0], device=xa.device, dtype=torch.float32)
     assert out.is_contiguous() and tuple(out.shape) == (n, w3.shape[0])
+    for h, w in ((h1_out, w1), (h2_out, w2)):
+        assert h is None or (h.is_contiguous() and tuple(h.shape) == (n, w.shape[0]) and h.dtype == torch.float32)
     lib, P = _sim.load_library(), _sim._ptr
     rc = lib.kr_mlp3_forward(n, in_a, in_b, w1.shape[0], w2.shape[0], w3.shape[0], P(xa), xa.stride(0), P(xb) if xb is not None else None,
-                             xb.stride(0) if xb is not None else 0, P(w1), P(b1), P(w2), P(b2), P(w3), P(b3), act, float(scale), P(out),
+                             xb.stride(0) if xb is not None else 0, P(w1), P(b1), P(w2), P(b2), P(w3), P(b3), act, float(scale), P(out), P(h1_out), P(h2_out),
                              ctypes.c_void_p(torch.cuda.current_stream(xa.device).cuda_stream))
     if rc != 0:
         raise RuntimeError(f"kr_mlp3_forward failed ({rc}): unsupported layer widths or bad arguments")

@@ -40,8 +40,7 @@ class GraphedTrainer:
         except Exception:
             pass
         self.main = torch.cuda.current_stream(self.dev)
-        import os
-        self.side = torch.cuda.Stream(self.dev, priority=int(os.environ.get("KS_EXP_SIDE_PRIO", "0")))
+        self.side = torch.cuda.Stream(self.dev)
         self.acted = torch.cuda.Event()
         self.head_done = torch.cuda.Event()
         self.g_pre = self.g_post = None
@@ -147,9 +146,7 @@ class GraphedTrainer:
                     self.g_head.replay()
                     self.head_done.record(side)
                     self._body()
-                import os
-                if not os.environ.get("KS_EXP_NOWAIT"):
-                    main.wait_event(self.head_done)    # windows sampled, actor weights settled: the body runs on its own
+                main.wait_event(self.head_done)    # windows sampled, actor weights settled: the body runs on its own
             else:
                 self.g_head.replay()
                 self._body()

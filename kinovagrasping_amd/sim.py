@@ -69,7 +69,7 @@ def load_library(path: Path | None = None):
     L.kr_sigmoid_scale_backward.argtypes = [i64, vp, f32, vp, vp]
     L.kr_adam_step.argtypes = [i64, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, vp]
     L.kr_soft_update.argtypes = [i64, vp, vp, f32, vp, i32, vp]
-    L.kr_mlp3_forward.argtypes = [i32] * 6 + [vp, i32, vp, i32] + [vp] * 6 + [i32, f32, vp, vp]
+    L.kr_mlp3_forward.argtypes = [i32] * 6 + [vp, i32, vp, i32] + [vp] * 6 + [i32, f32, vp, vp, vp, vp]
     L.kr_actor_select.argtypes = [i32] * 3 + [vp] * 12 + [C.c_uint64, vp, f32, f32, i32] + [vp] * 5
     _lib = L
     return L

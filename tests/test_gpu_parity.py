@@ -595,8 +595,12 @@ def test_fused_mlp_forward_matches_torch():
             s, a = wide[:, :82], (0.8 * torch.rand(n, 4, generator=g)).to(dev)
             with torch.no_grad():
                 ref_a, ref_q = actor(s), critic(s, a)
-            out_a = mlp.mlp3_forward(mlp.layers_of(actor), s, act=mlp.ACT_SIGMOID, scale=0.8)
+            h1, h2 = torch.zeros(n, hidden[0], device=dev), torch.zeros(n, hidden[1], device=dev)
+            out_a = mlp.mlp3_forward(mlp.layers_of(actor), s, act=mlp.ACT_SIGMOID, scale=0.8, h1_out=h1, h2_out=h2)
             out_q = mlp.mlp3_forward(mlp.layers_of(critic), s, a, act=mlp.ACT_NONE)
+            with torch.no_grad():                       # the hidden activations a backward pass would read
+                r1 = torch.relu(actor.l1(s)); r2 = torch.relu(actor.l2(r1))
+            assert (h1 - r1).abs().max().item() < 2e-5 and (h2 - r2).abs().max().item() < 2e-5, (hidden, n)
             assert out_a.shape == ref_a.shape and out_q.shape == ref_q.shape
             assert (out_a - ref_a).abs().max().item() < 2e-5, (hidden, n, (out_a - ref_a).abs().max().item())
             assert (out_q - ref_q).abs().max().item() < 2e-5 * max(1.0, ref_q.abs().max().item()), (hidden, n, (out_q - ref_q).abs().max().item())
