@@ -51,8 +51,9 @@ class MultiShapeSim:
         o = self.offsets
         outs = self._fan_out(lambda i, sim: sim.step(action[:, o[i]:o[i + 1]]))
         self.final_obs = torch.cat([s.final_obs for s in self.sims], 0)
-        return (torch.cat([x[0] for x in outs], 0), torch.cat([x[1] for x in outs], 0), torch.cat([x[2] for x in outs], 0),
-                torch.cat([x[3] for x in outs], 1))
+        # the same output attributes a single KinovaSim keeps (rollout.RolloutEngine reads them)
+        self.obs, self.reward, self.done = (torch.cat([x[k] for x in outs], 0) for k in range(3))
+        return self.obs, self.reward, self.done, torch.cat([x[3] for x in outs], 1)
 
     def set_env_params(self, obj_mass=None, obj_mu=None):
         """per-env object mass [N] and object-hand friction [N] (None = leave as is)"""

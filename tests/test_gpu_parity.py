@@ -667,3 +667,29 @@ def test_fused_actor_select_equals_separate_kernels():
     assert lib.kr_actor_select(n, 256, 256, P(obs), P(prev), P(nobody), P(t), P(nobody.clone()), P(w1), P(b1), P(w2), P(b2), P(w3), P(b3), None, 1234,
                                P(rng2), 0.01, 0.8, 6, None, P(a_again), P(torch.zeros(4, n, device=dev)), P(nobody.clone()), st) == 0
     assert torch.equal((a_again - 0.4) / 0.01, zs[0])          # same (seed, counter, env) -> same draw
+
+
+def test_curriculum_stage_runs_and_hands_over_to_the_next(tmp_path):
+    """curriculum.run_stage: experiment 1 (sizes: CubeS + CubeB, normal orientation) trained from scratch for one round,
+    saved in the reference's directory layout; experiment 4 (sizes x shapes x orientations) then starts from that
+    stage's policy and agent replay (rl_experiment, main_DDPGfD.py:776-800).  Plumbing check at toy sizes."""
+    from kinovagrasping_amd import curriculum
+    from kinovagrasping_amd.ddpgfd import DDPGfD
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(2)
+    policy = DDPGfD(82, 4, 0.8, 5, batch_size=8, hidden=(64, 64), device=dev)
+    p1 = curriculum.experiment_plan(1, root=tmp_path)
+    r1 = curriculum.run_stage(p1, policy, n_envs=64, rounds=1, updates_per_round=2, load_previous=False)
+    assert r1["shapes"] == ["CubeS", "CubeB"] and r1["skipped_shapes"] == [] and r1["updates"] == 2 and r1["num_total"] == 64
+    assert curriculum.policy_basename(p1["dirs"]["policy_dir"]).startswith("DDPGfD_kinovaGrip_")
+    assert (p1["dirs"]["output_dir"] / "experiment_info.txt").read_text().startswith("NO grasp Experiment 1: sizes, Stage 1")
+    w_saved = policy.actor.l1.weight.detach().clone()
+    fresh = DDPGfD(82, 4, 0.8, 5, batch_size=8, hidden=(64, 64), device=dev)
+    assert not torch.equal(fresh.actor.l1.weight, w_saved)
+    p4 = curriculum.experiment_plan(4, root=tmp_path)
+    assert p4["dirs"]["prev_policy_dir"] == p1["dirs"]["policy_dir"]
+    r4 = curriculum.run_stage(p4, fresh, n_envs=96, rounds=1, updates_per_round=1, save=False)
+    # Bottle / Bowl / TBottle have no compiled asset; the other 8 size x shape keys run, in all three orientation classes
+    assert r4["shapes"] == ["CubeS", "CylinderS", "Cube45S", "Vase2S", "CubeB", "CylinderB", "Cube45B", "Vase2B"]
+    assert sorted(r4["skipped_shapes"]) == ["BottleB", "BottleS", "BowlB", "BowlS", "TBottleB", "TBottleS"]
+    assert set(r4["orientation_counts"]) == {"normal", "rotated", "top"} and r4["updates"] == 1

@@ -196,3 +196,27 @@ def test_object_schedule_and_orientation_selection_match_reference():
     got = [scenarios.select_orientation(str(s), str(h), rng) for s, h in zip(g["or_shapes"], g["or_modes"])]
     assert got == [str(o) for o in g["or_out"]]
     assert set(got[:120]) == {"normal", "rotated", "top"} and set(got[120:]) == {"normal"}
+
+
+def test_curriculum_tables_equal_the_reference(golden_dir):
+    """experiment_info / experiment_input against the reference's get_experiment_info / get_exp_input
+    (tests/golden/curriculum.json, tools/gen_golden_curriculum.py).  Outside experiments 1..6 the reference itself
+    fails (NameError on its commented-out stage3 table); this package raises ValueError there."""
+    import json
+    from kinovagrasping_amd import curriculum
+    gold = json.loads((golden_dir / "curriculum.json").read_text())
+    for num, want in gold["info"].items():
+        if isinstance(want, list):
+            assert list(curriculum.experiment_info(int(num))) == want, num
+            assert list(curriculum.experiment_info(num)) == want, num
+        else:
+            with pytest.raises(ValueError):
+                curriculum.experiment_info(int(num))
+    for case in gold["input"]:
+        req, ori = curriculum.experiment_input(case["exp_name"], case["shapes"], case["sizes"])
+        assert req == case["requested_shapes"] and ori == case["orientation"], case["exp_name"]
+    plan = curriculum.experiment_plan(5, root="/tmp/x")
+    assert plan["exp_name"] == "shapes_sizes_orientations" and plan["prev_exp_name"] == "shapes" and plan["requested_orientation_list"] == ["normal", "rotated", "top"]
+    assert str(plan["dirs"]["policy_dir"]) == "/tmp/x/rl_experiments/no_grasp/stage2/shapes_sizes_orientations/policy"
+    assert str(plan["dirs"]["prev_replay_dir"]) == "/tmp/x/rl_experiments/no_grasp/stage1/shapes/replay_buffer"
+    assert len(plan["requested_shapes"]) == 14 and plan["requested_shapes"][:2] == ["CubeS", "CylinderS"]
