@@ -105,6 +105,14 @@ int kr_mlp3_forward(int32_t n, int32_t in_a, int32_t in_b, int32_t h1, int32_t h
                     const float *xb, int32_t ldb, const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
                     const float *b3, int32_t act, float scale, float *out, float *h1_out, float *h2_out, void *stream);
 
+/* The same forward WITHOUT LDS (one wavefront per 16 rows, everything in registers, <= 168 registers per lane): its
+ * waves can be resident beside a kernel that holds a CU's whole LDS (k_env_step), so a learner's forward-only passes
+ * run in that kernel's shadow instead of behind it.  Widths 256-256, 128-128, 64-64; otherwise KS_ERR_INVALID. */
+int kr_mlp3_forward_shadow(int32_t n, int32_t in_a, int32_t in_b, int32_t h1, int32_t h2, int32_t out_dim, const float *xa, int32_t lda,
+                           const float *xb, int32_t ldb, const float *W1, const float *b1, const float *W2, const float *b2,
+                           const float *W3, const float *b3, int32_t act, float scale, float *out, float *h1_out, float *h2_out,
+                           void *stream);
+
 /* Actor forward + exploration noise + kr_select_action in ONE launch (main_DDPGfD.py:424-451): the epilogue of the
  * fused MLP applies the selection rule to its own output.  obs .. ready and action .. lifting as in kr_select_action;
  * W1 .. b3 the actor (82 -> h1 -> h2 -> 4).  Noise: either `noise` [n,4] ~ N(0,1) (then rng_state = NULL), or

@@ -200,6 +200,78 @@ __global__ __launch_bounds__(64 * NW) void k_mlp3(int n, int in_a, int in_b, int
     }
 }
 
+// ---- the same network WITHOUT LDS: one wave = 16 batch rows, all layers in registers.  Layer 1's output quads (NT1
+// float4 registers) are the B operands of layer 2; every layer-2 output quad feeds layer 3's MFMAs right away, so h2
+// is never stored.  The kernel is capped at 168 registers per lane (3 waves per SIMD): k_env_step holds all of a
+// CU's LDS and 344 of the 512 registers of every SIMD lane, so these waves can be resident BESIDE it and use the
+// matrix pipes and issue slots the stepping kernel leaves idle - the learner's forward-only passes run in its shadow
+// instead of waiting for its workgroups to retire.  Slower per wave than the LDS kernel (no split of the tiles over
+// four waves), which does not matter there.
+template <int NT1, int NT2, bool VEC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_mlp3_wave(
+    int n, int in_a, int in_b, int h1, int h2, int out_dim, const float* __restrict__ xa, int lda, const float* __restrict__ xb, int ldb,
+    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+    const float* __restrict__ W3, const float* __restrict__ b3, int act, float scale, float* __restrict__ out, float* __restrict__ h1_out,
+    float* __restrict__ h2_out) {
+    const int lane = threadIdx.x & 63, nn = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * ROWS + nn;
+    const bool row_ok = row < n;
+    const int in_dim = in_a + in_b;
+    f32x4 h1r[NT1];
+    {
+        f32x4 bx[KS_IN_MAX];
+#pragma unroll
+        for (int s = 0; s < KS_IN_MAX; s++) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = 16 * s + 4 * q + j;
+                float x = 0.f;
+                if (row_ok && k < in_a) x = xa[(long)row * lda + k];
+                else if (row_ok && k < in_dim) x = xb[(long)row * ldb + (k - in_a)];
+                v[j] = x;
+            }
+            bx[s] = f32x4{v[0], v[1], v[2], v[3]};
+        }
+#pragma unroll
+        for (int t = 0; t < NT1; t++) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS_IN_MAX; s++) {
+                const f32x4 w = load_w4<false>(W1, t * 16 + nn, h1, 16 * s + 4 * q, in_dim);
+                if (s & 1) acc1 = mfma4(w, bx[s], acc1);
+                else acc0 = mfma4(w, bx[s], acc0);
+            }
+            h1r[t] = bias_relu(acc0 + acc1, b1, t * 16 + 4 * q, h1);
+            if (h1_out && row_ok && t * 16 + 4 * q < h1) *(f32x4*)(h1_out + (long)row * h1 + t * 16 + 4 * q) = h1r[t];
+        }
+    }
+    f32x4 acc3 = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT2; t++) {
+        f32x4 w[NT1];
+#pragma unroll
+        for (int s = 0; s < NT1; s++) w[s] = load_w4<VEC>(W2, t * 16 + nn, h2, 16 * s + 4 * q, h1);
+        const f32x4 w3 = load_w4<VEC>(W3, nn, out_dim, 16 * t + 4 * q, h2);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NT1; s++) {
+            if (s & 1) acc1 = mfma4(w[s], h1r[s], acc1);
+            else acc0 = mfma4(w[s], h1r[s], acc0);
+        }
+        const f32x4 hq = bias_relu(acc0 + acc1, b2, t * 16 + 4 * q, h2);
+        if (h2_out && row_ok && t * 16 + 4 * q < h2) *(f32x4*)(h2_out + (long)row * h2 + t * 16 + 4 * q) = hq;
+        acc3 = mfma4(w3, hq, acc3);
+    }
+    if (q == 0 && row_ok) {
+        const float z[4] = {acc3.x, acc3.y, acc3.z, acc3.w};
+        for (int i = 0; i < out_dim; i++) {
+            float y = z[i] + b3[i];
+            if (act == KR_ACT_SIGMOID) y = scale / (1.f + __expf(-y));
+            out[(long)row * out_dim + i] = y;
+        }
+    }
+}
+
 template <int NT1, int NT2, bool SEL>
 int launch(int n, int in_a, int in_b, int h1, int h2, int out_dim, const float* xa, int lda, const float* xb, int ldb, const float* W1,
            const float* b1, const float* W2, const float* b2, const float* W3, const float* b3, int act, float scale, float* out,
@@ -244,6 +316,33 @@ int kr_mlp3_forward(int32_t n, int32_t in_a, int32_t in_b, int32_t h1, int32_t h
     if (in_a + in_b > 16 * KS_IN_MAX || out_dim < 1 || out_dim > 4 || h1 < 1 || h2 < 1) return KS_ERR_INVALID;
     if (act != KR_ACT_NONE && act != KR_ACT_SIGMOID) return KS_ERR_INVALID;
     return dispatch<false>(n, in_a, in_b, h1, h2, out_dim, xa, lda, xb, ldb, W1, b1, W2, b2, W3, b3, act, scale, out, h1_out, h2_out, SelectArgs{}, (hipStream_t)stream);
+}
+
+int kr_mlp3_forward_shadow(int32_t n, int32_t in_a, int32_t in_b, int32_t h1, int32_t h2, int32_t out_dim, const float* xa, int32_t lda,
+                           const float* xb, int32_t ldb, const float* W1, const float* b1, const float* W2, const float* b2,
+                           const float* W3, const float* b3, int32_t act, float scale, float* out, float* h1_out, float* h2_out, void* stream) {
+    if (n <= 0) return KS_OK;
+    if (((h1_out && (h1 % 4 || (uintptr_t)h1_out % 16)) || (h2_out && (h2 % 4 || (uintptr_t)h2_out % 16)))) return KS_ERR_INVALID;
+    if (!xa || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out || in_a <= 0 || in_b < 0 || (in_b > 0 && !xb)) return KS_ERR_INVALID;
+    if (in_a + in_b > 16 * KS_IN_MAX || out_dim < 1 || out_dim > 4 || h1 < 1 || h2 < 1) return KS_ERR_INVALID;
+    if (act != KR_ACT_NONE && act != KR_ACT_SIGMOID) return KS_ERR_INVALID;
+    const int nt1 = (h1 + 15) / 16, nt2 = (h2 + 15) / 16;
+    const bool vec = (h1 % 4 == 0) && (h2 % 4 == 0) && ((uintptr_t)W2 % 16 == 0) && ((uintptr_t)W3 % 16 == 0);
+    const dim3 grid((n + ROWS - 1) / ROWS), block(64);
+    hipStream_t s = (hipStream_t)stream;
+#define KR_WAVE_CASE(A, B)                                                                                                                       \
+    if (nt1 == A && nt2 == B) {                                                                                                                  \
+        if (vec) hipLaunchKernelGGL((k_mlp3_wave<A, B, true>), grid, block, 0, s, n, in_a, in_b, h1, h2, out_dim, xa, lda, xb, ldb, W1, b1, W2, b2, \
+                                    W3, b3, act, scale, out, h1_out, h2_out);                                                                    \
+        else hipLaunchKernelGGL((k_mlp3_wave<A, B, false>), grid, block, 0, s, n, in_a, in_b, h1, h2, out_dim, xa, lda, xb, ldb, W1, b1, W2, b2,   \
+                                W3, b3, act, scale, out, h1_out, h2_out);                                                                        \
+        return hipGetLastError() == hipSuccess ? KS_OK : KS_ERR_HIP;                                                                             \
+    }
+    KR_WAVE_CASE(16, 16)     // 256-256 (BASELINE); wider first layers do not fit the register budget
+    KR_WAVE_CASE(8, 8)
+    KR_WAVE_CASE(4, 4)
+#undef KR_WAVE_CASE
+    return KS_ERR_INVALID;
 }
 
 int kr_actor_select(int32_t n, int32_t h1, int32_t h2, const float* obs, const float* prev_obs, const uint8_t* has_prev, const int64_t* t,

@@ -66,6 +66,11 @@ class NativeDDPGfDUpdate:
         # backward pass (1600 rows).  The 8000-row forwards of the actor phase stay on the library GEMMs - at that size
         # three large-tile GEMMs beat the 16-row-tile kernel (measured: 1.48 vs 1.44 ms per env-step in bench.py).
         self.fuse_critic_fwd, self.fuse_actor_fwd = True, False
+        # ... in their LDS-free form when the widths allow: these launches open the update, and without LDS their waves
+        # are resident beside the stepping kernel (which holds every CU's LDS) instead of waiting for it to finish
+        import os
+        self.shadow = (os.environ.get("KS_EXP_SHADOW", "1") == "1" and _mlp.supported(list(zip(self.actor_t.W, self.actor_t.b)), self.actor_t.W[0].shape[1], shadow=True)
+                       and _mlp.supported(list(zip(self.critic_t.W, self.critic_t.b)), self.critic_t.W[0].shape[1], shadow=True))
         self.fused_targets = (all(w.shape[0] % 4 == 0 for w in self.critic.W[:2] + self.actor.W[:2]) and _mlp.supported(list(zip(self.actor_t.W, self.actor_t.b)), self.actor_t.W[0].shape[1])
                               and _mlp.supported(list(zip(self.critic_t.W, self.critic_t.b)), self.critic_t.W[0].shape[1]))
 
@@ -124,8 +129,8 @@ class NativeDDPGfDUpdate:
         nx = torch.cat([next_state[:, 0], next_state[:, -1]], 0)
         if self.fused_targets:
             # forward-only networks: one fused fp32-MFMA launch each (mlp.mlp3_forward) instead of 3 GEMMs + glue
-            ta = _mlp.mlp3_forward(list(zip(self.actor_t.W, self.actor_t.b)), nx, act=_mlp.ACT_SIGMOID, scale=pol.max_action)
-            tq = _mlp.mlp3_forward(list(zip(self.critic_t.W, self.critic_t.b)), nx, ta, act=_mlp.ACT_NONE)
+            ta = _mlp.mlp3_forward(list(zip(self.actor_t.W, self.actor_t.b)), nx, act=_mlp.ACT_SIGMOID, scale=pol.max_action, shadow=self.shadow)
+            tq = _mlp.mlp3_forward(list(zip(self.critic_t.W, self.critic_t.b)), nx, ta, act=_mlp.ACT_NONE, shadow=self.shadow)
         else:
             _, _, ta = self._actor_forward(self.actor_t, nx)
             ct = self.critic_t
@@ -134,7 +139,7 @@ class NativeDDPGfDUpdate:
         c = self.critic
         if self.fused_targets and self.fuse_critic_fwd:
             h1, h2 = x0.new_empty(R, c.W[0].shape[0]), x0.new_empty(R, c.W[1].shape[0])
-            q = _mlp.mlp3_forward(list(zip(c.W, c.b)), state[:, 0], action[:, 0], act=_mlp.ACT_NONE, h1_out=h1, h2_out=h2)
+            q = _mlp.mlp3_forward(list(zip(c.W, c.b)), state[:, 0], action[:, 0], act=_mlp.ACT_NONE, h1_out=h1, h2_out=h2, shadow=self.shadow)
         else:
             h1 = self._lin_relu(c, 0, x0)
             h2 = self._lin_relu(c, 1, h1)
