@@ -113,6 +113,21 @@ int kr_mlp3_forward_shadow(int32_t n, int32_t in_a, int32_t in_b, int32_t h1, in
                            const float *W3, const float *b3, int32_t act, float scale, float *out, float *h1_out, float *h2_out,
                            void *stream);
 
+/* Backward of the same MLP, LDS-free like kr_mlp3_forward_shadow (DDPGfD.train_batch's loss.backward(), DDPGfD.py:330-356):
+ *   kr_mlp3_backward_shadow   data gradients  dz2 = (dz3 W3) * [h2 > 0],  dz1 = (dz2 W2) * [h1 > 0]  ([n,h2], [n,h1];
+ *                             either may be NULL) and optionally  dx = dz1 W1[:, col0 : col0 + ncol]  ([n,ncol], ncol <= 4:
+ *                             dQ/da through the critic's first layer), followed - when act_out [n,ncol] is given - by the
+ *                             backward of a = scale * sigmoid(z):  dx *= a (1 - a / scale).  dz3 [n,out_dim], h1 / h2 the
+ *                             activations kr_mlp3_forward* stored.  Widths: multiples of 16 up to 256.
+ *   kr_weight_grad_shadow     dW [M,N] = dz^T [ha | hb]  and  db [M] = column sums of dz, dz [n,M], ha [n,>=Na] (row stride
+ *                             lda), hb [n,>=Nb] (ldb; Nb = 0: unused); the batch rows are split into `chunks` partial sums
+ *                             in `workspace` (chunks * (M*N + M) floats) that a second launch adds up in chunk order. */
+int kr_mlp3_backward_shadow(int32_t n, int32_t in_dim, int32_t h1, int32_t h2, int32_t out_dim, const float *dz3, const float *W3,
+                            const float *h2a, const float *W2, const float *h1a, float *dz2_out, float *dz1_out, const float *W1,
+                            int32_t col0, int32_t ncol, const float *act_out, float scale, float *dx_out, void *stream);
+int kr_weight_grad_shadow(int32_t n, int32_t M, int32_t Na, int32_t Nb, const float *dz, const float *ha, int32_t lda, const float *hb,
+                          int32_t ldb, int32_t chunks, float *workspace, float *dW, float *db, void *stream);
+
 /* Actor forward + exploration noise + kr_select_action in ONE launch (main_DDPGfD.py:424-451): the epilogue of the
  * fused MLP applies the selection rule to its own output.  obs .. ready and action .. lifting as in kr_select_action;
  * W1 .. b3 the actor (82 -> h1 -> h2 -> 4).  Noise: either `noise` [n,4] ~ N(0,1) (then rng_state = NULL), or

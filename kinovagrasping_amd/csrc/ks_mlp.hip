@@ -272,6 +272,175 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     }
 }
 
+// ---- backward of the same network, also without LDS (one wave = 16 batch rows).
+// Data gradients: with dz3 = dLoss/d(output pre-activation) [n, out_dim],
+//     dz2 = (dz3 W3) * [h2 > 0],   dz1 = (dz2 W2) * [h1 > 0],   dx = dz1 W1[:, col0 : col0 + ncol]   (optional)
+// again in the transposed orientation: dh^T = W^T dz^T, A = W^T (16 features of the layer below x 4 k), B = dz^T
+// (4 k x 16 rows); the masked output quads are the next product's B operands, exactly as in the forward kernel.
+// dx (<= 4 columns: the action inputs of the critic, DDPGfD.py:345-349) can be followed in the epilogue by the
+// backward of  a = scale * sigmoid(z):  dz = dx * a (1 - a / scale)  (kr_sigmoid_scale_backward), which makes it the
+// dz3 of the actor.  dz2_out / dz1_out may be NULL when only dx is wanted.
+template <int NT1, int NT2>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_mlp3_bwd_wave(
+    int n, int in_dim, int h1, int h2, int out_dim, const float* __restrict__ dz3, const float* __restrict__ W3, const float* __restrict__ h2a,
+    const float* __restrict__ W2, const float* __restrict__ h1a, float* __restrict__ dz2_out, float* __restrict__ dz1_out,
+    const float* __restrict__ W1, int col0, int ncol, const float* __restrict__ act_out, float scale, float* __restrict__ dx_out) {
+    const int lane = threadIdx.x & 63, nn = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * ROWS + nn;
+    const bool row_ok = row < n;
+    // B operand of the first product: dz3^T, k = output index = q
+    const float b3 = (row_ok && q < out_dim) ? dz3[(long)row * out_dim + q] : 0.f;
+    f32x4 dz2r[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; t++) {
+        const int f = t * 16 + nn;                                          // A: W3^T[f][k = q] = W3[q][f]
+        const float a3 = (q < out_dim && f < h2) ? W3[(long)q * h2 + f] : 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc, 0, 0, 0);
+        const int f4 = t * 16 + 4 * q;
+        f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+        if (row_ok && f4 < h2) hv = *(const f32x4*)(h2a + (long)row * h2 + f4);
+        f32x4 dz;
+        dz.x = hv.x > 0.f ? acc.x : 0.f; dz.y = hv.y > 0.f ? acc.y : 0.f; dz.z = hv.z > 0.f ? acc.z : 0.f; dz.w = hv.w > 0.f ? acc.w : 0.f;
+        dz2r[t] = dz;
+        if (dz2_out && row_ok && f4 < h2) *(f32x4*)(dz2_out + (long)row * h2 + f4) = dz;
+    }
+    f32x4 accx = {0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W2), 0, h1 * h2 * 4, 0x00020000);
+#pragma unroll 1
+    for (int t = 0; t < NT1; t++) {
+        // A: W2^T[f][k] = W2[k][f], k = 16 s + 4 q + j (rows of W2, stride h1), f = 16 t + nn
+        const int f = t * 16 + nn;
+        // (host checks h1 % 16 == h2 % 16 == 0: every row / column of the tile exists).  Buffer loads: ONE 32-bit lane
+        // offset for the whole tile, the row steps (16 s + j) * h1 are wave-uniform and go in the scalar offset - flat
+        // loads would hold a 64-bit address per load in flight and spill at this register budget.
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const int voff = (4 * q * h1 + f) * 4;
+        constexpr int HALF = (NT2 + 1) / 2;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            f32x4 w[HALF];
+#pragma unroll
+            for (int u = 0; u < HALF; u++) {
+                const int s = half * HALF + u;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (s < NT2) {
+                    v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW2, voff, (16 * s + 0) * h1 * 4, 0));
+                    v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW2, voff, (16 * s + 1) * h1 * 4, 0));
+                    v.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW2, voff, (16 * s + 2) * h1 * 4, 0));
+                    v.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW2, voff, (16 * s + 3) * h1 * 4, 0));
+                }
+                w[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < HALF; u++) {
+                const int s = half * HALF + u;
+                if (s < NT2) {
+                    if (s & 1) acc1 = mfma4(w[u], dz2r[s], acc1);
+                    else acc0 = mfma4(w[u], dz2r[s], acc0);
+                }
+            }
+        }
+        const f32x4 acc = acc0 + acc1;
+        const int f4 = t * 16 + 4 * q;
+        f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+        if (row_ok && f4 < h1) hv = *(const f32x4*)(h1a + (long)row * h1 + f4);
+        f32x4 dz;
+        dz.x = hv.x > 0.f ? acc.x : 0.f; dz.y = hv.y > 0.f ? acc.y : 0.f; dz.z = hv.z > 0.f ? acc.z : 0.f; dz.w = hv.w > 0.f ? acc.w : 0.f;
+        if (dz1_out && row_ok && f4 < h1) *(f32x4*)(dz1_out + (long)row * h1 + f4) = dz;
+        if (dx_out) {
+            // A: W1[:, col0 + m]^T: [m][k] = W1[k][col0 + m], k = 16 t + 4 q + j (rows of W1, stride in_dim), m = nn < ncol
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (nn < ncol) {
+                const int k = 16 * t + 4 * q;
+                const float* p = W1 + (long)k * in_dim + col0 + nn;
+                if (k < h1) v.x = p[0];
+                if (k + 1 < h1) v.y = p[in_dim];
+                if (k + 2 < h1) v.z = p[2 * (long)in_dim];
+                if (k + 3 < h1) v.w = p[3 * (long)in_dim];
+            }
+            accx = mfma4(v, dz, accx);
+        }
+    }
+    if (dx_out && q == 0 && row_ok) {
+        const float g[4] = {accx.x, accx.y, accx.z, accx.w};
+        for (int i = 0; i < ncol; i++) {
+            float v = g[i];
+            if (act_out) { const float a = act_out[(long)row * ncol + i]; v *= a * (1.f - a / scale); }
+            dx_out[(long)row * ncol + i] = v;
+        }
+    }
+}
+
+// Weight gradients  dW[M][N] = dz^T h  (dz [n][M], h = [ha | hb] [n][N]) and the bias gradient  db[M] = column sums of dz,
+// without LDS: a wave owns one 16-row tile of dW and TN 16-column tiles, and one chunk of the batch rows; A = dz^T
+// (lane: feature m, row k), B = h (lane: row k, column).  The chunk partials go to a workspace [chunk][M * N + M] that
+// k_wgrad_reduce sums in chunk order (deterministic, unlike atomics).
+constexpr int WG_TN = 4;
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wgrad_wave(
+    int n, int M, int Na, int Nb, int rows_per_chunk, const float* __restrict__ dz, const float* __restrict__ ha, int lda,
+    const float* __restrict__ hb, int ldb, float* __restrict__ ws) {
+    const int lane = threadIdx.x & 63, nn = lane & 15, q = lane >> 4;
+    const int N = Na + Nb, n_blocks = (N + 16 * WG_TN - 1) / (16 * WG_TN);
+    const int mt = blockIdx.x / n_blocks, nb = blockIdx.x % n_blocks, chunk = blockIdx.y;
+    const int r0 = chunk * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+    const int m = mt * 16 + nn;
+    f32x4 acc[WG_TN];
+#pragma unroll
+    for (int u = 0; u < WG_TN; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float colsum = 0.f;
+    for (int k0 = r0; k0 < r1; k0 += 16) {
+        // four k-steps (16 rows) per round: all loads first
+        float a[4], b[4][WG_TN];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r = k0 + 4 * j + q;
+            const bool ok = r < r1;
+            a[j] = (ok && m < M) ? dz[(long)r * M + m] : 0.f;
+#pragma unroll
+            for (int u = 0; u < WG_TN; u++) {
+                const int c = (nb * WG_TN + u) * 16 + nn;
+                float v = 0.f;
+                if (ok && c < Na) v = ha[(long)r * lda + c];
+                else if (ok && c < N) v = hb[(long)r * ldb + (c - Na)];
+                b[j][u] = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            colsum += a[j];
+#pragma unroll
+            for (int u = 0; u < WG_TN; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j][u], acc[u], 0, 0, 0);
+        }
+    }
+    float* out = ws + (long)chunk * ((long)M * N + M);
+#pragma unroll
+    for (int u = 0; u < WG_TN; u++) {
+        const int c = (nb * WG_TN + u) * 16 + nn;
+        const float v[4] = {acc[u].x, acc[u].y, acc[u].z, acc[u].w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int mr = mt * 16 + 4 * q + i;
+            if (mr < M && c < N) out[(long)mr * N + c] = v[i];
+        }
+    }
+    if (nb == 0) {
+        colsum += __shfl_xor(colsum, 16);
+        colsum += __shfl_xor(colsum, 32);
+        if (q == 0 && m < M) out[(long)M * N + m] = colsum;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(long count_w, long count_b, int chunks, const float* __restrict__ ws, float* __restrict__ dW,
+                                                      float* __restrict__ db) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x, total = count_w + count_b;
+    if (i >= total) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; c++) s += ws[(long)c * total + i];
+    if (i < count_w) dW[i] = s;
+    else db[i - count_w] = s;
+}
+
 template <int NT1, int NT2, bool SEL>
 int launch(int n, int in_a, int in_b, int h1, int h2, int out_dim, const float* xa, int lda, const float* xb, int ldb, const float* W1,
            const float* b1, const float* W2, const float* b2, const float* W3, const float* b3, int act, float scale, float* out,
@@ -343,6 +512,42 @@ int kr_mlp3_forward_shadow(int32_t n, int32_t in_a, int32_t in_b, int32_t h1, in
     KR_WAVE_CASE(4, 4)
 #undef KR_WAVE_CASE
     return KS_ERR_INVALID;
+}
+
+int kr_mlp3_backward_shadow(int32_t n, int32_t in_dim, int32_t h1, int32_t h2, int32_t out_dim, const float* dz3, const float* W3,
+                            const float* h2a, const float* W2, const float* h1a, float* dz2_out, float* dz1_out, const float* W1, int32_t col0,
+                            int32_t ncol, const float* act_out, float scale, float* dx_out, void* stream) {
+    if (n <= 0) return KS_OK;
+    if (!dz3 || !W3 || !h2a || !W2 || !h1a || out_dim < 1 || out_dim > 4 || h1 < 16 || h2 < 16 || h1 % 16 || h2 % 16) return KS_ERR_INVALID;
+    if (dx_out && (!W1 || ncol < 1 || ncol > 4 || col0 < 0 || col0 + ncol > in_dim)) return KS_ERR_INVALID;
+    if ((uintptr_t)h1a % 16 || (uintptr_t)h2a % 16 || (dz1_out && (uintptr_t)dz1_out % 16) || (dz2_out && (uintptr_t)dz2_out % 16)) return KS_ERR_INVALID;
+    const int nt1 = (h1 + 15) / 16, nt2 = (h2 + 15) / 16;
+    const dim3 grid((n + ROWS - 1) / ROWS), block(64);
+    hipStream_t s = (hipStream_t)stream;
+#define KR_BWD_CASE(A, B)                                                                                                                    \
+    if (nt1 == A && nt2 == B) {                                                                                                              \
+        hipLaunchKernelGGL((k_mlp3_bwd_wave<A, B>), grid, block, 0, s, n, in_dim, h1, h2, out_dim, dz3, W3, h2a, W2, h1a, dz2_out, dz1_out, W1, \
+                           col0, ncol, act_out, scale, dx_out);                                                                              \
+        return hipGetLastError() == hipSuccess ? KS_OK : KS_ERR_HIP;                                                                         \
+    }
+    KR_BWD_CASE(16, 16)
+    KR_BWD_CASE(8, 8)
+    KR_BWD_CASE(4, 4)
+#undef KR_BWD_CASE
+    return KS_ERR_INVALID;
+}
+
+int kr_weight_grad_shadow(int32_t n, int32_t M, int32_t Na, int32_t Nb, const float* dz, const float* ha, int32_t lda, const float* hb, int32_t ldb,
+                          int32_t chunks, float* workspace, float* dW, float* db, void* stream) {
+    if (n <= 0 || M < 1 || Na < 1 || Nb < 0 || chunks < 1 || !dz || !ha || (Nb > 0 && !hb) || !workspace || !dW || !db) return KS_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int N = Na + Nb, n_blocks = (N + 16 * WG_TN - 1) / (16 * WG_TN), m_tiles = (M + 15) / 16;
+    int rows_per_chunk = (n + chunks - 1) / chunks;
+    rows_per_chunk = (rows_per_chunk + 15) / 16 * 16;
+    hipLaunchKernelGGL(k_wgrad_wave, dim3(m_tiles * n_blocks, chunks), dim3(64), 0, s, n, M, Na, Nb, rows_per_chunk, dz, ha, lda, hb, ldb, workspace);
+    const long total = (long)M * N + M;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (long)M * N, (long)M, chunks, workspace, dW, db);
+    return hipGetLastError() == hipSuccess ? KS_OK : KS_ERR_HIP;
 }
 
 int kr_actor_select(int32_t n, int32_t h1, int32_t h2, const float* obs, const float* prev_obs, const uint8_t* has_prev, const int64_t* t,

@@ -61,18 +61,24 @@ class NativeDDPGfDUpdate:
         ao, co = policy.actor_optimizer.param_groups[0], policy.critic_optimizer.param_groups[0]
         self.hyper_a = (ao["lr"], ao["betas"][0], ao["betas"][1], ao["eps"], ao["weight_decay"])
         self.hyper_c = (co["lr"], co["betas"][0], co["betas"][1], co["eps"], co["weight_decay"])
-        # Forward passes as fused MFMA launches (mlp.mlp3_forward) when the widths are supported, library GEMMs otherwise:
-        # the forward-only target networks (3200 rows) and the critic's forward with its activations kept for the
-        # backward pass (1600 rows).  The 8000-row forwards of the actor phase stay on the library GEMMs - at that size
-        # three large-tile GEMMs beat the 16-row-tile kernel (measured: 1.48 vs 1.44 ms per env-step in bench.py).
-        self.fuse_critic_fwd, self.fuse_actor_fwd = True, False
-        # ... in their LDS-free form when the widths allow: these launches open the update, and without LDS their waves
-        # are resident beside the stepping kernel (which holds every CU's LDS) instead of waiting for it to finish
+        # How much of the update runs on the hand-written MFMA kernels of csrc/ks_mlp.hip (mlp.py):
+        #  * fused_targets: the forward-only target networks (3200 rows) and the critic's forward (1600 rows, activations
+        #    kept for the backward pass) as ONE launch each instead of three library GEMMs + glue;
+        #  * shadow: ... in their LDS-free form, whose waves are resident beside the stepping kernel (which holds every
+        #    CU's LDS) instead of waiting for its workgroups to retire;
+        #  * lds_free: the backward passes too (mlp.mlp3_backward, mlp.weight_grad) - then no launch of the update needs
+        #    LDS and the whole learner runs in the simulator's shadow.  Widths 256-256 / 128-128 / 64-64.
+        # Otherwise (e.g. the reference's 400-300) the passes go through the library GEMMs (hipBLASLt).
         import os
-        self.shadow = (os.environ.get("KS_EXP_SHADOW", "1") == "1" and _mlp.supported(list(zip(self.actor_t.W, self.actor_t.b)), self.actor_t.W[0].shape[1], shadow=True)
-                       and _mlp.supported(list(zip(self.critic_t.W, self.critic_t.b)), self.critic_t.W[0].shape[1], shadow=True))
-        self.fused_targets = (all(w.shape[0] % 4 == 0 for w in self.critic.W[:2] + self.actor.W[:2]) and _mlp.supported(list(zip(self.actor_t.W, self.actor_t.b)), self.actor_t.W[0].shape[1])
-                              and _mlp.supported(list(zip(self.critic_t.W, self.critic_t.b)), self.critic_t.W[0].shape[1]))
+        tl = [list(zip(net.W, net.b)) for net in (self.actor_t, self.critic_t)]
+        ins = [net.W[0].shape[1] for net in (self.actor_t, self.critic_t)]
+        mult = lambda k: all(w.shape[0] % k == 0 for w in self.critic.W[:2] + self.actor.W[:2])
+        self.fused_targets = mult(4) and all(_mlp.supported(layers, d) for layers, d in zip(tl, ins))
+        self.shadow = self.fused_targets and all(_mlp.supported(layers, d, shadow=True) for layers, d in zip(tl, ins))
+        self.lds_free = self.shadow and mult(16) and os.environ.get("KS_EXP_LDSFREE", "1") == "1"
+        # The 8000-row forwards of the actor phase stay on the library GEMMs unless the update is LDS-free: at that size
+        # three large-tile GEMMs beat the 16-row-tile LDS kernel (measured 1.48 vs 1.44 ms per env-step in bench.py).
+        self.fuse_critic_fwd, self.fuse_actor_fwd = True, False
 
     # -- helpers ------------------------------------------------------------------------------------------------------
     def _st(self):
@@ -135,8 +141,23 @@ class NativeDDPGfDUpdate:
             _, _, ta = self._actor_forward(self.actor_t, nx)
             ct = self.critic_t
             tq = torch.addmm(ct.b[2], self._lin_relu(ct, 1, self._lin_relu(ct, 0, torch.cat([nx, ta], 1))), ct.W[2].t())
-        x0 = torch.cat([state[:, 0], action[:, 0]], 1)
         c = self.critic
+        if self.lds_free:
+            # the whole critic step without LDS: forward, loss gradient, data and weight gradients (csrc/ks_mlp.hip)
+            cl = list(zip(c.W, c.b))
+            s0, a0 = state[:, 0], action[:, 0]
+            h1, h2 = s0.new_empty(R, c.W[0].shape[0]), s0.new_empty(R, c.W[1].shape[0])
+            q = _mlp.mlp3_forward(cl, s0, a0, act=_mlp.ACT_NONE, h1_out=h1, h2_out=h2, shadow=True)
+            dq = torch.empty_like(q)
+            reward = reward.contiguous()
+            self._chk(self.lib.kr_critic_grad(R, pol.n, P(q), P(tq), P(tq[R:]), P(reward), P(weight), P(self.wsum), pol.discount, P(dq), P(self.losses),
+                                              self._st()), "kr_critic_grad")
+            dz2, dz1, _ = _mlp.mlp3_backward(cl, dq, h1, h2)
+            _mlp.weight_grad(dq, h2, None, c.gW[2], c.gb[2])
+            _mlp.weight_grad(dz2, h1, None, c.gW[1], c.gb[1])
+            _mlp.weight_grad(dz1, s0, a0, c.gW[0], c.gb[0])
+            return self.losses[0], self.losses[1], self.losses[2]
+        x0 = torch.cat([state[:, 0], action[:, 0]], 1)
         if self.fused_targets and self.fuse_critic_fwd:
             h1, h2 = x0.new_empty(R, c.W[0].shape[0]), x0.new_empty(R, c.W[1].shape[0])
             q = _mlp.mlp3_forward(list(zip(c.W, c.b)), state[:, 0], action[:, 0], act=_mlp.ACT_NONE, h1_out=h1, h2_out=h2, shadow=self.shadow)
@@ -159,6 +180,21 @@ class NativeDDPGfDUpdate:
         n = state.shape[1]
         sa = state.reshape(-1, state.shape[2])
         a_, c = self.actor, self.critic
+        if self.lds_free:
+            rows = sa.shape[0]
+            al, cl = list(zip(a_.W, a_.b)), list(zip(c.W, c.b))
+            ha1, ha2 = sa.new_empty(rows, a_.W[0].shape[0]), sa.new_empty(rows, a_.W[1].shape[0])
+            a = _mlp.mlp3_forward(al, sa, act=_mlp.ACT_SIGMOID, scale=pol.max_action, h1_out=ha1, h2_out=ha2, shadow=True)
+            hc1, hc2 = sa.new_empty(rows, c.W[0].shape[0]), sa.new_empty(rows, c.W[1].shape[0])
+            _mlp.mlp3_forward(cl, sa, a, act=_mlp.ACT_NONE, h1_out=hc1, h2_out=hc2, shadow=True)           # Q itself is not needed
+            dq = (self.weight / (self.wsum * (-float(n)))).repeat_interleave(n).unsqueeze(1).contiguous()
+            # dLoss/d(actor pre-activation): through the critic to its action inputs, then through 0.8 * sigmoid
+            _, _, dz3 = _mlp.mlp3_backward(cl, dq, hc1, hc2, want_dz=False, dx_cols=(sa.shape[1], a.shape[1]), act_out=a, scale=pol.max_action)
+            dz2, dz1, _ = _mlp.mlp3_backward(al, dz3, ha1, ha2)
+            _mlp.weight_grad(dz3, ha2, None, a_.gW[2], a_.gb[2])
+            _mlp.weight_grad(dz2, ha1, None, a_.gW[1], a_.gb[1])
+            _mlp.weight_grad(dz1, sa, None, a_.gW[0], a_.gb[0])
+            return None
         if self.fused_targets and self.fuse_actor_fwd:
             rows = sa.shape[0]
             ha1, ha2 = sa.new_empty(rows, a_.W[0].shape[0]), sa.new_empty(rows, a_.W[1].shape[0])

@@ -49,3 +49,45 @@ def mlp3_forward(layers, xa: torch.Tensor, xb: torch.Tensor | None = None, act: 
     if rc != 0:
         raise RuntimeError(f"kr_mlp3_forward failed ({rc}): unsupported layer widths or bad arguments")
     return out
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def mlp3_backward(layers, dz3: torch.Tensor, h1: torch.Tensor, h2: torch.Tensor, want_dz: bool = True, dx_cols: tuple[int, int] | None = None,
+                  act_out: torch.Tensor | None = None, scale: float = 1.0):
+    """Data gradients of the 3-layer MLP without LDS (kr_mlp3_backward_shadow).  dz3 [n, out_dim] = dLoss/d(last
+    pre-activation); h1 / h2 the activations of the forward pass.  Returns (dz2, dz1, dx): dz2 / dz1 None unless want_dz;
+    dx [n, ncol] = dLoss/d(input columns col0..col0+ncol) for dx_cols = (col0, ncol), None otherwise - multiplied by the
+    derivative of scale * sigmoid when act_out (that sigmoid's output) is given."""
+    (w1, _), (w2, _), (w3, _) = layers
+    n = dz3.shape[0]
+    assert dz3.is_contiguous() and h1.is_contiguous() and h2.is_contiguous() and tuple(h1.shape) == (n, w1.shape[0]) and tuple(h2.shape) == (n, w2.shape[0])
+    dz2 = torch.empty_like(h2) if want_dz else None
+    dz1 = torch.empty_like(h1) if want_dz else None
+    dx, col0, ncol = None, 0, 0
+    if dx_cols is not None:
+        col0, ncol = dx_cols
+        dx = torch.empty(n, ncol, device=dz3.device, dtype=torch.float32)
+        assert act_out is None or (act_out.is_contiguous() and tuple(act_out.shape) == (n, ncol))
+    lib, P = _sim.load_library(), _sim._ptr
+    rc = lib.kr_mlp3_backward_shadow(n, w1.shape[1], w1.shape[0], w2.shape[0], w3.shape[0], P(dz3), P(w3), P(h2), P(w2), P(h1), P(dz2), P(dz1), P(w1),
+                                     col0, ncol, P(act_out), float(scale), P(dx), _stream(dz3))
+    if rc != 0:
+        raise RuntimeError(f"kr_mlp3_backward_shadow failed ({rc})")
+    return dz2, dz1, dx
+
+
+def weight_grad(dz: torch.Tensor, ha: torch.Tensor, hb: torch.Tensor | None, dW: torch.Tensor, db: torch.Tensor, rows_per_chunk: int = 400):
+    """dW [M, N] = dz^T [ha | hb], db [M] = dz.sum(0) without LDS (kr_weight_grad_shadow), written in place."""
+    n, M = dz.shape
+    Na, Nb = ha.shape[1], (0 if hb is None else hb.shape[1])
+    assert dz.is_contiguous() and ha.stride(1) == 1 and (hb is None or hb.stride(1) == 1) and dW.is_contiguous() and tuple(dW.shape) == (M, Na + Nb)
+    assert db.is_contiguous() and db.numel() == M
+    chunks = max(1, (n + rows_per_chunk - 1) // rows_per_chunk)
+    ws = torch.empty(chunks * (M * (Na + Nb) + M), device=dz.device, dtype=torch.float32)
+    lib, P = _sim.load_library(), _sim._ptr
+    rc = lib.kr_weight_grad_shadow(n, M, Na, Nb, P(dz), P(ha), ha.stride(0), P(hb), 0 if hb is None else hb.stride(0), chunks, P(ws), P(dW), P(db), _stream(dz))
+    if rc != 0:
+        raise RuntimeError(f"kr_weight_grad_shadow failed ({rc})")

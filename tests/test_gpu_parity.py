@@ -701,3 +701,48 @@ def test_curriculum_stage_runs_and_hands_over_to_the_next(tmp_path):
     assert r4["shapes"] == ["CubeS", "CylinderS", "Cube45S", "Vase2S", "CubeB", "CylinderB", "Cube45B", "Vase2B"]
     assert sorted(r4["skipped_shapes"]) == ["BottleB", "BottleS", "BowlB", "BowlS", "TBottleB", "TBottleS"]
     assert set(r4["orientation_counts"]) == {"normal", "rotated", "top"} and r4["updates"] == 1
+
+
+def test_lds_free_backward_matches_autograd():
+    """kr_mlp3_backward_shadow + kr_weight_grad_shadow against torch autograd on the same networks: the critic's
+    gradients for a given dLoss/dQ (all weight / bias gradients and dQ/da), and the actor's for a given dLoss/da
+    through the 0.8 * sigmoid output.  fp32, different summation order: 1e-4 relative to the largest entry."""
+    from kinovagrasping_amd import mlp
+    from kinovagrasping_amd.ddpgfd import Actor, Critic
+    dev = torch.device("cuda", 0)
+    for hidden, n in (((256, 256), 1600), ((256, 256), 8000), ((64, 64), 333)):
+        torch.manual_seed(5)
+        actor, critic = Actor(82, 4, 0.8, hidden).to(dev), Critic(82, 4, hidden).to(dev)
+        s = torch.randn(n, 82, device=dev)
+        a = (0.8 * torch.rand(n, 4, device=dev)).requires_grad_(True)
+        dq = torch.randn(n, 1, device=dev) / n
+        q = critic(s, a)
+        (q * dq).sum().backward()
+        lc = mlp.layers_of(critic)
+        h1, h2 = torch.empty(n, hidden[0], device=dev), torch.empty(n, hidden[1], device=dev)
+        mlp.mlp3_forward(lc, s, a.detach(), h1_out=h1, h2_out=h2, shadow=True)
+        dz2, dz1, da = mlp.mlp3_backward(lc, dq, h1, h2, want_dz=True, dx_cols=(82, 4))
+        close = lambda x, y: (x - y).abs().max().item() <= 1e-4 * max(y.abs().max().item(), 1e-12)
+        assert close(da, a.grad), (hidden, n)
+        for (dz, ha, hb, lin) in ((dq, h2, None, critic.l3), (dz2, h1, None, critic.l2), (dz1, s, a.detach(), critic.l1)):
+            gW, gb = torch.zeros_like(lin.weight), torch.zeros_like(lin.bias)
+            mlp.weight_grad(dz, ha, hb, gW, gb)
+            assert close(gW, lin.weight.grad) and close(gb, lin.bias.grad), (hidden, n, tuple(gW.shape))
+        # actor: dLoss/da given, through a = 0.8 sigmoid(z)
+        pa = actor(s)
+        g = torch.randn(n, 4, device=dev) / n
+        (pa * g).sum().backward()
+        la = mlp.layers_of(actor)
+        mlp.mlp3_forward(la, s, act=mlp.ACT_SIGMOID, scale=0.8, h1_out=h1, h2_out=h2, shadow=True)
+        dz3 = g * pa.detach() * (1 - pa.detach() / 0.8)
+        dz2, dz1, _ = mlp.mlp3_backward(la, dz3.contiguous(), h1, h2)
+        for (dz, ha, lin) in ((dz3.contiguous(), h2, actor.l3), (dz2, h1, actor.l2), (dz1, s, actor.l1)):
+            gW, gb = torch.zeros_like(lin.weight), torch.zeros_like(lin.bias)
+            mlp.weight_grad(dz, ha, None, gW, gb)
+            assert close(gW, lin.weight.grad) and close(gb, lin.bias.grad), (hidden, n, tuple(gW.shape))
+        # the fused sigmoid epilogue of dx: dz3 of an actor whose output pa feeds the critic's action columns
+        _, _, dz3_fused = mlp.mlp3_backward(lc, dq, *( (lambda H1, H2: (mlp.mlp3_forward(lc, s, pa.detach(), h1_out=H1, h2_out=H2, shadow=True), H1, H2)[1:])(torch.empty_like(h1), torch.empty_like(h2)) ),
+                                            want_dz=False, dx_cols=(82, 4), act_out=pa.detach().contiguous(), scale=0.8)
+        pa2 = pa.detach().clone().requires_grad_(True)
+        (critic(s, pa2) * dq).sum().backward()
+        assert close(dz3_fused, pa2.grad * pa.detach() * (1 - pa.detach() / 0.8)), (hidden, n)
