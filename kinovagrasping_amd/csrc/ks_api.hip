@@ -33,6 +33,8 @@ template <typename T> struct Buffers {
     T *hand_quat, *qpos0;         // [4][N], [16][N]   stored initial state
     T *snap;                      // [SNAP_TOTAL][N]
     T *rays;                      // [17][N]
+    T *obs0;                      // [N][82] observation of every env's stored initial state (written by the reset pass):
+                                  // an auto-reset returns this row instead of casting the rays of the initial state again
     T *contact;                   // [NCON_MAX*CON_STRIDE][N] parity tap (last substep)
     T *gscratch;                  // [SCR_TOTAL][N] (fp64 contexts only; fp32 uses LDS)
     T *envp;                      // [2][N] per-env object mass, object-hand friction (config 5 randomisation)
@@ -282,7 +284,8 @@ __global__ __launch_bounds__(WG) void k_substep(const Model<T>* __restrict__ mp,
 }
 
 // (re)initialise flagged envs from their stored initial state
-template <typename T, bool USE_LDS> __global__ __launch_bounds__(WAVE) void k_reset(const Model<T>* __restrict__ mp, Buffers<T> b, int N) {
+template <typename T, bool USE_LDS>
+__global__ __launch_bounds__(WAVE) void k_reset(const Model<T>* __restrict__ mp, Buffers<T> b, int N, int clear_flag) {
     __shared__ T lds[SCR_CON * WAVE];       // forward kinematics only touches the body-pose part of the scratch
     const int env = blockIdx.x * WAVE + threadIdx.x;
     if (env >= N || !b.flag[env]) return;
@@ -299,6 +302,7 @@ template <typename T, bool USE_LDS> __global__ __launch_bounds__(WAVE) void k_re
     store_state(b, env, N, st);
     b.step_count[env] = 0;
     b.ncon[env] = 0;
+    if (clear_flag) b.flag[env] = 0;
 }
 
 // scatter caller-provided initial states into the stored per-env initial state and flag the envs
@@ -368,7 +372,6 @@ __global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ mp, B
     if (mode == 1) {
         if (!b.flag[env]) return;
         b.flag[env] = 0;
-        if (!obs) return;
     }
     Col<T> snap{b.snap + env, N};
     T rays[NRAY];
@@ -387,8 +390,23 @@ __global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ mp, B
         if (info) { info[env] = inf[0]; info[(long)N + env] = inf[1]; info[2L * N + env] = inf[2]; }
         if (d && auto_reset) b.flag[env] = 1;
     }
+    if (mode == 1) {
+        KS_UNROLL
+        for (int j = 0; j < NOBS; j++) b.obs0[(long)env * NOBS + j] = o[j];
+    }
     T* dst = obs;
-    if (mode == 0 && d && auto_reset) dst = final_obs;   // obs row is rewritten by the reset pass
+    if (mode == 0 && d && auto_reset) {
+        // the episode is over: this observation is the terminal one; the env restarts from its stored initial state
+        // (k_reset, next launch), whose observation was computed when that state was set
+        dst = final_obs;
+        if (obs) {
+            for (int j = 0; j < NOBS; j++) {
+                const T v = b.obs0[(long)env * NOBS + j];
+                if (env_major) obs[(long)env * NOBS + j] = v;
+                else obs[(long)j * N + env] = v;
+            }
+        }
+    }
     if (dst) {
         if (env_major) {
             KS_UNROLL
@@ -460,6 +478,7 @@ template <typename T> struct Ctx : CtxBase {
         if ((r = alloc(&b.qpos0, NQ * N))) return r;
         if ((r = alloc(&b.snap, SNAP_TOTAL * N))) return r;
         if ((r = alloc(&b.rays, NRAY * N))) return r;
+        if ((r = alloc(&b.obs0, (size_t)NOBS * N))) return r;
         if ((r = alloc(&b.contact, (size_t)NCON_MAX * CON_STRIDE * N))) return r;
         if (!USE_LDS && (r = alloc(&b.gscratch, (size_t)SCR_TOTAL * N))) return r;
         if ((r = alloc(&b.envp, (size_t)2 * N))) return r;
@@ -563,7 +582,7 @@ template <typename T> struct Ctx : CtxBase {
     }
     int post_reset(void* obs, hipStream_t s) {
         const int N = cfg.n_envs;
-        hipLaunchKernelGGL((k_reset<T, USE_LDS>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N);
+        hipLaunchKernelGGL((k_reset<T, USE_LDS>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0);
         hipLaunchKernelGGL((k_rays<T>), dim3((N + RAY_ENVS - 1) / RAY_ENVS, NRAY), dim3(WAVE), 0, s, d_model, b, N, 1);
         hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 1, cfg.horizon, cfg.auto_reset, cfg.obs_env_major,
                            (T*)obs, (T*)nullptr, (uint8_t*)nullptr, (T*)nullptr, (T*)nullptr);
@@ -588,8 +607,9 @@ template <typename T> struct Ctx : CtxBase {
         hipLaunchKernelGGL((k_rays<T>), dim3((N + RAY_ENVS - 1) / RAY_ENVS, NRAY), dim3(WAVE), 0, s, d_model, b, N, 0);
         hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0, cfg.horizon, cfg.auto_reset, cfg.obs_env_major,
                            (T*)obs, (T*)reward, done, (T*)info, (T*)final_obs);
+        // auto-reset: flagged envs restart from their stored initial state; their observation came from the cache above
+        if (cfg.auto_reset) hipLaunchKernelGGL((k_reset<T, USE_LDS>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 1);
         HIPCHK(hipGetLastError());
-        if (cfg.auto_reset) return post_reset(obs, s);
         return KS_OK;
     }
     int substep(const void* ctrl, hipStream_t s) override {
