@@ -1,21 +1,24 @@
-"""DDPGfD update without autograd: explicit forward / backward GEMMs (PyTorch -> hipBLASLt, matrix cores) with the
-elementwise steps between them as single kernels of libkinova_sim.so (include/kinova_rollout.h).
+"""DDPGfD update without autograd (DDPGfD.train_batch, DDPGfD.py:219-367 of the reference), in two forms:
 
-The eager update (ddpgfd.DDPGfD.train_on_batch: autograd + torch.optim.Adam) is ~180 kernel launches of a few
-microseconds each for two 3-layer MLPs - on MI355X the launches, not the arithmetic, are the cost.  This module does
-the same update in ~75 launches:
+* **LDS-free MFMA kernels** (widths 256-256 / 128-128 / 64-64; `lds_free`): every forward, data-gradient and
+  weight-gradient pass is a hand-written fp32-MFMA launch of libkinova_sim.so (csrc/ks_mlp.hip, mlp.py) that keeps its
+  tiles in registers - one wave per 16 batch rows, <= 168 registers per lane, no LDS.  The simulator's stepping kernel
+  holds all of every CU's LDS and 344 of the 512 registers per SIMD lane, so these waves are resident BESIDE it: the
+  whole update runs in the stepping kernel's shadow on the matrix pipes and issue slots it leaves idle
+  (pipeline.GraphedTrainer launches it on a second stream), instead of waiting for its workgroups to retire as the
+  library GEMMs (which need LDS) must.  ~35 launches per update.
+* **library GEMMs** (any width, e.g. the reference's 400-300): explicit forward / backward GEMMs (PyTorch -> hipBLASLt)
+  with the elementwise steps between them as single kernels (kr_relu_backward, ...), weight gradients written by the
+  GEMMs straight into one flat gradient buffer per network; the forward-only target networks and the critic forward
+  still go through the fused LDS kernel (kr_mlp3_forward) when the width has an instantiation.  ~75 launches.
 
-  * forward layers are addmm with the ReLU fused in the GEMM epilogue (torch._addmm_activation);
-  * weight gradients are written by the GEMMs straight into one flat gradient buffer per network
-    (torch.mm(..., out=view)), bias gradients by column sums;
-  * targets + critic loss gradient, ReLU / sigmoid backward, Adam and the soft target update are one kernel each
-    (kr_critic_grad, kr_relu_backward, kr_sigmoid_scale_backward, kr_adam_step, kr_soft_update);
-  * with world_size > 1 the flat gradient buffers are all-reduced directly (no pack / unpack).
-
-Same arithmetic as DDPGfD.py:219-367 of the reference (critic loss L1 + 0.5 LN on masked row means, actor loss
--mean Q(s, pi(s)) over all n-step rows, Adam lr 1e-4 / default lr + weight_decay 1e-4, soft target update every 10th
-call); tests/test_gpu_parity.py checks it against the autograd implementation.  The three `phase_*` methods mirror
-DDPGfD.phase_* so that pipeline.GraphedTrainer can capture them and run the gradient exchange between them.
+Common to both: targets + critic loss gradient, Adam and the soft target update are one kernel each (kr_critic_grad,
+kr_adam_step, kr_soft_update); with world_size > 1 the flat gradient buffers are all-reduced directly (no pack /
+unpack).  Same arithmetic as the reference (critic loss L1 + 0.5 LN on masked row means, actor loss -mean Q(s, pi(s))
+over all n-step rows, Adam lr 1e-4 / default lr + weight_decay 1e-4, soft target update every 10th call);
+tests/test_gpu_parity.py checks both forms against the autograd implementation (ddpgfd.DDPGfD.train_on_batch).  The
+three `phase_*` methods mirror DDPGfD.phase_* so that pipeline.GraphedTrainer can capture them and run the gradient
+exchange between them.
 """
 from __future__ import annotations
 

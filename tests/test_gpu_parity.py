@@ -327,17 +327,20 @@ def test_rollout_kernels_equal_torch_bookkeeping():
         assert torch.equal(x, y)
 
 
-def test_native_learner_update_equals_autograd_update():
-    """learner_native (explicit GEMMs + kr_* glue kernels) against DDPGfD.train_on_batch (autograd + torch.optim.Adam):
-    same losses and the same parameters / targets after several updates on masked fixed-shape batches."""
+@pytest.mark.parametrize("hidden,form", [((256, 256), "lds_free"), ((400, 300), "library_gemm")])
+def test_native_learner_update_equals_autograd_update(hidden, form):
+    """learner_native against DDPGfD.train_on_batch (autograd + torch.optim.Adam): same losses and the same parameters /
+    targets after several updates on masked fixed-shape batches - in both of its forms: the LDS-free MFMA kernels
+    (BASELINE widths 256-256) and the library GEMMs + kr_* glue kernels (the reference's 400-300)."""
     from kinovagrasping_amd.ddpgfd import DDPGfD
     from kinovagrasping_amd.learner_native import NativeDDPGfDUpdate
     dev = torch.device("cuda", 0)
     torch.manual_seed(7)
-    pa = DDPGfD(82, 4, 0.8, 5, hidden=(256, 256), device=dev)
+    pa = DDPGfD(82, 4, 0.8, 5, hidden=hidden, device=dev)
     torch.manual_seed(7)
-    pb = DDPGfD(82, 4, 0.8, 5, hidden=(256, 256), device=dev)
+    pb = DDPGfD(82, 4, 0.8, 5, hidden=hidden, device=dev)
     nat = NativeDDPGfDUpdate(pb)
+    assert nat.lds_free == (form == "lds_free") and nat.fused_targets
     g = torch.Generator(device=dev).manual_seed(3)
     R, n = 320, 5
     for it in range(12):                      # crosses the soft target update of the 10th call
@@ -741,8 +744,9 @@ def test_lds_free_backward_matches_autograd():
             mlp.weight_grad(dz, ha, None, gW, gb)
             assert close(gW, lin.weight.grad) and close(gb, lin.bias.grad), (hidden, n, tuple(gW.shape))
         # the fused sigmoid epilogue of dx: dz3 of an actor whose output pa feeds the critic's action columns
-        _, _, dz3_fused = mlp.mlp3_backward(lc, dq, *( (lambda H1, H2: (mlp.mlp3_forward(lc, s, pa.detach(), h1_out=H1, h2_out=H2, shadow=True), H1, H2)[1:])(torch.empty_like(h1), torch.empty_like(h2)) ),
-                                            want_dz=False, dx_cols=(82, 4), act_out=pa.detach().contiguous(), scale=0.8)
+        k1, k2 = torch.empty_like(h1), torch.empty_like(h2)
+        mlp.mlp3_forward(lc, s, pa.detach(), h1_out=k1, h2_out=k2, shadow=True)
+        _, _, dz3_fused = mlp.mlp3_backward(lc, dq, k1, k2, want_dz=False, dx_cols=(82, 4), act_out=pa.detach().contiguous(), scale=0.8)
         pa2 = pa.detach().clone().requires_grad_(True)
         (critic(s, pa2) * dq).sum().backward()
         assert close(dz3_fused, pa2.grad * pa.detach() * (1 - pa.detach() / 0.8)), (hidden, n)
