@@ -105,6 +105,7 @@ def main():
             torch.cuda.synchronize()
 
     updates = 0
+    learner_form = "none" if args.mode == "sim" else "autograd"
     if args.mode == "sim":
         base = scenarios.config_actions(min(n, 256), 30, base_seed=1000 + rank * n)
         acts = torch.as_tensor(np.tile(base, (1, 1, (n + base.shape[2] - 1) // base.shape[2]))[:, :, :n]).to(dev)
@@ -125,6 +126,7 @@ def main():
             eng.start(obs0)
             trainer = GraphedTrainer(sim, policy, replay, eng, batch_episodes=64, overlap=not args.serial_learner)
             trainer.capture()
+            learner_form = "lds-free fp32-mfma kernels" if trainer.native.lds_free else "library gemms + kr_* glue"
 
             def step_fn(t):
                 nonlocal updates
@@ -204,6 +206,7 @@ def main():
                        "mode": args.mode, "envs_per_gpu": n, "frame_skip": 15, "solver": "newton x6", "hidden": list(args.hidden),
                        "learner_updates_timed": updates - upd0 if args.mode == "ddpg" else 0, "priming_steps": priming,
                        "launch": ("eager" if args.eager else "hip-graphs") if args.mode == "ddpg" else "direct",
+                       "learner": learner_form,
                        "parallelism": f"env-shard x{world}" + (" + grad all-reduce" if world > 1 and args.mode == "ddpg" else "")},
             "roofline": {"bound": "hbm", "kernel": "k_env_step", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_note": traffic_note,
