@@ -105,6 +105,7 @@ def main():
             torch.cuda.synchronize()
 
     updates = 0
+    trainer = None
     learner_form = "none" if args.mode == "sim" else "autograd"
     if args.mode == "sim":
         base = scenarios.config_actions(min(n, 256), 30, base_seed=1000 + rank * n)
@@ -174,6 +175,8 @@ def main():
     t0 = time.perf_counter()
     for t in range(args.steps):
         step_fn(priming + args.warmup + t)
+    if trainer is not None:
+        trainer.flush()                                    # the last step's deferred replay-ring update belongs to the timed work
     t_issue = time.perf_counter() - t0                 # host time to issue the timed steps (before the device catches up)
     barrier()
     dt = time.perf_counter() - t0

@@ -43,7 +43,8 @@ class GraphedTrainer:
         self.side = torch.cuda.Stream(self.dev)
         self.acted = torch.cuda.Event()
         self.head_done = torch.cuda.Event()
-        self.g_pre = self.g_post = None
+        self.g_pre = self.g_post = self.g_commit = None
+        self.defer_commit = self.pending_commit = False
         self.g_learn = []
         self.losses = None
         # the update itself: explicit GEMMs + fused glue kernels (learner_native), same arithmetic as policy.train_on_batch
@@ -103,9 +104,17 @@ class GraphedTrainer:
         mode = dict(capture_error_mode="thread_local")
         with torch.cuda.graph(self.g_pre, **mode):
             eng.pre()
+        # With the learner on its own stream the ring update of a step (rank / commit / advance) is deferred to the start of
+        # the NEXT step on that stream, ahead of the window sampling that needs it: three launches less between two
+        # launches of the stepping kernel.
+        self.defer_commit = self.overlap and eng.native and eng.replay is not None
         self.g_post = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_post, **mode):
-            eng.post()
+            eng.post(commit=not self.defer_commit)
+        if self.defer_commit:
+            self.g_commit = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_commit, **mode):
+                eng.commit()
         self.g_head = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_head, **mode):
             self._head()
@@ -136,20 +145,37 @@ class GraphedTrainer:
         main, side = self.main, self.side
         self.g_pre.replay()
         learn = self.steps >= self.learn_after
-        if learn and self.overlap:
+        if self.overlap and (learn or self.pending_commit):
             self.acted.record(main)
         self.sim.step(self.eng.action_t)
-        if learn:
-            if self.overlap:
+        if self.overlap:
+            if learn or self.pending_commit:
                 side.wait_event(self.acted)        # the actor's weights are free once this step's forward is done
                 with torch.cuda.stream(side):
-                    self.g_head.replay()
+                    self._commit_pending()         # episodes that finished in the previous step enter the ring
+                    if learn:
+                        self.g_head.replay()
                     self.head_done.record(side)
-                    self._body()
-                main.wait_event(self.head_done)    # windows sampled, actor weights settled: the body runs on its own
-            else:
-                self.g_head.replay()
-                self._body()
+                    if learn:
+                        self._body()
+                main.wait_event(self.head_done)    # ring updated, windows sampled, actor weights settled: the body runs on its own
+        elif learn:
+            self.g_head.replay()
+            self._body()
         self.g_post.replay()
+        self.pending_commit = self.defer_commit
         self.steps += 1
         return self.eng.reward_out, self.eng.done_out
+
+    def _commit_pending(self):
+        if self.pending_commit:
+            self.g_commit.replay()
+            self.pending_commit = False
+
+    def flush(self):
+        """Apply the deferred ring update of the last step (call before reading the replay from the host)."""
+        if self.pending_commit:
+            self.side.wait_stream(self.main)
+            with torch.cuda.stream(self.side):
+                self._commit_pending()
+            self.main.wait_stream(self.side)

@@ -132,8 +132,17 @@ class RolloutEngine:
         return self.action
 
     @torch.no_grad()
-    def post(self):
-        """Consume the sim's output buffers: replay writes and per-env bookkeeping for the next step."""
+    def commit(self):
+        """Second half of post(commit=False): move the episodes that finished in the last stored step from the open-episode
+        buffers into the replay ring (kr_rank_episodes / kr_commit_episodes / kr_advance_ring).  Must run before the next
+        post(); pipeline.GraphedTrainer runs it on the learner's stream at the start of the next env-step."""
+        if self.native and self.replay is not None:
+            self.replay.commit_native(self._keep, self.done_out)
+
+    @torch.no_grad()
+    def post(self, commit=True):
+        """Consume the sim's output buffers: replay writes and per-env bookkeeping for the next step.  commit=False
+        (kernel path only) leaves the ring update to commit()."""
         sim = self.sim
         if self.native:
             rp, P = self.replay, self._ptr
@@ -146,7 +155,7 @@ class RolloutEngine:
                                                P(self.reward_out), P(self.done_out), P(self._keep), self._stream())
             if rc != 0:
                 raise RuntimeError(f"kr_store_transition failed ({rc})")
-            if rp is not None:
+            if rp is not None and commit:
                 rp.commit_native(self._keep, self.done_out)
             return
         obs, reward = sim.obs, sim.reward

@@ -387,6 +387,7 @@ def test_graphed_trainer_runs_rollout_and_updates():
     for _ in range(70):
         rew, done = tr.step()
         ep_done += int(done.sum())
+    tr.flush()
     torch.cuda.synchronize()
     assert tr.updates >= 35 and ep_done >= 2 * n
     assert replay.count >= n                               # every env committed at least one episode
