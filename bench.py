@@ -187,6 +187,15 @@ def main():
         dt = tt.item()
     status = sim.get_state()["status"]
     bad = int((status & 2).ne(0).sum().item())
+    # replicas must hold bit-identical weights after the all-reduced updates: spread of two checksums over the ranks
+    replica_spread = None
+    if world > 1 and args.mode == "ddpg":
+        chk = torch.stack([f(policy._flat_params[k].double()) for k in ("actor", "critic", "actor_target", "critic_target")
+                           for f in (torch.sum, lambda x: x.abs().sum())])
+        hi, lo = chk.clone(), chk.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        replica_spread = float((hi - lo).abs().max().item())
     if rank == 0:
         value = n * world * args.steps / dt
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
@@ -217,6 +226,7 @@ def main():
                          "avg_launch_ms": round(kern_ms, 4), "launches_timed": launches,
                          "note": "algorithmic 768 B/env-step x envs per launch; the path is latency/VALU bound, not HBM bound (SURVEY 8d)"},
             "nonfinite_envs": bad,
+            "replica_weight_checksum_spread": replica_spread,
             "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 4),
         }
         if world == 1 and not args.no_cpu_baseline:
