@@ -220,3 +220,32 @@ def test_curriculum_tables_equal_the_reference(golden_dir):
     assert str(plan["dirs"]["policy_dir"]) == "/tmp/x/rl_experiments/no_grasp/stage2/shapes_sizes_orientations/policy"
     assert str(plan["dirs"]["prev_replay_dir"]) == "/tmp/x/rl_experiments/no_grasp/stage1/shapes/replay_buffer"
     assert len(plan["requested_shapes"]) == 14 and plan["requested_shapes"][:2] == ["CubeS", "CylinderS"]
+
+
+def test_heatmap_files_equal_the_reference(golden_dir, tmp_path):
+    """metrics.save_heatmap_coords writes the same files with the same contents as the reference's
+    filter_heatmap_coords for the same evaluation outcomes (tests/golden/heatmap.npz, tools/gen_golden_heatmap.py);
+    ScalarLog carries the reference's tensorboard tags."""
+    import os
+    from kinovagrasping_amd import metrics
+    g = np.load(golden_dir / "heatmap.npz")
+    sc = {"x": [], "y": [], "orientation": []}
+    fc = {"x": [], "y": [], "orientation": []}
+    for x, y, o, ok in zip(g["x"], g["y"], g["orientation"], g["success"]):
+        c = sc if ok else fc
+        c["x"].append(float(x)); c["y"].append(float(y)); c["orientation"].append(str(o))
+    metrics.save_heatmap_coords(sc, fc, 300, tmp_path)
+    names = sorted(os.path.relpath(os.path.join(r, f), tmp_path) for r, _, fs in os.walk(tmp_path) for f in fs)
+    assert names == [str(n) for n in g["names"]]
+    for n in names:
+        if n.endswith(".npy"):
+            assert np.array_equal(np.load(tmp_path / n), g["file:" + n]), n
+        else:
+            assert (tmp_path / n).read_text().replace(str(tmp_path), "<DIR>") == str(g["text:" + n]), n
+    log = metrics.ScalarLog(tmp_path / "tb", eval_freq=200)
+    log.write_eval(400, 12.5, {"finger_reward": 0.0, "grasp_reward": 0.0, "lift_reward": 12.5}, -1.0, 2.0, 1.5, 0.5)
+    rec = log.read()
+    assert [r["tag"] for r in rec][:2] == ["Episode total reward, Avg. 200 episodes", "Episode finger reward, Avg. 200 episodes"]
+    assert rec[-1] == {"tag": "Critic LNloss", "value": 0.5, "step": 400} and len(rec) == 8
+    metrics.save_boxplot_rewards(tmp_path / "box", 400, [[0.0, 0.0]], [[0.0, 0.0]], [[50.0, 0.0]], [[50.0, 0.0]])
+    assert np.load(tmp_path / "box" / "lift_reward_400.npy").tolist() == [[50.0, 0.0]]
