@@ -79,19 +79,25 @@ __global__ __launch_bounds__(WAVE) void k_store_transition(int n, int H, int n_s
     }
 }
 
-__global__ __launch_bounds__(1024) void k_rank_episodes(int n, const uint8_t* __restrict__ keep, int64_t* __restrict__ rank, int64_t* total) {
-    using Scan = hipcub::BlockScan<int, 1024>;
-    __shared__ typename Scan::TempStorage tmp;
-    const int per = (n + 1023) / 1024, i0 = threadIdx.x * per, i1 = min(i0 + per, n);
+// One wavefront, no LDS (so that the launch can run while the stepping kernel holds the CUs' LDS): every lane counts a
+// contiguous slice of the flags, the lane totals are scanned with shuffles, the ranks written back per slice.
+__global__ __launch_bounds__(WAVE) void k_rank_episodes(int n, const uint8_t* __restrict__ keep, int64_t* __restrict__ rank, int64_t* total) {
+    const int lane = threadIdx.x;
+    const int per = (n + WAVE - 1) / WAVE, i0 = min(lane * per, n), i1 = min(i0 + per, n);
     int local = 0;
     for (int i = i0; i < i1; i++) local += keep[i] != 0;
-    int before = 0, all = 0;
-    Scan(tmp).ExclusiveSum(local, before, all);
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    int before = incl - local;
     for (int i = i0; i < i1; i++) {
         before += keep[i] != 0;
         rank[i] = before;
     }
-    if (threadIdx.x == 0) total[0] = all;
+    if (lane == WAVE - 1) total[0] = incl;
 }
 
 // one wave per env; only kept envs move data
@@ -262,7 +268,7 @@ int kr_store_transition(int32_t n, int32_t horizon, int32_t n_steps, int32_t aut
 
 int kr_rank_episodes(int32_t n, const uint8_t* keep, int64_t* rank, int64_t* total, void* stream) {
     if (n <= 0 || !keep || !rank || !total) return KS_ERR_INVALID;
-    hipLaunchKernelGGL(k_rank_episodes, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, keep, rank, total);
+    hipLaunchKernelGGL(k_rank_episodes, dim3(1), dim3(WAVE), 0, (hipStream_t)stream, n, keep, rank, total);
     return launched();
 }
 
