@@ -352,9 +352,20 @@ template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model
             best = ray_ground(m, pnt, vec);
             if (best >= 0) pub[threadIdx.x] = best;
         }
+#ifdef KS_RAY_COUNT
+        // diagnostic build: ray_mesh returns its node visits; they go to the contact tap buffer, rows ray * 8 + (g - 1)
+        T cnt = T(0);
+        if (m.geom_body[g] != sb) {
+            cnt = ray_geom(m, snap, g, pnt, vec, GroupBound<T>{(KS_LDS T*)pub + (threadIdx.x & ~7), (int)(threadIdx.x & 7)},
+                           LdsStack<T>{(KS_LDS unsigned*)stk + threadIdx.x, WAVE});
+            if (cnt < 0) cnt = T(0);
+        }
+        b.contact[((long)ray * 8 + (g - 1)) * N + env] = cnt;
+#else
         if (m.geom_body[g] != sb)
             best = ray_nearer(best, ray_geom(m, snap, g, pnt, vec, GroupBound<T>{(KS_LDS T*)pub + (threadIdx.x & ~7), (int)(threadIdx.x & 7)},
                                               LdsStack<T>{(KS_LDS unsigned*)stk + threadIdx.x, WAVE}));
+#endif
     }
     KS_UNROLL
     for (int mask = 1; mask < 8; mask <<= 1) best = ray_nearer(best, (T)__shfl_xor(best, mask));

@@ -60,6 +60,22 @@ template <typename T> KS_HD T bvh_box_entry(const float* bx, const T* lp, const 
     T hi[3] = {T(bx[3]) + T(1e-6), T(bx[4]) + T(1e-6), T(bx[5]) + T(1e-6)};
     return ray_box_entry(lp, lv, lo, hi, tmax);
 }
+// The same test for the traversal, with the reciprocals of the direction computed once per walk (inv[a] = 1 / d[a],
+// par[a]: the ray is parallel to the slab): multiplications instead of 6 divisions per box, no branches.  A product with
+// a rounded reciprocal is within 1.5 ulp of the quotient; the 1e-6 padding of the boxes is orders of magnitude wider.
+template <typename T> KS_HD T bvh_box_entry_inv(const float* bx, const T* lp, const T* inv, const bool* par, T tmax) {
+    T t0 = 0, t1 = tmax;
+    bool miss = false;
+    KS_UNROLL
+    for (int a = 0; a < 3; a++) {
+        const T lo = T(bx[a]) - T(1e-6), hi = T(bx[3 + a]) + T(1e-6);
+        const T ta = (lo - lp[a]) * inv[a], tb = (hi - lp[a]) * inv[a];
+        const T tn = ta < tb ? ta : tb, tf = ta < tb ? tb : ta;
+        if (par[a]) miss = miss || lp[a] < lo || lp[a] > hi;
+        else { t0 = tn > t0 ? tn : t0; t1 = tf < t1 ? tf : t1; }
+    }
+    return (miss || t0 > t1) ? T(-1) : t0;
+}
 KS_HD int float_bits(float f) {
     int i;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -136,7 +152,17 @@ KS_HD T ray_mesh(const float* tri, const float* wnode, const T* size, const T* l
     }
     T best = T(-1);
     int node = 0;
+    T inv[3];
+    bool par[3];
+    KS_UNROLL
+    for (int a = 0; a < 3; a++) { par[a] = kabs(lv[a]) < T(1e-15); inv[a] = par[a] ? T(0) : T(1) / lv[a]; }
+#ifdef KS_RAY_COUNT
+    int visits_ = 0;
+#endif
     for (;;) {
+#ifdef KS_RAY_COUNT
+        visits_++;
+#endif
         float w[16];
         KS_UNROLL
         for (int i = 0; i < 16; i++) w[i] = wnode[16 * (long)node + i];
@@ -163,7 +189,7 @@ KS_HD T ray_mesh(const float* tri, const float* wnode, const T* size, const T* l
         } else {
             // both children's boxes are in the record; the farther one waits on the stack with its entry t
             const T tmax = bound(best);
-            const T ta = bvh_box_entry(w, lp, lv, tmax), tb = bvh_box_entry(w + 6, lp, lv, tmax);
+            const T ta = bvh_box_entry_inv(w, lp, inv, par, tmax), tb = bvh_box_entry_inv(w + 6, lp, inv, par, tmax);
             if (ta >= 0 && tb >= 0) {
                 const bool a_first = ta <= tb;
                 stack.push(a_first ? b : a, a_first ? tb : ta);
@@ -184,6 +210,9 @@ KS_HD T ray_mesh(const float* tri, const float* wnode, const T* size, const T* l
         }
         if (!found) break;
     }
+#ifdef KS_RAY_COUNT
+    return T(visits_);
+#endif
     return best;
 }
 
