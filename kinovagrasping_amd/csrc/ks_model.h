@@ -8,7 +8,8 @@ namespace ks {
 
 constexpr int NQ = 16, NV = 15, NU = 9, NBODY = 10, NGEOM = 9, NSITE = 17, NSENSOR = 26, NOBS = 82;
 constexpr int NPAIR_MAX = 32;
-constexpr int RAY_STACK = 16;   // depth bound of the ray-casting hierarchies (ks_obs.h: ray_mesh), checked at load
+constexpr int RAY_STACK = 24;   // pending-node bound of the ray-casting hierarchies (ks_obs.h: ray_mesh), checked at load
+constexpr int RAY_EMPTY = (int)0x80000000;   // unused child slot of a 4-wide node
 constexpr int NCON_MAX = 24;   // contacts kept per env per substep (oracle: KO_NCON_MAX)
 constexpr int NRAY = 17;
 constexpr int SUPPORT_R = 16, SUPPORT_CELLS = 6 * SUPPORT_R * SUPPORT_R;   // cube-map resolution of the support start tables
@@ -45,7 +46,7 @@ template <typename T> struct Model {
     const T* mesh_vert[4];     // [nvert_pad][4] (x,y,z,0) in the geom frame; rows >= nvert repeat vertex 0
     // rangefinder geometry: the original mesh triangles (geom frame) under a bounding-volume hierarchy
     const float* mesh_tri[4];      // [ntri][9], leaf ranges contiguous
-    const float* mesh_bvh_box[4];  // [nnode][16] wide nodes: child A box (min xyz, max xyz), child B box, child ids
+    const float* mesh_bvh_box[4];  // [wide nodes][32] 4-wide ray hierarchy: 4 child boxes (min xyz, max xyz), 4 child words, padding (ks_model_host.h)
                                    // (int bits; leaf: first triangle, -count), 2 pad
     const int* mesh_bvh_lr[4];     // [nnode][2] internal: (left, right); leaf: (first triangle, -count)
     // vertex adjacency of the hull graph in chunks of 4 neighbour ids (uint16, ascending, padded with the

@@ -192,37 +192,57 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
             if (!blob_find(b, n, nm, rl) || rl.code != 1 || rl.shape[0] != rb.shape[0]) { e = std::string("missing ") + nm; return false; }
             hm.tri[s].resize(rt.count); std::memcpy(hm.tri[s].data(), rt.data, rt.count * 4);
             hm.bvh_lr[s].resize(rl.count); std::memcpy(hm.bvh_lr[s].data(), rl.data, rl.count * 4);
-            // wide nodes for the traversal: one 64-byte record per node = the boxes of BOTH children (12 floats) + the two
-            // child ids (leaf: first triangle, -count) as int bit patterns + padding -> one visit = one cache line
+            // 4-wide nodes for the traversal, collapsed from the binary hierarchy of the blob: a node's children are its
+            // grandchildren (a child that is a leaf stays one slot).  One 128-byte record = one L2 line: 4 boxes (24 floats),
+            // 4 child words (>= 0: wide node id; < 0: leaf, -(1 + first_triangle * 8 + count); RAY_EMPTY: unused slot whose
+            // box is inverted so that it is always missed), 4 words of padding.  Half the levels of the binary tree means half
+            // the dependent memory round trips per walk.
             {
                 std::vector<float> nb(rb.count);
                 std::memcpy(nb.data(), rb.data, rb.count * 4);
                 const int nn = (int)(rl.count / 2);
-                {
-                    // limits of the traversal (ks_obs.h): 16-bit node ids, at most RAY_STACK pending far children
-                    std::vector<int> depth(nn, 0);
-                    int deepest = nn > 0 ? 1 : 0;
-                    if (nn > 0) depth[0] = 1;
-                    for (int i = 0; i < nn; i++) {       // children follow their parent in the node order
-                        const int a = hm.bvh_lr[s][2 * i], b = hm.bvh_lr[s][2 * i + 1];
-                        if (b < 0) continue;
-                        if (a <= i || b <= i || a >= nn || b >= nn) { hm.error = "ray hierarchy: child ids out of order"; return false; }
-                        depth[a] = depth[b] = depth[i] + 1;
-                        if (depth[a] > deepest) deepest = depth[a];
-                    }
-                    if (nn > 65535 || deepest > RAY_STACK + 1) { hm.error = "ray hierarchy too large (nodes > 65535 or depth > 17)"; return false; }
-                }
-                hm.bvh_box[s].assign((size_t)nn * 16, 0.0f);
+                const std::vector<int>& lr = hm.bvh_lr[s];
                 for (int i = 0; i < nn; i++) {
-                    const int a = hm.bvh_lr[s][2 * i], b = hm.bvh_lr[s][2 * i + 1];
-                    float* w = &hm.bvh_box[s][(size_t)i * 16];
-                    if (b >= 0) {
-                        std::memcpy(w, &nb[6 * (size_t)a], 24);
-                        std::memcpy(w + 6, &nb[6 * (size_t)b], 24);
-                    }
-                    std::memcpy(w + 12, &a, 4);
-                    std::memcpy(w + 13, &b, 4);
+                    const int ca = lr[2 * i], cb = lr[2 * i + 1];
+                    if (cb >= 0 && (ca <= i || cb <= i || ca >= nn || cb >= nn)) { hm.error = "ray hierarchy: child ids out of order"; return false; }
+                    if (cb < 0 && (-cb > 7 || ca < 0)) { hm.error = "ray hierarchy: leaf with more than 7 triangles"; return false; }
                 }
+                std::vector<float>& W = hm.bvh_box[s];
+                W.clear();
+                struct Item { int bnode, wide, depth; };
+                std::vector<Item> todo;
+                auto new_wide = [&]() { const int id = (int)(W.size() / 32); W.resize(W.size() + 32, 0.0f); return id; };
+                int deepest = 0;
+                if (nn > 0) { todo.push_back({0, new_wide(), 1}); }
+                while (!todo.empty()) {
+                    const Item it = todo.back();
+                    todo.pop_back();
+                    if (it.depth > deepest) deepest = it.depth;
+                    int kids[4], nk = 0;
+                    if (lr[2 * it.bnode + 1] < 0) kids[nk++] = it.bnode;                 // the whole mesh is one leaf
+                    else {
+                        for (int c = 0; c < 2; c++) {
+                            const int ch = lr[2 * it.bnode + c];
+                            if (lr[2 * ch + 1] < 0) kids[nk++] = ch;
+                            else { kids[nk++] = lr[2 * ch]; kids[nk++] = lr[2 * ch + 1]; }
+                        }
+                    }
+                    for (int k = 0; k < 4; k++) {
+                        float box[6] = {1.0f, 1.0f, 1.0f, -1.0f, -1.0f, -1.0f};
+                        int word = RAY_EMPTY;
+                        if (k < nk) {
+                            const int ch = kids[k];
+                            std::memcpy(box, &nb[6 * (size_t)ch], 24);
+                            if (lr[2 * ch + 1] < 0) word = -(1 + lr[2 * ch] * 8 + (-lr[2 * ch + 1]));
+                            else { word = new_wide(); todo.push_back({ch, word, it.depth + 1}); }
+                        }
+                        float* w = &W[(size_t)it.wide * 32];             // (W may have been reallocated by new_wide)
+                        std::memcpy(w + 6 * k, box, 24);
+                        std::memcpy(w + 24 + k, &word, 4);
+                    }
+                }
+                // limits of the traversal (ks_obs.h): 16-bit node ids on the stack, at most 3 pending children per level
+                if (W.size() / 32 > 65535 || 3 * deepest > RAY_STACK) { hm.error = "ray hierarchy too large (wide nodes > 65535 or depth > RAY_STACK / 3)"; return false; }
             }
             m.mesh_ntri[s] = (int)rt.shape[0];
             m.mesh_nnode[s] = (int)rb.shape[0];

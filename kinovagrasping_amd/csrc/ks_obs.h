@@ -97,7 +97,7 @@ KS_HD float bits_float(int i) {
 
 // Ray vs mesh geom, MuJoCo's mj_rayMesh semantics: bounding-box pre-test (geom_size about the geom origin),
 // then the faces of the ORIGINAL triangle mesh, both orientations, nearest t >= 0 (-1 = miss).  The faces
-// are visited through a bounding-volume hierarchy of wide nodes (one 64-byte record holds both children's boxes),
+// are visited through a bounding-volume hierarchy of 4-wide nodes (one 128-byte record holds four children's boxes),
 // nearer child first, so that the nearest hit found so far prunes the rest; the result is the minimum over all
 // faces, exactly what the exhaustive oracle computes.
 // `bound(best)`: the pruning distance for the traversal, given this lane's nearest hit so far (-1 = none).  The serial
@@ -107,6 +107,24 @@ KS_HD float bits_float(int i) {
 struct OwnBound {
     template <typename T> KS_HD T operator()(T best) const { return best < 0 ? Lim<T>::big : best; }
 };
+
+// ray vs one triangle (9 floats), both orientations: parameter t >= 0 of the hit, -1 = miss
+template <typename T> KS_HD T ray_tri(const float* v, const T* lp, const T* lv) {
+    T v0[3] = {T(v[0]), T(v[1]), T(v[2])}, e1[3] = {T(v[3]) - v0[0], T(v[4]) - v0[1], T(v[5]) - v0[2]};
+    T e2[3] = {T(v[6]) - v0[0], T(v[7]) - v0[1], T(v[8]) - v0[2]}, pv[3], tv[3], qv[3];
+    cross3(pv, lv, e2);
+    T det = dot3(e1, pv);
+    if (kabs(det) < T(1e-30)) return T(-1);
+    T inv = T(1) / det;
+    sub3(tv, lp, v0);
+    T u = dot3(tv, pv) * inv;
+    if (u < 0 || u > 1) return T(-1);
+    cross3(qv, tv, e1);
+    T ww = dot3(lv, qv) * inv;
+    if (ww < 0 || u + ww > 1) return T(-1);
+    T tt = dot3(e2, qv) * inv;
+    return tt >= 0 ? tt : T(-1);
+}
 
 // Traversal stack of ray_mesh: the far child of a node waits here with its entry parameter.  RAY_STACK bounds the depth
 // of the hierarchy (checked when the model is loaded).  LocalStack keeps it in the lane's own registers / stack frame
@@ -163,44 +181,46 @@ KS_HD T ray_mesh(const float* tri, const float* wnode, const T* size, const T* l
 #ifdef KS_RAY_COUNT
         visits_++;
 #endif
-        float w[16];
+        // one 4-wide node = one 128-byte line: 4 child boxes + 4 child words (ks_model_host.h)
+        float w[28];
         KS_UNROLL
-        for (int i = 0; i < 16; i++) w[i] = wnode[16 * (long)node + i];
-        const int a = float_bits(w[12]), b = float_bits(w[13]);
-        bool descend = false;
-        if (b < 0) {
-            for (int i = a; i < a - b; i++) {
-                const float* v = &tri[9 * i];
-                T v0[3] = {T(v[0]), T(v[1]), T(v[2])}, e1[3] = {T(v[3]) - v0[0], T(v[4]) - v0[1], T(v[5]) - v0[2]};
-                T e2[3] = {T(v[6]) - v0[0], T(v[7]) - v0[1], T(v[8]) - v0[2]}, pv[3], tv[3], qv[3];
-                cross3(pv, lv, e2);
-                T det = dot3(e1, pv);
-                if (kabs(det) < T(1e-30)) continue;
-                T inv = T(1) / det;
-                sub3(tv, lp, v0);
-                T u = dot3(tv, pv) * inv;
-                if (u < 0 || u > 1) continue;
-                cross3(qv, tv, e1);
-                T ww = dot3(lv, qv) * inv;
-                if (ww < 0 || u + ww > 1) continue;
-                T tt = dot3(e2, qv) * inv;
-                if (tt >= 0 && (best < 0 || tt < best)) best = tt;
-            }
-        } else {
-            // both children's boxes are in the record; the farther one waits on the stack with its entry t
-            const T tmax = bound(best);
-            const T ta = bvh_box_entry_inv(w, lp, inv, par, tmax), tb = bvh_box_entry_inv(w + 6, lp, inv, par, tmax);
-            if (ta >= 0 && tb >= 0) {
-                const bool a_first = ta <= tb;
-                stack.push(a_first ? b : a, a_first ? tb : ta);
-                node = a_first ? a : b;
-                descend = true;
-            } else if (ta >= 0 || tb >= 0) {
-                node = ta >= 0 ? a : b;
-                descend = true;
+        for (int i = 0; i < 28; i++) w[i] = wnode[32 * (long)node + i];
+        const T tmax = bound(best);
+        int id[4];
+        T te[4];
+        KS_UNROLL
+        for (int k = 0; k < 4; k++) {
+            id[k] = float_bits(w[24 + k]);
+            te[k] = id[k] == RAY_EMPTY ? T(-1) : bvh_box_entry_inv(w + 6 * k, lp, inv, par, tmax);
+        }
+        // leaves among the children first: their hits tighten the bound for the rest
+        KS_UNROLL
+        for (int k = 0; k < 4; k++) {
+            if (te[k] >= 0 && id[k] < 0) {
+                const int code = -id[k] - 1, first = code >> 3, cnt = code & 7;
+                for (int i = first; i < first + cnt; i++) {
+                    const T tt = ray_tri(&tri[9 * (long)i], lp, lv);
+                    if (tt >= 0 && (best < 0 || tt < best)) best = tt;
+                }
+                te[k] = T(-1);
             }
         }
-        if (descend) continue;
+        // inner children still in front of the nearest hit: nearest first, the others wait on the stack (farthest pushed first)
+        KS_UNROLL
+        for (int k = 0; k < 4; k++)
+            if (te[k] >= 0 && best >= 0 && te[k] > best) te[k] = T(-1);
+        // sort the (<= 4) candidates by entry parameter, misses (-1 -> +big) last: 5 compare-exchanges
+        T key[4];
+        KS_UNROLL
+        for (int k = 0; k < 4; k++) key[k] = te[k] >= 0 ? te[k] : Lim<T>::big;
+#define KS_CSWAP(i, j) { const bool sw = key[j] < key[i]; const T tk = sw ? key[j] : key[i]; key[j] = sw ? key[i] : key[j]; key[i] = tk; \
+                         const int ti = sw ? id[j] : id[i]; id[j] = sw ? id[i] : id[j]; id[i] = ti; }
+        KS_CSWAP(0, 1) KS_CSWAP(2, 3) KS_CSWAP(0, 2) KS_CSWAP(1, 3) KS_CSWAP(1, 2)
+#undef KS_CSWAP
+        KS_UNROLL
+        for (int k = 3; k >= 1; k--)
+            if (key[k] < Lim<T>::big) stack.push(id[k], key[k]);
+        if (key[0] < Lim<T>::big) { node = id[0]; continue; }
         // next stacked node whose entry is still in front of the nearest hit
         bool found = false;
         int pn;
