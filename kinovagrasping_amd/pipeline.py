@@ -45,6 +45,7 @@ class GraphedTrainer:
         self.head_done = torch.cuda.Event()
         self.g_pre = self.g_post = self.g_commit = None
         self.defer_commit = self.pending_commit = False
+        self.direct_pre = self.direct_post = False
         self.g_learn = []
         self.losses = None
         # the update itself: explicit GEMMs + fused glue kernels (learner_native), same arithmetic as policy.train_on_batch
@@ -99,18 +100,25 @@ class GraphedTrainer:
         torch.cuda.synchronize(self.dev)
         if tune:
             torch.cuda.tunable.tuning_enable(False)
-        self.g_pre = torch.cuda.CUDAGraph()
         # thread_local: other threads (the RCCL watchdog of torch.distributed) keep issuing HIP calls during a capture
         mode = dict(capture_error_mode="thread_local")
-        with torch.cuda.graph(self.g_pre, **mode):
-            eng.pre()
+        # Action selection and the replay write are ONE kernel each on the fused path (kr_actor_select with its in-kernel
+        # noise; kr_store_transition): those are launched directly - a one-node graph only adds the graph -> stream
+        # hand-over (~10-20 us on this runtime) in front of the stepping kernel.
+        self.direct_pre = eng.native and eng.device_noise and eng._fused_actor_layers() is not None
+        if not self.direct_pre:
+            self.g_pre = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_pre, **mode):
+                eng.pre()
         # With the learner on its own stream the ring update of a step (rank / commit / advance) is deferred to the start of
         # the NEXT step on that stream, ahead of the window sampling that needs it: three launches less between two
         # launches of the stepping kernel.
         self.defer_commit = self.overlap and eng.native and eng.replay is not None
-        self.g_post = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_post, **mode):
-            eng.post(commit=not self.defer_commit)
+        self.direct_post = self.defer_commit
+        if not self.direct_post:
+            self.g_post = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_post, **mode):
+                eng.post(commit=not self.defer_commit)
         if self.defer_commit:
             self.g_commit = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_commit, **mode):
@@ -143,7 +151,10 @@ class GraphedTrainer:
     def step(self):
         """One env-step for every env + one learner update (once the replay holds episodes)."""
         main, side = self.main, self.side
-        self.g_pre.replay()
+        if self.direct_pre:
+            self.eng.pre()
+        else:
+            self.g_pre.replay()
         learn = self.steps >= self.learn_after
         if self.overlap and (learn or self.pending_commit):
             self.acted.record(main)
@@ -162,7 +173,10 @@ class GraphedTrainer:
         elif learn:
             self.g_head.replay()
             self._body()
-        self.g_post.replay()
+        if self.direct_post:
+            self.eng.post(commit=False)
+        else:
+            self.g_post.replay()
         self.pending_commit = self.defer_commit
         self.steps += 1
         return self.eng.reward_out, self.eng.done_out
