@@ -378,6 +378,7 @@ template <typename T>
 __global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ mp, Buffers<T> b, int N, int mode, int horizon, int auto_reset,
                                               int env_major, T* __restrict__ obs, T* __restrict__ reward, uint8_t* __restrict__ done,
                                               T* __restrict__ info, T* __restrict__ final_obs) {
+    __shared__ T rlds[SCR_CON * WAVE];      // scratch of an auto-reset's forward kinematics (body-pose part only, as in k_reset)
     const int env = blockIdx.x * WAVE + threadIdx.x;
     if (env >= N) return;
     if (mode == 1) {
@@ -399,7 +400,6 @@ __global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ mp, B
         if (reward) reward[env] = rew;
         if (done) done[env] = d;
         if (info) { info[env] = inf[0]; info[(long)N + env] = inf[1]; info[2L * N + env] = inf[2]; }
-        if (d && auto_reset) b.flag[env] = 1;
     }
     if (mode == 1) {
         KS_UNROLL
@@ -417,6 +417,20 @@ __global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ mp, B
                 else obs[(long)j * N + env] = v;
             }
         }
+        // ... and the restart itself (what k_reset does for a caller's ks_reset): state, snapshot, counters
+        const Model<T>& m = *mp;
+        Scratch<T, KS_LDS T*> scr{(KS_LDS T*)rlds + threadIdx.x, WAVE};
+        LaneState<T> st;
+        T hq[4], q0[NQ];
+        KS_UNROLL
+        for (int i = 0; i < 4; i++) hq[i] = b.hand_quat[(long)i * N + env];
+        KS_UNROLL
+        for (int i = 0; i < NQ; i++) q0[i] = b.qpos0[(long)i * N + env];
+        ColW<T> rsnap{b.snap + env, N};
+        lane_reset(m, st, hq, q0, scr, rsnap);
+        store_state(b, env, N, st);
+        b.step_count[env] = 0;
+        b.ncon[env] = 0;
     }
     if (dst) {
         if (env_major) {
@@ -618,8 +632,7 @@ template <typename T> struct Ctx : CtxBase {
         hipLaunchKernelGGL((k_rays<T>), dim3((N + RAY_ENVS - 1) / RAY_ENVS, NRAY), dim3(WAVE), 0, s, d_model, b, N, 0);
         hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0, cfg.horizon, cfg.auto_reset, cfg.obs_env_major,
                            (T*)obs, (T*)reward, done, (T*)info, (T*)final_obs);
-        // auto-reset: flagged envs restart from their stored initial state; their observation came from the cache above
-        if (cfg.auto_reset) hipLaunchKernelGGL((k_reset<T, USE_LDS>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 1);
+        // (auto-reset: k_obs restarts finished envs from their stored initial state and returns the cached observation)
         HIPCHK(hipGetLastError());
         return KS_OK;
     }
