@@ -201,11 +201,17 @@ def main():
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/pmc_run.sh);
         # the committed summary applies to the 4096-env workload only
-        traffic, traffic_note = None, "no PMC summary for this workload"
+        traffic, traffic_note, issue = None, "no PMC summary for this workload", None
         pmc = ROOT / "profiles" / "r01_pmc.json"
         if pmc.exists() and n == 4096:
             pj = json.loads(pmc.read_text())
             traffic, traffic_note = pj["hbm_bytes_per_launch"], pj["note"]
+            pl = pj["per_launch"]
+            if "SQ_WAVE_CYCLES" in pl:           # what actually bounds the kernel: one wave per SIMD, issue + LDS latency
+                issue = {"valu_busy_frac_of_wave_cycles": round(pl["SQ_ACTIVE_INST_VALU"] / pl["SQ_WAVE_CYCLES"], 3),
+                         "waiting_frac_of_wave_cycles": round(pl["SQ_WAIT_ANY"] / pl["SQ_WAVE_CYCLES"], 3),
+                         "valu_instructions_per_wave": round(pl["SQ_INSTS_VALU"] / pl["SQ_WAVES"]), "waves_per_simd": 1,
+                         "source": "profiles/r01_pmc.json (rocprofv3 --pmc, sim-only workload)"}
         out = {
             "metric": "env-steps/sec (whole node) at 4096 envs/GPU", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -224,7 +230,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "avg_launch_ms": round(kern_ms, 4), "launches_timed": launches,
-                         "note": "algorithmic 768 B/env-step x envs per launch; the path is latency/VALU bound, not HBM bound (SURVEY 8d)"},
+                         "note": "algorithmic 768 B/env-step x envs per launch; the path is latency/VALU bound, not HBM bound (SURVEY 8d)",
+                         "issue_bound": issue},
             "nonfinite_envs": bad,
             "replica_weight_checksum_spread": replica_spread,
             "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 4),
