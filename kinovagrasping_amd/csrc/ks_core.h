@@ -1432,20 +1432,31 @@ KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> te
     KS_TICK(9)
     team.sync();
     // merge the staged records in pair order (= the oracle's contact order); contacts beyond NCON_MAX are dropped.
-    // Every lane reads all per-pair counts at once and copies the records of the pairs pi = sub (mod SUBS).
-    T cnt[NPAIR_MAX];
-    KS_UNROLL
-    for (int j = 0; j < NPAIR_MAX; j++) cnt[j] = scr(SCR_PC + j);
+    // Every lane copies the records of the pairs pi = sub (mod SUBS).
     int total = 0;
     int before[(NPAIR_MAX + SUBS - 1) / SUBS];
-    KS_UNROLL
-    for (int q = 0; q < (NPAIR_MAX + SUBS - 1) / SUBS; q++) before[q] = 0;
-    KS_UNROLL
-    for (int j = 0; j < NPAIR_MAX; j++) {
-        const int c = j < npair ? ((int)cnt[j] & PC_COUNT_MASK) : 0;
+    if constexpr (SUBS == 16) {
+        // lane `sub` owns pairs sub and sub + 16: two row scans give every pair the number of contacts before it
+        static_assert(NPAIR_MAX <= 32, "two pairs per lane");
+        const int c0 = team.sub < npair ? ((int)scr(SCR_PC + team.sub) & PC_COUNT_MASK) : 0;
+        const int c1 = team.sub + 16 < npair ? ((int)scr(SCR_PC + team.sub + 16) & PC_COUNT_MASK) : 0;
+        int t0, t1;
+        before[0] = team.scan(c0, t0);
+        before[1] = t0 + team.scan(c1, t1);
+        total = t0 + t1;
+    } else {
+        T cnt[NPAIR_MAX];
         KS_UNROLL
-        for (int q = 0; q < (NPAIR_MAX + SUBS - 1) / SUBS; q++) before[q] += (j < team.sub + q * SUBS) ? c : 0;
-        total += c;
+        for (int j = 0; j < NPAIR_MAX; j++) cnt[j] = scr(SCR_PC + j);
+        KS_UNROLL
+        for (int q = 0; q < (NPAIR_MAX + SUBS - 1) / SUBS; q++) before[q] = 0;
+        KS_UNROLL
+        for (int j = 0; j < NPAIR_MAX; j++) {
+            const int c = j < npair ? ((int)cnt[j] & PC_COUNT_MASK) : 0;
+            KS_UNROLL
+            for (int q = 0; q < (NPAIR_MAX + SUBS - 1) / SUBS; q++) before[q] += (j < team.sub + q * SUBS) ? c : 0;
+            total += c;
+        }
     }
     KS_UNROLL
     for (int q = 0; q < (NPAIR_MAX + SUBS - 1) / SUBS; q++) {
