@@ -147,9 +147,98 @@ constexpr int LANE_STRIDE = KS_LANE_STRIDE;   // lanes reserved per env (16 = te
 constexpr int WG = 16 * LANE_STRIDE;          // stepping workgroup: 16 envs sharing the hull tables in LDS
 constexpr int EPW_MAX = WG / LANE_STRIDE;
 
+// ---- the rangefinder rays of a workgroup's own envs, inside the stepping kernel (fp32 / LDS variant).
+// A workgroup that has finished its 15 substeps casts the 17 rays of its 16 envs before it retires: workgroups finish
+// at different times (0.7 .. 1.1 ms), so all but the last do this while others are still stepping - the separate k_rays
+// launch (and its launch gap) leaves the critical path, only the slowest workgroup's own rays stay on it.
+// Two passes over the (env, ray, geom) tasks: every thread culls its share against the geoms' bounding boxes and appends
+// the survivors (6 - 15 %) to a list in LDS; the list is then walked one task per thread - dense lanes instead of one
+// walker per eight.  The nearest hit of an (env, ray) is an LDS word updated with atomicMin on the float's bit pattern
+// (non-negative floats order like unsigned integers); walkers read it as their pruning bound, exactly as k_rays' group
+// bound.  The per-env LDS blocks are dead by then and hold the list, the hit words and the traversal stacks.
+struct SlotBound {
+    KS_LDS unsigned* slot;
+    __device__ float operator()(float best) const {
+        if (best >= 0) atomicMin((unsigned*)slot, (unsigned)__float_as_int(best));
+        return __int_as_float((int)*(volatile KS_LDS unsigned*)slot);
+    }
+};
+constexpr int WG_RAY_TASKS = NRAY * (NGEOM - 1);                       // per env
+constexpr int WG_SNAP = 97;                                            // body poses of an env (96 floats), odd stride
+__host__ __device__ constexpr int wg_rays_words(int epw) { return epw * NRAY + 4 + epw * WG_RAY_TASKS + RAY_STACK * WG + epw * WG_SNAP; }
+struct LdsSnap {
+    KS_LDS const float* base;
+    __device__ float operator()(int k) const { return base[k]; }
+};
+
+__device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>& b, int N, int env0, int epw, KS_LDS unsigned* w) {
+    KS_LDS unsigned* hit = w;                                          // [epw][17] nearest hit so far (float bits), big = none
+    KS_LDS unsigned* count = w + epw * NRAY;
+    KS_LDS unsigned* list = count + 4;                                 // surviving task ids
+    KS_LDS unsigned* stk = list + epw * WG_RAY_TASKS;                  // [RAY_STACK][WG]
+    KS_LDS float* snaps = (KS_LDS float*)(stk + RAY_STACK * WG);       // [epw][WG_SNAP] body poses (one global read round for everything)
+    const int tid = threadIdx.x, total = epw * WG_RAY_TASKS;
+    for (int i = tid; i < epw * NRAY; i += WG) hit[i] = (unsigned)__float_as_int(Lim<float>::big);
+    for (int i = tid; i < epw * 96; i += WG) {
+        const int e = i / 96, k = i % 96, env = env0 + e;
+        snaps[e * WG_SNAP + k] = env < N ? b.snap[(long)(SNAP_BP + k) * N + env] : 0.f;
+    }
+    if (tid == 0) { count[0] = 0; count[1] = 0; }
+    __syncthreads();
+    for (int task = tid; task < total; task += WG) {
+        const int e = task / WG_RAY_TASKS, r = (task % WG_RAY_TASKS) >> 3, g = 1 + (task & 7), env = env0 + e;
+        if (env >= N) continue;
+        LdsSnap snap{snaps + e * WG_SNAP - SNAP_BP};
+        float pnt[3], vec[3];
+        const int sb = ray_origin(m, snap, r, pnt, vec);
+        if (g == 1) {
+            const float tg = ray_ground(m, pnt, vec);
+            if (tg >= 0) atomicMin((unsigned*)(hit + e * NRAY + r), (unsigned)__float_as_int(tg));
+        }
+        if (m.geom_body[g] != sb && ray_may_hit_geom(m, snap, g, pnt, vec)) list[atomicAdd((unsigned*)count, 1u)] = (unsigned)task;
+    }
+    __syncthreads();
+    // The walks, one node visit per loop iteration: a lane whose walk has ended takes the next task from the list in the
+    // SAME loop, so the lanes of a wave do not wait for the longest walk of a round - the pass lasts about as long as the
+    // single longest walk (or the total number of visits / 256, whichever is more).
+    const unsigned nlist = *count;
+    KS_LDS unsigned* next = count + 1;
+    RayWalk<float, SlotBound, LdsStack<float>> walk;
+    KS_LDS unsigned* slot = hit;
+    bool busy = false;
+    for (;;) {
+        if (!busy) {
+            const unsigned i = atomicAdd((unsigned*)next, 1u);
+            if (i >= nlist) break;
+            const int task = (int)list[i];
+            const int e = task / WG_RAY_TASKS, r = (task % WG_RAY_TASKS) >> 3, g = 1 + (task & 7);
+            LdsSnap snap{snaps + e * WG_SNAP - SNAP_BP};
+            float pnt[3], vec[3], lp[3], lv[3];
+            ray_origin(m, snap, r, pnt, vec);
+            ray_to_geom(m, snap, g, pnt, vec, lp, lv);
+            slot = hit + e * NRAY + r;
+            const int mesh = m.geom_mesh[g];
+            busy = walk.start(m.mesh_tri[mesh], m.mesh_bvh_box[mesh], m.geom_size[g], lp, lv, SlotBound{slot}, LdsStack<float>{stk + tid, WG});
+            if (!busy) continue;
+        }
+        if (!walk.step()) {
+            if (walk.best >= 0) atomicMin((unsigned*)slot, (unsigned)__float_as_int(walk.best));
+            busy = false;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < epw * NRAY; i += WG) {
+        const int e = i / NRAY, r = i % NRAY, env = env0 + e;
+        if (env < N) {
+            const float t = __int_as_float((int)hit[i]);
+            b.rays[(long)r * N + env] = t < Lim<float>::big ? t : -1.0f;
+        }
+    }
+}
+
 template <typename T, bool USE_LDS>
 __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ action, int N,
-                                                   int frame_skip, int iters, int epw, int tap) {
+                                                   int frame_skip, int iters, int epw, int tap, int rays_in_step) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KS_LDS T* lds = (KS_LDS T*)smem;
     const Model<T>* ml = mp;
@@ -172,7 +261,9 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
     const int e = threadIdx.x / LANE_STRIDE;
     const Team<SUBS> team{(int)threadIdx.x % LANE_STRIDE};
     const int env = blockIdx.x * epw + e;
-    if (team.sub >= SUBS || e >= epw || env >= N) return;
+    const bool active = !(team.sub >= SUBS || e >= epw || env >= N);
+    if (!active && !(USE_LDS && rays_in_step)) return;
+    if (active) {
     T hq[4], act[4];
     KS_UNROLL
     for (int i = 0; i < 4; i++) { hq[i] = b.hand_quat[(long)i * N + env]; act[i] = action[(long)i * N + env]; }
@@ -228,6 +319,15 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
     }
     if (status) atomicOr(&b.status[env], status);
     if (team.sub == 0) b.ncon[env] = ncon;
+    }
+    if constexpr (USE_LDS && sizeof(T) == 4) {
+        if (rays_in_step) {
+            // every thread of the workgroup is here (inactive lanes included): snapshots written, env blocks dead
+            __threadfence_block();
+            __syncthreads();
+            wg_rays(m, b, N, blockIdx.x * epw, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)));
+        }
+    }
 }
 
 template <typename T, bool USE_LDS>
@@ -588,6 +688,7 @@ template <typename T> struct Ctx : CtxBase {
     int blocks() const { return (cfg.n_envs + WAVE - 1) / WAVE; }
     // envs per wave and dynamic LDS bytes of the stepping kernels
     int lpw = WAVE;
+    bool rays_in_step = false;
     size_t step_lds = 0;
     int hull_words = 0;
     int plan_launch() {
@@ -600,6 +701,10 @@ template <typename T> struct Ctx : CtxBase {
         int want = cfg.envs_per_wave > 0 ? cfg.envs_per_wave : EPW_MAX;
         lpw = want > cap ? cap : want;
         step_lds = hull_bytes + per_env * lpw;
+        // fp32: the workgroups cast their own envs' rays at the end of the stepping kernel (wg_rays) when the dead env blocks
+        // are large enough for its list and stacks; KS_RAYS_IN_STEP=0 keeps the separate k_rays launch
+        rays_in_step = USE_LDS && sizeof(T) == 4 && (size_t)wg_rays_words(lpw) <= (size_t)SCR_TOTAL * lpw &&
+                       !(getenv("KS_RAYS_IN_STEP") && getenv("KS_RAYS_IN_STEP")[0] == '0');
         if (getenv("KS_DEBUG")) fprintf(stderr, "[ks] stepping kernel: %d envs per workgroup, LDS %zu B (tables %zu B, %zu B per env), limit %zu\n", lpw, step_lds, hull_bytes, per_env, lds_max);
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<T, USE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_substep<T, USE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
@@ -627,9 +732,9 @@ template <typename T> struct Ctx : CtxBase {
         const bool timed = ev_used < NEV;
         if (timed) HIPCHK(hipEventRecord(ev0[ev_used], s));
         hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3((N + lpw - 1) / lpw), dim3(WG), step_lds, s, d_model, b, (const T*)action, N,
-                           cfg.frame_skip, cfg.solver_iterations, lpw, cfg.contact_tap);
+                           cfg.frame_skip, cfg.solver_iterations, lpw, cfg.contact_tap, (int)rays_in_step);
         if (timed) { HIPCHK(hipEventRecord(ev1[ev_used], s)); ev_used++; }
-        hipLaunchKernelGGL((k_rays<T>), dim3((N + RAY_ENVS - 1) / RAY_ENVS, NRAY), dim3(WAVE), 0, s, d_model, b, N, 0);
+        if (!rays_in_step) hipLaunchKernelGGL((k_rays<T>), dim3((N + RAY_ENVS - 1) / RAY_ENVS, NRAY), dim3(WAVE), 0, s, d_model, b, N, 0);
         hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0, cfg.horizon, cfg.auto_reset, cfg.obs_env_major,
                            (T*)obs, (T*)reward, done, (T*)info, (T*)final_obs);
         // (auto-reset: k_obs restarts finished envs from their stored initial state and returns the cached observation)

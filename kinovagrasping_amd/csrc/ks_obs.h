@@ -162,22 +162,35 @@ template <typename T> struct LdsStack {
     }
 };
 
-template <typename T, typename Bound = OwnBound, typename Stack = LocalStack<T>>
-KS_HD T ray_mesh(const float* tri, const float* wnode, const T* size, const T* lp, const T* lv, Bound bound = Bound(), Stack stack = Stack()) {
-    {
-        T lo[3] = {-size[0], -size[1], -size[2]}, hi[3] = {size[0], size[1], size[2]};
-        if (!ray_box(lp, lv, lo, hi, Lim<T>::big)) return T(-1);
-    }
-    T best = T(-1);
-    int node = 0;
-    T inv[3];
+// The walk as a resumable object: start() does the bounding-box pre-test and the per-walk constants, step() visits ONE
+// node and says whether there is another.  ray_mesh below just loops; the stepping kernel's in-step ray pass (ks_api.hip:
+// wg_rays) interleaves the walks of different tasks on one lane, a node at a time.
+template <typename T, typename Bound = OwnBound, typename Stack = LocalStack<T>> struct RayWalk {
+    const float* tri;
+    const float* wnode;
+    T lp[3], lv[3], inv[3];
     bool par[3];
-    KS_UNROLL
-    for (int a = 0; a < 3; a++) { par[a] = kabs(lv[a]) < T(1e-15); inv[a] = par[a] ? T(0) : T(1) / lv[a]; }
+    T best;
+    int node;
+    Bound bound;
+    Stack stack;
 #ifdef KS_RAY_COUNT
-    int visits_ = 0;
+    int visits_;
 #endif
-    for (;;) {
+    KS_HD bool start(const float* tri_, const float* wnode_, const T* size, const T* lp_, const T* lv_, Bound bound_, Stack stack_) {
+        T lo[3] = {-size[0], -size[1], -size[2]}, hi[3] = {size[0], size[1], size[2]};
+        if (!ray_box(lp_, lv_, lo, hi, Lim<T>::big)) return false;
+        tri = tri_; wnode = wnode_; bound = bound_; stack = stack_;
+        best = T(-1);
+        node = 0;
+        KS_UNROLL
+        for (int a = 0; a < 3; a++) { lp[a] = lp_[a]; lv[a] = lv_[a]; par[a] = kabs(lv_[a]) < T(1e-15); inv[a] = par[a] ? T(0) : T(1) / lv_[a]; }
+#ifdef KS_RAY_COUNT
+        visits_ = 0;
+#endif
+        return true;
+    }
+    KS_HD bool step() {
 #ifdef KS_RAY_COUNT
         visits_++;
 #endif
@@ -220,7 +233,7 @@ KS_HD T ray_mesh(const float* tri, const float* wnode, const T* size, const T* l
         KS_UNROLL
         for (int k = 3; k >= 1; k--)
             if (key[k] < Lim<T>::big) stack.push(id[k], key[k]);
-        if (key[0] < Lim<T>::big) { node = id[0]; continue; }
+        if (key[0] < Lim<T>::big) { node = id[0]; return true; }
         // next stacked node whose entry is still in front of the nearest hit
         bool found = false;
         int pn;
@@ -228,12 +241,19 @@ KS_HD T ray_mesh(const float* tri, const float* wnode, const T* size, const T* l
         while (stack.pop(pn, pt)) {
             if (best < 0 || pt <= best) { node = pn; found = true; break; }
         }
-        if (!found) break;
+        return found;
     }
+};
+
+template <typename T, typename Bound = OwnBound, typename Stack = LocalStack<T>>
+KS_HD T ray_mesh(const float* tri, const float* wnode, const T* size, const T* lp, const T* lv, Bound bound = Bound(), Stack stack = Stack()) {
+    RayWalk<T, Bound, Stack> w;
+    if (!w.start(tri, wnode, size, lp, lv, bound, stack)) return T(-1);
+    while (w.step()) {}
 #ifdef KS_RAY_COUNT
-    return T(visits_);
+    return T(w.visits_);
 #endif
-    return best;
+    return w.best;
 }
 
 // ---- one rangefinder = ray from site `si` along its +z against the ground plane and the 8 mesh geoms (those of the
@@ -259,17 +279,29 @@ template <typename T> KS_HD T ray_ground(const Model<T>& m, const T* pnt, const 
     }
     return T(-1);
 }
-template <typename T, typename C, typename Bound = OwnBound, typename Stack = LocalStack<T>>
-KS_HD T ray_geom(const Model<T>& m, C snap, int g, const T* pnt, const T* vec, Bound bound = Bound(), Stack stack = Stack()) {
+// the ray (origin pnt, direction vec, world frame) in the frame of geom g
+template <typename T, typename C> KS_HD void ray_to_geom(const Model<T>& m, C snap, int g, const T* pnt, const T* vec, T* lp, T* lv) {
     T R[9], p[3], Rg[9], pg[3], t[3];
     snap_body<T>(snap, m.geom_body[g], R, p);
     mulRR(Rg, R, m.geom_R[g]);
     mulRv(t, R, m.geom_pos[g]);
     add3(pg, p, t);
-    T lp[3], lv[3];
     sub3(t, pnt, pg);
     mulRtv(lp, Rg, t);
     mulRtv(lv, Rg, vec);
+}
+// does the ray pass through geom g's bounding box at all (the first test of ray_mesh)
+template <typename T, typename C> KS_HD bool ray_may_hit_geom(const Model<T>& m, C snap, int g, const T* pnt, const T* vec) {
+    T lp[3], lv[3];
+    ray_to_geom(m, snap, g, pnt, vec, lp, lv);
+    const T* size = m.geom_size[g];
+    T lo[3] = {-size[0], -size[1], -size[2]}, hi[3] = {size[0], size[1], size[2]};
+    return ray_box(lp, lv, lo, hi, Lim<T>::big);
+}
+template <typename T, typename C, typename Bound = OwnBound, typename Stack = LocalStack<T>>
+KS_HD T ray_geom(const Model<T>& m, C snap, int g, const T* pnt, const T* vec, Bound bound = Bound(), Stack stack = Stack()) {
+    T lp[3], lv[3];
+    ray_to_geom(m, snap, g, pnt, vec, lp, lv);
     const int mesh = m.geom_mesh[g];
     return ray_mesh(m.mesh_tri[mesh], m.mesh_bvh_box[mesh], m.geom_size[g], lp, lv, bound, stack);
 }
