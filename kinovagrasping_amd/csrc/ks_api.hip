@@ -1,11 +1,14 @@
 // ks_api.hip -- gfx950 kernels + C ABI of libkinova_sim.so (see include/kinova_sim.h).
 //
-// Kernels (one env per wavefront lane unless noted):
-//   k_env_step   15 x mj_step per launch; per-lane dynamic state in LDS (144 KB / wave), model tables
-//                through wave-uniform scalar loads.  THE dominant kernel.
-//   k_reset      state <- stored initial state for flagged envs, kinematics -> snapshot
-//   k_rays       17 rangefinder rays x 8 mesh geoms, one (env, ray, geom) per lane: grid (N/8, 17)
-//   k_obs        82-d observation, reward, termination, time limit, auto-reset flagging
+// Kernels:
+//   k_env_step   15 x mj_step per launch: 16 lanes per env, 4 envs per wave, 16 envs per 256-thread workgroup, all
+//                per-env data + model + hull tables in LDS (~155 KB).  THE dominant kernel.  fp32 contexts: each
+//                workgroup then casts the 17 rangefinder rays of its own envs before it retires (wg_rays).
+//   k_obs        82-d observation, reward, termination, time limit; on an auto-reset returns the cached observation of
+//                the env's stored initial state and restarts the env (one env per lane)
+//   k_reset      state <- stored initial state for flagged envs, kinematics -> snapshot (ks_reset only)
+//   k_rays       17 rangefinder rays x 8 mesh geoms as a launch of their own, one (env, ray, geom) per lane, grid
+//                (N/8, 17): ks_reset, fp64 contexts, KS_RAYS_IN_STEP=0
 //   k_substep    one mj_step with explicit controls (parity tap)
 // No CPU fallback exists in this library.
 #include <hip/hip_runtime.h>

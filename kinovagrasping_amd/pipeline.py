@@ -1,22 +1,27 @@
-"""HIP-graph pipeline for rollout + DDPGfD training on one GPU (one process per GPU).
+"""Pipeline for rollout + DDPGfD training on one GPU (one process per GPU): HIP graphs for the many-kernel parts,
+direct launches for the one-kernel parts, the learner on a second stream beside the simulator.
 
-An env-step of the eager RolloutEngine + learner is ~250 small kernels (actor MLP, masked replay writes, window
-gather, two backward passes, Adam, target update); launched one by one they cost more host time than the
-physics kernel takes on the device.  GraphedTrainer captures them once into HIP graphs and replays them:
+Per env-step, on the main stream (the critical chain):
 
-    g_pre    action selection (check_grasp, actor forward, exploration noise, scripted lift)
-    ks_step  the simulator (libkinova_sim, launched directly on the stream - not part of a graph)
-    g_post   replay writes + episode bookkeeping
+    pre      action selection: ONE kernel (kr_actor_select = actor forward on MFMA + in-kernel exploration noise +
+             check_grasp latch / scripted lift), launched directly; a graph (g_pre) when the actor is not a supported MLP
+    ks_step  the simulator (libkinova_sim): k_env_step (15 substeps + the rays of the workgroup's envs) and k_obs
+    post     kr_store_transition (open-episode buffers + per-env bookkeeping), launched directly
+
+and on the learner's stream, started right behind the action selection:
+
+    g_commit finished episodes of the PREVIOUS step enter the replay ring (rank / commit / advance)
     g_head   actor Adam + soft target update (previous update's gradients), window sampling
-    g_learn  the body of one DDPGfD update (learner_native: explicit GEMMs + fused glue kernels); with
-             world_size > 1 it is two graphs (critic backward | critic step + actor backward) with the all-reduce of
-             the flat gradient buffers (RCCL) issued after each - collectives stay outside the captures.
+    g_learn  the body of one DDPGfD update (learner_native); with world_size > 1 it is two graphs (critic backward |
+             critic step + actor backward) with the all-reduce of the flat gradient buffers (RCCL) issued after each -
+             collectives stay outside the captures.
 
-The learner runs on a second stream as a one-step software pipeline.  Each update is a short HEAD (the actor's Adam
-step + soft target update for the gradients of the PREVIOUS update, then the window sampling) and a BODY (targets,
-critic backward + Adam, actor backward).  The rollout only waits for the head - a few launches that need no LDS and
-finish while the simulator kernel is still running - so replay writes and the next actor forward never wait for the
-GEMMs, which can only get CUs once simulator workgroups retire (the stepping kernel holds all of every CU's LDS).
+The learner is a one-step software pipeline: each update is a short HEAD (the actor's Adam step + soft target update
+for the gradients of the PREVIOUS update, then the window sampling) and a BODY (targets, critic backward + Adam, actor
+backward).  The rollout only waits for the head before it writes the replay.  At 256-256 every launch of the update is
+LDS-free (csrc/ks_mlp.hip), so the whole body executes on the registers, matrix pipes and issue slots the stepping
+kernel leaves idle and ends before that kernel does; with library GEMMs (other widths) the body can only get CUs once
+simulator workgroups retire (the stepping kernel holds all of every CU's LDS) and runs behind it.
 The actor therefore acts with weights that lag the learner by one update; the reference's own loop acts with a policy
 that is a whole episode old (100 updates at the end of each episode, main_DDPGfD.py:466-486).
 """
