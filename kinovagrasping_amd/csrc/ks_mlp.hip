@@ -217,41 +217,63 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const int row = blockIdx.x * ROWS + nn;
     const bool row_ok = row < n;
     const int in_dim = in_a + in_b;
+    // All operand reads are raw buffer loads: ONE 32-bit lane offset per matrix, the tile / k-step advance in the
+    // wave-uniform scalar offset, out-of-range reads return 0 in hardware.  The flat-load version spent 5 VALU + 7 SALU
+    // instructions (address arithmetic, bounds branches) per MFMA - issue slots this kernel shares with the stepping
+    // kernel's wave on the same SIMD.  (The host checks h1 % 16 == h2 % 16 == 0 for this variant.)
+    const auto rW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W1), 0, h1 * in_dim * 4, 0x00020000);
+    const auto rW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W2), 0, h2 * h1 * 4, 0x00020000);
+    const auto rW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W3), 0, out_dim * h2 * 4, 0x00020000);
+    const auto rXa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xa), 0, ((n - 1) * lda + in_a) * 4, 0x00020000);
+    const auto rXb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb ? xb : xa), 0, xb ? ((n - 1) * ldb + in_b) * 4 : 0, 0x00020000);
+#define KS_LDF(rsrc, voff, soff) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0))
     f32x4 h1r[NT1];
     {
+        // B operands of layer 1: the 16 input rows, k = 16 s + 4 q + j.  A row beyond n is out of the buffer's range (0).
+        // (the range check covers the LANE offset only, not the scalar offset: an element that does not exist gets an
+        //  out-of-range lane offset instead of relying on the sum)
+        constexpr int OOR = 0x7ffffff0;
         f32x4 bx[KS_IN_MAX];
+        const int oa = row * lda * 4 + 16 * q, ob = (row * ldb + 4 * q - in_a) * 4;
 #pragma unroll
         for (int s = 0; s < KS_IN_MAX; s++) {
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int k = 16 * s + 4 * q + j;
-                float x = 0.f;
-                if (row_ok && k < in_a) x = xa[(long)row * lda + k];
-                else if (row_ok && k < in_dim) x = xb[(long)row * ldb + (k - in_a)];
-                v[j] = x;
+                const float fa = KS_LDF(rXa, (row_ok && k < in_a) ? oa : OOR, (16 * s + j) * 4);
+                const float fb = KS_LDF(rXb, (row_ok && k >= in_a && k < in_dim) ? ob + (16 * s + j) * 4 : OOR, 0);
+                v[j] = k < in_a ? fa : fb;
             }
             bx[s] = f32x4{v[0], v[1], v[2], v[3]};
         }
+        // A operands: W1[16 t + nn][16 s + 4 q + j], zero beyond in_dim
+        const int o1 = (nn * in_dim + 4 * q) * 4;
 #pragma unroll
         for (int t = 0; t < NT1; t++) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KS_IN_MAX; s++) {
-                const f32x4 w = load_w4<false>(W1, t * 16 + nn, h1, 16 * s + 4 * q, in_dim);
+                const int so = (16 * t * in_dim + 16 * s) * 4, k0 = 16 * s + 4 * q;
+                const f32x4 w = {KS_LDF(rW1, k0 < in_dim ? o1 : OOR, so), KS_LDF(rW1, k0 + 1 < in_dim ? o1 : OOR, so + 4),
+                                 KS_LDF(rW1, k0 + 2 < in_dim ? o1 : OOR, so + 8), KS_LDF(rW1, k0 + 3 < in_dim ? o1 : OOR, so + 12)};
                 if (s & 1) acc1 = mfma4(w, bx[s], acc1);
                 else acc0 = mfma4(w, bx[s], acc0);
             }
             h1r[t] = bias_relu(acc0 + acc1, b1, t * 16 + 4 * q, h1);
-            if (h1_out && row_ok && t * 16 + 4 * q < h1) *(f32x4*)(h1_out + (long)row * h1 + t * 16 + 4 * q) = h1r[t];
+            if (h1_out && row_ok) *(f32x4*)(h1_out + (long)row * h1 + t * 16 + 4 * q) = h1r[t];
         }
     }
     f32x4 acc3 = {0.f, 0.f, 0.f, 0.f};
+    const int o2 = (nn * h1 + 4 * q) * 4;                       // W2[16 t + nn][16 s + 4 q ..]: 16-byte reads (h1 % 4 == 0)
+    const int o3 = (nn * h2 + 4 * q) * 4;                       // W3[nn][16 t + 4 q ..]: rows >= out_dim are out of range (0)
+#pragma unroll 1
     for (int t = 0; t < NT2; t++) {
         f32x4 w[NT1];
 #pragma unroll
-        for (int s = 0; s < NT1; s++) w[s] = load_w4<VEC>(W2, t * 16 + nn, h2, 16 * s + 4 * q, h1);
-        const f32x4 w3 = load_w4<VEC>(W3, nn, out_dim, 16 * t + 4 * q, h2);
+        for (int s = 0; s < NT1; s++)
+            w[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW2, o2, (16 * t * h1 + 16 * s) * 4, 0));
+        const f32x4 w3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW3, nn < out_dim ? o3 : 0x7ffffff0, 16 * t * 4, 0));   // rows >= out_dim do not exist
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < NT1; s++) {
@@ -259,9 +281,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             else acc0 = mfma4(w[s], h1r[s], acc0);
         }
         const f32x4 hq = bias_relu(acc0 + acc1, b2, t * 16 + 4 * q, h2);
-        if (h2_out && row_ok && t * 16 + 4 * q < h2) *(f32x4*)(h2_out + (long)row * h2 + t * 16 + 4 * q) = hq;
+        if (h2_out && row_ok) *(f32x4*)(h2_out + (long)row * h2 + t * 16 + 4 * q) = hq;
         acc3 = mfma4(w3, hq, acc3);
     }
+#undef KS_LDF
     if (q == 0 && row_ok) {
         const float z[4] = {acc3.x, acc3.y, acc3.z, acc3.w};
         for (int i = 0; i < out_dim; i++) {
@@ -496,7 +519,8 @@ int kr_mlp3_forward_shadow(int32_t n, int32_t in_a, int32_t in_b, int32_t h1, in
     if (in_a + in_b > 16 * KS_IN_MAX || out_dim < 1 || out_dim > 4 || h1 < 1 || h2 < 1) return KS_ERR_INVALID;
     if (act != KR_ACT_NONE && act != KR_ACT_SIGMOID) return KS_ERR_INVALID;
     const int nt1 = (h1 + 15) / 16, nt2 = (h2 + 15) / 16;
-    const bool vec = (h1 % 4 == 0) && (h2 % 4 == 0) && ((uintptr_t)W2 % 16 == 0) && ((uintptr_t)W3 % 16 == 0);
+    if (h1 % 16 || h2 % 16 || (uintptr_t)W2 % 16 || (uintptr_t)W3 % 16) return KS_ERR_INVALID;      // 16-byte buffer loads, whole tiles
+    const bool vec = true;
     const dim3 grid((n + ROWS - 1) / ROWS), block(64);
     hipStream_t s = (hipStream_t)stream;
 #define KR_WAVE_CASE(A, B)                                                                                                                       \
