@@ -160,7 +160,7 @@ def run_stage(plan, policy, n_envs: int = 1024, rounds: int = 10, updates_per_ro
     # final evaluation: one deterministic episode per env (eval_policy, main_DDPGfD.py:130-272)
     obs0, classes = reset_all(sim, n_envs)
     res = eval_policy(sim, policy, obs0, horizon=30, orientation=plan["requested_orientation"])
-    out = {"num_success": res["num_success"], "num_total": n_envs, "avg_reward": res["avg_reward"], "skipped_shapes": skipped, "shapes": shapes,
+    out = {"expert_episodes": 0 if expert is None else int(expert.count), "num_success": res["num_success"], "num_total": n_envs, "avg_reward": res["avg_reward"], "skipped_shapes": skipped, "shapes": shapes,
            "updates": len(losses), "orientation_counts": {c: classes.count(c) for c in sorted(set(classes))}}
     if save:
         for k in ("policy_dir", "replay_dir", "output_dir"):

@@ -691,8 +691,23 @@ def test_curriculum_stage_runs_and_hands_over_to_the_next(tmp_path):
     torch.manual_seed(2)
     policy = DDPGfD(82, 4, 0.8, 5, batch_size=8, hidden=(64, 64), device=dev)
     p1 = curriculum.experiment_plan(1, root=tmp_path)
+    # expert demonstrations for the stage's shapes, in the reference's directory layout (expert_replay_data/<grasp>/combined/
+    # <shape>/<orientation>/replay_buffer, main_DDPGfD.py:1183-1187): run_stage mixes them in at expert_prob (DDPGfD.py:232-254)
+    from kinovagrasping_amd.demonstrators import run_controller_episodes
+    from kinovagrasping_amd.replay import DeviceEpisodeReplay
+    for shape in ("CubeS", "CubeB"):
+        tab = scenarios.start_coord_table(shape)
+        q0 = np.zeros((16, 32)); q0[12] = 1; q0[9:12] = tab[np.linspace(0, len(tab) - 1, 32).astype(int)].T
+        hq = np.repeat(scenarios.hand_quat_for("normal")[:, None], 32, 1)
+        sim = _sim(32, shape, horizon=30, auto_reset=False)
+        rep = DeviceEpisodeReplay(32, capacity=64, horizon=30, device=dev)
+        res = run_controller_episodes(sim, sim.reset(torch.as_tensor(q0), torch.as_tensor(hq)), replay=rep, mode="combined")
+        assert res["success"].float().mean().item() > 0.5
+        rep.save(p1["dirs"]["expert_replay_dir"] / shape / "normal" / "replay_buffer")
+        sim.close()
     r1 = curriculum.run_stage(p1, policy, n_envs=64, rounds=1, updates_per_round=2, load_previous=False)
     assert r1["shapes"] == ["CubeS", "CubeB"] and r1["skipped_shapes"] == [] and r1["updates"] == 2 and r1["num_total"] == 64
+    assert r1["expert_episodes"] >= 40                      # both shapes' demonstrations were found and loaded
     assert curriculum.policy_basename(p1["dirs"]["policy_dir"]).startswith("DDPGfD_kinovaGrip_")
     assert (p1["dirs"]["output_dir"] / "experiment_info.txt").read_text().startswith("NO grasp Experiment 1: sizes, Stage 1")
     w_saved = policy.actor.l1.weight.detach().clone()
