@@ -61,11 +61,11 @@ for t in range(NSTEP):
         print("  workgroups starting late (> 25% of a loop):", int(late.sum()))
     if t == NSTEP - 1:
         full = st["contact"].reshape(-1, n)[:480].cpu().numpy().reshape(16, 30, n)
-        names = {0: "fk+dyn", 1: "collision", 2: "constraints", 3: "chol M", 5: "euler", 8: "c:plane", 9: "c:hull", 10: "c:merge", 14: "(end)", 15: "n:chol", 16: "n:solve", 17: "n:pproj", 18: "n:ls", 21: "#newton", 22: "#ls"}
+        names = {0: "fk+dyn", 1: "collision", 2: "constraints", 3: "chol M", 5: "euler", 8: "c:plane", 9: "c:hull", 10: "c:merge", 13: "n:setup|wg-start", 14: "n:hessian|wg-end", 19: "n:update|hwid", 20: "post|xcc", 15: "n:chol", 16: "n:solve", 17: "n:pproj", 18: "n:ls", 21: "#newton", 22: "#ls"}
         order = np.argsort(-d)
         st2 = sim.get_state()
         nc = st2["ncon"].cpu().numpy()
         for rank in (0, 1, 2, 3, n // 2, n - 1):
             e = order[rank]
             p = full[:, :, e].max(0)
-            print(f"  env {e} (rank {rank}) duration {d[e]:.0f} ticks, ncon(last) {nc[e]}, total cyc {p[6]:.0f}: " + ", ".join(f"{names[k]} {p[k]:.0f}" for k in (0, 1, 8, 9, 10, 2, 3, 5, 21, 22)) + f" | gjk calls {full[:, 24, e].sum():.0f} gjk supports {full[:, 25, e].sum():.0f} busiest lane: pre-GJK cycles {full[:, 26, e].max():.0f} gjk_distance cycles {full[:, 27, e].max():.0f} gjk sup {full[:, 25, e].max():.0f} gjk calls {full[:, 24, e].max():.0f}; support cycles {full[:, 28, e].max():.0f} closest cycles {full[:, 29, e].max():.0f}")
+            print(f"  env {e} (rank {rank}) duration {d[e]:.0f} ticks, ncon(last) {nc[e]}, total cyc {p[6]:.0f}: " + ", ".join(f"{names[k]} {p[k]:.0f}" for k in (0, 1, 8, 9, 10, 2, 3, 5, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22)) + f" | gjk calls {full[:, 24, e].sum():.0f} gjk supports {full[:, 25, e].sum():.0f} busiest lane: pre-GJK cycles {full[:, 26, e].max():.0f} gjk_distance cycles {full[:, 27, e].max():.0f} gjk sup {full[:, 25, e].max():.0f} gjk calls {full[:, 24, e].max():.0f}; support cycles {full[:, 28, e].max():.0f} closest cycles {full[:, 29, e].max():.0f}")
