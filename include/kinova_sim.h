@@ -107,7 +107,8 @@ int ks_set_env_params(ks_ctx *ctx, const void *obj_mass, const void *obj_mu, voi
 int ks_substep(ks_ctx *ctx, const void *ctrl, void *stream);
 
 /* HIP event timing of the dominant kernel: average duration (ms) of the env-step kernel launches
- * since the last call with reset != 0, measured with hipEvents on the launch stream.  Host sync. */
+ * since the last call with reset != 0, measured with hipEvents on the launch stream.  Host sync.
+ * (fp32 contexts: that kernel is the 15 substeps of every env plus the rangefinder rays of the workgroup's own envs.) */
 int ks_kernel_time(ks_ctx *ctx, int reset, double *avg_ms_host, int64_t *launches_host);
 
 int ks_version(void);
