@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/kinova_rollout.h"
 #include "../../include/kinova_sim.h"
 #include "ks_select.h"
@@ -408,24 +410,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const int mt = blockIdx.x / n_blocks, nb = blockIdx.x % n_blocks, chunk = blockIdx.y;
     const int r0 = chunk * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
     const int m = mt * 16 + nn;
+    // Raw buffer loads (as in k_mlp3_wave): per matrix ONE lane offset (row q of a 4-row group, this lane's column), the row
+    // advance in the wave-uniform scalar offset; an element that does not exist gets an out-of-range lane offset (-> 0).
+    // The flat-load version spent ~10 VALU + ~20 SALU instructions per MFMA on addresses and bounds branches.
+    constexpr int OOR = 0x7ffffff0;
+    const auto rZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, n * M * 4, 0x00020000);
+    const auto rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ha), 0, ((n - 1) * lda + Na) * 4, 0x00020000);
+    const auto rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hb ? hb : ha), 0, hb ? ((n - 1) * ldb + Nb) * 4 : 0, 0x00020000);
+#define KS_LDF(rsrc, voff, soff) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0))
+    const int vz = m < M ? (q * M + m) * 4 : OOR;
+    int va[WG_TN], vb[WG_TN];
+#pragma unroll
+    for (int u = 0; u < WG_TN; u++) {
+        const int c = (nb * WG_TN + u) * 16 + nn;
+        va[u] = c < Na ? (q * lda + c) * 4 : OOR;
+        vb[u] = (c >= Na && c < N) ? (q * ldb + c - Na) * 4 : OOR;
+    }
     f32x4 acc[WG_TN];
 #pragma unroll
     for (int u = 0; u < WG_TN; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     float colsum = 0.f;
-    for (int k0 = r0; k0 < r1; k0 += 16) {
-        // four k-steps (16 rows) per round: all loads first
+    // four k-steps (16 rows) per round, all loads first; only the last round of a chunk can hold rows that do not exist
+    auto round = [&](int k0, auto guard, auto hasb) {
+        constexpr bool GUARD = decltype(guard)::value, HASB = decltype(hasb)::value;
         float a[4], b[4][WG_TN];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int r = k0 + 4 * j + q;
-            const bool ok = r < r1;
-            a[j] = (ok && m < M) ? dz[(long)r * M + m] : 0.f;
+            const int rj = k0 + 4 * j;                                 // wave-uniform; this lane's row is rj + q
+            const bool ok = !GUARD || rj + q < r1;
+            a[j] = KS_LDF(rZ, ok ? vz : OOR, rj * M * 4);
 #pragma unroll
             for (int u = 0; u < WG_TN; u++) {
-                const int c = (nb * WG_TN + u) * 16 + nn;
-                float v = 0.f;
-                if (ok && c < Na) v = ha[(long)r * lda + c];
-                else if (ok && c < N) v = hb[(long)r * ldb + (c - Na)];
+                float v = KS_LDF(rA, ok ? va[u] : OOR, rj * lda * 4);
+                if (HASB) v += KS_LDF(rB, ok ? vb[u] : OOR, rj * ldb * 4);      // at most one of the two exists
                 b[j][u] = v;
             }
         }
@@ -435,7 +452,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 #pragma unroll
             for (int u = 0; u < WG_TN; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j][u], acc[u], 0, 0, 0);
         }
+    };
+    const int full_end = r0 + ((r1 - r0) >> 4 << 4);
+    if (Nb > 0) {
+        for (int k0 = r0; k0 < full_end; k0 += 16) round(k0, std::false_type{}, std::true_type{});
+        if (full_end < r1) round(full_end, std::true_type{}, std::true_type{});
+    } else {
+        for (int k0 = r0; k0 < full_end; k0 += 16) round(k0, std::false_type{}, std::false_type{});
+        if (full_end < r1) round(full_end, std::true_type{}, std::false_type{});
     }
+#undef KS_LDF
     float* out = ws + (long)chunk * ((long)M * N + M);
 #pragma unroll
     for (int u = 0; u < WG_TN; u++) {
