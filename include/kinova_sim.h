@@ -13,6 +13,7 @@
  *                               _get_obs(), _get_reward()                           ENV:1495-1552
  *                               + gym TimeLimit (max_episode_steps)                 gym_kinova_gripper/__init__.py:3-7, main_DDPGfD.py:384
  *   ks_set_env_params        <- (none: the reference edits geom mass / pair friction in the XML; config-5 extension)
+ *   ks_obs_from_snapshot     <- _get_obs() + _get_reward() on a given engine state          ENV:438-534, 631-687
  *   ks_get_state/ks_set_state<- sim.data.qpos / qvel / qacc_warmstart, sim.data.ncon,
  *                               contact forces (parity taps)                        ENV:109, 347-353
  *
@@ -105,6 +106,15 @@ int ks_set_env_params(ks_ctx *ctx, const void *obj_mass, const void *obj_mu, voi
 
 /* Advance by ONE mj_step with explicit controls ctrl [9, N] (no observation); parity testing. */
 int ks_substep(ks_ctx *ctx, const void *ctrl, void *stream);
+
+/* Observation / reward / termination of caller-provided kinematic snapshots: snap [105, N] = world poses of bodies 2..9
+ * (j2s7s300_link_7, finger 1 proximal, distal, finger 2 ..., object; 12 values each: rotation row-major 9, position 3)
+ * followed by the 9 jointpos sensors (slides, proximal 1-3, distal 1-3); rays [17, N] = the rangefinder distances
+ * (-1 = no hit).  Replaces _get_obs() + _get_reward() on a given mujoco-py state (ENV:438-534, 631-687) without any
+ * stepping: done bit0 = lifted; no step counter, no time limit, no auto-reset.  Overwrites the context's snapshot and ray
+ * buffers (call ks_reset afterwards to continue an episode).  Parity hook: the reference-generated env-layer golden
+ * vectors go through the HIP observation kernel this way. */
+int ks_obs_from_snapshot(ks_ctx *ctx, const void *snap, const void *rays, void *obs, void *reward, uint8_t *done, void *info, void *stream);
 
 /* HIP event timing of the dominant kernel: average duration (ms) of the env-step kernel launches
  * since the last call with reset != 0, measured with hipEvents on the launch stream.  Host sync.

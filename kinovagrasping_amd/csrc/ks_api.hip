@@ -476,7 +476,8 @@ template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model
 }
 
 // mode 0: after a step (reward / done / time limit / auto-reset flagging); mode 1: after a reset
-// (observation of flagged envs only, flag cleared)
+// (observation of flagged envs only, flag cleared); mode 2: observation / reward / lifted flag of whatever snapshot and
+// rays the buffers hold, no episode bookkeeping (ks_obs_from_snapshot, the parity hook for the env-layer golden vectors)
 template <typename T>
 __global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ mp, Buffers<T> b, int N, int mode, int horizon, int auto_reset,
                                               int env_major, T* __restrict__ obs, T* __restrict__ reward, uint8_t* __restrict__ done,
@@ -496,10 +497,10 @@ __global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ mp, B
     bool lifted;
     build_obs(*mp, snap, rays, [&](int j, T v) { o[j] = v; }, rew, lifted, inf);
     uint8_t d = 0;
-    if (mode == 0) {
-        const int sc = b.step_count[env] + 1;
-        b.step_count[env] = sc;
-        d = (lifted ? 1 : 0) | ((horizon > 0 && sc >= horizon) ? 2 : 0);
+    if (mode == 0 || mode == 2) {
+        int sc = 0;
+        if (mode == 0) { sc = b.step_count[env] + 1; b.step_count[env] = sc; }
+        d = (lifted ? 1 : 0) | ((mode == 0 && horizon > 0 && sc >= horizon) ? 2 : 0);
         if (reward) reward[env] = rew;
         if (done) done[env] = d;
         if (info) { info[env] = inf[0]; info[(long)N + env] = inf[1]; info[2L * N + env] = inf[2]; }
@@ -559,6 +560,7 @@ struct CtxBase {
     virtual int set_state(const void* qpos, const void* qvel, const void* warm, hipStream_t s) = 0;
     virtual int set_env_params(const void* mass, const void* mu, hipStream_t s) = 0;
     virtual int substep(const void* ctrl, hipStream_t s) = 0;
+    virtual int obs_from_snapshot(const void* snap, const void* rays, void* obs, void* reward, uint8_t* done, void* info, hipStream_t s) = 0;
     virtual int kernel_time(int reset, double* avg_ms, int64_t* launches) = 0;
 };
 
@@ -775,6 +777,17 @@ template <typename T> struct Ctx : CtxBase {
         if (mu) HIPCHK(hipMemcpyAsync(b.envp + N, mu, N * sizeof(T), hipMemcpyDefault, s));
         return KS_OK;
     }
+    int obs_from_snapshot(const void* snap, const void* rays, void* obs, void* reward, uint8_t* done, void* info, hipStream_t s) override {
+        if (!model_loaded) { error = "ks_obs_from_snapshot before ks_load_model"; return KS_ERR_STATE; }
+        if (!snap || !rays || !obs) { error = "ks_obs_from_snapshot: snapshot, rays and obs are required"; return KS_ERR_INVALID; }
+        const size_t N = cfg.n_envs;
+        HIPCHK(hipMemcpyAsync(b.snap, snap, (size_t)SNAP_TOTAL * N * sizeof(T), hipMemcpyDefault, s));
+        HIPCHK(hipMemcpyAsync(b.rays, rays, (size_t)NRAY * N * sizeof(T), hipMemcpyDefault, s));
+        hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, (int)N, 2, 0, 0, cfg.obs_env_major,
+                           (T*)obs, (T*)reward, done, (T*)info, (T*)nullptr);
+        HIPCHK(hipGetLastError());
+        return KS_OK;
+    }
     int kernel_time(int reset, double* avg_ms, int64_t* launches) override {
         HIPCHK(hipDeviceSynchronize());
         for (int i = 0; i < ev_used; i++) {
@@ -871,6 +884,10 @@ int ks_set_env_params(ks_ctx* ctx, const void* obj_mass, const void* obj_mu, voi
 int ks_substep(ks_ctx* ctx, const void* ctrl, void* stream) {
     if (!ctx) return KS_ERR_INVALID;
     return ctx->impl->substep(ctrl, (hipStream_t)stream);
+}
+int ks_obs_from_snapshot(ks_ctx* ctx, const void* snap, const void* rays, void* obs, void* reward, uint8_t* done, void* info, void* stream) {
+    if (!ctx) return KS_ERR_INVALID;
+    return ctx->impl->obs_from_snapshot(snap, rays, obs, reward, done, info, (hipStream_t)stream);
 }
 int ks_kernel_time(ks_ctx* ctx, int reset, double* avg_ms, int64_t* launches) {
     if (!ctx) return KS_ERR_INVALID;

@@ -900,24 +900,46 @@ template <typename T> KS_HD void gjk_support(PairGeo<T>& g, const T* dir, T* y, 
     sub3(y, a, b);
 }
 
-// closest point to the origin on a triangle: barycentric weights (Ericson, RTCD 5.1.5)
+// closest point to the origin on the segment A + t (B - A), t clamped to [0, 1]; returns its squared norm
+template <typename T> KS_HD T closest_seg(const T* A, const T* B, T& t) {
+    T d[3], q[3];
+    sub3(d, B, A);
+    const T dd = dot3(d, d), tt = -dot3(A, d);
+    t = dd > T(1e-30) ? (tt <= 0 ? T(0) : (tt >= dd ? T(1) : tt / dd)) : T(0);
+    copy3(q, A);
+    addscl3(q, d, t);
+    return dot3(q, q);
+}
+
+// Closest point to the origin on a triangle: barycentric weights l[3].  The minimum over four candidates - the closest
+// points of the three (clamped) edges and, when the origin projects inside, the interior point - every one of which IS a
+// point of the triangle, so the result can only be too far, never outside the simplex.  The textbook region tests
+// (Ericson, RTCD 5.1.5; what the fp64 oracle uses) decide on products like d1 d4 - d3 d2 that cancel for the sliver
+// triangles a Minkowski difference of two hulls produces (two nearly parallel edges): in fp32 a wrong region gave a
+// "closest" point that was not orthogonal to the simplex, GJK then met a repeated support vertex and stopped 3 % short
+// of the distance with a normal several degrees off.  No data-dependent branches besides the selects.
 template <typename T> KS_HD void closest_tri(const T* A, const T* B, const T* C, T* l) {
-    T ab[3], ac[3];
+    T tab, tac, tbc;
+    const T dab = closest_seg(A, B, tab), dac = closest_seg(A, C, tac), dbc = closest_seg(B, C, tbc);
+    T best = dab;
+    l[0] = 1 - tab; l[1] = tab; l[2] = 0;
+    if (dac < best) { best = dac; l[0] = 1 - tac; l[1] = 0; l[2] = tac; }
+    if (dbc < best) { best = dbc; l[0] = 0; l[1] = 1 - tbc; l[2] = tbc; }
+    T ab[3], ac[3], n[3], c1[3], c2[3];
     sub3(ab, B, A); sub3(ac, C, A);
-    T d1 = -dot3(ab, A), d2 = -dot3(ac, A);
-    if (d1 <= 0 && d2 <= 0) { l[0] = 1; l[1] = 0; l[2] = 0; return; }
-    T d3 = -dot3(ab, B), d4 = -dot3(ac, B);
-    if (d3 >= 0 && d4 <= d3) { l[0] = 0; l[1] = 1; l[2] = 0; return; }
-    T vc = d1 * d4 - d3 * d2;
-    if (vc <= 0 && d1 >= 0 && d3 <= 0) { T v = d1 / (d1 - d3); l[0] = 1 - v; l[1] = v; l[2] = 0; return; }
-    T d5 = -dot3(ab, C), d6 = -dot3(ac, C);
-    if (d6 >= 0 && d5 <= d6) { l[0] = 0; l[1] = 0; l[2] = 1; return; }
-    T vb = d5 * d2 - d1 * d6;
-    if (vb <= 0 && d2 >= 0 && d6 <= 0) { T w = d2 / (d2 - d6); l[0] = 1 - w; l[1] = 0; l[2] = w; return; }
-    T va = d3 * d6 - d5 * d4;
-    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { T w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); l[0] = 0; l[1] = 1 - w; l[2] = w; return; }
-    T den = T(1) / (va + vb + vc);
-    l[1] = vb * den; l[2] = vc * den; l[0] = 1 - l[1] - l[2];
+    cross3(n, ab, ac);
+    const T nn = dot3(n, n);
+    if (nn > T(1e-30)) {
+        // barycentric coordinates of the origin's projection: with ap = -A, l1 = ((ap x ac) . n) / nn, l2 = ((ab x ap) . n) / nn
+        cross3(c1, ac, A);
+        cross3(c2, A, ab);
+        const T l1 = dot3(c1, n) / nn, l2 = dot3(c2, n) / nn, l0 = 1 - l1 - l2;
+        if (l0 > 0 && l1 > 0 && l2 > 0) {
+            T q[3] = {0, 0, 0};
+            addscl3(q, A, l0); addscl3(q, B, l1); addscl3(q, C, l2);
+            if (dot3(q, q) < best) { l[0] = l0; l[1] = l1; l[2] = l2; }
+        }
+    }
 }
 
 template <typename T> KS_HD void swap_slots(Simplex<T>& S, T* l, int i, int j, bool doit) {
@@ -1004,7 +1026,10 @@ template <typename T> KS_HD void gjk_remember(GjkWarm* ws, const Simplex<T>& S) 
 template <typename T> KS_FN int gjk_distance(PairGeo<T>& g, T margin, T* dist, T* normal, T* pos, GjkWarm* ws = nullptr) {
     Simplex<T> S;
     T lam[4] = {1, 0, 0, 0}, v[3], d[3];
-    const T tol = T(1e-6);
+#ifndef KS_GJK_TOL
+#define KS_GJK_TOL 1e-6
+#endif
+    const T tol = T(KS_GJK_TOL);
     KS_UNROLL
     for (int i = 0; i < 4; i++) {
         S.ia[i] = 0; S.ib[i] = 0;
@@ -1058,6 +1083,9 @@ template <typename T> KS_FN int gjk_distance(PairGeo<T>& g, T margin, T* dist, T
         KS_UNROLL
         for (int i = 0; i < 4; i++)
             if (i < S.n && S.y[i][0] == w[0] && S.y[i][1] == w[1] && S.y[i][2] == w[2]) dup = true;
+#ifdef KS_DEBUG_GJK
+        if (dup) printf("  -> dup\n");
+#endif
         if (dup) break;
         Simplex<T> prev = S;
         T plam[4] = {lam[0], lam[1], lam[2], lam[3]}, pv[3] = {v[0], v[1], v[2]};
@@ -1072,6 +1100,9 @@ template <typename T> KS_FN int gjk_distance(PairGeo<T>& g, T margin, T* dist, T
         if (inside_) { gjk_remember(ws, S); return 2; }
 #else
         if (gjk_closest(S, lam, v)) { gjk_remember(ws, S); return 2; }
+#endif
+#ifdef KS_DEBUG_GJK
+        printf("  -> new vv %.9g (n %d) lam %.4g %.4g %.4g %.4g%s\n", (double)dot3(v, v), S.n, (double)lam[0], (double)lam[1], (double)lam[2], (double)lam[3], dot3(v, v) >= vv ? " NO DECREASE" : "");
 #endif
         if (dot3(v, v) >= vv) {
             copy3(v, pv);

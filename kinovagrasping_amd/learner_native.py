@@ -82,6 +82,10 @@ class NativeDDPGfDUpdate:
         # The 8000-row forwards of the actor phase stay on the library GEMMs unless the update is LDS-free: at that size
         # three large-tile GEMMs beat the 16-row-tile LDS kernel (measured 1.48 vs 1.44 ms per env-step in bench.py).
         self.fuse_critic_fwd, self.fuse_actor_fwd = True, False
+        # diagnostics: the actor loss -mean_w Q(s, pi(s)) is not needed by the update (dLoss/dQ is constant); with
+        # track_actor_loss it is evaluated from the Q of phase_actor's critic forward and kept in self.actor_loss
+        self.track_actor_loss = False
+        self.actor_loss = torch.zeros((), device=policy.device)
 
     # -- helpers ------------------------------------------------------------------------------------------------------
     def _st(self):
@@ -189,7 +193,9 @@ class NativeDDPGfDUpdate:
             ha1, ha2 = sa.new_empty(rows, a_.W[0].shape[0]), sa.new_empty(rows, a_.W[1].shape[0])
             a = _mlp.mlp3_forward(al, sa, act=_mlp.ACT_SIGMOID, scale=pol.max_action, h1_out=ha1, h2_out=ha2, shadow=True)
             hc1, hc2 = sa.new_empty(rows, c.W[0].shape[0]), sa.new_empty(rows, c.W[1].shape[0])
-            _mlp.mlp3_forward(cl, sa, a, act=_mlp.ACT_NONE, h1_out=hc1, h2_out=hc2, shadow=True)           # Q itself is not needed
+            q = _mlp.mlp3_forward(cl, sa, a, act=_mlp.ACT_NONE, h1_out=hc1, h2_out=hc2, shadow=True)       # Q itself is not needed
+            if self.track_actor_loss:
+                self._set_actor_loss(q, n)
             dq = (self.weight / (self.wsum * (-float(n)))).repeat_interleave(n).unsqueeze(1).contiguous()
             # dLoss/d(actor pre-activation): through the critic to its action inputs, then through 0.8 * sigmoid
             _, _, dz3 = _mlp.mlp3_backward(cl, dq, hc1, hc2, want_dz=False, dx_cols=(sa.shape[1], a.shape[1]), act_out=a, scale=pol.max_action)
@@ -208,6 +214,8 @@ class NativeDDPGfDUpdate:
             ha1, ha2, a = self._actor_forward(a_, sa)
             hc1 = self._lin_relu(c, 0, torch.cat([sa, a], 1))
             hc2 = self._lin_relu(c, 1, hc1)
+        if self.track_actor_loss:
+            self._set_actor_loss(torch.addmm(c.b[2], hc2, c.W[2].t()), n)
         # d(-sum_r w_r sum_k Q_rk / (sum(w) n)) / dQ_rk
         dq = (self.weight / (self.wsum * (-float(n)))).repeat_interleave(n).unsqueeze(1)
         dh2 = torch.mm(dq, c.W[2])
@@ -218,6 +226,10 @@ class NativeDDPGfDUpdate:
         self._chk(self.lib.kr_sigmoid_scale_backward(da.numel(), P(a), pol.max_action, P(da), self._st()), "kr_sigmoid_scale_backward")
         self._weight_grads(a_, sa, ha1, ha2, da)
         return None
+
+    def _set_actor_loss(self, q, n):
+        """-sum_r w_r sum_k Q_rk / (sum(w) n)  (DDPGfD.py:341: -critic(state, actor(state)).mean())"""
+        self.actor_loss = -(q.view(-1, n).sum(1) * self.weight).sum() / (self.wsum[0] * float(n))
 
     @torch.no_grad()
     def phase_head(self):

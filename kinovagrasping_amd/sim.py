@@ -22,7 +22,7 @@ class KsConfig(C.Structure):
 
 
 EXPORTS = ["ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_load_model", "ks_reset", "ks_step",
-           "ks_get_state", "ks_set_state", "ks_set_env_params", "ks_substep", "ks_kernel_time", "ks_version"]
+           "ks_get_state", "ks_set_state", "ks_set_env_params", "ks_substep", "ks_obs_from_snapshot", "ks_kernel_time", "ks_version"]
 # include/kinova_rollout.h
 ROLLOUT_EXPORTS = ["kr_select_action", "kr_store_transition", "kr_rank_episodes", "kr_commit_episodes", "kr_advance_ring",
                    "kr_sample_windows", "kr_critic_grad", "kr_relu_backward", "kr_sigmoid_scale_backward", "kr_adam_step", "kr_soft_update",
@@ -56,6 +56,7 @@ def load_library(path: Path | None = None):
     L.ks_set_state.argtypes = [vp, vp, vp, vp, vp]
     L.ks_set_env_params.argtypes = [vp, vp, vp, vp]
     L.ks_substep.argtypes = [vp, vp, vp]
+    L.ks_obs_from_snapshot.argtypes = [vp] * 8
     L.ks_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     i32, f32 = C.c_int32, C.c_float
     L.kr_select_action.argtypes = [i32] + [vp] * 7 + [f32, f32, i32] + [vp] * 4
@@ -159,6 +160,18 @@ class KinovaSim:
         ctrl = ctrl.to(self.device, self.dtype).contiguous()
         self._check(self.lib.ks_substep(self.ctx, _ptr(ctrl), self._stream()))
         self._keep_c = ctrl
+
+    def obs_from_snapshot(self, snap: torch.Tensor, rays: torch.Tensor):
+        """snap [105, N] (poses of bodies 2..9, then the 9 jointpos sensors), rays [17, N] -> (obs, reward, done, info) of
+        that engine state (ks_obs_from_snapshot: _get_obs + _get_reward without stepping)."""
+        snap = snap.to(self.device, self.dtype).contiguous()
+        rays = rays.to(self.device, self.dtype).contiguous()
+        if tuple(snap.shape) != (105, self.n_envs) or tuple(rays.shape) != (17, self.n_envs):
+            raise ValueError("obs_from_snapshot: snap [105, N], rays [17, N]")
+        self._check(self.lib.ks_obs_from_snapshot(self.ctx, _ptr(snap), _ptr(rays), _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
+                                                  _ptr(self.info), self._stream()))
+        self._keep_s = (snap, rays)
+        return self.obs, self.reward, self.done, self.info
 
     def get_state(self, contacts: bool = False):
         N, dt, dev = self.n_envs, self.dtype, self.device

@@ -23,6 +23,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef KO_GJK_TOL
+#define KO_GJK_TOL 1e-6
+#endif
 #define CCD_EPS 1e-15
 #define PLANE_MESH_TOL 0.3 /* extra plane-hull contacts must be > 0.3*rbound apart */
 #define MINVAL 1e-15
@@ -531,24 +534,43 @@ static void gjk_support(mpr_ctx *c, const double *dir, double *y, double *a, dou
     c->s->mpr_support_calls++;
 }
 
-/* closest point to the origin on triangle (p0,p1,p2): barycentric l[3] (Ericson, RTCD 5.1.5) */
+/* closest point to the origin on the segment A + t (B - A), t clamped to [0, 1]; returns its squared norm */
+static double closest_seg(const double *A, const double *B, double *t) {
+    double d[3], q[3];
+    sub3(d, B, A);
+    double dd = dot3(d, d), tt = -dot3(A, d);
+    *t = dd > 1e-30 ? (tt <= 0 ? 0.0 : (tt >= dd ? 1.0 : tt / dd)) : 0.0;
+    copy3(q, A);
+    addscl3(q, d, *t);
+    return dot3(q, q);
+}
+
+/* closest point to the origin on triangle (A,B,C): barycentric l[3].  Minimum over four candidates that are all
+ * points of the triangle: the closest points of the three clamped edges and, when the origin projects inside, the
+ * interior point.  (The textbook region tests - Ericson, RTCD 5.1.5 - decide on products such as d1 d4 - d3 d2 that
+ * cancel for the sliver triangles of a Minkowski difference; in single precision a wrong region ends GJK early with a
+ * normal several degrees off.  The kernels use this same formulation so that both sides break ties alike.) */
 static void closest_tri(const double *A, const double *B, const double *C, double *l) {
-    double ab[3], ac[3];
+    double tab, tac, tbc;
+    double dab = closest_seg(A, B, &tab), dac = closest_seg(A, C, &tac), dbc = closest_seg(B, C, &tbc);
+    double best = dab;
+    l[0] = 1 - tab; l[1] = tab; l[2] = 0;
+    if (dac < best) { best = dac; l[0] = 1 - tac; l[1] = 0; l[2] = tac; }
+    if (dbc < best) { best = dbc; l[0] = 0; l[1] = 1 - tbc; l[2] = tbc; }
+    double ab[3], ac[3], n[3], c1[3], c2[3];
     sub3(ab, B, A); sub3(ac, C, A);
-    double d1 = -dot3(ab, A), d2 = -dot3(ac, A);
-    if (d1 <= 0 && d2 <= 0) { l[0] = 1; l[1] = 0; l[2] = 0; return; }
-    double d3 = -dot3(ab, B), d4 = -dot3(ac, B);
-    if (d3 >= 0 && d4 <= d3) { l[0] = 0; l[1] = 1; l[2] = 0; return; }
-    double vc = d1 * d4 - d3 * d2;
-    if (vc <= 0 && d1 >= 0 && d3 <= 0) { double v = d1 / (d1 - d3); l[0] = 1 - v; l[1] = v; l[2] = 0; return; }
-    double d5 = -dot3(ab, C), d6 = -dot3(ac, C);
-    if (d6 >= 0 && d5 <= d6) { l[0] = 0; l[1] = 0; l[2] = 1; return; }
-    double vb = d5 * d2 - d1 * d6;
-    if (vb <= 0 && d2 >= 0 && d6 <= 0) { double w = d2 / (d2 - d6); l[0] = 1 - w; l[1] = 0; l[2] = w; return; }
-    double va = d3 * d6 - d5 * d4;
-    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { double w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); l[0] = 0; l[1] = 1 - w; l[2] = w; return; }
-    double den = 1.0 / (va + vb + vc);
-    l[1] = vb * den; l[2] = vc * den; l[0] = 1 - l[1] - l[2];
+    cross3(n, ab, ac);
+    double nn = dot3(n, n);
+    if (nn > 1e-30) {
+        cross3(c1, ac, A);
+        cross3(c2, A, ab);
+        double l1 = dot3(c1, n) / nn, l2 = dot3(c2, n) / nn, l0 = 1 - l1 - l2;
+        if (l0 > 0 && l1 > 0 && l2 > 0) {
+            double q[3] = {0, 0, 0};
+            addscl3(q, A, l0); addscl3(q, B, l1); addscl3(q, C, l2);
+            if (dot3(q, q) < best) { l[0] = l0; l[1] = l1; l[2] = l2; }
+        }
+    }
 }
 
 /* closest point to the origin on the simplex; reduces it to the supporting sub-simplex, writes
@@ -610,7 +632,7 @@ static int gjk_closest(gjk_simplex *S, double *lam, double *v) {
 static int gjk_distance(mpr_ctx *c, double margin, double *dist, double *normal, double *pos) {
     gjk_simplex S;
     double lam[4] = {1, 0, 0, 0}, v[3], d[3];
-    const double tol = 1e-6; /* relative progress tolerance; polytopes normally stop on a repeated vertex */
+    const double tol = KO_GJK_TOL; /* relative progress tolerance; polytopes normally stop on a repeated vertex */
     sub3(d, c->s->geom_xpos[c->g2], c->s->geom_xpos[c->g1]);
     if (dot3(d, d) < MINVAL) { d[0] = 1; d[1] = 0; d[2] = 0; }
     gjk_support(c, d, S.y[0], S.a[0], S.b[0]);

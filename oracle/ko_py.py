@@ -171,6 +171,30 @@ class OracleSim:
         return out
 
 
+def _contact_forces(self):
+    """[ncon, 3] constraint force of every contact of the last forward pass in its own frame (normal, tangent 1,
+    tangent 2), recovered from the pyramid rows of efc_force as MuJoCo's mj_contactForce does: normal = sum of the four
+    edge forces, tangent k = mu_k * (f+ - f-).  Contacts outside their margin have no rows (zero force)."""
+    s = self.s
+    ty = _np(s.efc_type)[:s.nefc]
+    f = _np(s.efc_force)[:s.nefc]
+    row = int((ty != 2).sum())
+    out = np.zeros((s.ncon, 3))
+    for i in range(s.ncon):
+        c = s.contact[i]
+        if c.dist >= c.margin:
+            continue
+        e = f[row:row + 4]
+        out[i] = [e.sum(), c.mu[0] * (e[0] - e[1]), c.mu[1] * (e[2] - e[3])]
+        row += 4
+    assert row == s.nefc
+    return out
+
+
+OracleSim.contact_forces = _contact_forces
+GEOM_BODY = [0, 2, 3, 4, 5, 6, 7, 8, 9]        # body of geom g (ground, palm, f1_prox, f1_dist, ..., object)
+
+
 def env_obs_from_inputs(inputs: dict):
     """Pure env-layer functions on fake-sim inputs (golden-vector pinning)."""
     ei = EnvInputs()

@@ -74,10 +74,10 @@ def test_one_step_fp64_matches_oracle(cube):
     eq, ev, ncon, onc = run_teacher_forced(64, cube, rec, hq)
     print(f"fp64 one-step |dqpos|: median {np.median(eq):.2e} p99 {np.percentile(eq, 99):.2e} max {eq.max():.2e}")
     assert (ncon == onc).all()
-    # exact except where an exact tie in the single-point contact position (parallel features) is broken
-    # differently by FMA contraction (DESIGN.md "known limits")
-    assert np.percentile(eq, 98) < 1e-9, np.percentile(eq, 98)
-    assert eq.max() < 5e-3, eq.max()
+    # every state, no percentile: kernel and oracle share the closest-point formulation (closest_tri), so even the
+    # single-point contact positions on parallel features break their ties alike
+    assert eq.max() < 1e-9, eq.max()
+    assert ev.max() < 1e-7, ev.max()
 
 
 def test_one_step_fp32_matches_oracle(cube):

@@ -90,6 +90,12 @@ def snapshot(sim, geom_size):
         "body_xpos": {"j2s7s300_link_7": sim.view("xpos").reshape(10, 3)[2].copy()},
         "sensordata": sim.view("sensordata").copy(),
         "geom_size": geom_size,
+        # the body poses the geom / site positions above derive from (not read by the reference: they let the
+        # GPU test feed the SAME kinematic state to the HIP build_obs, whose input is body poses)
+        "all_body_xpos": sim.view("xpos").reshape(10, 3).copy(),
+        "all_body_xmat": sim.view("xmat").reshape(10, 9).copy(),
+        "qpos": sim.view("qpos").copy(),
+        "hand_quat": np.array(sim.s.hand_quat[:]),
     }
 
 
@@ -136,7 +142,7 @@ def main():
 
     out = {k: [] for k in ("palm_xpos", "palm_xmat", "finger_xpos", "obj_xpos", "link7_xpos", "site_xpos", "sensordata",
                            "obj_size", "obs_local", "obs_global", "reward", "done", "info", "action", "ctrl", "Tfw",
-                           "wrist", "palm_hit", "shape_idx")}
+                           "wrist", "palm_hit", "shape_idx", "body_xpos", "body_xmat", "qpos", "hand_quat")}
     for shape, oname, snap, action in cases:
         env = kge.KinovaGripper_Env.__new__(kge.KinovaGripper_Env)
         data = FakeData(snap)
@@ -194,6 +200,10 @@ def main():
         out["wrist"].append(env.wrist_pose)
         out["palm_hit"].append(palm_hit)
         out["shape_idx"].append(shapes.index(shape))
+        out["body_xpos"].append(snap["all_body_xpos"])
+        out["body_xmat"].append(snap["all_body_xmat"])
+        out["qpos"].append(snap["qpos"])
+        out["hand_quat"].append(snap["hand_quat"])
     # check_grasp known answers (expert_data.py:559-593)
     cg_old = rng.uniform(-0.1, 0.1, (40, 8))
     cg_new = cg_old + rng.uniform(-1, 1, (40, 8)) * rng.choice([1e-4, 1e-3, 1e-2], (40, 1))
