@@ -13,7 +13,13 @@ the rank.  4096 envs per GPU (BASELINE metric), CubeS, 'normal' hand pose, env i
       action streams resident in HBM; sim kernels only.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel k_env_step, HIP-event timed on the
-launch stream inside this process) and `cpu_baseline` (the fp64 CPU oracle on the host cores, N=1 only).
+launch stream inside this process), `mfma` (the learner's MLP kernels against the fp32 MFMA peak), `steady_state`
+(a second timed window after 1500 learner updates: the policy has by then learned to drive the hands into contact-rich
+grasps, which lengthens the stepping kernel) and `cpu_baseline` (the fp64 CPU oracle on the host cores, N=1 only).
+
+Multi-GPU: `python bench.py --gpus N` starts N ranks itself (fresh child processes, spawned BEFORE this process touches
+torch or HIP; rendezvous on 127.0.0.1) - the same thing the driver does with `python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N`; under a launcher (WORLD_SIZE set) --gpus must equal WORLD_SIZE.
 """
 from __future__ import annotations
 
@@ -60,6 +66,47 @@ def cpu_baseline(n_cores: int, budget_s: float = 12.0):
                       f"{sum(s for s, _ in res)} env-steps total"}
 
 
+def launch_ranks(n_ranks: int, argv) -> int:
+    """Start `n_ranks` copies of this script as child processes (one per GPU, env-style rendezvous on 127.0.0.1) and wait.
+    Nothing in this process has touched torch / HIP at this point, and no process that has is ever re-exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + list(argv), env=env))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+            if rc:                                   # one rank failed: the others would wait in a collective for ever
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
+    except KeyboardInterrupt:
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        rc = 130
+    return rc
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32)
+
+
+def update_flops(hidden, rows, n=5, state=82, action=4):
+    """FLOPs of one DDPGfD update on `rows` sampled windows: MACs per sample A (actor) / C (critic), forward
+    equivalents 2 (A + C) targets on 2R rows... = R (17 A + 20 C) MACs, x2 flops."""
+    h1, h2 = hidden
+    A = state * h1 + h1 * h2 + h2 * action
+    C = (state + action) * h1 + h1 * h2 + h2
+    return 2.0 * rows * (17 * A + 20 * C)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,7 +118,14 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch the rollout / learner ops one by one instead of replaying HIP graphs")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--steady-updates", type=int, default=1500, help="learner updates before the steady_state window (ddpg mode; 0 = skip)")
+    ap.add_argument("--steady-steps", type=int, default=300, help="length of the steady_state window in env-steps (a multiple of the 30-step episode)")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: start it as `python bench.py --gpus N` "
+                 "or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
 
     import numpy as np
     import torch
@@ -181,10 +235,57 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kern_ms, launches = sim.kernel_time()
+    timed_updates = updates - upd0
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
+    # ---- the learner's MLP kernels against the fp32 MFMA peak: the update's graphs replayed ALONE (no simulator beside
+    # them), HIP-graph launch gaps and the small glue kernels (sampling, loss gradient, Adam) included
+    mfma = None
+    if trainer is not None and updates > upd0:
+        reps = 20
+        barrier()
+        t1 = time.perf_counter()
+        with torch.cuda.stream(trainer.side):
+            for _ in range(reps):
+                trainer.g_head.replay()
+                trainer._body()
+        trainer.main.wait_stream(trainer.side)
+        barrier()
+        upd_ms = (time.perf_counter() - t1) / reps * 1e3
+        updates = trainer.updates
+        rows = 64 * 25
+        fl = update_flops(tuple(args.hidden), rows)
+        tf = fl / (upd_ms * 1e-3) / 1e12
+        mfma = {"bound": "mfma", "kernels": "learner update (k_mlp3_wave, k_mlp3_bwd_wave, k_wgrad_wave + glue) replayed alone",
+                "flop_per_update": fl, "rows": rows, "update_ms_alone": round(upd_ms, 4), "achieved": round(tf, 3), "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 5), "dtype": "f32 (v_mfma_f32_16x16x4_f32, exact fp32)",
+                "note": "in the pipeline the update runs on a second stream in the shadow of k_env_step (one wave per SIMD leaves the matrix "
+                        "pipes idle) and is off the critical path; small-batch, latency-bound by design"}
+    # ---- steady state: the same step after `--steady-updates` learner updates (the trained policy closes the hand into
+    # contact-rich grasps, the stepping kernel grows with the contact count), window = a multiple of the 30-step episode
+    steady = None
+    if args.mode == "ddpg" and trainer is not None and args.steady_updates > 0:
+        k = priming + args.warmup + args.steps
+        while updates < args.steady_updates:
+            step_fn(k); k += 1
+        barrier()
+        sim.kernel_time(reset=True)
+        u0, t2 = updates, time.perf_counter()
+        for _ in range(args.steady_steps):
+            step_fn(k); k += 1
+        trainer.flush()
+        barrier()
+        dts = time.perf_counter() - t2
+        ks_ms, ks_n = sim.kernel_time()
+        if world > 1:
+            tt = torch.tensor([dts], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dts = tt.item()
+        steady = {"value": round(n * world * args.steady_steps / dts, 1), "unit": "env-steps/s", "steps": args.steady_steps,
+                  "after_updates": u0, "learner_updates_timed": updates - u0, "ms_per_step": round(dts / args.steady_steps * 1e3, 4),
+                  "k_env_step_avg_launch_ms": round(ks_ms, 4), "launches_timed": ks_n}
     status = sim.get_state()["status"]
     bad = int((status & 2).ne(0).sum().item())
     # replicas must hold bit-identical weights after the all-reduced updates: spread of two checksums over the ranks
@@ -222,7 +323,7 @@ def main():
                                    (f"{n} envs/GPU CubeS normal-pose grasp sim, PCG64(1000+i) random-action rollout (BASELINE config 2 at the "
                                     "metric's env count); sim kernels only"),
                        "mode": args.mode, "envs_per_gpu": n, "frame_skip": 15, "solver": "newton x6", "hidden": list(args.hidden),
-                       "learner_updates_timed": updates - upd0 if args.mode == "ddpg" else 0, "priming_steps": priming,
+                       "learner_updates_timed": timed_updates if args.mode == "ddpg" else 0, "priming_steps": priming,
                        "launch": ("eager" if args.eager else "hip-graphs") if args.mode == "ddpg" else "direct",
                        "learner": learner_form,
                        "parallelism": f"env-shard x{world}" + (" + grad all-reduce" if world > 1 and args.mode == "ddpg" else "")},
@@ -232,7 +333,12 @@ def main():
                          "avg_launch_ms": round(kern_ms, 4), "launches_timed": launches,
                          "note": "algorithmic 768 B/env-step x envs per launch; the path is latency/VALU bound, not HBM bound (SURVEY 8d)",
                          "issue_bound": issue},
+            "mfma": mfma,
+            "steady_state": steady,
             "nonfinite_envs": bad,
+            "rccl": ({"ranks": world, "backend": os.environ.get("KS_DIST_BACKEND", "nccl"), "NCCL_ALGO": os.environ.get("NCCL_ALGO", "default"),
+                      "allreduces_per_update": 2, "bytes_per_allreduce": int(policy._flat_params["critic"].numel() * 4)}
+                     if world > 1 and args.mode == "ddpg" else None),
             "replica_weight_checksum_spread": replica_spread,
             "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 4),
         }

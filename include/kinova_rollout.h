@@ -63,10 +63,12 @@ int kr_advance_ring(int32_t n, int32_t capacity, const int64_t *total, int64_t *
                     int64_t *cur_len, void *stream);
 
 /* n-step window batch: B episodes x W = horizon - n_steps rows.  u_ep [B], u_start [B,W] uniform in [0,1).
+ * Episode b is the floor(u_ep[b] * (count - 1))-th OLDEST of the ring (slot head - count + k mod capacity): the newest
+ * episode is never sampled (np.random.randint(replay_ep_num - 1), utils.py:259), before and after the ring wraps.
  * Outputs state/next_state [B*W,n_steps,82], action [B*W,n_steps,4], reward/not_done [B*W,n_steps], weight [B*W]
- * (1 for real windows, 0 for padding rows). */
-int kr_sample_windows(int32_t batch, int32_t horizon, int32_t n_steps, const int64_t *count, const int64_t *ep_len, const float *u_ep,
-                      const float *u_start, const float *ep_state, const float *ep_next, const float *ep_action, const float *ep_reward,
+ * (1 for real windows, 0 for padding rows; all 0 while the ring holds fewer than two episodes). */
+int kr_sample_windows(int32_t batch, int32_t horizon, int32_t n_steps, const int64_t *count, const int64_t *head, int32_t capacity,
+                      const int64_t *ep_len, const float *u_ep, const float *u_start, const float *ep_state, const float *ep_next, const float *ep_action, const float *ep_reward,
                       const float *ep_not_done, float *state, float *action, float *next_state, float *reward, float *not_done,
                       float *weight, void *stream);
 

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void k_advance_ring(int n, int capacity, const
 
 // one wave per window row (b, w)
 __global__ __launch_bounds__(WAVE) void k_sample_windows(int B, int H, int n_steps, const int64_t* __restrict__ count,
+                                                         const int64_t* __restrict__ head, int capacity,
                                                          const int64_t* __restrict__ ep_len, const float* __restrict__ u_ep,
                                                          const float* __restrict__ u_start, const float* __restrict__ ep_state,
                                                          const float* __restrict__ ep_next, const float* __restrict__ ep_action,
@@ -148,10 +149,17 @@ __global__ __launch_bounds__(WAVE) void k_sample_windows(int B, int H, int n_ste
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= B * W) return;
     const int b = r / W, w = r % W;
-    long hi = count[0] - 1;                    // the newest episode is never sampled (utils.py:259)
+    // np.random.randint(replay_ep_num - 1): the k-th OLDEST episode, k in [0, count - 1) - the newest one is never sampled
+    // (utils.py:259).  In the ring the oldest episode sits at head - count, so after the first wrap the excluded slot is
+    // head - 1, wherever that is.  With fewer than two episodes there is nothing to sample: every row gets weight 0.
+    const long cnt = count[0];
+    const bool none = cnt < 2;
+    long hi = cnt - 1;
     hi = hi > 1 ? hi : 1;
-    long ep = (long)(u_ep[b] * (float)hi);
-    ep = ep < hi - 1 ? ep : hi - 1;
+    long k = (long)(u_ep[b] * (float)hi);
+    k = k < hi - 1 ? k : hi - 1;
+    long ep = (head[0] - cnt + k) % capacity;
+    ep = ep < 0 ? ep + capacity : ep;
     long ceiling = ep_len[ep] - n_steps;
     ceiling = ceiling > 1 ? ceiling : 1;
     long start = (long)(u_start[(long)b * W + w] * (float)ceiling);
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(WAVE) void k_sample_windows(int B, int H, int n_ste
         reward[dst + lane] = ep_reward[src + lane];
         not_done[dst + lane] = ep_not_done[src + lane];
     }
-    if (lane == 0) weight[r] = w < ceiling ? 1.0f : 0.0f;
+    if (lane == 0) weight[r] = (!none && w < ceiling) ? 1.0f : 0.0f;
 }
 
 // ---- learner glue: plain grid-stride elementwise kernels, no fma contraction where the torch expression has none
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(256) void k_critic_grad(int R, int n, const float* 
     // single workgroup: the batch is a few thousand rows; the three masked means are block reductions
     using Reduce = hipcub::BlockReduce<float, 256>;
     __shared__ typename Reduce::TempStorage tmp;
-    const float inv = 1.0f / wsum[0];
+    const float inv = wsum[0] > 0.0f ? 1.0f / wsum[0] : 0.0f;     // an all-padding batch (empty replay) has zero loss and gradient
     float l1 = 0, ln = 0;
     for (int r = threadIdx.x; r < R; r += 256) {
         const float t1 = reward[(long)r * n] + discount * tq1[r];
@@ -291,15 +299,15 @@ int kr_advance_ring(int32_t n, int32_t capacity, const int64_t* total, int64_t* 
     return launched();
 }
 
-int kr_sample_windows(int32_t batch, int32_t horizon, int32_t n_steps, const int64_t* count, const int64_t* ep_len, const float* u_ep,
-                      const float* u_start, const float* ep_state, const float* ep_next, const float* ep_action, const float* ep_reward,
+int kr_sample_windows(int32_t batch, int32_t horizon, int32_t n_steps, const int64_t* count, const int64_t* head, int32_t capacity,
+                      const int64_t* ep_len, const float* u_ep, const float* u_start, const float* ep_state, const float* ep_next, const float* ep_action, const float* ep_reward,
                       const float* ep_not_done, float* state, float* action, float* next_state, float* reward, float* not_done, float* weight,
                       void* stream) {
-    if (batch <= 0 || horizon <= n_steps || n_steps <= 0 || n_steps > WAVE || !count || !ep_len || !u_ep || !u_start || !ep_state || !ep_next ||
+    if (batch <= 0 || horizon <= n_steps || n_steps <= 0 || n_steps > WAVE || capacity <= 0 || !count || !head || !ep_len || !u_ep || !u_start || !ep_state || !ep_next ||
         !ep_action || !ep_reward || !ep_not_done || !state || !action || !next_state || !reward || !not_done || !weight)
         return KS_ERR_INVALID;
     hipLaunchKernelGGL(k_sample_windows, dim3(batch * (horizon - n_steps)), dim3(WAVE), 0, (hipStream_t)stream, batch, horizon, n_steps, count,
-                       ep_len, u_ep, u_start, ep_state, ep_next, ep_action, ep_reward, ep_not_done, state, action, next_state, reward, not_done,
+                       head, capacity, ep_len, u_ep, u_start, ep_state, ep_next, ep_action, ep_reward, ep_not_done, state, action, next_state, reward, not_done,
                        weight);
     return launched();
 }

@@ -94,6 +94,7 @@ class DDPGfD:
         self.max_action = max_action
         self.process_group = process_group
         self._flat = None
+        self._native = None          # learner_native.NativeDDPGfDUpdate attached to this policy (keeps its own flat Adam state)
 
     # -- inference ------------------------------------------------------------------------------
     @torch.no_grad()
@@ -143,7 +144,7 @@ class DDPGfD:
         if weight is None:
             return x.mean()
         w = weight.view(-1, *([1] * (x.dim() - 1)))
-        return (x * w).sum() / (w.sum() * per_row)
+        return (x * w).sum() / (w.sum().clamp_min(1.0) * per_row)      # 0 / 1 weights: exact unless the batch is all padding
 
     def phase_critic(self, state, action, next_state, reward, weight=None):
         """targets + critic loss + backward (DDPGfD.py:256-330).  Returns (critic, L1, LN) losses."""
@@ -213,6 +214,8 @@ class DDPGfD:
 
     # -- checkpoints: the reference's four files (DDPGfD.py:371-382) ---------------------------------
     def save(self, filename):
+        if self._native is not None:
+            self._native.export_optimizer_state()     # the native learner's Adam moments / step -> the torch optimizers' state
         torch.save(self.critic.state_dict(), filename + "_critic")
         torch.save(self.critic_optimizer.state_dict(), filename + "_critic_optimizer")
         torch.save(self.actor.state_dict(), filename + "_actor")
@@ -231,3 +234,5 @@ class DDPGfD:
         if sync_targets:
             self.critic_target.load_state_dict(self.critic.state_dict())
             self.actor_target.load_state_dict(self.actor.state_dict())
+        if self._native is not None:
+            self._native.import_optimizer_state()     # ... and back: the native learner continues from the loaded Adam state

@@ -60,6 +60,12 @@ class NativeDDPGfDUpdate:
         self.critic, self.actor = _Net(policy.critic, fp["critic"]), _Net(policy.actor, fp["actor"])
         self.critic_t, self.actor_t = _Net(policy.critic_target, fp["critic_target"]), _Net(policy.actor_target, fp["actor_target"])
         self.it = torch.zeros(1, dtype=torch.long, device=policy.device)      # updates done (Adam step of both nets)
+        # Pipelined form (phase_head): the actor's Adam step + soft target update of update k run at the START of update
+        # k + 1.  `it_head` is k while that step is pending and 0 otherwise, so the head is a no-op when nothing is pending
+        # (before the first update, or after finish_pending() has applied it eagerly, e.g. ahead of a checkpoint).
+        self.it_head = torch.zeros(1, dtype=torch.long, device=policy.device)
+        policy._native = self                                                  # DDPGfD.save / load keep the Adam state in sync
+        self.import_optimizer_state()
         self.losses = torch.zeros(3, device=policy.device)                   # critic loss, L1, LN of the last update
         ao, co = policy.actor_optimizer.param_groups[0], policy.critic_optimizer.param_groups[0]
         self.hyper_a = (ao["lr"], ao["betas"][0], ao["betas"][1], ao["eps"], ao["weight_decay"])
@@ -109,11 +115,57 @@ class NativeDDPGfDUpdate:
     def _relu_bwd(self, act, grad):
         self._chk(self.lib.kr_relu_backward(grad.numel(), _sim._ptr(act), _sim._ptr(grad), self._st()), "kr_relu_backward")
 
-    def _adam(self, net, hyper):
+    def _adam(self, net, hyper, step=None):
         lr, b1, b2, eps, wd = hyper
         P = _sim._ptr
-        self._chk(self.lib.kr_adam_step(net.flat.numel(), P(net.flat), P(net.grad), P(net.exp_avg), P(net.exp_avg_sq), P(self.it), lr, b1, b2,
-                                        eps, wd, self._st()), "kr_adam_step")
+        self._chk(self.lib.kr_adam_step(net.flat.numel(), P(net.flat), P(net.grad), P(net.exp_avg), P(net.exp_avg_sq),
+                                        P(self.it if step is None else step), lr, b1, b2, eps, wd, self._st()), "kr_adam_step")
+
+    # -- optimizer state <-> torch.optim.Adam (the reference's 4-file checkpoint keeps it: DDPGfD.py:371-382) ------------
+    def _optim_pairs(self):
+        return ((self.actor, self.p.actor_optimizer), (self.critic, self.p.critic_optimizer))
+
+    def export_optimizer_state(self):
+        """Make policy.{actor,critic}_optimizer.state describe the native Adam state: exp_avg / exp_avg_sq are VIEWS of the
+        flat moment buffers (they stay current), `step` is the number of updates applied.  Applies a pending pipelined
+        actor step first, so that both networks are at the same update."""
+        torch.cuda.synchronize(self.p.device)          # a pipelined update may still be running on the learner's stream
+        self.finish_pending()
+        step = float(self.it.item())
+        for net, opt in self._optim_pairs():
+            off = 0
+            for p in opt.param_groups[0]["params"]:
+                n = p.numel()
+                cap = opt.param_groups[0].get("capturable", False)
+                opt.state[p] = {"step": torch.tensor(step, dtype=torch.float32, device=p.device if cap else "cpu"),
+                                "exp_avg": net.exp_avg[off:off + n].view_as(p), "exp_avg_sq": net.exp_avg_sq[off:off + n].view_as(p)}
+                off += n
+
+    def import_optimizer_state(self):
+        """Adopt the state the torch optimizers hold (after DDPGfD.load, or after autograd updates): moments into the flat
+        buffers, the update counter from `step`.  No state = a fresh optimizer (zeros)."""
+        steps = []
+        for net, opt in self._optim_pairs():
+            off = 0
+            for p in opt.param_groups[0]["params"]:
+                n = p.numel()
+                stt = opt.state.get(p, None)
+                if stt:
+                    if stt["exp_avg"].data_ptr() != net.exp_avg[off:off + n].data_ptr():
+                        net.exp_avg[off:off + n].copy_(stt["exp_avg"].reshape(-1))
+                        net.exp_avg_sq[off:off + n].copy_(stt["exp_avg_sq"].reshape(-1))
+                    steps.append(int(float(stt["step"])))
+                off += n
+        if steps:
+            assert min(steps) == max(steps), "actor and critic optimizers are at different steps"
+            self.it.fill_(steps[0])
+            self.it_head.zero_()
+            self.p.total_it = steps[0]
+
+    @torch.no_grad()
+    def finish_pending(self):
+        """apply the pipelined actor step that is still waiting for the next update's head (no-op otherwise)"""
+        self.phase_head()
 
     def _weight_grads(self, net, x, h1, h2, dz3):
         """dz3: gradient at the last layer's pre-activation; fills net.grad, returns nothing"""
@@ -137,7 +189,7 @@ class NativeDDPGfDUpdate:
         R = reward.shape[0]
         if weight is None:
             weight = torch.ones(R, device=reward.device)
-        self.weight, self.wsum = weight, weight.sum().reshape(1)
+        self.weight, self.wsum = weight, weight.sum().clamp_min(1.0).reshape(1)      # 0 / 1 weights: exact unless the batch is all padding
         # both target evaluations (1-step: next_state[:, 0], n-step: next_state[:, -1]) in one pass of the target nets
         nx = torch.cat([next_state[:, 0], next_state[:, -1]], 0)
         if self.fused_targets:
@@ -234,9 +286,20 @@ class NativeDDPGfDUpdate:
     @torch.no_grad()
     def phase_head(self):
         """Pipelined form of phase_targets: applied at the START of the next update (pipeline.GraphedTrainer), so that
-        the actor's weights change at one known, early point of every update instead of at its end.  A no-op before the
-        first update (device counter 0)."""
-        self.phase_targets()
+        the actor's weights change at one known, early point of every update instead of at its end.  Gated on the device
+        counter `it_head` (set by mark_pending at the end of an update's body, cleared here): a no-op when no actor step is
+        pending."""
+        pol, P = self.p, _sim._ptr
+        self._adam(self.actor, self.hyper_a, step=self.it_head)
+        for net, tgt in ((self.critic, self.critic_t), (self.actor, self.actor_t)):
+            self._chk(self.lib.kr_soft_update(net.flat.numel(), P(net.flat), P(tgt.flat), pol.tau, P(self.it_head), pol.network_repl_freq, self._st()),
+                      "kr_soft_update")
+        self.it_head.zero_()
+
+    @torch.no_grad()
+    def mark_pending(self):
+        """end of an update's body in the pipelined form: its actor step is now pending"""
+        self.it_head.copy_(self.it)
 
     @torch.no_grad()
     def phase_targets(self):

@@ -71,6 +71,7 @@ class GraphedTrainer:
 
     def _phase2(self):
         self.native.phase_actor(self.batch[0], self.batch[5])
+        self.native.mark_pending()                 # the actor's Adam step of this update runs in the next update's head
 
     def _learn_eager(self):
         self._head()
@@ -92,6 +93,14 @@ class GraphedTrainer:
             torch.cuda.tunable.tuning_enable(True)
             torch.cuda.tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "ks_tunableop.csv"), insert_device_ordinal=True)
             torch.cuda.tunable.set_max_tuning_duration(15)
+        # The eager warm-up runs real learner updates - on an EMPTY replay when capture() is called at the start of training
+        # (all-padding batches: zero gradients, but Adam's weight decay and bias correction would still move the weights
+        # and advance the counters).  The learner's whole state is therefore saved here and restored after the warm-up: the
+        # warm-up only warms the allocator and the GEMM selection, it never trains.
+        nat, pol = self.native, self.policy
+        saved = {k: v.clone() for k, v in pol._flat_params.items()}
+        saved_opt = [(net, net.grad.clone(), net.exp_avg.clone(), net.exp_avg_sq.clone()) for net in (nat.actor, nat.critic)]
+        saved_it, saved_head, saved_total = nat.it.clone(), nat.it_head.clone(), pol.total_it
         s = torch.cuda.Stream(self.dev)
         s.wait_stream(self.main)
         with torch.cuda.stream(s):
@@ -103,6 +112,12 @@ class GraphedTrainer:
                 self.steps += 1
         self.main.wait_stream(s)
         torch.cuda.synchronize(self.dev)
+        for k, v in saved.items():
+            pol._flat_params[k].copy_(v)
+        for net, g, m, v in saved_opt:
+            net.grad.copy_(g); net.exp_avg.copy_(m); net.exp_avg_sq.copy_(v)
+        nat.it.copy_(saved_it); nat.it_head.copy_(saved_head)
+        pol.total_it = saved_total
         if tune:
             torch.cuda.tunable.tuning_enable(False)
         # thread_local: other threads (the RCCL watchdog of torch.distributed) keep issuing HIP calls during a capture
@@ -191,10 +206,14 @@ class GraphedTrainer:
             self.g_commit.replay()
             self.pending_commit = False
 
-    def flush(self):
-        """Apply the deferred ring update of the last step (call before reading the replay from the host)."""
-        if self.pending_commit:
+    def flush(self, finish_update=False):
+        """Apply the deferred ring update of the last step (call before reading the replay from the host).
+        finish_update=True also applies the last update's pending actor step (call before saving a checkpoint; DDPGfD.save
+        does it by itself through the native learner)."""
+        if self.pending_commit or finish_update:
             self.side.wait_stream(self.main)
             with torch.cuda.stream(self.side):
                 self._commit_pending()
+                if finish_update:
+                    self.native.finish_pending()
             self.main.wait_stream(self.side)

@@ -259,21 +259,24 @@ class DeviceEpisodeReplay:
             out = (torch.empty(R, n, S, device=dev), torch.empty(R, n, A, device=dev), torch.empty(R, n, S, device=dev),
                    torch.empty(R, n, device=dev), torch.empty(R, n, device=dev), torch.empty(R, device=dev))
             P = self._ptr
-            self._check(self._lib.kr_sample_windows(batch_size, self.horizon, n, P(self._count), P(self.ep_len), P(u), P(u[batch_size:]),
+            self._check(self._lib.kr_sample_windows(batch_size, self.horizon, n, P(self._count), P(self._head), self.capacity, P(self.ep_len), P(u),
+                                                    P(u[batch_size:]),
                                                     P(self.ep_state), P(self.ep_next), P(self.ep_action), P(self.ep_reward),
                                                     P(self.ep_not_done), P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(out[4]), P(out[5]),
                                                     self._stream()), "kr_sample_windows")
             return out
-        hi = (self._count - 1).clamp(min=1)                # newest episode excluded (utils.py:259)
+        # the k-th oldest episode, k in [0, count - 1): the newest one (ring slot head - 1) is never sampled (utils.py:259)
+        hi = (self._count - 1).clamp(min=1)
         ue = torch.rand(batch_size, device=self.device, generator=generator) if uniforms is None else uniforms[:batch_size]
-        ep = torch.minimum((ue * hi).long(), hi - 1)
+        k = torch.minimum((ue * hi).long(), hi - 1)
+        ep = (self._head - self._count + k) % self.capacity
         ceiling = (self.ep_len[ep] - n).clamp(min=1)       # [B]
         row = self._row                                                      # [1,W]
         u = torch.rand(batch_size, W, device=self.device, generator=generator) if uniforms is None else uniforms[batch_size:].view(batch_size, W)
         start = (u * ceiling.unsqueeze(1)).long().clamp(max=self.horizon - n)
         start = torch.where(row == (ceiling.unsqueeze(1) - 1), ceiling.unsqueeze(1).expand(-1, W), start)
         start = start.clamp(max=self.horizon - n)
-        weight = (row < ceiling.unsqueeze(1)).float().reshape(-1)
+        weight = ((row < ceiling.unsqueeze(1)) & (self._count >= 2)).float().reshape(-1)     # nothing to sample from < 2 episodes
         t = start.unsqueeze(-1) + self._win                                  # [B,W,n]
         e = ep.view(-1, 1, 1).expand(-1, W, n)
         g = lambda x: x[e, t].reshape(batch_size * W, n, *x.shape[2:])

@@ -64,7 +64,7 @@ def load_library(path: Path | None = None):
     L.kr_rank_episodes.argtypes = [i32, vp, vp, vp, vp]
     L.kr_commit_episodes.argtypes = [i32, i32, i32] + [vp] * 16
     L.kr_advance_ring.argtypes = [i32, i32] + [vp] * 6
-    L.kr_sample_windows.argtypes = [i32, i32, i32] + [vp] * 16
+    L.kr_sample_windows.argtypes = [i32, i32, i32, vp, vp, i32] + [vp] * 15
     i64 = C.c_int64
     L.kr_critic_grad.argtypes = [i32, i32] + [vp] * 6 + [f32, vp, vp, vp]
     L.kr_relu_backward.argtypes = [i64, vp, vp, vp]

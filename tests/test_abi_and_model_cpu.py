@@ -95,3 +95,28 @@ def test_all_shapes_have_blobs(assets_dir):
         M = mc.read_blob(assets_dir / f"{shape}.ksm")
         assert M["mesh3_vert"].shape[1] == 3 and abs(M["body_mass"][9] - 0.1) < 1e-12
         assert scenarios.start_coord_table(shape).shape[0] == 4499
+
+
+def test_example_script_resolves_every_global_name():
+    """examples/train_ddpgfd.py: every global its functions load exists after import (a NameError used to hide in the
+    expert-collection loop); importing it touches no GPU."""
+    import builtins
+    import dis
+    import importlib.util
+    from pathlib import Path
+    path = Path(__file__).resolve().parents[1] / "examples" / "train_ddpgfd.py"
+    spec = importlib.util.spec_from_file_location("example_train_ddpgfd", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    def globals_loaded(code):
+        for ins in dis.get_instructions(code):
+            if ins.opname == "LOAD_GLOBAL":
+                yield ins.argval
+        for c in code.co_consts:
+            if hasattr(c, "co_code"):
+                yield from globals_loaded(c)
+
+    missing = sorted({n for f in vars(mod).values() if callable(f) and getattr(f, "__module__", None) == mod.__name__ and hasattr(f, "__code__")
+                      for n in globals_loaded(f.__code__) if not hasattr(mod, n) and not hasattr(builtins, n)})
+    assert not missing, missing

@@ -1,0 +1,66 @@
+"""bench.py as a launcher: `--gpus N` starts N ranks itself (children spawned before any torch / HIP call), refuses a
+WORLD_SIZE that contradicts --gpus, and the N > 1 line carries n_gpus, the RCCL block and the replica checksum spread."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def run_bench(args, env=None, timeout=900):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpus_flag_must_match_world_size():
+    """under a launcher (WORLD_SIZE set) a contradicting --gpus fails fast, before torch is imported"""
+    r = run_bench(["--gpus", "1"], env={"WORLD_SIZE": "2", "RANK": "0"}, timeout=60)
+    assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in r.stderr
+    r = run_bench(["--gpus", "4"], env={"WORLD_SIZE": "2", "RANK": "0"}, timeout=60)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_launcher_spawns_ranks_before_touching_torch(tmp_path):
+    """launch_ranks: N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* on 127.0.0.1; the parent never imports torch"""
+    probe = tmp_path / "probe.py"
+    probe.write_text("import os, sys\nprint(os.environ['RANK'], os.environ['WORLD_SIZE'], os.environ['MASTER_ADDR'], os.environ['LOCAL_RANK'], 'torch' in sys.modules)\n")
+    code = ("import sys, pathlib; sys.path.insert(0, %r); import bench; bench.__file__ = %r; "
+            "rc = bench.launch_ranks(3, []); print('parent torch', 'torch' in sys.modules); sys.exit(rc)") % (str(ROOT), str(probe))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = sorted(l for l in r.stdout.splitlines() if l and l[0].isdigit())
+    assert lines == ["0 3 127.0.0.1 0 False", "1 3 127.0.0.1 1 False", "2 3 127.0.0.1 2 False"]
+    assert "parent torch False" in r.stdout
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_through_the_self_launcher():
+    """`python bench.py --gpus 2` on a 1-GPU box: two ranks share GPU 0 and exchange gradients over gloo (plumbing check
+    of the launcher, the two-graph learner split and the checksum all-reduce; RCCL needs one GPU per rank)."""
+    r = run_bench(["--gpus", "2", "--steps", "6", "--warmup", "4", "--envs-per-gpu", "512", "--no-cpu-baseline", "--steady-updates", "0"],
+                  env={"KS_DIST_BACKEND": "gloo", "KS_VISIBLE_GPUS": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "env-shard x2 + grad all-reduce"
+    assert line["rccl"]["ranks"] == 2 and line["rccl"]["backend"] == "gloo"
+    assert line["replica_weight_checksum_spread"] == 0.0
+    assert line["config"]["learner_updates_timed"] == 6 and line["nonfinite_envs"] == 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_two_gpus_rccl():
+    """the real thing when the box has two GPUs: RCCL (backend nccl) over xGMI, replicas stay bit-identical"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    r = run_bench(["--gpus", "2", "--steps", "10", "--warmup", "5", "--no-cpu-baseline", "--steady-updates", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl"]["backend"] == "nccl" and line["replica_weight_checksum_spread"] == 0.0

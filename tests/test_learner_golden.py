@@ -126,6 +126,30 @@ def test_device_replay_ring_and_sampling_distribution():
     assert all(0 <= s <= L - 5 for (e, s), L in zip(wins, [[30, 12, 30][e] for e, _ in wins]))
 
 
+def test_wrapped_ring_never_samples_the_newest_episode():
+    """utils.py:259 draws np.random.randint(replay_ep_num - 1): episodes 0 .. count-2 in AGE order.  Once the ring has
+    wrapped, the newest episode sits at slot head - 1 (not at slot capacity - 1): it must never be sampled, every other
+    slot must be; and a ring with fewer than two episodes yields weight 0 everywhere."""
+    torch.manual_seed(1)
+    cap = 6
+    rep = DeviceEpisodeReplay(n_envs=1, capacity=cap, horizon=30, device="cpu")
+    st, ac, ns, rw, nd, w = rep.sample_batch_nstep(4)
+    assert w.sum().item() == 0                                   # empty ring
+    for epi in range(10):                                         # 10 episodes into 6 slots: wraps, head ends at 4
+        for t in range(30):
+            s = torch.full((1, 82), float(100 * epi + t))
+            rep.add(s, torch.zeros(1, 4), s, torch.zeros(1), torch.tensor([t == 29]))
+        rep.end_episodes(torch.tensor([True]))
+        if epi == 0:
+            assert rep.sample_batch_nstep(4)[5].sum().item() == 0  # one episode: still nothing to sample
+    assert rep.count == cap and rep.head == 10 % cap
+    seen = set()
+    for _ in range(40):
+        st, ac, ns, rw, nd, w = rep.sample_batch_nstep(16)
+        seen |= set((st[w > 0][:, 0, 0] // 100).long().tolist())
+    assert seen == {4, 5, 6, 7, 8}                               # episode 9 is the newest; 0-3 were overwritten
+
+
 def test_scripted_controllers_match_reference_known_answers():
     """demonstrators.controller_action against expert_data.get_action (naive / position-dependent / combined) on the
     600 cases of tests/golden/controllers.npz (tools/gen_golden_controllers.py ran the reference itself)."""
