@@ -67,7 +67,11 @@ typedef struct {
     int32_t envs_per_wave;      /* envs per stepping workgroup (256 threads = 16 lanes per env): 0 = automatic (16,
                                    or fewer when the model's hull tables leave less LDS); else 1..16 */
     int32_t contact_tap;        /* 1: keep the per-contact records of the last substep for ks_get_state (parity) */
-    int32_t reserved[3];
+    int32_t pair_memory;        /* 1 (default): every env carries what its hull pairs remember of their last narrow-phase
+                                   queries (support hints, closest-feature simplex, penetration portal: vertex ids only)
+                                   from one ks_step to the next, so no substep starts its queries cold; 0: cold start
+                                   at every ks_step.  Same contacts to the queries' 1e-6 tolerance either way. */
+    int32_t reserved[2];
 } ks_config;
 
 typedef struct ks_ctx ks_ctx;

@@ -41,6 +41,9 @@ template <typename T> struct Buffers {
     T *contact;                   // [NCON_MAX*CON_STRIDE][N] parity tap (last substep)
     T *gscratch;                  // [SCR_TOTAL][N] (fp64 contexts only; fp32 uses LDS)
     T *envp;                      // [2][N] per-env object mass, object-hand friction (config 5 randomisation)
+    unsigned *pairmem;            // [N][SUBS][2 * WARM_WORDS] pair memory carried from launch to launch (fp32 / LDS contexts):
+                                  // what every lane of an env's team remembers of its (<= 2) hull pairs' last queries
+                                  // (ks_core.h: PairWarm), env-major: a team moves its 512 bytes as 16 x 32-byte pieces
     int32_t *ncon, *status, *step_count;
     uint8_t *flag;                // envs to (re)initialise
 };
@@ -241,7 +244,7 @@ __device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>
 
 template <typename T, bool USE_LDS>
 __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ action, int N,
-                                                   int frame_skip, int iters, int epw, int tap, int rays_in_step) {
+                                                   int frame_skip, int iters, int epw, int tap, int rays_in_step, int pair_memory) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KS_LDS T* lds = (KS_LDS T*)smem;
     const Model<T>* ml = mp;
@@ -287,11 +290,26 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
         T* stp = (T*)(blk + SCR_STATE);
         load_state_team<T, SUBS>(b, env, N, stp, team.sub);
         load_env_params(scr, team, b, env, N);
-        // what this lane remembers of its hull pairs' GJK queries, across the substeps of the launch
-        GjkWarm gw[(NPAIR_MAX + SUBS - 1) / SUBS];
+        // Pair memory: what this lane remembers of its hull pairs' narrow-phase queries (GJK simplex, MPR portal: vertex ids)
+        // lives in registers across the substeps and comes back from the previous launch, so the first substep of an
+        // env-step starts as warm as the other fourteen (a cold GJK is ~10 iterations, a warm one 1-2: the first substep
+        // used to cost as much as five of the others).  A stale memory (after a reset) is still a valid start: any ids are.
+        constexpr int WPL = (NPAIR_MAX + SUBS - 1) / SUBS;              // pairs per lane
+        PairWarm gw[WPL];
+        unsigned* pm = b.pairmem + ((long)env * SUBS + team.sub) * (WPL * WARM_WORDS);
         KS_UNROLL
-        for (int q = 0; q < (NPAIR_MAX + SUBS - 1) / SUBS; q++) { gw[q].n = 0; gw[q].mn = 0; }
+        for (int q = 0; q < WPL; q++) {
+            KS_UNROLL
+            for (int j = 0; j < WARM_WORDS; j++) gw[q].w[j] = pair_memory ? pm[q * WARM_WORDS + j] : 0u;
+        }
         lane_env_step(m, hu, *(LaneState<T>*)stp, hq, act, scr, team, snap, frame_skip, iters, ncon, status, prof, stp + NQ + 2 * NV, gw);
+        if (pair_memory) {
+            KS_UNROLL
+            for (int q = 0; q < WPL; q++) {
+                KS_UNROLL
+                for (int j = 0; j < WARM_WORDS; j++) pm[q * WARM_WORDS + j] = gw[q].w[j];
+            }
+        }
 #ifdef KS_STAMP
         // diagnostic build only: per-phase cycle sums of this lane go to the contact tap buffer
         prof[6] = (float)(clock64() - tk0);
@@ -612,6 +630,7 @@ template <typename T> struct Ctx : CtxBase {
         if ((r = alloc(&b.contact, (size_t)NCON_MAX * CON_STRIDE * N))) return r;
         if (!USE_LDS && (r = alloc(&b.gscratch, (size_t)SCR_TOTAL * N))) return r;
         if ((r = alloc(&b.envp, (size_t)2 * N))) return r;
+        if (USE_LDS && (r = alloc(&b.pairmem, (size_t)SUBS * ((NPAIR_MAX + SUBS - 1) / SUBS) * WARM_WORDS * N))) return r;
         if ((r = alloc(&b.ncon, N))) return r;
         if ((r = alloc(&b.status, N))) return r;
         if ((r = alloc(&b.step_count, N))) return r;
@@ -737,7 +756,7 @@ template <typename T> struct Ctx : CtxBase {
         const bool timed = ev_used < NEV;
         if (timed) HIPCHK(hipEventRecord(ev0[ev_used], s));
         hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3((N + lpw - 1) / lpw), dim3(WG), step_lds, s, d_model, b, (const T*)action, N,
-                           cfg.frame_skip, cfg.solver_iterations, lpw, cfg.contact_tap, (int)rays_in_step);
+                           cfg.frame_skip, cfg.solver_iterations, lpw, cfg.contact_tap, (int)rays_in_step, (int)(USE_LDS && cfg.pair_memory));
         if (timed) { HIPCHK(hipEventRecord(ev1[ev_used], s)); ev_used++; }
         if (!rays_in_step) hipLaunchKernelGGL((k_rays<T>), dim3((N + RAY_ENVS - 1) / RAY_ENVS, NRAY), dim3(WAVE), 0, s, d_model, b, N, 0);
         hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0, cfg.horizon, cfg.auto_reset, cfg.obs_env_major,
@@ -825,6 +844,7 @@ void ks_default_config(ks_config* cfg) {
     cfg->obs_env_major = 1;
     cfg->envs_per_wave = 0;
     cfg->contact_tap = 0;
+    cfg->pair_memory = 1;
 }
 
 const char* ks_last_error(const ks_ctx* ctx) { return ctx ? ctx->impl->error.c_str() : g_create_error.c_str(); }

@@ -747,22 +747,30 @@ KS_HD void find_pos(const Supp<T>& v0, const Supp<T>& v1, const Supp<T>& v2, con
     }
 }
 
-// Minkowski Portal Refinement penetration query (same decision structure as the oracle's
-// mpr_penetration / libccd's ccdMPRPenetration).  Returns true on overlap.
-// What a lane remembers of a hull pair's last narrow-phase queries (lane-private: the pair -> lane dealing is fixed;
-// lives in the stepping kernel's frame across the substeps of a launch).
-//   GJK: the vertex ids of the final simplex (<= 3 points).  The next substep starts GJK from that simplex - the poses
+// ---- What a lane remembers of a hull pair's last narrow-phase queries (lane-private: the pair -> lane dealing is fixed):
+//   GJK: the vertex ids of the final simplex (<= 3 points).  The next query starts GJK from that simplex - the poses
 //        have barely moved, so it is usually still the closest feature and the query ends after one confirming support
 //        instead of ~10 iterations.
 //   MPR: the vertex ids of the final portal.  While the origin ray still passes through it, the next query skips the
 //        portal discovery and refines from there (a few supports instead of ~22).
-struct GjkWarm {
-    int n;
-    int ia[3], ib[3];
-    int mn;                    // 3: MPR portal ids valid
-    int ma[3], mb[3];
+// Four 32-bit words per pair: vertex ids are < 1024 (checked when the model is loaded), three ids per word, a count in the
+// two top bits; word 0 = GJK ids on hull 1 + simplex size, 1 = GJK ids on hull 2, 2 = portal ids on hull 1 + 3 if valid,
+// 3 = portal ids on hull 2.  All zeros = nothing remembered (cold start).  The stepping kernel keeps the words in registers
+// across the substeps of a launch and carries them from one launch to the next through global memory (ks_api.hip), so the
+// first substep of an env-step starts as warm as the other fourteen.
+constexpr int WARM_WORDS = 4;
+struct PairWarm {
+    unsigned w[WARM_WORDS];
 };
+KS_HD unsigned pack3(int a, int b, int c, int top) { return (unsigned)a | ((unsigned)b << 10) | ((unsigned)c << 20) | ((unsigned)top << 30); }
+KS_HD void unpack3(unsigned w, int* ids, int& top) {
+    ids[0] = (int)(w & 1023u); ids[1] = (int)((w >> 10) & 1023u); ids[2] = (int)((w >> 20) & 1023u);
+    top = (int)(w >> 30);
+}
 
+// Minkowski Portal Refinement penetration query (same decision structure as the oracle's mpr_penetration, i.e. the
+// published algorithm of libccd's ccdMPRPenetration - libccd is (c) D. Fiser, BSD-3; it is a dependency of MuJoCo, not
+// part of /root/reference, and no code of it is used here).  Returns true on overlap.
 template <typename T> KS_HD void hull_point(const T* R, const T* p, KS_LDS const T* V, int i, T* out) {
     const T v[3] = {V[4 * i], V[4 * i + 1], V[4 * i + 2]};
     mulRv(out, R, v);
@@ -770,7 +778,7 @@ template <typename T> KS_HD void hull_point(const T* R, const T* p, KS_LDS const
 }
 
 template <typename T>
-KS_FN bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir, T* pos, GjkWarm* ws = nullptr) {
+KS_FN bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir, T* pos, PairWarm* ws = nullptr) {
     Supp<T> v0, v1, v2, v3, v4;
     T d[3], va[3], vb[3];
     copy3(v0.v1, g.p1);
@@ -779,22 +787,20 @@ KS_FN bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir,
     if (vec_is_zero(v0.v)) v0.v[0] += T(1e-5);
     v0.i1 = 0; v0.i2 = 0;
     bool have_portal = false;
-    if (ws != nullptr && ws->mn == 3) {
+    int ma[3] = {0, 0, 0}, mb[3] = {0, 0, 0}, mn = 0, unused = 0;
+    if (ws != nullptr) { unpack3(ws->w[2], ma, mn); unpack3(ws->w[3], mb, unused); }
+    if (mn == 3) {
         // the previous query's portal at the current poses: still a portal if the origin ray (from v0 through the
         // origin) passes through the triangle, i.e. the origin is on the inner side of the three planes (v0, vi, vj)
-        Supp<T>* vs[3] = {&v1, &v2, &v3};
-        KS_UNROLL
-        for (int k = 0; k < 3; k++) {
-            vs[k]->i1 = ws->ma[k]; vs[k]->i2 = ws->mb[k];
-            hull_point(g.R1, g.p1, g.V1, ws->ma[k], vs[k]->v1);
-            hull_point(g.R2, g.p2, g.V2, ws->mb[k], vs[k]->v2);
-            sub3(vs[k]->v, vs[k]->v1, vs[k]->v2);
-        }
+        v1.i1 = ma[0]; v1.i2 = mb[0]; v2.i1 = ma[1]; v2.i2 = mb[1]; v3.i1 = ma[2]; v3.i2 = mb[2];
+        hull_point(g.R1, g.p1, g.V1, ma[0], v1.v1); hull_point(g.R2, g.p2, g.V2, mb[0], v1.v2); sub3(v1.v, v1.v1, v1.v2);
+        hull_point(g.R1, g.p1, g.V1, ma[1], v2.v1); hull_point(g.R2, g.p2, g.V2, mb[1], v2.v2); sub3(v2.v, v2.v1, v2.v2);
+        hull_point(g.R1, g.p1, g.V1, ma[2], v3.v1); hull_point(g.R2, g.p2, g.V2, mb[2], v3.v2); sub3(v3.v, v3.v1, v3.v2);
         T c13[3], c32[3], c21[3], e1[3], e2[3], nn[3];
         cross3(c13, v1.v, v3.v); cross3(c32, v3.v, v2.v); cross3(c21, v2.v, v1.v);
         sub3(e1, v2.v, v1.v); sub3(e2, v3.v, v1.v); cross3(nn, e1, e2);
         have_portal = dot3(c13, v0.v) >= 0 && dot3(c32, v0.v) >= 0 && dot3(c21, v0.v) >= 0 && dot3(nn, nn) > T(1e-24);
-        ws->mn = 0;
+        ws->w[2] = 0;                                   // valid again only if this query ends on a portal
     }
     if (!have_portal) {
     scl3(d, v0.v, T(-1));
@@ -869,8 +875,8 @@ KS_FN bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir,
             normalize3(dir);
             find_pos(v0, v1, v2, v3, pos);
             if (ws != nullptr) {
-                ws->mn = 3;
-                ws->ma[0] = v1.i1; ws->mb[0] = v1.i2; ws->ma[1] = v2.i1; ws->mb[1] = v2.i2; ws->ma[2] = v3.i1; ws->mb[2] = v3.i2;
+                ws->w[2] = pack3(v1.i1, v2.i1, v3.i1, 3);
+                ws->w[3] = pack3(v1.i2, v2.i2, v3.i2, 0);
             }
             return true;
         }
@@ -1016,14 +1022,13 @@ template <typename T> KS_HD bool gjk_closest(Simplex<T>& S, T* lam, T* v) {
 }
 
 // 0: separated by >= margin, 1: contact in the margin zone, 2: overlap (fall back to MPR)
-template <typename T> KS_HD void gjk_remember(GjkWarm* ws, const Simplex<T>& S) {
+template <typename T> KS_HD void gjk_remember(PairWarm* ws, const Simplex<T>& S) {
     if (ws == nullptr) return;
-    ws->n = S.n < 3 ? S.n : 3;
-    KS_UNROLL
-    for (int i = 0; i < 3; i++) { ws->ia[i] = S.ia[i]; ws->ib[i] = S.ib[i]; }
+    ws->w[0] = pack3(S.ia[0], S.ia[1], S.ia[2], S.n < 3 ? S.n : 3);
+    ws->w[1] = pack3(S.ib[0], S.ib[1], S.ib[2], 0);
 }
 
-template <typename T> KS_FN int gjk_distance(PairGeo<T>& g, T margin, T* dist, T* normal, T* pos, GjkWarm* ws = nullptr) {
+template <typename T> KS_FN int gjk_distance(PairGeo<T>& g, T margin, T* dist, T* normal, T* pos, PairWarm* ws = nullptr) {
     Simplex<T> S;
     T lam[4] = {1, 0, 0, 0}, v[3], d[3];
 #ifndef KS_GJK_TOL
@@ -1037,13 +1042,15 @@ template <typename T> KS_FN int gjk_distance(PairGeo<T>& g, T margin, T* dist, T
         for (int c = 0; c < 3; c++) { S.y[i][c] = 0; S.a[i][c] = 0; S.b[i][c] = 0; }
     }
     bool warm = false;
-    if (ws != nullptr && ws->n > 0) {
+    int wia[3] = {0, 0, 0}, wib[3] = {0, 0, 0}, wn = 0, unused = 0;
+    if (ws != nullptr) { unpack3(ws->w[0], wia, wn); unpack3(ws->w[1], wib, unused); }
+    if (wn > 0) {
         // the previous query's simplex at the current poses
-        S.n = ws->n;
+        S.n = wn;
         KS_UNROLL
         for (int i = 0; i < 3; i++) {
             if (i < S.n) {
-                S.ia[i] = ws->ia[i]; S.ib[i] = ws->ib[i];
+                S.ia[i] = wia[i]; S.ib[i] = wib[i];
                 hull_point(g.R1, g.p1, g.V1, S.ia[i], S.a[i]);
                 hull_point(g.R2, g.p2, g.V2, S.ib[i], S.b[i]);
                 sub3(S.y[i], S.a[i], S.b[i]);
@@ -1335,7 +1342,7 @@ KS_HD bool hull_pair_may_touch(S scr, KS_LDS const PairRec<T>* prp) {
 // narrow phase of a hull pair that passed hull_pair_may_touch
 template <typename T, typename S>
 KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S scr, KS_LDS const PairRec<T>* prp, int packed_in, int& h1_out,
-                            int& h2_out, GjkWarm* ws, float* prof = nullptr) {
+                            int& h2_out, PairWarm* ws, float* prof = nullptr) {
     KS_LDS const PairRec<T>& pr = *prp;
     PairGeo<T> pg;
 #ifdef KS_STAMP_HULL
@@ -1389,7 +1396,7 @@ template <typename T, typename S, int SUBS> KS_HD void reset_pair_words(S scr, T
 }
 
 template <typename T, typename S, int SUBS>
-KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> team, int& ncon, int& status, GjkWarm* warm = nullptr,
+KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> team, int& ncon, int& status, PairWarm* warm = nullptr,
                      float* prof = nullptr) {
     KS_T0
     const unsigned plane_mask = hu.plane_mask;
@@ -2226,7 +2233,7 @@ KS_FN void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm, S scr,
 // ---------------------------------------------------------------- one mj_step (forward + Euler)
 template <typename T, typename S, int SUBS>
 KS_HD void mj_forward_step(const Model<T>& m, const Hulls<T>& hu, T* qpos, T* qvel, T* warm, const T* ctrl, const T* R7, S scr, Team<SUBS> team,
-                           int solver_iterations, bool integrate, int& ncon_out, int& status, float* prof = nullptr, GjkWarm* gjk_warm = nullptr) {
+                           int solver_iterations, bool integrate, int& ncon_out, int& status, float* prof = nullptr, PairWarm* gjk_warm = nullptr) {
     KS_T0
     team.sync();                                   // the previous substep's readers of the body poses are done
     dynamics_rows(m, qpos, qvel, ctrl, R7, scr, team);

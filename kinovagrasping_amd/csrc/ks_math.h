@@ -18,12 +18,33 @@
 #endif
 
 #include <math.h>
+#include <string.h>
 
 namespace ks {
 
 template <typename T> struct Lim;
 template <> struct Lim<float> { static constexpr float minval = 1e-30f; static constexpr float big = 3.0e38f; };
 template <> struct Lim<double> { static constexpr double minval = 1e-300; static constexpr double big = 1e300; };
+
+// bit pattern of a float and back (integer words kept in float-typed scratch slots)
+KS_HD int float_bits(float f) {
+    int i;
+#if defined(__HIP_DEVICE_COMPILE__)
+    i = __float_as_int(f);
+#else
+    memcpy(&i, &f, 4);
+#endif
+    return i;
+}
+KS_HD float bits_float(int i) {
+    float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    f = __int_as_float(i);
+#else
+    memcpy(&f, &i, 4);
+#endif
+    return f;
+}
 
 KS_HD float ksqrt(float x) { return sqrtf(x); }
 KS_HD double ksqrt(double x) { return sqrt(x); }

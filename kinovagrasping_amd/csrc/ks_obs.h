@@ -76,25 +76,6 @@ template <typename T> KS_HD T bvh_box_entry_inv(const float* bx, const T* lp, co
     }
     return (miss || t0 > t1) ? T(-1) : t0;
 }
-KS_HD int float_bits(float f) {
-    int i;
-#if defined(__HIP_DEVICE_COMPILE__)
-    i = __float_as_int(f);
-#else
-    memcpy(&i, &f, 4);
-#endif
-    return i;
-}
-KS_HD float bits_float(int i) {
-    float f;
-#if defined(__HIP_DEVICE_COMPILE__)
-    f = __int_as_float(i);
-#else
-    memcpy(&f, &i, 4);
-#endif
-    return f;
-}
-
 // Ray vs mesh geom, MuJoCo's mj_rayMesh semantics: bounding-box pre-test (geom_size about the geom origin),
 // then the faces of the ORIGINAL triangle mesh, both orientations, nearest t >= 0 (-1 = miss).  The faces
 // are visited through a bounding-volume hierarchy of 4-wide nodes (one 128-byte record holds four children's boxes),

@@ -18,7 +18,7 @@ ASSETS = Path(__file__).resolve().parent / "assets"
 class KsConfig(C.Structure):
     _fields_ = [("n_envs", C.c_int32), ("frame_skip", C.c_int32), ("horizon", C.c_int32), ("solver_iterations", C.c_int32),
                 ("precision", C.c_int32), ("auto_reset", C.c_int32), ("obs_env_major", C.c_int32), ("envs_per_wave", C.c_int32),
-                ("contact_tap", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("contact_tap", C.c_int32), ("pair_memory", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 EXPORTS = ["ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_load_model", "ks_reset", "ks_step",
@@ -89,7 +89,7 @@ class KinovaSim:
 
     def __init__(self, n_envs: int, model: str | bytes = "CubeS", device: int | torch.device = 0, precision: int = 32,
                  frame_skip: int = 15, horizon: int = 30, solver_iterations: int = 6, auto_reset: bool = False,
-                 obs_env_major: bool = True, envs_per_wave: int = 0, contact_tap: bool = False):
+                 obs_env_major: bool = True, envs_per_wave: int = 0, contact_tap: bool = False, pair_memory: bool = True):
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise RuntimeError("KinovaSim needs a HIP GPU (torch.cuda.is_available() is False); there is no CPU path")
@@ -101,7 +101,7 @@ class KinovaSim:
         self.lib.ks_default_config(C.byref(cfg))
         cfg.n_envs, cfg.frame_skip, cfg.horizon, cfg.solver_iterations = self.n_envs, frame_skip, horizon, solver_iterations
         cfg.precision, cfg.auto_reset, cfg.obs_env_major = precision, int(auto_reset), int(obs_env_major)
-        cfg.envs_per_wave, cfg.contact_tap = int(envs_per_wave), int(contact_tap)
+        cfg.envs_per_wave, cfg.contact_tap, cfg.pair_memory = int(envs_per_wave), int(contact_tap), int(pair_memory)
         self.cfg = cfg
         self.ctx = C.c_void_p()
         rc = self.lib.ks_create(C.byref(cfg), self.device.index, C.byref(self.ctx))

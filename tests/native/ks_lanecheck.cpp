@@ -75,8 +75,8 @@ static int env_step_t(const Model<T>& m, double* qpos, double* qvel, double* war
         lane_reset(m, st, q4, q0, scr, put);
     } else {
         // as on the GPU: GJK warm-started from the previous substep's simplex within the env-step
-        GjkWarm gw[NPAIR_MAX];
-        for (int q = 0; q < NPAIR_MAX; q++) { gw[q].n = 0; gw[q].mn = 0; }
+        PairWarm gw[NPAIR_MAX];
+        std::memset(gw, 0, sizeof gw);
         lane_env_step(m, host_hulls(m), st, q4, a4, scr, Team<1>{0}, put, frame_skip, iters, nc, status, nullptr, (T*)nullptr, gw);
     }
     Col<T> sc{snap.data(), 1};
