@@ -23,6 +23,32 @@
 
 namespace ks {
 
+// Which stages are real (out-of-line) device functions.  The narrow-phase queries are inlined into `collision`
+// (measured: +2.3 % env-steps/s, and the parity suite is indifferent to it now - see DESIGN.md on the round-1 "inlining
+// breaks parity" symptom); -DKS_OUTLINE_NARROW restores the calls.  Of the other stages the solver is inlined into the
+// substep as well (+1.9 %; collision and dynamics measured +1 % alone and nothing in combination, so they stay calls):
+// KS_INLINE_COLLISION / KS_INLINE_DYNAMICS / KS_OUTLINE_SOLVER are the experiment switches.
+#ifdef KS_OUTLINE_NARROW
+#define KS_NARROW KS_FN
+#else
+#define KS_NARROW KS_HD
+#endif
+#ifdef KS_INLINE_COLLISION
+#define KS_FN_COLLISION KS_HD
+#else
+#define KS_FN_COLLISION KS_FN
+#endif
+#ifdef KS_INLINE_DYNAMICS
+#define KS_FN_DYNAMICS KS_HD
+#else
+#define KS_FN_DYNAMICS KS_FN
+#endif
+#ifdef KS_OUTLINE_SOLVER
+#define KS_FN_SOLVER KS_FN
+#else
+#define KS_FN_SOLVER KS_HD
+#endif
+
 // ---------------------------------------------------------------- scratch layout (units of T)
 // body poses b = 2..9: 12 each (R row-major 9, p 3)
 constexpr int SCR_BP = 0;
@@ -372,7 +398,7 @@ template <typename T, typename S> KS_HD void geom_pose_cached(S scr, int g, T* R
 // (SCR_BP / SCR_AX) and its part of the mass matrix and of qfrc_smooth = passive - bias + actuator into the
 // env's LDS block; consumers read them by row (load_dynamics_row).  With SUBS = 1 one lane plays all roles.
 template <typename T, typename S, int SUBS>
-KS_FN void dynamics_rows(const Model<T>& m, const T* qpos, const T* qvel, const T* ctrl, const T* R7, S scr, Team<SUBS> team) {
+KS_FN_DYNAMICS void dynamics_rows(const Model<T>& m, const T* qpos, const T* qvel, const T* ctrl, const T* R7, S scr, Team<SUBS> team) {
     // entries no role writes (finger-finger cross terms, hand-object) stay zero
     for (int k = team.sub; k < 81 + 36; k += SUBS) scr(SCR_MH + k) = T(0);
     team.sync();
@@ -778,7 +804,7 @@ template <typename T> KS_HD void hull_point(const T* R, const T* p, KS_LDS const
 }
 
 template <typename T>
-KS_FN bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir, T* pos, PairWarm* ws = nullptr) {
+KS_NARROW bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir, T* pos, PairWarm* ws = nullptr) {
     Supp<T> v0, v1, v2, v3, v4;
     T d[3], va[3], vb[3];
     copy3(v0.v1, g.p1);
@@ -1028,7 +1054,7 @@ template <typename T> KS_HD void gjk_remember(PairWarm* ws, const Simplex<T>& S)
     ws->w[1] = pack3(S.ib[0], S.ib[1], S.ib[2], 0);
 }
 
-template <typename T> KS_FN int gjk_distance(PairGeo<T>& g, T margin, T* dist, T* normal, T* pos, PairWarm* ws = nullptr) {
+template <typename T> KS_NARROW int gjk_distance(PairGeo<T>& g, T margin, T* dist, T* normal, T* pos, PairWarm* ws = nullptr) {
     Simplex<T> S;
     T lam[4] = {1, 0, 0, 0}, v[3], d[3];
 #ifndef KS_GJK_TOL
@@ -1396,7 +1422,7 @@ template <typename T, typename S, int SUBS> KS_HD void reset_pair_words(S scr, T
 }
 
 template <typename T, typename S, int SUBS>
-KS_FN void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> team, int& ncon, int& status, PairWarm* warm = nullptr,
+KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> team, int& ncon, int& status, PairWarm* warm = nullptr,
                      float* prof = nullptr) {
     KS_T0
     const unsigned plane_mask = hu.plane_mask;
@@ -1802,7 +1828,7 @@ KS_HD void rows_replicate(Team<SUBS> team, const T (&x)[RPL], T (&out)[NV]) {
 // The stage also builds the constraint rows (S5), solves M qacc_smooth = qfrc_smooth and finishes with the
 // semi-implicit Euler update (S7): everything that needs the mass matrix by rows lives in one function.
 template <typename T, typename S, int SUBS>
-KS_FN void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm, S scr, Team<SUBS> team, int ncon, int iterations, int& status,
+KS_FN_SOLVER void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm, S scr, Team<SUBS> team, int ncon, int iterations, int& status,
                             float* prof = nullptr) {
     static_assert(SUBS == 1 || SUBS == 16, "row distribution: one lane or one DPP row per env");
     constexpr int RPL = (NV + SUBS - 1) / SUBS;         // rows per lane
