@@ -2053,6 +2053,21 @@ KS_FN_SOLVER void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm,
             lim_x[j] = r.lim_sign[j] * a[dof] - r.lim_aref[j];
             lim_p[j] = r.lim_sign[j] * p[dof];
         }
+        // SUBS = 16: the nine scalar rows are dealt to the lanes (lane 0-2 one tendon equality each, lane 3-8 one joint limit
+        // each, lane 9 the Gauss term) instead of all being evaluated by every lane and counted on the lead lane: a
+        // line-search iteration is then one scalar row + the owned contact rows per lane.  sx + alpha * sp is the row,
+        // sw its weight, s_eq: always active (equality), s_on: a limit row that exists.
+        T sx = 0, sp = 0, sw = 0;
+        bool s_eq = false, s_on = false;
+        if constexpr (SUBS == 16) {
+            KS_UNROLL
+            for (int t = 0; t < 3; t++)
+                if (team.sub == t) { sx = eq_x[t]; sp = eq_p[t]; sw = eqD[t]; s_eq = true; }
+            KS_UNROLL
+            for (int j = 0; j < 6; j++)
+                if (team.sub == 3 + j) { sx = lim_x[j]; sp = lim_p[j]; sw = limD[j]; s_on = r.lim_sign[j] != 0; }
+        }
+        const T gauss = (SUBS == 16 && team.sub == 9) ? T(1) : T(0);
         // rows of the owned contacts along the search line: x(alpha) = rx + alpha * rj, weight rD (0 = not a row)
         T rx[CPL][4], rj[CPL][4], rD[CPL];
         KS_UNROLL
@@ -2088,18 +2103,25 @@ KS_FN_SOLVER void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm,
 #ifdef KS_STAMP
             if (prof) prof[22] += 1.f;
 #endif
-            T d1 = pMa + alpha * pMp, d2 = pMp, mag = kabs(pMa) + kabs(alpha * pMp);
-            KS_UNROLL
-            for (int t = 0; t < 3; t++) {
-                const T xx = eq_x[t] + alpha * eq_p[t], w = eqD[t] * eq_p[t];
-                d1 += w * xx; d2 += w * eq_p[t]; mag += kabs(w * xx);
+            T d1, d2, mag;
+            if constexpr (SUBS == 16) {
+                d1 = gauss * (pMa + alpha * pMp); d2 = gauss * pMp; mag = gauss * (kabs(pMa) + kabs(alpha * pMp));
+                const T xx = sx + alpha * sp, w = sw * sp;
+                if (s_eq || (s_on && xx < 0)) { d1 += w * xx; d2 += w * sp; mag += kabs(w * xx); }
+            } else {
+                d1 = pMa + alpha * pMp; d2 = pMp; mag = kabs(pMa) + kabs(alpha * pMp);
+                KS_UNROLL
+                for (int t = 0; t < 3; t++) {
+                    const T xx = eq_x[t] + alpha * eq_p[t], w = eqD[t] * eq_p[t];
+                    d1 += w * xx; d2 += w * eq_p[t]; mag += kabs(w * xx);
+                }
+                KS_UNROLL
+                for (int j = 0; j < 6; j++) {
+                    const T xx = lim_x[j] + alpha * lim_p[j], w = limD[j] * lim_p[j];
+                    if (r.lim_sign[j] != 0 && xx < 0) { d1 += w * xx; d2 += w * lim_p[j]; mag += kabs(w * xx); }
+                }
+                d1 *= lead; d2 *= lead; mag *= lead;
             }
-            KS_UNROLL
-            for (int j = 0; j < 6; j++) {
-                const T xx = lim_x[j] + alpha * lim_p[j], w = limD[j] * lim_p[j];
-                if (r.lim_sign[j] != 0 && xx < 0) { d1 += w * xx; d2 += w * lim_p[j]; mag += kabs(w * xx); }
-            }
-            d1 *= lead; d2 *= lead; mag *= lead;
             KS_UNROLL
             for (int q = 0; q < CPL; q++) {
                 KS_UNROLL
@@ -2124,9 +2146,13 @@ KS_FN_SOLVER void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm,
         // Did any row change sides between a and a + alpha p?  If not, the cost is one quadratic on the whole step,
         // the exact line search landed on its minimiser and that is the solution: no confirming iteration needed.
         T flips = 0;
-        KS_UNROLL
-        for (int j = 0; j < 6; j++)
-            if (r.lim_sign[j] != 0 && ((lim_x[j] < 0) != (lim_x[j] + alpha * lim_p[j] < 0))) flips += lead;
+        if constexpr (SUBS == 16) {
+            if (s_on && ((sx < 0) != (sx + alpha * sp < 0))) flips += T(1);
+        } else {
+            KS_UNROLL
+            for (int j = 0; j < 6; j++)
+                if (r.lim_sign[j] != 0 && ((lim_x[j] < 0) != (lim_x[j] + alpha * lim_p[j] < 0))) flips += lead;
+        }
         KS_UNROLL
         for (int q = 0; q < CPL; q++) {
             KS_UNROLL
