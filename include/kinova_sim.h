@@ -7,6 +7,8 @@
  *   ks_create / ks_destroy   <- MjSim(model) construction / garbage collection      ENV:102, 879, 1003
  *   ks_load_model            <- mujoco_py.load_model_from_path(xml)                 ENV:62, 878, 1002
  *                               (the MJCF+STL compile happens offline: model_compiler.py -> .ksm)
+ *   ks_load_models /
+ *   ks_reset_objects         <- the per-episode object choice: select_object + load of another XML   ENV:986-1005, 1180-1222
  *   ks_reset                 <- KinovaGripper_Env.reset: write_xml (hand euler) + _set_state
  *                               + sim.forward() + _get_obs()                        ENV:1310-1410, 851-881, 692-703
  *   ks_step                  <- KinovaGripper_Env.step: action->ctrl, 15 x sim.step(),
@@ -81,8 +83,14 @@ int ks_create(const ks_config *cfg, int device, ks_ctx **out);
 void ks_destroy(ks_ctx *ctx);
 const char *ks_last_error(const ks_ctx *ctx);   /* ctx may be NULL: last creation error */
 
-/* blob_host: KSMB model blob in HOST memory (copied; may be freed after the call) */
+/* blob_host: KSMB model blob in HOST memory (copied; may be freed after the call).  A context loads its model(s) once. */
 int ks_load_model(ks_ctx *ctx, const void *blob_host, size_t nbytes);
+
+/* Mixed-object batches (BASELINE config 5; the reference swaps the object by loading another MJCF per episode,
+ * ENV:986-1005): n_models (<= 32) blobs of the SAME hand with different objects; object k of ks_reset_objects is
+ * blobs_host[k].  One context, one stepping launch: envs are grouped by object inside the library (every stepping
+ * workgroup stages one object's hull tables), the hand's meshes are kept once. */
+int ks_load_models(ks_ctx *ctx, int32_t n_models, const void *const *blobs_host, const size_t *nbytes);
 
 /* Reset `n` envs.  env_ids: device int32[n] or NULL for envs 0..n-1 (then n must be n_envs).
  * qpos0: [16, n] start configuration (3 slides, 6 finger joints, object xyz + quat wxyz),
@@ -90,6 +98,16 @@ int ks_load_model(ks_ctx *ctx, const void *blob_host, size_t nbytes);
  * Both are stored as the env's initial state for auto-reset.  obs (optional): observation buffer of
  * the WHOLE batch (layout per cfg); only the rows of the reset envs are written. */
 int ks_reset(ks_ctx *ctx, const int32_t *env_ids, int32_t n, const void *qpos0, const void *hand_quat, void *obs, void *stream);
+
+/* ks_reset that also chooses every reset env's object and (optionally) its randomised parameters - the reference's
+ * reset(): select_object (ENV:986-1005) + select_orienation (ENV:1180-1222) + _set_state (ENV:692-703).
+ * object_id: device int32 [n], index into the blobs of ks_load_models, or NULL (objects stay);
+ * mass_friction: device [2, n] (row 0 object mass in kg - the inertia scales with it -, row 1 friction of the seven
+ * object-hand pairs), or NULL: an env whose object is (re)assigned takes that object's compiled mass / friction, other
+ * envs keep theirs.  (Mass / friction randomisation is an extension: the reference fixes 0.1 kg, XML:153, and mu 1,
+ * XML:160-166.) */
+int ks_reset_objects(ks_ctx *ctx, const int32_t *env_ids, int32_t n, const void *qpos0, const void *hand_quat, const int32_t *object_id,
+                     const void *mass_friction, void *obs, void *stream);
 
 /* One env.step() for every env.  action: [4, N] (wrist, finger1..3), obs: N x 82, reward: [N],
  * done: uint8 [N] (bit0 lifted, bit1 time limit), info: [3, N] (finger, grasp, lift reward).

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -46,6 +47,13 @@ template <typename T> struct Buffers {
                                   // (ks_core.h: PairWarm), env-major: a team moves its 512 bytes as 16 x 32-byte pieces
     int32_t *ncon, *status, *step_count;
     uint8_t *flag;                // envs to (re)initialise
+    // mixed-object batches (BASELINE config 5): the object model of every env, and the stepping kernel's work list - its
+    // workgroups stage ONE object's hull tables, so envs are grouped by object: slot s of the list holds an env id or -1
+    // (a group is padded to whole workgroups), workgroup w steps slots [w * epw, (w + 1) * epw) with model wg_model[w]
+    int32_t *obj_id;              // [N]
+    int32_t *slot_env;            // [n_wg * epw]
+    int32_t *wg_model;            // [n_wg]
+    T *nominal;                   // [n_models][2] object mass / object-hand friction of every model as compiled
 };
 
 template <typename T> struct ColW {
@@ -177,7 +185,7 @@ struct LdsSnap {
     __device__ float operator()(int k) const { return base[k]; }
 };
 
-__device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>& b, int N, int env0, int epw, KS_LDS unsigned* w) {
+__device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>& b, int N, int slot0, int epw, KS_LDS unsigned* w) {
     KS_LDS unsigned* hit = w;                                          // [epw][17] nearest hit so far (float bits), big = none
     KS_LDS unsigned* count = w + epw * NRAY;
     KS_LDS unsigned* list = count + 4;                                 // surviving task ids
@@ -186,14 +194,14 @@ __device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>
     const int tid = threadIdx.x, total = epw * WG_RAY_TASKS;
     for (int i = tid; i < epw * NRAY; i += WG) hit[i] = (unsigned)__float_as_int(Lim<float>::big);
     for (int i = tid; i < epw * 96; i += WG) {
-        const int e = i / 96, k = i % 96, env = env0 + e;
-        snaps[e * WG_SNAP + k] = env < N ? b.snap[(long)(SNAP_BP + k) * N + env] : 0.f;
+        const int e = i / 96, k = i % 96, env = b.slot_env[slot0 + e];
+        snaps[e * WG_SNAP + k] = env >= 0 ? b.snap[(long)(SNAP_BP + k) * N + env] : 0.f;
     }
     if (tid == 0) { count[0] = 0; count[1] = 0; }
     __syncthreads();
     for (int task = tid; task < total; task += WG) {
-        const int e = task / WG_RAY_TASKS, r = (task % WG_RAY_TASKS) >> 3, g = 1 + (task & 7), env = env0 + e;
-        if (env >= N) continue;
+        const int e = task / WG_RAY_TASKS, r = (task % WG_RAY_TASKS) >> 3, g = 1 + (task & 7), env = b.slot_env[slot0 + e];
+        if (env < 0) continue;
         LdsSnap snap{snaps + e * WG_SNAP - SNAP_BP};
         float pnt[3], vec[3];
         const int sb = ray_origin(m, snap, r, pnt, vec);
@@ -234,8 +242,8 @@ __device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>
     }
     __syncthreads();
     for (int i = tid; i < epw * NRAY; i += WG) {
-        const int e = i / NRAY, r = i % NRAY, env = env0 + e;
-        if (env < N) {
+        const int e = i / NRAY, r = i % NRAY, env = b.slot_env[slot0 + e];
+        if (env >= 0) {
             const float t = __int_as_float((int)hit[i]);
             b.rays[(long)r * N + env] = t < Lim<float>::big ? t : -1.0f;
         }
@@ -243,10 +251,11 @@ __device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>
 }
 
 template <typename T, bool USE_LDS>
-__global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ action, int N,
+__global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ models, Buffers<T> b, const T* __restrict__ action, int N,
                                                    int frame_skip, int iters, int epw, int tap, int rays_in_step, int pair_memory) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KS_LDS T* lds = (KS_LDS T*)smem;
+    const Model<T>* mp = models + b.wg_model[blockIdx.x];          // every env of this workgroup holds this object
     const Model<T>* ml = mp;
     if constexpr (USE_LDS) { ml = stage_model(mp, lds); lds += model_words<T>(); }
     const Model<T>& m = *ml;
@@ -266,8 +275,8 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
     // split the vertex scans / per-pair (collision) and per-contact (solver) loops; per-env dynamic data is shared in LDS
     const int e = threadIdx.x / LANE_STRIDE;
     const Team<SUBS> team{(int)threadIdx.x % LANE_STRIDE};
-    const int env = blockIdx.x * epw + e;
-    const bool active = !(team.sub >= SUBS || e >= epw || env >= N);
+    const int env = e < epw ? b.slot_env[blockIdx.x * epw + e] : -1;
+    const bool active = !(team.sub >= SUBS || env < 0);
     if (!active && !(USE_LDS && rays_in_step)) return;
     if (active) {
     T hq[4], act[4];
@@ -352,9 +361,10 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mp
 }
 
 template <typename T, bool USE_LDS>
-__global__ __launch_bounds__(WG) void k_substep(const Model<T>* __restrict__ mp, Buffers<T> b, const T* __restrict__ ctrl, int N, int iters, int epw, int tap) {
+__global__ __launch_bounds__(WG) void k_substep(const Model<T>* __restrict__ models, Buffers<T> b, const T* __restrict__ ctrl, int N, int iters, int epw, int tap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KS_LDS T* lds = (KS_LDS T*)smem;
+    const Model<T>* mp = models + b.wg_model[blockIdx.x];
     const Model<T>* ml = mp;
     if constexpr (USE_LDS) { ml = stage_model(mp, lds); lds += model_words<T>(); }
     const Model<T>& m = *ml;
@@ -372,8 +382,8 @@ __global__ __launch_bounds__(WG) void k_substep(const Model<T>* __restrict__ mp,
     const Hulls<T>& hu = *hup;
     const int e = threadIdx.x / LANE_STRIDE;
     const Team<SUBS> team{(int)threadIdx.x % LANE_STRIDE};
-    const int env = blockIdx.x * epw + e;
-    if (team.sub >= SUBS || e >= epw || env >= N) return;
+    const int env = e < epw ? b.slot_env[blockIdx.x * epw + e] : -1;
+    if (team.sub >= SUBS || env < 0) return;
     LaneState<T> st;
     load_state(b, env, N, st);
     T hq[4], c[NU], R7[9];
@@ -406,11 +416,11 @@ __global__ __launch_bounds__(WG) void k_substep(const Model<T>* __restrict__ mp,
 
 // (re)initialise flagged envs from their stored initial state
 template <typename T, bool USE_LDS>
-__global__ __launch_bounds__(WAVE) void k_reset(const Model<T>* __restrict__ mp, Buffers<T> b, int N, int clear_flag) {
+__global__ __launch_bounds__(WAVE) void k_reset(const Model<T>* __restrict__ models, Buffers<T> b, int N, int clear_flag) {
     __shared__ T lds[SCR_CON * WAVE];       // forward kinematics only touches the body-pose part of the scratch
     const int env = blockIdx.x * WAVE + threadIdx.x;
     if (env >= N || !b.flag[env]) return;
-    const Model<T>& m = *mp;
+    const Model<T>& m = models[b.obj_id[env]];
     Scratch<T, KS_LDS T*> scr{(KS_LDS T*)lds + threadIdx.x, WAVE};
     LaneState<T> st;
     T hq[4], q0[NQ];
@@ -428,14 +438,54 @@ __global__ __launch_bounds__(WAVE) void k_reset(const Model<T>* __restrict__ mp,
 
 // scatter caller-provided initial states into the stored per-env initial state and flag the envs
 template <typename T>
-__global__ void k_store_init(Buffers<T> b, const int32_t* __restrict__ env_ids, int n, const T* __restrict__ qpos0, const T* __restrict__ hq, int N) {
+__global__ void k_store_init(Buffers<T> b, const int32_t* __restrict__ env_ids, int n, const T* __restrict__ qpos0, const T* __restrict__ hq,
+                             const int32_t* __restrict__ object_id, const T* __restrict__ mass_friction, int n_models, int N) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int env = env_ids ? env_ids[i] : i;
     if (env < 0 || env >= N) return;
     for (int k = 0; k < NQ; k++) b.qpos0[(long)k * N + env] = qpos0[(long)k * n + i];
     for (int k = 0; k < 4; k++) b.hand_quat[(long)k * N + env] = hq[(long)k * n + i];
+    if (object_id) {
+        int o = object_id[i];
+        o = o < 0 ? 0 : (o >= n_models ? n_models - 1 : o);
+        b.obj_id[env] = o;
+        if (!mass_friction) { b.envp[env] = b.nominal[2 * o]; b.envp[(long)N + env] = b.nominal[2 * o + 1]; }   // the new object's own mass / friction
+    }
+    if (mass_friction) { b.envp[env] = mass_friction[i]; b.envp[(long)N + env] = mass_friction[(long)n + i]; }
     b.flag[env] = 1;
+}
+
+// The stepping kernel's work list: envs grouped by object model (stable: ascending env id inside a group), every group
+// padded to whole workgroups with -1.  One workgroup of 256 threads; thread t owns a contiguous chunk of envs.
+constexpr int SLOT_THREADS = 256, MODELS_MAX = 32;
+__global__ __launch_bounds__(SLOT_THREADS) void k_slots(const int32_t* __restrict__ obj_id, int N, int n_models, int epw, int n_wg,
+                                                          int32_t* __restrict__ slot_env, int32_t* __restrict__ wg_model) {
+    __shared__ int cnt[SLOT_THREADS][MODELS_MAX + 1];     // +1: odd stride
+    __shared__ int base[MODELS_MAX + 1];
+    const int t = threadIdx.x, chunk = (N + SLOT_THREADS - 1) / SLOT_THREADS, e0 = t * chunk, e1 = e0 + chunk < N ? e0 + chunk : N;
+    for (int m = 0; m < n_models; m++) cnt[t][m] = 0;
+    for (int e = e0; e < e1; e++) cnt[t][obj_id[e]]++;
+    for (int s = t; s < n_wg * epw; s += SLOT_THREADS) slot_env[s] = -1;
+    __syncthreads();
+    if (t < n_models) {                                   // exclusive scan over the chunks, per model
+        int run = 0;
+        for (int k = 0; k < SLOT_THREADS; k++) { const int c = cnt[k][t]; cnt[k][t] = run; run += c; }
+        base[t + 1] = (run + epw - 1) / epw * epw;        // group size, whole workgroups
+    }
+    __syncthreads();
+    if (t == 0) {
+        base[0] = 0;
+        for (int m = 0; m < n_models; m++) base[m + 1] += base[m];
+        for (int m = 0; m < n_models; m++)
+            for (int w = base[m] / epw; w < base[m + 1] / epw && w < n_wg; w++) wg_model[w] = m;
+        for (int w = base[n_models] / epw; w < n_wg; w++) wg_model[w] = 0;        // idle workgroups
+    }
+    __syncthreads();
+    for (int e = e0; e < e1; e++) {
+        const int m = obj_id[e], s = base[m] + cnt[t][m]++;
+        if (s < n_wg * epw) slot_env[s] = e;
+    }
 }
 
 // one (env, ray, geom) per lane: eight envs per wave, the eight mesh geoms of an env in adjacent lanes (lane 0 of the
@@ -456,7 +506,7 @@ template <typename T> struct GroupBound {
 
 constexpr int RAY_ENVS = WAVE / (NGEOM - 1);
 static_assert(NGEOM - 1 == 8, "k_rays: eight mesh geoms per env, one per lane");
-template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model<T>* __restrict__ mp, Buffers<T> b, int N, int masked) {
+template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model<T>* __restrict__ models, Buffers<T> b, int N, int masked) {
     const int g = 1 + (threadIdx.x & 7);
     const int env = blockIdx.x * RAY_ENVS + (threadIdx.x >> 3), ray = blockIdx.y;
     const bool live = env < N && !(masked && !b.flag[env]);
@@ -465,7 +515,7 @@ template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model
     __shared__ unsigned stk[RAY_STACK * WAVE];
     pub[threadIdx.x] = Lim<T>::big;
     if (live) {
-        const Model<T>& m = *mp;
+        const Model<T>& m = models[b.obj_id[env]];
         Col<T> snap{b.snap + env, N};
         T pnt[3], vec[3];
         const int sb = ray_origin(m, snap, ray, pnt, vec);
@@ -497,7 +547,7 @@ template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model
 // (observation of flagged envs only, flag cleared); mode 2: observation / reward / lifted flag of whatever snapshot and
 // rays the buffers hold, no episode bookkeeping (ks_obs_from_snapshot, the parity hook for the env-layer golden vectors)
 template <typename T>
-__global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ mp, Buffers<T> b, int N, int mode, int horizon, int auto_reset,
+__global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ models, Buffers<T> b, int N, int mode, int horizon, int auto_reset,
                                               int env_major, T* __restrict__ obs, T* __restrict__ reward, uint8_t* __restrict__ done,
                                               T* __restrict__ info, T* __restrict__ final_obs) {
     __shared__ T rlds[SCR_CON * WAVE];      // scratch of an auto-reset's forward kinematics (body-pose part only, as in k_reset)
@@ -507,6 +557,7 @@ __global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ mp, B
         if (!b.flag[env]) return;
         b.flag[env] = 0;
     }
+    const Model<T>* mp = models + b.obj_id[env];
     Col<T> snap{b.snap + env, N};
     T rays[NRAY];
     KS_UNROLL
@@ -571,8 +622,9 @@ struct CtxBase {
     std::string error;
     bool model_loaded = false;
     virtual ~CtxBase() {}
-    virtual int load_model(const void* blob, size_t n) = 0;
-    virtual int reset(const int32_t* ids, int n, const void* q0, const void* hq, void* obs, hipStream_t s) = 0;
+    virtual int load_models(int n_models, const void* const* blobs, const size_t* sizes) = 0;
+    virtual int reset(const int32_t* ids, int n, const void* q0, const void* hq, const int32_t* object_id, const void* mass_friction, void* obs,
+                      hipStream_t s) = 0;
     virtual int step(const void* action, void* obs, void* reward, uint8_t* done, void* info, void* final_obs, hipStream_t s) = 0;
     virtual int get_state(void* qpos, void* qvel, void* warm, void* contact, int32_t* ncon, int32_t* status, hipStream_t s) = 0;
     virtual int set_state(const void* qpos, const void* qvel, const void* warm, hipStream_t s) = 0;
@@ -594,14 +646,10 @@ struct CtxBase {
 template <typename T> struct Ctx : CtxBase {
     static constexpr bool USE_LDS = sizeof(T) == 4;
     Buffers<T> b{};
-    Model<T>* d_model = nullptr;
-    T* d_vert[4] = {nullptr, nullptr, nullptr, nullptr};
-    float* d_tri[4] = {nullptr, nullptr, nullptr, nullptr};
-    float* d_box[4] = {nullptr, nullptr, nullptr, nullptr};
-    int* d_lr[4] = {nullptr, nullptr, nullptr, nullptr};
-    unsigned short* d_adj_off[4] = {nullptr, nullptr, nullptr, nullptr};
-    unsigned short* d_adj[4] = {nullptr, nullptr, nullptr, nullptr};
-    unsigned short* d_dirtab = nullptr;
+    Model<T>* d_model = nullptr;          // [n_models] model table
+    int n_models = 0, n_wg = 0;
+    std::map<std::pair<size_t, uint64_t>, void*> shared;      // uploaded arrays by (bytes, content hash): the hand's meshes are
+                                                              // the same in every object's blob and are kept once
     std::vector<void*> allocs;
     // HIP-event timing of k_env_step
     static constexpr int NEV = 512;
@@ -635,7 +683,7 @@ template <typename T> struct Ctx : CtxBase {
         if ((r = alloc(&b.status, N))) return r;
         if ((r = alloc(&b.step_count, N))) return r;
         if ((r = alloc(&b.flag, N))) return r;
-        if ((r = alloc(&d_model, 1))) return r;
+        if ((r = alloc(&b.obj_id, N))) return r;
         ev0.resize(NEV); ev1.resize(NEV);
         for (int i = 0; i < NEV; i++) { HIPCHK(hipEventCreate(&ev0[i])); HIPCHK(hipEventCreate(&ev1[i])); }
         return KS_OK;
@@ -645,67 +693,75 @@ template <typename T> struct Ctx : CtxBase {
         for (auto& e : ev0) (void)hipEventDestroy(e);
         for (auto& e : ev1) (void)hipEventDestroy(e);
     }
-    int load_model(const void* blob, size_t n) override {
-        HostModel<T> hm;
-        if (!parse_model<T>(blob, n, hm)) { error = "ks_load_model: " + hm.error; return KS_ERR_MODEL; }
-        {
+    // device copy of a host array; identical content (the hand's hull / ray meshes, shared by all object blobs) is uploaded once
+    template <typename U> int upload(const std::vector<U>& v, const U** out) {
+        const size_t bytes = v.size() * sizeof(U);
+        uint64_t h = 1469598103934665603ull;
+        const unsigned char* p = (const unsigned char*)v.data();
+        for (size_t i = 0; i < bytes; i++) { h ^= p[i]; h *= 1099511628211ull; }
+        auto it = shared.find({bytes, h});
+        if (it != shared.end()) { *out = (const U*)it->second; return KS_OK; }
+        U* d = nullptr;
+        int r = alloc(&d, v.size() ? v.size() : 1);
+        if (r) return r;
+        HIPCHK(hipMemcpy(d, v.data(), bytes, hipMemcpyHostToDevice));
+        shared[{bytes, h}] = d;
+        *out = d;
+        return KS_OK;
+    }
+    int load_models(int nm, const void* const* blobs, const size_t* sizes) override {
+        if (model_loaded) { error = "ks_load_model: a context loads its model(s) once"; return KS_ERR_STATE; }
+        if (nm <= 0 || nm > MODELS_MAX) { error = "ks_load_models: between 1 and 32 object models"; return KS_ERR_INVALID; }
+        std::vector<Model<T>> table(nm);
+        std::vector<T> nominal(2 * (size_t)nm);
+        hull_words = 0;
+        for (int k = 0; k < nm; k++) {
+            HostModel<T> hm;
+            if (!parse_model<T>(blobs[k], sizes[k], hm)) { error = "ks_load_model: " + hm.error; return KS_ERR_MODEL; }
             // the stepping kernel gives every lane of an env's team at most two hull pairs (ks_core.h, collision)
             const unsigned planes = plane_pair_mask(hm.m);
             int nh = 0;
             for (int pi = 0; pi < hm.m.npair; pi++) nh += ((planes >> pi) & 1u) ? 0 : 1;
             if (nh > 2 * SUBS) { error = "ks_load_model: more than 32 hull-hull contact pairs"; return KS_ERR_MODEL; }
-        }
-        for (int s = 0; s < 4; s++) {
-            int r;
-            if ((r = alloc(&d_vert[s], hm.vert[s].size()))) return r;
-            if ((r = alloc(&d_tri[s], hm.tri[s].size()))) return r;
-            if ((r = alloc(&d_box[s], hm.bvh_box[s].size()))) return r;
-            if ((r = alloc(&d_lr[s], hm.bvh_lr[s].size()))) return r;
-            HIPCHK(hipMemcpy(d_vert[s], hm.vert[s].data(), hm.vert[s].size() * sizeof(T), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(d_tri[s], hm.tri[s].data(), hm.tri[s].size() * sizeof(float), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(d_box[s], hm.bvh_box[s].data(), hm.bvh_box[s].size() * sizeof(float), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(d_lr[s], hm.bvh_lr[s].data(), hm.bvh_lr[s].size() * sizeof(int), hipMemcpyHostToDevice));
-            hm.m.mesh_vert[s] = d_vert[s];
-            hm.m.mesh_tri[s] = d_tri[s];
-            hm.m.mesh_bvh_box[s] = d_box[s];
-            hm.m.mesh_bvh_lr[s] = d_lr[s];
-        }
-        HIPCHK(hipMemcpy(d_model, &hm.m, sizeof(Model<T>), hipMemcpyHostToDevice));
-        hull_words = 0;
-        int adj_ints = 0;
-        for (int s = 0; s < 4; s++) {
-            int r;
-            if ((r = alloc(&d_adj_off[s], hm.adj_off[s].size()))) return r;
-            if ((r = alloc(&d_adj[s], hm.adj[s].size()))) return r;
-            HIPCHK(hipMemcpy(d_adj_off[s], hm.adj_off[s].data(), hm.adj_off[s].size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(d_adj[s], hm.adj[s].data(), hm.adj[s].size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-            hm.m.mesh_adj_off[s] = d_adj_off[s];
-            hm.m.mesh_adj[s] = d_adj[s];
-            hull_words += hm.m.mesh_nvert_pad[s] * 4;
-            adj_ints += ((hm.m.mesh_nvert[s] + 1 + 3) & ~3) + hm.m.mesh_nchunk[s] * 4;
-        }
-        {
-            int r;
-            if ((r = alloc(&d_dirtab, hm.dirtab.size()))) return r;
-            HIPCHK(hipMemcpy(d_dirtab, hm.dirtab.data(), hm.dirtab.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-            hm.m.mesh_dirtab = d_dirtab;
-        }
-        HIPCHK(hipMemcpy(d_model, &hm.m, sizeof(Model<T>), hipMemcpyHostToDevice));
-        {
+            int words = 0, adj_ints = 0, r;
+            for (int s = 0; s < 4; s++) {
+                if ((r = upload(hm.vert[s], &hm.m.mesh_vert[s]))) return r;
+                if ((r = upload(hm.tri[s], &hm.m.mesh_tri[s]))) return r;
+                if ((r = upload(hm.bvh_box[s], &hm.m.mesh_bvh_box[s]))) return r;
+                if ((r = upload(hm.bvh_lr[s], &hm.m.mesh_bvh_lr[s]))) return r;
+                if ((r = upload(hm.adj_off[s], &hm.m.mesh_adj_off[s]))) return r;
+                if ((r = upload(hm.adj[s], &hm.m.mesh_adj[s]))) return r;
+                words += hm.m.mesh_nvert_pad[s] * 4;
+                adj_ints += ((hm.m.mesh_nvert[s] + 1 + 3) & ~3) + hm.m.mesh_nchunk[s] * 4;
+            }
+            if ((r = upload(hm.dirtab, &hm.m.mesh_dirtab))) return r;
             const int iwords = (adj_ints * (int)sizeof(unsigned short) + (int)sizeof(T) - 1) / (int)sizeof(T);
-            hull_words += (iwords + 3) & ~3;
-            hull_words += NPAIR_MAX * pair_rec_bytes<T>() / (int)sizeof(T);
+            words += (iwords + 3) & ~3;
+            words += NPAIR_MAX * pair_rec_bytes<T>() / (int)sizeof(T);
+            hull_words = words > hull_words ? words : hull_words;          // LDS is sized for the largest object
+            table[k] = hm.m;
+            nominal_env_params(hm.m, nominal[2 * k], nominal[2 * k + 1]);
         }
+        n_models = nm;
+        int r;
+        if ((r = alloc(&d_model, (size_t)nm))) return r;
+        HIPCHK(hipMemcpy(d_model, table.data(), sizeof(Model<T>) * nm, hipMemcpyHostToDevice));
+        if ((r = alloc(&b.nominal, nominal.size()))) return r;
+        HIPCHK(hipMemcpy(b.nominal, nominal.data(), nominal.size() * sizeof(T), hipMemcpyHostToDevice));
         {
-            // nominal per-env parameters until ks_set_env_params says otherwise
-            T mass, mu;
-            nominal_env_params(hm.m, mass, mu);
-            std::vector<T> ep(2 * (size_t)cfg.n_envs, mu);
-            std::fill(ep.begin(), ep.begin() + cfg.n_envs, mass);
+            // every env starts with object 0 and its nominal parameters until ks_reset_objects / ks_set_env_params say otherwise
+            std::vector<T> ep(2 * (size_t)cfg.n_envs, nominal[1]);
+            std::fill(ep.begin(), ep.begin() + cfg.n_envs, nominal[0]);
             HIPCHK(hipMemcpy(b.envp, ep.data(), ep.size() * sizeof(T), hipMemcpyHostToDevice));
         }
-        int r = plan_launch();
-        if (r != KS_OK) return r;
+        if ((r = plan_launch()) != KS_OK) return r;
+        // the stepping kernel's work list: at most one partly filled workgroup per object
+        n_wg = (cfg.n_envs + lpw - 1) / lpw + (nm - 1);
+        if ((r = alloc(&b.slot_env, (size_t)n_wg * lpw))) return r;
+        if ((r = alloc(&b.wg_model, (size_t)n_wg))) return r;
+        hipLaunchKernelGGL(k_slots, dim3(1), dim3(SLOT_THREADS), 0, 0, b.obj_id, cfg.n_envs, n_models, lpw, n_wg, b.slot_env, b.wg_model);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipDeviceSynchronize());
         model_loaded = true;
         return KS_OK;
     }
@@ -743,10 +799,15 @@ template <typename T> struct Ctx : CtxBase {
         HIPCHK(hipGetLastError());
         return KS_OK;
     }
-    int reset(const int32_t* ids, int n, const void* q0, const void* hq, void* obs, hipStream_t s) override {
+    int reset(const int32_t* ids, int n, const void* q0, const void* hq, const int32_t* object_id, const void* mass_friction, void* obs,
+              hipStream_t s) override {
         if (!model_loaded) { error = "ks_reset before ks_load_model"; return KS_ERR_STATE; }
         if (n <= 0 || n > cfg.n_envs || !q0 || !hq || (!ids && n != cfg.n_envs)) { error = "ks_reset: bad arguments"; return KS_ERR_INVALID; }
-        hipLaunchKernelGGL((k_store_init<T>), dim3((n + 255) / 256), dim3(256), 0, s, b, ids, n, (const T*)q0, (const T*)hq, cfg.n_envs);
+        hipLaunchKernelGGL((k_store_init<T>), dim3((n + 255) / 256), dim3(256), 0, s, b, ids, n, (const T*)q0, (const T*)hq, object_id,
+                           (const T*)mass_friction, n_models, cfg.n_envs);
+        // objects changed: regroup the stepping kernel's work list by object
+        if (object_id && n_models > 1)
+            hipLaunchKernelGGL(k_slots, dim3(1), dim3(SLOT_THREADS), 0, s, b.obj_id, cfg.n_envs, n_models, lpw, n_wg, b.slot_env, b.wg_model);
         return post_reset(obs, s);
     }
     int step(const void* action, void* obs, void* reward, uint8_t* done, void* info, void* final_obs, hipStream_t s) override {
@@ -755,7 +816,7 @@ template <typename T> struct Ctx : CtxBase {
         const int N = cfg.n_envs;
         const bool timed = ev_used < NEV;
         if (timed) HIPCHK(hipEventRecord(ev0[ev_used], s));
-        hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3((N + lpw - 1) / lpw), dim3(WG), step_lds, s, d_model, b, (const T*)action, N,
+        hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3(n_wg), dim3(WG), step_lds, s, d_model, b, (const T*)action, N,
                            cfg.frame_skip, cfg.solver_iterations, lpw, cfg.contact_tap, (int)rays_in_step, (int)(USE_LDS && cfg.pair_memory));
         if (timed) { HIPCHK(hipEventRecord(ev1[ev_used], s)); ev_used++; }
         if (!rays_in_step) hipLaunchKernelGGL((k_rays<T>), dim3((N + RAY_ENVS - 1) / RAY_ENVS, NRAY), dim3(WAVE), 0, s, d_model, b, N, 0);
@@ -767,7 +828,7 @@ template <typename T> struct Ctx : CtxBase {
     }
     int substep(const void* ctrl, hipStream_t s) override {
         if (!model_loaded) { error = "ks_substep before ks_load_model"; return KS_ERR_STATE; }
-        hipLaunchKernelGGL((k_substep<T, USE_LDS>), dim3((cfg.n_envs + lpw - 1) / lpw), dim3(WG), step_lds, s, d_model, b, (const T*)ctrl, cfg.n_envs,
+        hipLaunchKernelGGL((k_substep<T, USE_LDS>), dim3(n_wg), dim3(WG), step_lds, s, d_model, b, (const T*)ctrl, cfg.n_envs,
                            cfg.solver_iterations, lpw, cfg.contact_tap);
         HIPCHK(hipGetLastError());
         return KS_OK;
@@ -879,11 +940,22 @@ void ks_destroy(ks_ctx* ctx) {
 
 int ks_load_model(ks_ctx* ctx, const void* blob, size_t n) {
     if (!ctx || !blob) return KS_ERR_INVALID;
-    return ctx->impl->load_model(blob, n);
+    return ctx->impl->load_models(1, &blob, &n);
+}
+int ks_load_models(ks_ctx* ctx, int32_t n_models, const void* const* blobs, const size_t* nbytes) {
+    if (!ctx || !blobs || !nbytes) return KS_ERR_INVALID;
+    for (int k = 0; k < n_models; k++)
+        if (!blobs[k]) return KS_ERR_INVALID;
+    return ctx->impl->load_models(n_models, blobs, nbytes);
 }
 int ks_reset(ks_ctx* ctx, const int32_t* ids, int32_t n, const void* q0, const void* hq, void* obs, void* stream) {
     if (!ctx) return KS_ERR_INVALID;
-    return ctx->impl->reset(ids, n, q0, hq, obs, (hipStream_t)stream);
+    return ctx->impl->reset(ids, n, q0, hq, nullptr, nullptr, obs, (hipStream_t)stream);
+}
+int ks_reset_objects(ks_ctx* ctx, const int32_t* ids, int32_t n, const void* q0, const void* hq, const int32_t* object_id, const void* mass_friction,
+                     void* obs, void* stream) {
+    if (!ctx) return KS_ERR_INVALID;
+    return ctx->impl->reset(ids, n, q0, hq, object_id, mass_friction, obs, (hipStream_t)stream);
 }
 int ks_step(ks_ctx* ctx, const void* action, void* obs, void* reward, uint8_t* done, void* info, void* final_obs, void* stream) {
     if (!ctx) return KS_ERR_INVALID;

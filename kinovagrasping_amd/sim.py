@@ -21,7 +21,7 @@ class KsConfig(C.Structure):
                 ("contact_tap", C.c_int32), ("pair_memory", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
-EXPORTS = ["ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_load_model", "ks_reset", "ks_step",
+EXPORTS = ["ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_load_model", "ks_load_models", "ks_reset", "ks_reset_objects", "ks_step",
            "ks_get_state", "ks_set_state", "ks_set_env_params", "ks_substep", "ks_obs_from_snapshot", "ks_kernel_time", "ks_version"]
 # include/kinova_rollout.h
 ROLLOUT_EXPORTS = ["kr_select_action", "kr_store_transition", "kr_rank_episodes", "kr_commit_episodes", "kr_advance_ring",
@@ -50,7 +50,9 @@ def load_library(path: Path | None = None):
     L.ks_last_error.argtypes = [vp]
     L.ks_last_error.restype = C.c_char_p
     L.ks_load_model.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.ks_load_models.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
     L.ks_reset.argtypes = [vp, i32p, C.c_int32, vp, vp, vp, vp]
+    L.ks_reset_objects.argtypes = [vp, i32p, C.c_int32, vp, vp, vp, vp, vp, vp]
     L.ks_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.ks_get_state.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.ks_set_state.argtypes = [vp, vp, vp, vp, vp]
@@ -107,12 +109,19 @@ class KinovaSim:
         rc = self.lib.ks_create(C.byref(cfg), self.device.index, C.byref(self.ctx))
         if rc != 0:
             raise RuntimeError(f"ks_create failed ({rc}): {self.lib.ks_last_error(None).decode()}")
-        if isinstance(model, (bytes, bytearray)):
-            blob = model
+        from .model_compiler import load_model_blob
+        as_blob = lambda m: bytes(m) if isinstance(m, (bytes, bytearray)) else bytes(load_model_blob(m, ASSETS))
+        if isinstance(model, (list, tuple)):
+            # mixed-object context (BASELINE config 5): object k of reset(object_id=...) is model[k]
+            self.models = list(model)
+            blobs = [as_blob(m) for m in model]
+            arr = (C.c_char_p * len(blobs))(*blobs)
+            sizes = (C.c_size_t * len(blobs))(*[len(b) for b in blobs])
+            self._check(self.lib.ks_load_models(self.ctx, len(blobs), arr, sizes))
         else:
-            from .model_compiler import load_model_blob
-            blob = load_model_blob(model, ASSETS)
-        self._check(self.lib.ks_load_model(self.ctx, bytes(blob), len(blob)))
+            self.models = [model]
+            blob = as_blob(model)
+            self._check(self.lib.ks_load_model(self.ctx, blob, len(blob)))
         N, dt, dev = self.n_envs, self.dtype, self.device
         self.obs = torch.zeros((N, NOBS) if obs_env_major else (NOBS, N), dtype=dt, device=dev)
         self.final_obs = torch.zeros_like(self.obs)
@@ -138,14 +147,24 @@ class KinovaSim:
         except Exception:
             pass
 
-    def reset(self, qpos0: torch.Tensor, hand_quat: torch.Tensor, env_ids: torch.Tensor | None = None):
-        """qpos0 [16, n], hand_quat [4, n]; env_ids int32 [n] or None (all envs).  Returns the obs buffer."""
+    def reset(self, qpos0: torch.Tensor, hand_quat: torch.Tensor, env_ids: torch.Tensor | None = None, object_id=None, mass_friction=None):
+        """qpos0 [16, n], hand_quat [4, n]; env_ids int32 [n] or None (all envs); object_id int32 [n] (index into the
+        context's model list) and mass_friction [2, n] (object mass, object-hand friction) optional (ks_reset_objects).
+        Returns the obs buffer."""
         qpos0 = qpos0.to(self.device, self.dtype).contiguous()
         hand_quat = hand_quat.to(self.device, self.dtype).contiguous()
         n = qpos0.shape[1]
         ids = None if env_ids is None else env_ids.to(self.device, torch.int32).contiguous()
-        self._check(self.lib.ks_reset(self.ctx, _ptr(ids), n, _ptr(qpos0), _ptr(hand_quat), _ptr(self.obs), self._stream()))
-        self._keep = (qpos0, hand_quat, ids)
+        if object_id is None and mass_friction is None:
+            self._check(self.lib.ks_reset(self.ctx, _ptr(ids), n, _ptr(qpos0), _ptr(hand_quat), _ptr(self.obs), self._stream()))
+            self._keep = (qpos0, hand_quat, ids)
+            return self.obs
+        oid = None if object_id is None else torch.as_tensor(object_id).to(self.device, torch.int32).contiguous()
+        mf = None if mass_friction is None else torch.as_tensor(mass_friction).to(self.device, self.dtype).contiguous()
+        if oid is not None and oid.numel() != n or mf is not None and tuple(mf.shape) != (2, n):
+            raise ValueError("reset: object_id [n], mass_friction [2, n]")
+        self._check(self.lib.ks_reset_objects(self.ctx, _ptr(ids), n, _ptr(qpos0), _ptr(hand_quat), _ptr(oid), _ptr(mf), _ptr(self.obs), self._stream()))
+        self._keep = (qpos0, hand_quat, ids, oid, mf)
         return self.obs
 
     def step(self, action: torch.Tensor):
