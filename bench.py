@@ -113,10 +113,13 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--mode", choices=["ddpg", "sim"], default="ddpg")
+    ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=None,
+                    help="BASELINE config: 2 = --mode sim, 3 / 4 = DDPG training (4: with --gpus 8), 5 = DDPG training on the domain-"
+                         "randomised set: 14 shapes x 3 hand poses, per-env mass / friction, 8192 envs per GPU")
     ap.add_argument("--hidden", type=int, nargs=2, default=[256, 256])
     ap.add_argument("--serial-learner", action="store_true", help="run the learner update after the sim step instead of beside it")
     ap.add_argument("--eager", action="store_true", help="launch the rollout / learner ops one by one instead of replaying HIP graphs")
-    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--envs-per-gpu", type=int, default=None, help="default 4096 (the metric's env count); 8192 for --config 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steady-updates", type=int, default=1500, help="learner updates before the steady_state window (ddpg mode; 0 = skip)")
     ap.add_argument("--steady-steps", type=int, default=300, help="length of the steady_state window in env-steps (a multiple of the 30-step episode)")
@@ -126,6 +129,12 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: start it as `python bench.py --gpus N` "
                  "or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+
+    if args.config == 2:
+        args.mode = "sim"
+    mixed = args.config == 5
+    if args.envs_per_gpu is None:
+        args.envs_per_gpu = 8192 if mixed else 4096
 
     import numpy as np
     import torch
@@ -147,10 +156,16 @@ def main():
     n = args.envs_per_gpu
     dev = torch.device("cuda", local_rank)
     # envs shard by global index: rank r owns envs [r*n, (r+1)*n); no data-path collective in the sim
-    q0_all, hq_all = scenarios.config2_states(n * world)
-    q0, hq = q0_all[:, rank * n:(rank + 1) * n], hq_all[:, rank * n:(rank + 1) * n]
-    sim = KinovaSim(n, "CubeS", device=local_rank, auto_reset=True, horizon=30)
-    obs0 = sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+    sl = slice(rank * n, (rank + 1) * n)
+    if mixed:
+        # config 5: 14 shapes x {normal, rotated, top} x mass / friction per env, all in ONE context and one stepping launch
+        oid_all, pose_all, q0_all, hq_all, mf_all = scenarios.config5_states(n * world, seed=5)
+        sim = KinovaSim(n, scenarios.SHAPES, device=local_rank, auto_reset=True, horizon=30)
+        obs0 = sim.reset(torch.as_tensor(q0_all[:, sl]), torch.as_tensor(hq_all[:, sl]), object_id=oid_all[sl], mass_friction=mf_all[:, sl])
+    else:
+        q0_all, hq_all = scenarios.config2_states(n * world)
+        sim = KinovaSim(n, "CubeS", device=local_rank, auto_reset=True, horizon=30)
+        obs0 = sim.reset(torch.as_tensor(q0_all[:, sl]), torch.as_tensor(hq_all[:, sl]))
 
     def barrier():
         torch.cuda.synchronize()
@@ -317,7 +332,11 @@ def main():
             "metric": "env-steps/sec (whole node) at 4096 envs/GPU", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"{n} envs/GPU DDPG training, 256-256 actor/critic, CubeS normal pose: actor inference + exploration noise + "
+            "config": {"workload": (f"{n} envs/GPU DDPG training on the domain-randomised object set: 14 README shapes x {{normal, rotated, top}} hand "
+                                    "poses (reference thresholds, no-noise tables, pose hand offsets), per-env mass U[0.05,0.15] kg and friction "
+                                    "U[0.5,1.0], one simulator context / one stepping launch; 256-256 actor/critic, one DDPGfD update per env-step "
+                                    "(BASELINE config 5; 65536 envs when n_gpus=8)") if mixed else
+                                   (f"{n} envs/GPU DDPG training, 256-256 actor/critic, CubeS normal pose: actor inference + exploration noise + "
                                     "scripted lift in the loop, device replay, one DDPGfD update (64 episodes x 25 five-step windows) per "
                                     "env-step (BASELINE config 3; config 4 when n_gpus=8)") if args.mode == "ddpg" else
                                    (f"{n} envs/GPU CubeS normal-pose grasp sim, PCG64(1000+i) random-action rollout (BASELINE config 2 at the "

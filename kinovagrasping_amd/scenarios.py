@@ -36,6 +36,64 @@ def hand_quat_for(orientation: str) -> np.ndarray:
     return euler_to_quat(truncated_euler(ORIENTATION_EULER[orientation]))
 
 
+_palm_quat = None
+
+
+def hand_slide_offsets(orientation: str, shape: str, mode: str = "pose") -> np.ndarray:
+    """Start values of the three slide joints, KinovaGripper_Env.determine_hand_location (ENV:1286-1307): zero for
+    'normal'; for 'rotated' -T [0.051, -0.075, 0.06] and for 'top' -T [-0.005, -0.155, Z + 0.06] (x, y negated, z kept;
+    Z = 0.13 / 0.15 for S / B objects) with T = Tfw[:3, :3], the world -> palm rotation.
+
+    mode "pose": T is the palm rotation of the orientation itself - what the authors intended and what a persistent env
+    (the evaluation loops) uses once it has seen the pose: the hand hovers above / beside the object.
+    mode "fresh-env": zeros - what the training driver actually gets, because it builds a new env for every episode
+    (main_DDPGfD.py:381) whose Tfw is still the zero matrix of __init__ (ENV:110) when reset() multiplies by it; the
+    'rotated' / 'top' hands then start inside the floor and larger objects inside the hand (SURVEY note N5)."""
+    global _palm_quat
+    if orientation == "normal" or mode == "fresh-env":
+        return np.zeros(3)
+    if mode != "pose":
+        raise ValueError("hand_slide_offsets: mode is 'pose' or 'fresh-env'")
+    from .model_compiler import quat_to_mat, read_blob
+    if _palm_quat is None:
+        _palm_quat = read_blob(model_blob("CubeS"))["geom_quat"][1]
+    Rp = quat_to_mat(hand_quat_for(orientation)) @ quat_to_mat(_palm_quat)
+    T = (Rp @ np.array([[0, 0, 1], [-1, 0, 0], [0, -1, 0]], dtype=np.float64)).T
+    if orientation == "top":
+        Z = 0.15 if shape.endswith("B") else (0.14 if shape.endswith("M") else 0.13)
+        v = T @ np.array([-0.005, -0.155, Z + 0.06])
+    else:
+        v = T @ np.array([0.051, -0.075, 0.06])
+    return np.array([-v[0], -v[1], v[2]])
+
+
+def config5_states(n_envs: int, seed: int = 5, hand_offsets: str = "pose"):
+    """BASELINE config 5: env i holds one of the README's 14 shapes drawn uniformly, an orientation class from
+    the reference's thresholds (ENV:1212-1220: t = rand(); < 0.333 normal, > 0.667 top, else rotated) with the env's
+    no-noise Euler constants and hand offsets (ENV:1267-1273, 1286-1307), the object at a row of the matching no_noise
+    table, mass ~ U[0.05, 0.15] kg and finger-object friction ~ U[0.5, 1.0]; Generator(PCG64(seed)).
+    Returns object_id [N] int32, orientation names [N], qpos0 [16, N], hand_quat [4, N], mass_friction [2, N]."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    oid = rng.integers(0, len(SHAPES), n_envs).astype(np.int32)
+    t = rng.random(n_envs)
+    names = ["normal" if x < 0.333 else ("top" if x > 0.667 else "rotated") for x in t]
+    q = np.zeros((16, n_envs))
+    hq = np.zeros((4, n_envs))
+    q[12] = 1.0
+    rows = rng.random(n_envs)
+    cache = {}
+    for i in range(n_envs):
+        key = (SHAPES[oid[i]], names[i])
+        if key not in cache:
+            cache[key] = (start_coord_table(*key), hand_quat_for(names[i]), hand_slide_offsets(names[i], key[0], hand_offsets))
+        tab, quat, off = cache[key]
+        q[0:3, i] = off
+        q[9:12, i] = tab[int(rows[i] * len(tab))]
+        hq[:, i] = quat
+    mass, mu = rng.uniform(0.05, 0.15, n_envs), rng.uniform(0.5, 1.0, n_envs)
+    return oid, names, q, hq, np.stack([mass, mu])
+
+
 def config1_state(shape: str = "CubeS"):
     """BASELINE config 1: hand joints 0, object at row 2 of Normal/<shape>.txt, identity quaternion."""
     q = np.zeros(16)

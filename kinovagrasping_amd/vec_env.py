@@ -4,37 +4,58 @@ Keeps the names, argument meaning and return layout of KinovaGripper_Env
 (gym-kinova-gripper/gym_kinova_gripper/envs/kinova_gripper_env.py): reset(...) -> observations,
 step(action) -> (obs, reward, done, info) with info keys finger_reward / grasp_reward / lift_reward
 (ENV:685), action_space Box(+-0.8, (4,)) (ENV:128), _max_episode_steps (main_DDPGfD.py:384),
-get_obj_coords / get_orientation (main_DDPGfD.py:167,253).  Batched: every quantity gains a leading
-env dimension and lives on the GPU as a torch tensor; the compute is libkinova_sim.so.
+get_obj_coords / get_orientation (main_DDPGfD.py:167,253), Tfw (main_DDPGfD.py:170,406), get_orientation_idx
+(main_DDPGfD.py:411), get_coords_filename (main_DDPGfD.py:161), Generate_Latin_Square / check_obj_file_empty
+(main_DDPGfD.py:387-388).  Batched: every quantity gains a leading env dimension and lives on the GPU as a torch tensor;
+the compute is libkinova_sim.so.  With a LIST of shapes the env holds all those objects in one simulator context and
+every reset picks each env's object the way the reference's reset() does per episode (select_object, ENV:986-1005).
 """
 from __future__ import annotations
 
+import csv
+import os
 from types import SimpleNamespace
 
 import numpy as np
 import torch
 
 from . import scenarios
+from .model_compiler import read_blob
 from .sim import KinovaSim, NOBS
+
+COORDS_DIR = "gym_kinova_gripper/envs/kinova_description/obj_hand_coords/"     # ENV:1245
 
 
 class KinovaGripperVecEnv:
     metadata = {"render.modes": []}
 
-    def __init__(self, n_envs: int, shape: str = "CubeS", device: int = 0, frame_skip: int = 15, max_episode_steps: int = 30,
-                 auto_reset: bool = True, solver_iterations: int = 6, seed: int = 0):
+    def __init__(self, n_envs: int, shape="CubeS", device: int = 0, frame_skip: int = 15, max_episode_steps: int = 30,
+                 auto_reset: bool = True, solver_iterations: int = 6, seed: int = 0, hand_offsets: str = "pose"):
+        """shape: one object name, or a list of them (mixed-object batches, BASELINE config 5).
+        hand_offsets: where the 'rotated' / 'top' hands start (determine_hand_location, ENV:1286-1307) - "pose": with the
+        pose's own palm rotation, as intended; "fresh-env": zero, as the reference's training driver ends up doing because it
+        recreates the env (zero Tfw) for every episode (scenarios.hand_slide_offsets)."""
+        self.hand_offsets = hand_offsets
         self.n_envs = n_envs
-        self.random_shape = shape
+        self.shapes = [shape] if isinstance(shape, str) else list(shape)
+        self.random_shape = self.shapes[0] if isinstance(shape, str) else [self.shapes[0]] * n_envs
+        self.shape_id = np.zeros(n_envs, dtype=np.int32)
         self.frame_skip = frame_skip
         self._max_episode_steps = max_episode_steps
         self.action_space = SimpleNamespace(low=np.full(4, -0.8, np.float32), high=np.full(4, 0.8, np.float32), shape=(4,), dtype=np.float32)
         self.observation_dim = NOBS
-        self.sim = KinovaSim(n_envs, shape, device=device, frame_skip=frame_skip, horizon=max_episode_steps,
+        self.sim = KinovaSim(n_envs, shape if isinstance(shape, str) else self.shapes, device=device, frame_skip=frame_skip, horizon=max_episode_steps,
                              solver_iterations=solver_iterations, auto_reset=auto_reset, obs_env_major=True)
         self.np_random = np.random.RandomState(seed)
         self.orientation = ["normal"] * n_envs
         self.obj_coords = np.zeros((n_envs, 3))
+        self.orientation_idx = np.zeros(n_envs, dtype=np.int64)
+        self.hand_quat = np.repeat(scenarios.hand_quat_for("normal")[:, None], n_envs, 1)
+        self.obj_keys = []                       # Latin-square object queue (Generate_Latin_Square); reset() pops from its end
         self.with_grasp_reward = False
+        M = read_blob(scenarios.model_blob(self.shapes[0]))        # hand constants for Tfw (the same in every object's blob)
+        self._l7_pos, self._slide_axis = M["body_pos"][2], M["slide_axis"]
+        self._palm_pos, self._palm_quat = M["geom_pos"][1], M["geom_quat"][1]
 
     # -- reference-compatible accessors -----------------------------------------------------------
     def seed(self, seed=None):
@@ -50,6 +71,62 @@ class KinovaGripperVecEnv:
     def get_random_shape(self):
         return self.random_shape
 
+    def get_orientation_idx(self):
+        """row of the start-coordinate table every env's episode started from (ENV:1044, main_DDPGfD.py:411)"""
+        return self.orientation_idx
+
+    def get_coords_filename(self):
+        """the coordinate file of every env's (orientation, shape), the path the reference builds at ENV:1245"""
+        names = self.random_shape if isinstance(self.random_shape, list) else [self.random_shape] * self.n_envs
+        return [COORDS_DIR + "no_noise/train_coords/" + o + "/" + sh + ".txt" for o, sh in zip(self.orientation, names)]
+
+    @property
+    def Tfw(self):
+        """[N, 4, 4] world -> palm-local transforms (ENV:274-288: T = (R_palm C)^T, Tfw = [T, -T wrist]) of the envs'
+        CURRENT joint state (the reference refreshes its copy inside _get_obs, i.e. at the pose the last observation
+        saw; right after a reset - where the drivers read it, main_DDPGfD.py:170,406 - the two are the same)."""
+        from .model_compiler import quat_to_mat
+        qpos = self.sim.get_state()["qpos"].double().cpu().numpy()
+        C_ = np.array([[0, 0, 1], [-1, 0, 0], [0, -1, 0]], dtype=np.float64)
+        Rg = quat_to_mat(self._palm_quat)
+        out = np.zeros((self.n_envs, 4, 4))
+        for e in range(self.n_envs):
+            R7 = quat_to_mat(self.hand_quat[:, e] / np.linalg.norm(self.hand_quat[:, e]))
+            p7 = self._l7_pos + R7 @ (self._slide_axis.T @ qpos[0:3, e])
+            Rp, pp = R7 @ Rg, p7 + R7 @ self._palm_pos
+            T = (Rp @ C_).T
+            wrist = pp + T.T @ np.array([-0.009, 0.048, 0.0])
+            out[e, :3, :3], out[e, :3, 3], out[e, 3, 3] = T, -T @ wrist, 1.0
+        return out
+
+    # -- object schedule (ENV:884-1005) --------------------------------------------------------------
+    def check_obj_file_empty(self, filename):
+        """ENV:884-893: False when the file does not exist (sic), True when it exists and is empty"""
+        if not os.path.exists(filename):
+            return False
+        with open(filename, "r") as f:
+            return not f.read(1)
+
+    def Generate_Latin_Square(self, max_elements, filename, shape_keys, test=False):
+        """ENV:895-964: the cyclic-rotation object list (scenarios.latin_square_object_keys, pinned by
+        tests/golden/schedule.npz), kept as the env's queue and written to `filename` in the reference's csv form (one
+        key per row, one character per column - csv.writer.writerow on a string)."""
+        self.obj_keys = self.obj_keys + scenarios.latin_square_object_keys(list(shape_keys), max_elements)
+        with open(filename, "w", newline="") as out:
+            w = csv.writer(out)
+            for key in self.obj_keys:
+                w.writerow(key)
+
+    def get_obj_keys(self):
+        return self.obj_keys
+
+    def select_object(self, shape_keys):
+        """one env's object for its next episode: popped from the END of the Latin-square queue when there is one
+        (get_object, ENV:986-989), else drawn uniformly from shape_keys"""
+        if self.obj_keys:
+            return self.obj_keys.pop()
+        return shape_keys[self.np_random.randint(0, len(shape_keys))]
+
     def set_with_grasp_reward(self, with_grasp):
         if with_grasp:
             raise NotImplementedError("the grasp-classifier reward needs gc_model.pkl, which the reference does not ship "
@@ -57,38 +134,53 @@ class KinovaGripperVecEnv:
         self.with_grasp_reward = False
 
     # -- reset ------------------------------------------------------------------------------------
-    def select_orienation(self, hand_orientation: str):
+    def select_orienation(self, hand_orientation: str, shape=None):
         """ENV:1180-1222 (scenarios.select_orientation, pinned by tests/golden/schedule.npz); a fixed class name
         ('normal' / 'rotated' / 'top') is taken as is."""
         if hand_orientation in scenarios.ORIENTATION_EULER:
             return hand_orientation
-        return scenarios.select_orientation(self.random_shape, hand_orientation, self.np_random)
+        return scenarios.select_orientation(shape if shape is not None else self.random_shape, hand_orientation, self.np_random)
 
     def reset(self, shape_keys=None, hand_orientation="normal", with_grasp=False, env_name="env", mode="train", start_pos=None,
               obj_params=None, qpos=None, obj_coord_region=None, with_noise=False, env_ids=None):
         """Reset all envs (or `env_ids`).  start_pos: optional [n,3] object positions; otherwise rows are
         sampled from the no_noise start-coordinate table of the shape (ENV:1008-1054, SURVEY note N5).
-        Slide offsets are zero for every orientation: determine_hand_location (ENV:1286-1307) multiplies by the
-        env's Tfw *before* it is first computed, and the training loop builds a fresh env (Tfw = zeros, ENV:114)
-        for every episode (main_DDPGfD.py:381), so the offsets it actually uses are 0."""
+        obj_params: the reference's [shape, size] test hook is not supported; a [2, n] ARRAY here is the config-5
+        extension (per-env object mass, object-hand friction).  With several objects loaded every reset env draws its
+        object from `shape_keys` (default: all loaded) - Latin-square queue first, see select_object.
+        Slide offsets of the 'rotated' / 'top' hands: see `hand_offsets` of the constructor."""
         self.set_with_grasp_reward(with_grasp)
         ids = np.arange(self.n_envs) if env_ids is None else np.asarray(env_ids)
         n = len(ids)
         q = np.zeros((16, n))
         hq = np.zeros((4, n))
         q[12] = 1.0
+        multi = isinstance(self.random_shape, list)
+        keys = [k for k in (shape_keys or self.shapes)]
+        if multi and any(k not in self.shapes for k in keys):
+            raise ValueError(f"shape_keys {keys} not all among the env's objects {self.shapes}")
         for k, e in enumerate(ids):
-            o = self.select_orienation(hand_orientation)
+            if multi:
+                name = self.select_object(keys)
+                self.random_shape[e], self.shape_id[e] = name, self.shapes.index(name)
+            shape = self.random_shape[e] if multi else self.random_shape
+            o = self.select_orienation(hand_orientation, shape)
             self.orientation[e] = o
             hq[:, k] = scenarios.hand_quat_for(o)
             if start_pos is not None:
                 q[9:12, k] = np.asarray(start_pos)[k][:3]
+                self.orientation_idx[e] = -1
             else:
-                tab = scenarios.start_coord_table(self.random_shape, o)
-                q[9:12, k] = tab[self.np_random.randint(0, len(tab))]
+                tab = scenarios.start_coord_table(shape, o)
+                row = self.np_random.randint(0, len(tab))
+                q[9:12, k] = tab[row]
+                self.orientation_idx[e] = row
+            q[0:3, k] = scenarios.hand_slide_offsets(o, shape, self.hand_offsets)
             self.obj_coords[e] = q[9:12, k]
+            self.hand_quat[:, e] = hq[:, k]
         t_ids = None if env_ids is None else torch.as_tensor(ids, dtype=torch.int32)
-        obs = self.sim.reset(torch.as_tensor(q), torch.as_tensor(hq), t_ids)
+        obs = self.sim.reset(torch.as_tensor(q), torch.as_tensor(hq), t_ids, object_id=self.shape_id[ids].copy() if multi else None,
+                             mass_friction=obj_params if (obj_params is not None and not isinstance(obj_params, (list, tuple))) else None)
         return obs
 
     # -- step -------------------------------------------------------------------------------------

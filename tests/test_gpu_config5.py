@@ -123,3 +123,54 @@ def test_objects_change_at_a_partial_reset():
         torch.cuda.synchronize()
         assert torch.equal(o1[0], obb[e]), (k, e)
         one.close()
+
+
+def test_vec_env_mixed_objects_and_reference_accessors(tmp_path):
+    """KinovaGripperVecEnv with a list of shapes: reset(shape_keys, 'random') draws each env's object (Latin-square queue
+    first, as the reference pops objects.csv), orientation class and start row; Tfw / get_orientation_idx /
+    get_coords_filename / Generate_Latin_Square / check_obj_file_empty behave as the drivers expect
+    (main_DDPGfD.py:161,170,387-388,406,411)."""
+    import csv
+    from kinovagrasping_amd.vec_env import KinovaGripperVecEnv
+    shapes = ["CubeS", "CylinderB", "Vase2S", "Cone1B"]
+    n = 64
+    env = KinovaGripperVecEnv(n, shapes, seed=11, auto_reset=False)
+    f = tmp_path / "objects.csv"
+    assert env.check_obj_file_empty(str(f)) is False            # sic: a missing file is "not empty" (ENV:885-886)
+    f.write_text("")
+    assert env.check_obj_file_empty(str(f)) is True
+    env.Generate_Latin_Square(n, str(f), shape_keys=shapes)
+    assert env.check_obj_file_empty(str(f)) is False
+    rows = ["".join(r) for r in csv.reader(open(f, newline=""))]
+    assert rows == scenarios.latin_square_object_keys(shapes, n) and len(env.get_obj_keys()) == n
+    expect = scenarios.latin_square_object_keys(shapes, n)[::-1]                 # episodes pop the queue from its end
+    obs = env.reset(shape_keys=shapes, hand_orientation="random", mode="train")
+    torch.cuda.synchronize()
+    assert env.get_random_shape() == expect and env.get_obj_keys() == []
+    assert tuple(obs.shape) == (n, 82) and torch.isfinite(obs).all()
+    assert set(env.get_orientation()) == {"normal", "rotated", "top"}
+    # start coordinates, row index and file name agree with the tables
+    for e in (0, 13, n - 1):
+        tab = scenarios.start_coord_table(env.get_random_shape()[e], env.get_orientation()[e])
+        assert np.array_equal(tab[env.get_orientation_idx()[e]], env.get_obj_coords()[e])
+        assert env.get_coords_filename()[e].endswith(f"no_noise/train_coords/{env.get_orientation()[e]}/{env.get_random_shape()[e]}.txt")
+    # Tfw against the oracle's env layer at the reset pose; object position in the palm frame = obs[21:24]
+    T = env.Tfw
+    for e in (0, 5, 31, n - 1):
+        model = ko.OracleModel(scenarios.model_blob(env.get_random_shape()[e]))
+        o = ko.OracleSim(model, scenarios.hand_quat_for(env.get_orientation()[e]), solver_iterations=6)
+        q0 = np.zeros(16); q0[9:12] = env.get_obj_coords()[e]; q0[12] = 1
+        q0[0:3] = scenarios.hand_slide_offsets(env.get_orientation()[e], env.get_random_shape()[e])     # the env's default: "pose"
+        ob = o.env_reset(q0)
+        Tfw_o = ko.env_ctrl(o.view("geom_xpos").reshape(9, 3)[1], o.view("geom_xmat").reshape(9, 9)[1], np.zeros(4))[0]
+        np.testing.assert_allclose(T[e], Tfw_o, rtol=0, atol=1e-7)             # the slide positions come back from the fp32 state
+        np.testing.assert_allclose(obs[e].double().cpu().numpy(), ob, rtol=2e-4, atol=2e-5)
+    # the objects really differ per env: the object-size slots of the observation follow the env's shape
+    sizes = {sh: ko.OracleModel(scenarios.model_blob(sh)) for sh in shapes}
+    a = torch.zeros(n, 4); a[:, 1:] = 0.4
+    obs2, rew, done, info = env.step(a)
+    assert torch.isfinite(obs2).all() and len({tuple(np.round(obs2[e, 33:36].cpu().numpy(), 6)) for e in range(n)}) == len(shapes)
+    # a partial reset without a queue draws uniformly from the given keys
+    env.reset(shape_keys=["Vase2S"], hand_orientation="normal", env_ids=[2, 9])
+    assert env.get_random_shape()[2] == "Vase2S" and env.get_random_shape()[9] == "Vase2S"
+    env.close()
