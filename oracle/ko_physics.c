@@ -9,12 +9,19 @@
  * Deliberately written in the plainest dense form (15x15 matrices, full Jacobians) so that it
  * is an independent check of the specialised HIP kernels.
  *
+ * Third-party algorithms restated here: the penetration query (mpr_penetration and its helpers portal_dir, expand_portal,
+ * find_pos, portal_reach_tolerance, point-triangle distance) follows the structure of libccd's ccdMPRPenetration
+ * (libccd, (c) Daniel Fiser, BSD-3-Clause - the collision library MuJoCo 1.50 links; it is NOT part of /root/reference and
+ * none of its source text is used); the distance query is the textbook GJK (Gilbert, Johnson, Keerthi 1988).
+ *
  *   S1 ko_kinematics      mj_kinematics / mj_comPos
  *   S2 mass_matrix        mj_crb + mj_factorM         (here: M = sum_b J_b^T I_b J_b, Cholesky)
  *   S3 bias/passive/act   mj_rne / mj_passive / mj_fwdActuation
  *   S4 collision          mj_collision                (plane-hull, hull-hull via MPR)
  *   S5 make_constraint    mj_makeConstraint / mj_projectConstraint / mj_referenceConstraint
- *   S6 solve_pgs          mj_fwdConstraint (PGS, fixed sweep count, warm start from qacc_warmstart)
+ *   S6 solve_newton       mj_fwdConstraint (Newton on the primal problem, MuJoCo's default for this XML; solve_pgs =
+ *                         projected Gauss-Seidel on the dual, kept as an independent cross-check of the same optimum:
+ *                         tests/test_oracle_known_answers.py)
  *   S7 euler              mj_Euler (implicit joint damping)
  *   S8 sensors            mj_sensorPos (jointpos, rangefinder)
  */

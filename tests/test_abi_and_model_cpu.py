@@ -120,3 +120,32 @@ def test_example_script_resolves_every_global_name():
     missing = sorted({n for f in vars(mod).values() if callable(f) and getattr(f, "__module__", None) == mod.__name__ and hasattr(f, "__code__")
                       for n in globals_loaded(f.__code__) if not hasattr(mod, n) and not hasattr(builtins, n)})
     assert not missing, missing
+
+
+def test_c_program_compiles_against_the_headers_and_links_every_symbol(lib, tmp_path):
+    """A plain C translation unit (gcc -std=c99 -Wall -Werror, no torch, no C++) that includes include/*.h, checks the
+    struct layout a caller relies on and references every declared entry point, linked against libkinova_sim.so and
+    run: what a maintainer binding the library from C / cgo / JNI would hit first."""
+    import subprocess
+    names = []
+    for h in ("kinova_sim.h", "kinova_rollout.h"):
+        text = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / h).read_text(), flags=re.S)
+        names += sorted(set(re.findall(r"\b(k[sr]_[a-z_0-9]+)\s*\(", text)))
+    src = tmp_path / "abi_check.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "kinova_sim.h"\n#include "kinova_rollout.h"\n'
+                   "typedef char cfg_is_48_bytes[sizeof(ks_config) == 48 ? 1 : -1];\n"
+                   "typedef char cfg_pair_memory_at_36[offsetof(ks_config, pair_memory) == 36 ? 1 : -1];\n"
+                   "typedef void (*fn)(void);\nstatic fn table[] = {" + ", ".join(f"(fn){n}" for n in names) + "};\n"
+                   "int main(void) {\n  ks_config c; ks_ctx *ctx = NULL; int rc;\n  ks_default_config(&c);\n"
+                   "  if (c.frame_skip != 15 || c.horizon != 30 || c.precision != 32 || c.pair_memory != 1) return 2;\n"
+                   "  rc = ks_create(&c, 0, &ctx);\n"
+                   "  if (rc == KS_OK) ks_destroy(ctx); else if (rc != KS_ERR_NO_DEVICE || !ks_last_error(NULL)[0]) return 3;\n"
+                   '  printf("%d symbols, ks_version %d, ks_create rc %d\\n", (int)(sizeof table / sizeof table[0]), ks_version(), rc);\n  return 0;\n}\n')
+    exe = tmp_path / "abi_check"
+    libdir = Path(ks._build.LIB).parent
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), str(src), "-o", str(exe),
+                           "-L", str(libdir), "-lkinova_sim", "-Wl,-rpath," + str(libdir), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
+                           "-Wl,--allow-shlib-undefined"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert f"{len(names)} symbols" in out.stdout and len(names) >= 30
