@@ -66,6 +66,34 @@ def cpu_baseline(n_cores: int, budget_s: float = 12.0):
                       f"{sum(s for s, _ in res)} env-steps total"}
 
 
+def cpu_baseline_mujoco(budget_s: float = 8.0):
+    """Only where the third-party `mujoco` package is importable (not on this image / the GPU boxes): real MuJoCo stepping
+    the same CubeS model (rebuilt from the compiled blob, kinovagrasping_amd/mjcf_export.py) with config-2 actions, ONE
+    thread; env-steps/s = mj_step rate / 15.  Returns None when mujoco is missing."""
+    try:
+        import mujoco
+    except Exception:
+        return None
+    import numpy as np
+    from kinovagrasping_amd import mjcf_export, scenarios
+    q0, hq = scenarios.config2_states(1)
+    m = mujoco.MjModel.from_xml_string(mjcf_export.to_mjcf(scenarios.model_blob("CubeS"), hq[:, 0]))
+    d = mujoco.MjData(m)
+    acts = scenarios.config_actions(1, 30)[:, :, 0]
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        d.qpos[:] = q0[:, 0]; d.qvel[:] = 0
+        mujoco.mj_forward(m, d)
+        for t in range(30):
+            d.ctrl[:] = [0, 0.2932 * 0, 0, 0, acts[t][0], 0.2932, acts[t][1], acts[t][2], acts[t][3]]     # normal pose: wrist = slide_z
+            for _ in range(15):
+                mujoco.mj_step(m, d)
+        steps += 30
+    dt = time.perf_counter() - t0
+    return {"value": round(steps / dt, 2), "unit": "env-steps/s", "cores": 1, "kind": "third-party mujoco " + mujoco.__version__,
+            "sample": f"{steps} env-steps of 30-step CubeS episodes, one thread, model rebuilt from the compiled blob"}
+
+
 def launch_ranks(n_ranks: int, argv) -> int:
     """Start `n_ranks` copies of this script as child processes (one per GPU, env-style rendezvous on 127.0.0.1) and wait.
     Nothing in this process has touched torch / HIP at this point, and no process that has is ever re-exec'ed."""
@@ -363,6 +391,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            mj = cpu_baseline_mujoco()                     # None unless the third-party mujoco package happens to be installed
+            if mj is not None:
+                out["cpu_baseline_mujoco"] = mj
         print(json.dumps(out))
     sim.close()
     if world > 1:
