@@ -221,13 +221,37 @@ def build_bvh(tri: np.ndarray, leaf: int = 4):
     return tri[order].reshape(-1, 9).astype(np.float32), np.array(boxes, dtype=np.float32), np.array(lr, dtype=np.int32)
 
 
+def box_triangles(hx, hy, hz):
+    """the 12 triangles of a box with half extents (hx, hy, hz), outward winding"""
+    c = np.array([[sx * hx, sy * hy, sz * hz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])   # index = 4 ix + 2 iy + iz
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]         # -x +x -y +y -z +z
+    return np.array([[c[a], c[b], c[d]] for a, b, d, e in quads] + [[c[a], c[d], c[e]] for a, b, d, e in quads])
+
+
+def cylinder_triangles(r, h, n=64):
+    """an n-gon prism (radius r to the vertices, half height h, axis z): side quads + cap fans, outward winding"""
+    ang = 2 * np.pi * np.arange(n) / n
+    ring = np.stack([r * np.cos(ang), r * np.sin(ang)], 1)
+    tri = []
+    for i in range(n):
+        j = (i + 1) % n
+        a, b = ring[i], ring[j]
+        tri += [[[a[0], a[1], -h], [b[0], b[1], -h], [b[0], b[1], h]], [[a[0], a[1], -h], [b[0], b[1], h], [a[0], a[1], h]],
+                [[0, 0, h], [a[0], a[1], h], [b[0], b[1], h]], [[0, 0, -h], [b[0], b[1], -h], [a[0], a[1], -h]]]
+    return np.array(tri, dtype=np.float64)
+
+
 class CompiledMesh:
-    def __init__(self, tri: np.ndarray, name: str):
+    def __init__(self, tri: np.ndarray, name: str, keep_frame: bool = False):
+        """keep_frame: the triangles already are in the geom frame (primitive geoms: MuJoCo keeps the user frame of a box /
+        cylinder, only meshes are re-centred on their inertial frame)"""
         from scipy.spatial import ConvexHull
         self.name = name
         self.ntri = len(tri)
         self.volume, self.com, inertia = mesh_mass_properties(tri)
         self.principal, self.R = principal_frame(inertia)        # unit-density moments
+        if keep_frame:
+            self.com, self.R, self.principal = np.zeros(3), np.eye(3), np.diag(inertia).copy()
         self.quat = mat_to_quat(self.R)
         pts = np.unique(tri.reshape(-1, 3), axis=0)
         hull = ConvexHull(pts)
@@ -371,17 +395,39 @@ def compile_model(xml_path: Path) -> dict:
             assert g.get("class") == "ground"
             geom_size[gi] = _floats(g.get("size"), 3)
             continue
-        assert g.get("type") == "mesh", f"{xml_path.name}: only mesh objects are compiled (got {g.get('type')})"
         slot = GEOM_MESH[gi]
-        if meshes[slot] is None:
-            meshes[slot] = get_mesh(g.get("mesh"))
+        gtype = g.get("type", "sphere")
+        if gtype in ("box", "cylinder"):
+            # Primitive object geoms (the env's default model is ..._mbox.xml, ENV:62; bbox / scyl / mcyl / bcyl likewise):
+            # compiled to their convex polytope in the geom's own frame - a box exactly (8 vertices), a cylinder as a
+            # 64-gon prism (radial deviation <= r (1 - cos(pi/64)) = 1.2e-3 r; the README's CylinderS/B meshes are 67-gons) -
+            # so that one narrow phase (GJK / MPR on hulls, plane-hull) and one ray caster serve every object.
+            # Inertia and the sizes the observation reports are the primitive's own (analytic), not the polytope's.
+            assert gi == 8, "only the object may be a primitive"
+            raw = _floats(g.get("size"))
+            if gtype == "box":
+                assert len(raw) == 3
+                prim = dict(kind="box", raw=raw, half=raw.copy(), rbound=float(np.linalg.norm(raw)),
+                            inertia=np.array([raw[1] ** 2 + raw[2] ** 2, raw[0] ** 2 + raw[2] ** 2, raw[0] ** 2 + raw[1] ** 2]) / 3.0)
+                meshes[slot] = CompiledMesh(box_triangles(*raw), "box", keep_frame=True)
+            else:
+                assert len(raw) == 2
+                r_, h_ = raw
+                prim = dict(kind="cylinder", raw=np.array([r_, h_, 0.0]), half=np.array([r_, r_, h_]), rbound=float(np.hypot(r_, h_)),
+                            inertia=np.array([r_ ** 2 / 4 + h_ ** 2 / 3, r_ ** 2 / 4 + h_ ** 2 / 3, r_ ** 2 / 2]))
+                meshes[slot] = CompiledMesh(cylinder_triangles(r_, h_), "cylinder", keep_frame=True)
+        else:
+            assert gtype == "mesh", f"{xml_path.name}: geom type {gtype} is not compiled"
+            prim = None
+            if meshes[slot] is None:
+                meshes[slot] = get_mesh(g.get("mesh"))
         cm = meshes[slot]
         gp, gq = _frame_of(g)                       # user frame of the geom in the body (identity here)
         Rg = quat_to_mat(gq)
         geom_pos[gi] = gp + Rg @ cm.com
         geom_quat[gi] = mat_to_quat(Rg @ cm.R)
-        geom_size[gi] = cm.size
-        geom_rbound[gi] = cm.rbound
+        geom_size[gi] = cm.size if prim is None else prim["half"]
+        geom_rbound[gi] = cm.rbound if prim is None else prim["rbound"]
     # object inertial inferred from its geom (mass on the geom, XML:153)
     og = geom_elems["object"]
     omass = float(og.get("mass"))
@@ -389,7 +435,7 @@ def compile_model(xml_path: Path) -> dict:
     body_mass[9] = omass
     body_ipos[9] = geom_pos[8]
     body_iquat[9] = geom_quat[8]
-    body_inertia[9] = cm.principal * (omass / cm.volume)
+    body_inertia[9] = cm.principal * (omass / cm.volume) if prim is None else prim["inertia"] * omass
     M["body_pos"], M["body_quat"], M["body_mass"] = body_pos, body_quat, body_mass
     M["body_ipos"], M["body_iquat"], M["body_inertia"] = body_ipos, body_iquat, body_inertia
     M["geom_pos"], M["geom_quat"], M["geom_size"], M["geom_rbound"] = geom_pos, geom_quat, geom_size, geom_rbound
@@ -458,7 +504,8 @@ def compile_model(xml_path: Path) -> dict:
 
     # inverse weights at qpos0 ------------------------------------------------------------------------
     M.update(_invweights(M))
-    M["obj_size_obs"] = object_size_obs(geom_size[8], xml_path.name)
+    # the observation's object size comes from MuJoCo's geom_size: AABB half extents of a mesh, the size attribute of a primitive
+    M["obj_size_obs"] = object_size_obs(geom_size[8] if prim is None else prim["raw"], xml_path.name)
     return M
 
 

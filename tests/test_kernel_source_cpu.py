@@ -129,3 +129,51 @@ def test_hand_pressed_on_the_ground(blob, orientation, min_seen):
         # Newton iterations and are not converged to round-off, hence 1e-6 here instead of 1e-9
         assert np.abs(qp - o.view("qpos")).max() < 1e-6, (i, np.abs(qp - o.view("qpos")).max())
     assert seen >= min_seen, seen      # hand geoms did touch the ground
+
+
+@pytest.mark.parametrize("shape,n_ground", [("mbox", 4), ("bbox", 4), ("scyl", 4), ("bcyl", 4)])
+def test_primitive_objects_drop_rest_and_grasp(assets_dir, shape, n_ground):
+    """The env's default model (..._mbox.xml, ENV:62) and its primitive siblings: box / cylinder object geoms compiled to
+    their convex polytopes (model_compiler.compile_model).  Kernel-source lane and oracle agree substep for substep (fp64)
+    through a drop, the rest on the plane and a closing grasp; at rest the contacts carry exactly the object's weight."""
+    blob = scenarios.model_blob(shape)
+    M = __import__("kinovagrasping_amd.model_compiler", fromlist=["x"]).read_blob(blob)
+    m = ko.OracleModel(blob)
+    hq = scenarios.hand_quat_for("normal")
+    o = ko.OracleSim(m, hq, solver_iterations=6)
+    half_h = M["geom_size"][8][2]
+    q0 = np.zeros(16); q0[9:12] = [0.0, 0.0, half_h + 0.01]; q0[12] = 1
+    o.env_reset(q0)
+    lane = Lane(blob, 64)
+    ctrl = np.zeros(9); ctrl[5] = 0.2932
+    for i in range(300):
+        if i == 60:
+            ctrl[6:9] = 0.6
+        before = (o.view("qpos").copy(), o.view("qvel").copy(), o.view("qacc_warmstart").copy())
+        o.step(ctrl)
+        qp, qv, qw, nc, con, st = lane.substep(*before, ctrl, hq)
+        assert nc == o.s.ncon and st == 0
+        assert np.abs(qp - o.view("qpos")).max() < 1e-9, (shape, i)
+        if i == 59:
+            f = o.contact_forces()
+            ground = [k for k, c in enumerate(o.contacts()) if c["geom1"] == 0 and c["geom2"] == 8]
+            assert len(ground) == n_ground and abs(f[ground, 0].sum() - 0.1 * 9.81) < 1e-4 * 0.981
+            assert abs(o.view("qpos")[11] - half_h) < 1.1e-3                    # resting inside the 1 mm margin
+    assert any(c["geom2"] == 8 and c["geom1"] in (2, 3, 4, 5, 6, 7) for c in o.contacts())      # the fingers reached the object
+
+
+def test_primitive_object_compile_known_answers(assets_dir):
+    """box / cylinder geoms: analytic inertia at 0.1 kg, the size triple the observation reports (ENV:706-746 on MuJoCo's
+    geom_size: half extents of a box, (radius, half height, 0) of a cylinder), polytope vertex counts, the mbox slide ranges"""
+    from kinovagrasping_amd import model_compiler as mc
+    B, C = mc.read_blob(scenarios.model_blob("mbox")), mc.read_blob(scenarios.model_blob("scyl"))
+    a, c = 0.02125, 0.055
+    np.testing.assert_allclose(B["body_inertia"][9], [0.1 * (a * a + c * c) / 3, 0.1 * (a * a + c * c) / 3, 0.1 * 2 * a * a / 3], rtol=1e-12)
+    np.testing.assert_allclose(B["obj_size_obs"], [a, a, 2 * c], rtol=1e-12)
+    assert len(B["mesh3_vert"]) == 8 and np.allclose(np.abs(B["mesh3_vert"]), [a, a, c])
+    np.testing.assert_allclose(B["slide_range"], [[-0.2, 0.2], [-0.2, 0.2], [0.0, 0.2]])
+    r, h = 0.0175, 0.05
+    np.testing.assert_allclose(C["body_inertia"][9], [0.1 * (r * r / 4 + h * h / 3)] * 2 + [0.1 * r * r / 2], rtol=1e-12)
+    np.testing.assert_allclose(C["obj_size_obs"], [r, r, 2 * h], rtol=1e-12)
+    assert len(C["mesh3_vert"]) == 128 and np.allclose(np.hypot(C["mesh3_vert"][:, 0], C["mesh3_vert"][:, 1]), r)
+    np.testing.assert_allclose(C["geom_size"][8], [r, r, h])

@@ -13,11 +13,12 @@ from kinovagrasping_amd import model_compiler as mc
 KD = Path("/root/reference/gym-kinova-gripper/gym_kinova_gripper/envs/kinova_description")
 OUT = Path(__file__).resolve().parents[1] / "kinovagrasping_amd" / "assets"
 SHAPES = [s + z for s in ["Cube", "Cylinder", "Cube45", "Cone1", "Cone2", "Vase1", "Vase2"] for z in "SB"]  # README.md:59
+PRIMITIVES = ["mbox", "bbox", "scyl", "mcyl", "bcyl"]      # the env's default model (ENV:62) and its primitive siblings
 
 
 def main():
     OUT.mkdir(exist_ok=True)
-    for shape in SHAPES:
+    for shape in SHAPES + PRIMITIVES:
         M = mc.compile_model(KD / f"j2s7s300_end_effector_v1_{shape}.xml")
         hand = {k: M.pop(k) for k in mc.HAND_RAY_KEYS}          # identical for every object: stored once
         if shape == SHAPES[0]:
