@@ -346,16 +346,19 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/pmc_run.sh);
         # the committed summary applies to the 4096-env workload only
         traffic, traffic_note, issue = None, "no PMC summary for this workload", None
-        pmc = ROOT / "profiles" / "r01_pmc.json"
-        if pmc.exists() and n == 4096:
+        pmc = ROOT / "profiles" / "r02_pmc.json"
+        if pmc.exists() and n == 4096 and not mixed:
             pj = json.loads(pmc.read_text())
             traffic, traffic_note = pj["hbm_bytes_per_launch"], pj["note"]
             pl = pj["per_launch"]
             if "SQ_WAVE_CYCLES" in pl:           # what actually bounds the kernel: one wave per SIMD, issue + LDS latency
-                issue = {"valu_busy_frac_of_wave_cycles": round(pl["SQ_ACTIVE_INST_VALU"] / pl["SQ_WAVE_CYCLES"], 3),
+                issue = {"bound": "valu-issue", "valu_busy_frac_of_wave_cycles": round(pl["SQ_ACTIVE_INST_VALU"] / pl["SQ_WAVE_CYCLES"], 3),
                          "waiting_frac_of_wave_cycles": round(pl["SQ_WAIT_ANY"] / pl["SQ_WAVE_CYCLES"], 3),
                          "valu_instructions_per_wave": round(pl["SQ_INSTS_VALU"] / pl["SQ_WAVES"]), "waves_per_simd": 1,
-                         "source": "profiles/r01_pmc.json (rocprofv3 --pmc, sim-only workload)"}
+                         "valu_lane_efficiency": round(pj.get("valu_lane_efficiency", 0.0), 3),
+                         "lds_bank_conflict_frac": round(pj.get("lds_bank_conflict_frac", 0.0), 3),
+                         "l2_hit_rate": round(pj.get("l2_hit_rate", 0.0), 3),
+                         "source": "profiles/r02_pmc.json (rocprofv3 --pmc, sim-only workload)"}
         out = {
             "metric": "env-steps/sec (whole node) at 4096 envs/GPU", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),

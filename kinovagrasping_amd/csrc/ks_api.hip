@@ -667,6 +667,7 @@ template <typename T> struct Ctx : CtxBase {
     int init() {
         const size_t N = cfg.n_envs;
         int r;
+        if (getenv("KS_PAIR_MEMORY")) cfg.pair_memory = getenv("KS_PAIR_MEMORY")[0] != '0';      // experiment switch
         if ((r = alloc(&b.qpos, NQ * N))) return r;
         if ((r = alloc(&b.qvel, NV * N))) return r;
         if ((r = alloc(&b.warm, NV * N))) return r;

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_pmc_k_env_step_summary.txt (tools/pmc_run.sh) -> profiles/<round>_pmc.json, the file bench.py reads for
+`roofline.traffic` and the issue-bound figures.  Usage: tools/pmc_to_json.py profiles/r02_a_pmc_k_env_step_summary.txt profiles/r02_pmc.json"""
+import json
+import re
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+per = {}
+for line in open(src):
+    m = re.match(r"(\S+)\s+per-launch avg\s+([0-9.eE+-]+)", line)
+    if m:
+        per[m.group(1)] = float(m.group(2))
+kib = 1024.0
+out = {
+    "kernel": "k_env_step",
+    "workload": "bench.py --mode sim, 4096 envs, CubeS (tools/pmc_run.sh: rocprofv3 --kernel-trace --pmc, one counter set per pass)",
+    "source": src,
+    "per_launch": per,
+    # FETCH_SIZE / WRITE_SIZE are reported in KiB.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half the
+    # bytes of WIDE (16 B / lane) coalesced reads; this kernel's global reads are dword-per-lane gathers (state, slot list,
+    # pair memory, cube-map tables, ray-mesh nodes) for which the width is uncalibrated, so the read side is given as
+    # measured with the doubled value as an upper bound.  WRITE_SIZE is exact for streaming stores.
+    "fetch_bytes_per_launch": per.get("FETCH_SIZE", 0) * kib,
+    "fetch_bytes_per_launch_upper_bound": 2 * per.get("FETCH_SIZE", 0) * kib,
+    "write_bytes_per_launch": per.get("WRITE_SIZE", 0) * kib,
+    "hbm_bytes_per_launch": (per.get("FETCH_SIZE", 0) + per.get("WRITE_SIZE", 0)) * kib,
+    "note": "fetch = per-workgroup staging of the hull / model tables (256 workgroups x ~50 KB, L2 / MALL hits count) + env state + "
+            "pair memory + the in-step rays' mesh nodes; write = state + snapshot + rays + pair memory (4.9 MB) + write-through of the "
+            "private-memory (stack) stores of the out-of-line stages.  The counters sit on the L2's memory side: Infinity-Cache hits "
+            "are included, so this is an upper bound on HBM traffic.",
+}
+if "SQ_THREAD_CYCLES_VALU" in per and "SQ_ACTIVE_INST_VALU" in per:
+    out["valu_lane_efficiency"] = per["SQ_THREAD_CYCLES_VALU"] / (64.0 * per["SQ_ACTIVE_INST_VALU"])
+if "SQ_LDS_BANK_CONFLICT" in per and "SQ_LDS_IDX_ACTIVE" in per:
+    out["lds_bank_conflict_frac"] = per["SQ_LDS_BANK_CONFLICT"] / per["SQ_LDS_IDX_ACTIVE"]
+if "TCC_HIT_sum" in per:
+    out["l2_hit_rate"] = per["TCC_HIT_sum"] / (per["TCC_HIT_sum"] + per["TCC_MISS_sum"])
+json.dump(out, open(dst, "w"), indent=1)
+print({k: v for k, v in out.items() if k not in ("per_launch", "note")})
