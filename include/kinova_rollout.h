@@ -86,6 +86,12 @@ int kr_sample_windows(int32_t batch, int32_t horizon, int32_t n_steps, const int
  */
 int kr_critic_grad(int32_t rows, int32_t n_steps, const float *q, const float *tq1, const float *tqn, const float *reward,
                    const float *weight, const float *weight_sum, float discount, float *dq, float *losses, void *stream);
+/* start of an update (one launch): weight_sum[0] = max(sum(weight), 1) (weight NULL = all ones), dq_actor[rows * n_steps] =
+ * -weight[row] / (weight_sum * n_steps) (dLoss/dQ of the actor loss -mean Q(s, pi(s)), DDPGfD.py:341), it[0] += 1 (the update
+ * counter Adam and the soft update read), and with pipelined != 0 it_head[0] = it[0]: this update's actor step will be applied by
+ * the head of the next one (learner_native.phase_head). */
+int kr_update_prologue(int32_t rows, int32_t n_steps, const float *weight, float *weight_sum, float *dq_actor, int64_t *it, int64_t *it_head,
+                       int32_t pipelined, void *stream);
 int kr_relu_backward(int64_t count, const float *act, float *grad, void *stream);
 int kr_sigmoid_scale_backward(int64_t count, const float *a, float max_action, float *grad, void *stream);
 int kr_adam_step(int64_t count, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *step, float lr,

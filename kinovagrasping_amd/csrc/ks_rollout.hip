@@ -206,6 +206,27 @@ __global__ __launch_bounds__(256) void k_critic_grad(int R, int n, const float* 
     if (threadIdx.x == 0) { losses[1] = l1 * inv; losses[2] = ln * inv; losses[0] = l1 * inv + 0.5f * (ln * inv); }
 }
 
+// start of an update's body: what used to be eight tiny library launches (sum, clamp, mul, div, copy, add, fill, copy)
+__global__ __launch_bounds__(256) void k_update_prologue(int R, int n, const float* __restrict__ weight, float* __restrict__ wsum,
+                                                         float* __restrict__ dq_actor, int64_t* it, int64_t* it_head, int pipelined) {
+#pragma clang fp contract(off)
+    using Reduce = hipcub::BlockReduce<float, 256>;
+    __shared__ typename Reduce::TempStorage tmp;
+    __shared__ float total;
+    float s = 0;
+    for (int r = threadIdx.x; r < R; r += 256) s += weight ? weight[r] : 1.0f;
+    s = Reduce(tmp).Sum(s);
+    if (threadIdx.x == 0) {
+        total = s > 1.0f ? s : 1.0f;                  // 0 / 1 weights: exact unless the batch is all padding
+        wsum[0] = total;
+        it[0] += 1;                                   // this update's number (Adam bias correction, soft-update phase)
+        if (pipelined) it_head[0] = it[0];            // its actor step is applied by the NEXT update's head
+    }
+    __syncthreads();
+    const float scale = -1.0f / (total * (float)n);   // d(-sum_r w_r sum_k Q_rk / (sum(w) n)) / dQ_rk
+    for (int i = threadIdx.x; i < R * n; i += 256) dq_actor[i] = (weight ? weight[i / n] : 1.0f) * scale;
+}
+
 __global__ __launch_bounds__(256) void k_relu_backward(long count, const float* __restrict__ act, float* __restrict__ grad) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) grad[i] = act[i] > 0.0f ? grad[i] : 0.0f;
 }
@@ -317,6 +338,13 @@ int kr_critic_grad(int32_t rows, int32_t n_steps, const float* q, const float* t
     if (rows <= 0 || n_steps <= 0 || !q || !tq1 || !tqn || !reward || !weight_sum || !dq || !losses) return KS_ERR_INVALID;
     hipLaunchKernelGGL(k_critic_grad, dim3(1), dim3(256), 0, (hipStream_t)stream, rows, n_steps, q, tq1, tqn, reward, weight, weight_sum, discount, dq,
                        losses);
+    return launched();
+}
+
+int kr_update_prologue(int32_t rows, int32_t n_steps, const float* weight, float* weight_sum, float* dq_actor, int64_t* it, int64_t* it_head,
+                       int32_t pipelined, void* stream) {
+    if (rows <= 0 || n_steps <= 0 || !weight_sum || !dq_actor || !it || !it_head) return KS_ERR_INVALID;
+    hipLaunchKernelGGL(k_update_prologue, dim3(1), dim3(256), 0, (hipStream_t)stream, rows, n_steps, weight, weight_sum, dq_actor, it, it_head, pipelined);
     return launched();
 }
 

@@ -64,6 +64,7 @@ class NativeDDPGfDUpdate:
         # k + 1.  `it_head` is k while that step is pending and 0 otherwise, so the head is a no-op when nothing is pending
         # (before the first update, or after finish_pending() has applied it eagerly, e.g. ahead of a checkpoint).
         self.it_head = torch.zeros(1, dtype=torch.long, device=policy.device)
+        self.pipelined = False        # set by pipeline.GraphedTrainer: the body marks its actor step pending for the next head
         policy._native = self                                                  # DDPGfD.save / load keep the Adam state in sync
         self.import_optimizer_state()
         self.losses = torch.zeros(3, device=policy.device)                   # critic loss, L1, LN of the last update
@@ -166,6 +167,7 @@ class NativeDDPGfDUpdate:
     def finish_pending(self):
         """apply the pipelined actor step that is still waiting for the next update's head (no-op otherwise)"""
         self.phase_head()
+        self.it_head.zero_()
 
     def _weight_grads(self, net, x, h1, h2, dz3):
         """dz3: gradient at the last layer's pre-activation; fills net.grad, returns nothing"""
@@ -185,11 +187,14 @@ class NativeDDPGfDUpdate:
     def phase_critic(self, state, action, next_state, reward, weight=None):
         """targets, critic forward, loss gradient, critic weight gradients -> self.critic.grad"""
         pol, P = self.p, _sim._ptr
-        self.it += 1
         R = reward.shape[0]
         if weight is None:
             weight = torch.ones(R, device=reward.device)
-        self.weight, self.wsum = weight, weight.sum().clamp_min(1.0).reshape(1)      # 0 / 1 weights: exact unless the batch is all padding
+        # one launch: update counter, sum of the row weights, dLoss/dQ of the actor loss (and, pipelined, the pending mark)
+        self.weight, self.wsum = weight, torch.empty(1, device=reward.device)
+        self.dq_actor = torch.empty(R * pol.n, 1, device=reward.device)
+        self._chk(self.lib.kr_update_prologue(R, pol.n, P(weight), P(self.wsum), P(self.dq_actor), P(self.it), P(self.it_head),
+                                              int(self.pipelined), self._st()), "kr_update_prologue")
         # both target evaluations (1-step: next_state[:, 0], n-step: next_state[:, -1]) in one pass of the target nets
         nx = torch.cat([next_state[:, 0], next_state[:, -1]], 0)
         if self.fused_targets:
@@ -248,7 +253,7 @@ class NativeDDPGfDUpdate:
             q = _mlp.mlp3_forward(cl, sa, a, act=_mlp.ACT_NONE, h1_out=hc1, h2_out=hc2, shadow=True)       # Q itself is not needed
             if self.track_actor_loss:
                 self._set_actor_loss(q, n)
-            dq = (self.weight / (self.wsum * (-float(n)))).repeat_interleave(n).unsqueeze(1).contiguous()
+            dq = self.dq_actor
             # dLoss/d(actor pre-activation): through the critic to its action inputs, then through 0.8 * sigmoid
             _, _, dz3 = _mlp.mlp3_backward(cl, dq, hc1, hc2, want_dz=False, dx_cols=(sa.shape[1], a.shape[1]), act_out=a, scale=pol.max_action)
             dz2, dz1, _ = _mlp.mlp3_backward(al, dz3, ha1, ha2)
@@ -268,8 +273,8 @@ class NativeDDPGfDUpdate:
             hc2 = self._lin_relu(c, 1, hc1)
         if self.track_actor_loss:
             self._set_actor_loss(torch.addmm(c.b[2], hc2, c.W[2].t()), n)
-        # d(-sum_r w_r sum_k Q_rk / (sum(w) n)) / dQ_rk
-        dq = (self.weight / (self.wsum * (-float(n)))).repeat_interleave(n).unsqueeze(1)
+        # d(-sum_r w_r sum_k Q_rk / (sum(w) n)) / dQ_rk  (kr_update_prologue)
+        dq = self.dq_actor
         dh2 = torch.mm(dq, c.W[2])
         self._relu_bwd(hc2, dh2)
         dh1 = torch.mm(dh2, c.W[1])
@@ -294,12 +299,8 @@ class NativeDDPGfDUpdate:
         for net, tgt in ((self.critic, self.critic_t), (self.actor, self.actor_t)):
             self._chk(self.lib.kr_soft_update(net.flat.numel(), P(net.flat), P(tgt.flat), pol.tau, P(self.it_head), pol.network_repl_freq, self._st()),
                       "kr_soft_update")
-        self.it_head.zero_()
-
-    @torch.no_grad()
-    def mark_pending(self):
-        """end of an update's body in the pipelined form: its actor step is now pending"""
-        self.it_head.copy_(self.it)
+        # (no clearing here: in the pipelined form every body re-marks it_head and a head always runs between two bodies;
+        # finish_pending, the eager caller, clears it)
 
     @torch.no_grad()
     def phase_targets(self):

@@ -56,6 +56,7 @@ class GraphedTrainer:
         # the update itself: explicit GEMMs + fused glue kernels (learner_native), same arithmetic as policy.train_on_batch
         from .learner_native import NativeDDPGfDUpdate
         self.native = NativeDDPGfDUpdate(policy)
+        self.native.pipelined = True
 
     # -- learner phases on the static batch -------------------------------------------------------------
     def _sample(self):
@@ -70,8 +71,7 @@ class GraphedTrainer:
         self.loss_c = self.native.phase_critic(st, ac, ns, rw, w)
 
     def _phase2(self):
-        self.native.phase_actor(self.batch[0], self.batch[5])
-        self.native.mark_pending()                 # the actor's Adam step of this update runs in the next update's head
+        self.native.phase_actor(self.batch[0], self.batch[5])     # (its actor Adam step runs in the next update's head: native.pipelined)
 
     def _learn_eager(self):
         self._head()
