@@ -975,17 +975,21 @@ template <typename T> KS_HD void closest_tri(const T* A, const T* B, const T* C,
 }
 
 template <typename T> KS_HD void swap_slots(Simplex<T>& S, T* l, int i, int j, bool doit) {
-    KS_UNROLL
-    for (int c = 0; c < 3; c++) {
-        T t;
-        t = S.y[i][c]; S.y[i][c] = doit ? S.y[j][c] : t; S.y[j][c] = doit ? t : S.y[j][c];
-        t = S.a[i][c]; S.a[i][c] = doit ? S.a[j][c] : t; S.a[j][c] = doit ? t : S.a[j][c];
-        t = S.b[i][c]; S.b[i][c] = doit ? S.b[j][c] : t; S.b[j][c] = doit ? t : S.b[j][c];
+    // a branch, not selects: the few lanes of a wave that are in a narrow phase rarely need a swap at the same turn, and
+    // the wave then skips the ~30 moves (the usual case: a face contact keeps all three vertices)
+    if (doit) {
+        KS_UNROLL
+        for (int c = 0; c < 3; c++) {
+            T t;
+            t = S.y[i][c]; S.y[i][c] = S.y[j][c]; S.y[j][c] = t;
+            t = S.a[i][c]; S.a[i][c] = S.a[j][c]; S.a[j][c] = t;
+            t = S.b[i][c]; S.b[i][c] = S.b[j][c]; S.b[j][c] = t;
+        }
+        const T t = l[i]; l[i] = l[j]; l[j] = t;
+        int k;
+        k = S.ia[i]; S.ia[i] = S.ia[j]; S.ia[j] = k;
+        k = S.ib[i]; S.ib[i] = S.ib[j]; S.ib[j] = k;
     }
-    T t = l[i]; l[i] = doit ? l[j] : t; l[j] = doit ? t : l[j];
-    int k;
-    k = S.ia[i]; S.ia[i] = doit ? S.ia[j] : k; S.ia[j] = doit ? k : S.ia[j];
-    k = S.ib[i]; S.ib[i] = doit ? S.ib[j] : k; S.ib[j] = doit ? k : S.ib[j];
 }
 
 // closest point on the simplex; reduces it to the supporting sub-simplex (stable compaction),
@@ -1061,6 +1065,14 @@ template <typename T> KS_NARROW int gjk_distance(PairGeo<T>& g, T margin, T* dis
 #define KS_GJK_TOL 1e-6
 #endif
     const T tol = T(KS_GJK_TOL);
+    // ... plus, in single precision, an absolute floor on the remaining gap |v| - v.w/|v|: the support points are world
+    // coordinates of ~0.1 m, so v.w carries ~1e-8 m |v| of rounding and a relative test on distances of 0.01 - 1 mm is decided
+    // by noise - the query then crawls across coplanar vertices (a tetrahedron's closest point per turn) for gains of a few
+    // nanometres until a vertex repeats.  0.3 um is 3e-4 of the contact margin; the fp64 lane keeps the oracle's test.
+#ifndef KS_GJK_GAP
+#define KS_GJK_GAP 3e-7
+#endif
+    const T gap = sizeof(T) == 4 ? T(KS_GJK_GAP) : T(0);
     KS_UNROLL
     for (int i = 0; i < 4; i++) {
         S.ia[i] = 0; S.ib[i] = 0;
@@ -1111,7 +1123,7 @@ template <typename T> KS_NARROW int gjk_distance(PairGeo<T>& g, T margin, T* dis
         printf("  gjk[%d] it %d n %d vv %.9g vw %.9g |v| %.9g\n", (int)sizeof(T), it, S.n, (double)vv, (double)vw, (double)ksqrt(vv));
 #endif
         if (vw > 0 && vw * vw >= margin * margin * vv) { gjk_remember(ws, S); return 0; }
-        if (vv - vw <= tol * vv) break;
+        if (vv - vw <= tol * vv + gap * ksqrt(vv)) break;
         bool dup = false;
         KS_UNROLL
         for (int i = 0; i < 4; i++)
@@ -1482,15 +1494,14 @@ KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Tea
                 if (!live_[r]) scr(SCR_PC + pi_[r]) = T(word_[r] & ~PC_COUNT_MASK);     // no contact, hints kept
             }
         }
-        KS_UNROLL
-        for (int pass = 0; pass < 2; pass++) {
-            const bool go = pass == 0 ? (live_[0] || live_[1]) : (live_[0] && live_[1]);
-            if (go) {
-                const int r = (pass == 0 && live_[0]) ? 0 : 1;
-                int h1 = 0, h2 = 0;
-                const int c = collide_hull_hull(m, dirtab, scr, pairs + pi_[r], word_[r], h1, h2, warm ? warm + r : nullptr, prof);
-                scr(SCR_PC + pi_[r]) = T(pc_pack(c, h1, h2));
-            }
+        // one call site: as many turns as the busiest lane of the wave has live pairs
+        unsigned todo = (live_[0] ? 1u : 0u) | (live_[1] ? 2u : 0u);
+        while (todo != 0) {
+            const int r = (todo & 1u) ? 0 : 1;
+            int h1 = 0, h2 = 0;
+            const int c = collide_hull_hull(m, dirtab, scr, pairs + pi_[r], word_[r], h1, h2, warm ? warm + r : nullptr, prof);
+            scr(SCR_PC + pi_[r]) = T(pc_pack(c, h1, h2));
+            todo &= todo - 1;
         }
     }
     KS_TICK(9)

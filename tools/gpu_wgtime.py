@@ -39,6 +39,8 @@ if MODE.startswith("policy"):
     MODE = "policy"
 NSTEP = {"grasp": 22, "random": 12}.get(MODE, 0) or LAST + 1
 for t in range(NSTEP):
+    if t == NSTEP - 1:
+        pre = {k: v.clone() for k, v in sim.get_state().items() if k in ("qpos", "qvel", "qacc_warmstart")}
     if eng is not None:
         eng.step()
     else:
@@ -65,6 +67,10 @@ for t in range(NSTEP):
         order = np.argsort(-d)
         st2 = sim.get_state()
         nc = st2["ncon"].cpu().numpy()
+        import os
+        os.makedirs("gpurun_out", exist_ok=True)
+        act = (eng.action_t if eng is not None else (closing if MODE == "grasp" else acts[NSTEP - 1])).cpu().numpy()
+        np.savez("gpurun_out/slow_envs.npz", envs=order[:8], action=act[:, order[:8]], hand_quat=np.asarray(hq)[:, order[:8]], dur=d[order[:8]], **{k: v.cpu().numpy()[:, order[:8]] for k, v in pre.items()})
         for rank in (0, 1, 2, 3, n // 2, n - 1):
             e = order[rank]
             p = full[:, :, e].max(0)
