@@ -1253,7 +1253,8 @@ KS_HD bool plane_may_touch(S scr, KS_LDS const PairRec<T>* prp) {
 // Ground plane z = 0 (normal +z) vs the hull of geom g2, worked on by the WHOLE team: deepest vertex, then up
 // to 3 more within the margin that are > 0.3*rbound from every accepted vertex (index order).  The lanes
 // scan the vertex table SUBS rows at a time; the team then agrees on the deepest vertex and on the
-// vertices the oracle's greedy index-order rule accepts (see pass 2 below).
+// vertices the oracle's greedy index-order rule accepts (see pass 2 below; the 16-lane team walks only the vertices
+// its first pass found within the margin).
 // Returns the number of contacts staged at record `slot`.
 template <typename T, typename S, int SUBS>
 KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* prp, float* prof = nullptr) {
@@ -1277,6 +1278,7 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     // 16-byte rows, no LDS bank conflicts), four rounds of reads in flight: the deepest vertex.
     T bd = T(1e30);
     int best = nv;
+    unsigned long long cand = 0;                    // bit r: this lane's vertex of round r (index r SUBS + sub) is within the margin
     for (int base0 = 0; base0 < nv; base0 += 4 * SUBS) {
         T dd[4];
         KS_UNROLL
@@ -1288,6 +1290,8 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
         for (int u = 0; u < 4; u++) {
             const int i = base0 + u * SUBS + team.sub;
             if (i < nv && dd[u] < bd) { bd = dd[u]; best = i; }
+            if constexpr (SUBS == 16)
+                if (i < nv && dd[u] <= margin) cand |= 1ull << (base0 / SUBS + u);
         }
     }
     KS_TICK(12)
@@ -1305,6 +1309,42 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     // lowest index) and resumes behind it: at most nv/SUBS + 3 rounds in total, however many vertices lie within
     // the margin (a palm lying flat on the ground has hundreds).
     int start = 0;
+    if constexpr (SUBS == 16) {
+        // The first pass has seen every vertex: each lane kept the rounds in which its vertex was within the margin (nv <=
+        // 1024, checked when the model is loaded: 64 rounds).  The walk then only touches those - a finger tip or a cube
+        // corner on the ground has a handful, and the old search for a vertex that is not there was a second full scan of the
+        // hull (24 rounds for the palm) per plane pair and substep.  Every lane offers its lowest candidate >= start that is far
+        // from everything accepted so far (one that is too close stays too close: dropped), the team takes the lowest offer.
+        while (nc < 4) {
+            int mine = 0x7fffffff;
+            while (cand != 0) {
+                const int i = __builtin_ctzll(cand) * SUBS + team.sub;
+                bool ok = i >= start;
+                if (ok) {
+                    const T v[3] = {V[4 * i], V[4 * i + 1], V[4 * i + 2]};
+                    KS_UNROLL
+                    for (int k = 0; k < 3; k++) {
+                        if (k < nc) {
+                            T dv[3];
+                            sub3(dv, v, cv[k]);
+                            if (dot3(dv, dv) <= thr2) ok = false;
+                        }
+                    }
+                }
+                if (ok) { mine = i; break; }
+                cand &= cand - 1;
+            }
+            T key = T(0);
+            int found = mine;
+            team.argmin(key, found);
+            if (found == 0x7fffffff) break;
+            KS_UNROLL
+            for (int k = 1; k < 4; k++)
+                if (k == nc) { cv[k][0] = V[4 * found]; cv[k][1] = V[4 * found + 1]; cv[k][2] = V[4 * found + 2]; }
+            nc++;
+            start = found + 1;
+        }
+    } else
     while (nc < 4 && start < nv) {
         int found = -1;
         for (int base = start; base < nv; base += 2 * SUBS) {

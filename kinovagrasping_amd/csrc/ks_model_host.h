@@ -175,6 +175,8 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
         if (!blob_find(b, n, nm, r) || r.code != 0) { e = std::string("missing ") + nm; return false; }
         {
             const int nv = (int)r.shape[0], npad = (nv + 7) / 8 * 8;   // HULL_CHUNK
+            // 10-bit vertex ids in the pair memory (ks_core.h PairWarm), 64 rounds of 16 in the plane scan's candidate mask
+            if (nv < 1 || nv > 1024) { e = std::string(nm) + ": a hull has 1 .. 1024 vertices"; return false; }
             hm.vert[s].assign((size_t)npad * 4, T(0));
             for (int i = 0; i < npad; i++)
                 for (int c = 0; c < 3; c++) { double v; std::memcpy(&v, r.data + 8 * (3 * (i < nv ? i : 0) + c), 8); hm.vert[s][4 * i + c] = (T)v; }

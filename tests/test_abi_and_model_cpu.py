@@ -149,3 +149,32 @@ def test_c_program_compiles_against_the_headers_and_links_every_symbol(lib, tmp_
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert f"{len(names)} symbols" in out.stdout and len(names) >= 30
+
+
+def _register_footprints(src: str, tmp_path) -> dict:
+    """{mangled name: (vgprs, agprs)} of every function in a HIP source, from the compiler's device assembly"""
+    import subprocess
+    out = tmp_path / (src + ".s")
+    subprocess.check_call([kb.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", str(out), src],
+                          cwd=str(kb.CSRC), stderr=subprocess.DEVNULL)
+    regs, name, v = {}, None, 0
+    for line in out.read_text().splitlines():
+        if line.startswith("\t.size\t_Z"):
+            name = line.split()[1].rstrip(",")
+        elif line.startswith("; NumVgprs:"):
+            v = int(line.split()[2])
+        elif line.startswith("; NumAgprs:") and name:
+            regs[name] = (v, int(line.split()[2]))
+    return regs
+
+
+def test_stepping_kernel_leaves_registers_for_the_learner(tmp_path):
+    """The learner's LDS-free kernels (ks_mlp.hip *_wave) run on the registers k_env_step leaves free: one wave of <= 128
+    beside the stepping kernel's one wave per SIMD, 512 registers per lane in all.  A stepping kernel above 384 silently
+    serialises the two (measured: 1.15 -> 1.73 ms per env-step when a change took it to 418), so the footprint is a contract."""
+    step = {k: v for k, v in _register_footprints("ks_api.hip", tmp_path).items() if "k_env_stepIf" in k}
+    assert len(step) == 1, step
+    (v, a), = step.values()
+    assert v + a <= 384, (v, a)
+    waves = {k: v for k, v in _register_footprints("ks_mlp.hip", tmp_path).items() if "_wave" in k}
+    assert waves and all(v + a <= 128 for v, a in waves.values()), waves
