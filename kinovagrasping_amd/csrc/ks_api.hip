@@ -543,56 +543,53 @@ template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model
     if (live && g == 1) b.rays[(long)ray * N + env] = best;
 }
 
+// Where a step's (or reset's) results go
+template <typename T> struct ObsOut {
+    T* obs; T* reward; uint8_t* done; T* info; T* final_obs;
+    int horizon, auto_reset, env_major;
+};
+
+// One env's episode bookkeeping + observation.
 // mode 0: after a step (reward / done / time limit / auto-reset flagging); mode 1: after a reset
 // (observation of flagged envs only, flag cleared); mode 2: observation / reward / lifted flag of whatever snapshot and
-// rays the buffers hold, no episode bookkeeping (ks_obs_from_snapshot, the parity hook for the env-layer golden vectors)
-template <typename T>
-__global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ models, Buffers<T> b, int N, int mode, int horizon, int auto_reset,
-                                              int env_major, T* __restrict__ obs, T* __restrict__ reward, uint8_t* __restrict__ done,
-                                              T* __restrict__ info, T* __restrict__ final_obs) {
-    __shared__ T rlds[SCR_CON * WAVE];      // scratch of an auto-reset's forward kinematics (body-pose part only, as in k_reset)
-    const int env = blockIdx.x * WAVE + threadIdx.x;
-    if (env >= N) return;
-    if (mode == 1) {
-        if (!b.flag[env]) return;
-        b.flag[env] = 0;
-    }
-    const Model<T>* mp = models + b.obj_id[env];
-    Col<T> snap{b.snap + env, N};
-    T rays[NRAY];
-    KS_UNROLL
-    for (int i = 0; i < NRAY; i++) rays[i] = b.rays[(long)i * N + env];
-    T o[NOBS], rew, inf[3];
-    bool lifted;
-    build_obs(*mp, snap, rays, [&](int j, T v) { o[j] = v; }, rew, lifted, inf);
+// rays the buffers hold, no episode bookkeeping (ks_obs_from_snapshot, the parity hook for the env-layer golden vectors).
+// `snap` reads the env's snapshot, `rays` its 17 distances, `rscr` is scratch for an auto-reset's forward kinematics (the
+// body-pose part of a stepping block, SCR_CON words).  The observation is written straight to where it belongs (the
+// termination test runs first), nothing of it is kept in registers.
+template <typename T, typename SnapT, typename ScrT>
+__device__ __forceinline__ void obs_epilogue(const Model<T>& m, const Buffers<T>& b, int env, int N, int mode, const ObsOut<T>& o, SnapT snap,
+                                             const T* rays, ScrT rscr) {
+    const bool lifted0 = object_lifted(m, snap);
     uint8_t d = 0;
+    int sc = 0;
+    if (mode == 0) { sc = b.step_count[env] + 1; b.step_count[env] = sc; }
+    if (mode == 0 || mode == 2) d = (lifted0 ? 1 : 0) | ((mode == 0 && o.horizon > 0 && sc >= o.horizon) ? 2 : 0);
+    const bool restart = mode == 0 && d && o.auto_reset;
+    // the episode is over: this observation is the terminal one (final_obs); the env restarts from its stored initial state,
+    // whose observation was computed when that state was set
+    T* dst = restart ? o.final_obs : o.obs;
+    T* keep = mode == 1 ? b.obs0 + (long)env * NOBS : nullptr;
+    const long base = o.env_major ? (long)env * NOBS : (long)env, stride = o.env_major ? 1 : (long)N;
+    T rew, inf[3];
+    bool lifted;
+    build_obs(m, snap, rays, [&](int j, T v) {
+        if (dst) dst[base + j * stride] = v;
+        if (keep) keep[j] = v;
+    }, rew, lifted, inf);
+    // one decision for done, reward and the destination: the early test's (the same arithmetic; this only rules out the two
+    // inlined copies ever being contracted differently by the compiler)
+    rew = lifted0 ? T(50) : T(0);
+    inf[2] = rew;
     if (mode == 0 || mode == 2) {
-        int sc = 0;
-        if (mode == 0) { sc = b.step_count[env] + 1; b.step_count[env] = sc; }
-        d = (lifted ? 1 : 0) | ((mode == 0 && horizon > 0 && sc >= horizon) ? 2 : 0);
-        if (reward) reward[env] = rew;
-        if (done) done[env] = d;
-        if (info) { info[env] = inf[0]; info[(long)N + env] = inf[1]; info[2L * N + env] = inf[2]; }
+        if (o.reward) o.reward[env] = rew;
+        if (o.done) o.done[env] = d;
+        if (o.info) { o.info[env] = inf[0]; o.info[(long)N + env] = inf[1]; o.info[2L * N + env] = inf[2]; }
     }
-    if (mode == 1) {
-        KS_UNROLL
-        for (int j = 0; j < NOBS; j++) b.obs0[(long)env * NOBS + j] = o[j];
-    }
-    T* dst = obs;
-    if (mode == 0 && d && auto_reset) {
-        // the episode is over: this observation is the terminal one; the env restarts from its stored initial state
-        // (k_reset, next launch), whose observation was computed when that state was set
-        dst = final_obs;
-        if (obs) {
-            for (int j = 0; j < NOBS; j++) {
-                const T v = b.obs0[(long)env * NOBS + j];
-                if (env_major) obs[(long)env * NOBS + j] = v;
-                else obs[(long)j * N + env] = v;
-            }
+    if (restart) {
+        if (o.obs) {
+            for (int j = 0; j < NOBS; j++) o.obs[base + j * stride] = b.obs0[(long)env * NOBS + j];
         }
         // ... and the restart itself (what k_reset does for a caller's ks_reset): state, snapshot, counters
-        const Model<T>& m = *mp;
-        Scratch<T, KS_LDS T*> scr{(KS_LDS T*)rlds + threadIdx.x, WAVE};
         LaneState<T> st;
         T hq[4], q0[NQ];
         KS_UNROLL
@@ -600,20 +597,27 @@ __global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ model
         KS_UNROLL
         for (int i = 0; i < NQ; i++) q0[i] = b.qpos0[(long)i * N + env];
         ColW<T> rsnap{b.snap + env, N};
-        lane_reset(m, st, hq, q0, scr, rsnap);
+        lane_reset(m, st, hq, q0, rscr, rsnap);
         store_state(b, env, N, st);
         b.step_count[env] = 0;
         b.ncon[env] = 0;
     }
-    if (dst) {
-        if (env_major) {
-            KS_UNROLL
-            for (int j = 0; j < NOBS; j++) dst[(long)env * NOBS + j] = o[j];
-        } else {
-            KS_UNROLL
-            for (int j = 0; j < NOBS; j++) dst[(long)j * N + env] = o[j];
-        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ models, Buffers<T> b, int N, int mode, ObsOut<T> o) {
+    __shared__ T rlds[SCR_CON * WAVE];      // scratch of an auto-reset's forward kinematics (body-pose part only, as in k_reset)
+    const int env = blockIdx.x * WAVE + threadIdx.x;
+    if (env >= N) return;
+    if (mode == 1) {
+        if (!b.flag[env]) return;
+        b.flag[env] = 0;
     }
+    Col<T> snap{b.snap + env, N};
+    T rays[NRAY];
+    KS_UNROLL
+    for (int i = 0; i < NRAY; i++) rays[i] = b.rays[(long)i * N + env];
+    obs_epilogue(models[b.obj_id[env]], b, env, N, mode, o, snap, rays, Scratch<T, KS_LDS T*>{(KS_LDS T*)rlds + threadIdx.x, WAVE});
 }
 
 struct CtxBase {
@@ -795,8 +799,8 @@ template <typename T> struct Ctx : CtxBase {
         const int N = cfg.n_envs;
         hipLaunchKernelGGL((k_reset<T, USE_LDS>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0);
         hipLaunchKernelGGL((k_rays<T>), dim3((N + RAY_ENVS - 1) / RAY_ENVS, NRAY), dim3(WAVE), 0, s, d_model, b, N, 1);
-        hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 1, cfg.horizon, cfg.auto_reset, cfg.obs_env_major,
-                           (T*)obs, (T*)nullptr, (uint8_t*)nullptr, (T*)nullptr, (T*)nullptr);
+        hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 1,
+                           ObsOut<T>{(T*)obs, nullptr, nullptr, nullptr, nullptr, cfg.horizon, cfg.auto_reset, cfg.obs_env_major});
         HIPCHK(hipGetLastError());
         return KS_OK;
     }
@@ -821,8 +825,8 @@ template <typename T> struct Ctx : CtxBase {
                            cfg.frame_skip, cfg.solver_iterations, lpw, cfg.contact_tap, (int)rays_in_step, (int)(USE_LDS && cfg.pair_memory));
         if (timed) { HIPCHK(hipEventRecord(ev1[ev_used], s)); ev_used++; }
         if (!rays_in_step) hipLaunchKernelGGL((k_rays<T>), dim3((N + RAY_ENVS - 1) / RAY_ENVS, NRAY), dim3(WAVE), 0, s, d_model, b, N, 0);
-        hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0, cfg.horizon, cfg.auto_reset, cfg.obs_env_major,
-                           (T*)obs, (T*)reward, done, (T*)info, (T*)final_obs);
+        hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0,
+                           ObsOut<T>{(T*)obs, (T*)reward, done, (T*)info, (T*)final_obs, cfg.horizon, cfg.auto_reset, cfg.obs_env_major});
         // (auto-reset: k_obs restarts finished envs from their stored initial state and returns the cached observation)
         HIPCHK(hipGetLastError());
         return KS_OK;
@@ -864,8 +868,8 @@ template <typename T> struct Ctx : CtxBase {
         const size_t N = cfg.n_envs;
         HIPCHK(hipMemcpyAsync(b.snap, snap, (size_t)SNAP_TOTAL * N * sizeof(T), hipMemcpyDefault, s));
         HIPCHK(hipMemcpyAsync(b.rays, rays, (size_t)NRAY * N * sizeof(T), hipMemcpyDefault, s));
-        hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, (int)N, 2, 0, 0, cfg.obs_env_major,
-                           (T*)obs, (T*)reward, done, (T*)info, (T*)nullptr);
+        hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, (int)N, 2,
+                           ObsOut<T>{(T*)obs, (T*)reward, done, (T*)info, nullptr, 0, 0, cfg.obs_env_major});
         HIPCHK(hipGetLastError());
         return KS_OK;
     }

@@ -346,6 +346,18 @@ template <typename T> KS_HD void action_to_ctrl(const T* T3, const T* act4, T* c
     }
 }
 
+// The termination test of build_obs alone (object centre at / above the 0.2 m target, ENV:631-687): the same operations
+// on the same inputs, so the same answer - callers that must know where the observation goes before they build it.
+template <typename T, typename C>
+KS_HD bool object_lifted(const Model<T>& m, C snap) {
+    T Ro[9], po[3], ow[3], t[3];
+    snap_body<T>(snap, 9, Ro, po);
+    mulRv(t, Ro, m.geom_pos[8]);
+    add3(ow, po, t);
+    const T target = T(0.2);
+    return (kabs(ow[2] - target) < T(0.005)) || (ow[2] >= target);
+}
+
 // Full local observation + reward from a snapshot and the 17 ray distances.
 // obs is written through `put(j, value)`.
 template <typename T, typename C, typename Put>
