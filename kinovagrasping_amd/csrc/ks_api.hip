@@ -180,6 +180,8 @@ struct SlotBound {
 constexpr int WG_RAY_TASKS = NRAY * (NGEOM - 1);                       // per env
 constexpr int WG_SNAP = 97;                                            // body poses of an env (96 floats), odd stride
 __host__ __device__ constexpr int wg_rays_words(int epw) { return epw * NRAY + 4 + epw * WG_RAY_TASKS + RAY_STACK * WG + epw * WG_SNAP; }
+// ... followed by what wg_obs adds: the final ray distances [epw][NRAY + 1] and an auto-reset's kinematics scratch [epw][SCR_CON + 1]
+__host__ __device__ constexpr int wg_obs_words(int epw) { return epw * (NRAY + 1) + epw * (SCR_CON + 1); }
 struct LdsSnap {
     KS_LDS const float* base;
     __device__ float operator()(int k) const { return base[k]; }
@@ -250,9 +252,19 @@ __device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>
     }
 }
 
+// Where a step's (or reset's) results go
+template <typename T> struct ObsOut {
+    T* obs; T* reward; uint8_t* done; T* info; T* final_obs;
+    int horizon, auto_reset, env_major;
+};
+__device__ void wg_obs(const Model<float>& m, const Buffers<float>& b, int N, int slot0, int epw, KS_LDS unsigned* w, const ObsOut<float>& o);
+
+// obs_in_step: the observation / reward / done / auto-reset of the workgroup's envs are produced here too (wg_obs), the
+// separate k_obs launch of a step is gone; needs rays_in_step (fp32 / LDS variant).
 template <typename T, bool USE_LDS>
 __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ models, Buffers<T> b, const T* __restrict__ action, int N,
-                                                   int frame_skip, int iters, int epw, int tap, int rays_in_step, int pair_memory) {
+                                                   int frame_skip, int iters, int epw, int tap, int rays_in_step, int pair_memory, int obs_in_step,
+                                                   ObsOut<T> out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KS_LDS T* lds = (KS_LDS T*)smem;
     const Model<T>* mp = models + b.wg_model[blockIdx.x];          // every env of this workgroup holds this object
@@ -356,6 +368,7 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
             __threadfence_block();
             __syncthreads();
             wg_rays(m, b, N, blockIdx.x * epw, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)));
+            if (obs_in_step) wg_obs(m, b, N, blockIdx.x * epw, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)), out);
         }
     }
 }
@@ -543,12 +556,6 @@ template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model
     if (live && g == 1) b.rays[(long)ray * N + env] = best;
 }
 
-// Where a step's (or reset's) results go
-template <typename T> struct ObsOut {
-    T* obs; T* reward; uint8_t* done; T* info; T* final_obs;
-    int horizon, auto_reset, env_major;
-};
-
 // One env's episode bookkeeping + observation.
 // mode 0: after a step (reward / done / time limit / auto-reset flagging); mode 1: after a reset
 // (observation of flagged envs only, flag cleared); mode 2: observation / reward / lifted flag of whatever snapshot and
@@ -618,6 +625,33 @@ __global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ model
     KS_UNROLL
     for (int i = 0; i < NRAY; i++) rays[i] = b.rays[(long)i * N + env];
     obs_epilogue(models[b.obj_id[env]], b, env, N, mode, o, snap, rays, Scratch<T, KS_LDS T*>{(KS_LDS T*)rlds + threadIdx.x, WAVE});
+}
+
+// The tail of the stepping kernel (fp32 / LDS variant, after wg_rays): thread e < epw of the workgroup finishes env e's step -
+// time limit, termination, reward, the 82-d observation, the restart of a finished episode - from the body poses wg_rays
+// left in LDS and the ray distances it just produced.  One thread per env, as in k_obs; what leaves the critical path is the
+// launch, its gap and the wait for the slowest workgroup before ANY env's observation could start.
+__device__ __noinline__ void wg_obs(const Model<float>& m, const Buffers<float>& b, int N, int slot0, int epw, KS_LDS unsigned* w, const ObsOut<float>& o) {
+    KS_LDS const unsigned* hit = w;
+    KS_LDS const float* snaps = (KS_LDS const float*)(w + epw * NRAY + 4 + epw * WG_RAY_TASKS + RAY_STACK * WG);
+    KS_LDS float* rscr = (KS_LDS float*)(w + wg_rays_words(epw) + epw * (NRAY + 1));
+    const int e = threadIdx.x;
+    if (e >= epw) return;
+    const int env = b.slot_env[slot0 + e];
+    if (env < 0) return;
+    float rays[NRAY];
+    KS_UNROLL
+    for (int r = 0; r < NRAY; r++) {
+        const float t = __int_as_float((int)hit[e * NRAY + r]);
+        rays[r] = t < Lim<float>::big ? t : -1.0f;
+    }
+    // body poses from LDS, the nine joint positions of the snapshot from where lane_env_step wrote them
+    struct Snap {
+        KS_LDS const float* poses; const float* jpos; long N;
+        __device__ float operator()(int k) const { return k < SNAP_JPOS ? poses[k - SNAP_BP] : jpos[(long)(k - SNAP_JPOS) * N]; }
+    };
+    const Snap snap{snaps + e * WG_SNAP, b.snap + (long)SNAP_JPOS * N + env, N};
+    obs_epilogue(m, b, env, N, 0, o, snap, rays, ScratchC<float, KS_LDS float*>{rscr + e * (SCR_CON + 1)});
 }
 
 struct CtxBase {
@@ -773,7 +807,7 @@ template <typename T> struct Ctx : CtxBase {
     int blocks() const { return (cfg.n_envs + WAVE - 1) / WAVE; }
     // envs per wave and dynamic LDS bytes of the stepping kernels
     int lpw = WAVE;
-    bool rays_in_step = false;
+    bool rays_in_step = false, obs_in_step = false;
     size_t step_lds = 0;
     int hull_words = 0;
     int plan_launch() {
@@ -790,6 +824,9 @@ template <typename T> struct Ctx : CtxBase {
         // are large enough for its list and stacks; KS_RAYS_IN_STEP=0 keeps the separate k_rays launch
         rays_in_step = USE_LDS && sizeof(T) == 4 && (size_t)wg_rays_words(lpw) <= (size_t)SCR_TOTAL * lpw &&
                        !(getenv("KS_RAYS_IN_STEP") && getenv("KS_RAYS_IN_STEP")[0] == '0');
+        // ... and then finish the step there as well (wg_obs: observation, reward, done, auto-reset); KS_OBS_IN_STEP=0 keeps k_obs
+        obs_in_step = rays_in_step && (size_t)(wg_rays_words(lpw) + wg_obs_words(lpw)) <= (size_t)SCR_TOTAL * lpw &&
+                      !(getenv("KS_OBS_IN_STEP") && getenv("KS_OBS_IN_STEP")[0] == '0');
         if (getenv("KS_DEBUG")) fprintf(stderr, "[ks] stepping kernel: %d envs per workgroup, LDS %zu B (tables %zu B, %zu B per env), limit %zu\n", lpw, step_lds, hull_bytes, per_env, lds_max);
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<T, USE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_substep<T, USE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
@@ -820,14 +857,15 @@ template <typename T> struct Ctx : CtxBase {
         if (!action) { error = "ks_step: action is NULL"; return KS_ERR_INVALID; }
         const int N = cfg.n_envs;
         const bool timed = ev_used < NEV;
+        const ObsOut<T> out{(T*)obs, (T*)reward, done, (T*)info, (T*)final_obs, cfg.horizon, cfg.auto_reset, cfg.obs_env_major};
         if (timed) HIPCHK(hipEventRecord(ev0[ev_used], s));
         hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3(n_wg), dim3(WG), step_lds, s, d_model, b, (const T*)action, N,
-                           cfg.frame_skip, cfg.solver_iterations, lpw, cfg.contact_tap, (int)rays_in_step, (int)(USE_LDS && cfg.pair_memory));
+                           cfg.frame_skip, cfg.solver_iterations, lpw, cfg.contact_tap, (int)rays_in_step, (int)(USE_LDS && cfg.pair_memory),
+                           (int)obs_in_step, out);
         if (timed) { HIPCHK(hipEventRecord(ev1[ev_used], s)); ev_used++; }
         if (!rays_in_step) hipLaunchKernelGGL((k_rays<T>), dim3((N + RAY_ENVS - 1) / RAY_ENVS, NRAY), dim3(WAVE), 0, s, d_model, b, N, 0);
-        hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0,
-                           ObsOut<T>{(T*)obs, (T*)reward, done, (T*)info, (T*)final_obs, cfg.horizon, cfg.auto_reset, cfg.obs_env_major});
-        // (auto-reset: k_obs restarts finished envs from their stored initial state and returns the cached observation)
+        if (!obs_in_step) hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0, out);
+        // (auto-reset: wg_obs / k_obs restarts finished envs from their stored initial state and returns the cached observation)
         HIPCHK(hipGetLastError());
         return KS_OK;
     }

@@ -378,3 +378,42 @@ def test_fourteen_shapes_three_poses_observations_track_the_oracle():
     assert all(r[7] == 0 for r in summary), summary
     assert sum(r[8] for r in summary) <= 0.01 * 14 * 12 * len(RAY_SLOTS)
     assert launched_total <= 14 * 12 // 2
+
+
+@pytest.mark.gpu
+def test_step_finished_inside_the_stepping_kernel_equals_the_separate_observation_launch(monkeypatch):
+    """ks_step's observation / reward / done / auto-reset are produced at the tail of the stepping kernel (wg_obs); with
+    KS_OBS_IN_STEP=0 a context uses the separate k_obs launch (what fp64 contexts and ks_reset use).  Both run the same
+    source (obs_epilogue), so an episode with lifts, the time limit and restarts must agree: flags and rewards exactly,
+    observations and states to the last bits (different inlining contexts may contract an fma differently)."""
+    from kinovagrasping_amd.sim import KinovaSim
+    n, horizon = 256, 12
+    q0, hq = scenarios.config2_states(n)
+    acts = torch.as_tensor(scenarios.config_actions(n, 30)).cuda()
+    # half of the envs start with the object above the lift target: done by `lifted` in the first step
+    q0 = q0.copy(); q0[11, ::2] = 0.25
+    monkeypatch.setenv("KS_OBS_IN_STEP", "0")
+    a = KinovaSim(n, "CubeS", auto_reset=True, horizon=horizon)
+    monkeypatch.delenv("KS_OBS_IN_STEP")
+    b = KinovaSim(n, "CubeS", auto_reset=True, horizon=horizon)
+    oa, ob = a.reset(torch.as_tensor(q0), torch.as_tensor(hq)), b.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+    assert torch.equal(oa, ob)
+    restarts = 0
+    for t in range(2 * horizon + 3):
+        ra, rb = a.step(acts[t]), b.step(acts[t])
+        torch.cuda.synchronize()
+        assert torch.equal(ra[2], rb[2]) and torch.equal(ra[1], rb[1]), t            # done, reward
+        assert torch.equal(ra[3], rb[3]), t                                           # info
+        tol = torch.full((82,), 1e-6, device="cuda"); tol[73:82] = 5e-5          # 73-81: ratios and 20th powers (SURVEY O2)
+        assert a.obs.shape == (n, 82)
+        close = lambda x, y: bool(((x - y).abs() <= tol + tol * y.abs()).all())
+        assert close(ra[0], rb[0]), t
+        d = ra[2].bool()
+        restarts += int(d.sum())
+        if d.any():
+            assert close(a.final_obs[d], b.final_obs[d]), t
+        sa, sb = a.get_state(), b.get_state()
+        for k in ("qpos", "qvel", "qacc_warmstart"):
+            torch.testing.assert_close(sa[k], sb[k], rtol=0, atol=0)
+    assert restarts >= 2 * n        # lifted envs restart every step, the others at the time limit
+    a.close(); b.close()
