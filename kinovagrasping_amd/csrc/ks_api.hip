@@ -82,16 +82,21 @@ template <typename T> __device__ __forceinline__ const Model<T>* stage_model(con
 // size of a PairRec in DEVICE code (LDS pointers are 4 bytes there; the host pass of this file sees 8)
 template <typename T> constexpr int pair_rec_bytes() { return sizeof(T) == 4 ? 96 : 144; }
 
-template <typename T> __device__ __forceinline__ Hulls<T> stage_hulls(const Model<T>& m, KS_LDS T* lds, int& used) {
-    Hulls<T> hu;
+// SHARED: `hu` is the workgroup's one descriptor in LDS, filled by thread 0 (every thread writing its own private copy
+// was 240 bytes of stack per lane, written through to memory at every launch: 16 of the 27 MB a launch wrote);
+// otherwise `hu` is the calling thread's own.
+template <typename T, bool SHARED> __device__ __forceinline__ void stage_hulls(const Model<T>& m, KS_LDS T* lds, int& used, Hulls<T>& hu) {
+    const bool writer = !SHARED || threadIdx.x == 0;
     int off = 0;
     for (int s = 0; s < 4; s++) {
         const int n = m.mesh_nvert_pad[s] * 4;
         const T* src = m.mesh_vert[s];
         for (int i = threadIdx.x; i < n; i += blockDim.x) lds[off + i] = src[i];
-        hu.vert[s] = lds + off;
-        hu.nvert[s] = m.mesh_nvert[s];
-        hu.nvert_pad[s] = m.mesh_nvert_pad[s];
+        if (writer) {
+            hu.vert[s] = lds + off;
+            hu.nvert[s] = m.mesh_nvert[s];
+            hu.nvert_pad[s] = m.mesh_nvert_pad[s];
+        }
         off += n;
     }
     // adjacency (uint16 chunk tables) behind the vertex tables; `used` stays in units of T
@@ -100,24 +105,26 @@ template <typename T> __device__ __forceinline__ Hulls<T> stage_hulls(const Mode
     for (int s = 0; s < 4; s++) {
         const int no = m.mesh_nvert[s] + 1, na = m.mesh_nchunk[s] * 4;
         for (int i = threadIdx.x; i < no; i += blockDim.x) ulds[uoff + i] = m.mesh_adj_off[s][i];
-        hu.adj_off[s] = ulds + uoff;
+        if (writer) hu.adj_off[s] = ulds + uoff;
         uoff += (no + 3) & ~3;                       // keep the chunk tables 8-byte aligned
         for (int i = threadIdx.x; i < na; i += blockDim.x) ulds[uoff + i] = m.mesh_adj[s][i];
-        hu.adj[s] = ulds + uoff;
+        if (writer) hu.adj[s] = ulds + uoff;
         uoff += na;
     }
     const int iwords = (uoff * (int)sizeof(unsigned short) + (int)sizeof(T) - 1) / (int)sizeof(T);
     used = off + ((iwords + 3) & ~3);
     // pair records behind the adjacency tables, one thread per pair
-    hulls_set_pairs(m, hu);
+    if (writer) {
+        hulls_set_pairs(m, hu);
+        hu.pair = (KS_LDS const PairRec<T>*)(lds + used);
+    }
+    if (SHARED) __syncthreads();
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(sizeof(PairRec<T>) == pair_rec_bytes<T>(), "device size of a pair record");
 #endif
-    hu.pair = (KS_LDS const PairRec<T>*)(lds + used);
-    if ((int)threadIdx.x < m.npair) fill_pair_rec(m, hu, threadIdx.x, *(PairRec<T>*)(hu.pair + threadIdx.x));
+    if ((int)threadIdx.x < m.npair) fill_pair_rec(m, hu, threadIdx.x, *(PairRec<T>*)((KS_LDS const PairRec<T>*)(lds + used) + threadIdx.x));
     used += NPAIR_MAX * pair_rec_bytes<T>() / (int)sizeof(T);
     __syncthreads();
-    return hu;
 }
 
 template <typename T> __device__ __forceinline__ void load_state(const Buffers<T>& b, int env, int N, LaneState<T>& st) {
@@ -262,9 +269,9 @@ __device__ void wg_obs(const Model<float>& m, const Buffers<float>& b, int N, in
 // obs_in_step: the observation / reward / done / auto-reset of the workgroup's envs are produced here too (wg_obs), the
 // separate k_obs launch of a step is gone; needs rays_in_step (fp32 / LDS variant).
 template <typename T, bool USE_LDS>
-__global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ models, Buffers<T> b, const T* __restrict__ action, int N,
-                                                   int frame_skip, int iters, int epw, int tap, int rays_in_step, int pair_memory, int obs_in_step,
-                                                   ObsOut<T> out) {
+__global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ models, Buffers<T> b, const Buffers<T>* __restrict__ bdev,
+                                                   const T* __restrict__ action, int N, int frame_skip, int iters, int epw, int tap, int rays_in_step,
+                                                   int pair_memory, int obs_in_step, const ObsOut<T>* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KS_LDS T* lds = (KS_LDS T*)smem;
     const Model<T>* mp = models + b.wg_model[blockIdx.x];          // every env of this workgroup holds this object
@@ -272,16 +279,12 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
     if constexpr (USE_LDS) { ml = stage_model(mp, lds); lds += model_words<T>(); }
     const Model<T>& m = *ml;
     int hull_words = 0;
-    const Hulls<T> hu_reg = stage_hulls(*mp, lds, hull_words);
-    const Hulls<T>* hup = &hu_reg;
-    if constexpr (USE_LDS) {
-        // the out-of-line stages reach the descriptor through a generic reference as well: keep it in LDS
-        static_assert(sizeof(Hulls<T>) <= HULLS_BYTES, "Hulls descriptor slot");
-        Hulls<T>* slot = (Hulls<T>*)(smem + (sizeof(Model<T>) + 15) / 16 * 16);
-        if (threadIdx.x == 0) *slot = hu_reg;
-        __syncthreads();
-        hup = slot;
-    }
+    // the out-of-line stages reach the descriptor through a generic reference: the workgroup's one copy in LDS (behind the model)
+    static_assert(sizeof(Hulls<T>) <= HULLS_BYTES, "Hulls descriptor slot");
+    Hulls<T> hu_own;
+    Hulls<T>* hup = &hu_own;
+    if constexpr (USE_LDS) hup = (Hulls<T>*)(smem + (sizeof(Model<T>) + 15) / 16 * 16);
+    stage_hulls<T, USE_LDS>(*mp, lds, hull_words, *hup);
     const Hulls<T>& hu = *hup;
     // epw envs per workgroup, SUBS lanes per env: the lanes of a team keep identical copies of the env state and
     // split the vertex scans / per-pair (collision) and per-contact (solver) loops; per-env dynamic data is shared in LDS
@@ -367,8 +370,10 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
             // every thread of the workgroup is here (inactive lanes included): snapshots written, env blocks dead
             __threadfence_block();
             __syncthreads();
-            wg_rays(m, b, N, blockIdx.x * epw, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)));
-            if (obs_in_step) wg_obs(m, b, N, blockIdx.x * epw, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)), out);
+            // (the out-of-line tails take the pointer table and the output record by reference: from device memory - a
+            // reference to the by-value kernel arguments made every lane copy them to its stack, 224 bytes written through per launch)
+            wg_rays(m, *bdev, N, blockIdx.x * epw, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)));
+            if (obs_in_step) wg_obs(m, *bdev, N, blockIdx.x * epw, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)), *out);
         }
     }
 }
@@ -382,16 +387,12 @@ __global__ __launch_bounds__(WG) void k_substep(const Model<T>* __restrict__ mod
     if constexpr (USE_LDS) { ml = stage_model(mp, lds); lds += model_words<T>(); }
     const Model<T>& m = *ml;
     int hull_words = 0;
-    const Hulls<T> hu_reg = stage_hulls(*mp, lds, hull_words);
-    const Hulls<T>* hup = &hu_reg;
-    if constexpr (USE_LDS) {
-        // the out-of-line stages reach the descriptor through a generic reference as well: keep it in LDS
-        static_assert(sizeof(Hulls<T>) <= HULLS_BYTES, "Hulls descriptor slot");
-        Hulls<T>* slot = (Hulls<T>*)(smem + (sizeof(Model<T>) + 15) / 16 * 16);
-        if (threadIdx.x == 0) *slot = hu_reg;
-        __syncthreads();
-        hup = slot;
-    }
+    // the out-of-line stages reach the descriptor through a generic reference: the workgroup's one copy in LDS (behind the model)
+    static_assert(sizeof(Hulls<T>) <= HULLS_BYTES, "Hulls descriptor slot");
+    Hulls<T> hu_own;
+    Hulls<T>* hup = &hu_own;
+    if constexpr (USE_LDS) hup = (Hulls<T>*)(smem + (sizeof(Model<T>) + 15) / 16 * 16);
+    stage_hulls<T, USE_LDS>(*mp, lds, hull_words, *hup);
     const Hulls<T>& hu = *hup;
     const int e = threadIdx.x / LANE_STRIDE;
     const Team<SUBS> team{(int)threadIdx.x % LANE_STRIDE};
@@ -684,6 +685,10 @@ struct CtxBase {
 template <typename T> struct Ctx : CtxBase {
     static constexpr bool USE_LDS = sizeof(T) == 4;
     Buffers<T> b{};
+    Buffers<T>* d_b = nullptr;            // the same pointer table in device memory (what the stepping kernels' out-of-line tails read)
+    ObsOut<T>* d_out = nullptr;           // ... and where ks_step's results go (re-sent only when a caller changes its buffers)
+    ObsOut<T> out_sent{};
+    bool out_valid = false;
     Model<T>* d_model = nullptr;          // [n_models] model table
     int n_models = 0, n_wg = 0;
     std::map<std::pair<size_t, uint64_t>, void*> shared;      // uploaded arrays by (bytes, content hash): the hand's meshes are
@@ -801,6 +806,9 @@ template <typename T> struct Ctx : CtxBase {
         hipLaunchKernelGGL(k_slots, dim3(1), dim3(SLOT_THREADS), 0, 0, b.obj_id, cfg.n_envs, n_models, lpw, n_wg, b.slot_env, b.wg_model);
         HIPCHK(hipGetLastError());
         HIPCHK(hipDeviceSynchronize());
+        if ((r = alloc(&d_b, (size_t)1))) return r;
+        if ((r = alloc(&d_out, (size_t)1))) return r;
+        HIPCHK(hipMemcpy(d_b, &b, sizeof b, hipMemcpyHostToDevice));
         model_loaded = true;
         return KS_OK;
     }
@@ -858,10 +866,18 @@ template <typename T> struct Ctx : CtxBase {
         const int N = cfg.n_envs;
         const bool timed = ev_used < NEV;
         const ObsOut<T> out{(T*)obs, (T*)reward, done, (T*)info, (T*)final_obs, cfg.horizon, cfg.auto_reset, cfg.obs_env_major};
+        const bool same = out.obs == out_sent.obs && out.reward == out_sent.reward && out.done == out_sent.done && out.info == out_sent.info &&
+                          out.final_obs == out_sent.final_obs && out.horizon == out_sent.horizon && out.auto_reset == out_sent.auto_reset &&
+                          out.env_major == out_sent.env_major;
+        if (obs_in_step && !(same && out_valid)) {
+            out_valid = true;
+            out_sent = out;
+            HIPCHK(hipMemcpyAsync(d_out, &out_sent, sizeof out, hipMemcpyHostToDevice, s));
+        }
         if (timed) HIPCHK(hipEventRecord(ev0[ev_used], s));
-        hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3(n_wg), dim3(WG), step_lds, s, d_model, b, (const T*)action, N,
+        hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3(n_wg), dim3(WG), step_lds, s, d_model, b, (const Buffers<T>*)d_b, (const T*)action, N,
                            cfg.frame_skip, cfg.solver_iterations, lpw, cfg.contact_tap, (int)rays_in_step, (int)(USE_LDS && cfg.pair_memory),
-                           (int)obs_in_step, out);
+                           (int)obs_in_step, (const ObsOut<T>*)d_out);
         if (timed) { HIPCHK(hipEventRecord(ev1[ev_used], s)); ev_used++; }
         if (!rays_in_step) hipLaunchKernelGGL((k_rays<T>), dim3((N + RAY_ENVS - 1) / RAY_ENVS, NRAY), dim3(WAVE), 0, s, d_model, b, N, 0);
         if (!obs_in_step) hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0, out);
