@@ -1376,8 +1376,21 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
         start = found + 1;
     }
     KS_TICK(23)
-    if (team.sub == 0) {
-        const T normal[3] = {0, 0, 1};
+    const T normal[3] = {0, 0, 1};
+    if constexpr (SUBS >= 4) {
+        // lane k stages contact k: every lane holds the four vertices, one instruction stream for all of them
+        T c[3] = {cv[0][0], cv[0][1], cv[0][2]};
+        KS_UNROLL
+        for (int q = 1; q < 4; q++)
+            if (team.sub == q) { c[0] = cv[q][0]; c[1] = cv[q][1]; c[2] = cv[q][2]; }
+        if (team.sub < nc) {
+            T d = cdist + dot3(c, ln), w[3];
+            mulRv(w, R2, c);
+            add3(w, w, p2);
+            w[2] -= T(0.5) * d;
+            stage_contact(scr, slot + team.sub, 0, body2, mu, d, w, normal);
+        }
+    } else {
         KS_UNROLL
         for (int k = 0; k < 4; k++) {
             if (k < nc) {
