@@ -1930,31 +1930,36 @@ KS_FN_SOLVER void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm,
     }
     KS_TICK(3)
 
-    // cost at x (replicated): Gauss part by rows, scalar rows on the lead lane, contacts by their owners
-    auto cost = [&](const T* x) -> T {
-        T d[NV], c = 0;
+    // Warm start: the cheaper of the previous substep's solution and the unconstrained one.  Both costs in ONE pass (Gauss part
+    // by rows, scalar rows on the lead lane, contacts by their owners): the rows of M and each contact's 3 x 15 basis are read
+    // once for the two candidates, not once each.
+    {
+        T x[2][NV], c[2] = {0, 0};
         KS_UNROLL
-        for (int j = 0; j < NV; j++) d[j] = x[j] - a0[j];
+        for (int j = 0; j < NV; j++) { x[0][j] = warm[j]; x[1][j] = a0[j]; }
         KS_UNROLL
         for (int rr = 0; rr < RPL; rr++) {
-            T md = 0;
+            T md = 0;                                   // candidate 1 is a0 itself: its Gauss term is zero
             KS_UNROLL
-            for (int j = 0; j < NV; j++) md += Mrow[rr][j] * d[j];
-            c += T(0.5) * pick(d, row[rr]) * md;
-        }
-        T cs = 0;
-        KS_UNROLL
-        for (int t = 0; t < 3; t++) {
-            T xx = tc0[t] * x[3 + 2 * t] + tc1[t] * x[4 + 2 * t] - r.eq_aref[t];
-            cs += T(0.5) * xx * xx * eqD[t];
+            for (int j = 0; j < NV; j++) md += Mrow[rr][j] * (x[0][j] - a0[j]);
+            c[0] += T(0.5) * (pick(x[0], row[rr]) - pick(a0, row[rr])) * md;
         }
         KS_UNROLL
-        for (int j = 0; j < 6; j++) {
-            const int dof = j < 3 ? j : 3 + 2 * (j - 3);
-            T xx = r.lim_sign[j] * x[dof] - r.lim_aref[j];
-            if (r.lim_sign[j] != 0 && xx < 0) cs += T(0.5) * xx * xx * limD[j];
+        for (int v = 0; v < 2; v++) {
+            T cs = 0;
+            KS_UNROLL
+            for (int t = 0; t < 3; t++) {
+                T xx = tc0[t] * x[v][3 + 2 * t] + tc1[t] * x[v][4 + 2 * t] - r.eq_aref[t];
+                cs += T(0.5) * xx * xx * eqD[t];
+            }
+            KS_UNROLL
+            for (int j = 0; j < 6; j++) {
+                const int dof = j < 3 ? j : 3 + 2 * (j - 3);
+                T xx = r.lim_sign[j] * x[v][dof] - r.lim_aref[j];
+                if (r.lim_sign[j] != 0 && xx < 0) cs += T(0.5) * xx * xx * limD[j];
+            }
+            c[v] += lead * cs;
         }
-        c += lead * cs;
         KS_UNROLL
         for (int q = 0; q < CPL; q++) {
             const int ci = team.sub + q * SUBS;
@@ -1962,34 +1967,33 @@ KS_FN_SOLVER void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm,
                 const int o = SCR_CON + ci * CON_STRIDE;
                 const T R = scr(o + 9);
                 if (R >= 0) {
-                    T B[3][NV], dist, mu, xb[3];
+                    T B[3][NV], dist, mu;
                     contact_basis_cached<T>(scr, ci, B, dist, mu);
-                    KS_UNROLL
-                    for (int b = 0; b < 3; b++) {
-                        T v = 0;
-                        KS_UNROLL
-                        for (int j = 0; j < NV; j++) v += B[b][j] * x[j];
-                        xb[b] = v;
-                    }
                     const T D = T(1) / R;
+                    const T ar[4] = {scr(o + 10), scr(o + 11), scr(o + 12), scr(o + 13)};
                     KS_UNROLL
-                    for (int kk = 0; kk < 4; kk++) {
-                        T xx = xb[0] + ((kk & 1) ? -mu : mu) * xb[1 + (kk >> 1)] - scr(o + 10 + kk);
-                        if (xx < 0) c += T(0.5) * xx * xx * D;
+                    for (int v = 0; v < 2; v++) {
+                        T xb3[3];
+                        KS_UNROLL
+                        for (int bb = 0; bb < 3; bb++) {
+                            T s_ = 0;
+                            KS_UNROLL
+                            for (int j = 0; j < NV; j++) s_ += B[bb][j] * x[v][j];
+                            xb3[bb] = s_;
+                        }
+                        KS_UNROLL
+                        for (int kk = 0; kk < 4; kk++) {
+                            T xx = xb3[0] + ((kk & 1) ? -mu : mu) * xb3[1 + (kk >> 1)] - ar[kk];
+                            if (xx < 0) c[v] += T(0.5) * xx * xx * D;
+                        }
                     }
                 }
             }
         }
-        return team.sum(c);
-    };
-    {
-        T w[NV];
-        KS_UNROLL
-        for (int j = 0; j < NV; j++) w[j] = warm[j];
-        const T cw = cost(w), cs = cost(a0);
+        const T cw = team.sum(c[0]), cs = team.sum(c[1]);
         const bool use_warm = cw < cs;
         KS_UNROLL
-        for (int j = 0; j < NV; j++) a[j] = use_warm ? w[j] : a0[j];
+        for (int j = 0; j < NV; j++) a[j] = use_warm ? x[0][j] : a0[j];
     }
     KS_TICK(13)
     T xb[CPL][3], pb[CPL][3];
