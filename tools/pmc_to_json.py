@@ -27,7 +27,7 @@ out = {
     "hbm_bytes_per_launch": (per.get("FETCH_SIZE", 0) + per.get("WRITE_SIZE", 0)) * kib,
     "note": "fetch = per-workgroup staging of the hull / model tables (256 workgroups x ~50 KB, L2 / MALL hits count) + env state + "
             "pair memory + the in-step rays' mesh nodes; write = state + snapshot + rays + pair memory (4.9 MB) + write-through of the "
-            "private-memory (stack) stores of the out-of-line stages.  The counters sit on the L2's memory side: Infinity-Cache hits "
+            "private-memory (stack) stores of the out-of-line stages (~4 MB: the pair memory words and an out-of-line fallback's result).  The counters sit on the L2's memory side: Infinity-Cache hits "
             "are included, so this is an upper bound on HBM traffic.",
 }
 if "SQ_THREAD_CYCLES_VALU" in per and "SQ_ACTIVE_INST_VALU" in per:
