@@ -2,9 +2,9 @@
 the same seeded inputs.  Run with `-m gpu` on an MI355X.
 
 Tolerances (fp32 product vs fp64 oracle), stated once:
-  * one mj_step from identical states (teacher forced): |dqpos|_inf <= 2e-6 for >= 95% of the states
-    and median <= 2e-7; the tail is the single-point contact *position* on parallel features
-    (DESIGN.md "known limits"), for which the bound is 5e-3.
+  * one mj_step from identical states (teacher forced): |dqpos|_inf <= 5e-7 for >= 95% of the states
+    and median <= 1e-7; the tail (<= 3% of the states above 1e-5) is the single-point contact *position* on
+    parallel features (DESIGN.md "known limits"), for which the bound is 3e-3.
   * free-running config-1 episode: relative qpos error <= 1e-4 (north_star) for at least the first
     200 substeps; afterwards contact make/break makes trajectories chaotic (SURVEY hard part 2) and
     the test only reports the first substep that exceeds the tolerance.
@@ -85,10 +85,14 @@ def test_one_step_fp32_matches_oracle(cube):
     eq, ev, ncon, onc = run_teacher_forced(32, cube, rec, hq)
     print(f"one-step |dqpos|: median {np.median(eq):.2e} p95 {np.percentile(eq, 95):.2e} max {eq.max():.2e};"
           f" contact-count mismatches {int((ncon != onc).sum())}/{len(onc)}")
-    assert np.median(eq) <= 2e-7
-    assert np.percentile(eq, 95) <= 2e-6
-    assert eq.max() <= 5e-3
-    assert (ncon != onc).mean() <= 0.02
+    tail = eq > 1e-5
+    print(f" states above 1e-5: {int(tail.sum())}/{len(eq)}, p99 {np.percentile(eq, 99):.2e}")
+    assert np.median(eq) <= 1e-7
+    assert np.percentile(eq, 95) <= 5e-7
+    # the tail: single-point contact POSITION on parallel features (DESIGN.md "known limits" (i)) - a handful of states, bounded
+    assert tail.mean() <= 0.03
+    assert eq.max() <= 3e-3
+    assert (ncon != onc).sum() <= 1
 
 
 def test_config1_episode_free_running(cube):
@@ -141,8 +145,9 @@ def test_batch_config2_first_steps(cube):
         qo = np.stack([orc[i].view("qpos").copy() for i in range(n)], 1)
         rel = np.abs(qg - qo).max(0) / np.maximum(1e-3, np.abs(qo).max(0))
         worst = max(worst, np.median(rel))
-        assert np.median(rel) < 1e-5, (t, np.median(rel))
-        assert (rel < 1e-4).mean() > 0.9, (t, (rel < 1e-4).mean())
+        print(f" t={t}: median {np.median(rel):.2e}, share below 1e-4: {(rel < 1e-4).mean():.3f}, max {rel.max():.2e}")
+        assert np.median(rel) < 1e-6, (t, np.median(rel))
+        assert (rel < 1e-4).mean() > 0.97 and rel.max() < 5e-3, (t, (rel < 1e-4).mean(), rel.max())   # tail: as in the one-step test
     print("config2 x128: worst median relative qpos error over 3 env-steps", worst)
     sim.close()
 
