@@ -72,6 +72,15 @@ int kr_sample_windows(int32_t batch, int32_t horizon, int32_t n_steps, const int
                       const float *ep_not_done, float *state, float *action, float *next_state, float *reward, float *not_done,
                       float *weight, void *stream);
 
+/* The same batch with the uniforms drawn in the kernel: Philox4x32-10 keyed by `seed`, counter (draw[0], episode b | row) -
+ * `draw` is a device counter that is constant while the kernel runs and differs from call to call (the learner's update
+ * count).  No host-side generator, so a captured graph needs no generator-state launches.  next_ends (optional) [2 B W, 82]:
+ * next_state[:, 0] followed by next_state[:, n_steps - 1], the rows the target networks evaluate (DDPGfD.py:256-275). */
+int kr_sample_windows_draw(int32_t batch, int32_t horizon, int32_t n_steps, const int64_t *count, const int64_t *head, int32_t capacity,
+                           const int64_t *ep_len, uint64_t seed, const int64_t *draw, const float *ep_state, const float *ep_next,
+                           const float *ep_action, const float *ep_reward, const float *ep_not_done, float *state, float *action,
+                           float *next_state, float *reward, float *not_done, float *weight, float *next_ends, void *stream);
+
 /* ---- learner glue (DDPGfD.train_batch, DDPGfD.py:219-367): the elementwise steps between the GEMMs, one launch each
  *
  *   kr_critic_grad   targets + dLoss/dQ of the critic loss L1 + 0.5 LN with masked row means (DDPGfD.py:256-330):

@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256) void k_advance_ring(int n, int capacity, const
 __global__ __launch_bounds__(WAVE) void k_sample_windows(int B, int H, int n_steps, const int64_t* __restrict__ count,
                                                          const int64_t* __restrict__ head, int capacity,
                                                          const int64_t* __restrict__ ep_len, const float* __restrict__ u_ep,
-                                                         const float* __restrict__ u_start, const float* __restrict__ ep_state,
+                                                         const float* __restrict__ u_start, unsigned long long seed,
+                                                         const int64_t* __restrict__ draw, float* __restrict__ next_ends,
+                                                         const float* __restrict__ ep_state,
                                                          const float* __restrict__ ep_next, const float* __restrict__ ep_action,
                                                          const float* __restrict__ ep_reward, const float* __restrict__ ep_not_done,
                                                          float* __restrict__ state, float* __restrict__ action, float* __restrict__ next_state,
@@ -156,13 +158,25 @@ __global__ __launch_bounds__(WAVE) void k_sample_windows(int B, int H, int n_ste
     const bool none = cnt < 2;
     long hi = cnt - 1;
     hi = hi > 1 ? hi : 1;
-    long k = (long)(u_ep[b] * (float)hi);
+    // the uniforms: the caller's, or (u_ep == nullptr) Philox4x32-10 keyed by the seed at counter (draw[0], b | row, tag) -
+    // `draw` is a device counter that does not change while this kernel runs (the learner's update count)
+    float ue, us;
+    if (u_ep != nullptr) { ue = u_ep[b]; us = u_start[(long)b * W + w]; }
+    else {
+        const unsigned long long d = (unsigned long long)draw[0];
+        uint32_t r4[4];
+        krsel::philox4x32((uint32_t)b, (uint32_t)d, (uint32_t)(d >> 32), 0x5a4du, (uint32_t)seed, (uint32_t)(seed >> 32), r4);
+        ue = (float)(r4[0] >> 8) * (1.0f / 16777216.0f);
+        krsel::philox4x32((uint32_t)r, (uint32_t)d, (uint32_t)(d >> 32), 0x5a4eu, (uint32_t)seed, (uint32_t)(seed >> 32), r4);
+        us = (float)(r4[0] >> 8) * (1.0f / 16777216.0f);
+    }
+    long k = (long)(ue * (float)hi);
     k = k < hi - 1 ? k : hi - 1;
     long ep = (head[0] - cnt + k) % capacity;
     ep = ep < 0 ? ep + capacity : ep;
     long ceiling = ep_len[ep] - n_steps;
     ceiling = ceiling > 1 ? ceiling : 1;
-    long start = (long)(u_start[(long)b * W + w] * (float)ceiling);
+    long start = (long)(us * (float)ceiling);
     start = start < H - n_steps ? start : H - n_steps;
     if (w == ceiling - 1) start = ceiling;     // the final window of the episode (utils.py:283-301)
     start = start < H - n_steps ? start : H - n_steps;
@@ -170,6 +184,13 @@ __global__ __launch_bounds__(WAVE) void k_sample_windows(int B, int H, int n_ste
     for (int k = lane; k < n_steps * S; k += WAVE) {
         state[dst * S + k] = ep_state[src * S + k];
         next_state[dst * S + k] = ep_next[src * S + k];
+    }
+    // the rows the target networks evaluate (DDPGfD.py:256-275: next_state[:, 0] and next_state[:, -1]) as one [2 B W, 82] block
+    if (next_ends != nullptr) {
+        for (int k = lane; k < S; k += WAVE) {
+            next_ends[(long)r * S + k] = ep_next[src * S + k];
+            next_ends[((long)B * W + r) * S + k] = ep_next[(src + n_steps - 1) * S + k];
+        }
     }
     for (int k = lane; k < n_steps * A; k += WAVE) action[dst * A + k] = ep_action[src * A + k];
     if (lane < n_steps) {
@@ -328,8 +349,21 @@ int kr_sample_windows(int32_t batch, int32_t horizon, int32_t n_steps, const int
         !ep_action || !ep_reward || !ep_not_done || !state || !action || !next_state || !reward || !not_done || !weight)
         return KS_ERR_INVALID;
     hipLaunchKernelGGL(k_sample_windows, dim3(batch * (horizon - n_steps)), dim3(WAVE), 0, (hipStream_t)stream, batch, horizon, n_steps, count,
-                       head, capacity, ep_len, u_ep, u_start, ep_state, ep_next, ep_action, ep_reward, ep_not_done, state, action, next_state, reward, not_done,
-                       weight);
+                       head, capacity, ep_len, u_ep, u_start, 0ull, (const int64_t*)nullptr, (float*)nullptr, ep_state, ep_next, ep_action, ep_reward,
+                       ep_not_done, state, action, next_state, reward, not_done, weight);
+    return launched();
+}
+
+int kr_sample_windows_draw(int32_t batch, int32_t horizon, int32_t n_steps, const int64_t* count, const int64_t* head, int32_t capacity,
+                           const int64_t* ep_len, uint64_t seed, const int64_t* draw, const float* ep_state, const float* ep_next,
+                           const float* ep_action, const float* ep_reward, const float* ep_not_done, float* state, float* action, float* next_state,
+                           float* reward, float* not_done, float* weight, float* next_ends, void* stream) {
+    if (batch <= 0 || horizon <= n_steps || n_steps <= 0 || n_steps > WAVE || capacity <= 0 || !count || !head || !ep_len || !draw || !ep_state ||
+        !ep_next || !ep_action || !ep_reward || !ep_not_done || !state || !action || !next_state || !reward || !not_done || !weight)
+        return KS_ERR_INVALID;
+    hipLaunchKernelGGL(k_sample_windows, dim3(batch * (horizon - n_steps)), dim3(WAVE), 0, (hipStream_t)stream, batch, horizon, n_steps, count,
+                       head, capacity, ep_len, (const float*)nullptr, (const float*)nullptr, (unsigned long long)seed, draw, next_ends, ep_state, ep_next,
+                       ep_action, ep_reward, ep_not_done, state, action, next_state, reward, not_done, weight);
     return launched();
 }
 

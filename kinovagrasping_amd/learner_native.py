@@ -184,7 +184,7 @@ class NativeDDPGfDUpdate:
 
     # -- the three phases ---------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def phase_critic(self, state, action, next_state, reward, weight=None):
+    def phase_critic(self, state, action, next_state, reward, weight=None, next_ends=None):
         """targets, critic forward, loss gradient, critic weight gradients -> self.critic.grad"""
         pol, P = self.p, _sim._ptr
         R = reward.shape[0]
@@ -196,7 +196,8 @@ class NativeDDPGfDUpdate:
         self._chk(self.lib.kr_update_prologue(R, pol.n, P(weight), P(self.wsum), P(self.dq_actor), P(self.it), P(self.it_head),
                                               int(self.pipelined), self._st()), "kr_update_prologue")
         # both target evaluations (1-step: next_state[:, 0], n-step: next_state[:, -1]) in one pass of the target nets
-        nx = torch.cat([next_state[:, 0], next_state[:, -1]], 0)
+        # (next_ends: the sampler's own [2R, S] block of exactly these rows, kr_sample_windows_draw)
+        nx = torch.cat([next_state[:, 0], next_state[:, -1]], 0) if next_ends is None else next_ends
         if self.fused_targets:
             # forward-only networks: one fused fp32-MFMA launch each (mlp.mlp3_forward) instead of 3 GEMMs + glue
             ta = _mlp.mlp3_forward(list(zip(self.actor_t.W, self.actor_t.b)), nx, act=_mlp.ACT_SIGMOID, scale=pol.max_action, shadow=self.shadow)

@@ -57,18 +57,20 @@ class GraphedTrainer:
         from .learner_native import NativeDDPGfDUpdate
         self.native = NativeDDPGfDUpdate(policy)
         self.native.pipelined = True
+        self.sample_seed = int(torch.initial_seed())          # the window sampler's Philox key
 
     # -- learner phases on the static batch -------------------------------------------------------------
     def _sample(self):
-        self.batch = self.replay.sample_batch_nstep(self.batch_episodes)
+        # (uniforms drawn in the sampling kernel, keyed by the update count: no generator-state launches in the graph)
+        self.batch = self.replay.sample_batch_nstep(self.batch_episodes, draw=self.native.it if self.replay.native else None, seed=self.sample_seed)
 
     def _head(self):
         self.native.phase_head()
         self._sample()
 
     def _phase1(self):
-        st, ac, ns, rw, nd, w = self.batch
-        self.loss_c = self.native.phase_critic(st, ac, ns, rw, w)
+        st, ac, ns, rw, nd, w = self.batch[:6]
+        self.loss_c = self.native.phase_critic(st, ac, ns, rw, w, next_ends=self.batch[6] if len(self.batch) > 6 else None)
 
     def _phase2(self):
         self.native.phase_actor(self.batch[0], self.batch[5])     # (its actor Adam step runs in the next update's head: native.pipelined)

@@ -247,18 +247,29 @@ class DeviceEpisodeReplay:
                     "kr_advance_ring")
         return self._total[0]
 
-    def sample_batch_nstep(self, batch_size, generator=None, uniforms=None):
+    def sample_batch_nstep(self, batch_size, generator=None, uniforms=None, draw=None, seed=0):
         """Fixed-shape batch: batch_size episodes x (horizon - n) window rows, padding rows have weight 0.
         Returns state [R,n,S], action [R,n,A], next_state [R,n,S], reward [R,n], not_done [R,n], weight [R].
-        `uniforms` (optional, tests): the batch_size + batch_size*W numbers in [0,1) to use instead of torch.rand."""
+        `uniforms` (optional, tests): the batch_size + batch_size*W numbers in [0,1) to use instead of torch.rand.
+        `draw` (native path): a device int64 counter that differs from call to call (the learner's update count) - the
+        uniforms are then drawn inside the kernel (Philox keyed by `seed`; no torch generator, hence none of its state
+        launches in a captured graph) and a 7th tensor is returned: next_state[:, 0] and next_state[:, -1] stacked
+        [2R, S], the rows the target networks evaluate."""
         n, W = self.n_steps, self.horizon - self.n_steps
         if self.native:
-            u = torch.rand(batch_size * (W + 1), device=self.device, generator=generator) if uniforms is None else uniforms.contiguous()
             R, dev = batch_size * W, self.device
             S, A = self.ep_state.shape[2], self.ep_action.shape[2]
             out = (torch.empty(R, n, S, device=dev), torch.empty(R, n, A, device=dev), torch.empty(R, n, S, device=dev),
                    torch.empty(R, n, device=dev), torch.empty(R, n, device=dev), torch.empty(R, device=dev))
             P = self._ptr
+            if draw is not None and uniforms is None:
+                ends = torch.empty(2 * R, S, device=dev)
+                self._check(self._lib.kr_sample_windows_draw(batch_size, self.horizon, n, P(self._count), P(self._head), self.capacity, P(self.ep_len),
+                                                             int(seed) & (2 ** 64 - 1), P(draw), P(self.ep_state), P(self.ep_next), P(self.ep_action),
+                                                             P(self.ep_reward), P(self.ep_not_done), P(out[0]), P(out[1]), P(out[2]), P(out[3]),
+                                                             P(out[4]), P(out[5]), P(ends), self._stream()), "kr_sample_windows_draw")
+                return out + (ends,)
+            u = torch.rand(batch_size * (W + 1), device=self.device, generator=generator) if uniforms is None else uniforms.contiguous()
             self._check(self._lib.kr_sample_windows(batch_size, self.horizon, n, P(self._count), P(self._head), self.capacity, P(self.ep_len), P(u),
                                                     P(u[batch_size:]),
                                                     P(self.ep_state), P(self.ep_next), P(self.ep_action), P(self.ep_reward),

@@ -25,7 +25,7 @@ EXPORTS = ["ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_
            "ks_get_state", "ks_set_state", "ks_set_env_params", "ks_substep", "ks_obs_from_snapshot", "ks_kernel_time", "ks_version"]
 # include/kinova_rollout.h
 ROLLOUT_EXPORTS = ["kr_select_action", "kr_store_transition", "kr_rank_episodes", "kr_commit_episodes", "kr_advance_ring",
-                   "kr_sample_windows", "kr_critic_grad", "kr_update_prologue", "kr_relu_backward", "kr_sigmoid_scale_backward", "kr_adam_step", "kr_soft_update",
+                   "kr_sample_windows", "kr_sample_windows_draw", "kr_critic_grad", "kr_update_prologue", "kr_relu_backward", "kr_sigmoid_scale_backward", "kr_adam_step", "kr_soft_update",
                    "kr_mlp3_forward", "kr_mlp3_forward_shadow", "kr_mlp3_backward_shadow", "kr_weight_grad_shadow",
                    "kr_actor_select"]
 
@@ -67,6 +67,7 @@ def load_library(path: Path | None = None):
     L.kr_commit_episodes.argtypes = [i32, i32, i32] + [vp] * 16
     L.kr_advance_ring.argtypes = [i32, i32] + [vp] * 6
     L.kr_sample_windows.argtypes = [i32, i32, i32, vp, vp, i32] + [vp] * 15
+    L.kr_sample_windows_draw.argtypes = [i32, i32, i32, vp, vp, i32, vp, C.c_uint64, vp] + [vp] * 13
     i64 = C.c_int64
     L.kr_critic_grad.argtypes = [i32, i32] + [vp] * 6 + [f32, vp, vp, vp]
     L.kr_update_prologue.argtypes = [i32, i32, vp, vp, vp, vp, vp, i32, vp]

@@ -116,3 +116,64 @@ def test_capture_warmup_does_not_train():
     assert all(torch.isfinite(v).all() for v in policy._flat_params.values())
     assert (policy._flat_params["actor"] - before["actor"]).abs().max().item() > 0
     sim.close()
+
+
+def _philox4x32(c, k):
+    """Philox4x32-10 on numpy uint32 arrays: counter c [..., 4], key k [2] -> [..., 4] (Salmon et al. 2011)"""
+    c = [c[..., i].astype(np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(k[0]), np.uint64(k[1])
+    M0, M1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c = [(hi1 ^ c[1] ^ k0) & mask, lo1, (hi0 ^ c[3] ^ k1) & mask, lo0]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & mask, (k1 + np.uint64(0xBB67AE85)) & mask
+    return np.stack(c, -1).astype(np.uint32)
+
+
+@pytest.mark.gpu
+def test_window_sampler_with_in_kernel_uniforms_equals_the_sampler_fed_the_same_uniforms():
+    """kr_sample_windows_draw draws its uniforms in the kernel (Philox4x32-10 keyed by the seed at counter (draw, index, tag));
+    the same numbers computed on the host and handed to kr_sample_windows must select the same windows, and the extra
+    [2R, S] block is next_state[:, 0] / next_state[:, -1].  Two calls with different `draw` differ, the same `draw` repeats."""
+    from kinovagrasping_amd.replay import DeviceEpisodeReplay
+    dev = torch.device("cuda", 0)
+    B, H, n, S = 16, 30, 5, 82
+    W = H - n
+    rb = DeviceEpisodeReplay(8, capacity=40, horizon=H, device=dev)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    K = 23
+    rb.ep_state[:K] = torch.rand(K, H, S, generator=g).to(dev)
+    rb.ep_next[:K] = torch.rand(K, H, S, generator=g).to(dev)
+    rb.ep_action[:K] = torch.rand(K, H, 4, generator=g).to(dev)
+    rb.ep_reward[:K] = torch.rand(K, H, generator=g).to(dev)
+    rb.ep_not_done[:K] = 1.0
+    rb.ep_len[:K] = torch.randint(7, H + 1, (K,), generator=g).to(dev)
+    rb._count.fill_(K); rb._head.fill_(K)
+    seed, draw_v = 0x1234567890ABCDEF, 77
+    draw = torch.tensor([draw_v], dtype=torch.long, device=dev)
+    out = rb.sample_batch_nstep(B, draw=draw, seed=seed)
+    assert len(out) == 7
+    key = np.array([seed & 0xFFFFFFFF, seed >> 32], dtype=np.uint64)
+
+    def uniforms(idx, tag):
+        c = np.stack([idx.astype(np.uint32), np.full_like(idx, draw_v & 0xFFFFFFFF, dtype=np.uint32),
+                      np.full_like(idx, draw_v >> 32, dtype=np.uint32), np.full_like(idx, tag, dtype=np.uint32)], -1)
+        return (_philox4x32(c, key)[..., 0] >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+    u = np.concatenate([uniforms(np.arange(B), 0x5a4d), uniforms(np.arange(B * W), 0x5a4e)])
+    ref = rb.sample_batch_nstep(B, uniforms=torch.as_tensor(u).to(dev))
+    for a, b in zip(out[:6], ref):
+        assert torch.equal(a, b)
+    assert out[5].sum() > 0.5 * B * W * 0                                     # (weights exist; padding rows depend on the lengths)
+    assert torch.equal(out[6][:B * W], out[2][:, 0]) and torch.equal(out[6][B * W:], out[2][:, -1])
+    again = rb.sample_batch_nstep(B, draw=draw, seed=seed)
+    assert all(torch.equal(a, b) for a, b in zip(out, again))
+    other = rb.sample_batch_nstep(B, draw=draw + 1, seed=seed)
+    assert not torch.equal(out[0], other[0])
+    # the in-kernel uniforms are uniform: episode picks cover the ring's sampleable range
+    eps = set()
+    for d in range(40):
+        o = rb.sample_batch_nstep(B, draw=draw + 2 + d, seed=seed)
+        eps |= {int(x) for x in (o[0][::W, 0, 0].unsqueeze(1) == rb.ep_state[:K, :, 0].reshape(1, -1)).float().argmax(1) // H}
+    assert len(eps) >= K - 3 and (K - 1) not in eps                            # the newest episode is never sampled
