@@ -387,7 +387,10 @@ def main():
             "steady_state": steady,
             "nonfinite_envs": bad,
             "rccl": ({"ranks": world, "backend": os.environ.get("KS_DIST_BACKEND", "nccl"), "NCCL_ALGO": os.environ.get("NCCL_ALGO", "default"),
-                      "allreduces_per_update": 2, "bytes_per_allreduce": int(policy._flat_params["critic"].numel() * 4)}
+                      "allreduces_per_update": 2, "bytes_per_allreduce": int(policy._flat_params["critic"].numel() * 4),
+                      "exchange": getattr(trainer, "exchange_note", None),
+                      "exchange_failed_call": (trainer.native.exchange.failed_epoch() if getattr(trainer, "native", None) is not None
+                                               and trainer.native.exchange is not None else None)}
                      if world > 1 and args.mode == "ddpg" else None),
             "replica_weight_checksum_spread": replica_spread,
             "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 4),

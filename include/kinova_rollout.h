@@ -157,6 +157,28 @@ int kr_actor_select(int32_t n, int32_t h1, int32_t h2, const float *obs, const f
                     const float *noise, uint64_t seed, int64_t *rng_state, float sigma, float max_action, int32_t skip_steps,
                     float *actor_out, float *action, float *action_t, uint8_t *lifting, void *stream);
 
+/* ---- the learner's one exchange step (gradient mean over the env-shard ranks; the reference is single-process,
+ * its multi-GPU form is DDPGfD.train_batch on every rank + an all-reduce of the gradients, DDPGfD.py:330-356).
+ * An LDS-free all-reduce over peer-mapped device memory (csrc/ks_xchg.hip): it runs beside ks_step's stepping kernel, which
+ * holds every CU's LDS; a library (RCCL) collective would wait for it.  One process per GPU:
+ *   kr_xchg_create   allocates this rank's exchange block for buffers of up to max_count floats and returns its
+ *                    KR_XCHG_HANDLE_BYTES-byte inter-process handle (hipIpcGetMemHandle);
+ *   kr_xchg_connect  takes the handles of ALL ranks (world x KR_XCHG_HANDLE_BYTES, rank order; gathered by the caller, e.g.
+ *                    torch.distributed.all_gather_object) and maps the peers' blocks;
+ *   kr_xchg_allreduce_mean  grad[i] <- mean over ranks of grad[i], in place, asynchronous on `stream`; every rank must make
+ *                    the same sequence of calls (same counts).  The sum runs in rank order on every rank: bitwise identical
+ *                    results everywhere.  grad must be 16-byte aligned;
+ *   kr_xchg_status   failed_epoch = 0, or the number of the first call in which a peer did not arrive within ~4 s (the call
+ *                    then leaves grad unreduced instead of hanging the GPU). */
+#define KR_XCHG_MAX_RANKS 8
+#define KR_XCHG_HANDLE_BYTES 64
+typedef struct kr_xchg kr_xchg;
+int kr_xchg_create(kr_xchg **out, int32_t world, int32_t rank, int64_t max_count, uint8_t *handle_out);
+int kr_xchg_connect(kr_xchg *x, const uint8_t *handles);
+int kr_xchg_allreduce_mean(kr_xchg *x, float *grad, int64_t count, void *stream);
+int kr_xchg_status(kr_xchg *x, uint32_t *failed_epoch);
+void kr_xchg_destroy(kr_xchg *x);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libkinova_sim.so"
-SOURCES = ["ks_api.hip", "ks_rollout.hip", "ks_mlp.hip"]
+SOURCES = ["ks_api.hip", "ks_rollout.hip", "ks_mlp.hip", "ks_xchg.hip"]
 HEADERS = ["ks_math.h", "ks_model.h", "ks_model_host.h", "ks_core.h", "ks_obs.h", "ks_env.h", "../../include/kinova_sim.h", "../../include/kinova_rollout.h"]
 
 

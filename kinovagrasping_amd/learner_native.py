@@ -64,6 +64,7 @@ class NativeDDPGfDUpdate:
         # k + 1.  `it_head` is k while that step is pending and 0 otherwise, so the head is a no-op when nothing is pending
         # (before the first update, or after finish_pending() has applied it eagerly, e.g. ahead of a checkpoint).
         self.it_head = torch.zeros(1, dtype=torch.long, device=policy.device)
+        self.exchange = None             # exchange.PeerExchange when the ranks can map each other's memory (pipeline.GraphedTrainer)
         self.pipelined = False        # set by pipeline.GraphedTrainer: the body marks its actor step pending for the next head
         policy._native = self                                                  # DDPGfD.save / load keep the Adam state in sync
         self.import_optimizer_state()
@@ -322,6 +323,9 @@ class NativeDDPGfDUpdate:
         if world == 1:
             return
         g = getattr(self, net).grad
+        if self.exchange is not None:
+            self.exchange.allreduce_mean(g)        # LDS-free, over peer-mapped memory: runs beside the stepping kernel (exchange.py)
+            return
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.p.process_group)
         g.div_(world)
 

@@ -57,6 +57,22 @@ class GraphedTrainer:
         from .learner_native import NativeDDPGfDUpdate
         self.native = NativeDDPGfDUpdate(policy)
         self.native.pipelined = True
+        # the gradient exchange between the ranks: an LDS-free all-reduce over peer-mapped memory where the ranks can map each
+        # other's buffers (one process per GPU on a node) - it runs beside the stepping kernel, which a library collective
+        # cannot (its kernels need LDS).  Self-tested against the process group at start-up; KS_P2P=0 keeps the library path.
+        self.exchange_note = "none (single rank)"
+        if self.distributed:
+            import os
+            import torch.distributed as dist
+            backend = dist.get_backend(policy.process_group)
+            want = os.environ.get("KS_P2P", "1" if backend == "nccl" else "0") != "0"
+            if want:
+                from .exchange import try_peer_exchange
+                n_max = max(self.native.actor.flat.numel(), self.native.critic.flat.numel())
+                self.native.exchange, why = try_peer_exchange(n_max, policy.process_group, self.dev)
+                self.exchange_note = "peer-mapped memory, LDS-free (ks_xchg)" if why is None else f"{backend} all_reduce ({why})"
+            else:
+                self.exchange_note = f"{backend} all_reduce"
         self.sample_seed = int(torch.initial_seed())          # the window sampler's Philox key
 
     # -- learner phases on the static batch -------------------------------------------------------------

@@ -25,7 +25,8 @@ EXPORTS = ["ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_
            "ks_get_state", "ks_set_state", "ks_set_env_params", "ks_substep", "ks_obs_from_snapshot", "ks_kernel_time", "ks_version"]
 # include/kinova_rollout.h
 ROLLOUT_EXPORTS = ["kr_select_action", "kr_store_transition", "kr_rank_episodes", "kr_commit_episodes", "kr_advance_ring",
-                   "kr_sample_windows", "kr_sample_windows_draw", "kr_critic_grad", "kr_update_prologue", "kr_relu_backward", "kr_sigmoid_scale_backward", "kr_adam_step", "kr_soft_update",
+                   "kr_sample_windows", "kr_sample_windows_draw", "kr_xchg_create", "kr_xchg_connect", "kr_xchg_allreduce_mean", "kr_xchg_status",
+                   "kr_xchg_destroy", "kr_critic_grad", "kr_update_prologue", "kr_relu_backward", "kr_sigmoid_scale_backward", "kr_adam_step", "kr_soft_update",
                    "kr_mlp3_forward", "kr_mlp3_forward_shadow", "kr_mlp3_backward_shadow", "kr_weight_grad_shadow",
                    "kr_actor_select"]
 
@@ -68,6 +69,12 @@ def load_library(path: Path | None = None):
     L.kr_advance_ring.argtypes = [i32, i32] + [vp] * 6
     L.kr_sample_windows.argtypes = [i32, i32, i32, vp, vp, i32] + [vp] * 15
     L.kr_sample_windows_draw.argtypes = [i32, i32, i32, vp, vp, i32, vp, C.c_uint64, vp] + [vp] * 13
+    L.kr_xchg_create.argtypes = [C.POINTER(vp), i32, i32, C.c_int64, vp]
+    L.kr_xchg_connect.argtypes = [vp, C.c_char_p]
+    L.kr_xchg_allreduce_mean.argtypes = [vp, vp, C.c_int64, vp]
+    L.kr_xchg_status.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.kr_xchg_destroy.argtypes = [vp]
+    L.kr_xchg_destroy.restype = None
     i64 = C.c_int64
     L.kr_critic_grad.argtypes = [i32, i32] + [vp] * 6 + [f32, vp, vp, vp]
     L.kr_update_prologue.argtypes = [i32, i32, vp, vp, vp, vp, vp, i32, vp]

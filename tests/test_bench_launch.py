@@ -55,6 +55,18 @@ def test_two_ranks_on_one_gpu_through_the_self_launcher():
 
 
 @pytest.mark.gpu
+def test_two_ranks_on_one_gpu_exchange_gradients_through_peer_mapped_memory():
+    """The same two ranks with KS_P2P=1: gloo only carries the rendezvous, the handles and the checksums; the gradients go
+    through exchange.PeerExchange (the default under RCCL on a multi-GPU node).  Replicas must stay bit-identical."""
+    r = run_bench(["--gpus", "2", "--steps", "4", "--warmup", "3", "--envs-per-gpu", "512", "--no-cpu-baseline", "--steady-updates", "0"],
+                  env={"KS_DIST_BACKEND": "gloo", "KS_VISIBLE_GPUS": "1", "KS_P2P": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl"]["exchange"].startswith("peer-mapped memory"), line["rccl"]
+    assert line["replica_weight_checksum_spread"] == 0.0 and line["nonfinite_envs"] == 0
+
+
+@pytest.mark.gpu
 def test_two_ranks_two_gpus_rccl():
     """the real thing when the box has two GPUs: RCCL (backend nccl) over xGMI, replicas stay bit-identical"""
     import torch
@@ -64,3 +76,31 @@ def test_two_ranks_two_gpus_rccl():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rccl"]["backend"] == "nccl" and line["replica_weight_checksum_spread"] == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_exchange_between_processes(world):
+    """The LDS-free gradient all-reduce (csrc/ks_xchg.hip, exchange.PeerExchange): `world` processes on this box's GPU(s) map
+    each other's exchange blocks through hipIpc handles and run the learner's pattern of all-reduces; every result must be the
+    rank-order fp32 mean, bit for bit, and the self-test against the process group's all_reduce must pass."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   KS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tools" / "xchg_selftest.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, out))
+    for rc, out in outs:
+        assert rc == 0 and "peer exchange OK" in out, out[-2000:]
