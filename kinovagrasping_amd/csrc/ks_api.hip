@@ -54,6 +54,9 @@ template <typename T> struct Buffers {
     int32_t *slot_env;            // [n_wg * epw]
     int32_t *wg_model;            // [n_wg]
     T *nominal;                   // [n_models][2] object mass / object-hand friction of every model as compiled
+    // the ray pool of a stepping launch (wg_ray_pool): [0] tickets published, [1] tickets claimed, [2] workgroups that have left,
+    // [4 .. 4 + n_wg) the published workgroups in order, [4 + n_wg .. 4 + 2 n_wg) their done flags; all zero between launches
+    int32_t *rayq;
 };
 
 template <typename T> struct ColW {
@@ -265,13 +268,19 @@ template <typename T> struct ObsOut {
     int horizon, auto_reset, env_major;
 };
 __device__ void wg_obs(const Model<float>& m, const Buffers<float>& b, int N, int slot0, int epw, KS_LDS unsigned* w, const ObsOut<float>& o);
+__device__ void wg_ray_pool(const Model<float>* models, const Model<float>& mine, const Buffers<float>& b, int N, int epw, KS_LDS unsigned* w, int n_wg,
+                            int linger);
+#ifndef KS_POOL_LINGER_LAST
+#define KS_POOL_LINGER_LAST 64
+#endif
+constexpr int POOL_LINGER_LAST = KS_POOL_LINGER_LAST;
 
 // obs_in_step: the observation / reward / done / auto-reset of the workgroup's envs are produced here too (wg_obs), the
 // separate k_obs launch of a step is gone; needs rays_in_step (fp32 / LDS variant).
 template <typename T, bool USE_LDS>
 __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ models, Buffers<T> b, const Buffers<T>* __restrict__ bdev,
                                                    const T* __restrict__ action, int N, int frame_skip, int iters, int epw, int tap, int rays_in_step,
-                                                   int pair_memory, int obs_in_step, const ObsOut<T>* __restrict__ out) {
+                                                   int pair_memory, int obs_in_step, const ObsOut<T>* __restrict__ out, int ray_pool, int n_wg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KS_LDS T* lds = (KS_LDS T*)smem;
     const Model<T>* mp = models + b.wg_model[blockIdx.x];          // every env of this workgroup holds this object
@@ -284,6 +293,10 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
     Hulls<T> hu_own;
     Hulls<T>* hup = &hu_own;
     if constexpr (USE_LDS) hup = (Hulls<T>*)(smem + (sizeof(Model<T>) + 15) / 16 * 16);
+    // ray pool: how many of the workgroup's 16 team slots have their snapshot out (last 16 bytes of the descriptor slot)
+    static_assert(sizeof(Hulls<T>) <= HULLS_BYTES - 16, "Hulls descriptor slot + the arrival counter");
+    KS_LDS int* arrive = (KS_LDS int*)(smem + (sizeof(Model<T>) + 15) / 16 * 16 + HULLS_BYTES - 16);
+    if (USE_LDS && threadIdx.x == 0) *arrive = 0;
     stage_hulls<T, USE_LDS>(*mp, lds, hull_words, *hup);
     const Hulls<T>& hu = *hup;
     // epw envs per workgroup, SUBS lanes per env: the lanes of a team keep identical copies of the env state and
@@ -293,6 +306,22 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
     const int env = e < epw ? b.slot_env[blockIdx.x * epw + e] : -1;
     const bool active = !(team.sub >= SUBS || env < 0);
     if (!active && !(USE_LDS && rays_in_step)) return;
+    // Ray pool (fp32 / LDS, rays in the step): the snapshot the rays need exists once the LAST substep's kinematics are done, a
+    // whole substep (~60 us) before the env has finished stepping.  Every team slot reports its snapshot (empty slots at once);
+    // the slot that completes the workgroup's 16 publishes the workgroup in the launch's queue, and workgroups that have finished
+    // stepping cast the rays of whatever is queued (wg_ray_pool) - so the slowest workgroup's rays are done by others while it
+    // computes its last substep, instead of behind it on the critical path.
+    auto slot_arrived = [&]() {
+        if (!(USE_LDS && ray_pool) || team.sub != 0) return;
+        __threadfence();                                            // this team's snapshot stores are visible device-wide
+        if (__hip_atomic_fetch_add(arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == EPW_MAX - 1) {
+            __threadfence();
+            __hip_atomic_store(&b.rayq[4 + n_wg + blockIdx.x], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);     // published
+            const int t = atomicAdd(&b.rayq[0], 1);
+            __hip_atomic_store(&b.rayq[4 + t], (int)blockIdx.x + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (!active) slot_arrived();
     if (active) {
     T hq[4], act[4];
     KS_UNROLL
@@ -326,7 +355,7 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
             KS_UNROLL
             for (int j = 0; j < WARM_WORDS; j++) gw[q].w[j] = pair_memory ? pm[q * WARM_WORDS + j] : 0u;
         }
-        lane_env_step(m, hu, *(LaneState<T>*)stp, hq, act, scr, team, snap, frame_skip, iters, ncon, status, prof, stp + NQ + 2 * NV, gw);
+        lane_env_step(m, hu, *(LaneState<T>*)stp, hq, act, scr, team, snap, frame_skip, iters, ncon, status, prof, stp + NQ + 2 * NV, gw, slot_arrived);
         if (pair_memory) {
             KS_UNROLL
             for (int q = 0; q < WPL; q++) {
@@ -372,8 +401,24 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
             __syncthreads();
             // (the out-of-line tails take the pointer table and the output record by reference: from device memory - a
             // reference to the by-value kernel arguments made every lane copy them to its stack, 224 bytes written through per launch)
-            wg_rays(m, *bdev, N, blockIdx.x * epw, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)));
+            if (ray_pool) wg_ray_pool(models, m, *bdev, N, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)), n_wg, ray_pool == 2);
+            else {
+                wg_rays(m, *bdev, N, blockIdx.x * epw, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)));
+                __threadfence_block();
+                __syncthreads();
+            }
             if (obs_in_step) wg_obs(m, *bdev, N, blockIdx.x * epw, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)), *out);
+            if (ray_pool) {
+                // the last workgroup to leave clears the pool for the next launch
+                KS_LDS int* last = (KS_LDS int*)(lds + ((hull_words >> 2) << 2));
+                __syncthreads();
+                if (threadIdx.x == 0) *last = atomicAdd(&b.rayq[2], 1) == n_wg - 1;
+                __syncthreads();
+                if (*last) {
+                    for (int i = threadIdx.x; i < 2 * n_wg; i += WG) b.rayq[4 + i] = 0;
+                    if (threadIdx.x < 3) b.rayq[threadIdx.x] = 0;
+                }
+            }
         }
     }
 }
@@ -628,13 +673,11 @@ __global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ model
     obs_epilogue(models[b.obj_id[env]], b, env, N, mode, o, snap, rays, Scratch<T, KS_LDS T*>{(KS_LDS T*)rlds + threadIdx.x, WAVE});
 }
 
-// The tail of the stepping kernel (fp32 / LDS variant, after wg_rays): thread e < epw of the workgroup finishes env e's step -
-// time limit, termination, reward, the 82-d observation, the restart of a finished episode - from the body poses wg_rays
-// left in LDS and the ray distances it just produced.  One thread per env, as in k_obs; what leaves the critical path is the
+// The tail of the stepping kernel (fp32 / LDS variant, after the rays): thread e < epw of the workgroup finishes env e's step -
+// time limit, termination, reward, the 82-d observation, the restart of a finished episode - from the env's snapshot and ray
+// distances in global memory (whoever cast the rays).  One thread per env, as in k_obs; what leaves the critical path is the
 // launch, its gap and the wait for the slowest workgroup before ANY env's observation could start.
 __device__ __noinline__ void wg_obs(const Model<float>& m, const Buffers<float>& b, int N, int slot0, int epw, KS_LDS unsigned* w, const ObsOut<float>& o) {
-    KS_LDS const unsigned* hit = w;
-    KS_LDS const float* snaps = (KS_LDS const float*)(w + epw * NRAY + 4 + epw * WG_RAY_TASKS + RAY_STACK * WG);
     KS_LDS float* rscr = (KS_LDS float*)(w + wg_rays_words(epw) + epw * (NRAY + 1));
     const int e = threadIdx.x;
     if (e >= epw) return;
@@ -642,17 +685,82 @@ __device__ __noinline__ void wg_obs(const Model<float>& m, const Buffers<float>&
     if (env < 0) return;
     float rays[NRAY];
     KS_UNROLL
-    for (int r = 0; r < NRAY; r++) {
-        const float t = __int_as_float((int)hit[e * NRAY + r]);
-        rays[r] = t < Lim<float>::big ? t : -1.0f;
+    for (int r = 0; r < NRAY; r++) rays[r] = b.rays[(long)r * N + env];
+    obs_epilogue(m, b, env, N, 0, o, Col<float>{b.snap + env, N}, rays, ScratchC<float, KS_LDS float*>{rscr + e * (SCR_CON + 1)});
+}
+
+__device__ __forceinline__ int pool_wait(const int32_t* p, bool& ok) {
+    const long long t0 = wall_clock64();
+    int v;
+    while ((v = __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+        if (wall_clock64() - t0 > 200000000ll) { ok = false; break; }      // 2 s of the 100 MHz clock: report, do not hang
+        __builtin_amdgcn_s_sleep(8);
     }
-    // body poses from LDS, the nine joint positions of the snapshot from where lane_env_step wrote them
-    struct Snap {
-        KS_LDS const float* poses; const float* jpos; long N;
-        __device__ float operator()(int k) const { return k < SNAP_JPOS ? poses[k - SNAP_BP] : jpos[(long)(k - SNAP_JPOS) * N]; }
-    };
-    const Snap snap{snaps + e * WG_SNAP, b.snap + (long)SNAP_JPOS * N + env, N};
-    obs_epilogue(m, b, env, N, 0, o, snap, rays, ScratchC<float, KS_LDS float*>{rscr + e * (SCR_CON + 1)});
+    return v;
+}
+
+// The ray pool of a stepping launch (see k_env_step).  A workgroup's ticket (its 16 envs' rays: wg_rays with all 256 threads) is
+// published one substep before the workgroup is done and has a state word: 1 published, 2 claimed, 3 done.
+//   * A workgroup that finishes stepping first claims its OWN ticket (a compare-and-swap on its state word) and casts its own
+//     rays, as it always did; early finishers then leave, and their CUs' registers go to the learner's waves.
+//   * A workgroup that finishes when only the last POOL_LINGER_LAST tickets of the launch are still unpublished stays: it takes
+//     positions of that last stretch of the queue in order (one fetch-add each - no contended compare-and-swap loops: 256
+//     workgroups hammering one word cost 0.15 ms), waits for the ticket at its position to be published, claims it unless its
+//     owner was quicker, and casts its rays.  So when the slowest workgroups publish, hands are free at that moment and their
+//     rays are cast while they compute their last substep (~60 us) instead of behind it.
+//   * Everybody finally waits for its own ticket to be done (by itself or by a helper).
+// Only used when all workgroups of the launch are resident at once (one per CU): a helper waiting for a ticket of a
+// workgroup that cannot start until the helper leaves would never see it.
+__device__ __noinline__ void wg_ray_pool(const Model<float>* models, const Model<float>& mine, const Buffers<float>& b, int N, int epw, KS_LDS unsigned* w,
+                                         int n_wg, int linger) {
+    int32_t* q = b.rayq;
+    int32_t* state = q + 4 + n_wg;
+    KS_LDS int* bc = (KS_LDS int*)(w + wg_rays_words(EPW_MAX) + wg_obs_words(EPW_MAX));      // thread 0's decision, for everybody
+    const int own = blockIdx.x, first_late = n_wg > POOL_LINGER_LAST ? n_wg - POOL_LINGER_LAST : 0;
+    bool ok = true, late = false, tried_own = false;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = -1;
+            if (!tried_own) {
+                tried_own = true;
+                late = linger && __hip_atomic_load(&q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= first_late;
+                if (atomicCAS(&state[own], 1, 2) == 1) t = own;
+            }
+            while (t < 0 && late) {
+                const int c = first_late + atomicAdd(&q[1], 1);
+                if (c >= n_wg) break;
+                const int cand = pool_wait(&q[4 + c], ok) - 1;
+                if (cand < 0) break;
+                if (atomicCAS(&state[cand], 1, 2) == 1) t = cand;
+            }
+            *bc = t;
+        }
+        __syncthreads();
+        const int t = *bc;
+        if (t < 0) break;
+        // (the same object as mine: my LDS copy of the model - a flat load that resolves to LDS costs a fraction of one that goes to L2)
+        const int tm = b.wg_model[t];
+        wg_rays(tm == b.wg_model[own] ? mine : models[tm], b, N, t * epw, epw, w);
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&state[t], 3, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // my own envs' rays: cast by me or by a helper (the acquire also drops this CU's stale lines)
+    if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(&state[own], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 3) {
+            if (wall_clock64() - t0 > 200000000ll) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        *bc = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (*bc == 0 && (int)threadIdx.x < epw) {
+        const int env = b.slot_env[own * epw + threadIdx.x];
+        if (env >= 0) atomicOr(&b.status[env], ST_RAY_POOL_TIMEOUT);
+    }
+    __syncthreads();
 }
 
 struct CtxBase {
@@ -803,6 +911,14 @@ template <typename T> struct Ctx : CtxBase {
         n_wg = (cfg.n_envs + lpw - 1) / lpw + (nm - 1);
         if ((r = alloc(&b.slot_env, (size_t)n_wg * lpw))) return r;
         if ((r = alloc(&b.wg_model, (size_t)n_wg))) return r;
+        if ((r = alloc(&b.rayq, (size_t)4 + 2 * (size_t)n_wg))) return r;
+        // the rays pooled over the launch (wg_ray_pool): early finishers linger for the slowest workgroup's ticket only when all
+        // workgroups are resident at once (one per CU); KS_RAY_POOL=0 makes every workgroup cast its own envs' rays
+        if (obs_in_step && cfg.frame_skip >= 1 && !(getenv("KS_RAY_POOL") && getenv("KS_RAY_POOL")[0] == '0')) {
+            hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, device));
+            ray_pool = n_wg <= prop.multiProcessorCount ? 2 : 0;
+        }
         hipLaunchKernelGGL(k_slots, dim3(1), dim3(SLOT_THREADS), 0, 0, b.obj_id, cfg.n_envs, n_models, lpw, n_wg, b.slot_env, b.wg_model);
         HIPCHK(hipGetLastError());
         HIPCHK(hipDeviceSynchronize());
@@ -816,6 +932,7 @@ template <typename T> struct Ctx : CtxBase {
     // envs per wave and dynamic LDS bytes of the stepping kernels
     int lpw = WAVE;
     bool rays_in_step = false, obs_in_step = false;
+    int ray_pool = 0;                     // 0 every workgroup casts its own envs' rays, 1 pooled, 2 pooled + early finishers linger
     size_t step_lds = 0;
     int hull_words = 0;
     int plan_launch() {
@@ -833,7 +950,7 @@ template <typename T> struct Ctx : CtxBase {
         rays_in_step = USE_LDS && sizeof(T) == 4 && (size_t)wg_rays_words(lpw) <= (size_t)SCR_TOTAL * lpw &&
                        !(getenv("KS_RAYS_IN_STEP") && getenv("KS_RAYS_IN_STEP")[0] == '0');
         // ... and then finish the step there as well (wg_obs: observation, reward, done, auto-reset); KS_OBS_IN_STEP=0 keeps k_obs
-        obs_in_step = rays_in_step && (size_t)(wg_rays_words(lpw) + wg_obs_words(lpw)) <= (size_t)SCR_TOTAL * lpw &&
+        obs_in_step = rays_in_step && (size_t)(wg_rays_words(EPW_MAX) + wg_obs_words(EPW_MAX) + 4) <= (size_t)SCR_TOTAL * lpw &&
                       !(getenv("KS_OBS_IN_STEP") && getenv("KS_OBS_IN_STEP")[0] == '0');
         if (getenv("KS_DEBUG")) fprintf(stderr, "[ks] stepping kernel: %d envs per workgroup, LDS %zu B (tables %zu B, %zu B per env), limit %zu\n", lpw, step_lds, hull_bytes, per_env, lds_max);
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<T, USE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
@@ -842,6 +959,7 @@ template <typename T> struct Ctx : CtxBase {
     }
     int post_reset(void* obs, hipStream_t s) {
         const int N = cfg.n_envs;
+        if (b.rayq) HIPCHK(hipMemsetAsync(b.rayq, 0, (4 + 2 * (size_t)n_wg) * sizeof(int32_t), s));    // (clean even after an aborted launch)
         hipLaunchKernelGGL((k_reset<T, USE_LDS>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0);
         hipLaunchKernelGGL((k_rays<T>), dim3((N + RAY_ENVS - 1) / RAY_ENVS, NRAY), dim3(WAVE), 0, s, d_model, b, N, 1);
         hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 1,
@@ -877,7 +995,7 @@ template <typename T> struct Ctx : CtxBase {
         if (timed) HIPCHK(hipEventRecord(ev0[ev_used], s));
         hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3(n_wg), dim3(WG), step_lds, s, d_model, b, (const Buffers<T>*)d_b, (const T*)action, N,
                            cfg.frame_skip, cfg.solver_iterations, lpw, cfg.contact_tap, (int)rays_in_step, (int)(USE_LDS && cfg.pair_memory),
-                           (int)obs_in_step, (const ObsOut<T>*)d_out);
+                           (int)obs_in_step, (const ObsOut<T>*)d_out, ray_pool, n_wg);
         if (timed) { HIPCHK(hipEventRecord(ev1[ev_used], s)); ev_used++; }
         if (!rays_in_step) hipLaunchKernelGGL((k_rays<T>), dim3((N + RAY_ENVS - 1) / RAY_ENVS, NRAY), dim3(WAVE), 0, s, d_model, b, N, 0);
         if (!obs_in_step) hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0, out);

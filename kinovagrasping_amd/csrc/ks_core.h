@@ -2351,12 +2351,18 @@ KS_FN_SOLVER void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm,
 }
 
 // ---------------------------------------------------------------- one mj_step (forward + Euler)
-template <typename T, typename S, int SUBS>
+struct NoHook {
+    KS_HD void operator()() const {}
+};
+// after_kinematics(): called once the body poses of this step are in the env's scratch block (before collision / solver)
+template <typename T, typename S, int SUBS, typename Hook = NoHook>
 KS_HD void mj_forward_step(const Model<T>& m, const Hulls<T>& hu, T* qpos, T* qvel, T* warm, const T* ctrl, const T* R7, S scr, Team<SUBS> team,
-                           int solver_iterations, bool integrate, int& ncon_out, int& status, float* prof = nullptr, PairWarm* gjk_warm = nullptr) {
+                           int solver_iterations, bool integrate, int& ncon_out, int& status, float* prof = nullptr, PairWarm* gjk_warm = nullptr,
+                           Hook after_kinematics = Hook()) {
     KS_T0
     team.sync();                                   // the previous substep's readers of the body poses are done
     dynamics_rows(m, qpos, qvel, ctrl, R7, scr, team);
+    after_kinematics();
     KS_TICK(0)
     int ncon = 0;
     collision(m, hu, scr, team, ncon, status, gjk_warm, prof);

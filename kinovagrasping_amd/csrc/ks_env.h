@@ -25,11 +25,13 @@ template <typename T, typename S, typename SnapW> KS_HD void write_snapshot(S sc
 }
 
 // One env.step(): action -> ctrl (constant over the frame_skip substeps), frame_skip x mj_step.
-// The snapshot is what mj_forward saw at the START of the last substep.
-template <typename T, typename S, typename SnapW, int SUBS>
+// The snapshot is what mj_forward saw at the START of the last substep: it is written as soon as that substep's kinematics
+// are done (the collision / solver / Euler stages do not touch the body poses), and on_snapshot() is called right behind it -
+// the stepping kernel uses that to hand the env's rangefinder rays to whoever is free a whole substep before the env is done.
+template <typename T, typename S, typename SnapW, int SUBS, typename OnSnap = NoHook>
 KS_HD void lane_env_step(const Model<T>& m, const Hulls<T>& hu, LaneState<T>& st, const T* hand_quat, const T* act4, S scr, Team<SUBS> team,
                          SnapW snap_put, int frame_skip, int solver_iterations, int& ncon, int& status, float* prof = nullptr,
-                         T* ws = nullptr, PairWarm* warm = nullptr) {
+                         T* ws = nullptr, PairWarm* warm = nullptr, OnSnap on_snapshot = OnSnap()) {
     // ws (optional, 18 reals shared by the team): where the per-step constants live; the GPU passes LDS
     T Rpalm[9], T3[9], wrist[3], R7_[9], ctrl_[NU];
     T* R7 = ws ? ws : R7_;
@@ -44,8 +46,13 @@ KS_HD void lane_env_step(const Model<T>& m, const Hulls<T>& hu, LaneState<T>& st
         T jq[9];
         KS_UNROLL
         for (int j = 0; j < 9; j++) jq[j] = st.qpos[j];
-        mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, ctrl, R7, scr, team, solver_iterations, true, ncon, status, prof, warm);
-        if (sub == frame_skip - 1 && team.sub == 0) write_snapshot<T>(scr, jq, snap_put);
+        const bool last = sub == frame_skip - 1;
+        mj_forward_step(m, hu, st.qpos, st.qvel, st.warm, ctrl, R7, scr, team, solver_iterations, true, ncon, status, prof, warm, [&]() {
+            if (last) {
+                if (team.sub == 0) write_snapshot<T>(scr, jq, snap_put);
+                on_snapshot();
+            }
+        });
     }
 }
 

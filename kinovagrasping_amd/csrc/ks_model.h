@@ -15,7 +15,7 @@ constexpr int NRAY = 17;
 constexpr int SUPPORT_R = 16, SUPPORT_CELLS = 6 * SUPPORT_R * SUPPORT_R;   // cube-map resolution of the support start tables
 
 // status bits reported per env
-constexpr int ST_CONTACT_OVERFLOW = 1, ST_NONFINITE = 2;
+constexpr int ST_CONTACT_OVERFLOW = 1, ST_NONFINITE = 2, ST_RAY_POOL_TIMEOUT = 4;
 
 template <typename T> struct Model {
     T dt, impratio, gravity_z, mpr_tol;

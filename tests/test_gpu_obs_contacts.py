@@ -417,3 +417,31 @@ def test_step_finished_inside_the_stepping_kernel_equals_the_separate_observatio
             torch.testing.assert_close(sa[k], sb[k], rtol=0, atol=0)
     assert restarts >= 2 * n        # lifted envs restart every step, the others at the time limit
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_pooled_rays_equal_the_rays_every_workgroup_casts_for_itself(monkeypatch):
+    """At 4096 envs (one workgroup per CU) the stepping launch pools the rangefinder rays: workgroups publish their envs'
+    snapshot a substep early and late finishers cast the stragglers' rays (wg_ray_pool).  Who casts a ray must not matter:
+    observations, rewards, flags and states are bit-identical to a context with KS_RAY_POOL=0, and no env reports a pool
+    time-out."""
+    from kinovagrasping_amd.sim import KinovaSim
+    n = 4096
+    q0, hq = scenarios.config2_states(n)
+    acts = torch.as_tensor(scenarios.config_actions(n, 6)).cuda()
+    monkeypatch.setenv("KS_RAY_POOL", "0")
+    a = KinovaSim(n, "CubeS", auto_reset=True, horizon=4)
+    monkeypatch.delenv("KS_RAY_POOL")
+    b = KinovaSim(n, "CubeS", auto_reset=True, horizon=4)
+    assert torch.equal(a.reset(torch.as_tensor(q0), torch.as_tensor(hq)), b.reset(torch.as_tensor(q0), torch.as_tensor(hq)))
+    for t in range(6):
+        ra, rb = a.step(acts[t]), b.step(acts[t])
+        torch.cuda.synchronize()
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), t
+        assert torch.equal(a.final_obs, b.final_obs)
+    sa, sb = a.get_state(), b.get_state()
+    for k in ("qpos", "qvel", "qacc_warmstart", "ncon"):
+        assert torch.equal(sa[k], sb[k])
+    assert int(sb["status"].abs().sum()) == 0 and int(sa["status"].abs().sum()) == 0
+    a.close(); b.close()
