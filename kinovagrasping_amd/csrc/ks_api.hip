@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <map>
 #include <string>
 #include <vector>
@@ -85,6 +86,24 @@ template <typename T> __device__ __forceinline__ const Model<T>* stage_model(con
 // size of a PairRec in DEVICE code (LDS pointers are 4 bytes there; the host pass of this file sees 8)
 template <typename T> constexpr int pair_rec_bytes() { return sizeof(T) == 4 ? 96 : 144; }
 
+// Global -> LDS copy of a table by the whole workgroup in B-byte words (both ends B-byte aligned, `bytes` a multiple of B), four
+// loads in flight per thread: the tables of a workgroup are ~50 KB, and copied element by element (floats, 16-bit ids) the
+// staging was 56 dependent load -> store rounds = 27 us at the head of every launch.
+template <int B, typename D, typename Sx> __device__ __forceinline__ void stage_copy(KS_LDS D* dst, const Sx* src, size_t bytes) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    using W = typename std::conditional<B == 16, v4u, v2u>::type;
+    KS_LDS W* d = (KS_LDS W*)dst;
+    const W* s = (const W*)src;
+    const int n = (int)(bytes / B), step = blockDim.x;
+    int i = threadIdx.x;
+    for (; i + 3 * step < n; i += 4 * step) {
+        const W a = s[i], b = s[i + step], c = s[i + 2 * step], e = s[i + 3 * step];
+        d[i] = a; d[i + step] = b; d[i + 2 * step] = c; d[i + 3 * step] = e;
+    }
+    for (; i < n; i += step) d[i] = s[i];
+}
+
 // SHARED: `hu` is the workgroup's one descriptor in LDS, filled by thread 0 (every thread writing its own private copy
 // was 240 bytes of stack per lane, written through to memory at every launch: 16 of the 27 MB a launch wrote);
 // otherwise `hu` is the calling thread's own.
@@ -94,7 +113,7 @@ template <typename T, bool SHARED> __device__ __forceinline__ void stage_hulls(c
     for (int s = 0; s < 4; s++) {
         const int n = m.mesh_nvert_pad[s] * 4;
         const T* src = m.mesh_vert[s];
-        for (int i = threadIdx.x; i < n; i += blockDim.x) lds[off + i] = src[i];
+        stage_copy<16>(lds + off, src, (size_t)n * sizeof(T));
         if (writer) {
             hu.vert[s] = lds + off;
             hu.nvert[s] = m.mesh_nvert[s];
@@ -107,10 +126,10 @@ template <typename T, bool SHARED> __device__ __forceinline__ void stage_hulls(c
     int uoff = 0;
     for (int s = 0; s < 4; s++) {
         const int no = m.mesh_nvert[s] + 1, na = m.mesh_nchunk[s] * 4;
-        for (int i = threadIdx.x; i < no; i += blockDim.x) ulds[uoff + i] = m.mesh_adj_off[s][i];
+        stage_copy<8>(ulds + uoff, m.mesh_adj_off[s], (size_t)((no + 3) & ~3) * sizeof(unsigned short));   // (padded to whole 8-byte words at load)
         if (writer) hu.adj_off[s] = ulds + uoff;
         uoff += (no + 3) & ~3;                       // keep the chunk tables 8-byte aligned
-        for (int i = threadIdx.x; i < na; i += blockDim.x) ulds[uoff + i] = m.mesh_adj[s][i];
+        stage_copy<8>(ulds + uoff, m.mesh_adj[s], (size_t)na * sizeof(unsigned short));
         if (writer) hu.adj[s] = ulds + uoff;
         uoff += na;
     }
@@ -282,6 +301,9 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
                                                    const T* __restrict__ action, int N, int frame_skip, int iters, int epw, int tap, int rays_in_step,
                                                    int pair_memory, int obs_in_step, const ObsOut<T>* __restrict__ out, int ray_pool, int n_wg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef KS_STAMP_WG
+    const long long wk_entry = wall_clock64();
+#endif
     KS_LDS T* lds = (KS_LDS T*)smem;
     const Model<T>* mp = models + b.wg_model[blockIdx.x];          // every env of this workgroup holds this object
     const Model<T>* ml = mp;
@@ -297,7 +319,8 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
     static_assert(sizeof(Hulls<T>) <= HULLS_BYTES - 16, "Hulls descriptor slot + the arrival counter");
     KS_LDS int* arrive = (KS_LDS int*)(smem + (sizeof(Model<T>) + 15) / 16 * 16 + HULLS_BYTES - 16);
     if (USE_LDS && threadIdx.x == 0) *arrive = 0;
-    stage_hulls<T, USE_LDS>(*mp, lds, hull_words, *hup);
+    if constexpr (USE_LDS) __syncthreads();         // the model copy is complete: the table staging reads its pointers and counts from LDS
+    stage_hulls<T, USE_LDS>(*ml, lds, hull_words, *hup);
     const Hulls<T>& hu = *hup;
     // epw envs per workgroup, SUBS lanes per env: the lanes of a team keep identical copies of the env state and
     // split the vertex scans / per-pair (collision) and per-contact (solver) loops; per-env dynamic data is shared in LDS
@@ -369,6 +392,7 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
 #ifdef KS_STAMP_WG
         // wall clock (100 MHz) of the stepping loop's start / end, modulo 2^22 ticks, and the hardware id (CU / SE / XCC)
         prof[13] = (float)(wk0 & 0x3fffff);
+        prof[23] = (float)(wk0 - wk_entry);           // table staging + state load, 100 MHz ticks
         prof[14] = (float)(wall_clock64() & 0x3fffff);
         prof[19] = (float)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) & 0xffffff);
         prof[20] = (float)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf);

@@ -270,6 +270,7 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
                 hm.adj_off[s].push_back((unsigned short)(hm.adj[s].size() / 4));
             }
             if (hm.adj[s].size() / 4 > 65535) { e = "hull graph too large for 16-bit chunk offsets"; return false; }
+            while (hm.adj_off[s].size() % 4) hm.adj_off[s].push_back(hm.adj_off[s].back());   // whole 8-byte words (the stepping kernel stages them as such)
             m.mesh_nchunk[s] = (int)(hm.adj[s].size() / 4);
         }
         m.mesh_adj_off[s] = hm.adj_off[s].data();

@@ -59,6 +59,7 @@ for t in range(NSTEP):
         key = xcc * 1000 + se * 100 + sh * 20 + cu
         uniq, cnt = np.unique(key[::16], return_counts=True)
         print("  distinct (xcc,se,sh,cu) used by the 256 workgroups:", len(uniq), " max WGs on one CU:", cnt.max())
+        print(f"  kernel entry -> stepping loop (tables into LDS, state load), ticks: min {prof[23].min():.0f} mean {prof[23].mean():.0f} max {prof[23].max():.0f}")
         late = st_rel[::16] > 0.25 * d.mean()
         print("  workgroups starting late (> 25% of a loop):", int(late.sum()))
     if t == NSTEP - 1:
