@@ -336,7 +336,10 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
     // computes its last substep, instead of behind it on the critical path.
     auto slot_arrived = [&]() {
         if (!(USE_LDS && ray_pool) || team.sub != 0) return;
-        __threadfence();                                            // this team's snapshot stores are visible device-wide
+        // this team's snapshot stores have reached the L2 (workgroup-scope release: the workgroup's waves share one CU and one L2);
+        // the slot that completes the sixteen then makes them visible to the other XCDs' L2s - ONE device-scope release (an L2
+        // write-back) per workgroup, not one per team
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (__hip_atomic_fetch_add(arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == EPW_MAX - 1) {
             __threadfence();
             __hip_atomic_store(&b.rayq[4 + n_wg + blockIdx.x], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);     // published
