@@ -720,7 +720,7 @@ __device__ __forceinline__ int pool_wait(const int32_t* p, bool& ok) {
     const long long t0 = wall_clock64();
     int v;
     while ((v = __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
-        if (wall_clock64() - t0 > 200000000ll) { ok = false; break; }      // 2 s of the 100 MHz clock: report, do not hang
+        if (wall_clock64() - t0 > 50000000ll) { ok = false; break; }       // 0.5 s of the 100 MHz clock (a real wait is < 1 ms): report, do not hang
         __builtin_amdgcn_s_sleep(8);
     }
     return v;
@@ -777,7 +777,7 @@ __device__ __noinline__ void wg_ray_pool(const Model<float>* models, const Model
     if (threadIdx.x == 0) {
         const long long t0 = wall_clock64();
         while (__hip_atomic_load(&state[own], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 3) {
-            if (wall_clock64() - t0 > 200000000ll) { ok = false; break; }
+            if (wall_clock64() - t0 > 50000000ll) { ok = false; break; }
             __builtin_amdgcn_s_sleep(8);
         }
         *bc = ok ? 1 : 0;
