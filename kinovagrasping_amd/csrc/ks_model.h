@@ -12,7 +12,10 @@ constexpr int RAY_STACK = 24;   // pending-node bound of the ray-casting hierarc
 constexpr int RAY_EMPTY = (int)0x80000000;   // unused child slot of a 4-wide node
 constexpr int NCON_MAX = 24;   // contacts kept per env per substep (oracle: KO_NCON_MAX)
 constexpr int NRAY = 17;
-constexpr int SUPPORT_R = 16, SUPPORT_CELLS = 6 * SUPPORT_R * SUPPORT_R;   // cube-map resolution of the support start tables
+#ifndef KS_SUPPORT_R
+#define KS_SUPPORT_R 64
+#endif
+constexpr int SUPPORT_R = KS_SUPPORT_R, SUPPORT_CELLS = 6 * SUPPORT_R * SUPPORT_R;   // cube-map resolution of the support start tables
 
 // status bits reported per env
 constexpr int ST_CONTACT_OVERFLOW = 1, ST_NONFINITE = 2, ST_RAY_POOL_TIMEOUT = 4;
