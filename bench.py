@@ -386,6 +386,8 @@ def main():
             "mfma": mfma,
             "steady_state": steady,
             "nonfinite_envs": bad,
+            "status_counts": {"contact_overflow": int((status & 1).ne(0).sum().item()), "nonfinite": bad,
+                              "ray_pool_timeout": int((status & 4).ne(0).sum().item())},
             "rccl": ({"ranks": world, "backend": os.environ.get("KS_DIST_BACKEND", "nccl"), "NCCL_ALGO": os.environ.get("NCCL_ALGO", "default"),
                       "allreduces_per_update": 2, "bytes_per_allreduce": int(policy._flat_params["critic"].numel() * 4),
                       "exchange": getattr(trainer, "exchange_note", None),
