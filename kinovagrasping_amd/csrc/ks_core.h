@@ -83,7 +83,10 @@ constexpr int SCR_TOTAL = SCR_STATE + 64;
 // the contact basis Jacobians (45 values per contact) so that they are built once per substep, not 2x per
 // Newton iteration; contacts that do not fit are rebuilt on the fly.
 constexpr int SCR_BCACHE = SCR_STAGE;
-constexpr int BC_STRIDE = 48;                 // 3 x 15 values, padded to whole 16-byte vectors
+#ifndef KS_BC_STRIDE
+#define KS_BC_STRIDE 48
+#endif
+constexpr int BC_STRIDE = KS_BC_STRIDE;                // 3 x 15 values, padded to whole 16-byte vectors
 constexpr int NBCACHE = (SCR_MH - SCR_STAGE) / BC_STRIDE;
 static_assert(SCR_CON % 4 == 0 && SCR_STAGE % 4 == 0 && SCR_TOTAL % 4 == 0 && CON_STRIDE % 4 == 0, "16-byte aligned scratch regions");
 
