@@ -31,7 +31,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROWS = 16;        // batch rows per workgroup (the N of the MFMA)
 constexpr int KS_IN_MAX = 6;    // input k-steps: in_dim <= 96
-constexpr int NW = 4;           // waves per workgroup (one per SIMD)
+#ifndef KS_MLP_WAVES
+#define KS_MLP_WAVES 4
+#endif
+constexpr int NW = KS_MLP_WAVES;   // waves per workgroup
 
 // 4 consecutive weights W[row][k .. k+3] (zero beyond the matrix): one 16-byte load when the row is 16-byte aligned
 template <bool VEC> __device__ __forceinline__ f32x4 load_w4(const float* __restrict__ W, int row, int nrow, int k, int K) {
