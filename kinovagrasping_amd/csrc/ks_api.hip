@@ -823,6 +823,9 @@ template <typename T> struct Ctx : CtxBase {
     Buffers<T>* d_b = nullptr;            // the same pointer table in device memory (what the stepping kernels' out-of-line tails read)
     ObsOut<T>* d_out = nullptr;           // ... and where ks_step's results go (re-sent only when a caller changes its buffers)
     ObsOut<T> out_sent{};
+    ObsOut<T>* h_out = nullptr;           // pinned staging of that record (an async copy from pinned memory may be captured in a
+    int h_out_next = 0;                   // graph): a ring, so that a change does not overwrite a copy that is still queued
+    static constexpr int H_OUT_RING = 16;
     bool out_valid = false;
     Model<T>* d_model = nullptr;          // [n_models] model table
     int n_models = 0, n_wg = 0;
@@ -869,6 +872,7 @@ template <typename T> struct Ctx : CtxBase {
     }
     ~Ctx() override {
         for (void* p : allocs) (void)hipFree(p);
+        if (h_out) (void)hipHostFree(h_out);
         for (auto& e : ev0) (void)hipEventDestroy(e);
         for (auto& e : ev1) (void)hipEventDestroy(e);
     }
@@ -951,6 +955,7 @@ template <typename T> struct Ctx : CtxBase {
         HIPCHK(hipDeviceSynchronize());
         if ((r = alloc(&d_b, (size_t)1))) return r;
         if ((r = alloc(&d_out, (size_t)1))) return r;
+        HIPCHK(hipHostMalloc((void**)&h_out, H_OUT_RING * sizeof(ObsOut<T>), hipHostMallocDefault));
         HIPCHK(hipMemcpy(d_b, &b, sizeof b, hipMemcpyHostToDevice));
         model_loaded = true;
         return KS_OK;
@@ -1017,7 +1022,9 @@ template <typename T> struct Ctx : CtxBase {
         if (obs_in_step && !(same && out_valid)) {
             out_valid = true;
             out_sent = out;
-            HIPCHK(hipMemcpyAsync(d_out, &out_sent, sizeof out, hipMemcpyHostToDevice, s));
+            ObsOut<T>* slot = h_out + (h_out_next++ % H_OUT_RING);
+            *slot = out;
+            HIPCHK(hipMemcpyAsync(d_out, slot, sizeof out, hipMemcpyHostToDevice, s));
         }
         if (timed) HIPCHK(hipEventRecord(ev0[ev_used], s));
         hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3(n_wg), dim3(WG), step_lds, s, d_model, b, (const Buffers<T>*)d_b, (const T*)action, N,
