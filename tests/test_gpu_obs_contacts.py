@@ -445,3 +445,38 @@ def test_pooled_rays_equal_the_rays_every_workgroup_casts_for_itself(monkeypatch
         assert torch.equal(sa[k], sb[k])
     assert int(sb["status"].abs().sum()) == 0 and int(sa["status"].abs().sum()) == 0
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_ks_step_replayed_from_a_hip_graph_equals_direct_launches():
+    """every call is asynchronous on the caller's stream and does no host synchronisation, so ks_step can be
+    captured in a HIP graph (the output record travels through pinned memory, the launch's ray pool cleans up after itself).
+    A captured step replayed 8 times must walk the same trajectory as 8 direct calls."""
+    from kinovagrasping_amd.sim import KinovaSim
+    n = 4096
+    q0, hq = scenarios.config2_states(n)
+    a, b = KinovaSim(n, "CubeS", auto_reset=True, horizon=5), KinovaSim(n, "CubeS", auto_reset=True, horizon=5)
+    a.reset(torch.as_tensor(q0), torch.as_tensor(hq)); b.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+    acts = torch.as_tensor(scenarios.config_actions(n, 9)).cuda()
+    act = acts[0].clone()
+    # warm-up on a side stream (as torch.cuda.graphs requires), then capture ONE step reading the static action buffer
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        a.step(act)
+    torch.cuda.current_stream().wait_stream(s)
+    b.step(acts[0])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        a.step(act)
+    b.step(acts[0])               # the captured call itself is not executed: b takes that step after the capture ...
+    act.copy_(acts[0]); g.replay()  # ... and a replays it
+    for t in range(1, 9):
+        act.copy_(acts[t])
+        g.replay()
+        rb = b.step(acts[t])
+        torch.cuda.synchronize()
+        assert torch.equal(a.obs, rb[0]) and torch.equal(a.reward, rb[1]) and torch.equal(a.done, rb[2]), t
+    sa, sb = a.get_state(), b.get_state()
+    assert torch.equal(sa["qpos"], sb["qpos"]) and int(sa["status"].abs().sum()) == 0
+    a.close(); b.close()
