@@ -48,9 +48,9 @@ def oracle_grasp_trajectory(model, n_sub=330, x0=0.0, y0=0.0, iters=6):
     return hq, rec
 
 
-def run_teacher_forced(precision, model, rec, hq, iters=6):
+def run_teacher_forced(precision, model, rec, hq, iters=6, shape="CubeS"):
     n = len(rec)
-    sim = _sim(n, "CubeS", precision=precision, solver_iterations=iters)
+    sim = _sim(n, shape, precision=precision, solver_iterations=iters)
     dt = sim.dtype
     q0 = np.stack([r[0][0] for r in rec], 1)
     sim.reset(torch.as_tensor(q0), torch.as_tensor(np.repeat(hq[:, None], n, 1)))
@@ -93,6 +93,48 @@ def test_one_step_fp32_matches_oracle(cube):
     assert tail.mean() <= 0.03
     assert eq.max() <= 3e-3
     assert (ncon != onc).sum() <= 1
+
+
+@pytest.mark.parametrize("shape", ["mbox", "bbox", "scyl", "mcyl", "bcyl"])
+def test_primitive_objects_one_step_matches_oracle(shape):
+    """The env's default model (..._mbox.xml, ENV:62) and its primitive siblings through the HIP kernels: a drop onto the plane,
+    the rest on it and a closing grasp, every substep teacher-forced from the oracle's state - fp64 to round-off, fp32 with the
+    CubeS bounds (box / cylinder objects are compiled to their convex polytopes, model_compiler.compile_model)."""
+    from kinovagrasping_amd import model_compiler as mc
+    blob = scenarios.model_blob(shape)
+    model = ko.OracleModel(blob)
+    hq = scenarios.hand_quat_for("normal")
+    o = ko.OracleSim(model, hq, solver_iterations=6)
+    half_h = mc.read_blob(blob)["geom_size"][8][2]
+    q0 = np.zeros(16); q0[9:12] = [0.0, 0.0, half_h + 0.01]; q0[12] = 1
+    o.env_reset(q0)
+    ctrl = np.zeros(9); ctrl[5] = 0.2932
+    rec, touched = [], False
+    for i in range(300):
+        if i == 60:
+            ctrl[6:9] = 0.6
+        before = (o.view("qpos").copy(), o.view("qvel").copy(), o.view("qacc_warmstart").copy())
+        o.step(ctrl)
+        rec.append((before, ctrl.copy(), (o.view("qpos").copy(), o.view("qvel").copy(), o.view("qacc_warmstart").copy()), o.s.ncon))
+        touched = touched or any(c["geom2"] == 8 and c["geom1"] in (2, 3, 4, 5, 6, 7) for c in o.contacts())
+    assert touched                                              # the fingers reached the object
+    box = shape.endswith("box")
+    eq, ev, ncon, onc = run_teacher_forced(64, model, rec, hq, shape=shape)
+    print(f"{shape}: fp64 one-step |dqpos| max {eq.max():.2e}, states above 1e-9: {int((eq > 1e-9).sum())}/{len(eq)}")
+    assert (ncon == onc).all()
+    if box:
+        assert eq.max() < 1e-9 and ev.max() < 1e-7, (eq.max(), ev.max())
+    else:
+        # A cylinder standing on its base has 64 rim vertices at the same depth to the last bit or two: which of them is "the
+        # deepest" (and with it the greedy choice of the other three contacts, 0.3 rbound apart) is decided by rounding, and the
+        # kernel's fused multiply-adds round differently from the oracle's host arithmetic.  The contact SET then differs (same
+        # count, same physics to first order); the states without such a tie are exact.
+        assert (eq > 1e-9).mean() <= 0.05 and eq.max() < 1e-3, ((eq > 1e-9).mean(), eq.max())
+    eq, ev, ncon, onc = run_teacher_forced(32, model, rec, hq, shape=shape)
+    print(f"{shape}: fp32 one-step |dqpos| median {np.median(eq):.2e} p95 {np.percentile(eq, 95):.2e} max {eq.max():.2e}; ncon mismatches {int((ncon != onc).sum())}")
+    # flat faces resting on the plane and against the finger pads: more states with parallel features than the cube in a pinch;
+    # the standing cylinder's rim tie (above) is broken differently in every fp32 state
+    assert np.median(eq) <= (1e-7 if box else 2e-6) and np.percentile(eq, 95) <= 3e-5 and eq.max() <= 5e-3 and (ncon != onc).mean() <= 0.02
 
 
 def test_config1_episode_free_running(cube):
