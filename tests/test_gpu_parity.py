@@ -845,3 +845,27 @@ def test_in_step_rays_equal_the_separate_ray_kernel(monkeypatch):
     assert dr.max().item() < 1e-5 and (dr > 5e-7).float().mean().item() < 1e-3   # the ray distances themselves (grazing hits amplify rounding)
     assert (oa - ob).abs().max().item() < 2e-5 and (fa - fb).abs().max().item() < 2e-5   # and what the observation derives from them
     assert (oa[:, :, 50:67] < 6).any() and (da != 0).any()                      # rays hit something; episodes ended
+
+
+def test_full_size_batch_equals_its_slices():
+    """BASELINE's full size (4096 envs on one GPU, config 2 rows / actions) against a size-independent property: an env's
+    trajectory does not depend on what else is in the batch - envs 512..767 of the 4096-env context walk, bit for bit, the
+    trajectory of the same 256 envs alone in a context of their own (other workgroups, another ray-pool population, same kernels)."""
+    n, lo, m = 4096, 512, 256
+    q0, hq = scenarios.config2_states(n)
+    acts = scenarios.config_actions(n, 6)
+    big = _sim(n, "CubeS", solver_iterations=6, auto_reset=True, horizon=4)
+    small = _sim(m, "CubeS", solver_iterations=6, auto_reset=True, horizon=4)
+    ob = big.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+    os_ = small.reset(torch.as_tensor(q0[:, lo:lo + m]), torch.as_tensor(hq[:, lo:lo + m]))
+    assert torch.equal(ob[lo:lo + m], os_)
+    for t in range(6):
+        rb = big.step(torch.as_tensor(acts[t]))
+        rs = small.step(torch.as_tensor(np.ascontiguousarray(acts[t][:, lo:lo + m])))
+        torch.cuda.synchronize()
+        assert torch.equal(rb[0][lo:lo + m], rs[0]) and torch.equal(rb[1][lo:lo + m], rs[1]) and torch.equal(rb[2][lo:lo + m], rs[2]), t
+    sb, ss = big.get_state(), small.get_state()
+    for k in ("qpos", "qvel", "qacc_warmstart"):
+        assert torch.equal(sb[k][:, lo:lo + m], ss[k])
+    assert int(sb["status"].abs().sum()) == 0
+    big.close(); small.close()
