@@ -140,7 +140,8 @@ int ks_substep(ks_ctx *ctx, const void *ctrl, void *stream);
 int ks_obs_from_snapshot(ks_ctx *ctx, const void *snap, const void *rays, void *obs, void *reward, uint8_t *done, void *info, void *stream);
 
 /* HIP event timing of the dominant kernel: average duration (ms) of the env-step kernel launches
- * since the last call with reset != 0, measured with hipEvents on the launch stream.  Host sync.
+ * since the last call with reset != 0, measured with hipEvents on the launch stream - every 4th launch is sampled (the two
+ * event records cost ~8 us of stream time per sampled launch; KS_EVENT_STRIDE=1 samples all of them).  Host sync.
  * (fp32 contexts: that kernel is the 15 substeps of every env plus the rangefinder rays of the workgroup's own envs.) */
 int ks_kernel_time(ks_ctx *ctx, int reset, double *avg_ms_host, int64_t *launches_host);
 

@@ -834,6 +834,8 @@ template <typename T> struct Ctx : CtxBase {
     std::vector<void*> allocs;
     // HIP-event timing of k_env_step
     static constexpr int NEV = 512;
+    int ev_stride = 4;                    // KS_EVENT_STRIDE
+    long step_calls = 0;
     std::vector<hipEvent_t> ev0, ev1;
     int ev_used = 0;
     double ev_ms = 0;
@@ -849,6 +851,7 @@ template <typename T> struct Ctx : CtxBase {
         const size_t N = cfg.n_envs;
         int r;
         if (getenv("KS_PAIR_MEMORY")) cfg.pair_memory = getenv("KS_PAIR_MEMORY")[0] != '0';      // experiment switch
+        if (getenv("KS_EVENT_STRIDE")) ev_stride = atoi(getenv("KS_EVENT_STRIDE")) > 0 ? atoi(getenv("KS_EVENT_STRIDE")) : 1;
         if ((r = alloc(&b.qpos, NQ * N))) return r;
         if ((r = alloc(&b.qvel, NV * N))) return r;
         if ((r = alloc(&b.warm, NV * N))) return r;
@@ -1014,7 +1017,8 @@ template <typename T> struct Ctx : CtxBase {
         if (!model_loaded) { error = "ks_step before ks_load_model"; return KS_ERR_STATE; }
         if (!action) { error = "ks_step: action is NULL"; return KS_ERR_INVALID; }
         const int N = cfg.n_envs;
-        const bool timed = ev_used < NEV;
+        // ks_kernel_time's samples: every ev_stride-th launch is bracketed by two events (each costs ~4 us of stream time)
+        const bool timed = ev_used < NEV && (step_calls++ % ev_stride) == 0;
         const ObsOut<T> out{(T*)obs, (T*)reward, done, (T*)info, (T*)final_obs, cfg.horizon, cfg.auto_reset, cfg.obs_env_major};
         const bool same = out.obs == out_sent.obs && out.reward == out_sent.reward && out.done == out_sent.done && out.info == out_sent.info &&
                           out.final_obs == out_sent.final_obs && out.horizon == out_sent.horizon && out.auto_reset == out_sent.auto_reset &&
@@ -1090,7 +1094,7 @@ template <typename T> struct Ctx : CtxBase {
         ev_used = 0;
         if (avg_ms) *avg_ms = ev_launches ? ev_ms / (double)ev_launches : 0.0;
         if (launches) *launches = ev_launches;
-        if (reset) { ev_ms = 0; ev_launches = 0; }
+        if (reset) { ev_ms = 0; ev_launches = 0; step_calls = 0; }
         return KS_OK;
     }
 };
