@@ -629,20 +629,13 @@ template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model
     if (live && g == 1) b.rays[(long)ray * N + env] = best;
 }
 
-// One env's episode bookkeeping + observation.
-// mode 0: after a step (reward / done / time limit / auto-reset flagging); mode 1: after a reset
-// (observation of flagged envs only, flag cleared); mode 2: observation / reward / lifted flag of whatever snapshot and
-// rays the buffers hold, no episode bookkeeping (ks_obs_from_snapshot, the parity hook for the env-layer golden vectors).
-// `snap` reads the env's snapshot, `rays` its 17 distances, `rscr` is scratch for an auto-reset's forward kinematics (the
-// body-pose part of a stepping block, SCR_CON words).  The observation is written straight to where it belongs (the
-// termination test runs first), nothing of it is kept in registers.
-template <typename T, typename SnapT, typename ScrT>
-__device__ __forceinline__ void obs_epilogue(const Model<T>& m, const Buffers<T>& b, int env, int N, int mode, const ObsOut<T>& o, SnapT snap,
-                                             const T* rays, ScrT rscr) {
+// phase 1 (part = -1: all of it; 0..3: that quarter of the slots, see build_obs): the observation, straight to its destination
+template <typename T, typename SnapT>
+__device__ __forceinline__ void obs_write(const Model<T>& m, const Buffers<T>& b, int env, int N, int mode, const ObsOut<T>& o, SnapT snap,
+                                          const T* rays, int part) {
     const bool lifted0 = object_lifted(m, snap);
     uint8_t d = 0;
-    int sc = 0;
-    if (mode == 0) { sc = b.step_count[env] + 1; b.step_count[env] = sc; }
+    const int sc = mode == 0 ? b.step_count[env] + 1 : 0;            // (the counter itself is advanced in obs_finish)
     if (mode == 0 || mode == 2) d = (lifted0 ? 1 : 0) | ((mode == 0 && o.horizon > 0 && sc >= o.horizon) ? 2 : 0);
     const bool restart = mode == 0 && d && o.auto_reset;
     // the episode is over: this observation is the terminal one (final_obs); the env restarts from its stored initial state,
@@ -655,15 +648,26 @@ __device__ __forceinline__ void obs_epilogue(const Model<T>& m, const Buffers<T>
     build_obs(m, snap, rays, [&](int j, T v) {
         if (dst) dst[base + j * stride] = v;
         if (keep) keep[j] = v;
-    }, rew, lifted, inf);
-    // one decision for done, reward and the destination: the early test's (the same arithmetic; this only rules out the two
-    // inlined copies ever being contracted differently by the compiler)
-    rew = lifted0 ? T(50) : T(0);
-    inf[2] = rew;
+    }, rew, lifted, inf, part);
+}
+
+// phase 2 (after every part of phase 1 has read the snapshot): counters, reward, flags, and the restart of a finished episode
+template <typename T, typename SnapT, typename ScrT>
+__device__ __forceinline__ void obs_finish(const Model<T>& m, const Buffers<T>& b, int env, int N, int mode, const ObsOut<T>& o, SnapT snap, ScrT rscr) {
+    // one decision for done, reward and the destination: object_lifted's (the same arithmetic as build_obs' own test; this only
+    // rules out two inlined copies ever being contracted differently by the compiler)
+    const bool lifted0 = object_lifted(m, snap);
+    uint8_t d = 0;
+    int sc = 0;
+    if (mode == 0) { sc = b.step_count[env] + 1; b.step_count[env] = sc; }
+    if (mode == 0 || mode == 2) d = (lifted0 ? 1 : 0) | ((mode == 0 && o.horizon > 0 && sc >= o.horizon) ? 2 : 0);
+    const bool restart = mode == 0 && d && o.auto_reset;
+    const long base = o.env_major ? (long)env * NOBS : (long)env, stride = o.env_major ? 1 : (long)N;
+    const T rew = lifted0 ? T(50) : T(0);
     if (mode == 0 || mode == 2) {
         if (o.reward) o.reward[env] = rew;
         if (o.done) o.done[env] = d;
-        if (o.info) { o.info[env] = inf[0]; o.info[(long)N + env] = inf[1]; o.info[2L * N + env] = inf[2]; }
+        if (o.info) { o.info[env] = T(0); o.info[(long)N + env] = T(0); o.info[2L * N + env] = rew; }
     }
     if (restart) {
         if (o.obs) {
@@ -684,6 +688,20 @@ __device__ __forceinline__ void obs_epilogue(const Model<T>& m, const Buffers<T>
     }
 }
 
+// One env's episode bookkeeping + observation.
+// mode 0: after a step (reward / done / time limit / auto-reset flagging); mode 1: after a reset
+// (observation of flagged envs only, flag cleared); mode 2: observation / reward / lifted flag of whatever snapshot and
+// rays the buffers hold, no episode bookkeeping (ks_obs_from_snapshot, the parity hook for the env-layer golden vectors).
+// `snap` reads the env's snapshot, `rays` its 17 distances, `rscr` is scratch for an auto-reset's forward kinematics (the
+// body-pose part of a stepping block, SCR_CON words).  The observation is written straight to where it belongs (the
+// termination test runs first), nothing of it is kept in registers.
+template <typename T, typename SnapT, typename ScrT>
+__device__ __forceinline__ void obs_epilogue(const Model<T>& m, const Buffers<T>& b, int env, int N, int mode, const ObsOut<T>& o, SnapT snap,
+                                             const T* rays, ScrT rscr) {
+    obs_write(m, b, env, N, mode, o, snap, rays, -1);
+    obs_finish(m, b, env, N, mode, o, snap, rscr);
+}
+
 template <typename T>
 __global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ models, Buffers<T> b, int N, int mode, ObsOut<T> o) {
     __shared__ T rlds[SCR_CON * WAVE];      // scratch of an auto-reset's forward kinematics (body-pose part only, as in k_reset)
@@ -700,20 +718,26 @@ __global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ model
     obs_epilogue(models[b.obj_id[env]], b, env, N, mode, o, snap, rays, Scratch<T, KS_LDS T*>{(KS_LDS T*)rlds + threadIdx.x, WAVE});
 }
 
-// The tail of the stepping kernel (fp32 / LDS variant, after the rays): thread e < epw of the workgroup finishes env e's step -
-// time limit, termination, reward, the 82-d observation, the restart of a finished episode - from the env's snapshot and ray
-// distances in global memory (whoever cast the rays).  One thread per env, as in k_obs; what leaves the critical path is the
-// launch, its gap and the wait for the slowest workgroup before ANY env's observation could start.
+// The tail of the stepping kernel (fp32 / LDS variant, after the rays): the workgroup finishes its envs' step - the 82-d
+// observation (four waves, a quarter of the slots each), then per env the time limit, termination, reward and the restart of
+// a finished episode - from the env's snapshot and ray distances in global memory (whoever cast the rays).  What leaves the
+// critical path against a k_obs launch is the launch, its gap and the wait for the slowest workgroup before ANY env's
+// observation could start.
 __device__ __noinline__ void wg_obs(const Model<float>& m, const Buffers<float>& b, int N, int slot0, int epw, KS_LDS unsigned* w, const ObsOut<float>& o) {
     KS_LDS float* rscr = (KS_LDS float*)(w + wg_rays_words(epw) + epw * (NRAY + 1));
-    const int e = threadIdx.x;
-    if (e >= epw) return;
-    const int env = b.slot_env[slot0 + e];
-    if (env < 0) return;
-    float rays[NRAY];
-    KS_UNROLL
-    for (int r = 0; r < NRAY; r++) rays[r] = b.rays[(long)r * N + env];
-    obs_epilogue(m, b, env, N, 0, o, Col<float>{b.snap + env, N}, rays, ScratchC<float, KS_LDS float*>{rscr + e * (SCR_CON + 1)});
+    // team-parallel: wave p of the workgroup writes part p of the 82 slots (build_obs) of env e = lane, for the 16 envs at once -
+    // four instruction streams of a quarter of the length on the four SIMDs; then one thread per env finishes the step
+    const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int env = e < epw ? b.slot_env[slot0 + e] : -1;
+    if (env >= 0 && part < 4) {
+        float rays[NRAY];
+        KS_UNROLL
+        for (int r = 0; r < NRAY; r++) rays[r] = b.rays[(long)r * N + env];
+        obs_write(m, b, env, N, 0, o, Col<float>{b.snap + env, N}, rays, part);
+    }
+    __syncthreads();                                    // every part has read the snapshot (a restart overwrites it)
+    if (env >= 0 && part == 0)
+        obs_finish(m, b, env, N, 0, o, Col<float>{b.snap + env, N}, ScratchC<float, KS_LDS float*>{rscr + e * (SCR_CON + 1)});
 }
 
 __device__ __forceinline__ int pool_wait(const int32_t* p, bool& ok) {

@@ -361,7 +361,10 @@ KS_HD bool object_lifted(const Model<T>& m, C snap) {
 // Full local observation + reward from a snapshot and the 17 ray distances.
 // obs is written through `put(j, value)`.
 template <typename T, typename C, typename Put>
-KS_HD void build_obs(const Model<T>& m, C snap, const T* rays, Put put, T& reward, bool& lifted, T* info) {
+KS_HD void build_obs(const Model<T>& m, C snap, const T* rays, Put put, T& reward, bool& lifted, T* info, int part = -1) {
+    // part: -1 everything; 0..3 one quarter of the slots (the stepping kernel's tail gives the four waves of a workgroup one
+    // part each: 0 finger geometry (slots 0-17, 73-80), 1 / 2 the finger-site distances (36-41 / 42-47), 3 the rest + reward)
+    const bool all = part < 0, p0 = all || part == 0, p1 = all || part == 1, p2 = all || part == 2, p3 = all || part == 3;
     T R7[9], p7[3], Rpalm[9], ppalm[3], t[3];
     snap_body<T>(snap, 2, R7, p7);
     mulRR(Rpalm, R7, m.geom_R[1]);
@@ -370,9 +373,9 @@ KS_HD void build_obs(const Model<T>& m, C snap, const T* rays, Put put, T& rewar
     T T3[9], wrist[3];
     palm_transform(Rpalm, ppalm, T3, wrist);
     // finger link geom centres, order f1_prox f2_prox f3_prox f1_dist f2_dist f3_dist (ENV:478)
-    T fw[6][3], fl[18];
+    T fw[6][3] = {}, fl[18] = {};
     KS_UNROLL
-    for (int kq = 0; kq < 6; kq++) {
+    for (int kq = 0; kq < 6 && p0; kq++) {
         const int g = kq < 3 ? 2 + 2 * kq : 3 + 2 * (kq - 3);
         T R[9], p[3];
         snap_body<T>(snap, m.geom_body[g], R, p);
@@ -388,23 +391,28 @@ KS_HD void build_obs(const Model<T>& m, C snap, const T* rays, Put put, T& rewar
     add3(ow, po, t);
     sub3(t, ow, wrist);
     mulRv(ol, T3, t);
-    KS_UNROLL
-    for (int j = 0; j < 18; j++) put(j, fl[j]);
-    // wrist in its own frame: T3 (wrist - wrist) = 0 (ENV:513-516)
-    put(18, T(0)); put(19, T(0)); put(20, T(0));
-    put(21, ol[0]); put(22, ol[1]); put(23, ol[2]);
-    // joint states: jointpos sensors with the first two negated (ENV:356-362)
-    KS_UNROLL
-    for (int j = 0; j < 9; j++) {
-        T v = snap(SNAP_JPOS + j);
-        put(24 + j, j < 2 ? -v : v);
+    if (p0) {
+        KS_UNROLL
+        for (int j = 0; j < 18; j++) put(j, fl[j]);
     }
-    put(33, m.obj_size_obs[0]); put(34, m.obj_size_obs[1]); put(35, m.obj_size_obs[2]);
+    if (p3) {
+        // wrist in its own frame: T3 (wrist - wrist) = 0 (ENV:513-516)
+        put(18, T(0)); put(19, T(0)); put(20, T(0));
+        put(21, ol[0]); put(22, ol[1]); put(23, ol[2]);
+        // joint states: jointpos sensors with the first two negated (ENV:356-362)
+        KS_UNROLL
+        for (int j = 0; j < 9; j++) {
+            T v = snap(SNAP_JPOS + j);
+            put(24 + j, j < 2 ? -v : v);
+        }
+        put(33, m.obj_size_obs[0]); put(34, m.obj_size_obs[1]); put(35, m.obj_size_obs[2]);
+    }
     // finger-site to object distances (ENV:538-548), site order f1_prox f1_prox_1 f2_prox ... f1_dist ...
     {
         const int order[12] = {5, 6, 9, 10, 13, 14, 7, 8, 11, 12, 15, 16};
         KS_UNROLL
         for (int kq = 0; kq < 12; kq++) {
+            if (!(kq < 6 ? p1 : p2)) continue;
             const int si = order[kq];
             T R[9], p[3], sp[3], d[3];
             snap_body<T>(snap, m.site_body[si], R, p);
@@ -415,7 +423,7 @@ KS_HD void build_obs(const Model<T>& m, C snap, const T* rays, Put put, T& rewar
         }
     }
     // x / z angles (ENV:563-582)
-    {
+    if (p3) {
         // arccos(y / sqrt(y^2 + s^2)) == atan2(|s|, y): identical value, but well conditioned in
         // fp32 when the object sits on the palm centre line (ratio -> 1, SURVEY O2 caution)
         T za = katan2(kabs(ol[0]), ol[1]);
@@ -424,18 +432,11 @@ KS_HD void build_obs(const Model<T>& m, C snap, const T* rays, Put put, T& rewar
     }
     T rng[NRAY];
     KS_UNROLL
-    for (int i = 0; i < NRAY; i++) { rng[i] = rays[i] == T(-1) ? T(6) : rays[i]; put(50 + i, rng[i]); }
+    for (int i = 0; i < NRAY; i++) { rng[i] = rays[i] == T(-1) ? T(6) : rays[i]; if (p3) put(50 + i, rng[i]); }
     const T g[3] = {-T3[2], -T3[5], -T3[8]};
-    put(67, g[0]); put(68, g[1]); put(69, g[2]);
+    if (p3) { put(67, g[0]); put(68, g[1]); put(69, g[2]); }
     // experimental_sensor (ENV:290-343)
-    {
-        T s1[3], s2[3];
-        KS_UNROLL
-        for (int i = 0; i < 3; i++) { s1[i] = fl[i] - fl[6 + i]; s2[i] = fl[i] - fl[3 + i]; }
-        T front_area = tri_area(s1, s2);
-        T top1 = tri_area(&fl[0], &fl[9]), top2 = tri_area(&fl[9], &fl[12]), top3 = tri_area(&fl[3], &fl[12]);
-        T top4 = tri_area(&fl[6], &fl[15]), top5 = tri_area(&fl[9], &fl[15]);
-        T total1 = top1 + top2 + top3, total2 = top1 + top4 + top5, top_area = total1 > total2 ? total1 : total2;
+    if (p3) {
         T sx = 0, sy = 0, sz = 0, nh = 0;
         KS_UNROLL
         for (int i = 0; i < 5; i++) {
@@ -452,6 +453,15 @@ KS_HD void build_obs(const Model<T>& m, C snap, const T* rays, Put put, T& rewar
         }
         if (nh == 0) { put(70, T(0.2)); put(71, T(0.2)); put(72, T(0.2)); }
         else { put(70, sx / nh); put(71, sy / nh); put(72, sz / nh); }
+    }
+    if (p0) {
+        T s1[3], s2[3];
+        KS_UNROLL
+        for (int i = 0; i < 3; i++) { s1[i] = fl[i] - fl[6 + i]; s2[i] = fl[i] - fl[3 + i]; }
+        T front_area = tri_area(s1, s2);
+        T top1 = tri_area(&fl[0], &fl[9]), top2 = tri_area(&fl[9], &fl[12]), top3 = tri_area(&fl[3], &fl[12]);
+        T top4 = tri_area(&fl[6], &fl[15]), top5 = tri_area(&fl[9], &fl[15]);
+        T total1 = top1 + top2 + top3, total2 = top1 + top4 + top5, top_area = total1 > total2 ? total1 : total2;
         const T z0 = m.obj_size_obs[0], z1 = m.obj_size_obs[1], z2 = m.obj_size_obs[2] * T(0.5);
         int am = 0;
         if (kabs(g[1]) > kabs(g[am])) am = 1;
@@ -461,10 +471,10 @@ KS_HD void build_obs(const Model<T>& m, C snap, const T* rays, Put put, T& rewar
         else if (am == 1) { fp = kabs(z0 * z2) / front_area; tp = kabs(z1 * z2) / top_area; }
         else { fp = kabs(z0 * z1) / front_area; tp = kabs(z0 * z2) / top_area; }
         put(73, fp); put(74, tp);
+        KS_UNROLL
+        for (int kq = 0; kq < 6; kq++) put(75 + kq, dot_product20(fw[kq], p7));
     }
-    KS_UNROLL
-    for (int kq = 0; kq < 6; kq++) put(75 + kq, dot_product20(fw[kq], p7));
-    put(81, dot_product20(ow, p7));
+    if (p3) put(81, dot_product20(ow, p7));
     // reward / termination (ENV:631-687, with_grasp_reward False)
     const T target = T(0.2);
     lifted = (kabs(ow[2] - target) < T(0.005)) || (ow[2] >= target);
