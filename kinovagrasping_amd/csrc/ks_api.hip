@@ -56,6 +56,7 @@ template <typename T> struct Buffers {
     int32_t *wg_model;            // [n_wg]
     T *nominal;                   // [n_models][2] object mass / object-hand friction of every model as compiled
     // the ray pool of a stepping launch (wg_ray_pool): [0] tickets published, [1] tickets claimed, [2] workgroups that have left,
+    // [3] workgroups that have started,
     // [4 .. 4 + n_wg) the published workgroups in order, [4 + n_wg .. 4 + 2 n_wg) their done flags; all zero between launches
     int32_t *rayq;
 };
@@ -318,7 +319,10 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
     // ray pool: how many of the workgroup's 16 team slots have their snapshot out (last 16 bytes of the descriptor slot)
     static_assert(sizeof(Hulls<T>) <= HULLS_BYTES - 16, "Hulls descriptor slot + the arrival counter");
     KS_LDS int* arrive = (KS_LDS int*)(smem + (sizeof(Model<T>) + 15) / 16 * 16 + HULLS_BYTES - 16);
-    if (USE_LDS && threadIdx.x == 0) *arrive = 0;
+    if (USE_LDS && threadIdx.x == 0) {
+        *arrive = 0;
+        if (ray_pool) atomicAdd(&b.rayq[3], 1);                     // workgroups of this launch that have started
+    }
     if constexpr (USE_LDS) __syncthreads();         // the model copy is complete: the table staging reads its pointers and counts from LDS
     stage_hulls<T, USE_LDS>(*ml, lds, hull_words, *hup);
     const Hulls<T>& hu = *hup;
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
                 __syncthreads();
                 if (*last) {
                     for (int i = threadIdx.x; i < 2 * n_wg; i += WG) b.rayq[4 + i] = 0;
-                    if (threadIdx.x < 3) b.rayq[threadIdx.x] = 0;
+                    if (threadIdx.x < 4) b.rayq[threadIdx.x] = 0;
                 }
             }
         }
@@ -760,8 +764,9 @@ __device__ __forceinline__ int pool_wait(const int32_t* p, bool& ok) {
 //     owner was quicker, and casts its rays.  So when the slowest workgroups publish, hands are free at that moment and their
 //     rays are cast while they compute their last substep (~60 us) instead of behind it.
 //   * Everybody finally waits for its own ticket to be done (by itself or by a helper).
-// Only used when all workgroups of the launch are resident at once (one per CU): a helper waiting for a ticket of a
-// workgroup that cannot start until the helper leaves would never see it.
+// A workgroup only stays when every workgroup of the launch has STARTED (a counter at kernel entry): with more workgroups than
+// CUs (8192 envs: two rounds) a helper waiting for a ticket of a workgroup that cannot start until the helper leaves would
+// never see it.
 __device__ __noinline__ void wg_ray_pool(const Model<float>* models, const Model<float>& mine, const Buffers<float>& b, int N, int epw, KS_LDS unsigned* w,
                                          int n_wg, int linger) {
     int32_t* q = b.rayq;
@@ -775,7 +780,9 @@ __device__ __noinline__ void wg_ray_pool(const Model<float>* models, const Model
             int t = -1;
             if (!tried_own) {
                 tried_own = true;
-                late = linger && __hip_atomic_load(&q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= first_late;
+                // (every workgroup of the launch has started: nobody we might wait for is still queued behind the CUs we hold)
+                late = linger && __hip_atomic_load(&q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= first_late &&
+                       __hip_atomic_load(&q[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_wg;
                 if (atomicCAS(&state[own], 1, 2) == 1) t = own;
             }
             while (t < 0 && late) {
@@ -970,12 +977,9 @@ template <typename T> struct Ctx : CtxBase {
         if ((r = alloc(&b.slot_env, (size_t)n_wg * lpw))) return r;
         if ((r = alloc(&b.wg_model, (size_t)n_wg))) return r;
         if ((r = alloc(&b.rayq, (size_t)4 + 2 * (size_t)n_wg))) return r;
-        // the rays pooled over the launch (wg_ray_pool): early finishers linger for the slowest workgroup's ticket only when all
-        // workgroups are resident at once (one per CU); KS_RAY_POOL=0 makes every workgroup cast its own envs' rays
+        // the rays pooled over the launch (wg_ray_pool); KS_RAY_POOL=0 makes every workgroup cast its own envs' rays
         if (obs_in_step && cfg.frame_skip >= 1 && !(getenv("KS_RAY_POOL") && getenv("KS_RAY_POOL")[0] == '0')) {
-            hipDeviceProp_t prop;
-            HIPCHK(hipGetDeviceProperties(&prop, device));
-            ray_pool = n_wg <= prop.multiProcessorCount ? 2 : 0;
+            ray_pool = 2;
         }
         hipLaunchKernelGGL(k_slots, dim3(1), dim3(SLOT_THREADS), 0, 0, b.obj_id, cfg.n_envs, n_models, lpw, n_wg, b.slot_env, b.wg_model);
         HIPCHK(hipGetLastError());
