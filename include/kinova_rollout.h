@@ -139,6 +139,16 @@ int kr_mlp3_forward_shadow(int32_t n, int32_t in_a, int32_t in_b, int32_t h1, in
  *   kr_weight_grad_shadow     dW [M,N] = dz^T [ha | hb]  and  db [M] = column sums of dz, dz [n,M], ha [n,>=Na] (row stride
  *                             lda), hb [n,>=Nb] (ldb; Nb = 0: unused); the batch rows are split into `chunks` partial sums
  *                             in `workspace` (chunks * (M*N + M) floats) that a second launch adds up in chunk order. */
+/* kr_mlp3_forward_shadow with the tiles of each layer split over `waves` (2 or 4) wavefronts of a workgroup: the same LDS-free
+ * launch at ~1/waves of the latency (one wave per 16 rows is a serial chain of ~1400 MFMAs: 87 us whatever the batch).  The
+ * waves exchange layer 1's output through global memory: h1_out when the caller keeps it, else `scratch`; scratch_floats >=
+ * (h1_out ? 0 : ceil(n/16)*16*h1) + ceil(n/16)*waves*64.  Layers 1 and 2 are bitwise those of kr_mlp3_forward_shadow, layer 3's
+ * sum is associated per wave (deterministic). */
+int kr_mlp3_forward_split(int32_t n, int32_t in_a, int32_t in_b, int32_t h1, int32_t h2, int32_t out_dim, const float *xa, int32_t lda,
+                          const float *xb, int32_t ldb, const float *W1, const float *b1, const float *W2, const float *b2,
+                          const float *W3, const float *b3, int32_t act, float scale, float *out, float *h1_out, float *h2_out,
+                          float *scratch, int64_t scratch_floats, int32_t waves, void *stream);
+
 int kr_mlp3_backward_shadow(int32_t n, int32_t in_dim, int32_t h1, int32_t h2, int32_t out_dim, const float *dz3, const float *W3,
                             const float *h2a, const float *W2, const float *h1a, float *dz2_out, float *dz1_out, const float *W1,
                             int32_t col0, int32_t ncol, const float *act_out, float scale, float *dx_out, void *stream);

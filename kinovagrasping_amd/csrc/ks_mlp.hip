@@ -300,6 +300,115 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     }
 }
 
+// ---- the LDS-free network with the tiles of a layer SPLIT over NWS waves of one workgroup (still 16 batch rows per workgroup).
+// One wave per 16 rows is a serial chain of ~1400 MFMAs fed by ~1400 weight loads: 87 us whatever the batch, and the learner's
+// five forward passes are more than half of an update that - early in training - is what an env-step waits for.  Here wave w
+// computes the layer-1 tiles t = w (mod NWS), the waves exchange their output quads through global memory (the caller's
+// h1_out, or scratch; L2 resident, read back with glc loads) across a workgroup barrier - no LDS, so the kernel still runs
+// beside the stepping kernel - then wave w computes the layer-2 tiles t = w (mod NWS) and its share of layer 3, whose partial
+// sums meet in scratch (summed in wave order: deterministic).  Per output element the layer-1 / layer-2 fma chains are those
+// of k_mlp3_wave; only layer 3's sum is associated differently.
+template <int NT1, int NT2, int NWS>
+__global__ __launch_bounds__(64 * NWS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_mlp3_split(
+    int n, int in_a, int in_b, int h1, int h2, int out_dim, const float* __restrict__ xa, int lda, const float* __restrict__ xb, int ldb,
+    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+    const float* __restrict__ W3, const float* __restrict__ b3, int act, float scale, float* __restrict__ out, float* __restrict__ h1buf,
+    int h1_rows, float* __restrict__ h2_out, float* __restrict__ partial) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nn = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * ROWS + nn;
+    const bool row_ok = row < n;
+    const int in_dim = in_a + in_b;
+    const auto rW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W1), 0, h1 * in_dim * 4, 0x00020000);
+    const auto rW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W2), 0, h2 * h1 * 4, 0x00020000);
+    const auto rW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W3), 0, out_dim * h2 * 4, 0x00020000);
+    const auto rXa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xa), 0, ((n - 1) * lda + in_a) * 4, 0x00020000);
+    const auto rXb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb ? xb : xa), 0, xb ? ((n - 1) * ldb + in_b) * 4 : 0, 0x00020000);
+    const auto rH1 = __builtin_amdgcn_make_buffer_rsrc(h1buf, 0, h1_rows * h1 * 4, 0x00020000);
+#define KS_LDF(rsrc, voff, soff) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0))
+    constexpr int OOR = 0x7ffffff0;
+    {
+        f32x4 bx[KS_IN_MAX];
+        const int oa = row * lda * 4 + 16 * q, ob = (row * ldb + 4 * q - in_a) * 4;
+#pragma unroll
+        for (int s = 0; s < KS_IN_MAX; s++) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = 16 * s + 4 * q + j;
+                const float fa = KS_LDF(rXa, (row_ok && k < in_a) ? oa : OOR, (16 * s + j) * 4);
+                const float fb = KS_LDF(rXb, (row_ok && k >= in_a && k < in_dim) ? ob + (16 * s + j) * 4 : OOR, 0);
+                v[j] = k < in_a ? fa : fb;
+            }
+            bx[s] = f32x4{v[0], v[1], v[2], v[3]};
+        }
+        const int o1 = (nn * in_dim + 4 * q) * 4;
+#pragma unroll 1
+        for (int t = wave; t < NT1; t += NWS) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS_IN_MAX; s++) {
+                const int so = (16 * t * in_dim + 16 * s) * 4, k0 = 16 * s + 4 * q;
+                const f32x4 w = {KS_LDF(rW1, k0 < in_dim ? o1 : OOR, so), KS_LDF(rW1, k0 + 1 < in_dim ? o1 : OOR, so + 4),
+                                 KS_LDF(rW1, k0 + 2 < in_dim ? o1 : OOR, so + 8), KS_LDF(rW1, k0 + 3 < in_dim ? o1 : OOR, so + 12)};
+                if (s & 1) acc1 = mfma4(w, bx[s], acc1);
+                else acc0 = mfma4(w, bx[s], acc0);
+            }
+            const f32x4 hq = bias_relu(acc0 + acc1, b1, t * 16 + 4 * q, h1);
+            if (row < h1_rows) *(f32x4*)(h1buf + (long)row * h1 + t * 16 + 4 * q) = hq;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // every wave takes the whole layer-1 output of its 16 rows as B operands (glc: written by the other waves of this workgroup)
+    f32x4 h1r[NT1];
+    {
+        const int oh = row < h1_rows ? (row * h1 + 4 * q) * 4 : OOR;
+#pragma unroll
+        for (int s = 0; s < NT1; s++) h1r[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rH1, oh, 16 * s * 4, 1));
+    }
+    f32x4 acc3 = {0.f, 0.f, 0.f, 0.f};
+    const int o2 = (nn * h1 + 4 * q) * 4;
+    const int o3 = (nn * h2 + 4 * q) * 4;
+#pragma unroll 1
+    for (int t = wave; t < NT2; t += NWS) {
+        f32x4 w[NT1];
+#pragma unroll
+        for (int s = 0; s < NT1; s++)
+            w[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW2, o2, (16 * t * h1 + 16 * s) * 4, 0));
+        const f32x4 w3 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW3, nn < out_dim ? o3 : OOR, 16 * t * 4, 0));
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NT1; s++) {
+            if (s & 1) acc1 = mfma4(w[s], h1r[s], acc1);
+            else acc0 = mfma4(w[s], h1r[s], acc0);
+        }
+        const f32x4 hq = bias_relu(acc0 + acc1, b2, t * 16 + 4 * q, h2);
+        if (h2_out && row_ok) *(f32x4*)(h2_out + (long)row * h2 + t * 16 + 4 * q) = hq;
+        acc3 = mfma4(w3, hq, acc3);
+    }
+#undef KS_LDF
+    // layer 3: the waves' partial sums (lanes q == 0 hold the <= 4 outputs of row nn) meet in scratch
+    float* pw = partial + ((long)blockIdx.x * NWS + wave) * 64;
+    if (q == 0) *(f32x4*)(pw + 4 * nn) = acc3;
+    __threadfence_block();
+    __syncthreads();
+    if (wave == 0 && q == 0 && row_ok) {
+        const auto rP = __builtin_amdgcn_make_buffer_rsrc(partial + (long)blockIdx.x * NWS * 64, 0, NWS * 64 * 4, 0x00020000);
+        f32x4 z4 = acc3;
+#pragma unroll
+        for (int w = 1; w < NWS; w++) {
+            const f32x4 p = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rP, (w * 64 + 4 * nn) * 4, 0, 1));
+            z4 += p;
+        }
+        const float z[4] = {z4.x, z4.y, z4.z, z4.w};
+        for (int i = 0; i < out_dim; i++) {
+            float y = z[i] + b3[i];
+            if (act == KR_ACT_SIGMOID) y = scale / (1.f + __expf(-y));
+            out[(long)row * out_dim + i] = y;
+        }
+    }
+}
+
 // ---- backward of the same network, also without LDS (one wave = 16 batch rows).
 // Data gradients: with dz3 = dLoss/d(output pre-activation) [n, out_dim],
 //     dz2 = (dz3 W3) * [h2 > 0],   dz1 = (dz2 W2) * [h1 > 0],   dx = dz1 W1[:, col0 : col0 + ncol]   (optional)
@@ -564,6 +673,38 @@ int kr_mlp3_forward_shadow(int32_t n, int32_t in_a, int32_t in_b, int32_t h1, in
     KR_WAVE_CASE(8, 8)
     KR_WAVE_CASE(4, 4)
 #undef KR_WAVE_CASE
+    return KS_ERR_INVALID;
+}
+
+int kr_mlp3_forward_split(int32_t n, int32_t in_a, int32_t in_b, int32_t h1, int32_t h2, int32_t out_dim, const float* xa, int32_t lda,
+                          const float* xb, int32_t ldb, const float* W1, const float* b1, const float* W2, const float* b2,
+                          const float* W3, const float* b3, int32_t act, float scale, float* out, float* h1_out, float* h2_out,
+                          float* scratch, int64_t scratch_floats, int32_t waves, void* stream) {
+    if (n <= 0) return KS_OK;
+    if (((h1_out && (h1 % 4 || (uintptr_t)h1_out % 16)) || (h2_out && (h2 % 4 || (uintptr_t)h2_out % 16)))) return KS_ERR_INVALID;
+    if (!xa || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out || in_a <= 0 || in_b < 0 || (in_b > 0 && !xb)) return KS_ERR_INVALID;
+    if (in_a + in_b > 16 * KS_IN_MAX || out_dim < 1 || out_dim > 4 || h1 < 1 || h2 < 1) return KS_ERR_INVALID;
+    if (act != KR_ACT_NONE && act != KR_ACT_SIGMOID) return KS_ERR_INVALID;
+    if (h1 % 16 || h2 % 16 || (uintptr_t)W2 % 16 || (uintptr_t)W3 % 16 || (waves != 2 && waves != 4)) return KS_ERR_INVALID;
+    const int nt1 = h1 / 16, nt2 = h2 / 16, blocks = (n + ROWS - 1) / ROWS;
+    // scratch: [the layer-1 exchange, blocks x 16 rows x h1, unless the caller keeps h1 itself][blocks x waves x 64 partial sums]
+    const int64_t need = (h1_out ? 0 : (int64_t)blocks * ROWS * h1) + (int64_t)blocks * waves * 64;
+    if (!scratch || (uintptr_t)scratch % 16 || scratch_floats < need) return KS_ERR_INVALID;
+    float* h1buf = h1_out ? h1_out : scratch;
+    const int h1_rows = h1_out ? n : blocks * ROWS;
+    float* partial = scratch + (h1_out ? 0 : (int64_t)blocks * ROWS * h1);
+    const dim3 grid(blocks);
+    hipStream_t s = (hipStream_t)stream;
+#define KR_SPLIT_CASE(A, B, NWS)                                                                                                               \
+    if (nt1 == A && nt2 == B && waves == NWS) {                                                                                                \
+        hipLaunchKernelGGL((k_mlp3_split<A, B, NWS>), grid, dim3(64 * NWS), 0, s, n, in_a, in_b, h1, h2, out_dim, xa, lda, xb, ldb, W1, b1, W2, b2, \
+                           W3, b3, act, scale, out, h1buf, h1_rows, h2_out, partial);                                                          \
+        return hipGetLastError() == hipSuccess ? KS_OK : KS_ERR_HIP;                                                                           \
+    }
+    KR_SPLIT_CASE(16, 16, 4) KR_SPLIT_CASE(16, 16, 2)
+    KR_SPLIT_CASE(8, 8, 4) KR_SPLIT_CASE(8, 8, 2)
+    KR_SPLIT_CASE(4, 4, 4) KR_SPLIT_CASE(4, 4, 2)
+#undef KR_SPLIT_CASE
     return KS_ERR_INVALID;
 }
 

@@ -25,6 +25,16 @@ def supported(layers, in_dim: int, shadow: bool = False) -> bool:
             and all(w.is_contiguous() and b.is_contiguous() for w, b in layers))
 
 
+def _split_waves(n: int) -> int:
+    """waves per workgroup of the split LDS-free forward: 4 while the launch still fits the GPU in one round beside the
+    stepping kernel (one learner wave per SIMD: 1024 of them), 2 for larger batches; KS_MLP_SPLIT=0 / 2 / 4 forces."""
+    import os
+    forced = os.environ.get("KS_MLP_SPLIT")
+    if forced is not None:
+        return int(forced)
+    return 4 if (n + 15) // 16 * 4 <= 1024 else 2
+
+
 def mlp3_forward(layers, xa: torch.Tensor, xb: torch.Tensor | None = None, act: int = ACT_NONE, scale: float = 1.0,
                  out: torch.Tensor | None = None, h1_out: torch.Tensor | None = None, h2_out: torch.Tensor | None = None,
                  shadow: bool = False) -> torch.Tensor:
@@ -43,6 +53,18 @@ def mlp3_forward(layers, xa: torch.Tensor, xb: torch.Tensor | None = None, act: 
     for h, w in ((h1_out, w1), (h2_out, w2)):
         assert h is None or (h.is_contiguous() and tuple(h.shape) == (n, w.shape[0]) and h.dtype == torch.float32)
     lib, P = _sim.load_library(), _sim._ptr
+    waves = _split_waves(n) if shadow and w1.shape[0] % 16 == 0 and w2.shape[0] % 16 == 0 and w1.shape[0] // 16 in (4, 8, 16) and w1.shape[0] == w2.shape[0] else 0
+    if waves:
+        # the LDS-free launch with each layer's tiles split over 2 / 4 waves of a workgroup (kr_mlp3_forward_split)
+        blocks = (n + 15) // 16
+        need = (0 if h1_out is not None else blocks * 16 * w1.shape[0]) + blocks * waves * 64
+        scratch = torch.empty(need, device=xa.device, dtype=torch.float32)
+        rc = lib.kr_mlp3_forward_split(n, in_a, in_b, w1.shape[0], w2.shape[0], w3.shape[0], P(xa), xa.stride(0), P(xb) if xb is not None else None,
+                                       xb.stride(0) if xb is not None else 0, P(w1), P(b1), P(w2), P(b2), P(w3), P(b3), act, float(scale), P(out),
+                                       P(h1_out), P(h2_out), P(scratch), need, waves, ctypes.c_void_p(torch.cuda.current_stream(xa.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"kr_mlp3_forward_split failed ({rc})")
+        return out
     rc = (lib.kr_mlp3_forward_shadow if shadow else lib.kr_mlp3_forward)(n, in_a, in_b, w1.shape[0], w2.shape[0], w3.shape[0], P(xa), xa.stride(0), P(xb) if xb is not None else None,
                              xb.stride(0) if xb is not None else 0, P(w1), P(b1), P(w2), P(b2), P(w3), P(b3), act, float(scale), P(out), P(h1_out), P(h2_out),
                              ctypes.c_void_p(torch.cuda.current_stream(xa.device).cuda_stream))
