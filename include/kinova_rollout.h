@@ -152,6 +152,13 @@ int kr_mlp3_forward_split(int32_t n, int32_t in_a, int32_t in_b, int32_t h1, int
 int kr_mlp3_backward_shadow(int32_t n, int32_t in_dim, int32_t h1, int32_t h2, int32_t out_dim, const float *dz3, const float *W3,
                             const float *h2a, const float *W2, const float *h1a, float *dz2_out, float *dz1_out, const float *W1,
                             int32_t col0, int32_t ncol, const float *act_out, float scale, float *dx_out, void *stream);
+
+/* kr_mlp3_backward_shadow with the dz1 tiles split over `waves` (2 or 4) wavefronts of a workgroup (as kr_mlp3_forward_split);
+ * scratch (only used for dx_out: >= ceil(n/16) * waves * 64 floats) holds the waves' partial sums of dx, added in wave order. */
+int kr_mlp3_backward_split(int32_t n, int32_t in_dim, int32_t h1, int32_t h2, int32_t out_dim, const float *dz3, const float *W3,
+                           const float *h2a, const float *W2, const float *h1a, float *dz2_out, float *dz1_out, const float *W1, int32_t col0,
+                           int32_t ncol, const float *act_out, float scale, float *dx_out, float *scratch, int64_t scratch_floats,
+                           int32_t waves, void *stream);
 int kr_weight_grad_shadow(int32_t n, int32_t M, int32_t Na, int32_t Nb, const float *dz, const float *ha, int32_t lda, const float *hb,
                           int32_t ldb, int32_t chunks, float *workspace, float *dW, float *db, void *stream);
 

@@ -509,6 +509,112 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     }
 }
 
+// ... and with the tiles of dz1 split over NWS waves of a workgroup (as k_mlp3_split): every wave computes dz2 itself (one MFMA per
+// tile), wave w the dz1 tiles t = w (mod NWS); the partial sums of dx meet in scratch, summed in wave order.
+template <int NT1, int NT2, int NWS>
+__global__ __launch_bounds__(64 * NWS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_mlp3_bwd_split(
+    int n, int in_dim, int h1, int h2, int out_dim, const float* __restrict__ dz3, const float* __restrict__ W3, const float* __restrict__ h2a,
+    const float* __restrict__ W2, const float* __restrict__ h1a, float* __restrict__ dz2_out, float* __restrict__ dz1_out,
+    const float* __restrict__ W1, int col0, int ncol, const float* __restrict__ act_out, float scale, float* __restrict__ dx_out,
+    float* __restrict__ partial) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nn = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * ROWS + nn;
+    const bool row_ok = row < n;
+    // B operand of the first product: dz3^T, k = output index = q
+    const float b3 = (row_ok && q < out_dim) ? dz3[(long)row * out_dim + q] : 0.f;
+    f32x4 dz2r[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; t++) {
+        const int f = t * 16 + nn;                                          // A: W3^T[f][k = q] = W3[q][f]
+        const float a3 = (q < out_dim && f < h2) ? W3[(long)q * h2 + f] : 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc, 0, 0, 0);
+        const int f4 = t * 16 + 4 * q;
+        f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+        if (row_ok && f4 < h2) hv = *(const f32x4*)(h2a + (long)row * h2 + f4);
+        f32x4 dz;
+        dz.x = hv.x > 0.f ? acc.x : 0.f; dz.y = hv.y > 0.f ? acc.y : 0.f; dz.z = hv.z > 0.f ? acc.z : 0.f; dz.w = hv.w > 0.f ? acc.w : 0.f;
+        dz2r[t] = dz;
+        if (dz2_out && row_ok && f4 < h2 && t % NWS == wave) *(f32x4*)(dz2_out + (long)row * h2 + f4) = dz;
+    }
+    f32x4 accx = {0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W2), 0, h1 * h2 * 4, 0x00020000);
+#pragma unroll 1
+    for (int t = wave; t < NT1; t += NWS) {
+        // A: W2^T[f][k] = W2[k][f], k = 16 s + 4 q + j (rows of W2, stride h1), f = 16 t + nn
+        const int f = t * 16 + nn;
+        // (host checks h1 % 16 == h2 % 16 == 0: every row / column of the tile exists).  Buffer loads: ONE 32-bit lane
+        // offset for the whole tile, the row steps (16 s + j) * h1 are wave-uniform and go in the scalar offset - flat
+        // loads would hold a 64-bit address per load in flight and spill at this register budget.
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const int voff = (4 * q * h1 + f) * 4;
+        constexpr int HALF = (NT2 + 1) / 2;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            f32x4 w[HALF];
+#pragma unroll
+            for (int u = 0; u < HALF; u++) {
+                const int s = half * HALF + u;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (s < NT2) {
+                    v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW2, voff, (16 * s + 0) * h1 * 4, 0));
+                    v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW2, voff, (16 * s + 1) * h1 * 4, 0));
+                    v.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW2, voff, (16 * s + 2) * h1 * 4, 0));
+                    v.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW2, voff, (16 * s + 3) * h1 * 4, 0));
+                }
+                w[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < HALF; u++) {
+                const int s = half * HALF + u;
+                if (s < NT2) {
+                    if (s & 1) acc1 = mfma4(w[u], dz2r[s], acc1);
+                    else acc0 = mfma4(w[u], dz2r[s], acc0);
+                }
+            }
+        }
+        const f32x4 acc = acc0 + acc1;
+        const int f4 = t * 16 + 4 * q;
+        f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+        if (row_ok && f4 < h1) hv = *(const f32x4*)(h1a + (long)row * h1 + f4);
+        f32x4 dz;
+        dz.x = hv.x > 0.f ? acc.x : 0.f; dz.y = hv.y > 0.f ? acc.y : 0.f; dz.z = hv.z > 0.f ? acc.z : 0.f; dz.w = hv.w > 0.f ? acc.w : 0.f;
+        if (dz1_out && row_ok && f4 < h1) *(f32x4*)(dz1_out + (long)row * h1 + f4) = dz;
+        if (dx_out) {
+            // A: W1[:, col0 + m]^T: [m][k] = W1[k][col0 + m], k = 16 t + 4 q + j (rows of W1, stride in_dim), m = nn < ncol
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (nn < ncol) {
+                const int k = 16 * t + 4 * q;
+                const float* p = W1 + (long)k * in_dim + col0 + nn;
+                if (k < h1) v.x = p[0];
+                if (k + 1 < h1) v.y = p[in_dim];
+                if (k + 2 < h1) v.z = p[2 * (long)in_dim];
+                if (k + 3 < h1) v.w = p[3 * (long)in_dim];
+            }
+            accx = mfma4(v, dz, accx);
+        }
+    }
+    if (dx_out) {
+        float* pw = partial + ((long)blockIdx.x * NWS + wave) * 64;
+        if (q == 0) *(f32x4*)(pw + 4 * nn) = accx;
+        __threadfence_block();
+        __syncthreads();
+        if (wave == 0 && q == 0) {
+            const auto rP = __builtin_amdgcn_make_buffer_rsrc(partial + (long)blockIdx.x * NWS * 64, 0, NWS * 64 * 4, 0x00020000);
+#pragma unroll
+            for (int w = 1; w < NWS; w++) accx += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rP, (w * 64 + 4 * nn) * 4, 0, 1));
+        }
+    }
+    if (dx_out && wave == 0 && q == 0 && row_ok) {
+        const float g[4] = {accx.x, accx.y, accx.z, accx.w};
+        for (int i = 0; i < ncol; i++) {
+            float v = g[i];
+            if (act_out) { const float a = act_out[(long)row * ncol + i]; v *= a * (1.f - a / scale); }
+            dx_out[(long)row * ncol + i] = v;
+        }
+    }
+}
+
 // Weight gradients  dW[M][N] = dz^T h  (dz [n][M], h = [ha | hb] [n][N]) and the bias gradient  db[M] = column sums of dz,
 // without LDS: a wave owns one 16-row tile of dW and TN 16-column tiles, and one chunk of the batch rows; A = dz^T
 // (lane: feature m, row k), B = h (lane: row k, column).  The chunk partials go to a workspace [chunk][M * N + M] that
@@ -728,6 +834,31 @@ int kr_mlp3_backward_shadow(int32_t n, int32_t in_dim, int32_t h1, int32_t h2, i
     KR_BWD_CASE(8, 8)
     KR_BWD_CASE(4, 4)
 #undef KR_BWD_CASE
+    return KS_ERR_INVALID;
+}
+
+int kr_mlp3_backward_split(int32_t n, int32_t in_dim, int32_t h1, int32_t h2, int32_t out_dim, const float* dz3, const float* W3,
+                            const float* h2a, const float* W2, const float* h1a, float* dz2_out, float* dz1_out, const float* W1, int32_t col0,
+                            int32_t ncol, const float* act_out, float scale, float* dx_out, float* scratch, int64_t scratch_floats, int32_t waves, void* stream) {
+    if (n <= 0) return KS_OK;
+    if (!dz3 || !W3 || !h2a || !W2 || !h1a || out_dim < 1 || out_dim > 4 || h1 < 16 || h2 < 16 || h1 % 16 || h2 % 16) return KS_ERR_INVALID;
+    if (dx_out && (!W1 || ncol < 1 || ncol > 4 || col0 < 0 || col0 + ncol > in_dim)) return KS_ERR_INVALID;
+    if ((uintptr_t)h1a % 16 || (uintptr_t)h2a % 16 || (dz1_out && (uintptr_t)dz1_out % 16) || (dz2_out && (uintptr_t)dz2_out % 16)) return KS_ERR_INVALID;
+    const int nt1 = (h1 + 15) / 16, nt2 = (h2 + 15) / 16;
+    if ((waves != 2 && waves != 4) || (dx_out && (!scratch || (uintptr_t)scratch % 16 || scratch_floats < (int64_t)((n + ROWS - 1) / ROWS) * waves * 64)))
+        return KS_ERR_INVALID;
+    const dim3 grid((n + ROWS - 1) / ROWS);
+    hipStream_t s = (hipStream_t)stream;
+#define KR_BWDS_CASE(A, B, NWS)                                                                                                              \
+    if (nt1 == A && nt2 == B && waves == NWS) {                                                                                              \
+        hipLaunchKernelGGL((k_mlp3_bwd_split<A, B, NWS>), grid, dim3(64 * NWS), 0, s, n, in_dim, h1, h2, out_dim, dz3, W3, h2a, W2, h1a, dz2_out, \
+                           dz1_out, W1, col0, ncol, act_out, scale, dx_out, scratch);                                                        \
+        return hipGetLastError() == hipSuccess ? KS_OK : KS_ERR_HIP;                                                                         \
+    }
+    KR_BWDS_CASE(16, 16, 4) KR_BWDS_CASE(16, 16, 2)
+    KR_BWDS_CASE(8, 8, 4) KR_BWDS_CASE(8, 8, 2)
+    KR_BWDS_CASE(4, 4, 4) KR_BWDS_CASE(4, 4, 2)
+#undef KR_BWDS_CASE
     return KS_ERR_INVALID;
 }
 

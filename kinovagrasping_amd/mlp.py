@@ -94,10 +94,17 @@ def mlp3_backward(layers, dz3: torch.Tensor, h1: torch.Tensor, h2: torch.Tensor,
         dx = torch.empty(n, ncol, device=dz3.device, dtype=torch.float32)
         assert act_out is None or (act_out.is_contiguous() and tuple(act_out.shape) == (n, ncol))
     lib, P = _sim.load_library(), _sim._ptr
-    rc = lib.kr_mlp3_backward_shadow(n, w1.shape[1], w1.shape[0], w2.shape[0], w3.shape[0], P(dz3), P(w3), P(h2), P(w2), P(h1), P(dz2), P(dz1), P(w1),
-                                     col0, ncol, P(act_out), float(scale), P(dx), _stream(dz3))
+    waves = _split_waves(n) if w1.shape[0] == w2.shape[0] and w1.shape[0] % 16 == 0 and w1.shape[0] // 16 in (4, 8, 16) else 0
+    if waves:
+        need = (n + 15) // 16 * waves * 64 if dx is not None else 0
+        scratch = torch.empty(max(need, 4), device=dz3.device, dtype=torch.float32)
+        rc = lib.kr_mlp3_backward_split(n, w1.shape[1], w1.shape[0], w2.shape[0], w3.shape[0], P(dz3), P(w3), P(h2), P(w2), P(h1), P(dz2), P(dz1), P(w1),
+                                        col0, ncol, P(act_out), float(scale), P(dx), P(scratch), need, waves, _stream(dz3))
+    else:
+        rc = lib.kr_mlp3_backward_shadow(n, w1.shape[1], w1.shape[0], w2.shape[0], w3.shape[0], P(dz3), P(w3), P(h2), P(w2), P(h1), P(dz2), P(dz1), P(w1),
+                                         col0, ncol, P(act_out), float(scale), P(dx), _stream(dz3))
     if rc != 0:
-        raise RuntimeError(f"kr_mlp3_backward_shadow failed ({rc})")
+        raise RuntimeError(f"kr_mlp3_backward failed ({rc})")
     return dz2, dz1, dx
 
 

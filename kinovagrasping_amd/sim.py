@@ -27,7 +27,7 @@ EXPORTS = ["ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_
 ROLLOUT_EXPORTS = ["kr_select_action", "kr_store_transition", "kr_rank_episodes", "kr_commit_episodes", "kr_advance_ring",
                    "kr_sample_windows", "kr_sample_windows_draw", "kr_xchg_create", "kr_xchg_connect", "kr_xchg_allreduce_mean", "kr_xchg_status",
                    "kr_xchg_destroy", "kr_critic_grad", "kr_update_prologue", "kr_relu_backward", "kr_sigmoid_scale_backward", "kr_adam_step", "kr_soft_update",
-                   "kr_mlp3_forward", "kr_mlp3_forward_shadow", "kr_mlp3_forward_split", "kr_mlp3_backward_shadow", "kr_weight_grad_shadow",
+                   "kr_mlp3_forward", "kr_mlp3_forward_shadow", "kr_mlp3_forward_split", "kr_mlp3_backward_shadow", "kr_mlp3_backward_split", "kr_weight_grad_shadow",
                    "kr_actor_select"]
 
 _lib = None
@@ -86,6 +86,7 @@ def load_library(path: Path | None = None):
     L.kr_mlp3_forward_shadow.argtypes = L.kr_mlp3_forward.argtypes
     L.kr_mlp3_forward_split.argtypes = [i32] * 6 + [vp, i32, vp, i32] + [vp] * 6 + [i32, f32, vp, vp, vp, vp, C.c_int64, i32, vp]
     L.kr_mlp3_backward_shadow.argtypes = [i32] * 5 + [vp] * 8 + [i32, i32, vp, f32, vp, vp]
+    L.kr_mlp3_backward_split.argtypes = [i32] * 5 + [vp] * 8 + [i32, i32, vp, f32, vp, vp, C.c_int64, i32, vp]
     L.kr_weight_grad_shadow.argtypes = [i32] * 4 + [vp, vp, i32, vp, i32, i32, vp, vp, vp, vp]
     L.kr_actor_select.argtypes = [i32] * 3 + [vp] * 12 + [C.c_uint64, vp, f32, f32, i32] + [vp] * 5
     _lib = L

@@ -169,12 +169,15 @@ def _register_footprints(src: str, tmp_path) -> dict:
 
 
 def test_stepping_kernel_leaves_registers_for_the_learner(tmp_path):
-    """The learner's LDS-free kernels (ks_mlp.hip *_wave) run on the registers k_env_step leaves free: one wave of <= 128
-    beside the stepping kernel's one wave per SIMD, 512 registers per lane in all.  A stepping kernel above 384 silently
-    serialises the two (measured: 1.15 -> 1.73 ms per env-step when a change took it to 418), so the footprint is a contract."""
+    """The learner's LDS-free kernels (ks_mlp.hip: *_wave, k_mlp3_split, k_mlp3_bwd_split) run on the registers k_env_step leaves
+    free: one of their waves beside the stepping kernel's one wave per SIMD, 512 registers per lane in all (allocated in
+    blocks of 8).  A stepping kernel that does not leave room silently serialises the two (measured: 1.15 -> 1.73 ms per
+    env-step when a change took it to 418), so the footprint is a contract."""
     step = {k: v for k, v in _register_footprints("ks_api.hip", tmp_path).items() if "k_env_stepIf" in k}
     assert len(step) == 1, step
     (v, a), = step.values()
-    assert v + a <= 384, (v, a)
-    waves = {k: v for k, v in _register_footprints("ks_mlp.hip", tmp_path).items() if "_wave" in k}
-    assert waves and all(v + a <= 128 for v, a in waves.values()), waves
+    up8 = lambda x: (x + 7) // 8 * 8
+    learner = {k: v for k, v in _register_footprints("ks_mlp.hip", tmp_path).items() if "_wave" in k or "_split" in k}
+    assert learner
+    widest = max(up8(lv + la) for lv, la in learner.values())
+    assert up8(v + a) + widest <= 512, (v, a, widest, learner)

@@ -779,11 +779,17 @@ def test_curriculum_stage_runs_and_hands_over_to_the_next(tmp_path):
     assert set(r4["orientation_counts"]) == {"normal", "rotated", "top"} and r4["updates"] == 1
 
 
-def test_lds_free_backward_matches_autograd():
-    """kr_mlp3_backward_shadow + kr_weight_grad_shadow against torch autograd on the same networks: the critic's
+@pytest.mark.parametrize("split", ["0", "2", "4", None])
+def test_lds_free_backward_matches_autograd(split, monkeypatch):
+    """kr_mlp3_backward_shadow / _split + kr_weight_grad_shadow against torch autograd on the same networks: the critic's
     gradients for a given dLoss/dQ (all weight / bias gradients and dQ/da), and the actor's for a given dLoss/da
-    through the 0.8 * sigmoid output.  fp32, different summation order: 1e-4 relative to the largest entry."""
+    through the 0.8 * sigmoid output.  fp32, different summation order: 1e-4 relative to the largest entry.
+    split: one wave per 16 rows ("0"), the tiles split over 2 / 4 waves of a workgroup, or mlp.py's own choice (None)."""
     from kinovagrasping_amd import mlp
+    if split is None:
+        monkeypatch.delenv("KS_MLP_SPLIT", raising=False)
+    else:
+        monkeypatch.setenv("KS_MLP_SPLIT", split)
     from kinovagrasping_amd.ddpgfd import Actor, Critic
     dev = torch.device("cuda", 0)
     for hidden, n in (((256, 256), 1600), ((256, 256), 8000), ((64, 64), 333)):
