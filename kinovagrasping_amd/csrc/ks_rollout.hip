@@ -112,9 +112,24 @@ __global__ __launch_bounds__(WAVE) void k_commit_episodes(int n, int H, int capa
     if (i >= n || keep[i] == 0) return;
     const long slot = (head[0] + rank[i] - 1) % capacity;
     const long src = (long)i * H, dst = slot * H;
-    for (int k = lane; k < H * S; k += WAVE) {
-        ep_state[dst * S + k] = cur_state[src * S + k];
-        ep_next[dst * S + k] = cur_next[src * S + k];
+    // 16-byte copies where the episode blocks are 16-byte aligned (H * 82 floats: even H), several loads in flight: at an
+    // episode boundary all 4096 envs commit (84 MB) while the rollout waits - float by float this took 0.4 ms
+    if ((H * S) % 4 == 0) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f* s0 = (const v4f*)(cur_state + src * S); const v4f* s1 = (const v4f*)(cur_next + src * S);
+        v4f* d0 = (v4f*)(ep_state + dst * S); v4f* d1 = (v4f*)(ep_next + dst * S);
+        const int n4 = H * S / 4;
+        int k = lane;
+        for (; k + WAVE < n4; k += 2 * WAVE) {
+            const v4f a = s0[k], b = s0[k + WAVE], c = s1[k], d = s1[k + WAVE];
+            d0[k] = a; d0[k + WAVE] = b; d1[k] = c; d1[k + WAVE] = d;
+        }
+        for (; k < n4; k += WAVE) { d0[k] = s0[k]; d1[k] = s1[k]; }
+    } else {
+        for (int k = lane; k < H * S; k += WAVE) {
+            ep_state[dst * S + k] = cur_state[src * S + k];
+            ep_next[dst * S + k] = cur_next[src * S + k];
+        }
     }
     for (int k = lane; k < H * A; k += WAVE) ep_action[dst * A + k] = cur_action[src * A + k];
     for (int k = lane; k < H; k += WAVE) {
