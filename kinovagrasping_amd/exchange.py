@@ -62,31 +62,38 @@ class PeerExchange:
         """None when the exchange reproduces the process group's all_reduce on every rank, else the reason (same on all ranks)"""
         dist, dev = self.dist, self.device
         reason = None
-        try:
-            g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
-            for k in range(rounds):
-                n = max(1, min(self.max_count, self.max_count - 3 * k - (k % 2)))     # also counts that are not multiples of 4
-                a = torch.randn(n, generator=g).to(dev)
-                ref = a.clone()
+
+        def note(text):
+            nonlocal reason
+            reason = reason or text
+
+        # every rank walks the same sequence of collectives whatever it finds on the way (a rank that left the loop early
+        # would leave its peers inside an all_reduce): findings are only recorded, and compared at the end
+        g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
+        for k in range(rounds):
+            n = max(1, min(self.max_count, self.max_count - 3 * k - (k % 2)))     # also counts that are not multiples of 4
+            a = torch.randn(n, generator=g).to(dev)
+            ref = a.clone()
+            try:
                 self.allreduce_mean(a)
-                dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.group)
-                ref /= self.world
-                torch.cuda.synchronize(dev)
+            except Exception as e:      # noqa: BLE001 - any failure means: keep the library collective
+                note(f"{type(e).__name__}: {e}")
+            dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.group)
+            ref /= self.world
+            torch.cuda.synchronize(dev)
+            try:
                 if self.failed_epoch():
-                    reason = f"a peer did not arrive (call {self.failed_epoch()})"
-                    break
-                if not torch.allclose(a, ref, rtol=1e-5, atol=1e-6):
-                    reason = f"mismatch against all_reduce: {float((a - ref).abs().max()):.3e}"
-                    break
-                # bitwise identical on all ranks
-                lo, hi = a.clone(), a.clone()
-                dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
-                dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
-                if not torch.equal(lo, hi):
-                    reason = "ranks disagree bitwise"
-                    break
-        except Exception as e:      # noqa: BLE001 - any failure means: keep the library collective
-            reason = f"{type(e).__name__}: {e}"
+                    note(f"a peer did not arrive (call {self.failed_epoch()})")
+            except Exception as e:      # noqa: BLE001
+                note(f"{type(e).__name__}: {e}")
+            if not torch.allclose(a, ref, rtol=1e-5, atol=1e-6):
+                note(f"mismatch against all_reduce: {float((a - ref).abs().max()):.3e}")
+            # bitwise identical on all ranks
+            lo, hi = a.clone(), a.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            if not torch.equal(lo, hi):
+                note("ranks disagree bitwise")
         reasons = [None] * self.world
         dist.all_gather_object(reasons, reason, group=self.group)
         bad = [f"rank {i}: {r}" for i, r in enumerate(reasons) if r]
