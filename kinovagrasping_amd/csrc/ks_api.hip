@@ -105,16 +105,89 @@ template <int B, typename D, typename Sx> __device__ __forceinline__ void stage_
     for (; i < n; i += step) d[i] = s[i];
 }
 
+// The packed hull tables (Model::hull_pack, already in LDS order) in one pass: up to eight 16-byte loads in flight per thread, so
+// the ~50 KB of a workgroup are two round trips to the L2 instead of twelve table-by-table copies (each a round trip or more).
+template <typename D> __device__ __forceinline__ void stage_tables(KS_LDS D* dst, const void* src, int bytes) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    KS_LDS v4u* d = (KS_LDS v4u*)dst;
+    const __attribute__((address_space(1))) v4u* s = (const __attribute__((address_space(1))) v4u*)src;
+    const int n = bytes >> 4, step = blockDim.x;
+    constexpr int K = 8;
+    // (every load unconditional, with a clamped index: a register array that is only conditionally loaded makes the compiler
+    // wait for each load on its own)
+    for (int i = threadIdx.x; i < n; i += K * step) {
+        v4u r[K];
+        KS_UNROLL
+        for (int k = 0; k < K; k++) r[k] = s[i + k * step < n ? i + k * step : n - 1];
+        KS_UNROLL
+        for (int k = 0; k < K; k++)
+            if (i + k * step < n) d[i + k * step] = r[k];
+    }
+}
+
+// Model constants and packed hull tables of a workgroup in one go: the model's loads and the first eight table loads of every
+// thread are in flight together (the table staging used to start behind the model copy and a barrier, because it read its
+// pointers from the LDS copy).  Returns the model in LDS; the tables land behind it, where stage_hulls expects them.
+template <typename T, int NT> __device__ __forceinline__ const Model<T>* stage_model_and_tables(const Model<T>* __restrict__ mp, KS_LDS T* lds) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    constexpr int MW = (int)(sizeof(Model<T>) / 4), MR = (MW + NT - 1) / NT, K = 8;
+    const int tid = threadIdx.x;
+    const __attribute__((address_space(1))) v4u* ps = (const __attribute__((address_space(1))) v4u*)mp->hull_pack;
+    const int n = mp->hull_pack_bytes >> 4;
+    const __attribute__((address_space(1))) unsigned* src = (const __attribute__((address_space(1))) unsigned*)mp;
+    KS_LDS unsigned* dm = (KS_LDS unsigned*)lds;
+    KS_LDS v4u* dt = (KS_LDS v4u*)(lds + model_words<T>());
+    unsigned mr[MR];
+    v4u r[K], r2[K];
+    auto at = [&](int j) { return j < n ? j : n - 1; };
+    // unconditional loads with clamped indices (see stage_tables); a context always has the pack (n >= 1).  The tables of a
+    // workgroup are ~50 KB = 12.5 loads per thread: two sets of eight in flight together cover them in one round trip
+    const bool more = n > K * NT;                 // (uniform)
+    KS_UNROLL
+    for (int k = 0; k < MR; k++) mr[k] = src[tid + k * NT < MW ? tid + k * NT : MW - 1];
+    if (n > 0) {
+        KS_UNROLL
+        for (int k = 0; k < K; k++) r[k] = ps[at(tid + k * NT)];
+        if (more) {
+            KS_UNROLL
+            for (int k = 0; k < K; k++) r2[k] = ps[at(tid + (K + k) * NT)];
+        }
+    }
+    KS_UNROLL
+    for (int k = 0; k < MR; k++)
+        if (tid + k * NT < MW) dm[tid + k * NT] = mr[k];
+    if (n > 0) {
+        KS_UNROLL
+        for (int k = 0; k < K; k++)
+            if (tid + k * NT < n) dt[at(tid + k * NT)] = r[k];
+        if (more) {
+            KS_UNROLL
+            for (int k = 0; k < K; k++)
+                if (tid + (K + k) * NT < n) dt[at(tid + (K + k) * NT)] = r2[k];
+        }
+    }
+    for (int i = tid + 2 * K * NT; i < n; i += K * NT) {
+        KS_UNROLL
+        for (int k = 0; k < K; k++) r[k] = ps[at(i + k * NT)];
+        KS_UNROLL
+        for (int k = 0; k < K; k++)
+            if (i + k * NT < n) dt[at(i + k * NT)] = r[k];
+    }
+    return (const Model<T>*)lds;
+}
+
 // SHARED: `hu` is the workgroup's one descriptor in LDS, filled by thread 0 (every thread writing its own private copy
 // was 240 bytes of stack per lane, written through to memory at every launch: 16 of the 27 MB a launch wrote);
 // otherwise `hu` is the calling thread's own.
-template <typename T, bool SHARED> __device__ __forceinline__ void stage_hulls(const Model<T>& m, KS_LDS T* lds, int& used, Hulls<T>& hu) {
+template <typename T, bool SHARED> __device__ __forceinline__ void stage_hulls(const Model<T>& m, KS_LDS T* lds, int& used, Hulls<T>& hu, bool prestaged = false) {
     const bool writer = !SHARED || threadIdx.x == 0;
+    const bool packed = m.hull_pack != nullptr;
+    if (packed && !prestaged) stage_tables(lds, m.hull_pack, m.hull_pack_bytes);
     int off = 0;
     for (int s = 0; s < 4; s++) {
         const int n = m.mesh_nvert_pad[s] * 4;
         const T* src = m.mesh_vert[s];
-        stage_copy<16>(lds + off, src, (size_t)n * sizeof(T));
+        if (!packed) stage_copy<16>(lds + off, src, (size_t)n * sizeof(T));
         if (writer) {
             hu.vert[s] = lds + off;
             hu.nvert[s] = m.mesh_nvert[s];
@@ -127,10 +200,10 @@ template <typename T, bool SHARED> __device__ __forceinline__ void stage_hulls(c
     int uoff = 0;
     for (int s = 0; s < 4; s++) {
         const int no = m.mesh_nvert[s] + 1, na = m.mesh_nchunk[s] * 4;
-        stage_copy<8>(ulds + uoff, m.mesh_adj_off[s], (size_t)((no + 3) & ~3) * sizeof(unsigned short));   // (padded to whole 8-byte words at load)
+        if (!packed) stage_copy<8>(ulds + uoff, m.mesh_adj_off[s], (size_t)((no + 3) & ~3) * sizeof(unsigned short));   // (padded to whole 8-byte words at load)
         if (writer) hu.adj_off[s] = ulds + uoff;
         uoff += (no + 3) & ~3;                       // keep the chunk tables 8-byte aligned
-        stage_copy<8>(ulds + uoff, m.mesh_adj[s], (size_t)na * sizeof(unsigned short));
+        if (!packed) stage_copy<8>(ulds + uoff, m.mesh_adj[s], (size_t)na * sizeof(unsigned short));
         if (writer) hu.adj[s] = ulds + uoff;
         uoff += na;
     }
@@ -306,9 +379,10 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
     const long long wk_entry = wall_clock64();
 #endif
     KS_LDS T* lds = (KS_LDS T*)smem;
-    const Model<T>* mp = models + b.wg_model[blockIdx.x];          // every env of this workgroup holds this object
+    // every env of this workgroup holds this object (the id is made wave-uniform by hand: the loads through `mp` are scalar then)
+    const Model<T>* mp = models + __builtin_amdgcn_readfirstlane(b.wg_model[blockIdx.x]);
     const Model<T>* ml = mp;
-    if constexpr (USE_LDS) { ml = stage_model(mp, lds); lds += model_words<T>(); }
+    if constexpr (USE_LDS) { ml = stage_model_and_tables<T, WG>(mp, lds); lds += model_words<T>(); }
     const Model<T>& m = *ml;
     int hull_words = 0;
     // the out-of-line stages reach the descriptor through a generic reference: the workgroup's one copy in LDS (behind the model)
@@ -323,8 +397,8 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
         *arrive = 0;
         if (ray_pool) atomicAdd(&b.rayq[3], 1);                     // workgroups of this launch that have started
     }
-    if constexpr (USE_LDS) __syncthreads();         // the model copy is complete: the table staging reads its pointers and counts from LDS
-    stage_hulls<T, USE_LDS>(*ml, lds, hull_words, *hup);
+    if constexpr (USE_LDS) __syncthreads();         // the model copy is complete: the descriptor is built from its counts in LDS
+    stage_hulls<T, USE_LDS>(*ml, lds, hull_words, *hup, USE_LDS);
     const Hulls<T>& hu = *hup;
     // epw envs per workgroup, SUBS lanes per env: the lanes of a team keep identical copies of the env state and
     // split the vertex scans / per-pair (collision) and per-contact (solver) loops; per-env dynamic data is shared in LDS
@@ -952,6 +1026,21 @@ template <typename T> struct Ctx : CtxBase {
                 adj_ints += ((hm.m.mesh_nvert[s] + 1 + 3) & ~3) + hm.m.mesh_nchunk[s] * 4;
             }
             if ((r = upload(hm.dirtab, &hm.m.mesh_dirtab))) return r;
+            {
+                // the LDS image of the hull tables (stage_hulls' layout) as one block
+                std::vector<unsigned char> pack;
+                auto put = [&](const void* p, size_t bytes) { pack.insert(pack.end(), (const unsigned char*)p, (const unsigned char*)p + bytes); };
+                for (int s = 0; s < 4; s++) put(hm.vert[s].data(), hm.vert[s].size() * sizeof(T));
+                for (int s = 0; s < 4; s++) {
+                    put(hm.adj_off[s].data(), hm.adj_off[s].size() * sizeof(unsigned short));
+                    put(hm.adj[s].data(), hm.adj[s].size() * sizeof(unsigned short));
+                }
+                pack.resize((pack.size() + 15) / 16 * 16, 0);
+                const unsigned char* d = nullptr;
+                if ((r = upload(pack, &d))) return r;
+                hm.m.hull_pack = d;
+                hm.m.hull_pack_bytes = (int)pack.size();
+            }
             const int iwords = (adj_ints * (int)sizeof(unsigned short) + (int)sizeof(T) - 1) / (int)sizeof(T);
             words += (iwords + 3) & ~3;
             words += NPAIR_MAX * pair_rec_bytes<T>() / (int)sizeof(T);

@@ -60,6 +60,10 @@ template <typename T> struct Model {
     // support vertex of every hull for the centre direction of every cell of a cube map (6 faces x R x R): where a
     // hill climb towards an arbitrary direction starts, [4][SUPPORT_CELLS]; global memory (12 KB, L1/L2 resident)
     const unsigned short* mesh_dirtab;
+    // the hull tables once more as ONE block in the order the stepping kernels keep them in LDS ([vert 0..3][adj_off 0 | adj 0 | ..
+    // | adj_off 3 | adj 3], padded to 16 bytes): staged with a single copy (ks_api.hip, stage_tables); device contexts only
+    const void* hull_pack;
+    int hull_pack_bytes;
 };
 
 }  // namespace ks

@@ -78,6 +78,8 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
     using namespace detail;
     const unsigned char* b = (const unsigned char*)vblob;
     Model<T>& m = hm.m;
+    m.hull_pack = nullptr;       // filled by a device context (ks_api.hip, load_models)
+    m.hull_pack_bytes = 0;
     std::string& e = hm.error;
     BlobRec probe;
     if (!blob_find(b, n, "opt", probe)) { e = "not a KSMB v5 model blob (merge <shape>.ksm with hand_raymesh.kst: model_compiler.load_model_blob)"; return false; }
