@@ -72,6 +72,19 @@ for t in range(NSTEP):
         os.makedirs("gpurun_out", exist_ok=True)
         act = (eng.action_t if eng is not None else (closing if MODE == "grasp" else acts[NSTEP - 1])).cpu().numpy()
         np.savez("gpurun_out/slow_envs.npz", envs=order[:8], action=act[:, order[:8]], hand_quat=np.asarray(hq)[:, order[:8]], dur=d[order[:8]], **{k: v.cpu().numpy()[:, order[:8]] for k, v in pre.items()})
+        wd = d[::4]                                  # one entry per wave (its four envs share the duration)
+        print("  wave durations, percentiles 50/90/99/99.9/max:", [int(x) for x in np.percentile(wd, [50, 90, 99, 99.9, 100])],
+              " waves above 1.2x / 1.4x the median:", int((wd > 1.2 * np.median(wd)).sum()), int((wd > 1.4 * np.median(wd)).sum()))
+        seen = set()
+        for e in order:
+            if e // 4 in seen:
+                continue
+            seen.add(e // 4)
+            envs4 = range(e // 4 * 4, e // 4 * 4 + 4)
+            print(f"    wave {e // 4}: {d[e]:.0f} ticks; per env (gjk supports of the busiest lane, #newton, hull cycles):",
+                  [(int(full[:, 25, x].max()), int(full[:, 21, x].max()), int(full[:, 9, x].max())) for x in envs4])
+            if len(seen) >= 12:
+                break
         for rank in (0, 1, 2, 3, n // 2, n - 1):
             e = order[rank]
             p = full[:, :, e].max(0)
