@@ -125,7 +125,7 @@ template <typename D> __device__ __forceinline__ void stage_tables(KS_LDS D* dst
     }
 }
 
-// Model constants and packed hull tables of a workgroup in one go: the model's loads and the first eight table loads of every
+// Model constants and packed hull tables of a workgroup in one go: the model's loads and the first sixteen table loads of every
 // thread are in flight together (the table staging used to start behind the model copy and a barrier, because it read its
 // pointers from the LDS copy).  Returns the model in LDS; the tables land behind it, where stage_hulls expects them.
 template <typename T, int NT> __device__ __forceinline__ const Model<T>* stage_model_and_tables(const Model<T>* __restrict__ mp, KS_LDS T* lds) {
@@ -159,11 +159,11 @@ template <typename T, int NT> __device__ __forceinline__ const Model<T>* stage_m
     if (n > 0) {
         KS_UNROLL
         for (int k = 0; k < K; k++)
-            if (tid + k * NT < n) dt[at(tid + k * NT)] = r[k];
+            if (tid + k * NT < n) dt[tid + k * NT] = r[k];
         if (more) {
             KS_UNROLL
             for (int k = 0; k < K; k++)
-                if (tid + (K + k) * NT < n) dt[at(tid + (K + k) * NT)] = r2[k];
+                if (tid + (K + k) * NT < n) dt[tid + (K + k) * NT] = r2[k];
         }
     }
     for (int i = tid + 2 * K * NT; i < n; i += K * NT) {
@@ -171,7 +171,7 @@ template <typename T, int NT> __device__ __forceinline__ const Model<T>* stage_m
         for (int k = 0; k < K; k++) r[k] = ps[at(i + k * NT)];
         KS_UNROLL
         for (int k = 0; k < K; k++)
-            if (i + k * NT < n) dt[at(i + k * NT)] = r[k];
+            if (i + k * NT < n) dt[i + k * NT] = r[k];
     }
     return (const Model<T>*)lds;
 }
