@@ -385,6 +385,14 @@ def main():
                          "issue_bound": issue},
             "mfma": mfma,
             "steady_state": steady,
+            # every env runs the same 30-step episode clock (auto-reset), and an env-step costs more late in an episode (hands
+            # closed, more contacts) than early: a window that is not whole episodes is not an average
+            "timed_window": {"first_episode_step": (priming + args.warmup) % 30, "steps": args.steps, "whole_episodes": args.steps % 30 == 0,
+                             "note": (None if args.steps % 30 == 0 else
+                                      f"the {args.steps} timed steps are steps {(priming + args.warmup) % 30}..{(priming + args.warmup + args.steps - 1) % 30} of the "
+                                      "30-step episode - not a whole episode, and early in training the first two thirds of an episode (hands still "
+                                      "closing) are its cheapest part: quote `steady_state` (whole episodes, trained policy), or the default "
+                                      "`python bench.py` line (60 steps = two whole episodes)")},
             "nonfinite_envs": bad,
             "status_counts": {"contact_overflow": int((status & 1).ne(0).sum().item()), "nonfinite": bad,
                               "ray_pool_timeout": int((status & 4).ne(0).sum().item())},
