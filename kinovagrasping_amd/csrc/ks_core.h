@@ -2203,6 +2203,8 @@ KS_FN_SOLVER void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm,
             }
             d1 = team.sum(d1);
             d2 = team.sum(d2);
+            T magsum = 0;
+            if constexpr (sizeof(T) == 4) magsum = team.sum(mag);     // (here, so that the three butterflies are issued interleaved)
             if (d2 < T(1e-15)) break;
             if (d1 < 0) lo = alpha; else hi = alpha;
             T next = alpha - d1 / d2;
@@ -2210,7 +2212,7 @@ KS_FN_SOLVER void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm,
             if (next < lo) next = lo;
             bool stop = kabs(next - alpha) <= LS_RTOL<T>() * kabs(alpha) || kabs(next - alpha) <= T(1e-14) * (1 + kabs(alpha));
             // fp32: the derivative is below the rounding noise of its own terms - alpha cannot be resolved further
-            if constexpr (sizeof(T) == 4) stop = stop || kabs(d1) <= T(2e-6) * team.sum(mag);
+            if constexpr (sizeof(T) == 4) stop = stop || kabs(d1) <= T(2e-6) * magsum;
             alpha = next;
             if (stop) break;
         }
