@@ -1,6 +1,6 @@
 #!/bin/bash
 # Dev tool: the measurements the docs and profiles/ quote, in one GPU call.  Usage: tools/measure_round.sh <tag>
-tag=${1:-r02_g}
+tag=${1:-r02_h}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
