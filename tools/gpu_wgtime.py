@@ -62,6 +62,25 @@ for t in range(NSTEP):
         print(f"  kernel entry -> stepping loop (tables into LDS, state load), ticks: min {prof[23].min():.0f} mean {prof[23].mean():.0f} max {prof[23].max():.0f}")
         late = st_rel[::16] > 0.25 * d.mean()
         print("  workgroups starting late (> 25% of a loop):", int(late.sum()))
+    if t >= NSTEP - 4:
+        # persistence of an env's cost from one env-step to the next (would a cost-aware placement of envs in waves help?)
+        fullh = st["contact"].reshape(-1, n)[:480].cpu().numpy().reshape(16, 30, n)
+        hist = globals().setdefault("hist", [])
+        hist.append((fullh[:, 21].max(0).copy(), fullh[:, 9].max(0).copy(), d.copy()))
+        if len(hist) >= 3:
+            a, b, c = hist[-3][0], hist[-2][0], hist[-1][0]
+            top = lambda x: set(np.argsort(-x)[: n // 20])
+            print(f"step {t}: #newton per env: corr(t-1, t) {np.corrcoef(b, c)[0, 1]:.2f}  corr(t-2, t) {np.corrcoef(a, c)[0, 1]:.2f};  top-5% envs shared with t-1: {len(top(b) & top(c)) / (n // 20):.2f}, with t-2: {len(top(a) & top(c)) / (n // 20):.2f}")
+            # what a placement by the cost of step t-2 would do: waves = 4 envs; wave cost model = sum over its envs' excess iterations is not it -
+            # the wave pays roughly max-per-substep; proxy: max of the four envs' #newton
+            def wave_max(order):
+                return c[order].reshape(-1, 4).max(1)
+            ident = np.arange(n)
+            rank = np.argsort(-a)                      # dealt round-robin: ranks w, w + n/4, ... share wave w
+            dealt = rank.reshape(4, n // 4).T.reshape(-1)
+            wm0, wm1 = wave_max(ident), wave_max(dealt)
+            two = lambda order: int(((c[order].reshape(-1, 4) > 40).sum(1) >= 2).sum())
+            print(f"   waves with >= 2 envs above 40 iterations: as placed {two(ident)}, dealt by the cost of t-2 {two(dealt)}")
     if t == NSTEP - 1:
         full = st["contact"].reshape(-1, n)[:480].cpu().numpy().reshape(16, 30, n)
         names = {0: "fk+dyn", 1: "collision", 2: "constraints", 3: "chol M", 5: "euler", 8: "c:plane", 9: "c:hull", 10: "c:merge", 13: "n:setup|wg-start", 14: "n:hessian|wg-end", 19: "n:update|hwid", 20: "post|xcc", 15: "n:chol", 16: "n:solve", 17: "n:pproj", 18: "n:ls", 21: "#newton", 22: "#ls"}
