@@ -12,10 +12,14 @@ the rank.  4096 envs per GPU (BASELINE metric), CubeS, 'normal' hand pose, env i
   --mode sim (BASELINE config 2 at the metric's env count): replays Generator(PCG64(1000 + i)).uniform(-0.8, 0.8)
       action streams resident in HBM; sim kernels only.
 
+Timed region (round 3): in ddpg mode the policy is first trained for `--pretrain-updates` (1500) untimed env-steps - the hands
+then close into contact-rich grasps and the envs' episode clocks are spread over the 30 phases - then W warm-up steps, then
+EXACTLY K timed steps.  (Rounds 1-2 timed the first episodes of a random policy, the cheapest regime.)
+
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel k_env_step, HIP-event timed on the
 launch stream inside this process), `mfma` (the learner's MLP kernels against the fp32 MFMA peak), `steady_state`
-(a second timed window after 1500 learner updates: the policy has by then learned to drive the hands into contact-rich
-grasps, which lengthens the stepping kernel) and `cpu_baseline` (the fp64 CPU oracle on the host cores, N=1 only).
+(a longer window of whole episodes right after the timed one: `value` should agree with it) and `cpu_baseline` (the fp64 CPU
+oracle on the host cores, N=1 only).
 
 Multi-GPU: `python bench.py --gpus N` starts N ranks itself (fresh child processes, spawned BEFORE this process touches
 torch or HIP; rendezvous on 127.0.0.1) - the same thing the driver does with `python -m torch.distributed.run
@@ -42,13 +46,14 @@ def cpu_baseline(n_cores: int, budget_s: float = 12.0):
     """fp64 oracle ("port"), one env per thread, same workload (config-2 start rows / action streams)."""
     import numpy as np
     from kinovagrasping_amd import scenarios
+    from kinovagrasping_amd.sim import SOLVER_ITERATIONS
     from oracle import ko_py as ko
     model = ko.OracleModel(scenarios.model_blob("CubeS"))
     q0, hq = scenarios.config2_states(n_cores)
     acts = scenarios.config_actions(n_cores, 30)
 
     def worker(i):
-        sim = ko.OracleSim(model, hq[:, i], solver_iterations=6)
+        sim = ko.OracleSim(model, hq[:, i], solver_iterations=SOLVER_ITERATIONS)
         sim.env_reset(q0[:, i])
         steps, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < budget_s:
@@ -109,12 +114,28 @@ def launch_ranks(n_ranks: int, argv) -> int:
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + list(argv), env=env))
     rc = 0
     try:
-        for p in procs:
-            rc = max(rc, abs(p.wait()))
-            if rc:                                   # one rank failed: the others would wait in a collective for ever
-                for q in procs:
-                    if q.poll() is None:
-                        q.terminate()
+        # poll ALL children: a rank that dies while rank 0 is still blocked in the rendezvous or a collective must bring the
+        # others down now, not after their NCCL timeout
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                rc = max(rc, abs(code))
+            if rc and live:
+                for q in live:
+                    q.terminate()
+                deadline = time.monotonic() + 10.0
+                for q in live:
+                    try:
+                        q.wait(timeout=max(0.1, deadline - time.monotonic()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+                live = []
+            elif live:
+                time.sleep(0.05)
     except KeyboardInterrupt:
         for q in procs:
             if q.poll() is None:
@@ -149,7 +170,12 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch the rollout / learner ops one by one instead of replaying HIP graphs")
     ap.add_argument("--envs-per-gpu", type=int, default=None, help="default 4096 (the metric's env count); 8192 for --config 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--steady-updates", type=int, default=1500, help="learner updates before the steady_state window (ddpg mode; 0 = skip)")
+    ap.add_argument("--pretrain-updates", type=int, default=1500,
+                    help="ddpg mode: untimed env-steps with learner updates BEFORE the warm-up, so that the timed steps see the trained policy's "
+                         "contact-rich grasps and de-synchronised episode clocks instead of the cheap first episodes of a random policy (0 = time the "
+                         "first episodes, as rounds 1-2 did)")
+    ap.add_argument("--steady-updates", type=int, default=0, help="further learner updates before the steady_state window (whole episodes)")
+    ap.add_argument("--solver-iterations", type=int, default=None, help="Newton cap per substep (default: kinovagrasping_amd.sim.SOLVER_ITERATIONS)")
     ap.add_argument("--steady-steps", type=int, default=300, help="length of the steady_state window in env-steps (a multiple of the 30-step episode)")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -167,7 +193,8 @@ def main():
     import numpy as np
     import torch
     from kinovagrasping_amd import scenarios
-    from kinovagrasping_amd.sim import KinovaSim
+    from kinovagrasping_amd.sim import SOLVER_ITERATIONS, KinovaSim
+    iters = args.solver_iterations or SOLVER_ITERATIONS
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -188,11 +215,11 @@ def main():
     if mixed:
         # config 5: 14 shapes x {normal, rotated, top} x mass / friction per env, all in ONE context and one stepping launch
         oid_all, pose_all, q0_all, hq_all, mf_all = scenarios.config5_states(n * world, seed=5)
-        sim = KinovaSim(n, scenarios.SHAPES, device=local_rank, auto_reset=True, horizon=30)
+        sim = KinovaSim(n, scenarios.SHAPES, device=local_rank, auto_reset=True, horizon=30, solver_iterations=iters)
         obs0 = sim.reset(torch.as_tensor(q0_all[:, sl]), torch.as_tensor(hq_all[:, sl]), object_id=oid_all[sl], mass_friction=mf_all[:, sl])
     else:
         q0_all, hq_all = scenarios.config2_states(n * world)
-        sim = KinovaSim(n, "CubeS", device=local_rank, auto_reset=True, horizon=30)
+        sim = KinovaSim(n, "CubeS", device=local_rank, auto_reset=True, horizon=30, solver_iterations=iters)
         obs0 = sim.reset(torch.as_tensor(q0_all[:, sl]), torch.as_tensor(hq_all[:, sl]))
 
     def barrier():
@@ -262,16 +289,27 @@ def main():
     # ddpg mode: the learner only has data once every env has finished an episode (30 steps) - if the requested warm-up is
     # shorter, prime the replay first so that EVERY timed step carries a learner update (nothing skipped in the timed region)
     priming = max(0, 36 - args.warmup) if args.mode == "ddpg" else 0
-    for t in range(priming):
-        step_fn(t)
-    for t in range(args.warmup):
-        step_fn(priming + t)
+    k = 0
+    for _ in range(priming):
+        step_fn(k); k += 1
+    # untimed pre-training (round 3): the driver's `--steps 20 --warmup 5` used to time steps 6-25 of the FIRST episodes of a random
+    # policy - fingers still closing, the cheapest third of an episode.  Now the policy is trained for `--pretrain-updates` updates
+    # first: hands close into contact-rich grasps, episodes end at different steps (lift), so the envs' episode clocks are spread
+    # over the 30 phases and ANY window of K steps is representative (`timed_window.episode_clock_histogram`).
+    pretrained = 0
+    if args.mode == "ddpg" and args.pretrain_updates > 0:
+        while updates < args.pretrain_updates:
+            step_fn(k); k += 1
+        pretrained = updates
+    for _ in range(args.warmup):
+        step_fn(k); k += 1
     barrier()
+    clock_hist = torch.bincount(eng.t.clamp(0, 29), minlength=30).cpu().tolist() if args.mode == "ddpg" else None
     sim.kernel_time(reset=True)
     upd0 = updates
     t0 = time.perf_counter()
-    for t in range(args.steps):
-        step_fn(priming + args.warmup + t)
+    for _ in range(args.steps):
+        step_fn(k); k += 1
     if trainer is not None:
         trainer.flush()                                    # the last step's deferred replay-ring update belongs to the timed work
     t_issue = time.perf_counter() - t0                 # host time to issue the timed steps (before the device catches up)
@@ -309,8 +347,7 @@ def main():
     # ---- steady state: the same step after `--steady-updates` learner updates (the trained policy closes the hand into
     # contact-rich grasps, the stepping kernel grows with the contact count), window = a multiple of the 30-step episode
     steady = None
-    if args.mode == "ddpg" and trainer is not None and args.steady_updates > 0:
-        k = priming + args.warmup + args.steps
+    if args.mode == "ddpg" and trainer is not None and args.steady_steps > 0:
         while updates < args.steady_updates:
             step_fn(k); k += 1
         barrier()
@@ -334,12 +371,15 @@ def main():
     # replicas must hold bit-identical weights after the all-reduced updates: spread of two checksums over the ranks
     replica_spread = None
     if world > 1 and args.mode == "ddpg":
-        chk = torch.stack([f(policy._flat_params[k].double()) for k in ("actor", "critic", "actor_target", "critic_target")
-                           for f in (torch.sum, lambda x: x.abs().sum())])
-        hi, lo = chk.clone(), chk.clone()
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        replica_spread = float((hi - lo).abs().max().item())
+        if trainer is not None:
+            replica_spread = trainer.replica_checksum_spread()
+        else:
+            chk = torch.stack([f(policy._flat_params[k].double()) for k in ("actor", "critic", "actor_target", "critic_target")
+                               for f in (torch.sum, lambda x: x.abs().sum())])
+            hi, lo = chk.clone(), chk.clone()
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            replica_spread = float((hi - lo).abs().max().item())
     if rank == 0:
         value = n * world * args.steps / dt
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
@@ -372,7 +412,7 @@ def main():
                                     "env-step (BASELINE config 3; config 4 when n_gpus=8)") if args.mode == "ddpg" else
                                    (f"{n} envs/GPU CubeS normal-pose grasp sim, PCG64(1000+i) random-action rollout (BASELINE config 2 at the "
                                     "metric's env count); sim kernels only"),
-                       "mode": args.mode, "envs_per_gpu": n, "frame_skip": 15, "solver": "newton x6", "hidden": list(args.hidden),
+                       "mode": args.mode, "envs_per_gpu": n, "frame_skip": 15, "solver": f"newton, <= {iters} iterations per substep (early exit on convergence)", "hidden": list(args.hidden),
                        "learner_updates_timed": timed_updates if args.mode == "ddpg" else 0, "priming_steps": priming,
                        "launch": ("eager" if args.eager else "hip-graphs") if args.mode == "ddpg" else "direct",
                        "learner": learner_form,
@@ -387,15 +427,17 @@ def main():
             "steady_state": steady,
             # every env runs the same 30-step episode clock (auto-reset), and an env-step costs more late in an episode (hands
             # closed, more contacts) than early: a window that is not whole episodes is not an average
-            "timed_window": {"first_episode_step": (priming + args.warmup) % 30, "steps": args.steps, "whole_episodes": args.steps % 30 == 0,
-                             "note": (None if args.steps % 30 == 0 else
-                                      f"the {args.steps} timed steps are steps {(priming + args.warmup) % 30}..{(priming + args.warmup + args.steps - 1) % 30} of the "
-                                      "30-step episode - not a whole episode, and early in training the first two thirds of an episode (hands still "
-                                      "closing) are its cheapest part: quote `steady_state` (whole episodes, trained policy), or the default "
-                                      "`python bench.py` line (60 steps = two whole episodes)")},
+            "timed_window": {"after_learner_updates": upd0, "pretrain_updates": pretrained, "steps": args.steps,
+                             "episode_clock_histogram": clock_hist,
+                             "note": ("timed after the untimed pre-training: trained policy, contact-rich grasps, env episode clocks spread over the 30 "
+                                      "phases (histogram = envs per episode step at the start of the window) - the same regime as `steady_state`"
+                                      if pretrained else
+                                      "no pre-training (--pretrain-updates 0): all envs run the same episode clock and the first episodes of a random "
+                                      "policy are the cheapest; quote `steady_state`") if args.mode == "ddpg" else "sim-only: 30-step random-action episodes, all envs in phase"},
             "nonfinite_envs": bad,
             "status_counts": {"contact_overflow": int((status & 1).ne(0).sum().item()), "nonfinite": bad,
-                              "ray_pool_timeout": int((status & 4).ne(0).sum().item())},
+                              "ray_pool_timeout": int((status & 4).ne(0).sum().item()),
+                              "newton_ended_at_cap": int((status & 8).ne(0).sum().item())},
             "rccl": ({"ranks": world, "backend": os.environ.get("KS_DIST_BACKEND", "nccl"), "NCCL_ALGO": os.environ.get("NCCL_ALGO", "default"),
                       "allreduces_per_update": 2, "bytes_per_allreduce": int(policy._flat_params["critic"].numel() * 4),
                       "exchange": getattr(trainer, "exchange_note", None),
@@ -403,6 +445,7 @@ def main():
                                                and trainer.native.exchange is not None else None)}
                      if world > 1 and args.mode == "ddpg" else None),
             "replica_weight_checksum_spread": replica_spread,
+            "replica_checks_during_run": (getattr(trainer, "replica_checks", 0) if world > 1 else None),
             "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 4),
         }
         if world == 1 and not args.no_cpu_baseline:

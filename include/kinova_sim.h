@@ -118,7 +118,8 @@ int ks_step(ks_ctx *ctx, const void *action, void *obs, void *reward, uint8_t *d
 /* Parity taps; any pointer may be NULL.  contact: [KS_NCON_MAX*KS_CONTACT_STRIDE, N] records of the
  * last substep (pos3 normal3 dist mu bodies R aref4 force3(normal,t1,t2) active-row-mask D spare; needs cfg.contact_tap), ncon: int32 [N],
  * status: int32 [N] sticky bit flags (1 contact overflow, 2 non-finite state, 4 the env's rays were not delivered in time by the
- * stepping launch's ray pool - a wait ran out; never seen in practice, reported instead of hanging). */
+ * stepping launch's ray pool - a wait ran out; never seen in practice, reported instead of hanging; 8 a substep's Newton iteration
+ * ended at cfg.solver_iterations before its stop rule fired: that substep used a truncated iterate). */
 int ks_get_state(ks_ctx *ctx, void *qpos, void *qvel, void *qacc_warmstart, void *contact, int32_t *ncon, int32_t *status, void *stream);
 int ks_set_state(ks_ctx *ctx, const void *qpos, const void *qvel, const void *qacc_warmstart, void *stream);
 

@@ -2000,6 +2000,7 @@ KS_FN_SOLVER void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm,
     }
     KS_TICK(13)
     T xb[CPL][3], pb[CPL][3];
+    bool converged = false;
     for (int it = 0; it < iterations; it++) {
 #ifdef KS_STAMP
         if (prof) prof[21] += 1.f;
@@ -2245,8 +2246,11 @@ KS_FN_SOLVER void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm,
         team.sync();                                   // slots 14..18 are rewritten by the next iteration
         // converged: the step just taken is below 1e-5 of the solution scale (Newton is quadratic, the
         // next step would be far smaller); lanes that are done wait for the slowest env of the wave
-        if (dmax <= T(1e-5) * (1 + amax) || flips == 0) break;
+        if (dmax <= T(1e-5) * (1 + amax) || flips == 0) { converged = true; break; }
     }
+    // the iteration cap ended the loop before the stop rule did: the acceleration is a truncated Newton iterate (sticky flag,
+    // ks_get_state; tests/studies/solver_cap.py measures what a cap of 6 costs)
+    if (!converged) status |= ST_NEWTON_CAP;
     KS_TICK(19)
     // --- constraint forces at the final a: owners publish (fn, ft1, ft2) in slots 14..16 (also the parity tap)
     KS_UNROLL

@@ -18,7 +18,7 @@ constexpr int NRAY = 17;
 constexpr int SUPPORT_R = KS_SUPPORT_R, SUPPORT_CELLS = 6 * SUPPORT_R * SUPPORT_R;   // cube-map resolution of the support start tables
 
 // status bits reported per env
-constexpr int ST_CONTACT_OVERFLOW = 1, ST_NONFINITE = 2, ST_RAY_POOL_TIMEOUT = 4;
+constexpr int ST_CONTACT_OVERFLOW = 1, ST_NONFINITE = 2, ST_RAY_POOL_TIMEOUT = 4, ST_NEWTON_CAP = 8;
 
 template <typename T> struct Model {
     T dt, impratio, gravity_z, mpr_tol;

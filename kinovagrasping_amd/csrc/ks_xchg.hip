@@ -15,11 +15,14 @@
 //   signal every peer's flag set B[block][me] = epoch
 //
 // Workgroups are independent (a flag row per workgroup), 256 threads, no LDS, ~32 registers: they run on the registers and
-// issue slots the stepping kernel leaves free, like the learner's other launches.  Spins are bounded (wall clock): a peer that
-// never arrives makes the call set an error word instead of hanging the GPU; kr_xchg_status reports it.
+// issue slots the stepping kernel leaves free, like the learner's other launches.  Spins are bounded (wall clock, 60 s unless
+// KS_XCHG_TIMEOUT_S says otherwise; <= 0 waits for ever like a library collective): a peer that never arrives makes the call set a
+// sticky error word instead of hanging the GPU - from then on this rank's gradients are NOT reduced, so the host must look at
+// kr_xchg_status: PeerExchange.check() does, and the trainer calls it every few hundred updates and at every flush.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -31,7 +34,8 @@ namespace {
 constexpr int XB = 32;            // workgroups per all-reduce (each owns 1/32 of the buffer and one row of every flag set)
 constexpr int XT = 256;           // threads per workgroup
 constexpr int XR = KR_XCHG_MAX_RANKS;
-constexpr long long SPIN_TICKS = 400000000ll;   // 4 s of the 100 MHz wall clock
+constexpr long long TICKS_PER_S = 100000000ll;   // wall_clock64: 100 MHz
+constexpr double DEFAULT_TIMEOUT_S = 60.0;       // KS_XCHG_TIMEOUT_S overrides; <= 0: wait for ever (what a library collective does)
 
 struct Flags {
     uint32_t a[XB][XR];           // arrival of epoch e: peer r's data block holds its gradient slice
@@ -45,26 +49,30 @@ struct Peers {
     const float* data[XR];
 };
 
-__device__ __forceinline__ bool spin_until(const uint32_t* p, uint32_t want) {
+__device__ __forceinline__ bool spin_until(const uint32_t* p, uint32_t want, long long spin_ticks) {
     const long long t0 = wall_clock64();
     while ((int32_t)(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
-        if (wall_clock64() - t0 > SPIN_TICKS) return false;
+        if (spin_ticks > 0 && wall_clock64() - t0 > spin_ticks) return false;
         __builtin_amdgcn_s_sleep(2);
     }
     return true;
 }
 
 __global__ __launch_bounds__(XT) void k_xchg_allreduce(Peers peers, int world, int me, uint32_t epoch, float* __restrict__ grad, long count,
-                                                       float* __restrict__ mine) {
+                                                       float* __restrict__ mine, long per, long long spin_ticks) {
     Flags* my = peers.flags[me];
     const int blk = blockIdx.x, tid = threadIdx.x;
-    // slice of this workgroup, in float4 units; the last count % 4 elements go with workgroup 0
-    const long n4 = count >> 2, per = (n4 + XB - 1) / XB, lo = blk * per < n4 ? blk * per : n4, hi = lo + per < n4 ? lo + per : n4;
-    const long tail = (blk == 0 && tid < (count & 3)) ? 4 * n4 + tid : -1;
+    // Slice of this workgroup, in float4 units.  The partition is FIXED at create time (per = ceil(capacity / 4 / XB)), not derived
+    // from this call's count: a workgroup's departure flags only say that the peers' workgroup `blk` has finished reading region
+    // `blk` of my block, so region `blk` must be the same words in every call - with a count-dependent split (the learner
+    // alternates 88321 / 88068 floats) workgroup blk of call e+1 overwrote up to 31 float4 that a peer's workgroup blk-1 of call e
+    // could still be reading.  The last count % 4 elements belong to the workgroup whose region holds float4 index n4.
+    const long n4 = count >> 2, lo = blk * per < n4 ? blk * per : n4, hi = lo + per < n4 ? lo + per : n4;
+    const long tail = (blk == (int)(n4 / per) && tid < (count & 3)) ? 4 * n4 + tid : -1;
     // (no __syncthreads_and / shared flags: they would cost LDS.  The waiting lanes sit in wave 0; a spin that runs out sets the
     // block's sticky error word, which everybody reads after the barrier)
     // peers have read what the previous call left in my data block
-    if (epoch > 1 && tid < world && tid != me && !spin_until(&my->b[blk][tid], epoch - 1))
+    if (epoch > 1 && tid < world && tid != me && !spin_until(&my->b[blk][tid], epoch - 1, spin_ticks))
         __hip_atomic_store(&my->error, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
     float4* dst = (float4*)mine;
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(XT) void k_xchg_allreduce(Peers peers, int world, i
     __syncthreads();
     if (tid < world && tid != me) {
         __hip_atomic_store(&peers.flags[tid]->a[blk][me], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (!spin_until(&my->a[blk][tid], epoch)) __hip_atomic_store(&my->error, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!spin_until(&my->a[blk][tid], epoch, spin_ticks)) __hip_atomic_store(&my->error, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
     if (__hip_atomic_load(&my->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
@@ -105,6 +113,8 @@ __global__ __launch_bounds__(XT) void k_xchg_allreduce(Peers peers, int world, i
 struct kr_xchg {
     int world = 0, rank = 0;
     long capacity = 0;                 // floats
+    long per = 0;                      // float4 per workgroup region: ceil(capacity / 4 / XB), fixed for the life of the block
+    long long spin_ticks = 0;          // bound of every wait in wall-clock ticks; 0 = unbounded
     void* block = nullptr;             // [Flags | data]
     void* mapped[XR] = {};
     Peers peers{};
@@ -119,6 +129,10 @@ int kr_xchg_create(kr_xchg** out, int32_t world, int32_t rank, int64_t max_count
     kr_xchg* x = new kr_xchg;
     x->world = world; x->rank = rank;
     x->capacity = (max_count + 3) / 4 * 4;
+    x->per = (x->capacity / 4 + XB - 1) / XB;
+    double timeout_s = DEFAULT_TIMEOUT_S;
+    if (const char* e = getenv("KS_XCHG_TIMEOUT_S")) timeout_s = atof(e);
+    x->spin_ticks = timeout_s > 0 ? (long long)(timeout_s * (double)TICKS_PER_S) : 0;
     const size_t bytes = sizeof(Flags) + (size_t)x->capacity * sizeof(float);
     // uncached (fine-grained) device memory: peers' stores to the flags and loads of the data must not meet a stale L2 line
     if (hipExtMallocWithFlags(&x->block, bytes, hipDeviceMallocUncached) != hipSuccess) { delete x; return KS_ERR_HIP; }
@@ -152,7 +166,7 @@ int kr_xchg_allreduce_mean(kr_xchg* x, float* grad, int64_t count, void* stream)
     if (!x || !x->connected || !grad || count <= 0 || count > x->capacity || ((uintptr_t)grad & 15) != 0) return KS_ERR_INVALID;
     x->epoch++;
     hipLaunchKernelGGL(k_xchg_allreduce, dim3(XB), dim3(XT), 0, (hipStream_t)stream, x->peers, x->world, x->rank, x->epoch, grad, (long)count,
-                       (float*)((char*)x->block + sizeof(Flags)));
+                       (float*)((char*)x->block + sizeof(Flags)), x->per, x->spin_ticks);
     return hipGetLastError() == hipSuccess ? KS_OK : KS_ERR_HIP;
 }
 

@@ -87,10 +87,22 @@ def controller_action(mode: str, obs: torch.Tensor, init_x: torch.Tensor, init_d
     return out
 
 
+MIN_LIFT_TIMESTEPS = 10        # expert_data.py:762
+
+
 @torch.no_grad()
-def run_controller_episodes(sim, obs0: torch.Tensor, replay=None, horizon: int = 30, mode: str = "combined"):
-    """One episode per env with a scripted demonstrator (expert_data.py:690-921 loop: check_grasp after >= 6 steps
-    latches the lift flag).  Returns dict(success [N] bool, steps [N], total_reward [N]); all transitions go to `replay`."""
+def run_controller_episodes(sim, obs0: torch.Tensor, replay=None, horizon: int = 30, mode: str = "combined", lift_rule: str = "expert"):
+    """One episode per env with a scripted demonstrator.  Returns dict(success [N] bool, steps [N], total_reward [N]).
+
+    lift_rule "expert" (default) is the demonstration loop of expert_data.py:746-804 as it behaves: prev_obs is first set at
+    the END of step 1 (`if total_steps > 0: prev_obs = obs`, :798), so check_grasp runs from step 2 on; every hit counts
+    (`num_good_grasps`, never reset); the lift flag is `total_steps > min_lift_timesteps (10) and num_good_grasps >= 1`
+    (:762-772); transitions are stored only while NOT lifting (:789-790) and an episode that ends during the lift
+    overwrites its last stored transition with the outcome (`replay_buffer.replace`, :792-793, utils.py:309-343).
+    lift_rule "train" is the training loop's rule (main_DDPGfD.py:418-439): check_grasp from the 6th step on, latched; every
+    transition stored (what round 2 used for demonstrations too)."""
+    if lift_rule not in ("expert", "train"):
+        raise ValueError(lift_rule)
     n, dev = sim.n_envs, sim.device
     obs = obs0.clone()
     init_x, init_dot = obs[:, 21].clone(), obs[:, 81].clone()
@@ -101,15 +113,25 @@ def run_controller_episodes(sim, obs0: torch.Tensor, replay=None, horizon: int =
     steps = torch.zeros(n, dtype=torch.long, device=dev)
     total = torch.zeros(n, device=dev)
     for t in range(horizon):
-        if prev is not None and t + 1 >= SKIP_NUM_TS:
-            ready |= check_grasp(prev[:, 9:17], obs[:, 9:17]) & alive
-        action = controller_action(mode, obs, init_x, init_dot, ready).to(obs.dtype)
+        if lift_rule == "expert":
+            if prev is not None and t >= 2:
+                ready |= check_grasp(prev[:, 9:17], obs[:, 9:17]) & alive
+            lift = ready & (t > MIN_LIFT_TIMESTEPS)
+        else:
+            if prev is not None and t + 1 >= SKIP_NUM_TS:
+                ready |= check_grasp(prev[:, 9:17], obs[:, 9:17]) & alive
+            lift = ready
+        action = controller_action(mode, obs, init_x, init_dot, lift).to(obs.dtype)
         state = obs
         nobs, reward, done, info = sim.step(action.t().contiguous())
         done_b = (done != 0) & alive
         nxt = torch.where(done_b.unsqueeze(1), sim.final_obs, nobs) if sim.cfg.auto_reset else nobs
         if replay is not None:
-            replay.add(state, action, nxt, reward, done_b | (t == horizon - 1), store_mask=alive)
+            if lift_rule == "expert":
+                replay.add(state, action, nxt, reward, done_b | (t == horizon - 1), store_mask=alive & ~lift)
+                replay.replace_last(alive & lift & done_b, reward)
+            else:
+                replay.add(state, action, nxt, reward, done_b | (t == horizon - 1), store_mask=alive)
         total += torch.where(alive, reward, torch.zeros_like(reward))
         steps += alive.long()
         success |= done_b & (info[2] > 0)

@@ -58,6 +58,16 @@ class PeerExchange:
             raise RuntimeError("kr_xchg_status failed")
         return int(e.value)
 
+    def check(self):
+        """Raise if one of this rank's exchange kernels gave up waiting for a peer (KS_XCHG_TIMEOUT_S, 60 s by default).  From that
+        call on this rank's gradients are no longer reduced while its peers may carry on: the replicas have diverged and the run
+        must stop - loudly, on the training path (GraphedTrainer polls this every few hundred updates and at every flush)."""
+        e = self.failed_epoch()
+        if e:
+            raise RuntimeError(f"PeerExchange: rank {self.rank} timed out waiting for a peer in all-reduce call {e}; its gradients have not been "
+                               "reduced since - replicas have diverged.  (KS_XCHG_TIMEOUT_S sets the bound, <= 0 waits for ever; KS_P2P=0 uses "
+                               "the library collective.)")
+
     def self_test(self, rounds: int = 3) -> str | None:
         """None when the exchange reproduces the process group's all_reduce on every rank, else the reason (same on all ranks)"""
         dist, dev = self.dist, self.device

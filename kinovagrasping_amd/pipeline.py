@@ -74,6 +74,12 @@ class GraphedTrainer:
             else:
                 self.exchange_note = f"{backend} all_reduce"
         self.sample_seed = int(torch.initial_seed())          # the window sampler's Philox key
+        # first-contact safety on a real node: every `check_every` updates the exchange's error word is read (a rank whose wait for a
+        # peer ran out stops reducing: fail loudly instead of training diverged replicas) and the replicas' weight checksums are
+        # compared over the process group.  Both are host reads, hence not every update.
+        import os as _os
+        self.check_every = int(_os.environ.get("KS_REPLICA_CHECK_EVERY", "500")) if self.distributed else 0
+        self.replica_checks = 0
 
     # -- learner phases on the static batch -------------------------------------------------------------
     def _sample(self):
@@ -185,6 +191,33 @@ class GraphedTrainer:
             self.g_learn[1].replay()
             self.native.allreduce("actor")
         self.updates += 1
+        if self.check_every and self.updates % self.check_every == 0:
+            self.check_replicas()
+
+    def replica_checksum_spread(self) -> float:
+        """max over the four networks of |max - min| over the ranks of two checksums (sum, sum of |.|) of the flat parameters: 0.0
+        when the replicas are bit-identical.  Two small collectives on the process group + a host read."""
+        import torch.distributed as dist
+        pol = self.policy
+        chk = torch.stack([f(pol._flat_params[k].double()) for k in ("actor", "critic", "actor_target", "critic_target")
+                           for f in (torch.sum, lambda x: x.abs().sum())])
+        hi, lo = chk.clone(), chk.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=pol.process_group)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=pol.process_group)
+        return float((hi - lo).abs().max().item())
+
+    def check_replicas(self):
+        """Called every `check_every` updates on the learner's stream position (all ranks reach it at the same update count)."""
+        if not self.distributed:
+            return
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_stream(self.side)
+        if self.native.exchange is not None:
+            self.native.exchange.check()
+        spread = self.replica_checksum_spread()
+        self.replica_checks += 1
+        if spread != 0.0:
+            raise RuntimeError(f"replica weights differ between ranks after {self.updates} updates (checksum spread {spread:.3e}); exchange: {self.exchange_note}")
 
     def step(self):
         """One env-step for every env + one learner update (once the replay holds episodes)."""
@@ -235,3 +268,5 @@ class GraphedTrainer:
                 if finish_update:
                     self.native.finish_pending()
             self.main.wait_stream(self.side)
+        if self.distributed and self.native.exchange is not None:
+            self.native.exchange.check()

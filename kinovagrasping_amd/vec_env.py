@@ -21,7 +21,7 @@ import torch
 
 from . import scenarios
 from .model_compiler import read_blob
-from .sim import KinovaSim, NOBS
+from .sim import NOBS, SOLVER_ITERATIONS, KinovaSim
 
 COORDS_DIR = "gym_kinova_gripper/envs/kinova_description/obj_hand_coords/"     # ENV:1245
 
@@ -30,7 +30,7 @@ class KinovaGripperVecEnv:
     metadata = {"render.modes": []}
 
     def __init__(self, n_envs: int, shape="CubeS", device: int = 0, frame_skip: int = 15, max_episode_steps: int = 30,
-                 auto_reset: bool = True, solver_iterations: int = 6, seed: int = 0, hand_offsets: str = "pose"):
+                 auto_reset: bool = True, solver_iterations: int = SOLVER_ITERATIONS, seed: int = 0, hand_offsets: str = "pose"):
         """shape: one object name, or a list of them (mixed-object batches, BASELINE config 5).
         hand_offsets: where the 'rotated' / 'top' hands start (determine_hand_location, ENV:1286-1307) - "pose": with the
         pose's own palm rotation, as intended; "fresh-env": zero, as the reference's training driver ends up doing because it

@@ -96,6 +96,11 @@ typedef struct {
      * obj_mass > 0 replaces the object's mass (inertia scales with it, its body_invweight0 by
      * (m0 + armature) / (m + armature)); obj_mu > 0 replaces the friction of the object-hand pairs. */
     double obj_mass, obj_mu;
+    /* Newton stop rule: the iteration ends when the last step is below solver_tolerance * (1 + |qacc|_inf) (1e-5 by default, the
+     * product kernels' rule) or at solver_iterations.  newton_converged = 1 when the rule fired (0: the cap ended the loop),
+     * newton_last_step = that last relative step - what the solver-cap study (tests/studies/solver_cap.py) reads. */
+    double solver_tolerance, newton_last_step;
+    int newton_converged;
 } ko_sim;
 
 /* ---- model ---- */

@@ -945,6 +945,8 @@ static void solve_newton(ko_sim *s) {
     if (primal_cost(s, s->qacc_warmstart) < primal_cost(s, s->qacc_smooth)) memcpy(a, s->qacc_warmstart, sizeof a);
     else memcpy(a, s->qacc_smooth, sizeof a);
     s->newton_last_grad = 0;
+    s->newton_converged = 0;
+    s->newton_iters_used = 0;
     for (int it = 0; it < s->solver_iterations; it++) {
         /* gradient and Hessian at a */
         for (int i = 0; i < KO_NV; i++) {
@@ -1023,7 +1025,8 @@ static void solve_newton(ko_sim *s) {
             if (fabs(da) > dmax) dmax = fabs(da);
         }
         s->newton_iters_used = it + 1;
-        if (dmax <= 1e-5 * (1 + amax)) break; /* converged (same rule as the GPU kernel) */
+        s->newton_last_step = dmax / (1 + amax);
+        if (dmax <= s->solver_tolerance * (1 + amax)) { s->newton_converged = 1; break; } /* same rule as the GPU kernel */
     }
     /* outputs */
     memcpy(s->qacc, a, sizeof a);
@@ -1165,6 +1168,7 @@ ko_sim *ko_sim_new(const ko_model *m, const double hand_quat[4]) {
     quatnormalize(s->hand_quat);
     s->solver = 0;
     s->solver_iterations = 8;
+    s->solver_tolerance = 1e-5;
     s->ncon_max = KO_NCON_MAX;
     s->rays_enabled = 1;
     s->qpos[12] = 1.0;

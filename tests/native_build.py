@@ -5,6 +5,8 @@ from pathlib import Path
 
 import numpy as np
 
+from kinovagrasping_amd.sim import SOLVER_ITERATIONS
+
 HERE = Path(__file__).resolve().parent / "native"
 CSRC = Path(__file__).resolve().parents[1] / "kinovagrasping_amd" / "csrc"
 dp = C.POINTER(C.c_double)
@@ -32,7 +34,7 @@ def P(a):
 class Lane:
     """one lane of the kernel source on the CPU, fp32 or fp64"""
 
-    def __init__(self, blob: bytes, prec: int, iters: int = 6):
+    def __init__(self, blob: bytes, prec: int, iters: int = SOLVER_ITERATIONS):
         self.L = lanecheck_lib()
         self.h = self.L.lc_create(blob, len(blob))
         assert self.h

@@ -22,6 +22,7 @@ import torch
 
 from oracle import ko_py as ko
 from kinovagrasping_amd import scenarios
+from kinovagrasping_amd.sim import SOLVER_ITERATIONS
 
 pytestmark = pytest.mark.gpu
 POSES = ("normal", "rotated", "top")
@@ -60,7 +61,7 @@ def ctrl_of(o, action):
 def oracle_substep_records(model, shape, orientation, row, n_env_steps=22):
     """closing grasp then lift (the reference's scripted lift action), every substep recorded with its contacts"""
     q0, hq = pose_start(shape, orientation, row)
-    o = ko.OracleSim(model, hq, solver_iterations=6)
+    o = ko.OracleSim(model, hq, solver_iterations=SOLVER_ITERATIONS)
     o.env_reset(q0)
     rec = []
     for t in range(n_env_steps):
@@ -79,7 +80,7 @@ def oracle_substep_records(model, shape, orientation, row, n_env_steps=22):
 
 def gpu_one_substep(precision, shape, hq, rec):
     n = len(rec)
-    sim = _sim(n, shape, precision=precision, solver_iterations=6, contact_tap=True)
+    sim = _sim(n, shape, precision=precision, solver_iterations=SOLVER_ITERATIONS, contact_tap=True)
     q0 = np.stack([r["before"][0] for r in rec], 1)
     sim.reset(torch.as_tensor(q0), torch.as_tensor(np.repeat(hq[:, None], n, 1)))
     sim.set_state(torch.as_tensor(q0), torch.as_tensor(np.stack([r["before"][1] for r in rec], 1)),
@@ -162,7 +163,7 @@ def test_post_step_observation_reward_done_from_oracle_states(orientation):
     states, acts, ref = [], [], []
     for row in (0, 700, 2100, 3900):
         q0, hq = pose_start("CubeS", orientation, row)
-        o = ko.OracleSim(model, hq, solver_iterations=6)
+        o = ko.OracleSim(model, hq, solver_iterations=SOLVER_ITERATIONS)
         o.env_reset(q0)
         a = scenarios.config_actions(1, 24, base_seed=40 + row)[:, :, 0].astype(np.float64)
         a[:, 1:] = np.abs(a[:, 1:])                               # fingers close, wrist wanders: contact-rich states
@@ -209,8 +210,8 @@ def test_free_running_episode_observations_in_every_pose(orientation):
     model = ko.OracleModel(scenarios.model_blob("CubeS"))
     q0, hq = pose_start("CubeS", orientation, 0)
     acts = scenarios.config_actions(1, 30, base_seed=0)[:, :, 0]
-    o = ko.OracleSim(model, hq, solver_iterations=6)
-    sim = _sim(1, "CubeS", solver_iterations=6, horizon=0)
+    o = ko.OracleSim(model, hq, solver_iterations=SOLVER_ITERATIONS)
+    sim = _sim(1, "CubeS", solver_iterations=SOLVER_ITERATIONS, horizon=0)
     ob0 = o.env_reset(q0)
     og0 = sim.reset(torch.as_tensor(q0[:, None]), torch.as_tensor(hq[:, None])).double().cpu().numpy()[0].copy()
     np.testing.assert_allclose(og0, ob0, rtol=2e-4, atol=2e-5)
@@ -352,7 +353,7 @@ def test_fourteen_shapes_three_poses_observations_track_the_oracle():
         rel32, rel64, launched, nbad, nray = np.zeros(n), np.zeros(n), np.zeros(n, bool), 0, 0
         t_obs = obs_tolerance(5e-4)
         for i in range(n):
-            o = ko.OracleSim(model, hqs[i], solver_iterations=6)
+            o = ko.OracleSim(model, hqs[i], solver_iterations=SOLVER_ITERATIONS)
             o.env_reset(q0s[i])
             for t in range(4):
                 ob = o.env_step(act)[0]

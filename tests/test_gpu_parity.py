@@ -16,6 +16,7 @@ import torch
 
 from oracle import ko_py as ko
 from kinovagrasping_amd import scenarios
+from kinovagrasping_amd.sim import SOLVER_ITERATIONS
 
 pytestmark = pytest.mark.gpu
 
@@ -30,7 +31,7 @@ def cube(assets_dir):
     return ko.OracleModel(scenarios.model_blob("CubeS"))
 
 
-def oracle_grasp_trajectory(model, n_sub=330, x0=0.0, y0=0.0, iters=6):
+def oracle_grasp_trajectory(model, n_sub=330, x0=0.0, y0=0.0, iters=SOLVER_ITERATIONS):
     """closing fingers, then lifting: returns per-substep (state before, ctrl, state after)"""
     hq = scenarios.hand_quat_for("normal")
     s = ko.OracleSim(model, hq, solver_iterations=iters)
@@ -48,7 +49,7 @@ def oracle_grasp_trajectory(model, n_sub=330, x0=0.0, y0=0.0, iters=6):
     return hq, rec
 
 
-def run_teacher_forced(precision, model, rec, hq, iters=6, shape="CubeS"):
+def run_teacher_forced(precision, model, rec, hq, iters=SOLVER_ITERATIONS, shape="CubeS"):
     n = len(rec)
     sim = _sim(n, shape, precision=precision, solver_iterations=iters)
     dt = sim.dtype
@@ -104,7 +105,7 @@ def test_primitive_objects_one_step_matches_oracle(shape):
     blob = scenarios.model_blob(shape)
     model = ko.OracleModel(blob)
     hq = scenarios.hand_quat_for("normal")
-    o = ko.OracleSim(model, hq, solver_iterations=6)
+    o = ko.OracleSim(model, hq, solver_iterations=SOLVER_ITERATIONS)
     half_h = mc.read_blob(blob)["geom_size"][8][2]
     q0 = np.zeros(16); q0[9:12] = [0.0, 0.0, half_h + 0.01]; q0[12] = 1
     o.env_reset(q0)
@@ -141,9 +142,9 @@ def test_config1_episode_free_running(cube):
     """BASELINE config 1: one CubeS env, PCG64(0) actions, 30 env-steps, GPU fp32 vs oracle."""
     q0, hq = scenarios.config1_state("CubeS")
     acts = scenarios.config_actions(1, 30, base_seed=0)[:, :, 0]
-    o = ko.OracleSim(cube, hq, solver_iterations=6)
+    o = ko.OracleSim(cube, hq, solver_iterations=SOLVER_ITERATIONS)
     obs_o = [o.env_reset(q0)]
-    sim = _sim(1, "CubeS", solver_iterations=6, horizon=0)
+    sim = _sim(1, "CubeS", solver_iterations=SOLVER_ITERATIONS, horizon=0)
     obs_g = [sim.reset(torch.as_tensor(q0[:, None]), torch.as_tensor(hq[:, None])).double().cpu().numpy()[0].copy()]
     first_bad = None
     for t in range(30):
@@ -171,9 +172,9 @@ def test_batch_config2_first_steps(cube):
     n = 128
     q0, hq = scenarios.config2_states(n)
     acts = scenarios.config_actions(n, 3)
-    sim = _sim(n, "CubeS", solver_iterations=6)
+    sim = _sim(n, "CubeS", solver_iterations=SOLVER_ITERATIONS)
     og = sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
-    orc = [ko.OracleSim(cube, hq[:, i], solver_iterations=6) for i in range(n)]
+    orc = [ko.OracleSim(cube, hq[:, i], solver_iterations=SOLVER_ITERATIONS) for i in range(n)]
     oo = np.stack([orc[i].env_reset(q0[:, i]) for i in range(n)])
     torch.cuda.synchronize()
     np.testing.assert_allclose(og.double().cpu().numpy(), oo, rtol=2e-4, atol=2e-5)
@@ -300,7 +301,7 @@ def test_mixed_shape_batch_equals_per_shape_contexts(assets_dir):
         assert torch.equal(o1, om[sl]) and torch.equal(sim.get_state()["qpos"], qm[:, sl])
         # oracle for this shape, first env of the block
         model = ko.OracleModel(scenarios.model_blob(sh))
-        o = ko.OracleSim(model, hq[:, 0], solver_iterations=6)
+        o = ko.OracleSim(model, hq[:, 0], solver_iterations=SOLVER_ITERATIONS)
         o.s.obj_mass, o.s.obj_mu = mass[k * per], mu[k * per]
         o.env_reset(q0[:, k * per])
         for t in range(2):
@@ -456,7 +457,7 @@ def test_randomised_mass_and_friction_match_oracle(cube):
     hq = scenarios.hand_quat_for("normal")
     recs, env_of = [], []
     for e in range(n_env):
-        s = ko.OracleSim(cube, hq, solver_iterations=6)
+        s = ko.OracleSim(cube, hq, solver_iterations=SOLVER_ITERATIONS)
         s.s.obj_mass, s.s.obj_mu = masses[e], mus[e]
         q0 = np.zeros(16); q0[9:12] = [0.01 * (e - 2), 0.0, 0.0654]; q0[12] = 1
         s.env_reset(q0)
@@ -473,7 +474,7 @@ def test_randomised_mass_and_friction_match_oracle(cube):
     env_of = np.array(env_of)
     assert max(r[3] for r in recs) >= 4                      # the grasps do make finger contacts
     for precision, tol_med, tol_p99 in ((64, 1e-10, 1e-8), (32, 5e-7, 2e-4)):
-        sim = _sim(n, "CubeS", precision=precision, solver_iterations=6)
+        sim = _sim(n, "CubeS", precision=precision, solver_iterations=SOLVER_ITERATIONS)
         q0 = np.stack([r[0][0] for r in recs], 1)
         sim.reset(torch.as_tensor(q0), torch.as_tensor(np.repeat(hq[:, None], n, 1)))
         sim.set_env_params(masses[env_of], mus[env_of])
@@ -486,7 +487,7 @@ def test_randomised_mass_and_friction_match_oracle(cube):
         assert np.median(eq) <= tol_med and np.percentile(eq, 99) <= tol_p99
         # the overrides matter: the same states stepped with nominal parameters differ from the oracle where there is contact
         if precision == 64:
-            sim2 = _sim(n, "CubeS", precision=64, solver_iterations=6)
+            sim2 = _sim(n, "CubeS", precision=64, solver_iterations=SOLVER_ITERATIONS)
             sim2.reset(torch.as_tensor(q0), torch.as_tensor(np.repeat(hq[:, None], n, 1)))
             sim2.set_state(torch.as_tensor(q0), torch.as_tensor(np.stack([r[0][1] for r in recs], 1)), torch.as_tensor(np.stack([r[0][2] for r in recs], 1)))
             sim2.substep(torch.as_tensor(np.stack([r[1] for r in recs], 1)))
@@ -582,7 +583,7 @@ def test_all_fourteen_shapes_track_the_oracle(assets_dir):
         model = ko.OracleModel(scenarios.model_blob(sh))
         rel = {32: [], 64: []}
         for i in range(per):
-            o = ko.OracleSim(model, hq[:, i], solver_iterations=6)
+            o = ko.OracleSim(model, hq[:, i], solver_iterations=SOLVER_ITERATIONS)
             o.env_reset(q0[:, i])
             for t in range(6):
                 o.env_step(act[:, i])
@@ -870,8 +871,8 @@ def test_full_size_batch_equals_its_slices():
     n, lo, m = 4096, 512, 256
     q0, hq = scenarios.config2_states(n)
     acts = scenarios.config_actions(n, 6)
-    big = _sim(n, "CubeS", solver_iterations=6, auto_reset=True, horizon=4)
-    small = _sim(m, "CubeS", solver_iterations=6, auto_reset=True, horizon=4)
+    big = _sim(n, "CubeS", solver_iterations=SOLVER_ITERATIONS, auto_reset=True, horizon=4)
+    small = _sim(m, "CubeS", solver_iterations=SOLVER_ITERATIONS, auto_reset=True, horizon=4)
     ob = big.reset(torch.as_tensor(q0), torch.as_tensor(hq))
     os_ = small.reset(torch.as_tensor(q0[:, lo:lo + m]), torch.as_tensor(hq[:, lo:lo + m]))
     assert torch.equal(ob[lo:lo + m], os_)

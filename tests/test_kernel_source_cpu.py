@@ -6,6 +6,7 @@ import pytest
 
 from oracle import ko_py as ko
 from kinovagrasping_amd import scenarios
+from kinovagrasping_amd.sim import SOLVER_ITERATIONS
 from tests.native_build import Lane
 
 
@@ -14,7 +15,7 @@ def blob(assets_dir):
     return scenarios.model_blob("CubeS")
 
 
-def grasp_states(blob, n_sub=330, iters=6):
+def grasp_states(blob, n_sub=330, iters=SOLVER_ITERATIONS):
     m = ko.OracleModel(blob)
     hq = scenarios.hand_quat_for("normal")
     s = ko.OracleSim(m, hq, solver_iterations=iters)
@@ -64,7 +65,7 @@ def test_env_step_and_observation(blob, prec, tol):
     m = ko.OracleModel(blob)
     q0, hq = scenarios.config1_state("CubeS")
     acts = scenarios.config_actions(1, 8, base_seed=0)[:, :, 0]
-    o = ko.OracleSim(m, hq, solver_iterations=6)
+    o = ko.OracleSim(m, hq, solver_iterations=SOLVER_ITERATIONS)
     lane = Lane(blob, prec)
     obs_o = o.env_reset(q0)
     obs_l, rays = lane.reset_obs(q0, hq)
@@ -91,7 +92,7 @@ def test_shapes_load_and_rest(assets_dir):
         blob = scenarios.model_blob(shape)
         m = ko.OracleModel(blob)
         hq = scenarios.hand_quat_for("normal")
-        o = ko.OracleSim(m, hq, solver_iterations=6)
+        o = ko.OracleSim(m, hq, solver_iterations=SOLVER_ITERATIONS)
         q0 = np.zeros(16); q0[9:12] = [0.03, 0.01, 0.08]; q0[12] = 1
         o.env_reset(q0)
         lane = Lane(blob, 64)
@@ -111,7 +112,7 @@ def test_hand_pressed_on_the_ground(blob, orientation, min_seen):
     flood-filled margin patch) must reproduce the oracle's exhaustive scans, contact for contact (fp64)."""
     m = ko.OracleModel(blob)
     hq = scenarios.hand_quat_for(orientation)
-    o = ko.OracleSim(m, hq, solver_iterations=6)
+    o = ko.OracleSim(m, hq, solver_iterations=SOLVER_ITERATIONS)
     q0 = np.zeros(16); q0[9:12] = [0.03, 0.0, 0.0654]; q0[12] = 1
     o.env_reset(q0)
     lane = Lane(blob, 64)
@@ -125,8 +126,8 @@ def test_hand_pressed_on_the_ground(blob, orientation, min_seen):
         hand_ground = sum(1 for c in o.contacts() if c["geom1"] == 0 and c["geom2"] != 8)
         seen = max(seen, hand_ground)
         assert nc == o.s.ncon, (i, nc, o.s.ncon)
-        # deep start penetrations (the 'top' / 'rotated' poses start inside the floor, SURVEY note N5) need all six
-        # Newton iterations and are not converged to round-off, hence 1e-6 here instead of 1e-9
+        # deep start penetrations (the 'top' / 'rotated' poses start inside the floor, SURVEY note N5) take up to ten Newton
+        # iterations (rounds 1-2 capped them at six, un-converged); the last step's size is the 1e-5 stop rule's, hence 1e-6
         assert np.abs(qp - o.view("qpos")).max() < 1e-6, (i, np.abs(qp - o.view("qpos")).max())
     assert seen >= min_seen, seen      # hand geoms did touch the ground
 
@@ -140,7 +141,7 @@ def test_primitive_objects_drop_rest_and_grasp(assets_dir, shape, n_ground):
     M = __import__("kinovagrasping_amd.model_compiler", fromlist=["x"]).read_blob(blob)
     m = ko.OracleModel(blob)
     hq = scenarios.hand_quat_for("normal")
-    o = ko.OracleSim(m, hq, solver_iterations=6)
+    o = ko.OracleSim(m, hq, solver_iterations=SOLVER_ITERATIONS)
     half_h = M["geom_size"][8][2]
     q0 = np.zeros(16); q0[9:12] = [0.0, 0.0, half_h + 0.01]; q0[12] = 1
     o.env_reset(q0)

@@ -1,0 +1,181 @@
+"""The physics against every number of REAL MuJoCo 1.50 output that the reference tree holds
+(tests/golden/mujoco_recorded.npz, collected by tools/gen_golden_mujoco_recorded.py):
+
+  1. Old Code/Pose_file.csv - joint angles of a free finger closing, recorded from mujoco-py once per env.step() of the
+     frame_skip = 4 env (kinova_gripper_env_s.py:683-696): fingers 1 and 3 at the servo's maximum command 0.8, finger 2
+     commanded 0.  Pins, to ~1e-5 rad, the velocity-servo actuator (kv 2.5), joint damping 0.2 with its implicit
+     treatment in the Euler step, armature 0.01, the SOFT tendon equality (solref / solimp / tendon_invweight0: the
+     distal joint lags q_prox / 2 by 1.35 mrad after the first row, ratio 0.4754 -> 0.4996), gravity on the finger links
+     in the 'normal' hand orientation (finger 2 sags 1.5e-5 rad per row against its servo), and the fact that the jointpos
+     sensors are evaluated BEFORE the integration of their substep (row r is qpos after 4 r - 1 substeps).
+  2. expert_plots/*.npy - ten recorded demonstrations (expert_data.py:690-921): palm-frame start, outcome, env-steps.
+  3. expert_plots/heatmap_plots/*.png - naive-controller success / failure rate per start cell for CubeS.
+
+CPU tests run the fp64 oracle, `-m gpu` tests the HIP kernels through the C ABI (same host loops)."""
+import numpy as np
+import pytest
+import torch
+
+from kinovagrasping_amd import demonstrators, scenarios
+from kinovagrasping_amd.sim import SOLVER_ITERATIONS
+from tests.oracle_vec import OracleVecSim, place_at_palm_xy
+
+FREE_ROWS = 27           # rows 0..26: before finger 2 is commanded
+F1_FREE_ROWS = 13        # finger 1 meets the old env's object from row 13 on (its trace leaves finger 3's)
+COLS = [3, 5, 7, 4, 6, 8]  # qpos of f1_prox, f2_prox, f3_prox, f1_dist, f2_dist, f3_dist = Pose_file columns 1..6
+
+
+@pytest.fixture(scope="module")
+def rec(golden_dir):
+    return np.load(golden_dir / "mujoco_recorded.npz")
+
+
+def _free_closing_ctrl():
+    c = np.zeros(9)
+    c[6] = c[8] = 0.8
+    return c
+
+
+def _far_object_state():
+    q = np.zeros(16)
+    q[9:12] = [0.5, -0.5, scenarios.start_coord_table("CubeS")[0][2]]        # the object rests far from the hand
+    q[12] = 1.0
+    return q
+
+
+def _compare_with_pose_file(hist, pose, tol_f3, tol_f1):
+    """hist [4*FREE_ROWS + 1, 6]: joint angles after every substep.  Row r of the file = the jointpos sensors of the last
+    of its 4 substeps = qpos after 4 r - 1 integrations."""
+    idx = np.maximum(4 * np.arange(FREE_ROWS) - 1, 0)
+    ours, ref = hist[idx], pose[:FREE_ROWS, 1:7]
+    err = np.abs(ours - ref)
+    assert err[:, [1, 2, 4, 5]].max() < tol_f3, err[:, [1, 2, 4, 5]].max(0)          # fingers 2 and 3: all 27 rows
+    assert err[:F1_FREE_ROWS, [0, 3]].max() < tol_f1, err[:F1_FREE_ROWS, [0, 3]].max(0)
+    return err
+
+
+def test_oracle_free_closing_matches_recorded_mujoco_joint_traces(rec):
+    from oracle import ko_py as ko
+    pose = rec["pose_file"]
+    m = ko.OracleModel(scenarios.model_blob("CubeS"))
+    s = ko.OracleSim(m, scenarios.hand_quat_for("normal"), solver_iterations=100)
+    s.s.rays_enabled = 0
+    s.set_state(_far_object_state())
+    hist = [s.view("qpos")[COLS].copy()]
+    for _ in range(4 * FREE_ROWS):
+        s.step(_free_closing_ctrl())
+        hist.append(s.view("qpos")[COLS].copy())
+    hist = np.array(hist)
+    err = _compare_with_pose_file(hist, pose, 4e-5, 4e-5)
+    # what the recording discriminates: the data reject the un-lagged reading of the sensors by two orders of magnitude,
+    # and the other two hand orientations (gravity on the fingers) by three
+    unlagged = np.abs(hist[4 * np.arange(FREE_ROWS)] - pose[:FREE_ROWS, 1:7])
+    assert unlagged[:, 2].max() > 100 * err[:, 2].max()
+    # the soft tendon: distal / proximal after the first row is 0.4754 in MuJoCo (a rigid coupling would give 0.5)
+    assert abs(hist[3, 3] / hist[3, 0] - pose[1, 4] / pose[1, 1]) < 2e-4
+    assert abs(pose[1, 4] / pose[1, 1] - 0.4754) < 1e-4
+    # finger 2, commanded 0, sags under gravity against its servo: 4.04e-4 rad after 26 rows in MuJoCo
+    assert abs(hist[4 * 26 - 1, 1] - pose[26, 2]) < 2e-5 and pose[26, 2] > 3.9e-4
+
+
+@pytest.mark.parametrize("orientation", ["rotated", "top"])
+def test_recorded_traces_reject_the_other_hand_orientations(rec, orientation):
+    """sensitivity of the pin: with gravity along another axis of the hand the same run misses the recording by > 3e-3 rad"""
+    from oracle import ko_py as ko
+    pose = rec["pose_file"]
+    m = ko.OracleModel(scenarios.model_blob("CubeS"))
+    s = ko.OracleSim(m, scenarios.hand_quat_for(orientation), solver_iterations=100)
+    s.s.rays_enabled = 0
+    s.set_state(_far_object_state())
+    hist = [s.view("qpos")[COLS].copy()]
+    for _ in range(4 * FREE_ROWS):
+        s.step(_free_closing_ctrl())
+        hist.append(s.view("qpos")[COLS].copy())
+    hist = np.array(hist)
+    err = np.abs(hist[np.maximum(4 * np.arange(FREE_ROWS) - 1, 0)] - pose[:FREE_ROWS, 1:7])
+    assert err[:, 2].max() > 3e-3
+
+
+def _demo_episodes(sim, rec, mode="naive"):
+    q, hq, p = place_at_palm_xy(sim, rec["demo_x"], rec["demo_y"])
+    assert np.abs(p[0] - rec["demo_x"]).max() < 2e-5 and np.abs(p[1] - rec["demo_y"]).max() < 2e-5
+    obs0 = sim.reset(torch.as_tensor(q), torch.as_tensor(hq))
+    out = demonstrators.run_controller_episodes(sim, obs0.clone(), None, horizon=30, mode=mode, lift_rule="expert")
+    return out["success"].cpu().numpy().astype(int), out["steps"].cpu().numpy()
+
+
+def _check_demos(succ, steps, rec):
+    ref_s, ref_t = rec["demo_success"], rec["demo_steps"]
+    print("recorded outcome", ref_s, "steps", ref_t, "\nours     outcome", succ, "steps", steps)
+    # the eight recorded successes are successes here, six of them within 2 env-steps of the recorded duration
+    assert (succ[ref_s == 1] == 1).all()
+    d = np.abs(steps - ref_t)[ref_s == 1]
+    assert (d <= 3).sum() >= 7 and (d <= 2).sum() >= 6, d
+    # the two recorded failures sit in the near-palm centre zone where MuJoCo's naive controller fails (heat map); this
+    # simulator grasps there - a known behavioural deviation, asserted so that a change of it is noticed
+    assert (succ == ref_s).sum() >= 8
+
+
+def test_oracle_replays_the_recorded_demonstrations(rec):
+    sim = OracleVecSim(10, "CubeS", solver_iterations=100, rays=False)
+    succ, steps = _demo_episodes(sim, rec)
+    _check_demos(succ, steps, rec)
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [64, 32])
+def test_gpu_free_closing_matches_recorded_mujoco_joint_traces(rec, precision):
+    from kinovagrasping_amd.sim import KinovaSim
+    pose = rec["pose_file"]
+    n = 16
+    sim = KinovaSim(n, "CubeS", precision=precision, solver_iterations=SOLVER_ITERATIONS)
+    q = np.repeat(_far_object_state()[:, None], n, 1)
+    hq = np.repeat(scenarios.hand_quat_for("normal")[:, None], n, 1)
+    sim.reset(torch.as_tensor(q), torch.as_tensor(hq))
+    ctrl = torch.as_tensor(np.repeat(_free_closing_ctrl()[:, None], n, 1))
+    hist = [sim.get_state()["qpos"].double().cpu().numpy()[COLS, 0]]
+    for _ in range(4 * FREE_ROWS):
+        sim.substep(ctrl)
+        qp = sim.get_state()["qpos"].double().cpu().numpy()
+        assert np.abs(qp - qp[:, :1]).max() == 0.0               # identical envs stay bit-identical
+        hist.append(qp[COLS, 0])
+    tol = 4e-5 if precision == 64 else 6e-5
+    err = _compare_with_pose_file(np.array(hist), pose, tol, tol)
+    print(f"fp{precision}: max |dq| vs recorded MuJoCo, fingers 2/3 over 27 rows {err[:, [1, 2, 4, 5]].max():.2e}, finger 1 over 13 rows {err[:F1_FREE_ROWS, [0, 3]].max():.2e}")
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_gpu_replays_the_recorded_demonstrations(rec):
+    from kinovagrasping_amd.sim import KinovaSim
+    sim = KinovaSim(10, "CubeS", solver_iterations=SOLVER_ITERATIONS, horizon=30)
+    succ, steps = _demo_episodes(sim, rec)
+    _check_demos(succ, steps, rec)
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_gpu_naive_controller_success_map_vs_recorded_heatmap(rec):
+    """One naive-controller episode from the centre of every cell for which the reference's heat maps hold trials (1000+
+    cells); the outcome is compared with the recorded majority outcome of the cell.  The numbers asserted are the ones
+    measured in round 3 (profiles/r03_naive_heatmap.txt) with a margin - the map agrees on the outer success band and on the
+    far corners' failures, and DISAGREES on the near-palm centre blob, where MuJoCo fails and this simulator grasps."""
+    from kinovagrasping_amd.sim import KinovaSim
+    hs, hf, hx, hy = rec["heat_success"], rec["heat_fail"], rec["heat_x"], rec["heat_y"]
+    has = (hs > 0) | (hf > 0)
+    jj, ii = np.nonzero(has)
+    ref_rate = np.where(hs[jj, ii] > 0, hs[jj, ii], 100.0 - hf[jj, ii]) / 100.0
+    sim = KinovaSim(len(jj), "CubeS", solver_iterations=SOLVER_ITERATIONS, horizon=30)
+    q, hq, p = place_at_palm_xy(sim, hx[ii], hy[jj])
+    obs0 = sim.reset(torch.as_tensor(q), torch.as_tensor(hq))
+    out = demonstrators.run_controller_episodes(sim, obs0.clone(), None, horizon=30, mode="naive", lift_rule="expert")
+    ours = out["success"].cpu().numpy()
+    ref_ok, ref_bad = ref_rate >= 0.75, ref_rate <= 0.25
+    centre = ref_bad & (np.abs(hx[ii]) < 0.04) & (hy[jj] < 0.055)
+    corners = ref_bad & ~centre
+    agree_ok = ours[ref_ok].mean()
+    print(f"cells {len(jj)}: recorded success cells {ref_ok.sum()} -> ours succeed in {agree_ok:.3f}; recorded failure cells: "
+          f"far corners {corners.sum()} -> ours fail in {1 - ours[corners].mean():.3f}; near-palm centre {centre.sum()} -> ours fail in {1 - ours[centre].mean():.3f}")
+    assert agree_ok > 0.9
+    sim.close()

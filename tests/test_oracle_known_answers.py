@@ -191,3 +191,16 @@ def test_newton_and_pgs_meet_at_the_same_optimum(model):
         assert all(c1 <= c0 + 1e-12 for c0, c1 in zip(costs, costs[1:]))
         assert costs[-1] >= dual(f_newton) - 1e-9 and costs[-1] - dual(f_newton) < 1e-4 * abs(dual(f_newton))
         assert errs[-1] < 0.02 * max(1.0, np.abs(a_newton).max())
+
+
+def test_newton_cap_of_the_product_setting_is_never_the_exit(model):
+    """kernel and oracle shared a cap of 6 Newton iterations, so the parity tests could not see solver
+    truncation.  tests/studies/solver_cap.py (profiles/r03_solver_cap.txt): at cap 6, 2.3 % of 13 200 grasp / lift substeps end
+    at the cap with up to 20 % error in qacc; no problem needs more than 10.  Here, on one closing-grasp trajectory: the product
+    setting SOLVER_ITERATIONS converges by its stop rule in every substep and equals the cap-100 / 1e-10 answer, cap 6 does not."""
+    from kinovagrasping_amd.sim import SOLVER_ITERATIONS
+    from tests.studies.solver_cap import scenario
+    _, hi = scenario(("CubeS", "normal", 100, SOLVER_ITERATIONS))
+    assert hi["capped"].sum() == 0 and hi["dacc"].max() < 1e-9 and hi["drift"].max() < 1e-9 and hi["iters_a"].max() <= 12
+    _, lo = scenario(("CubeS", "normal", 100, 6))
+    assert lo["capped"].sum() > 0 and lo["dacc"].max() > 1e-2
