@@ -175,6 +175,9 @@ def main():
                          "contact-rich grasps and de-synchronised episode clocks instead of the cheap first episodes of a random policy (0 = time the "
                          "first episodes, as rounds 1-2 did)")
     ap.add_argument("--steady-updates", type=int, default=0, help="further learner updates before the steady_state window (whole episodes)")
+    ap.add_argument("--expert-prob", type=float, default=0.0,
+                    help="ddpg mode: DDPGfD's demonstration mix (DDPGfD.py:232-254) - an expert ring is filled with one scripted 'combined'-controller "
+                         "episode per env before training and every update samples int(64 (1 - p)) agent + the rest expert episodes (reference: 0.3)")
     ap.add_argument("--solver-iterations", type=int, default=None, help="Newton cap per substep (default: kinovagrasping_amd.sim.SOLVER_ITERATIONS)")
     ap.add_argument("--steady-steps", type=int, default=300, help="length of the steady_state window in env-steps (a multiple of the 30-step episode)")
     args = ap.parse_args()
@@ -216,11 +219,12 @@ def main():
         # config 5: 14 shapes x {normal, rotated, top} x mass / friction per env, all in ONE context and one stepping launch
         oid_all, pose_all, q0_all, hq_all, mf_all = scenarios.config5_states(n * world, seed=5)
         sim = KinovaSim(n, scenarios.SHAPES, device=local_rank, auto_reset=True, horizon=30, solver_iterations=iters)
-        obs0 = sim.reset(torch.as_tensor(q0_all[:, sl]), torch.as_tensor(hq_all[:, sl]), object_id=oid_all[sl], mass_friction=mf_all[:, sl])
+        reset_all = lambda: sim.reset(torch.as_tensor(q0_all[:, sl]), torch.as_tensor(hq_all[:, sl]), object_id=oid_all[sl], mass_friction=mf_all[:, sl])
     else:
         q0_all, hq_all = scenarios.config2_states(n * world)
         sim = KinovaSim(n, "CubeS", device=local_rank, auto_reset=True, horizon=30, solver_iterations=iters)
-        obs0 = sim.reset(torch.as_tensor(q0_all[:, sl]), torch.as_tensor(hq_all[:, sl]))
+        reset_all = lambda: sim.reset(torch.as_tensor(q0_all[:, sl]), torch.as_tensor(hq_all[:, sl]))
+    obs0 = reset_all()
 
     def barrier():
         torch.cuda.synchronize()
@@ -243,13 +247,23 @@ def main():
         policy = DDPGfD(82, 4, 0.8, 5, batch_size=64, hidden=tuple(args.hidden), device=dev, capturable=not args.eager)
         torch.manual_seed(2 + rank)                            # exploration noise / window sampling differ per rank
         replay = DeviceEpisodeReplay(n, capacity=max(4 * n, 1024), horizon=30, device=dev)
+        expert, expert_info = None, None
+        if args.expert_prob > 0:
+            # DDPGfD proper: demonstrations first (expert_data.py:690-921, one 'combined'-controller episode per env), kept in their own ring
+            from kinovagrasping_amd.demonstrators import run_controller_episodes
+            expert = DeviceEpisodeReplay(n, capacity=n, horizon=30, device=dev)
+            demo = run_controller_episodes(sim, obs0.clone(), expert, horizon=30, mode="combined")
+            expert_info = {"prob": args.expert_prob, "episodes": expert.count, "demonstrator": "combined", "demonstration_success_rate": round(float(demo["success"].float().mean()), 4),
+                           "agent_episodes_per_batch": int(64 * (1 - args.expert_prob)), "expert_episodes_per_batch": 64 - int(64 * (1 - args.expert_prob))}
+            obs0 = reset_all()
         if not args.eager:
             # rollout ops and the DDPGfD update replayed as HIP graphs; the simulator is launched between them and
             # the learner graph runs on a second stream beside the simulator kernel (kinovagrasping_amd/pipeline.py)
             from kinovagrasping_amd.pipeline import GraphedTrainer
             eng = RolloutEngine(sim, policy, replay, expl_noise=0.1)
             eng.start(obs0)
-            trainer = GraphedTrainer(sim, policy, replay, eng, batch_episodes=64, overlap=not args.serial_learner)
+            trainer = GraphedTrainer(sim, policy, replay, eng, batch_episodes=64, overlap=not args.serial_learner, expert_replay=expert,
+                                     expert_prob=args.expert_prob)
             trainer.capture()
             learner_form = "lds-free fp32-mfma kernels" if trainer.native.lds_free else "library gemms + kr_* glue"
 
@@ -272,7 +286,8 @@ def main():
                     return
                 side.wait_event(acted)                 # weights are free once this step's actor forward is done
                 with torch.cuda.stream(side), torch.enable_grad():
-                    st, ac, ns, rw, nd, w = replay.sample_batch_nstep(64, generator=lgen)
+                    st, ac, ns, rw, nd, w = (replay.sample_mixed(expert, 64, args.expert_prob, generator=lgen) if expert is not None
+                                             else replay.sample_batch_nstep(64, generator=lgen))
                     policy.train_on_batch(st, ac, ns, rw, w)
                 updates += 1
 
@@ -415,7 +430,7 @@ def main():
                        "mode": args.mode, "envs_per_gpu": n, "frame_skip": 15, "solver": f"newton, <= {iters} iterations per substep (early exit on convergence)", "hidden": list(args.hidden),
                        "learner_updates_timed": timed_updates if args.mode == "ddpg" else 0, "priming_steps": priming,
                        "launch": ("eager" if args.eager else "hip-graphs") if args.mode == "ddpg" else "direct",
-                       "learner": learner_form,
+                       "learner": learner_form, "expert_mix": (expert_info if args.mode == "ddpg" else None),
                        "parallelism": f"env-shard x{world}" + (" + grad all-reduce" if world > 1 and args.mode == "ddpg" else "")},
             "roofline": {"bound": "hbm", "kernel": "k_env_step", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_note": traffic_note,
@@ -438,7 +453,7 @@ def main():
             "status_counts": {"contact_overflow": int((status & 1).ne(0).sum().item()), "nonfinite": bad,
                               "ray_pool_timeout": int((status & 4).ne(0).sum().item()),
                               "newton_ended_at_cap": int((status & 8).ne(0).sum().item())},
-            "rccl": ({"ranks": world, "backend": os.environ.get("KS_DIST_BACKEND", "nccl"), "NCCL_ALGO": os.environ.get("NCCL_ALGO", "default"),
+            "rccl": ({"ranks": world, "backend": os.environ.get("KS_DIST_BACKEND", "nccl"), "NCCL_ALGO": os.environ.get("NCCL_ALGO", "default"), "NCCL_PROTO": os.environ.get("NCCL_PROTO", "default"),
                       "allreduces_per_update": 2, "bytes_per_allreduce": int(policy._flat_params["critic"].numel() * 4),
                       "exchange": getattr(trainer, "exchange_note", None),
                       "exchange_failed_call": (trainer.native.exchange.failed_epoch() if getattr(trainer, "native", None) is not None

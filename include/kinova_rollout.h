@@ -81,6 +81,22 @@ int kr_sample_windows_draw(int32_t batch, int32_t horizon, int32_t n_steps, cons
                            const float *ep_action, const float *ep_reward, const float *ep_not_done, float *state, float *action,
                            float *next_state, float *reward, float *not_done, float *weight, float *next_ends, void *stream);
 
+/* DDPGfD's demonstration mix (DDPGfD.train_batch, DDPGfD.py:232-254: agent_batch_size = int(batch_size * (1 - prob)) episodes from
+ * the agent's replay, the other batch_size - agent_batch_size from the expert replay, concatenated agent first) as ONE launch:
+ * episodes b < batch_agent of the batch are drawn from ring `agent`, the others from ring `expert`, each with the rule of
+ * kr_sample_windows on its own ring (k-th oldest of count - 1; a ring with fewer than two episodes yields weight-0 rows).
+ * Both rings have row shape [*, horizon, ...].  Uniforms: u_ep [batch] + u_start [batch, W] when given (tests), else drawn in the
+ * kernel exactly as kr_sample_windows_draw does (Philox keyed by seed, draw[0], b | row).  next_ends optional as there. */
+typedef struct {
+    const int64_t *count, *head;      /* device scalars: committed episodes, next slot */
+    int32_t capacity;
+    const int64_t *ep_len;            /* [capacity(+)] */
+    const float *ep_state, *ep_next, *ep_action, *ep_reward, *ep_not_done;
+} kr_ring;
+int kr_sample_windows_mixed(int32_t batch, int32_t batch_agent, int32_t horizon, int32_t n_steps, const kr_ring *agent, const kr_ring *expert,
+                            const float *u_ep, const float *u_start, uint64_t seed, const int64_t *draw, float *state, float *action,
+                            float *next_state, float *reward, float *not_done, float *weight, float *next_ends, void *stream);
+
 /* ---- learner glue (DDPGfD.train_batch, DDPGfD.py:219-367): the elementwise steps between the GEMMs, one launch each
  *
  *   kr_critic_grad   targets + dLoss/dQ of the critic loss L1 + 0.5 LN with masked row means (DDPGfD.py:256-330):

@@ -1140,8 +1140,13 @@ template <typename T> struct Ctx : CtxBase {
         const bool same = out.obs == out_sent.obs && out.reward == out_sent.reward && out.done == out_sent.done && out.info == out_sent.info &&
                           out.final_obs == out_sent.final_obs && out.horizon == out_sent.horizon && out.auto_reset == out_sent.auto_reset &&
                           out.env_major == out_sent.env_major;
-        if (obs_in_step && !(same && out_valid)) {
-            out_valid = true;
+        // Under stream capture the copy below is only RECORDED (it runs at every replay of the graph, not now): the device copy
+        // cannot be taken as current afterwards, so a capturing call always records the copy and never marks it as sent.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        const bool capturing = cap != hipStreamCaptureStatusNone;
+        if (obs_in_step && (capturing || !(same && out_valid))) {
+            out_valid = !capturing;
             out_sent = out;
             ObsOut<T>* slot = h_out + (h_out_next++ % H_OUT_RING);
             *slot = out;

@@ -1116,12 +1116,14 @@ template <typename T> KS_NARROW int gjk_distance(PairGeo<T>& g, T margin, T* dis
         S.n = 1;
         copy3(v, S.y[0]);
     }
+    T last_vw = T(1);
     for (int it = 0; it < 48; it++) {
         T vv = dot3(v, v);
         if (vv < T(1e-24)) { gjk_remember(ws, S); return 2; }
         T nd[3] = {-v[0], -v[1], -v[2]}, w[3], wa[3], wb[3];
         gjk_support(g, nd, w, wa, wb);
         T vw = dot3(v, w);
+        last_vw = vw;
 #ifdef KS_DEBUG_GJK
         printf("  gjk[%d] it %d n %d vv %.9g vw %.9g |v| %.9g\n", (int)sizeof(T), it, S.n, (double)vv, (double)vw, (double)ksqrt(vv));
 #endif
@@ -1160,9 +1162,18 @@ template <typename T> KS_NARROW int gjk_distance(PairGeo<T>& g, T margin, T* dis
         }
     }
     gjk_remember(ws, S);
+    // The iteration ended (no decrease / repeated vertex / tolerance) while the last support point lay BEYOND the origin along -v
+    // (v.w < 0): v is then no certified separation - a flat tetrahedron of a near-touching pair can stop here a few um "apart"
+    // although the hulls overlap (found on a 64-gon cylinder against a finger: +4.9 um reported, 34 um of penetration).  Such a
+    // result is handed to the penetration query first (return 3); only if that finds no overlap does the caller keep it.
+#ifndef KS_NO_OPEN_FALLBACK     // (experiment switch)
+    const bool open = last_vw < 0;
+#else
+    const bool open = false;
+#endif
     T dd = norm3(v);
     if (dd < T(1e-12)) return 2;
-    if (dd >= margin) return 0;
+    if (dd >= margin) return open ? 2 : 0;
     T p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
     KS_UNROLL
     for (int i = 0; i < 4; i++)
@@ -1170,7 +1181,7 @@ template <typename T> KS_NARROW int gjk_distance(PairGeo<T>& g, T margin, T* dis
     *dist = dd;
     KS_UNROLL
     for (int i = 0; i < 3; i++) { normal[i] = -v[i] / dd; pos[i] = T(0.5) * (p1[i] + p2[i]); }
-    return 1;
+    return open ? 3 : 1;
 }
 
 
@@ -1300,6 +1311,9 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     KS_TICK(12)
     team.argmin(bd, best);
     if (bd > margin) return 0;
+    // Ties (the oracle's rule, ko_physics.c collide_plane_hull): the first contact is the LOWEST-INDEX vertex within 1 um of the
+    // deepest one - a standing cylinder's 64 rim vertices or a landing cube's four corners are equally deep to the last bits and
+    // "the deepest" would be decided by rounding, differently in fp32 and fp64, and with it the greedy choice of the other three.
     KS_TICK(4)
     T cv[4][3];
     int nc = 1;
@@ -1471,13 +1485,16 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
 #endif
     h1_out = pg.hint1 & PC_HINT_MAX; h2_out = pg.hint2 & PC_HINT_MAX;
     if (r == 1) { stage_contact(scr, slot, body1, body2, mu, dist, pos, dir); return 1; }
-    if (r == 2) {
-        const bool hit = mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, dir, pos, ws);
+    if (r >= 2) {
+        // 2: overlap (or undecided beyond the margin), 3: a margin-zone result that is not a certified separation
+        T mdir[3], mpos[3];
+        const bool hit = mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, mdir, mpos, ws);
         h1_out = pg.hint1 & PC_HINT_MAX; h2_out = pg.hint2 & PC_HINT_MAX;
         if (hit) {
-            stage_contact(scr, slot, body1, body2, mu, -depth, pos, dir);
+            stage_contact(scr, slot, body1, body2, mu, -depth, mpos, mdir);
             return 1;
         }
+        if (r == 3) { stage_contact(scr, slot, body1, body2, mu, dist, pos, dir); return 1; }
     }
     return 0;
 }

@@ -249,9 +249,10 @@ template <typename T, typename C> KS_HD int ray_origin(const Model<T>& m, C snap
     mulRv(vec, Rb, m.site_z[si]);
     return sb;
 }
-// ground plane z = 0 with finite half-size (XML:148); -1 = miss
+// ground plane z = 0 with finite half-size (XML:148); -1 = miss.  Front face only (mju_rayGeom's plane case): the ray must
+// point down at the +z side; from below the floor nothing is seen.
 template <typename T> KS_HD T ray_ground(const Model<T>& m, const T* pnt, const T* vec) {
-    if (kabs(vec[2]) > T(1e-15)) {
+    if (vec[2] < -T(1e-15)) {
         T tt = -pnt[2] / vec[2];
         if (tt >= 0) {
             T x = pnt[0] + tt * vec[0], y = pnt[1] + tt * vec[1];

@@ -151,21 +151,29 @@ __global__ __launch_bounds__(256) void k_advance_ring(int n, int capacity, const
     if (i < n && ended[i] != 0) cur_len[i] = 0;
 }
 
-// one wave per window row (b, w)
-__global__ __launch_bounds__(WAVE) void k_sample_windows(int B, int H, int n_steps, const int64_t* __restrict__ count,
-                                                         const int64_t* __restrict__ head, int capacity,
-                                                         const int64_t* __restrict__ ep_len, const float* __restrict__ u_ep,
+struct Ring {                      // one episode ring of DeviceEpisodeReplay (kr_ring of the C ABI)
+    const int64_t* count;
+    const int64_t* head;
+    int capacity;
+    const int64_t* ep_len;
+    const float *ep_state, *ep_next, *ep_action, *ep_reward, *ep_not_done;
+};
+
+// one wave per window row (b, w); episodes b < B_agent are drawn from ring `ra`, the others from ring `re` (the expert
+// demonstrations DDPGfD mixes into every batch, DDPGfD.py:232-254; B_agent = B: one ring)
+__global__ __launch_bounds__(WAVE) void k_sample_windows(int B, int B_agent, int H, int n_steps, Ring ra, Ring re, const float* __restrict__ u_ep,
                                                          const float* __restrict__ u_start, unsigned long long seed,
                                                          const int64_t* __restrict__ draw, float* __restrict__ next_ends,
-                                                         const float* __restrict__ ep_state,
-                                                         const float* __restrict__ ep_next, const float* __restrict__ ep_action,
-                                                         const float* __restrict__ ep_reward, const float* __restrict__ ep_not_done,
                                                          float* __restrict__ state, float* __restrict__ action, float* __restrict__ next_state,
                                                          float* __restrict__ reward, float* __restrict__ not_done, float* __restrict__ weight) {
     const int W = H - n_steps;
     const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= B * W) return;
     const int b = r / W, w = r % W;
+    const Ring& g = b < B_agent ? ra : re;
+    const int64_t *count = g.count, *head = g.head, *ep_len = g.ep_len;
+    const int capacity = g.capacity;
+    const float *ep_state = g.ep_state, *ep_next = g.ep_next, *ep_action = g.ep_action, *ep_reward = g.ep_reward, *ep_not_done = g.ep_not_done;
     // np.random.randint(replay_ep_num - 1): the k-th OLDEST episode, k in [0, count - 1) - the newest one is never sampled
     // (utils.py:259).  In the ring the oldest episode sits at head - count, so after the first wrap the excluded slot is
     // head - 1, wherever that is.  With fewer than two episodes there is nothing to sample: every row gets weight 0.
@@ -363,9 +371,9 @@ int kr_sample_windows(int32_t batch, int32_t horizon, int32_t n_steps, const int
     if (batch <= 0 || horizon <= n_steps || n_steps <= 0 || n_steps > WAVE || capacity <= 0 || !count || !head || !ep_len || !u_ep || !u_start || !ep_state || !ep_next ||
         !ep_action || !ep_reward || !ep_not_done || !state || !action || !next_state || !reward || !not_done || !weight)
         return KS_ERR_INVALID;
-    hipLaunchKernelGGL(k_sample_windows, dim3(batch * (horizon - n_steps)), dim3(WAVE), 0, (hipStream_t)stream, batch, horizon, n_steps, count,
-                       head, capacity, ep_len, u_ep, u_start, 0ull, (const int64_t*)nullptr, (float*)nullptr, ep_state, ep_next, ep_action, ep_reward,
-                       ep_not_done, state, action, next_state, reward, not_done, weight);
+    const Ring g{count, head, capacity, ep_len, ep_state, ep_next, ep_action, ep_reward, ep_not_done};
+    hipLaunchKernelGGL(k_sample_windows, dim3(batch * (horizon - n_steps)), dim3(WAVE), 0, (hipStream_t)stream, batch, batch, horizon, n_steps, g, g,
+                       u_ep, u_start, 0ull, (const int64_t*)nullptr, (float*)nullptr, state, action, next_state, reward, not_done, weight);
     return launched();
 }
 
@@ -376,9 +384,29 @@ int kr_sample_windows_draw(int32_t batch, int32_t horizon, int32_t n_steps, cons
     if (batch <= 0 || horizon <= n_steps || n_steps <= 0 || n_steps > WAVE || capacity <= 0 || !count || !head || !ep_len || !draw || !ep_state ||
         !ep_next || !ep_action || !ep_reward || !ep_not_done || !state || !action || !next_state || !reward || !not_done || !weight)
         return KS_ERR_INVALID;
-    hipLaunchKernelGGL(k_sample_windows, dim3(batch * (horizon - n_steps)), dim3(WAVE), 0, (hipStream_t)stream, batch, horizon, n_steps, count,
-                       head, capacity, ep_len, (const float*)nullptr, (const float*)nullptr, (unsigned long long)seed, draw, next_ends, ep_state, ep_next,
-                       ep_action, ep_reward, ep_not_done, state, action, next_state, reward, not_done, weight);
+    const Ring g{count, head, capacity, ep_len, ep_state, ep_next, ep_action, ep_reward, ep_not_done};
+    hipLaunchKernelGGL(k_sample_windows, dim3(batch * (horizon - n_steps)), dim3(WAVE), 0, (hipStream_t)stream, batch, batch, horizon, n_steps, g, g,
+                       (const float*)nullptr, (const float*)nullptr, (unsigned long long)seed, draw, next_ends, state, action, next_state, reward,
+                       not_done, weight);
+    return launched();
+}
+
+static bool ring_ok(const kr_ring* r) {
+    return r && r->count && r->head && r->capacity > 0 && r->ep_len && r->ep_state && r->ep_next && r->ep_action && r->ep_reward && r->ep_not_done;
+}
+
+int kr_sample_windows_mixed(int32_t batch, int32_t batch_agent, int32_t horizon, int32_t n_steps, const kr_ring* agent, const kr_ring* expert,
+                            const float* u_ep, const float* u_start, uint64_t seed, const int64_t* draw, float* state, float* action,
+                            float* next_state, float* reward, float* not_done, float* weight, float* next_ends, void* stream) {
+    if (batch <= 0 || batch_agent < 0 || batch_agent > batch || horizon <= n_steps || n_steps <= 0 || n_steps > WAVE || !ring_ok(agent) || !ring_ok(expert) ||
+        ((u_ep == nullptr) != (u_start == nullptr)) || (!u_ep && !draw) || !state || !action || !next_state || !reward || !not_done || !weight)
+        return KS_ERR_INVALID;
+    const Ring ga{agent->count, agent->head, agent->capacity, agent->ep_len, agent->ep_state, agent->ep_next, agent->ep_action, agent->ep_reward,
+                  agent->ep_not_done};
+    const Ring ge{expert->count, expert->head, expert->capacity, expert->ep_len, expert->ep_state, expert->ep_next, expert->ep_action,
+                  expert->ep_reward, expert->ep_not_done};
+    hipLaunchKernelGGL(k_sample_windows, dim3(batch * (horizon - n_steps)), dim3(WAVE), 0, (hipStream_t)stream, batch, batch_agent, horizon, n_steps, ga,
+                       ge, u_ep, u_start, (unsigned long long)seed, draw, next_ends, state, action, next_state, reward, not_done, weight);
     return launched();
 }
 

@@ -19,6 +19,14 @@ from . import sim as _sim
 HANDLE_BYTES = 64
 
 
+def _injected(stage: str, rank: int) -> bool:
+    """KS_XCHG_INJECT="connect:<rank>" / "selftest:<rank>": make that rank fail that stage (tests/test_bench_launch.py proves that
+    EVERY rank then falls back to the process group's all_reduce and says so - the first run on a real 8-GPU node must not hang
+    or train diverged replicas whatever peer access turns out to do there)."""
+    import os
+    return os.environ.get("KS_XCHG_INJECT", "") == f"{stage}:{rank}"
+
+
 class PeerExchange:
     def __init__(self, max_count: int, group=None, device=None):
         import torch.distributed as dist
@@ -39,6 +47,8 @@ class PeerExchange:
             raise RuntimeError(f"kr_xchg_create failed on ranks {[i for i, (r, _) in enumerate(everyone) if r != 0]}")
         with torch.cuda.device(self.device):
             rc = self.lib.kr_xchg_connect(self.x, b"".join(h for _, h in everyone))
+        if _injected("connect", self.rank):
+            rc = -3             # fault injection (tests): this rank pretends hipIpcOpenMemHandle failed
         rcs = [None] * self.world
         dist.all_gather_object(rcs, rc, group=group)
         if any(r != 0 for r in rcs):
@@ -96,6 +106,8 @@ class PeerExchange:
                     note(f"a peer did not arrive (call {self.failed_epoch()})")
             except Exception as e:      # noqa: BLE001
                 note(f"{type(e).__name__}: {e}")
+            if _injected("selftest", self.rank):
+                a[0] += 1.0     # fault injection (tests): this rank's exchange "returns" a wrong mean
             if not torch.allclose(a, ref, rtol=1e-5, atol=1e-6):
                 note(f"mismatch against all_reduce: {float((a - ref).abs().max()):.3e}")
             # bitwise identical on all ranks

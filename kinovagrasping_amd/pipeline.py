@@ -31,9 +31,15 @@ import torch
 
 
 class GraphedTrainer:
-    def __init__(self, sim, policy, replay, engine, batch_episodes=64, overlap=True, learn_after=31):
+    def __init__(self, sim, policy, replay, engine, batch_episodes=64, overlap=True, learn_after=31, expert_replay=None, expert_prob=0.3):
+        """expert_replay (a DeviceEpisodeReplay filled by demonstrators.run_controller_episodes or loaded from a reference replay
+        bundle) turns the update into DDPGfD proper: every batch is int(batch_episodes * (1 - expert_prob)) agent episodes + the rest
+        expert episodes (DDPGfD.train_batch, DDPGfD.py:232-254), sampled by ONE launch inside the captured update."""
         assert engine.gen is None, "graph capture uses the default CUDA generator"
         self.sim, self.policy, self.replay, self.eng = sim, policy, replay, engine
+        self.expert_replay, self.expert_prob = expert_replay, float(expert_prob)
+        if expert_replay is not None and not (replay.native and expert_replay.native):
+            raise ValueError("GraphedTrainer: the expert mix needs device rings (DeviceEpisodeReplay on the GPU)")
         self.batch_episodes, self.overlap, self.learn_after = batch_episodes, overlap, learn_after
         self.dev = sim.device
         self.steps = 0
@@ -84,7 +90,10 @@ class GraphedTrainer:
     # -- learner phases on the static batch -------------------------------------------------------------
     def _sample(self):
         # (uniforms drawn in the sampling kernel, keyed by the update count: no generator-state launches in the graph)
-        self.batch = self.replay.sample_batch_nstep(self.batch_episodes, draw=self.native.it if self.replay.native else None, seed=self.sample_seed)
+        if self.expert_replay is not None and self.expert_prob > 0:
+            self.batch = self.replay.sample_mixed(self.expert_replay, self.batch_episodes, self.expert_prob, draw=self.native.it, seed=self.sample_seed)
+        else:
+            self.batch = self.replay.sample_batch_nstep(self.batch_episodes, draw=self.native.it if self.replay.native else None, seed=self.sample_seed)
 
     def _head(self):
         self.native.phase_head()

@@ -247,6 +247,49 @@ class DeviceEpisodeReplay:
                     "kr_advance_ring")
         return self._total[0]
 
+    def _ring(self):
+        from .sim import KrRing
+        P = lambda t: t.data_ptr()
+        return KrRing(P(self._count), P(self._head), self.capacity, P(self.ep_len), P(self.ep_state), P(self.ep_next), P(self.ep_action),
+                      P(self.ep_reward), P(self.ep_not_done))
+
+    def sample_mixed(self, expert: "DeviceEpisodeReplay", batch_size, prob=0.3, uniforms=None, draw=None, seed=0, generator=None):
+        """DDPGfD's batch (DDPGfD.train_batch, DDPGfD.py:232-254): agent_batch_size = int(batch_size * (1 - prob)) episodes from THIS
+        ring followed by batch_size - agent_batch_size episodes from `expert`, each sampled with sample_batch_nstep's rule on its own
+        ring.  Same return layout as sample_batch_nstep (incl. the 7th tensor when `draw` is given).  One kernel launch on the GPU
+        (kr_sample_windows_mixed); the torch path below - the concatenation of two sample_batch_nstep calls - is its checker."""
+        n, W = self.n_steps, self.horizon - self.n_steps
+        if expert.horizon != self.horizon or expert.n_steps != n:
+            raise ValueError("sample_mixed: the expert ring must have the agent ring's horizon and n_steps")
+        b_agent = int(batch_size * (1 - prob))
+        b_exp = batch_size - b_agent
+        if self.native and expert.native:
+            import ctypes
+            R, dev = batch_size * W, self.device
+            S, A = self.ep_state.shape[2], self.ep_action.shape[2]
+            out = (torch.empty(R, n, S, device=dev), torch.empty(R, n, A, device=dev), torch.empty(R, n, S, device=dev),
+                   torch.empty(R, n, device=dev), torch.empty(R, n, device=dev), torch.empty(R, device=dev))
+            P = self._ptr
+            ends = torch.empty(2 * R, S, device=dev) if (draw is not None and uniforms is None) else None
+            if uniforms is None and draw is None:
+                uniforms = torch.rand(batch_size * (W + 1), device=dev, generator=generator)
+            u = None if uniforms is None else uniforms.contiguous()
+            ra, re = self._ring(), expert._ring()
+            self._check(self._lib.kr_sample_windows_mixed(batch_size, b_agent, self.horizon, n, ctypes.byref(ra), ctypes.byref(re),
+                                                          P(u), P(u[batch_size:]) if u is not None else None, int(seed) & (2 ** 64 - 1),
+                                                          P(draw) if u is None else None, P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(out[4]),
+                                                          P(out[5]), P(ends), self._stream()), "kr_sample_windows_mixed")
+            return out if ends is None else out + (ends,)
+        if uniforms is None:
+            uniforms = torch.rand(batch_size * (W + 1), device=self.device, generator=generator)
+        ue, us = uniforms[:batch_size], uniforms[batch_size:].view(batch_size, W)
+        parts = []
+        if b_agent:
+            parts.append(self.sample_batch_nstep(b_agent, uniforms=torch.cat([ue[:b_agent], us[:b_agent].reshape(-1)])))
+        if b_exp:
+            parts.append(expert.sample_batch_nstep(b_exp, uniforms=torch.cat([ue[b_agent:], us[b_agent:].reshape(-1)])))
+        return tuple(torch.cat([p[k] for p in parts], 0) for k in range(6))
+
     def sample_batch_nstep(self, batch_size, generator=None, uniforms=None, draw=None, seed=0):
         """Fixed-shape batch: batch_size episodes x (horizon - n) window rows, padding rows have weight 0.
         Returns state [R,n,S], action [R,n,A], next_state [R,n,S], reward [R,n], not_done [R,n], weight [R].

@@ -36,6 +36,19 @@ def hand_quat_for(orientation: str) -> np.ndarray:
     return euler_to_quat(truncated_euler(ORIENTATION_EULER[orientation]))
 
 
+ORIENTATION_NOISE_SIGMA = 0.087      # rad (5 deg), the spread rotation_generation.py:20-25 uses
+
+
+def hand_euler_for(orientation: str, rng=None, sigma: float = ORIENTATION_NOISE_SIGMA) -> np.ndarray:
+    """Euler triple of j2s7s300_link_7 as the reference would patch it into the XML: the class constant (ENV:1267-1273), with
+    rng given plus ZERO-MEAN N(0, sigma) per axis (SURVEY note N5: the reference's with_noise tables are biased by -0.087 and
+    swapped between classes - an extension replaces them), then truncated to 5 characters (ENV:870-874)."""
+    e = np.asarray(ORIENTATION_EULER[orientation], dtype=np.float64)
+    if rng is not None:
+        e = e + rng.normal(0.0, sigma, 3)
+    return truncated_euler(e)
+
+
 _palm_quat = None
 
 

@@ -26,11 +26,17 @@ class KsConfig(C.Structure):
                 ("contact_tap", C.c_int32), ("pair_memory", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
+class KrRing(C.Structure):
+    """kr_ring (include/kinova_rollout.h): one device episode ring"""
+    _fields_ = [("count", C.c_void_p), ("head", C.c_void_p), ("capacity", C.c_int32), ("ep_len", C.c_void_p), ("ep_state", C.c_void_p),
+                ("ep_next", C.c_void_p), ("ep_action", C.c_void_p), ("ep_reward", C.c_void_p), ("ep_not_done", C.c_void_p)]
+
+
 EXPORTS = ["ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_load_model", "ks_load_models", "ks_reset", "ks_reset_objects", "ks_step",
            "ks_get_state", "ks_set_state", "ks_set_env_params", "ks_substep", "ks_obs_from_snapshot", "ks_kernel_time", "ks_version"]
 # include/kinova_rollout.h
 ROLLOUT_EXPORTS = ["kr_select_action", "kr_store_transition", "kr_rank_episodes", "kr_commit_episodes", "kr_advance_ring",
-                   "kr_sample_windows", "kr_sample_windows_draw", "kr_xchg_create", "kr_xchg_connect", "kr_xchg_allreduce_mean", "kr_xchg_status",
+                   "kr_sample_windows", "kr_sample_windows_draw", "kr_sample_windows_mixed", "kr_xchg_create", "kr_xchg_connect", "kr_xchg_allreduce_mean", "kr_xchg_status",
                    "kr_xchg_destroy", "kr_critic_grad", "kr_update_prologue", "kr_relu_backward", "kr_sigmoid_scale_backward", "kr_adam_step", "kr_soft_update",
                    "kr_mlp3_forward", "kr_mlp3_forward_shadow", "kr_mlp3_forward_split", "kr_mlp3_backward_shadow", "kr_mlp3_backward_split", "kr_weight_grad_shadow",
                    "kr_actor_select"]
@@ -74,6 +80,7 @@ def load_library(path: Path | None = None):
     L.kr_advance_ring.argtypes = [i32, i32] + [vp] * 6
     L.kr_sample_windows.argtypes = [i32, i32, i32, vp, vp, i32] + [vp] * 15
     L.kr_sample_windows_draw.argtypes = [i32, i32, i32, vp, vp, i32, vp, C.c_uint64, vp] + [vp] * 13
+    L.kr_sample_windows_mixed.argtypes = [i32, i32, i32, i32, C.POINTER(KrRing), C.POINTER(KrRing), vp, vp, C.c_uint64, vp] + [vp] * 7 + [vp]
     L.kr_xchg_create.argtypes = [C.POINTER(vp), i32, i32, C.c_int64, vp]
     L.kr_xchg_connect.argtypes = [vp, C.c_char_p]
     L.kr_xchg_allreduce_mean.argtypes = [vp, vp, C.c_int64, vp]

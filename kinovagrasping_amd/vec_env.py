@@ -51,6 +51,8 @@ class KinovaGripperVecEnv:
         self.obj_coords = np.zeros((n_envs, 3))
         self.orientation_idx = np.zeros(n_envs, dtype=np.int64)
         self.hand_quat = np.repeat(scenarios.hand_quat_for("normal")[:, None], n_envs, 1)
+        self.hand_euler = np.repeat(np.asarray(scenarios.ORIENTATION_EULER["normal"])[None], n_envs, 0)   # as patched into the XML (truncated)
+        self.with_noise = False
         self.obj_keys = []                       # Latin-square object queue (Generate_Latin_Square); reset() pops from its end
         self.with_grasp_reward = False
         M = read_blob(scenarios.model_blob(self.shapes[0]))        # hand constants for Tfw (the same in every object's blob)
@@ -148,7 +150,15 @@ class KinovaGripperVecEnv:
         obj_params: the reference's [shape, size] test hook is not supported; a [2, n] ARRAY here is the config-5
         extension (per-env object mass, object-hand friction).  With several objects loaded every reset env draws its
         object from `shape_keys` (default: all loaded) - Latin-square queue first, see select_object.
-        Slide offsets of the 'rotated' / 'top' hands: see `hand_offsets` of the constructor."""
+        Slide offsets of the 'rotated' / 'top' hands: see `hand_offsets` of the constructor.
+        with_noise=True: orientation noise as SURVEY note N5 prescribes - the class's no-noise Euler constants (ENV:1267-1273) plus
+        ZERO-MEAN N(0, 0.087 rad) per axis drawn from the env's np_random, then the reference's 5-character truncation
+        (ENV:870-874, model_compiler.truncated_euler); object coordinates still come from the no_noise tables.  An EXTENSION, not the
+        reference's behaviour: its with_noise tables (ENV:1254-1255; generator rotation_generation.py:20-25) carry Euler triples
+        that are swapped between the normal / top classes and biased by -0.087 (N5), so they are not reproduced.  The reference's
+        default is with_noise=True; the default here is False (the self-consistent no-noise branch)."""
+        from .model_compiler import euler_to_quat
+        self.with_noise = bool(with_noise)
         self.set_with_grasp_reward(with_grasp)
         ids = np.arange(self.n_envs) if env_ids is None else np.asarray(env_ids)
         n = len(ids)
@@ -166,7 +176,9 @@ class KinovaGripperVecEnv:
             shape = self.random_shape[e] if multi else self.random_shape
             o = self.select_orienation(hand_orientation, shape)
             self.orientation[e] = o
-            hq[:, k] = scenarios.hand_quat_for(o)
+            eul = scenarios.hand_euler_for(o, self.np_random if with_noise else None)
+            self.hand_euler[e] = eul
+            hq[:, k] = euler_to_quat(eul)
             if start_pos is not None:
                 q[9:12, k] = np.asarray(start_pos)[k][:3]
                 self.orientation_idx[e] = -1

@@ -645,12 +645,14 @@ static int gjk_distance(mpr_ctx *c, double margin, double *dist, double *normal,
     gjk_support(c, d, S.y[0], S.a[0], S.b[0]);
     S.n = 1;
     copy3(v, S.y[0]);
+    double last_vw = 1.0;
     for (int it = 0; it < 48; it++) {
         double vv = dot3(v, v);
         if (vv < 1e-24) return 2;
         double nd[3] = {-v[0], -v[1], -v[2]}, w[3], wa[3], wb[3];
         gjk_support(c, nd, w, wa, wb);
         double vw = dot3(v, w);
+        last_vw = vw;
         if (vw > 0 && vw * vw >= margin * margin * vv) return 0; /* separating plane beyond the margin */
         if (vv - vw <= tol * vv) break;                          /* no further progress possible */
         int dup = 0;
@@ -670,14 +672,18 @@ static int gjk_distance(mpr_ctx *c, double margin, double *dist, double *normal,
             break;
         }
     }
+    /* the last support point lay beyond the origin along -v: v is no certified separation (a flat tetrahedron of a near-touching
+     * pair can end the iteration a few um "apart" while the hulls overlap) - the penetration query decides first (return 3 /
+     * 2), the caller keeps this result only if that finds no overlap.  Same rule in the kernels (ks_core.h gjk_distance). */
+    int open = last_vw < 0;
     double dd = norm3(v);
     if (dd < 1e-12) return 2;
-    if (dd >= margin) return 0;
+    if (dd >= margin) return open ? 2 : 0;
     double p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
     for (int i = 0; i < S.n; i++) { addscl3(p1, S.a[i], lam[i]); addscl3(p2, S.b[i], lam[i]); }
     *dist = dd;
     for (int i = 0; i < 3; i++) { normal[i] = -v[i] / dd; pos[i] = 0.5 * (p1[i] + p2[i]); }
-    return 1;
+    return open ? 3 : 1;
 }
 
 /* MuJoCo's mju_makeFrame: complete a contact frame from its normal */
@@ -761,7 +767,11 @@ static void collide_hull_hull(ko_sim *s, int g1, int g2, const double *pair) {
     double depth, dist, dir[3], pos[3];
     int r = gjk_distance(&c, margin, &dist, dir, pos);
     if (r == 1) add_contact(s, g1, g2, pair, dist, pos, dir);
-    else if (r == 2 && mpr_penetration(&c, &depth, dir, pos) == 0) add_contact(s, g1, g2, pair, -depth, pos, dir);
+    else if (r >= 2) {
+        double mdir[3], mpos[3];
+        if (mpr_penetration(&c, &depth, mdir, mpos) == 0) add_contact(s, g1, g2, pair, -depth, mpos, mdir);
+        else if (r == 3) add_contact(s, g1, g2, pair, dist, pos, dir);
+    }
 }
 
 static void collision(ko_sim *s) {
@@ -1098,8 +1108,10 @@ static void sensors(ko_sim *s) {
         for (int g = 0; g < KO_NGEOM; g++) {
             if (m->geom_body[g] == m->site_body[i]) continue;
             double d = -1;
-            if (g == 0) { /* ground plane z=0, finite half-size (XML:148) */
-                if (fabs(vec[2]) > MINVAL) {
+            if (g == 0) { /* ground plane z=0, finite half-size (XML:148).  mju_rayGeom's plane case: a ray whose local z component
+                           * does not point at the FRONT face (+z side) is rejected - a site below the floor looking up (the
+                           * 'rotated' / 'top' fresh-env starts) sees no ground */
+                if (vec[2] < -MINVAL) {
                     double t = -(pnt[2] - s->geom_xpos[0][2]) / vec[2];
                     if (t >= 0) {
                         double x = pnt[0] + t * vec[0], y = pnt[1] + t * vec[1];

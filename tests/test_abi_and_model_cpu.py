@@ -181,3 +181,20 @@ def test_stepping_kernel_leaves_registers_for_the_learner(tmp_path):
     assert learner
     widest = max(up8(lv + la) for lv, la in learner.values())
     assert up8(v + a) + widest <= 512, (v, a, widest, learner)
+
+
+def test_orientation_noise_is_zero_mean_truncated_and_seeded():
+    """reset(with_noise=True) (SURVEY note N5's extension): class Euler constants + zero-mean N(0, 0.087), then the reference's
+    5-character truncation (ENV:870-874); without an rng exactly the class quaternion."""
+    import numpy as np
+    from kinovagrasping_amd import scenarios
+    from kinovagrasping_amd.model_compiler import euler_to_quat
+    for o, base in scenarios.ORIENTATION_EULER.items():
+        assert np.array_equal(euler_to_quat(scenarios.hand_euler_for(o)), scenarios.hand_quat_for(o))
+        rng = np.random.RandomState(11)
+        e = np.stack([scenarios.hand_euler_for(o, rng) for _ in range(4000)])
+        assert np.abs(e.mean(0) - np.asarray(base)).max() < 0.01            # zero mean (the truncation is toward zero: < 0.005 bias)
+        assert np.abs(e.std(0) - 0.087).max() < 0.006
+        assert all(len(repr(float(v))) <= 5 or abs(v) < 1e-4 or float(repr(float(v))[:5]) == v for v in e[:50].ravel())
+        rng2 = np.random.RandomState(11)
+        assert np.array_equal(e[0], scenarios.hand_euler_for(o, rng2))

@@ -44,7 +44,7 @@ def test_launcher_spawns_ranks_before_touching_torch(tmp_path):
 def test_two_ranks_on_one_gpu_through_the_self_launcher():
     """`python bench.py --gpus 2` on a 1-GPU box: two ranks share GPU 0 and exchange gradients over gloo (plumbing check
     of the launcher, the two-graph learner split and the checksum all-reduce; RCCL needs one GPU per rank)."""
-    r = run_bench(["--gpus", "2", "--steps", "6", "--warmup", "4", "--envs-per-gpu", "512", "--no-cpu-baseline", "--steady-updates", "0"],
+    r = run_bench(["--gpus", "2", "--steps", "6", "--warmup", "4", "--envs-per-gpu", "512", "--no-cpu-baseline", "--pretrain-updates", "0", "--steady-steps", "0"],
                   env={"KS_DIST_BACKEND": "gloo", "KS_VISIBLE_GPUS": "1"})
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -58,7 +58,7 @@ def test_two_ranks_on_one_gpu_through_the_self_launcher():
 def test_two_ranks_on_one_gpu_exchange_gradients_through_peer_mapped_memory():
     """The same two ranks with KS_P2P=1: gloo only carries the rendezvous, the handles and the checksums; the gradients go
     through exchange.PeerExchange (the default under RCCL on a multi-GPU node).  Replicas must stay bit-identical."""
-    r = run_bench(["--gpus", "2", "--steps", "4", "--warmup", "3", "--envs-per-gpu", "512", "--no-cpu-baseline", "--steady-updates", "0"],
+    r = run_bench(["--gpus", "2", "--steps", "4", "--warmup", "3", "--envs-per-gpu", "512", "--no-cpu-baseline", "--pretrain-updates", "0", "--steady-steps", "0"],
                   env={"KS_DIST_BACKEND": "gloo", "KS_VISIBLE_GPUS": "1", "KS_P2P": "1"})
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -72,7 +72,7 @@ def test_two_ranks_two_gpus_rccl():
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs")
-    r = run_bench(["--gpus", "2", "--steps", "10", "--warmup", "5", "--no-cpu-baseline", "--steady-updates", "0"])
+    r = run_bench(["--gpus", "2", "--steps", "10", "--warmup", "5", "--no-cpu-baseline", "--pretrain-updates", "0", "--steady-steps", "0"])
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rccl"]["backend"] == "nccl" and line["replica_weight_checksum_spread"] == 0.0
@@ -104,3 +104,34 @@ def test_peer_exchange_between_processes(world):
         outs.append((p.returncode, out))
     for rc, out in outs:
         assert rc == 0 and "peer exchange OK" in out, out[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stage", ["connect", "selftest"])
+def test_peer_exchange_failure_on_one_rank_makes_every_rank_fall_back(stage):
+    """First-contact robustness for the 8-GPU run: if peer access does not work on ONE rank (hipIpcOpenMemHandle fails there, or its
+    exchange returns a wrong mean in the connect-time self-test - injected with KS_XCHG_INJECT), ALL ranks must take the same
+    decision, keep the process group's all_reduce, say so in the bench line, and still end with bit-identical replicas."""
+    r = run_bench(["--gpus", "2", "--steps", "4", "--warmup", "3", "--envs-per-gpu", "512", "--no-cpu-baseline", "--pretrain-updates", "0", "--steady-steps", "0"],
+                  env={"KS_DIST_BACKEND": "gloo", "KS_VISIBLE_GPUS": "1", "KS_P2P": "1", "KS_XCHG_INJECT": f"{stage}:1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    ex = line["rccl"]["exchange"]
+    assert ex.startswith("gloo all_reduce (") and "rank" in ex and not ex.startswith("peer-mapped"), ex
+    assert line["replica_weight_checksum_spread"] == 0.0 and line["nonfinite_envs"] == 0 and line["rccl"]["exchange_failed_call"] is None
+
+
+@pytest.mark.gpu
+def test_eight_ranks_config5_dry_run_on_one_gpu():
+    """`bench.py --gpus 8 --config 5` end to end - the command of BASELINE config 5 on a node - as 8 ranks sharing this box's GPU
+    (gloo rendezvous, gradients through the peer exchange, 256 envs per rank): launcher, sharding of scenarios.config5_states by
+    rank, mixed-object contexts, the two-graph learner split, periodic replica checks (every 20 updates here) and the final
+    checksum all work with world size 8 before the first real node ever sees them."""
+    r = run_bench(["--gpus", "8", "--config", "5", "--steps", "6", "--warmup", "4", "--envs-per-gpu", "256", "--no-cpu-baseline",
+                   "--pretrain-updates", "45", "--steady-steps", "0"],
+                  env={"KS_DIST_BACKEND": "gloo", "KS_VISIBLE_GPUS": "1", "KS_P2P": "1", "KS_REPLICA_CHECK_EVERY": "20"}, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["config"]["envs_per_gpu"] == 256 and "14 README shapes" in line["config"]["workload"]
+    assert line["rccl"]["ranks"] == 8 and line["rccl"]["exchange"].startswith("peer-mapped memory"), line["rccl"]
+    assert line["replica_weight_checksum_spread"] == 0.0 and line["replica_checks_during_run"] >= 2 and line["nonfinite_envs"] == 0

@@ -195,6 +195,30 @@ def test_batch_config2_first_steps(cube):
     sim.close()
 
 
+def test_batched_long_horizon_parity_200_substeps():
+    """north_star's bar, batched: 256 BASELINE config-2 envs (random +-0.8 actions) free-running for 200 consecutive
+    substeps, fp32 kernels vs fp64 oracle, every substep compared; plus two shapes x 3 poses x 4 starts with the grasp-and-lift
+    script.  Asserted: the share of envs that is within 1e-4 relative at substep 200 and never left it on the way (measured in
+    round 3 over 512 envs: 0.992 - tests/studies/long_horizon.py, profiles/r03_long_horizon.txt has the per-phase histogram of
+    the first divergences with qvel / normal-force traces); the median stays at round-off level."""
+    from tests.studies import long_horizon as lh
+    res = lh.config2_batch(256, 200)
+    rel = res["rel"]
+    fb = lh.first_bad(rel)
+    never = float(np.mean(fb < 0))
+    print(lh.summarize("config 2 x 256", res))
+    assert (res["status"] == 0).all()
+    assert never >= 0.97 and np.median(rel[199]) < 1e-6 and np.percentile(rel[199], 90) < 1e-5
+    shapes = lh.shapes_batches(4, 200, shapes=["CubeS", "CylinderB"])
+    for sh, r in shapes.items():
+        print(lh.summarize(sh, r))
+        assert np.isfinite(r["rel"]).all() and (r["status"] & 2 == 0).all()
+    # grasp-and-lift scripts are harder than random actions: every env goes through a light first touch where the contact
+    # toggles from substep to substep; one toggle decided differently in fp32 (state error ~1e-7 against a threshold) is a
+    # |dqvel| ~ 5e-2 kick.  Measured: 111 of 168 envs (14 shapes x 3 poses x 4 starts) within 1e-4 at substep 200.
+    assert np.mean(shapes["CubeS"]["rel"][199] <= 1e-4) >= 0.65 and np.median(shapes["CubeS"]["rel"][199]) < 1e-4
+
+
 def test_time_limit_done_and_auto_reset():
     n = 64
     q0, hq = scenarios.config2_states(n)
@@ -447,6 +471,49 @@ def test_graphed_trainer_runs_rollout_and_updates():
     sim.close()
 
 
+def test_graphed_trainer_at_the_metric_shape_is_reproducible():
+    """BASELINE config 3 at ITS shape - 4096 envs, 256-256, 64-episode batches - through pipeline.GraphedTrainer for 70 env-steps,
+    twice from the same seeds: finite, no status flag beyond the Newton-cap bit, and the two runs end with the SAME weights and env
+    states to the bit (no atomics, no launch-order dependence in the stepping kernel, the ray pool, the window sampler or the
+    LDS-free learner beside it) - the single-GPU half of the replica-checksum invariant of SURVEY 8e."""
+    from kinovagrasping_amd.ddpgfd import DDPGfD
+    from kinovagrasping_amd.pipeline import GraphedTrainer
+    from kinovagrasping_amd.replay import DeviceEpisodeReplay
+    from kinovagrasping_amd.rollout import RolloutEngine
+    n = 4096
+    q0, hq = scenarios.config2_states(n)
+
+    def run():
+        sim = _sim(n, "CubeS", horizon=30, auto_reset=True)
+        obs0 = sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+        torch.manual_seed(2)
+        policy = DDPGfD(82, 4, 0.8, 5, batch_size=64, hidden=(256, 256), device=sim.device)
+        replay = DeviceEpisodeReplay(n, capacity=4 * n, horizon=30, device=sim.device)
+        eng = RolloutEngine(sim, policy, replay, expl_noise=0.1)
+        eng.start(obs0)
+        tr = GraphedTrainer(sim, policy, replay, eng, batch_episodes=64)
+        tr.capture()
+        for _ in range(70):
+            tr.step()
+        tr.flush(finish_update=True)
+        torch.cuda.synchronize()
+        st = sim.get_state()
+        out = {k: policy._flat_params[k].clone() for k in ("actor", "critic", "actor_target", "critic_target")}
+        out.update(qpos=st["qpos"].clone(), status=st["status"].clone(), count=torch.tensor(replay.count), updates=torch.tensor(tr.updates),
+                   losses=tr.native.losses.clone())
+        sim.close()
+        return out
+
+    a, b = run(), run()
+    assert int(a["updates"]) >= 38 and int(a["count"]) >= n
+    assert all(torch.isfinite(a[k]).all() for k in ("actor", "critic", "qpos", "losses"))
+    assert int((a["status"] & 7).sum()) == 0
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    chk = [float(a[k].double().sum()) for k in ("actor", "critic", "actor_target", "critic_target")]
+    print("4096-env trainer, 70 steps: weight checksums", [f"{c:.9e}" for c in chk], "identical in two runs")
+
+
 def test_randomised_mass_and_friction_match_oracle(cube):
     """BASELINE config 5 extension: per-env object mass U[0.05, 0.15] kg and object-hand friction U[0.5, 1.0]
     (ks_set_env_params) against the oracle with the same overrides: a closing + lifting grasp, teacher-forced one
@@ -624,6 +691,46 @@ def test_vec_env_keeps_the_reference_interface():
     assert changed[ids].all() and changed.sum() == len(ids)
     with pytest.raises(NotImplementedError):
         env.set_with_grasp_reward(True)
+    env.close()
+
+
+def test_vec_env_with_noise_resets_to_noisy_poses_that_match_the_oracle():
+    """reset(with_noise=True): zero-mean N(0, 0.087) Euler noise through the 5-character truncation (scenarios.hand_euler_for,
+    SURVEY N5 extension).  Every env's reset observation and its state after two env-steps equal the oracle run on the SAME noisy
+    hand quaternion; the noise is there (quaternions differ from the class constant) and seeded."""
+    from kinovagrasping_amd.vec_env import KinovaGripperVecEnv
+    from kinovagrasping_amd.model_compiler import euler_to_quat
+    n = 48
+    env = KinovaGripperVecEnv(n, "CubeS", seed=9, auto_reset=False)
+    obs = env.reset(hand_orientation="normal", with_noise=True).double().cpu().numpy().copy()
+    base = scenarios.hand_quat_for("normal")
+    ang = 2 * np.arccos(np.clip(np.abs(env.hand_quat.T @ base), 0, 1))
+    assert ang.min() > 1e-3 and 0.05 < ang.mean() < 0.3                      # a few degrees of tilt in every env
+    assert np.allclose(env.hand_quat, np.stack([euler_to_quat(e) for e in env.hand_euler], 1))
+    env2 = KinovaGripperVecEnv(n, "CubeS", seed=9, auto_reset=False)
+    env2.reset(hand_orientation="normal", with_noise=True)
+    assert np.array_equal(env.hand_euler, env2.hand_euler)
+    env2.close()
+    model = ko.OracleModel(scenarios.model_blob("CubeS"))
+    a = np.array([0.1, 0.5, 0.4, 0.6])
+    act = torch.as_tensor(np.repeat(a[None], n, 0))
+    for _ in range(2):
+        env.step(act)
+    qg = env.sim.get_state()["qpos"].double().cpu().numpy()
+    worst_o, worst_q = 0.0, 0.0
+    for e in range(0, n, 3):
+        o = ko.OracleSim(model, env.hand_quat[:, e].copy(), solver_iterations=SOLVER_ITERATIONS)
+        q0 = np.zeros(16); q0[9:12] = env.get_obj_coords()[e]; q0[12] = 1
+        ref = o.env_reset(q0)
+        tol = 2e-4 * np.maximum(1.0, np.abs(ref)) * np.where(np.isin(np.arange(82), [48, 49] + list(range(75, 82))), 50, 1)
+        assert (np.abs(obs[e] - ref) <= tol + 2e-5).all(), (e, np.abs(obs[e] - ref).max())
+        worst_o = max(worst_o, np.abs(obs[e] - ref).max())
+        for _ in range(2):
+            o.env_step(a)
+        qo = o.view("qpos")
+        worst_q = max(worst_q, np.abs(qg[:, e] - qo).max() / max(1e-3, np.abs(qo).max()))
+    print(f"noisy poses: worst reset-obs error {worst_o:.2e}, worst relative qpos error after 2 env-steps {worst_q:.2e}")
+    assert worst_q < 1e-4
     env.close()
 
 

@@ -204,3 +204,20 @@ def test_newton_cap_of_the_product_setting_is_never_the_exit(model):
     assert hi["capped"].sum() == 0 and hi["dacc"].max() < 1e-9 and hi["drift"].max() < 1e-9 and hi["iters_a"].max() <= 12
     _, lo = scenario(("CubeS", "normal", 100, 6))
     assert lo["capped"].sum() > 0 and lo["dacc"].max() > 1e-2
+
+
+def test_rangefinder_sees_only_the_front_face_of_the_ground_plane(model):
+    """mju_rayGeom, plane case: a ray whose direction does not point at the +z (front) side of the plane is rejected.  Matters in
+    the 'rotated' / 'top' fresh-env starts whose hand is partly below z = 0.  Palm sites look along the hand's
+    -z (site quat 0 1 0 0): hand upright and 0.255 m up -> the palm-centre ray reads its height; hand flipped and pushed 0.125 m
+    under the floor, looking UP through it -> no hit (rounds 1-2 returned 0.125)."""
+    far = np.zeros(16); far[9:12] = [0.5, -0.5, 0.0479]; far[12] = 1
+    up = ko.OracleSim(model, np.array([1.0, 0.0, 0.0, 0.0]))
+    q = far.copy(); q[1] = 0.3
+    up.set_state(q); up.forward()
+    z = up.view("site_xpos").reshape(17, 3)[0, 2]
+    assert abs(z - 0.2554) < 1e-3 and abs(up.view("sensordata")[9] - z) < 1e-12
+    down = ko.OracleSim(model, np.array([0.0, 1.0, 0.0, 0.0]))
+    down.set_state(q); down.forward()
+    assert down.view("site_xpos").reshape(17, 3)[0, 2] < -0.12 and down.view("site_xmat").reshape(17, 9)[0, 8] > 0.999
+    assert (down.view("sensordata")[9:14] == -1).all()
