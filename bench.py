@@ -175,6 +175,13 @@ def main():
                          "contact-rich grasps and de-synchronised episode clocks instead of the cheap first episodes of a random policy (0 = time the "
                          "first episodes, as rounds 1-2 did)")
     ap.add_argument("--steady-updates", type=int, default=0, help="further learner updates before the steady_state window (whole episodes)")
+    ap.add_argument("--rollout", choices=["lockstep", "free"], default="lockstep",
+                    help="ddpg mode: 'lockstep' (default) = one stepping launch per env-step for all envs (pipeline.GraphedTrainer; bit-reproducible "
+                         "training, the path every round's driver run has used); 'free' = the free-running rollout kernel (ks_rollout / "
+                         "pipeline.AsyncTrainer, round 3): every stepping workgroup loops over its 16 envs - in-kernel actor, 15 substeps, rays, "
+                         "observation, replay write - without waiting for other workgroups, learner beside it: +6-14 %% at 4096 envs (config 3), slower "
+                         "when the envs need more workgroups than the GPU has CUs (config 5).  One GPU, HIP-graph learner only.")
+    ap.add_argument("--chunk", type=int, default=10, help="free-running rollout: env-steps per launch (learner and rollout streams meet between launches)")
     ap.add_argument("--expert-prob", type=float, default=0.0,
                     help="ddpg mode: DDPGfD's demonstration mix (DDPGfD.py:232-254) - an expert ring is filled with one scripted 'combined'-controller "
                          "episode per env before training and every update samples int(64 (1 - p)) agent + the rest expert episodes (reference: 0.3)")
@@ -259,11 +266,15 @@ def main():
         if not args.eager:
             # rollout ops and the DDPGfD update replayed as HIP graphs; the simulator is launched between them and
             # the learner graph runs on a second stream beside the simulator kernel (kinovagrasping_amd/pipeline.py)
-            from kinovagrasping_amd.pipeline import GraphedTrainer
+            from kinovagrasping_amd.pipeline import AsyncTrainer, GraphedTrainer
             eng = RolloutEngine(sim, policy, replay, expl_noise=0.1)
             eng.start(obs0)
-            trainer = GraphedTrainer(sim, policy, replay, eng, batch_episodes=64, overlap=not args.serial_learner, expert_replay=expert,
-                                     expert_prob=args.expert_prob)
+            free_running = args.rollout == "free" and world == 1 and not args.serial_learner
+            if free_running:
+                trainer = AsyncTrainer(sim, policy, replay, eng, batch_episodes=64, expert_replay=expert, expert_prob=args.expert_prob)
+            else:
+                trainer = GraphedTrainer(sim, policy, replay, eng, batch_episodes=64, overlap=not args.serial_learner, expert_replay=expert,
+                                         expert_prob=args.expert_prob)
             trainer.capture()
             learner_form = "lds-free fp32-mfma kernels" if trainer.native.lds_free else "library gemms + kr_* glue"
 
@@ -304,9 +315,36 @@ def main():
     # ddpg mode: the learner only has data once every env has finished an episode (30 steps) - if the requested warm-up is
     # shorter, prime the replay first so that EVERY timed step carries a learner update (nothing skipped in the timed region)
     priming = max(0, 36 - args.warmup) if args.mode == "ddpg" else 0
+    free_running = trainer is not None and type(trainer).__name__ == "AsyncTrainer"
     k = 0
-    for _ in range(priming):
-        step_fn(k); k += 1
+    rollout_ms = []                     # free-running: (launch duration by HIP events on the launch stream, env-steps) per launch
+
+    def advance(n_steps, learn=True, timed=False):
+        """n_steps env-steps of every env (+ as many learner updates)"""
+        nonlocal k, updates
+        if not free_running:
+            for _ in range(n_steps):
+                step_fn(k); k += 1
+            return
+        left = n_steps
+        while left > 0:
+            c = min(left, args.chunk)
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                trainer.main.wait_stream(trainer.side)
+                e0.record(trainer.main)
+            trainer.run(c, learn=learn)
+            if timed:
+                e1.record(trainer.main)
+                rollout_ms.append((e0, e1, c))
+            left -= c; k += c
+        updates = trainer.updates
+
+    if free_running:
+        advance(priming, learn=False)
+        trainer.flush()
+    else:
+        advance(priming)
     # untimed pre-training (round 3): the driver's `--steps 20 --warmup 5` used to time steps 6-25 of the FIRST episodes of a random
     # policy - fingers still closing, the cheapest third of an episode.  Now the policy is trained for `--pretrain-updates` updates
     # first: hands close into contact-rich grasps, episodes end at different steps (lift), so the envs' episode clocks are spread
@@ -314,23 +352,25 @@ def main():
     pretrained = 0
     if args.mode == "ddpg" and args.pretrain_updates > 0:
         while updates < args.pretrain_updates:
-            step_fn(k); k += 1
+            advance(min(100, args.pretrain_updates - updates))
         pretrained = updates
-    for _ in range(args.warmup):
-        step_fn(k); k += 1
+    advance(args.warmup)
     barrier()
     clock_hist = torch.bincount(eng.t.clamp(0, 29), minlength=30).cpu().tolist() if args.mode == "ddpg" else None
     sim.kernel_time(reset=True)
     upd0 = updates
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step_fn(k); k += 1
+    advance(args.steps, timed=True)
     if trainer is not None:
         trainer.flush()                                    # the last step's deferred replay-ring update belongs to the timed work
     t_issue = time.perf_counter() - t0                 # host time to issue the timed steps (before the device catches up)
     barrier()
     dt = time.perf_counter() - t0
     kern_ms, launches = sim.kernel_time()
+    if free_running:                     # per env-step: the persistent launches' durations / their env-steps
+        tot = sum(e0.elapsed_time(e1) for e0, e1, _ in rollout_ms)
+        kern_ms, launches = tot / max(1, sum(c for _, _, c in rollout_ms)), len(rollout_ms)
+        rollout_ms.clear()
     timed_updates = updates - upd0
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -364,16 +404,18 @@ def main():
     steady = None
     if args.mode == "ddpg" and trainer is not None and args.steady_steps > 0:
         while updates < args.steady_updates:
-            step_fn(k); k += 1
+            advance(min(100, args.steady_updates - updates))
         barrier()
         sim.kernel_time(reset=True)
         u0, t2 = updates, time.perf_counter()
-        for _ in range(args.steady_steps):
-            step_fn(k); k += 1
+        advance(args.steady_steps, timed=True)
         trainer.flush()
         barrier()
         dts = time.perf_counter() - t2
         ks_ms, ks_n = sim.kernel_time()
+        if free_running:
+            tot = sum(e0.elapsed_time(e1) for e0, e1, _ in rollout_ms)
+            ks_ms, ks_n = tot / max(1, sum(c for _, _, c in rollout_ms)), len(rollout_ms)
         if world > 1:
             tt = torch.tensor([dts], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -429,10 +471,12 @@ def main():
                                     "metric's env count); sim kernels only"),
                        "mode": args.mode, "envs_per_gpu": n, "frame_skip": 15, "solver": f"newton, <= {iters} iterations per substep (early exit on convergence)", "hidden": list(args.hidden),
                        "learner_updates_timed": timed_updates if args.mode == "ddpg" else 0, "priming_steps": priming,
-                       "launch": ("eager" if args.eager else "hip-graphs") if args.mode == "ddpg" else "direct",
+                       "launch": (("eager" if args.eager else ("free-running rollout kernel (ks_rollout), %d env-steps per launch + learner graphs" % args.chunk
+                                                                if free_running else "hip-graphs, one stepping launch per env-step")) if args.mode == "ddpg" else "direct"),
+                       "free_running": (trainer.counts() if free_running else None),
                        "learner": learner_form, "expert_mix": (expert_info if args.mode == "ddpg" else None),
                        "parallelism": f"env-shard x{world}" + (" + grad all-reduce" if world > 1 and args.mode == "ddpg" else "")},
-            "roofline": {"bound": "hbm", "kernel": "k_env_step", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_rollout (per env-step)" if free_running else "k_env_step", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "avg_launch_ms": round(kern_ms, 4), "launches_timed": launches,

@@ -140,6 +140,53 @@ int ks_substep(ks_ctx *ctx, const void *ctrl, void *stream);
  * vectors go through the HIP observation kernel this way. */
 int ks_obs_from_snapshot(ks_ctx *ctx, const void *snap, const void *rays, void *obs, void *reward, uint8_t *done, void *info, void *stream);
 
+/* Free-running rollout: n_iter env-steps of EVERY env in ONE launch, every stepping workgroup (16 envs, one CU) running its own
+ * loop with no synchronisation between workgroups -
+ *     actor forward of its envs (3-layer MLP on the matrix cores, newest published weights) + exploration noise + the
+ *     check_grasp / scripted-lift rule  ->  15 substeps  ->  rangefinder rays  ->  observation / reward / done / auto-reset
+ *     ->  replay write (open-episode buffers) + episode hand-over
+ * i.e. what kr_actor_select + ks_step + kr_store_transition do per env-step (main_DDPGfD.py:424-464 around ENV:1495-1552), fused.
+ * A lock-step launch lasts as long as its slowest wave (1.6 - 1.9 x the median); here a workgroup starts its next env-step the
+ * moment it has finished the last.  Per env the arithmetic, the noise stream (Philox keyed by seed, the env's own step count,
+ * env) and therefore the trajectory are those of the lock-step calls for the same weights.
+ *
+ * Actor weights: `actor_pub` holds 3 parameter buffers of `actor_stride` floats (layout: offsets off_*, torch.nn.Linear
+ * layout); `actor_ver` is a device counter that the learner increments AFTER it has completely written buffer
+ * (ver % 3): a workgroup reads the counter at the start of every env-step and uses that buffer (and repeats the forward in the
+ * unlikely case that two more versions were published meanwhile).
+ * Episodes: two open-episode buffers per env, cur_* [2][n][horizon][...]; a finished episode that is kept (len - n_steps > 1,
+ * main_DDPGfD.py:469-471) is handed over by setting pub_len[buf][env] = len (release) and switching to the other buffer; the
+ * consumer (the learner's stream: kr_rank / kr_commit / kr_advance_ring on buffer `buf` with cur_len = pub_len + buf * n) clears
+ * it.  If the other buffer has not been consumed yet the finished episode is dropped and counted in `dropped`.
+ * fp32 contexts with observations in the stepping kernel only (the default); obs layout env-major; one model or many. */
+typedef struct {
+    const float *actor_pub;
+    const int64_t *actor_ver;
+    int64_t actor_stride;
+    int64_t off_w1, off_b1, off_w2, off_b2, off_w3, off_b3;
+    int32_t h1, h2;                  /* hidden widths: 256-256, 400-300, 128-128 or 64-64 */
+    float sigma, max_action;         /* exploration noise std (max_action * expl_noise), action bound */
+    int32_t skip_steps;              /* check_grasp from this step of an episode on (6, main_DDPGfD.py:418) */
+    int32_t with_replay;
+    uint64_t seed;
+    /* engine state (kinovagrasping_amd.rollout.RolloutEngine) */
+    float *obs, *prev_obs;           /* [n, 82] */
+    uint8_t *has_prev, *ready, *lifting;
+    int64_t *t, *steps_total;        /* [n] steps in the episode / since the start (the noise counter) */
+    float *action, *action_t;        /* [n, 4], [4, n] */
+    float *reward_out; uint8_t *done_out;
+    /* ks_step's outputs (as passed to ks_step) */
+    float *sim_obs, *sim_reward; uint8_t *sim_done; float *sim_info, *sim_final_obs;
+    /* open episodes */
+    int32_t horizon, n_steps;
+    float *cur_state, *cur_next, *cur_action, *cur_reward, *cur_not_done;
+    int64_t *cur_len;                /* [2][n] */
+    uint8_t *cur_sel;                /* [n] */
+    int64_t *pub_len;                /* [2][n] */
+    int64_t *counters;               /* [4]: episodes finished, lifted, kept, dropped */
+} ks_rollout_args;
+int ks_rollout(ks_ctx *ctx, int32_t n_iter, const ks_rollout_args *args_host, void *stream);
+
 /* HIP event timing of the dominant kernel: average duration (ms) of the env-step kernel launches
  * since the last call with reset != 0, measured with hipEvents on the launch stream - every 4th launch is sampled (the two
  * event records cost ~8 us of stream time per sampled launch; KS_EVENT_STRIDE=1 samples all of them).  Host sync.

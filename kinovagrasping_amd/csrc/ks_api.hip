@@ -24,6 +24,8 @@
 
 #include "../../include/kinova_sim.h"
 #include "ks_env.h"
+#include "ks_mlp_tile.h"
+#include "ks_select.h"
 #include "ks_model_host.h"
 
 using namespace ks;
@@ -528,6 +530,212 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
     }
 }
 
+
+// ---- free-running rollout (include/kinova_sim.h: ks_rollout): k_env_step's fp32 / LDS path inside a per-workgroup loop, with
+// the actor forward + action selection in front of the step and the replay write behind it.  No cross-workgroup state: the ray
+// pool is off (every workgroup casts its own envs' rays).  The two added phases are out-of-line and reach their arguments
+// through a pointer to device memory: nothing of them stays in registers across the stepping phase, whose footprint (344 of
+// the 512 registers per lane) is what lets the learner's LDS-free waves run beside this kernel for its whole life.
+template <int NT1, int NT2>
+__device__ __noinline__ void rollout_policy(const ks_rollout_args* __restrict__ rap, int N, int row_env, KS_LDS float* blocks) {
+    const ks_rollout_args& ra = *rap;
+    const int S = krsel::S, A = krsel::A;
+    // the policy's scratch lives in the (then dead) env blocks: H1 [NT1 * 4][16], H2 [NT2 * 4][16], P [4][16] float4
+    kmlp::f32x4(*H1)[kmlp::ROWS] = (kmlp::f32x4(*)[kmlp::ROWS])(float*)blocks;
+    kmlp::f32x4(*H2)[kmlp::ROWS] = H1 + NT1 * 4;
+    kmlp::f32x4(*Pp)[kmlp::ROWS] = H2 + NT2 * 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    long long seen = -1;
+    for (;;) {
+        const long long ver = (long long)__hip_atomic_load(ra.actor_ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ver != seen) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); seen = ver; }      // the newest complete weight buffer
+        const float* pw = ra.actor_pub + (ver % 3) * ra.actor_stride;
+        kmlp::f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        const bool mine = kmlp::mlp3_rows16<NT1, NT2, true>(wave, lane, (long)row_env, S, 0, ra.h1, ra.h2, A, ra.obs, S, nullptr, 0, pw + ra.off_w1,
+                                                            pw + ra.off_b1, pw + ra.off_w2, pw + ra.off_b2, pw + ra.off_w3, nullptr, nullptr, H1, H2, Pp,
+                                                            z4);
+        // (a buffer is rewritten when the counter has advanced by two more: then the weights just read may be torn - repeat)
+        const long long now = (long long)__hip_atomic_load(ra.actor_ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool stale = __builtin_amdgcn_readfirstlane((int)(now - ver >= 2)) != 0;
+        if (!stale) {
+            if (mine) {
+                const float z[4] = {z4.x, z4.y, z4.z, z4.w};
+                const float* b3 = pw + ra.off_b3;
+                float y[4], nz[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) y[i] = ra.max_action / (1.f + __expf(-(z[i] + b3[i])));
+                krsel::normal4(ra.seed, (unsigned long long)ra.steps_total[row_env], (uint32_t)row_env, nz);
+                krsel::select_one(row_env, N, y, nz, ra.obs, ra.prev_obs, ra.has_prev, ra.t, ra.ready, ra.sigma, ra.max_action, ra.skip_steps, ra.action,
+                                  ra.action_t, ra.lifting);
+            }
+            return;
+        }
+        __syncthreads();
+    }
+}
+
+// replay write + per-env bookkeeping of one env by its 16-lane team (k_store_transition of ks_rollout.hip + the episode hand-over)
+__device__ __noinline__ void rollout_store(const ks_rollout_args* __restrict__ rap, int N, int i, int sub) {
+    const ks_rollout_args& ra = *rap;
+    const int S = krsel::S, A = krsel::A, H = ra.horizon;
+    const bool done = ra.sim_done[i] != 0, lift = ra.lifting[i] != 0;
+    const float rew = ra.sim_reward[i];
+    const bool store = ra.with_replay && !lift;
+    const int sel = ra.with_replay ? ra.cur_sel[i] : 0;
+    const long bi = (long)sel * N + i;
+    const long len0 = ra.with_replay ? ra.cur_len[bi] : 0;
+    const long tt = len0 < H - 1 ? len0 : H - 1;
+    const long row = bi * H + tt;
+    for (int c = sub; c < S; c += SUBS) {
+        const float so = ra.sim_obs[(long)i * S + c];
+        const float st = ra.obs[(long)i * S + c];
+        const float nx = done ? ra.sim_final_obs[(long)i * S + c] : so;          // (auto-reset contexts: the terminal observation)
+        if (store) { ra.cur_state[row * S + c] = st; ra.cur_next[row * S + c] = nx; }
+        ra.prev_obs[(long)i * S + c] = done ? so : st;
+        ra.obs[(long)i * S + c] = so;
+    }
+    if (store && sub < A) ra.cur_action[row * A + sub] = ra.action[(long)i * A + sub];
+    if (sub != 0) return;
+    long len1 = len0;
+    if (store) {
+        ra.cur_reward[row] = rew;
+        ra.cur_not_done[row] = done ? 0.0f : 1.0f;
+        len1 = tt + 1;
+    }
+    if (ra.with_replay) {
+        if (done && lift && len1 > 0) {                                         // ended during the scripted lift: the outcome goes
+            ra.cur_reward[bi * H + len1 - 1] = rew;                              // into the last stored transition (utils.py:309-343)
+            ra.cur_not_done[bi * H + len1 - 1] = 0.0f;
+        }
+        ra.cur_len[bi] = len1;
+        if (done) {
+            const bool keep = len1 - ra.n_steps > 1;
+            const long bo = (long)(sel ^ 1) * N + i;
+            const bool free_other = __hip_atomic_load(&ra.pub_len[bo], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0;
+            if (keep && free_other) {
+                __threadfence();                                                // (the team's row stores were fenced by the caller)
+                __hip_atomic_store(&ra.pub_len[bi], (int64_t)len1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                ra.cur_sel[i] = (uint8_t)(sel ^ 1);
+                ra.cur_len[bo] = 0;
+                atomicAdd((unsigned long long*)&ra.counters[2], 1ull);
+            } else {
+                ra.cur_len[bi] = 0;
+                if (keep) atomicAdd((unsigned long long*)&ra.counters[3], 1ull);
+            }
+        }
+    }
+    if (done) {
+        atomicAdd((unsigned long long*)&ra.counters[0], 1ull);
+        if (ra.sim_done[i] & 1) atomicAdd((unsigned long long*)&ra.counters[1], 1ull);
+    }
+    ra.has_prev[i] = !done;
+    ra.t[i] = done ? 0 : ra.t[i] + 1;
+    ra.steps_total[i] += 1;
+    ra.ready[i] = (ra.ready[i] != 0) && !done;
+    ra.reward_out[i] = rew;
+    ra.done_out[i] = done;
+}
+
+// One env-step of the workgroup's envs (the body of k_rollout's loop).
+template <int NT1, int NT2>
+__device__ __forceinline__ void rollout_iter(const Model<float>& m, const Hulls<float>& hu, const Buffers<float>* __restrict__ bdev, int N, int frame_skip,
+                                          int iters, int epw, int pair_memory, const ObsOut<float>* __restrict__ out,
+                                          const ks_rollout_args* __restrict__ rap, KS_LDS float* blocks) {
+    using T = float;
+    const Buffers<T>& b = *bdev;
+    const int e = threadIdx.x / LANE_STRIDE;
+    const Team<SUBS> team{(int)threadIdx.x % LANE_STRIDE};
+    // (the env ids are re-read from the slot list in every iteration rather than kept in registers across the stepping phase)
+    const int env = e < epw ? b.slot_env[blockIdx.x * epw + e] : -1;
+    const bool active = !(team.sub >= SUBS || env < 0);
+    KS_LDS unsigned* w = (KS_LDS unsigned*)blocks;
+    {
+        const int nn = threadIdx.x & 15;
+        const int row_env = nn < epw ? b.slot_env[blockIdx.x * epw + nn] : -1;   // the policy row of this lane (the same in all four waves)
+        rollout_policy<NT1, NT2>(rap, N, row_env, blocks);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- the env-step (k_env_step's LDS path)
+    if (active) {
+        T hq[4], act[4];
+        KS_UNROLL
+        for (int i = 0; i < 4; i++) { hq[i] = b.hand_quat[(long)i * N + env]; act[i] = rap->action_t[(long)i * N + env]; }
+        int ncon = 0, status = 0;
+        ColW<T> snap{b.snap + env, N};
+        KS_LDS T* blk = blocks + e * SCR_TOTAL;
+        ScratchC<T, KS_LDS T*> scr{blk};
+        T* stp = (T*)(blk + SCR_STATE);
+        load_state_team<T, SUBS>(b, env, N, stp, team.sub);
+        load_env_params(scr, team, b, env, N);
+        constexpr int WPL = (NPAIR_MAX + SUBS - 1) / SUBS;
+        PairWarm gw[WPL];
+        unsigned* pm = b.pairmem + ((long)env * SUBS + team.sub) * (WPL * WARM_WORDS);
+        KS_UNROLL
+        for (int q = 0; q < WPL; q++) {
+            KS_UNROLL
+            for (int j = 0; j < WARM_WORDS; j++) gw[q].w[j] = pair_memory ? pm[q * WARM_WORDS + j] : 0u;
+        }
+        lane_env_step(m, hu, *(LaneState<T>*)stp, hq, act, scr, team, snap, frame_skip, iters, ncon, status, (float*)nullptr, stp + NQ + 2 * NV, gw,
+                      []() {});
+        if (pair_memory) {
+            KS_UNROLL
+            for (int q = 0; q < WPL; q++) {
+                KS_UNROLL
+                for (int j = 0; j < WARM_WORDS; j++) pm[q * WARM_WORDS + j] = gw[q].w[j];
+            }
+        }
+        team.sync();
+        store_state_team<T, SUBS>(b, env, N, stp, team.sub);
+        if (status) atomicOr(&b.status[env], status);
+        if (team.sub == 0) b.ncon[env] = ncon;
+    }
+    __threadfence_block();
+    __syncthreads();
+    wg_rays(m, b, N, blockIdx.x * epw, epw, w);
+    __threadfence_block();
+    __syncthreads();
+    wg_obs(m, b, N, blockIdx.x * epw, epw, w, *out);
+    __threadfence_block();
+    __syncthreads();
+    if (active) rollout_store(rap, N, env, team.sub);
+    __threadfence_block();
+    __syncthreads();
+}
+
+template <int NT1, int NT2>
+__global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__ models, Buffers<float> b, const Buffers<float>* __restrict__ bdev, int N,
+                                                int frame_skip, int iters, int epw, int pair_memory, const ObsOut<float>* __restrict__ out,
+                                                const ks_rollout_args* __restrict__ rap, int n_iter) {
+    using T = float;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    KS_LDS T* lds = (KS_LDS T*)smem;
+    const Model<T>* mp = models + __builtin_amdgcn_readfirstlane(b.wg_model[blockIdx.x]);
+    const Model<T>* ml = stage_model_and_tables<T, WG>(mp, lds);
+    lds += model_words<T>();
+    int hull_words = 0;
+    Hulls<T>* hup = (Hulls<T>*)(smem + (sizeof(Model<T>) + 15) / 16 * 16);
+    __syncthreads();
+    stage_hulls<T, true>(*ml, lds, hull_words, *hup, true);
+    KS_LDS T* blocks = lds + ((hull_words >> 2) << 2);                 // the 16 env blocks; scratch of the tails between the steps
+    // The loop's pointers are laundered through empty asm statements at the top of every iteration: otherwise the compiler hoists
+    // loop-invariant address arithmetic and model constants out of the loop and keeps them in registers for the whole launch
+    // (388 registers per lane instead of ~344; as an out-of-line call the body saves its callee-saved registers to scratch:
+    // 1.5 KB per lane) - and the learner's waves (<= 168 registers) must fit beside this kernel on every SIMD.
+#pragma clang loop unroll(disable)
+    for (int it = 0; it < n_iter; it++) {
+        const Model<T>* mi = ml;
+        Hulls<T>* hi = hup;
+        const Buffers<T>* bi = bdev;
+        const ObsOut<T>* oi = out;
+        const ks_rollout_args* ri = rap;
+        KS_LDS T* ki = blocks;
+        asm volatile("" : "+s"(mi), "+s"(hi), "+s"(bi), "+s"(oi), "+s"(ri));
+        asm volatile("" : "+v"(ki));
+        rollout_iter<NT1, NT2>(*mi, *hi, bi, N, frame_skip, iters, epw, pair_memory, oi, ri, ki);
+    }
+}
+
 template <typename T, bool USE_LDS>
 __global__ __launch_bounds__(WG) void k_substep(const Model<T>* __restrict__ models, Buffers<T> b, const T* __restrict__ ctrl, int N, int iters, int epw, int tap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -911,6 +1119,7 @@ struct CtxBase {
     virtual int substep(const void* ctrl, hipStream_t s) = 0;
     virtual int obs_from_snapshot(const void* snap, const void* rays, void* obs, void* reward, uint8_t* done, void* info, hipStream_t s) = 0;
     virtual int kernel_time(int reset, double* avg_ms, int64_t* launches) = 0;
+    virtual int rollout(int n_iter, const ks_rollout_args* args, hipStream_t s) = 0;
 };
 
 #define HIPCHK(expr)                                                                         \
@@ -926,6 +1135,9 @@ template <typename T> struct Ctx : CtxBase {
     static constexpr bool USE_LDS = sizeof(T) == 4;
     Buffers<T> b{};
     Buffers<T>* d_b = nullptr;            // the same pointer table in device memory (what the stepping kernels' out-of-line tails read)
+    ks_rollout_args* d_ra = nullptr;      // ks_rollout's argument record in device memory (+ a pinned host ring to copy it from)
+    ks_rollout_args* h_ra = nullptr;
+    unsigned h_ra_next = 0;
     ObsOut<T>* d_out = nullptr;           // ... and where ks_step's results go (re-sent only when a caller changes its buffers)
     ObsOut<T> out_sent{};
     ObsOut<T>* h_out = nullptr;           // pinned staging of that record (an async copy from pinned memory may be captured in a
@@ -981,6 +1193,8 @@ template <typename T> struct Ctx : CtxBase {
     ~Ctx() override {
         for (void* p : allocs) (void)hipFree(p);
         if (h_out) (void)hipHostFree(h_out);
+        if (h_ra) (void)hipHostFree(h_ra);
+        if (d_ra) (void)hipFree(d_ra);
         for (auto& e : ev0) (void)hipEventDestroy(e);
         for (auto& e : ev1) (void)hipEventDestroy(e);
     }
@@ -1163,6 +1377,49 @@ template <typename T> struct Ctx : CtxBase {
         HIPCHK(hipGetLastError());
         return KS_OK;
     }
+    int rollout(int n_iter, const ks_rollout_args* ra, hipStream_t s) override {
+        if (!model_loaded) { error = "ks_rollout before ks_load_model"; return KS_ERR_STATE; }
+        if constexpr (sizeof(T) != 4) { error = "ks_rollout: fp32 contexts only"; return KS_ERR_INVALID; }
+        else {
+            if (!ra || n_iter <= 0 || !ra->actor_pub || !ra->actor_ver || !ra->obs || !ra->prev_obs || !ra->has_prev || !ra->ready || !ra->lifting ||
+                !ra->t || !ra->steps_total || !ra->action || !ra->action_t || !ra->reward_out || !ra->done_out || !ra->sim_obs || !ra->sim_reward ||
+                !ra->sim_done || !ra->sim_info || !ra->sim_final_obs || !ra->counters) { error = "ks_rollout: NULL argument"; return KS_ERR_INVALID; }
+            if (ra->with_replay && (!ra->cur_state || !ra->cur_next || !ra->cur_action || !ra->cur_reward || !ra->cur_not_done || !ra->cur_len ||
+                                    !ra->cur_sel || !ra->pub_len || ra->horizon <= ra->n_steps)) { error = "ks_rollout: replay buffers"; return KS_ERR_INVALID; }
+            if (!obs_in_step || !cfg.obs_env_major || !cfg.auto_reset) { error = "ks_rollout needs the in-kernel observation path, env-major observations and auto_reset"; return KS_ERR_STATE; }
+            if ((ra->off_w2 | ra->off_w3 | ra->actor_stride) & 3) { error = "ks_rollout: weight offsets must be multiples of 4 floats"; return KS_ERR_INVALID; }
+            if ((ra->h1 | ra->h2) & 3) { error = "ks_rollout: hidden widths must be multiples of 4"; return KS_ERR_INVALID; }
+            if ((size_t)(((ra->h1 + 15) / 16 + (ra->h2 + 15) / 16) * 4 + 4) * 16 * 16 > (size_t)SCR_TOTAL * lpw * sizeof(T)) { error = "ks_rollout: no LDS for the policy"; return KS_ERR_STATE; }
+            const int N = cfg.n_envs;
+            const ObsOut<T> out{(T*)ra->sim_obs, (T*)ra->sim_reward, ra->sim_done, (T*)ra->sim_info, (T*)ra->sim_final_obs, cfg.horizon, cfg.auto_reset, cfg.obs_env_major};
+            ObsOut<T>* slot = h_out + (h_out_next++ % H_OUT_RING);
+            *slot = out;
+            out_valid = false;                                     // a following ks_step re-sends its own record
+            HIPCHK(hipMemcpyAsync(d_out, slot, sizeof out, hipMemcpyHostToDevice, s));
+            if (!d_ra) {
+                HIPCHK(hipMalloc((void**)&d_ra, sizeof(ks_rollout_args)));
+                HIPCHK(hipHostMalloc((void**)&h_ra, sizeof(ks_rollout_args) * H_OUT_RING));
+            }
+            ks_rollout_args* rslot = h_ra + (h_ra_next++ % H_OUT_RING);
+            *rslot = *ra;
+            HIPCHK(hipMemcpyAsync(d_ra, rslot, sizeof *ra, hipMemcpyHostToDevice, s));
+#define KS_ROLLOUT_CASE(A, B)                                                                                                                         \
+    if ((ra->h1 + 15) / 16 == A && (ra->h2 + 15) / 16 == B) {                                                                                                 \
+        HIPCHK(hipFuncSetAttribute((const void*)k_rollout<A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));                        \
+        hipLaunchKernelGGL((k_rollout<A, B>), dim3(n_wg), dim3(WG), step_lds, s, d_model, b, (const Buffers<T>*)d_b, N, cfg.frame_skip,              \
+                           cfg.solver_iterations, lpw, (int)cfg.pair_memory, (const ObsOut<T>*)d_out, (const ks_rollout_args*)d_ra, n_iter);                                \
+        HIPCHK(hipGetLastError());                                                                                                                    \
+        return KS_OK;                                                                                                                                 \
+    }
+            KS_ROLLOUT_CASE(16, 16)
+            KS_ROLLOUT_CASE(25, 19)
+            KS_ROLLOUT_CASE(8, 8)
+            KS_ROLLOUT_CASE(4, 4)
+#undef KS_ROLLOUT_CASE
+            error = "ks_rollout: hidden widths must be 256-256, 400-300, 128-128 or 64-64";
+            return KS_ERR_INVALID;
+        }
+    }
     int substep(const void* ctrl, hipStream_t s) override {
         if (!model_loaded) { error = "ks_substep before ks_load_model"; return KS_ERR_STATE; }
         hipLaunchKernelGGL((k_substep<T, USE_LDS>), dim3(n_wg), dim3(WG), step_lds, s, d_model, b, (const T*)ctrl, cfg.n_envs,
@@ -1309,6 +1566,10 @@ int ks_set_state(ks_ctx* ctx, const void* qpos, const void* qvel, const void* wa
 int ks_set_env_params(ks_ctx* ctx, const void* obj_mass, const void* obj_mu, void* stream) {
     if (!ctx) return KS_ERR_INVALID;
     return ctx->impl->set_env_params(obj_mass, obj_mu, (hipStream_t)stream);
+}
+int ks_rollout(ks_ctx* ctx, int32_t n_iter, const ks_rollout_args* args_host, void* stream) {
+    if (!ctx) return KS_ERR_INVALID;
+    return ctx->impl->rollout(n_iter, args_host, (hipStream_t)stream);
 }
 int ks_substep(ks_ctx* ctx, const void* ctrl, void* stream) {
     if (!ctx) return KS_ERR_INVALID;

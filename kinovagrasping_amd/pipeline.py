@@ -279,3 +279,143 @@ class GraphedTrainer:
             self.main.wait_stream(self.side)
         if self.distributed and self.native.exchange is not None:
             self.native.exchange.check()
+
+
+class AsyncTrainer(GraphedTrainer):
+    """Free-running rollout + learner (single GPU or one rank of several): the whole rollout side of an env-step - actor forward,
+    exploration noise, check_grasp / scripted lift, the 15 substeps, rays, observation, replay write - is ONE persistent launch
+    (ks_rollout) in which every stepping workgroup loops over its own 16 envs without waiting for any other workgroup, while the
+    learner's captured update graphs run beside it on a second stream.
+
+    Why: a lock-step launch lasts as long as its slowest wave (1.6 - 1.9 x the median wave) and the ~60 us of
+    launch gaps / actor / replay-write kernels between two launches idle every CU; free-running, a CU starts its next env-step
+    the moment it has finished the last.  What changes semantically: envs no longer advance in lock step (after K steps every env
+    has done K steps, but at different wall-clock times), the actor weights an env acts with are the newest PUBLISHED ones
+    (triple-buffered, published after every actor Adam step) instead of exactly one update old, and finished episodes reach the
+    replay ring in arrival order - training is no longer bit-reproducible run to run (GraphedTrainer remains the reproducible
+    path).  Per env the arithmetic and the noise stream are the lock-step ones (tests/test_gpu_async.py: identical trajectories
+    for fixed weights).  The reference's own loop acts with a policy that is a whole episode old (main_DDPGfD.py:466-486)."""
+
+    def __init__(self, sim, policy, replay, engine, batch_episodes=64, expert_replay=None, expert_prob=0.3):
+        import os
+        # the learner's LDS-free kernels must fit beside the persistent kernel's waves: 368 of the 512 registers per lane are taken
+        # for the whole launch, the 4-wave split forward / backward (160) does not fit, the one-wave variants (128) do
+        os.environ["KS_MLP_SPLIT"] = "0"
+        super().__init__(sim, policy, replay, engine, batch_episodes=batch_episodes, overlap=True, expert_replay=expert_replay, expert_prob=expert_prob)
+        from .sim import KsRolloutArgs
+        eng, dev = engine, self.dev
+        if not (eng.native and eng.device_noise and eng._fused_actor_layers() is not None and sim.cfg.auto_reset and sim.obs_env_major):
+            raise ValueError("AsyncTrainer needs the fused actor path (3-layer MLP at a supported width, in-kernel noise), auto_reset and env-major obs")
+        flat = policy._flat_params["actor"]
+        actor = policy.actor
+        off = lambda t: (t.data_ptr() - flat.data_ptr()) // 4
+        self.actor_flat = flat
+        stride = (flat.numel() + 3) // 4 * 4
+        self.pub = torch.zeros(3, stride, device=dev)
+        self.pub_ver = torch.zeros(1, dtype=torch.long, device=dev)
+        self.n_pub = 0
+        self.pub[0, :flat.numel()].copy_(flat)
+        replay.enable_async()
+        self.steps_total = torch.zeros(eng.n, dtype=torch.long, device=dev)
+        self.counters = torch.zeros(4, dtype=torch.long, device=dev)      # episodes finished, lifted, kept, dropped
+        P = lambda t: t.data_ptr()
+        a = KsRolloutArgs()
+        a.actor_pub, a.actor_ver, a.actor_stride = P(self.pub), P(self.pub_ver), stride
+        a.off_w1, a.off_b1, a.off_w2, a.off_b2, a.off_w3, a.off_b3 = (off(actor.l1.weight), off(actor.l1.bias), off(actor.l2.weight), off(actor.l2.bias),
+                                                                      off(actor.l3.weight), off(actor.l3.bias))
+        a.h1, a.h2 = actor.l1.weight.shape[0], actor.l2.weight.shape[0]
+        from .rollout import SKIP_NUM_TS
+        a.sigma, a.max_action, a.skip_steps, a.with_replay, a.seed = eng.sigma, eng.max_action, SKIP_NUM_TS, 1, eng.noise_seed
+        a.obs, a.prev_obs, a.has_prev, a.ready, a.lifting = P(eng.obs), P(eng.prev_obs), P(eng.has_prev), P(eng.ready), P(eng.lifting)
+        a.t, a.steps_total, a.action, a.action_t = P(eng.t), P(self.steps_total), P(eng.action), P(eng.action_t)
+        a.reward_out, a.done_out = P(eng.reward_out), P(eng.done_out)
+        a.sim_obs, a.sim_reward, a.sim_done, a.sim_info, a.sim_final_obs = P(sim.obs), P(sim.reward), P(sim.done), P(sim.info), P(sim.final_obs)
+        a.horizon, a.n_steps = replay.horizon, replay.n_steps
+        a.cur_state, a.cur_next, a.cur_action = P(replay.a_state), P(replay.a_next), P(replay.a_action)
+        a.cur_reward, a.cur_not_done, a.cur_len = P(replay.a_reward), P(replay.a_not_done), P(replay.a_len)
+        a.cur_sel, a.pub_len, a.counters = P(replay.a_sel), P(replay.pub_len), P(self.counters)
+        self.args = a
+        self.env_steps = 0
+
+    def publish(self):
+        """make the actor's current weights the newest published version: copy into the buffer two behind the one in use, then
+        advance the version counter (stream order: the copy is complete - and written back at its kernel's end - before the counter
+        moves; the rollout workgroups read the counter with an agent-scope load at the start of each of their env-steps)"""
+        self.n_pub += 1
+        self.pub[self.n_pub % 3, :self.actor_flat.numel()].copy_(self.actor_flat)
+        self.pub_ver.fill_(self.n_pub)
+
+    def capture(self, warmup_updates=2):
+        """captures the learner's update (head + body); the rollout is a single launch and needs no graph"""
+        nat, pol = self.native, self.policy
+        saved = {k: v.clone() for k, v in pol._flat_params.items()}
+        saved_opt = [(net, net.grad.clone(), net.exp_avg.clone(), net.exp_avg_sq.clone()) for net in (nat.actor, nat.critic)]
+        saved_it, saved_head, saved_total = nat.it.clone(), nat.it_head.clone(), pol.total_it
+        s = torch.cuda.Stream(self.dev)
+        s.wait_stream(self.main)
+        with torch.cuda.stream(s):
+            for _ in range(warmup_updates):
+                self.replay.commit_published()
+                self._learn_eager()
+        self.main.wait_stream(s)
+        torch.cuda.synchronize(self.dev)
+        for k, v in saved.items():
+            pol._flat_params[k].copy_(v)
+        for net, g, m, v in saved_opt:
+            net.grad.copy_(g); net.exp_avg.copy_(m); net.exp_avg_sq.copy_(v)
+        nat.it.copy_(saved_it); nat.it_head.copy_(saved_head)
+        pol.total_it = saved_total
+        mode = dict(capture_error_mode="thread_local")
+        self.g_commit = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_commit, **mode):
+            self.replay.commit_published()
+        self.g_head = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_head, pool=self.g_commit.pool(), **mode):
+            self._head()
+        phases = [self._phase1, self._phase2]
+        groups = [[p] for p in phases] if self.distributed else [phases]
+        pool = self.g_head.pool()
+        for grp in groups:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, **mode):
+                for p in grp:
+                    p()
+            pool = g.pool()
+            self.g_learn.append(g)
+        torch.cuda.synchronize(self.dev)
+
+    def run(self, n_steps: int, learn: bool = True):
+        """n_steps env-steps of EVERY env (one persistent launch on the main stream) and, beside it on the learner's stream, n_steps
+        updates: [episodes published so far -> ring, actor step + targets + sampling, publish the actor, body].  Returns after
+        ENQUEUEING both; synchronise (or call again) to wait.  The two streams only meet at the start of the next run()."""
+        main, side = self.main, self.side
+        side.wait_stream(main)
+        main.wait_stream(side)
+        self.sim.rollout(n_steps, self.args)
+        with torch.cuda.stream(side):
+            for _ in range(n_steps):
+                self.g_commit.replay()
+                if learn:
+                    self.g_head.replay()
+                    self.publish()
+                    self._body()
+        self.env_steps += n_steps
+
+    def step(self):
+        self.run(1)
+        return self.eng.reward_out, self.eng.done_out
+
+    def flush(self, finish_update=False):
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            self.g_commit.replay() if self.g_commit is not None else self.replay.commit_published()
+            if finish_update:
+                self.native.finish_pending()
+                self.publish()
+        self.main.wait_stream(self.side)
+        if self.distributed and self.native.exchange is not None:
+            self.native.exchange.check()
+
+    def counts(self):
+        c = self.counters.tolist()
+        return {"episodes_finished": c[0], "lifted": c[1], "episodes_kept": c[2], "episodes_dropped": c[3]}

@@ -235,6 +235,37 @@ class DeviceEpisodeReplay:
             self._count.copy_((self._count + 1).clamp(max=self.capacity))
         return info
 
+    def enable_async(self):
+        """Open-episode buffers of the free-running rollout kernel (ks_rollout): TWO per env, so that an env can start its next
+        episode while the learner's stream has not yet moved the finished one into the ring.  a_* [2, n, H, ...], a_len [2, n],
+        a_sel [n] (which one is open), pub_len [2, n] (> 0: a finished episode of that length awaits commit_published)."""
+        if hasattr(self, "pub_len"):
+            return
+        n, H, dev = self.n_envs, self.horizon, self.device
+        S, A = self.ep_state.shape[2], self.ep_action.shape[2]
+        z = lambda *sh, **k: torch.zeros(*sh, device=dev, **k)
+        self.a_state, self.a_next, self.a_action = z(2, n, H, S), z(2, n, H, S), z(2, n, H, A)
+        self.a_reward, self.a_not_done = z(2, n, H), z(2, n, H)
+        self.a_len, self.pub_len = z(2, n, dtype=torch.long), z(2, n, dtype=torch.long)
+        self.a_sel = z(n, dtype=torch.uint8)
+        self._keep2 = torch.zeros(2, n, dtype=torch.bool, device=dev)
+
+    def commit_published(self):
+        """Move every published episode (pub_len > 0) of both buffers into the ring, buffer 0 first, env order within a buffer,
+        and free the buffers (kr_rank_episodes / kr_commit_episodes / kr_advance_ring with the published lengths as cur_len).
+        Fixed-shape device ops: capturable; runs on the learner's stream ahead of the window sampling."""
+        L, P, st = self._lib, self._ptr, self._stream()
+        for b in (0, 1):
+            keep = self._keep2[b]
+            torch.gt(self.pub_len[b], 0, out=keep)
+            self._check(L.kr_rank_episodes(self.n_envs, P(keep), P(self._rank), P(self._total), st), "kr_rank_episodes")
+            self._check(L.kr_commit_episodes(self.n_envs, self.horizon, self.capacity, P(keep), P(self._rank), P(self._head), P(self.a_state[b]),
+                                             P(self.a_next[b]), P(self.a_action[b]), P(self.a_reward[b]), P(self.a_not_done[b]), P(self.pub_len[b]),
+                                             P(self.ep_state), P(self.ep_next), P(self.ep_action), P(self.ep_reward), P(self.ep_not_done),
+                                             P(self.ep_len), st), "kr_commit_episodes")
+            self._check(L.kr_advance_ring(self.n_envs, self.capacity, P(self._total), P(self._head), P(self._count), P(keep), P(self.pub_len[b]), st),
+                        "kr_advance_ring")
+
     def commit_native(self, keep, ended):
         """rank -> commit -> advance with the kr_* kernels; keep / ended: bool [n_envs]"""
         L, P, st = self._lib, self._ptr, self._stream()

@@ -32,8 +32,20 @@ class KrRing(C.Structure):
                 ("ep_next", C.c_void_p), ("ep_action", C.c_void_p), ("ep_reward", C.c_void_p), ("ep_not_done", C.c_void_p)]
 
 
+class KsRolloutArgs(C.Structure):
+    """ks_rollout_args (include/kinova_sim.h)"""
+    _fields_ = ([("actor_pub", C.c_void_p), ("actor_ver", C.c_void_p), ("actor_stride", C.c_int64)] +
+                [(k, C.c_int64) for k in ("off_w1", "off_b1", "off_w2", "off_b2", "off_w3", "off_b3")] +
+                [("h1", C.c_int32), ("h2", C.c_int32), ("sigma", C.c_float), ("max_action", C.c_float), ("skip_steps", C.c_int32),
+                 ("with_replay", C.c_int32), ("seed", C.c_uint64)] +
+                [(k, C.c_void_p) for k in ("obs", "prev_obs", "has_prev", "ready", "lifting", "t", "steps_total", "action", "action_t", "reward_out",
+                                           "done_out", "sim_obs", "sim_reward", "sim_done", "sim_info", "sim_final_obs")] +
+                [("horizon", C.c_int32), ("n_steps", C.c_int32)] +
+                [(k, C.c_void_p) for k in ("cur_state", "cur_next", "cur_action", "cur_reward", "cur_not_done", "cur_len", "cur_sel", "pub_len", "counters")])
+
+
 EXPORTS = ["ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_load_model", "ks_load_models", "ks_reset", "ks_reset_objects", "ks_step",
-           "ks_get_state", "ks_set_state", "ks_set_env_params", "ks_substep", "ks_obs_from_snapshot", "ks_kernel_time", "ks_version"]
+           "ks_get_state", "ks_set_state", "ks_set_env_params", "ks_substep", "ks_rollout", "ks_obs_from_snapshot", "ks_kernel_time", "ks_version"]
 # include/kinova_rollout.h
 ROLLOUT_EXPORTS = ["kr_select_action", "kr_store_transition", "kr_rank_episodes", "kr_commit_episodes", "kr_advance_ring",
                    "kr_sample_windows", "kr_sample_windows_draw", "kr_sample_windows_mixed", "kr_xchg_create", "kr_xchg_connect", "kr_xchg_allreduce_mean", "kr_xchg_status",
@@ -70,6 +82,7 @@ def load_library(path: Path | None = None):
     L.ks_set_state.argtypes = [vp, vp, vp, vp, vp]
     L.ks_set_env_params.argtypes = [vp, vp, vp, vp]
     L.ks_substep.argtypes = [vp, vp, vp]
+    L.ks_rollout.argtypes = [vp, C.c_int32, C.POINTER(KsRolloutArgs), vp]
     L.ks_obs_from_snapshot.argtypes = [vp] * 8
     L.ks_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     i32, f32 = C.c_int32, C.c_float
@@ -197,6 +210,10 @@ class KinovaSim:
                                      _ptr(self.final_obs), self._stream()))
         self._keep_a = action
         return self.obs, self.reward, self.done, self.info
+
+    def rollout(self, n_iter: int, args: "KsRolloutArgs"):
+        """n_iter free-running env-steps of every env in one launch (ks_rollout: in-kernel actor + step + replay write)"""
+        self._check(self.lib.ks_rollout(self.ctx, int(n_iter), C.byref(args), self._stream()))
 
     def substep(self, ctrl: torch.Tensor):
         ctrl = ctrl.to(self.device, self.dtype).contiguous()

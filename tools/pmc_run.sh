@@ -1,7 +1,13 @@
 #!/bin/bash
-# Dev tool: rocprofv3 PMC passes over the sim-only bench (separate passes; --kernel-trace only, as the pool requires)
+# Dev tool: rocprofv3 PMC passes over the bench (separate passes; --kernel-trace only, as the pool requires).
+# usage: bash tools/pmc_run.sh [sim|ddpg] [outdir]     - counters of the LAST 40 k_env_step launches of every pass are averaged
+#   sim : bench.py --mode sim (config 2 at 4096 envs)          ddpg: bench.py (config 3) after 600 untimed pre-training updates
+mode=${1:-sim}
+dir=${2:-gpurun_out/pmc_$mode}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ARGS="bench.py --mode sim --steps 6 --warmup 2 --no-cpu-baseline"
+rm -rf $dir; mkdir -p $dir
+if [ $mode = sim ]; then ARGS="bench.py --mode sim --steps 40 --warmup 4 --no-cpu-baseline"
+else ARGS="bench.py --steps 40 --warmup 5 --no-cpu-baseline --pretrain-updates 600 --steady-steps 0"; fi
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_FLAT" \
@@ -9,17 +15,22 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_DATA_FIFO_FULL" \
            "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_r2/p$i -- python3 $ARGS > gpurun_out/pmc_r2/p$i.log 2>&1
+  rocprofv3 --kernel-trace --kernel-include-regex k_env_step --pmc $set --output-format csv -d $dir/p$i -- python3 $ARGS > $dir/p$i.log 2>&1
 done
-python3 - <<'PY'
-import csv, glob, collections
+PMC_DIR=$dir python3 - <<'PY'
+import csv, glob, collections, os
+d = os.environ["PMC_DIR"]
 agg = collections.defaultdict(lambda: [0.0, 0])
-for f in glob.glob('gpurun_out/pmc_r2/p*/*/*counter_collection.csv'):
-    for r in csv.DictReader(open(f)):
-        if 'k_env_step' in r['Kernel_Name']:
+for f in glob.glob(d + '/p*/*/*counter_collection.csv'):
+    rows = [r for r in csv.DictReader(open(f)) if 'k_env_step' in r['Kernel_Name']]
+    ids = sorted({int(r['Dispatch_Id']) for r in rows})[-40:]
+    keep = set(ids)
+    for r in rows:
+        if int(r['Dispatch_Id']) in keep:
             a = agg[r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
-with open('gpurun_out/pmc_r2/summary.txt', 'w') as out:
+with open(d + '/summary.txt', 'w') as out:
     for k in sorted(agg):
         line = f"{k:28s} per-launch avg {agg[k][0]/agg[k][1]:16.1f}  launches {agg[k][1]}"
         print(line); out.write(line + "\n")
 PY
+rm -rf $dir/p*/

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """profiles/<tag>_pmc_k_env_step_summary.txt (tools/pmc_run.sh) -> profiles/<round>_pmc.json, the file bench.py reads for
-`roofline.traffic` and the issue-bound figures.  Usage: tools/pmc_to_json.py profiles/r02_a_pmc_k_env_step_summary.txt profiles/r02_pmc.json"""
+`roofline.traffic` and the issue-bound figures.  Usage: tools/pmc_to_json.py profiles/r03_a_pmc_sim_summary.txt profiles/r03_pmc_sim.json sim|ddpg"""
 import json
 import re
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else "sim"
 per = {}
 for line in open(src):
     m = re.match(r"(\S+)\s+per-launch avg\s+([0-9.eE+-]+)", line)
@@ -14,7 +15,9 @@ for line in open(src):
 kib = 1024.0
 out = {
     "kernel": "k_env_step",
-    "workload": "bench.py --mode sim, 4096 envs, CubeS (tools/pmc_run.sh: rocprofv3 --kernel-trace --pmc, one counter set per pass)",
+    "workload": ("bench.py --mode sim, 4096 envs, CubeS" if workload == "sim" else
+                 "bench.py (config 3: DDPG training, 4096 envs) after 600 pre-training updates") +
+                " (tools/pmc_run.sh: rocprofv3 --kernel-trace --pmc, one counter set per pass, last 40 launches of each pass)",
     "source": src,
     "per_launch": per,
     # FETCH_SIZE / WRITE_SIZE are reported in KiB.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half the
