@@ -443,8 +443,8 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/pmc_run.sh);
         # the committed summary applies to the 4096-env workload only
         traffic, traffic_note, issue = None, "no PMC summary for this workload", None
-        pmc = ROOT / "profiles" / "r02_pmc.json"
-        if pmc.exists() and n == 4096 and not mixed:
+        pmc = ROOT / "profiles" / ("r03_pmc_sim.json" if args.mode == "sim" else "r03_pmc_ddpg.json")     # counters of THIS workload
+        if pmc.exists() and n == 4096 and not mixed and not free_running:
             pj = json.loads(pmc.read_text())
             traffic, traffic_note = pj["hbm_bytes_per_launch"], pj["note"]
             pl = pj["per_launch"]
@@ -455,7 +455,7 @@ def main():
                          "valu_lane_efficiency": round(pj.get("valu_lane_efficiency", 0.0), 3),
                          "lds_bank_conflict_frac": round(pj.get("lds_bank_conflict_frac", 0.0), 3),
                          "l2_hit_rate": round(pj.get("l2_hit_rate", 0.0), 3),
-                         "source": "profiles/r02_pmc.json (rocprofv3 --pmc, sim-only workload)"}
+                         "source": f"profiles/{pmc.name} (rocprofv3 --pmc; {pj['workload']})"}
         out = {
             "metric": "env-steps/sec (whole node) at 4096 envs/GPU", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),

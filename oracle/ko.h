@@ -12,8 +12,11 @@
  *   - physics (mj_step, called at ENV:1535): lives in MuJoCo 1.50 / mujoco-py 1.50.1.0, a
  *     third-party binary that is NOT under /root/reference and not installable here.  The
  *     restatement follows MuJoCo's published algorithm (Computation chapter) on the compiled
- *     model data.  PARITY UNPINNED at the mj_step boundary: the reference holds no golden
- *     vectors, known-answer tests or fixtures for it.
+ *     model data.  The reference's TESTS hold no golden vectors at the mj_step boundary (SURVEY.md
+ *     sec. 4, 8c); its tree does hold three sets of recorded MuJoCo 1.50 output (finger joint
+ *     traces, ten demonstrations, success / failure maps): the physics is PINNED IN PART to those
+ *     (tests/test_mujoco_recorded.py) and UNPINNED for contact forces and
+ *     velocities, of which no recording exists.
  */
 #ifndef KO_H
 #define KO_H

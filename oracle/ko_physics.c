@@ -4,7 +4,11 @@
  * Reference call site: kinova_gripper_env.py:1535 (`self._sim.step()`), :703/:353 (`forward`).
  * The arithmetic itself is third-party (MuJoCo 1.50, not vendored, not installable here): this
  * file restates MuJoCo's published pipeline (documentation, "Computation" chapter; SURVEY.md
- * Appendix B) stage by stage.  PARITY UNPINNED against real MuJoCo.
+ * Appendix B) stage by stage.  PINNED IN PART against real MuJoCo 1.50 output recorded by the reference's authors and left in
+ * their tree (tests/golden/mujoco_recorded.npz, tests/test_mujoco_recorded.py): free-closing finger joint traces to 3e-5 rad
+ * (Old Code/Pose_file.csv: actuators, damping, armature, soft tendon equality, gravity, sensor lag), ten recorded demonstrations
+ * and the naive-controller success / failure maps (expert_plots/: outcome agreement outside one stated zone).  Contact forces
+ * and velocities of real MuJoCo are not available anywhere: for those, PARITY UNPINNED.
  *
  * Deliberately written in the plainest dense form (15x15 matrices, full Jacobians) so that it
  * is an independent check of the specialised HIP kernels.

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Dev tool: rocprofv3 PMC passes over the bench (separate passes; --kernel-trace only, as the pool requires).
 # usage: bash tools/pmc_run.sh [sim|ddpg] [outdir]     - counters of the LAST 40 k_env_step launches of every pass are averaged
-#   sim : bench.py --mode sim (config 2 at 4096 envs)          ddpg: bench.py (config 3) after 600 untimed pre-training updates
+#   sim : bench.py --mode sim (config 2 at 4096 envs)          ddpg: bench.py --eager (config 3, learner launched op by op) after 600 untimed pre-training updates
 mode=${1:-sim}
 dir=${2:-gpurun_out/pmc_$mode}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf $dir; mkdir -p $dir
 if [ $mode = sim ]; then ARGS="bench.py --mode sim --steps 40 --warmup 4 --no-cpu-baseline"
-else ARGS="bench.py --steps 40 --warmup 5 --no-cpu-baseline --pretrain-updates 600 --steady-steps 0"; fi
+else ARGS="bench.py --eager --steps 40 --warmup 5 --no-cpu-baseline --pretrain-updates 600 --steady-steps 0"; fi   # (--eager: counter collection + the kernel filter segfaults rocprofv3 when the learner runs from HIP graphs)
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_FLAT" \

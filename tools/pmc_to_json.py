@@ -16,7 +16,7 @@ kib = 1024.0
 out = {
     "kernel": "k_env_step",
     "workload": ("bench.py --mode sim, 4096 envs, CubeS" if workload == "sim" else
-                 "bench.py (config 3: DDPG training, 4096 envs) after 600 pre-training updates") +
+                 "bench.py --eager (config 3: DDPG training, 4096 envs, learner launched op by op - counter collection with the kernel filter segfaults when the learner runs from HIP graphs) after 600 pre-training updates") +
                 " (tools/pmc_run.sh: rocprofv3 --kernel-trace --pmc, one counter set per pass, last 40 launches of each pass)",
     "source": src,
     "per_launch": per,
