@@ -2,14 +2,14 @@
 """End-to-end DDPGfD training on the batched simulator (the counterpart of
 `python main_DDPGfD.py --mode train ...` in the reference, gym-kinova-gripper/main_DDPGfD.py:333-537):
 
-  1. expert data: the naive demonstrator (expert_data.py:596-607) on start positions sampled from the
+  1. expert data: a scripted demonstrator (expert_data.py:596-671, loop :746-804) on start positions sampled from the
      no_noise start table fills the expert replay;
   2. training: N envs roll out clip(pi(s) + N(0, 0.08), 0, 0.8) with the scripted lift after check_grasp,
      agent transitions go to the device replay, and every env-step one DDPGfD update mixes 70 % agent /
      30 % expert episodes (DDPGfD.py:232-254);
   3. periodic evaluation without exploration noise: lift success rate.
 
-    python examples/train_ddpgfd.py --envs 1024 --steps 600 --hidden 400 300
+    python examples/train_ddpgfd.py --envs 1024 --steps 600 --hidden 256 256 [--free-running]
 """
 import argparse
 import sys
@@ -40,50 +40,63 @@ def main():
     ap.add_argument("--envs", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--shape", default="CubeS")
-    ap.add_argument("--hidden", type=int, nargs=2, default=[400, 300])
+    ap.add_argument("--hidden", type=int, nargs=2, default=[256, 256])
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--expert-episodes", type=int, default=2048)
+    ap.add_argument("--controller", default="combined", choices=["naive", "position-dependent", "combined"])
+    ap.add_argument("--free-running", action="store_true", help="the persistent rollout kernel (ks_rollout) instead of one launch per env-step")
     args = ap.parse_args()
     torch.manual_seed(args.seed)
     rng = np.random.RandomState(args.seed)
     dev = torch.device("cuda", 0)
     n = args.envs
 
-    # 1. expert replay from the naive demonstrator
+    # 1. expert replay: the combined controller with the demonstration loop of expert_data.py:746-804
     expert = DeviceEpisodeReplay(n, capacity=args.expert_episodes, device=dev)
     sim = KinovaSim(n, args.shape, auto_reset=False, horizon=30)
     succ = []
     while expert.count < args.expert_episodes:
         q0, hq = start_states(n, args.shape, rng)
-        out = run_naive_episodes(sim, sim.reset(torch.as_tensor(q0), torch.as_tensor(hq)), expert)
+        out = run_controller_episodes(sim, sim.reset(torch.as_tensor(q0), torch.as_tensor(hq)), expert, mode=args.controller)
         succ.append(out["success"].float().mean().item())
-    print(f"expert replay: {expert.count} episodes, naive-controller lift success {np.mean(succ):.2f}")
+    print(f"expert replay: {expert.count} episodes, {args.controller}-controller lift success {np.mean(succ):.2f}")
     sim.close()
 
-    # 2. training
+    # 2. training on the product path: HIP-graph trainer, native MFMA learner, every batch 44 agent + 20 expert episodes sampled by
+    #    one launch inside the captured update (pipeline.GraphedTrainer; --free-running: the persistent rollout kernel, AsyncTrainer)
+    from kinovagrasping_amd.pipeline import AsyncTrainer, GraphedTrainer
     sim = KinovaSim(n, args.shape, auto_reset=True, horizon=30)
     q0, hq = start_states(n, args.shape, rng)
     policy = DDPGfD(82, 4, 0.8, 5, batch_size=64, hidden=tuple(args.hidden), device=dev)
     agent = DeviceEpisodeReplay(n, capacity=max(4 * n, 4096), device=dev)
     eng = RolloutEngine(sim, policy, agent)
     eng.start(sim.reset(torch.as_tensor(q0), torch.as_tensor(hq)))
+    Trainer = AsyncTrainer if args.free_running else GraphedTrainer
+    tr = Trainer(sim, policy, agent, eng, batch_episodes=64, expert_replay=expert, expert_prob=0.3)
+    tr.capture()
+    if args.free_running:
+        tr.run(36, learn=False)
+        tr.flush()
     lifted = episodes = 0
     t0 = time.perf_counter()
-    for it in range(args.steps):
-        reward, done = eng.step()
-        lifted += int(((reward > 0) & done).sum())
-        episodes += int(done.sum())
-        if agent.count >= 2:
-            ag = agent.sample_batch_nstep(int(64 * 0.7))
-            ex = expert.sample_batch_nstep(64 - int(64 * 0.7))
-            batch = [torch.cat((a, e), 0) for a, e in zip(ag, ex)]
-            losses = policy.train_on_batch(batch[0], batch[1], batch[2], batch[3], batch[5])
-        if (it + 1) % 60 == 0:
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            print(f"step {it + 1:5d}  episodes {episodes:7d}  lift rate {lifted / max(1, episodes):.3f}  "
-                  f"actor loss {losses[0].item():8.3f}  critic loss {losses[1].item():9.3f}  {n * (it + 1) / dt:9.0f} env-steps/s")
-            lifted = episodes = 0
+    for it in range(0, args.steps, 60):
+        if args.free_running:
+            for _ in range(6):
+                tr.run(10)
+            tr.flush()
+            c = tr.counts()
+            d_ep, d_lift = c["episodes_finished"] - episodes, c["lifted"] - lifted
+            episodes, lifted = c["episodes_finished"], c["lifted"]
+        else:
+            d_ep = d_lift = 0
+            for _ in range(60):
+                reward, done = tr.step()
+                d_lift += int(((reward > 0) & done).sum())
+                d_ep += int(done.sum())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ls = tr.native.losses.tolist()
+        print(f"step {it + 60:5d}  episodes {d_ep:7d}  lift rate {d_lift / max(1, d_ep):.3f}  critic loss {ls[0]:9.3f}  {n * (it + 60) / dt:9.0f} env-steps/s")
     sim.close()
 
 

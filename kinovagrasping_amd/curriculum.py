@@ -148,15 +148,23 @@ def run_stage(plan, policy, n_envs: int = 1024, rounds: int = 10, updates_per_ro
         return the_sim.reset(torch.as_tensor(q), torch.as_tensor(hq)), classes
 
     eng = RolloutEngine(sim, policy, replay, expl_noise=0.1)
+    # the updates run on the product learner (learner_native: fused MFMA forward / backward launches + kr_* glue), each batch =
+    # int(batch_size * (1 - expert_prob)) agent + the rest expert episodes sampled by ONE launch (kr_sample_windows_mixed,
+    # DDPGfD.train_batch's mix, DDPGfD.py:232-254); without expert data every episode comes from the agent ring
+    from .learner_native import NativeDDPGfDUpdate
+    native = NativeDDPGfDUpdate(policy)
+    mix = expert is not None and expert.count >= 2
     losses = []
     for r in range(rounds):
         obs0, _ = reset_all(sim, n_envs)
         eng.start(obs0)
         for t in range(30):
             eng.step()
-        if replay.count > 0:
+        if replay.count >= 2:
             for u in range(updates_per_round):
-                losses.append(policy.train_batch(30, expert, replay, prob=expert_prob if expert is not None else 0.0))
+                batch = replay.sample_mixed(expert, policy.batch_size, expert_prob) if mix else replay.sample_batch_nstep(policy.batch_size)
+                st, ac, ns, rw, nd, w = batch[:6]
+                losses.append(native.train_on_batch(st, ac, ns, rw, w))
     # final evaluation: one deterministic episode per env (eval_policy, main_DDPGfD.py:130-272)
     obs0, classes = reset_all(sim, n_envs)
     res = eval_policy(sim, policy, obs0, horizon=30, orientation=plan["requested_orientation"])

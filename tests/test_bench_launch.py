@@ -135,3 +135,18 @@ def test_eight_ranks_config5_dry_run_on_one_gpu():
     assert line["n_gpus"] == 8 and line["config"]["envs_per_gpu"] == 256 and "14 README shapes" in line["config"]["workload"]
     assert line["rccl"]["ranks"] == 8 and line["rccl"]["exchange"].startswith("peer-mapped memory"), line["rccl"]
     assert line["replica_weight_checksum_spread"] == 0.0 and line["replica_checks_during_run"] >= 2 and line["nonfinite_envs"] == 0
+
+
+@pytest.mark.gpu
+def test_free_running_rollout_bench_line():
+    """`bench.py --rollout free`: the persistent rollout kernel + learner graphs through the whole bench protocol (priming without
+    learning, pre-training, warm-up, K timed steps = K learner updates, steady window), no dropped episode, finite."""
+    r = run_bench(["--rollout", "free", "--chunk", "5", "--steps", "10", "--warmup", "5", "--envs-per-gpu", "512", "--no-cpu-baseline",
+                   "--pretrain-updates", "40", "--steady-steps", "30"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["launch"].startswith("free-running rollout kernel") and line["roofline"]["kernel"].startswith("k_rollout")
+    fr = line["config"]["free_running"]
+    assert fr["episodes_dropped"] == 0 and fr["episodes_finished"] >= 512 and fr["episodes_kept"] > 0
+    assert line["config"]["learner_updates_timed"] == 10 and line["nonfinite_envs"] == 0 and line["steps"] == 10
+    assert line["steady_state"]["learner_updates_timed"] == 30 and line["roofline"]["avg_launch_ms"] > 0

@@ -273,3 +273,33 @@ def test_heatmap_files_equal_the_reference(golden_dir, tmp_path):
     assert rec[-1] == {"tag": "Critic LNloss", "value": 0.5, "step": 400} and len(rec) == 8
     metrics.save_boxplot_rewards(tmp_path / "box", 400, [[0.0, 0.0]], [[0.0, 0.0]], [[50.0, 0.0]], [[50.0, 0.0]])
     assert np.load(tmp_path / "box" / "lift_reward_400.npy").tolist() == [[50.0, 0.0]]
+
+
+def test_expert_mix_sampler_torch_path_splits_like_the_reference():
+    """DeviceEpisodeReplay.sample_mixed on CPU tensors (the torch arithmetic that checks kr_sample_windows_mixed on the GPU): with
+    batch_size 64 and prob 0.3 the reference takes agent_batch_size = int(64 * 0.7) = 44 episodes from the agent buffer and 20 from
+    the expert buffer, concatenated agent first (DDPGfD.py:232-254); each part follows sample_batch_nstep's rule on its own ring."""
+    agent = DeviceEpisodeReplay(n_envs=1, capacity=40, horizon=30, device="cpu")
+    expert = DeviceEpisodeReplay(n_envs=1, capacity=16, horizon=30, device="cpu")
+    for rep, k, off in ((agent, 23, 0.0), (expert, 9, 100.0)):
+        for epi in range(k):
+            L = 8 + (3 * epi) % 22
+            for t in range(L):
+                st = torch.full((1, 82), off + epi + t / 100.0)
+                rep.add(st, torch.zeros(1, 4), st, torch.zeros(1), torch.tensor([t == L - 1]))
+            rep.end_episodes(torch.tensor([True]))
+    g = torch.Generator().manual_seed(3)
+    u = torch.rand(64 * 26, generator=g)
+    out = agent.sample_mixed(expert, 64, 0.3, uniforms=u)
+    st, w = out[0], out[5]
+    assert st.shape == (64 * 25, 5, 82) and int(64 * (1 - 0.3)) == 44
+    src_expert = (st[:, 0, 0] >= 100.0).view(64, 25)
+    live = (w > 0).view(64, 25)
+    assert not (src_expert[:44] & live[:44]).any() and (src_expert[44:] | ~live[44:]).all() and live[:44].any() and live[44:].any()
+    # the parts are the single-ring samplers fed their slices of the uniforms
+    a = agent.sample_batch_nstep(44, uniforms=torch.cat([u[:44], u[64:64 + 44 * 25]]))
+    e = expert.sample_batch_nstep(20, uniforms=torch.cat([u[44:64], u[64 + 44 * 25:]]))
+    for k in range(6):
+        assert torch.equal(out[k], torch.cat([a[k], e[k]], 0))
+    # the newest episode of either ring is never sampled (utils.py:259)
+    assert not (st[live.view(-1)][:, 0, 0].floor() == 22.0).any() and not (st[live.view(-1)][:, 0, 0].floor() == 108.0).any()
