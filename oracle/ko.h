@@ -104,6 +104,8 @@ typedef struct {
      * newton_last_step = that last relative step - what the solver-cap study (tests/studies/solver_cap.py) reads. */
     double solver_tolerance, newton_last_step;
     int newton_converged;
+    int narrow_phase; /* 0 (default, = the product kernels): GJK closest features in the margin zone, MPR on overlap; 1 (study only):
+                       * MPR on margin-inflated hulls for both, MuJoCo 1.50's scheme */
 } ko_sim;
 
 /* ---- model ---- */

@@ -767,6 +767,15 @@ static void collide_hull_hull(ko_sim *s, int g1, int g2, const double *pair) {
     sub3(t, s->geom_xpos[g1], s->geom_xpos[g2]);
     double bound = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
     if (dot3(t, t) > bound * bound) return;
+    if (s->narrow_phase == 1) {
+        /* study mode (tests/studies/narrow_phase.py): MuJoCo 1.50's own scheme - libccd MPR on hulls inflated by margin / 2 each, in
+         * the margin zone and in overlap alike; distance = margin - (penetration of the inflated hulls).  NOT what the product does
+         * (DESIGN.md section 2): kept to quantify that deviation. */
+        mpr_ctx ci = {s, g1, g2, 0.5 * margin};
+        double depth_i, dir_i[3], pos_i[3];
+        if (mpr_penetration(&ci, &depth_i, dir_i, pos_i) == 0) add_contact(s, g1, g2, pair, margin - depth_i, pos_i, dir_i);
+        return;
+    }
     mpr_ctx c = {s, g1, g2, 0.0};
     double depth, dist, dir[3], pos[3];
     int r = gjk_distance(&c, margin, &dist, dir, pos);

@@ -38,7 +38,7 @@ class Sim(C.Structure):
         ("qacc_smooth", d * NV), ("qacc", d * NV),
         ("mpr_calls", C.c_int), ("mpr_support_calls", C.c_int), ("newton_last_grad", d), ("newton_iters_used", C.c_int), ("rays_enabled", C.c_int),
         ("obj_mass", d), ("obj_mu", d),
-        ("solver_tolerance", d), ("newton_last_step", d), ("newton_converged", C.c_int),
+        ("solver_tolerance", d), ("newton_last_step", d), ("newton_converged", C.c_int), ("narrow_phase", C.c_int),
     ]
 
 

@@ -14,11 +14,12 @@ from oracle import ko_py as ko
 
 
 class OracleVecSim:
-    def __init__(self, n_envs: int, model: str = "CubeS", solver_iterations: int = SOLVER_ITERATIONS, horizon: int = 30, rays: bool = True):
+    def __init__(self, n_envs: int, model: str = "CubeS", solver_iterations: int = SOLVER_ITERATIONS, horizon: int = 30, rays: bool = True,
+                 narrow_phase: int = 0):
         self.n_envs, self.device = n_envs, torch.device("cpu")
         self.cfg = SimpleNamespace(auto_reset=0, horizon=horizon)
         self.model = ko.OracleModel(scenarios.model_blob(model))
-        self.iters, self.rays = solver_iterations, rays
+        self.iters, self.rays, self.narrow_phase = solver_iterations, rays, narrow_phase
         self.sims = []
         self.final_obs = torch.zeros(n_envs, 82, dtype=torch.float64)
         self.t = 0
@@ -28,6 +29,7 @@ class OracleVecSim:
         self.sims = [ko.OracleSim(self.model, h[:, i].copy(), solver_iterations=self.iters) for i in range(self.n_envs)]
         for s in self.sims:
             s.s.rays_enabled = int(self.rays)
+            s.s.narrow_phase = self.narrow_phase
         self.t = 0
         return torch.from_numpy(np.stack([s.env_reset(q[:, i].copy()) for i, s in enumerate(self.sims)]))
 

@@ -122,6 +122,17 @@ def test_oracle_replays_the_recorded_demonstrations(rec):
     _check_demos(succ, steps, rec)
 
 
+def test_recorded_demonstrations_under_mujocos_own_narrow_phase_scheme(rec):
+    """The oracle's study mode narrow_phase = 1 (libccd-style MPR on hulls inflated by margin / 2 in the margin zone AND on overlap:
+    MuJoCo 1.50's scheme; the product uses closest-feature GJK in the margin zone) replays the recorded demonstrations with the same
+    outcomes as the product scheme - the deviation is quantified in profiles/r03_narrow_phase.txt and does not change behaviour."""
+    sim = OracleVecSim(10, "CubeS", solver_iterations=100, rays=False, narrow_phase=1)
+    succ, steps = _demo_episodes(sim, rec)
+    _check_demos(succ, steps, rec)
+    ref_s, ref_t = rec["demo_success"], rec["demo_steps"]
+    assert (np.abs(steps - ref_t)[ref_s == 1] <= 1).sum() >= 6
+
+
 # ------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", [64, 32])
