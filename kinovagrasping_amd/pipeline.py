@@ -297,10 +297,6 @@ class AsyncTrainer(GraphedTrainer):
     for fixed weights).  The reference's own loop acts with a policy that is a whole episode old (main_DDPGfD.py:466-486)."""
 
     def __init__(self, sim, policy, replay, engine, batch_episodes=64, expert_replay=None, expert_prob=0.3):
-        import os
-        # the learner's LDS-free kernels must fit beside the persistent kernel's waves: 368 of the 512 registers per lane are taken
-        # for the whole launch, the 4-wave split forward / backward (160) does not fit, the one-wave variants (128) do
-        os.environ["KS_MLP_SPLIT"] = "0"
         super().__init__(sim, policy, replay, engine, batch_episodes=batch_episodes, overlap=True, expert_replay=expert_replay, expert_prob=expert_prob)
         from .sim import KsRolloutArgs
         eng, dev = engine, self.dev
@@ -347,6 +343,21 @@ class AsyncTrainer(GraphedTrainer):
 
     def capture(self, warmup_updates=2):
         """captures the learner's update (head + body); the rollout is a single launch and needs no graph"""
+        import os
+        # the learner's LDS-free kernels must fit beside the persistent kernel's waves: 368 of the 512 registers per lane are taken
+        # for the whole launch, the 4-wave split forward / backward (160) does not fit, the one-wave variants (128) do - the choice
+        # (mlp._split_waves reads KS_MLP_SPLIT at every call) is baked into the captured graphs
+        before = os.environ.get("KS_MLP_SPLIT")
+        os.environ["KS_MLP_SPLIT"] = "0"
+        try:
+            self._capture(warmup_updates)
+        finally:
+            if before is None:
+                os.environ.pop("KS_MLP_SPLIT", None)
+            else:
+                os.environ["KS_MLP_SPLIT"] = before
+
+    def _capture(self, warmup_updates):
         nat, pol = self.native, self.policy
         saved = {k: v.clone() for k, v in pol._flat_params.items()}
         saved_opt = [(net, net.grad.clone(), net.exp_avg.clone(), net.exp_avg_sq.clone()) for net in (nat.actor, nat.critic)]
