@@ -545,18 +545,25 @@ __device__ __noinline__ void rollout_policy(const ks_rollout_args* __restrict__ 
     kmlp::f32x4(*H2)[kmlp::ROWS] = H1 + NT1 * 4;
     kmlp::f32x4(*Pp)[kmlp::ROWS] = H2 + NT2 * 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    long long seen = -1;
+    // one word pair behind the scratch: the version this workgroup uses, and whether it went stale - decided by ONE thread and
+    // read by all after a barrier, so that the four waves can neither mix weight buffers nor disagree on repeating the forward
+    long long* vbox = (long long*)(Pp + kmlp::NW);          // (not volatile: that costs 28 registers here; the barriers order the accesses)
     for (;;) {
-        const long long ver = (long long)__hip_atomic_load(ra.actor_ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ver != seen) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); seen = ver; }      // the newest complete weight buffer
+        if (threadIdx.x == 0) vbox[0] = (long long)__hip_atomic_load(ra.actor_ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const long long ver = vbox[0];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                      // the newest complete weight buffer, as written
         const float* pw = ra.actor_pub + (ver % 3) * ra.actor_stride;
         kmlp::f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         const bool mine = kmlp::mlp3_rows16<NT1, NT2, true>(wave, lane, (long)row_env, S, 0, ra.h1, ra.h2, A, ra.obs, S, nullptr, 0, pw + ra.off_w1,
                                                             pw + ra.off_b1, pw + ra.off_w2, pw + ra.off_b2, pw + ra.off_w3, nullptr, nullptr, H1, H2, Pp,
                                                             z4);
-        // (a buffer is rewritten when the counter has advanced by two more: then the weights just read may be torn - repeat)
-        const long long now = (long long)__hip_atomic_load(ra.actor_ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool stale = __builtin_amdgcn_readfirstlane((int)(now - ver >= 2)) != 0;
+        // buffer ver % 3 is rewritten by publish ver + 3, which starts once ver + 2 is complete: if the counter has advanced by two
+        // while this forward ran, the weights just read may be torn - repeat with the newest ones (two update periods, > 1 ms,
+        // against a 25 us forward: never seen; the check makes it a protocol instead of a timing assumption)
+        if (threadIdx.x == 0) vbox[1] = (long long)__hip_atomic_load(ra.actor_ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ver;
+        __syncthreads();
+        const bool stale = vbox[1] >= 2;
         if (!stale) {
             if (mine) {
                 const float z[4] = {z4.x, z4.y, z4.z, z4.w};
@@ -1389,7 +1396,7 @@ template <typename T> struct Ctx : CtxBase {
             if (!obs_in_step || !cfg.obs_env_major || !cfg.auto_reset) { error = "ks_rollout needs the in-kernel observation path, env-major observations and auto_reset"; return KS_ERR_STATE; }
             if ((ra->off_w2 | ra->off_w3 | ra->actor_stride) & 3) { error = "ks_rollout: weight offsets must be multiples of 4 floats"; return KS_ERR_INVALID; }
             if ((ra->h1 | ra->h2) & 3) { error = "ks_rollout: hidden widths must be multiples of 4"; return KS_ERR_INVALID; }
-            if ((size_t)(((ra->h1 + 15) / 16 + (ra->h2 + 15) / 16) * 4 + 4) * 16 * 16 > (size_t)SCR_TOTAL * lpw * sizeof(T)) { error = "ks_rollout: no LDS for the policy"; return KS_ERR_STATE; }
+            if ((size_t)(((ra->h1 + 15) / 16 + (ra->h2 + 15) / 16) * 4 + 4) * 16 * 16 + 16 > (size_t)SCR_TOTAL * lpw * sizeof(T)) { error = "ks_rollout: no LDS for the policy"; return KS_ERR_STATE; }
             const int N = cfg.n_envs;
             const ObsOut<T> out{(T*)ra->sim_obs, (T*)ra->sim_reward, ra->sim_done, (T*)ra->sim_info, (T*)ra->sim_final_obs, cfg.horizon, cfg.auto_reset, cfg.obs_env_major};
             ObsOut<T>* slot = h_out + (h_out_next++ % H_OUT_RING);

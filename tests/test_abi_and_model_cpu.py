@@ -183,6 +183,22 @@ def test_stepping_kernel_leaves_registers_for_the_learner(tmp_path):
     assert up8(v + a) + widest <= 512, (v, a, widest, learner)
 
 
+def test_free_running_rollout_kernel_leaves_registers_for_the_learners_one_wave_kernels(tmp_path):
+    """k_rollout (ks_rollout) is resident for a whole K-step launch: the learner can only run beside it if one of its waves fits
+    on a SIMD next to one of the rollout's.  pipeline.AsyncTrainer captures the learner with the ONE-WAVE forward / backward /
+    weight-gradient kernels (KS_MLP_SPLIT=0) for that reason; the 4-wave split variants (160 registers) do not fit.  The
+    allocator is fragile here (a `volatile` on two LDS words cost 28 registers): the footprint is a contract."""
+    up8 = lambda x: (x + 7) // 8 * 8
+    roll = {k: v for k, v in _register_footprints("ks_api.hip", tmp_path).items() if "k_rolloutILi16ELi16" in k}
+    assert len(roll) == 1, roll
+    (v, a), = roll.values()
+    one_wave = {k: r for k, r in _register_footprints("ks_mlp.hip", tmp_path).items()
+                if ("k_mlp3_waveILi16ELi16" in k or "k_mlp3_bwd_waveILi16ELi16" in k or "k_wgrad_wave" in k)}
+    assert len(one_wave) >= 3, one_wave
+    widest = max(up8(lv + la) for lv, la in one_wave.values())
+    assert up8(v) + up8(a) + widest <= 512, (v, a, widest)
+
+
 def test_orientation_noise_is_zero_mean_truncated_and_seeded():
     """reset(with_noise=True) (SURVEY note N5's extension): class Euler constants + zero-mean N(0, 0.087), then the reference's
     5-character truncation (ENV:870-874); without an rng exactly the class quaternion."""
