@@ -4,7 +4,7 @@ oracle: max |qacc - qacc_converged| at states of a CubeS grasp run.  Output: pro
 import sys
 from pathlib import Path
 import numpy as np
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 from oracle import ko_py as ko
 from kinovagrasping_amd import scenarios

@@ -1,13 +1,13 @@
 """Per-env drift of the fp32 kernel from the fp64 oracle after 6 env steps of a closing grasp, for one shape
 (the measurement behind tests/test_gpu_parity.py::test_all_fourteen_shapes_track_the_oracle).
-usage: python tools/shape_drift.py Vase1B [fp64]"""
+usage: python tests/studies/shape_drift.py Vase1B [fp64]"""
 import sys
 from pathlib import Path
 
 import numpy as np
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 from kinovagrasping_amd import scenarios, sim as ks   # noqa: E402
 from oracle import ko_py as ko                        # noqa: E402
 

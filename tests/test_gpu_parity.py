@@ -594,7 +594,7 @@ def test_reference_trained_policy_grasps_in_this_simulator():
     """End-to-end behavioural cross-check: a 400-300 actor the reference authors trained on real
     MuJoCo (policies/rl_exp_pretrain_no_grasp_2_7_2021/pre_DDPGfD_kinovaGrip_02_05_21_2324_actor; weights committed as
     tests/golden/ref_policy_cubes_actor.npz) evaluated with evaluate.eval_policy on 512 CubeS starts of the reference's
-    no-noise table.  tools/eval_reference_policies.py ran all thirteen 82-d checkpoints of the reference through the CPU
+    no-noise table.  tests/studies/eval_reference_policies.py ran all thirteen 82-d checkpoints of the reference through the CPU
     oracle: they are pre-training snapshots of very uneven quality (0 - 0.88 success); the two best reach 0.88 here."""
     from pathlib import Path
     from kinovagrasping_amd.ddpgfd import DDPGfD
