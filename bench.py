@@ -271,8 +271,12 @@ def main():
             eng.start(obs0)
             free_running = args.rollout == "free" and world == 1 and not args.serial_learner
             if free_running:
-                trainer = AsyncTrainer(sim, policy, replay, eng, batch_episodes=64, expert_replay=expert, expert_prob=args.expert_prob)
-            else:
+                try:
+                    trainer = AsyncTrainer(sim, policy, replay, eng, batch_episodes=64, expert_replay=expert, expert_prob=args.expert_prob)
+                except ValueError as e:                       # e.g. widths whose learner needs LDS: the lock-step trainer handles those
+                    print(f"bench.py: --rollout free not available ({e}); using the lock-step trainer", file=sys.stderr)
+                    free_running = False
+            if not free_running:
                 trainer = GraphedTrainer(sim, policy, replay, eng, batch_episodes=64, overlap=not args.serial_learner, expert_replay=expert,
                                          expert_prob=args.expert_prob)
             trainer.capture()

@@ -300,6 +300,9 @@ class AsyncTrainer(GraphedTrainer):
         super().__init__(sim, policy, replay, engine, batch_episodes=batch_episodes, overlap=True, expert_replay=expert_replay, expert_prob=expert_prob)
         from .sim import KsRolloutArgs
         eng, dev = engine, self.dev
+        if not self.native.lds_free:
+            raise ValueError("AsyncTrainer needs the LDS-free learner kernels (hidden widths 256-256 / 128-128 / 64-64): the persistent rollout kernel "
+                             "holds every CU's LDS for the whole launch, a learner built on library GEMMs could only run behind it")
         if not (eng.native and eng.device_noise and eng._fused_actor_layers() is not None and sim.cfg.auto_reset and sim.obs_env_major):
             raise ValueError("AsyncTrainer needs the fused actor path (3-layer MLP at a supported width, in-kernel noise), auto_reset and env-major obs")
         flat = policy._flat_params["actor"]
