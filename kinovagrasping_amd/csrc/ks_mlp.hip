@@ -30,6 +30,12 @@ namespace {
 
 using namespace kmlp;
 
+// occupancy target of the 2- / 4-wave split learner kernels: 3 waves per SIMD = up to 168 registers (156 used, no spills); the
+// experiment switch 4 caps them at 128 (140 B of scratch per lane) so that they fit beside k_rollout's 368
+#ifndef KS_SPLIT_WAVES_PER_EU
+#define KS_SPLIT_WAVES_PER_EU 3
+#endif
+
 // Epilogue of the fused actor + action-selection launch (kr_actor_select): everything k_select_action takes, plus the
 // noise source (a tensor of N(0,1) draws, or the in-kernel counter-based generator keyed by (seed, rng_state[0], env))
 struct SelectArgs {
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 // sums meet in scratch (summed in wave order: deterministic).  Per output element the layer-1 / layer-2 fma chains are those
 // of k_mlp3_wave; only layer 3's sum is associated differently.
 template <int NT1, int NT2, int NWS>
-__global__ __launch_bounds__(64 * NWS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_mlp3_split(
+__global__ __launch_bounds__(64 * NWS) __attribute__((amdgpu_waves_per_eu(KS_SPLIT_WAVES_PER_EU, KS_SPLIT_WAVES_PER_EU))) void k_mlp3_split(
     int n, int in_a, int in_b, int h1, int h2, int out_dim, const float* __restrict__ xa, int lda, const float* __restrict__ xb, int ldb,
     const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
     const float* __restrict__ W3, const float* __restrict__ b3, int act, float scale, float* __restrict__ out, float* __restrict__ h1buf,
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 // ... and with the tiles of dz1 split over NWS waves of a workgroup (as k_mlp3_split): every wave computes dz2 itself (one MFMA per
 // tile), wave w the dz1 tiles t = w (mod NWS); the partial sums of dx meet in scratch, summed in wave order.
 template <int NT1, int NT2, int NWS>
-__global__ __launch_bounds__(64 * NWS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_mlp3_bwd_split(
+__global__ __launch_bounds__(64 * NWS) __attribute__((amdgpu_waves_per_eu(KS_SPLIT_WAVES_PER_EU, KS_SPLIT_WAVES_PER_EU))) void k_mlp3_bwd_split(
     int n, int in_dim, int h1, int h2, int out_dim, const float* __restrict__ dz3, const float* __restrict__ W3, const float* __restrict__ h2a,
     const float* __restrict__ W2, const float* __restrict__ h1a, float* __restrict__ dz2_out, float* __restrict__ dz1_out,
     const float* __restrict__ W1, int col0, int ncol, const float* __restrict__ act_out, float scale, float* __restrict__ dx_out,

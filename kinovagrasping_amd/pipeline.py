@@ -351,7 +351,7 @@ class AsyncTrainer(GraphedTrainer):
         # for the whole launch, the 4-wave split forward / backward (160) does not fit, the one-wave variants (128) do - the choice
         # (mlp._split_waves reads KS_MLP_SPLIT at every call) is baked into the captured graphs
         before = os.environ.get("KS_MLP_SPLIT")
-        os.environ["KS_MLP_SPLIT"] = "0"
+        os.environ["KS_MLP_SPLIT"] = os.environ.get("KS_ASYNC_MLP_SPLIT", "0")      # (experiment: a build whose split kernels fit in 128 registers)
         try:
             self._capture(warmup_updates)
         finally:
