@@ -656,6 +656,13 @@ __device__ __forceinline__ void rollout_iter(const Model<float>& m, const Hulls<
     const int env = e < epw ? b.slot_env[blockIdx.x * epw + e] : -1;
     const bool active = !(team.sub >= SUBS || env < 0);
     KS_LDS unsigned* w = (KS_LDS unsigned*)blocks;
+#ifdef KS_ROLLOUT_STAMP
+    // diagnostic build: wall-clock ticks (100 MHz) of the four phases, summed over workgroups and env-steps in counters[4..7]
+    long long tk = wall_clock64();
+#define KS_RS(i) { const long long t1_ = wall_clock64(); if (threadIdx.x == 0) atomicAdd((unsigned long long*)&rap->counters[4 + i], (unsigned long long)(t1_ - tk)); tk = t1_; }
+#else
+#define KS_RS(i)
+#endif
     {
         const int nn = threadIdx.x & 15;
         const int row_env = nn < epw ? b.slot_env[blockIdx.x * epw + nn] : -1;   // the policy row of this lane (the same in all four waves)
@@ -663,6 +670,7 @@ __device__ __forceinline__ void rollout_iter(const Model<float>& m, const Hulls<
     }
     __threadfence_block();
     __syncthreads();
+    KS_RS(0)
     // ---- the env-step (k_env_step's LDS path)
     if (active) {
         T hq[4], act[4];
@@ -699,15 +707,19 @@ __device__ __forceinline__ void rollout_iter(const Model<float>& m, const Hulls<
     }
     __threadfence_block();
     __syncthreads();
+    KS_RS(1)
     wg_rays(m, b, N, blockIdx.x * epw, epw, w);
     __threadfence_block();
     __syncthreads();
+    KS_RS(2)
     wg_obs(m, b, N, blockIdx.x * epw, epw, w, *out);
     __threadfence_block();
     __syncthreads();
     if (active) rollout_store(rap, N, env, team.sub);
     __threadfence_block();
     __syncthreads();
+    KS_RS(3)
+#undef KS_RS
 }
 
 template <int NT1, int NT2>

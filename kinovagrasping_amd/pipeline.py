@@ -316,7 +316,8 @@ class AsyncTrainer(GraphedTrainer):
         self.pub[0, :flat.numel()].copy_(flat)
         replay.enable_async()
         self.steps_total = torch.zeros(eng.n, dtype=torch.long, device=dev)
-        self.counters = torch.zeros(4, dtype=torch.long, device=dev)      # episodes finished, lifted, kept, dropped
+        self.counters = torch.zeros(8, dtype=torch.long, device=dev)      # episodes finished, lifted, kept, dropped (+ 4 phase timers of the
+                                                                          # -DKS_ROLLOUT_STAMP diagnostic build)
         P = lambda t: t.data_ptr()
         a = KsRolloutArgs()
         a.actor_pub, a.actor_ver, a.actor_stride = P(self.pub), P(self.pub_ver), stride
@@ -431,5 +432,5 @@ class AsyncTrainer(GraphedTrainer):
             self.native.exchange.check()
 
     def counts(self):
-        c = self.counters.tolist()
+        c = self.counters[:4].tolist()
         return {"episodes_finished": c[0], "lifted": c[1], "episodes_kept": c[2], "episodes_dropped": c[3]}

@@ -52,5 +52,9 @@ def learner_only():
 
 
 learn = timed(learner_only, 30)
+ph = tr.counters[4:].tolist()
+if sum(ph):
+    tot = tr.env_steps * (n // 16)
+    print("k_rollout phases, mean per workgroup and env-step [us]: policy %.1f  15 substeps %.1f  rays %.1f  observation + replay write %.1f" % tuple(p / tot / 100.0 for p in ph))
 print(f"chunk {chunk}: per env-step  rollout + learner {both:.4f} ms   rollout alone {roll:.4f} ms   learner alone {learn:.4f} ms", flush=True)
 sim.close()
