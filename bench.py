@@ -175,12 +175,13 @@ def main():
                          "contact-rich grasps and de-synchronised episode clocks instead of the cheap first episodes of a random policy (0 = time the "
                          "first episodes, as rounds 1-2 did)")
     ap.add_argument("--steady-updates", type=int, default=0, help="further learner updates before the steady_state window (whole episodes)")
-    ap.add_argument("--rollout", choices=["lockstep", "free"], default="lockstep",
-                    help="ddpg mode: 'lockstep' (default) = one stepping launch per env-step for all envs (pipeline.GraphedTrainer; bit-reproducible "
-                         "training, the path every round's driver run has used); 'free' = the free-running rollout kernel (ks_rollout / "
-                         "pipeline.AsyncTrainer, round 3): every stepping workgroup loops over its 16 envs - in-kernel actor, 15 substeps, rays, "
-                         "observation, replay write - without waiting for other workgroups, learner beside it: +6-14 %% at 4096 envs (config 3), slower "
-                         "when the envs need more workgroups than the GPU has CUs (config 5).  One GPU, HIP-graph learner only.")
+    ap.add_argument("--rollout", choices=["auto", "lockstep", "free"], default="auto",
+                    help="ddpg mode: 'free' = the free-running rollout kernel (ks_rollout / pipeline.AsyncTrainer, round 3): every stepping workgroup "
+                         "loops over its 16 envs - in-kernel actor, 15 substeps, rays, observation, replay write - without waiting for other workgroups, "
+                         "learner beside it (+6-18 %% at 4096 envs; training is not bit-reproducible run to run); 'lockstep' = one stepping launch per "
+                         "env-step for all envs (pipeline.GraphedTrainer, rounds 1-2; bit-reproducible).  'auto' (default): free where it pays - the "
+                         "learner is LDS-free (256-256) and the envs fit the GPU's CUs in one round of workgroups (<= 16 envs x CUs: config 3 / 4) - "
+                         "else lockstep (config 5's 8192 envs, 400-300, --eager, --serial-learner).  The JSON line says which (`config.launch`).")
     ap.add_argument("--chunk", type=int, default=10, help="free-running rollout: env-steps per launch (learner and rollout streams meet between launches)")
     ap.add_argument("--expert-prob", type=float, default=0.0,
                     help="ddpg mode: DDPGfD's demonstration mix (DDPGfD.py:232-254) - an expert ring is filled with one scripted 'combined'-controller "
@@ -269,7 +270,9 @@ def main():
             from kinovagrasping_amd.pipeline import AsyncTrainer, GraphedTrainer
             eng = RolloutEngine(sim, policy, replay, expl_noise=0.1)
             eng.start(obs0)
-            free_running = args.rollout == "free" and world == 1 and not args.serial_learner
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            fits = (n + 15) // 16 + (len(scenarios.SHAPES) - 1 if mixed else 0) <= cus           # one round of stepping workgroups
+            free_running = not args.serial_learner and (args.rollout == "free" or (args.rollout == "auto" and fits and tuple(args.hidden) in ((256, 256), (128, 128), (64, 64))))
             if free_running:
                 try:
                     trainer = AsyncTrainer(sim, policy, replay, eng, batch_episodes=64, expert_replay=expert, expert_prob=args.expert_prob)
@@ -447,8 +450,8 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/pmc_run.sh);
         # the committed summary applies to the 4096-env workload only
         traffic, traffic_note, issue = None, "no PMC summary for this workload", None
-        pmc = ROOT / "profiles" / ("r03_pmc_sim.json" if args.mode == "sim" else "r03_pmc_ddpg.json")     # counters of THIS workload
-        if pmc.exists() and n == 4096 and not mixed and not free_running:
+        pmc = ROOT / "profiles" / ("r03_pmc_sim.json" if args.mode == "sim" else "r03_pmc_free.json" if free_running else "r03_pmc_ddpg.json")     # counters of THIS workload and THIS kernel (k_rollout's are per env-step)
+        if pmc.exists() and n == 4096 and not mixed:
             pj = json.loads(pmc.read_text())
             traffic, traffic_note = pj["hbm_bytes_per_launch"], pj["note"]
             pl = pj["per_launch"]

@@ -150,3 +150,19 @@ def test_free_running_rollout_bench_line():
     assert fr["episodes_dropped"] == 0 and fr["episodes_finished"] >= 512 and fr["episodes_kept"] > 0
     assert line["config"]["learner_updates_timed"] == 10 and line["nonfinite_envs"] == 0 and line["steps"] == 10
     assert line["steady_state"]["learner_updates_timed"] == 30 and line["roofline"]["avg_launch_ms"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p2p", ["1", "0"])
+def test_two_ranks_free_running_rollout(p2p):
+    """`bench.py --gpus 2 --rollout free` (two ranks sharing this box's GPU): each rank's persistent rollout kernel runs its own env shard,
+    the learners' updates meet in the gradient all-reduces (peer exchange with KS_P2P=1, the process group's all_reduce with 0) - the replicas
+    must end bit-identical although every rank's rollout is free-running, and no episode may be dropped."""
+    r = run_bench(["--gpus", "2", "--rollout", "free", "--chunk", "5", "--steps", "10", "--warmup", "5", "--envs-per-gpu", "512", "--no-cpu-baseline",
+                   "--pretrain-updates", "45", "--steady-steps", "0"], env={"KS_DIST_BACKEND": "gloo", "KS_VISIBLE_GPUS": "1", "KS_P2P": p2p, "KS_REPLICA_CHECK_EVERY": "20"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["launch"].startswith("free-running rollout kernel")
+    assert line["replica_weight_checksum_spread"] == 0.0 and line["replica_checks_during_run"] >= 2 and line["nonfinite_envs"] == 0
+    assert line["config"]["free_running"]["episodes_dropped"] == 0 and line["config"]["learner_updates_timed"] == 10
+    assert line["rccl"]["exchange"].startswith("peer-mapped memory" if p2p == "1" else "gloo all_reduce")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/<tag>_pmc_k_env_step_summary.txt (tools/pmc_run.sh) -> profiles/<round>_pmc.json, the file bench.py reads for
-`roofline.traffic` and the issue-bound figures.  Usage: tools/pmc_to_json.py profiles/r03_a_pmc_sim_summary.txt profiles/r03_pmc_sim.json sim|ddpg"""
+`roofline.traffic` and the issue-bound figures.  Usage: tools/pmc_to_json.py profiles/r03_a_pmc_sim_summary.txt profiles/r03_pmc_sim.json sim|ddpg|free"""
 import json
 import re
 import sys
@@ -13,11 +13,15 @@ for line in open(src):
     if m:
         per[m.group(1)] = float(m.group(2))
 kib = 1024.0
+if workload == "free":          # k_rollout launches advance 10 env-steps each: normalise to ONE env-step so the figures compare with k_env_step's
+    per = {k: (v if k == "SQ_WAVES" else v / 10.0) for k, v in per.items()}
 out = {
-    "kernel": "k_env_step",
+    "kernel": "k_rollout" if workload == "free" else "k_env_step",
     "workload": ("bench.py --mode sim, 4096 envs, CubeS" if workload == "sim" else
+                 "bench.py --rollout free (config 3: DDPG training, 4096 envs, free-running rollout kernel, learner HIP graphs; counters on every dispatch, "
+                 "dispatches serialised by the collector so k_rollout runs alone; per-launch figures divided by the 10 env-steps of a launch) after 150 pre-training updates (the collector segfaults with 600)" if workload == "free" else
                  "bench.py --eager (config 3: DDPG training, 4096 envs, learner launched op by op - counter collection with the kernel filter segfaults when the learner runs from HIP graphs) after 600 pre-training updates") +
-                " (tools/pmc_run.sh: rocprofv3 --kernel-trace --pmc, one counter set per pass, last 40 launches of each pass)",
+                " (tools/pmc_run.sh: rocprofv3 --kernel-trace --pmc, one counter set per pass, last 40 launches of each pass; free: last 2 launches = 20 env-steps)",
     "source": src,
     "per_launch": per,
     # FETCH_SIZE / WRITE_SIZE are reported in KiB.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half the
