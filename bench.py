@@ -16,7 +16,12 @@ Timed region (round 3): in ddpg mode the policy is first trained for `--pretrain
 then close into contact-rich grasps and the envs' episode clocks are spread over the 30 phases - then W warm-up steps, then
 EXACTLY K timed steps.  (Rounds 1-2 timed the first episodes of a random policy, the cheapest regime.)
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel k_env_step, HIP-event timed on the
+Rollout form (--rollout, default auto): the free-running per-workgroup kernel k_rollout (actor + 15 substeps + rays + observation + replay
+write in one persistent launch of --chunk env-steps, learner graphs beside it) when the widths are LDS-free (256-256 / 128-128 / 64-64) and
+every workgroup is resident in one round; otherwise - config 5, 400-300, --eager, --serial-learner, or --rollout lockstep - one k_env_step
+launch per env-step from HIP graphs.  `config.launch` says which one ran.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel k_rollout / k_env_step, HIP-event timed on the
 launch stream inside this process), `mfma` (the learner's MLP kernels against the fp32 MFMA peak), `steady_state`
 (a longer window of whole episodes right after the timed one: `value` should agree with it) and `cpu_baseline` (the fp64 CPU
 oracle on the host cores, N=1 only).
