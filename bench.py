@@ -187,7 +187,8 @@ def main():
                          "env-step for all envs (pipeline.GraphedTrainer, rounds 1-2; bit-reproducible).  'auto' (default): free where it pays - the "
                          "learner is LDS-free (256-256) and the envs fit the GPU's CUs in one round of workgroups (<= 16 envs x CUs: config 3 / 4) - "
                          "else lockstep (config 5's 8192 envs, 400-300, --eager, --serial-learner).  The JSON line says which (`config.launch`).")
-    ap.add_argument("--chunk", type=int, default=10, help="free-running rollout: env-steps per launch (learner and rollout streams meet between launches)")
+    ap.add_argument("--chunk", type=int, default=60, help="free-running rollout: at most this many env-steps per launch (learner and rollout streams meet between launches); "
+                    "a launch lasts as long as its slowest workgroup, whose lead over the mean workgroup shrinks with the square root of the steps per launch")
     ap.add_argument("--expert-prob", type=float, default=0.0,
                     help="ddpg mode: DDPGfD's demonstration mix (DDPGfD.py:232-254) - an expert ring is filled with one scripted 'combined'-controller "
                          "episode per env before training and every update samples int(64 (1 - p)) agent + the rest expert episodes (reference: 0.3)")
@@ -382,6 +383,7 @@ def main():
     if free_running:                     # per env-step: the persistent launches' durations / their env-steps
         tot = sum(e0.elapsed_time(e1) for e0, e1, _ in rollout_ms)
         kern_ms, launches = tot / max(1, sum(c for _, _, c in rollout_ms)), len(rollout_ms)
+        timed_launches = "+".join(str(c) for _, _, c in rollout_ms)
         rollout_ms.clear()
     timed_updates = updates - upd0
     if world > 1:
@@ -483,7 +485,7 @@ def main():
                                     "metric's env count); sim kernels only"),
                        "mode": args.mode, "envs_per_gpu": n, "frame_skip": 15, "solver": f"newton, <= {iters} iterations per substep (early exit on convergence)", "hidden": list(args.hidden),
                        "learner_updates_timed": timed_updates if args.mode == "ddpg" else 0, "priming_steps": priming,
-                       "launch": (("eager" if args.eager else ("free-running rollout kernel (ks_rollout), %d env-steps per launch + learner graphs" % args.chunk
+                       "launch": (("eager" if args.eager else ("free-running rollout kernel (ks_rollout), <= %d env-steps per launch (timed region: %s) + learner graphs" % (args.chunk, timed_launches)
                                                                 if free_running else "hip-graphs, one stepping launch per env-step")) if args.mode == "ddpg" else "direct"),
                        "free_running": (trainer.counts() if free_running else None),
                        "learner": learner_form, "expert_mix": (expert_info if args.mode == "ddpg" else None),

@@ -81,8 +81,7 @@ def main():
     t0 = time.perf_counter()
     for it in range(0, args.steps, 60):
         if args.free_running:
-            for _ in range(6):
-                tr.run(10)
+            tr.run(60)                      # one persistent launch of 60 env-steps (+ 60 updates beside it): long launches keep the launch tail small
             tr.flush()
             c = tr.counts()
             d_ep, d_lift = c["episodes_finished"] - episodes, c["lifted"] - lifted

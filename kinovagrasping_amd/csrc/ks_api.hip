@@ -728,6 +728,9 @@ __global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__
                                                 const ks_rollout_args* __restrict__ rap, int n_iter) {
     using T = float;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef KS_ROLLOUT_STAMP
+    const long long wk_entry = wall_clock64();      // diagnostic build: counters[] is [8 + 3 * 512 + 2] there (pipeline.AsyncTrainer allocates that)
+#endif
     KS_LDS T* lds = (KS_LDS T*)smem;
     const Model<T>* mp = models + __builtin_amdgcn_readfirstlane(b.wg_model[blockIdx.x]);
     const Model<T>* ml = stage_model_and_tables<T, WG>(mp, lds);
@@ -737,6 +740,9 @@ __global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__
     __syncthreads();
     stage_hulls<T, true>(*ml, lds, hull_words, *hup, true);
     KS_LDS T* blocks = lds + ((hull_words >> 2) << 2);                 // the 16 env blocks; scratch of the tails between the steps
+#ifdef KS_ROLLOUT_STAMP
+    const long long wk_loop = wall_clock64();
+#endif
     // The loop's pointers are laundered through empty asm statements at the top of every iteration: otherwise the compiler hoists
     // loop-invariant address arithmetic and model constants out of the loop and keeps them in registers for the whole launch
     // (388 registers per lane instead of ~344; as an out-of-line call the body saves its callee-saved registers to scratch:
@@ -753,6 +759,15 @@ __global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__
         asm volatile("" : "+v"(ki));
         rollout_iter<NT1, NT2>(*mi, *hi, bi, N, frame_skip, iters, epw, pair_memory, oi, ri, ki);
     }
+#ifdef KS_ROLLOUT_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 512) {
+        // per workgroup, LAST launch: entry (absolute ticks), entry -> loop, loop duration; [8 + 1536 ..]: first entry / last exit of the launch
+        const long long wk_end = wall_clock64();
+        rap->counters[8 + blockIdx.x] = wk_entry;
+        rap->counters[8 + 512 + blockIdx.x] = wk_loop - wk_entry;
+        rap->counters[8 + 1024 + blockIdx.x] = wk_end - wk_loop;
+    }
+#endif
 }
 
 template <typename T, bool USE_LDS>

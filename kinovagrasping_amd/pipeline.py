@@ -316,8 +316,8 @@ class AsyncTrainer(GraphedTrainer):
         self.pub[0, :flat.numel()].copy_(flat)
         replay.enable_async()
         self.steps_total = torch.zeros(eng.n, dtype=torch.long, device=dev)
-        self.counters = torch.zeros(8, dtype=torch.long, device=dev)      # episodes finished, lifted, kept, dropped (+ 4 phase timers of the
-                                                                          # -DKS_ROLLOUT_STAMP diagnostic build)
+        self.counters = torch.zeros(8 + 3 * 512, dtype=torch.long, device=dev)      # episodes finished, lifted, kept, dropped (+ 4 phase timers and 3 x 512
+                                                                          # per-workgroup stamps of the -DKS_ROLLOUT_STAMP diagnostic build)
         P = lambda t: t.data_ptr()
         a = KsRolloutArgs()
         a.actor_pub, a.actor_ver, a.actor_stride = P(self.pub), P(self.pub_ver), stride

@@ -52,7 +52,20 @@ def learner_only():
 
 
 learn = timed(learner_only, 30)
-ph = tr.counters[4:].tolist()
+ph = tr.counters[4:8].tolist()
+if sum(ph):
+    import numpy as np
+    nwg = n // 16
+    for label, fn in (("rollout alone", lambda: tr.run(chunk, learn=False)), ("rollout + learner", lambda: tr.run(chunk))):
+        for _ in range(3):
+            fn()
+        tr.flush(); torch.cuda.synchronize()
+        c = tr.counters[8:].cpu().numpy().reshape(3, 512)[:, :nwg].astype(np.float64) / 100.0          # us
+        entry, stage, loop = c[0] - c[0].min(), c[1], c[2]
+        end = entry + stage + loop
+        print(f"{label}, last launch of {chunk} env-steps, per workgroup [us]: entry spread max {entry.max():.0f}; tables -> LDS mean {stage.mean():.0f} max {stage.max():.0f}; "
+              f"loop mean {loop.mean():.0f}  p50 {np.median(loop):.0f}  p90 {np.percentile(loop, 90):.0f}  max {loop.max():.0f}; first entry -> last exit {end.max():.0f} "
+              f"= {end.max() / chunk:.0f} per env-step (mean loop / step {loop.mean() / chunk:.0f})")
 if sum(ph):
     tot = tr.env_steps * (n // 16)
     print("k_rollout phases, mean per workgroup and env-step [us]: policy %.1f  15 substeps %.1f  rays %.1f  observation + replay write %.1f" % tuple(p / tot / 100.0 for p in ph))
