@@ -57,9 +57,13 @@ if sum(ph):
     import numpy as np
     nwg = n // 16
     for label, fn in (("rollout alone", lambda: tr.run(chunk, learn=False)), ("rollout + learner", lambda: tr.run(chunk))):
+        tr.flush(); torch.cuda.synchronize()
+        ph0, st0 = tr.counters[4:8].clone(), tr.env_steps
         for _ in range(3):
             fn()
         tr.flush(); torch.cuda.synchronize()
+        dph = ((tr.counters[4:8] - ph0).double() / ((tr.env_steps - st0) * nwg) / 100.0).tolist()
+        print(f"{label}: phases, mean per workgroup and env-step [us]: policy %.1f  15 substeps %.1f  rays %.1f  observation + replay write %.1f" % tuple(dph))
         c = tr.counters[8:].cpu().numpy().reshape(3, 512)[:, :nwg].astype(np.float64) / 100.0          # us
         entry, stage, loop = c[0] - c[0].min(), c[1], c[2]
         end = entry + stage + loop

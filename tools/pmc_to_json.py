@@ -32,7 +32,12 @@ out = {
     "fetch_bytes_per_launch_upper_bound": 2 * per.get("FETCH_SIZE", 0) * kib,
     "write_bytes_per_launch": per.get("WRITE_SIZE", 0) * kib,
     "hbm_bytes_per_launch": (per.get("FETCH_SIZE", 0) + per.get("WRITE_SIZE", 0)) * kib,
-    "note": "fetch = per-workgroup staging of the hull / model tables (256 workgroups x ~50 KB, L2 / MALL hits count) + env state + "
+    "note": ("per env-step of k_rollout: fetch = the actor's weights for every workgroup and env-step (L2 hits) + env state + pair memory + the rays' mesh nodes + "
+             "1/10 of the per-launch staging of the hull / model tables; write = state + body-pose snapshot + rays + observation (x3: output, next policy input, "
+             "terminal) + replay row + pair memory (2.3 MB), stored as 4-byte columns of [field][env] arrays (DESIGN section 5: ~12 MB of stores per env-step + "
+             "partial-line write-backs); no private-memory frame in this kernel.  The counters sit on the L2's memory side: Infinity-Cache hits are included, "
+             "so this is an upper bound on HBM traffic.") if workload == "free" else
+            "fetch = per-workgroup staging of the hull / model tables (256 workgroups x ~50 KB, L2 / MALL hits count) + env state + "
             "pair memory + the in-step rays' mesh nodes; write = state + snapshot + rays + pair memory (4.9 MB) + write-through of the "
             "private-memory (stack) stores of the out-of-line stages (~4 MB: the pair memory words and an out-of-line fallback's result).  The counters sit on the L2's memory side: Infinity-Cache hits "
             "are included, so this is an upper bound on HBM traffic.",
