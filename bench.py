@@ -331,6 +331,7 @@ def main():
     free_running = trainer is not None and type(trainer).__name__ == "AsyncTrainer"
     k = 0
     rollout_ms = []                     # free-running: (launch duration by HIP events on the launch stream, env-steps) per launch
+    all_launches = []                   # free-running: env-steps of EVERY k_rollout launch of this process, in order (tools/rollout_trace_join.py)
 
     def advance(n_steps, learn=True, timed=False):
         """n_steps env-steps of every env (+ as many learner updates)"""
@@ -347,6 +348,7 @@ def main():
                 trainer.main.wait_stream(trainer.side)
                 e0.record(trainer.main)
             trainer.run(c, learn=learn)
+            all_launches.append(c)
             if timed:
                 e1.record(trainer.main)
                 rollout_ms.append((e0, e1, c))
@@ -384,6 +386,7 @@ def main():
         tot = sum(e0.elapsed_time(e1) for e0, e1, _ in rollout_ms)
         kern_ms, launches = tot / max(1, sum(c for _, _, c in rollout_ms)), len(rollout_ms)
         timed_launches = "+".join(str(c) for _, _, c in rollout_ms)
+        timed_first = len(all_launches) - len(rollout_ms)          # index of the first timed launch among all k_rollout launches
         rollout_ms.clear()
     timed_updates = updates - upd0
     if world > 1:
@@ -487,7 +490,7 @@ def main():
                        "learner_updates_timed": timed_updates if args.mode == "ddpg" else 0, "priming_steps": priming,
                        "launch": (("eager" if args.eager else ("free-running rollout kernel (ks_rollout), <= %d env-steps per launch (timed region: %s) + learner graphs" % (args.chunk, timed_launches)
                                                                 if free_running else "hip-graphs, one stepping launch per env-step")) if args.mode == "ddpg" else "direct"),
-                       "free_running": (trainer.counts() if free_running else None),
+                       "free_running": (dict(trainer.counts(), launch_steps=all_launches, first_timed_launch=timed_first, timed_launches=launches) if free_running else None),
                        "learner": learner_form, "expert_mix": (expert_info if args.mode == "ddpg" else None),
                        "parallelism": f"env-shard x{world}" + (" + grad all-reduce" if world > 1 and args.mode == "ddpg" else "")},
             "roofline": {"bound": "hbm", "kernel": "k_rollout (per env-step)" if free_running else "k_env_step", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -10,7 +10,7 @@ KERNEL=k_env_step; FILTER="--kernel-include-regex k_env_step"
 if [ $mode = free ]; then
   # the free-running rollout kernel: the learner replays HIP graphs beside it, the kernel filter segfaults with those -> counters on every
   # dispatch (the collector segfaults at 600 pre-training updates, 150 works), k_rollout launches of 10 env-steps each (divide the per-launch figures by 10)
-  ARGS="bench.py --rollout free --steps 20 --warmup 10 --no-cpu-baseline --pretrain-updates ${PMC_PRETRAIN:-150} --steady-steps 0"; KERNEL=k_rollout; FILTER=""
+  ARGS="bench.py --rollout free --chunk 10 --steps 20 --warmup 10 --no-cpu-baseline --pretrain-updates ${PMC_PRETRAIN:-150} --steady-steps 0"; KERNEL=k_rollout; FILTER=""
 elif [ $mode = sim ]; then ARGS="bench.py --mode sim --steps 40 --warmup 4 --no-cpu-baseline"
 else ARGS="bench.py --rollout lockstep --eager --steps 40 --warmup 5 --no-cpu-baseline --pretrain-updates 600 --steady-steps 0"; fi   # (--eager: counter collection + the kernel filter segfaults rocprofv3 when the learner runs from HIP graphs)
 i=0
@@ -20,7 +20,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_DATA_FIFO_FULL" \
            "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace $FILTER --pmc $set --output-format csv -d $dir/p$i -- python3 $ARGS > $dir/p$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace $FILTER --pmc $set --output-format csv -d $dir/p$i -- python3 $ARGS > $dir/p$i.log 2>&1
 done
 PMC_DIR=$dir PMC_KERNEL=$KERNEL python3 - <<'PY'
 import csv, glob, collections, os
