@@ -729,7 +729,7 @@ __global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__
     using T = float;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef KS_ROLLOUT_STAMP
-    const long long wk_entry = wall_clock64();      // diagnostic build: counters[] is [8 + 3 * 512 + 2] there (pipeline.AsyncTrainer allocates that)
+    const long long wk_entry = wall_clock64();      // diagnostic build: counters[] is [8 + 4 * 512] there (pipeline.AsyncTrainer allocates that)
 #endif
     KS_LDS T* lds = (KS_LDS T*)smem;
     const Model<T>* mp = models + __builtin_amdgcn_readfirstlane(b.wg_model[blockIdx.x]);
@@ -742,6 +742,7 @@ __global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__
     KS_LDS T* blocks = lds + ((hull_words >> 2) << 2);                 // the 16 env blocks; scratch of the tails between the steps
 #ifdef KS_ROLLOUT_STAMP
     const long long wk_loop = wall_clock64();
+    const long long ck_loop = clock64();
 #endif
     // The loop's pointers are laundered through empty asm statements at the top of every iteration: otherwise the compiler hoists
     // loop-invariant address arithmetic and model constants out of the loop and keeps them in registers for the whole launch
@@ -766,6 +767,7 @@ __global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__
         rap->counters[8 + blockIdx.x] = wk_entry;
         rap->counters[8 + 512 + blockIdx.x] = wk_loop - wk_entry;
         rap->counters[8 + 1024 + blockIdx.x] = wk_end - wk_loop;
+        rap->counters[8 + 1536 + blockIdx.x] = clock64() - ck_loop;        // shader-clock cycles of the loop: / its wall time = the clock the CU ran at
     }
 #endif
 }

@@ -64,7 +64,10 @@ if sum(ph):
         tr.flush(); torch.cuda.synchronize()
         dph = ((tr.counters[4:8] - ph0).double() / ((tr.env_steps - st0) * nwg) / 100.0).tolist()
         print(f"{label}: phases, mean per workgroup and env-step [us]: policy %.1f  15 substeps %.1f  rays %.1f  observation + replay write %.1f" % tuple(dph))
-        c = tr.counters[8:].cpu().numpy().reshape(3, 512)[:, :nwg].astype(np.float64) / 100.0          # us
+        raw = tr.counters[8:].cpu().numpy().reshape(4, 512)[:, :nwg].astype(np.float64)
+        mhz = raw[3] / (raw[2] / 100.0)
+        print(f"{label}: shader clock during the loop (cycles / wall time) mean {mhz.mean():.0f} MHz  min {mhz.min():.0f}  max {mhz.max():.0f}")
+        c = raw[:3] / 100.0          # us
         entry, stage, loop = c[0] - c[0].min(), c[1], c[2]
         end = entry + stage + loop
         print(f"{label}, last launch of {chunk} env-steps, per workgroup [us]: entry spread max {entry.max():.0f}; tables -> LDS mean {stage.mean():.0f} max {stage.max():.0f}; "
