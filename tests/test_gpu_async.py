@@ -40,13 +40,14 @@ def _ring_episodes(replay):
     return sorted(key(e) for e in eps)
 
 
-@pytest.mark.parametrize("hidden,mixed,horizon,per", [((256, 256), False, 12, 9), ((64, 64), False, 12, 9), ((256, 256), True, 12, 9), ((256, 256), False, 30, 13)])
-def test_free_running_rollout_equals_the_lock_step_calls(hidden, mixed, horizon, per):
+@pytest.mark.parametrize("hidden,mixed,horizon,per,n", [((256, 256), False, 12, 9, 272), ((64, 64), False, 12, 9, 272), ((256, 256), True, 12, 9, 272),
+                                                        ((256, 256), False, 30, 13, 272), ((256, 256), False, 30, 12, 4096)])
+def test_free_running_rollout_equals_the_lock_step_calls(hidden, mixed, horizon, per, n):
     """horizon 12: every env runs into the time limit three times in 45 env-steps; horizon 30, 65 env-steps: the (bias-pushed) actor closes
     the hand, check_grasp fires, the scripted lift ends episodes early - the un-stored lift steps and the overwrite of the last stored
-    transition (utils.py:309-343) are part of what must match."""
+    transition (utils.py:309-343) are part of what must match.  n = 4096: the bench's shape (BASELINE config 3: one workgroup on every CU)."""
     from kinovagrasping_amd.pipeline import AsyncTrainer
-    n, chunks = 272, 5                                   # >= 17 workgroups
+    chunks = 5                                           # n = 272: 17 workgroups
     # lock step: the three calls per env-step
     sim, policy, replay, eng = _setup(n, horizon, hidden=hidden, mixed=mixed)
     for _ in range(chunks * per):
