@@ -303,6 +303,13 @@ class AsyncTrainer(GraphedTrainer):
         if not self.native.lds_free:
             raise ValueError("AsyncTrainer needs the LDS-free learner kernels (hidden widths 256-256 / 128-128 / 64-64): the persistent rollout kernel "
                              "holds every CU's LDS for the whole launch, a learner built on library GEMMs could only run behind it")
+        if self.distributed and self.native.exchange is None:
+            import os
+            import torch.distributed as dist
+            if dist.get_backend(policy.process_group) == "nccl" and os.environ.get("KS_ASYNC_LIBRARY_ALLREDUCE", "0") == "0":
+                # (a host-side backend such as gloo has no kernels to starve; KS_ASYNC_LIBRARY_ALLREDUCE=1 overrides)
+                raise ValueError("AsyncTrainer needs the LDS-free peer exchange between the ranks (" + self.exchange_note + "): the library's all-reduce kernels "
+                                 "need LDS and would only run between the persistent rollout launches")
         if not (eng.native and eng.device_noise and eng._fused_actor_layers() is not None and sim.cfg.auto_reset and sim.obs_env_major):
             raise ValueError("AsyncTrainer needs the fused actor path (3-layer MLP at a supported width, in-kernel noise), auto_reset and env-major obs")
         flat = policy._flat_params["actor"]
