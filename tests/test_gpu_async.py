@@ -102,3 +102,36 @@ def test_async_trainer_trains_beside_the_free_running_rollout():
     assert torch.isfinite(tr.native.losses).all()
     assert (sim.get_state()["status"] & 2).sum().item() == 0 and torch.equal(tr.steps_total, torch.full_like(tr.steps_total, 126))
     sim.close()
+
+
+def test_episodes_committed_beside_the_running_kernel_are_whole():
+    """BASELINE config 3's shape (4096 envs, one workgroup on every CU, launches of 60 env-steps): the learner's stream moves published episodes into the
+    ring WHILE the rollout kernel keeps writing the envs' other open buffer (release store of pub_len in k_rollout, plain loads in the commit kernels of
+    later launches, possibly on another XCD).  Every committed episode must be one env's consecutive transitions: next_state[t] == state[t + 1] bit for
+    bit, not_done 1 except on the last row, rewards 0 except possibly the last - a row of another episode (stale line, torn hand-over) breaks that."""
+    from kinovagrasping_amd.pipeline import AsyncTrainer
+    n = 4096
+    sim, policy, replay, eng = _setup(n, 30)
+    tr = AsyncTrainer(sim, policy, replay, eng, batch_episodes=64)
+    tr.capture()
+    tr.run(36, learn=False)
+    tr.flush()
+    for _ in range(3):
+        tr.run(60)
+    tr.flush(finish_update=True)
+    torch.cuda.synchronize()
+    c = tr.counts()
+    assert c["episodes_dropped"] == 0 and c["episodes_kept"] >= 6 * n and replay.count == min(c["episodes_kept"], replay.capacity)
+    L = replay.ep_len[: replay.count]
+    S, NX, R, ND = replay.ep_state[: replay.count], replay.ep_next[: replay.count], replay.ep_reward[: replay.count], replay.ep_not_done[: replay.count]
+    H = S.shape[1]
+    t = torch.arange(H, device=S.device)[None, :]
+    inner = t < (L[:, None] - 1)                               # rows with a successor in the same episode
+    assert L.min().item() > replay.n_steps + 1 and L.max().item() <= H
+    chain = (NX[:, :-1] == S[:, 1:]).all(2) | ~inner[:, :-1]
+    bad = (~chain).any(1)
+    assert not bad.any(), f"{int(bad.sum())} of {replay.count} committed episodes are not one env's consecutive transitions"
+    assert ((ND == 1) | ~inner).all() and (ND.gather(1, (L - 1)[:, None]) == 0).all()
+    assert ((R == 0) | ~inner).all()
+    print(f"{replay.count} committed episodes whole; lengths {L.min().item()}..{L.max().item()}, lifted {c['lifted']}")
+    sim.close()
