@@ -491,7 +491,7 @@ def main():
                        "launch": (("eager" if args.eager else ("free-running rollout kernel (ks_rollout), <= %d env-steps per launch (timed region: %s) + learner graphs" % (args.chunk, timed_launches)
                                                                 if free_running else "hip-graphs, one stepping launch per env-step")) if args.mode == "ddpg" else "direct"),
                        "free_running": (dict(trainer.counts(), launch_steps=all_launches, first_timed_launch=timed_first, timed_launches=launches) if free_running else None),
-                       "learner": learner_form, "expert_mix": (expert_info if args.mode == "ddpg" else None),
+                       "learner": learner_form, "learner_stream_overlaps_rollout_stream": (getattr(trainer, "streams_overlap", None) if trainer is not None else None), "expert_mix": (expert_info if args.mode == "ddpg" else None),
                        "parallelism": f"env-shard x{world}" + (" + grad all-reduce" if world > 1 and args.mode == "ddpg" else "")},
             "roofline": {"bound": "hbm", "kernel": "k_rollout (per env-step)" if free_running else "k_env_step", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_note": traffic_note,

@@ -183,7 +183,7 @@ typedef struct {
     int64_t *cur_len;                /* [2][n] */
     uint8_t *cur_sel;                /* [n] */
     int64_t *pub_len;                /* [2][n] */
-    int64_t *counters;               /* [4]: episodes finished, lifted, kept, dropped (a -DKS_ROLLOUT_STAMP diagnostic build writes [8 + 4 * 512]) */
+    int64_t *counters;               /* [4]: episodes finished, lifted, kept, dropped (a -DKS_ROLLOUT_STAMP diagnostic build writes [8 + 4 * 512 + 8]) */
 } ks_rollout_args;
 int ks_rollout(ks_ctx *ctx, int32_t n_iter, const ks_rollout_args *args_host, void *stream);
 

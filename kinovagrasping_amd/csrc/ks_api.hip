@@ -271,8 +271,8 @@ constexpr int EPW_MAX = WG / LANE_STRIDE;
 // at different times (0.7 .. 1.1 ms), so all but the last do this while others are still stepping - the separate k_rays
 // launch (and its launch gap) leaves the critical path, only the slowest workgroup's own rays stay on it.
 // Two passes over the (env, ray, geom) tasks: every thread culls its share against the geoms' bounding boxes and appends
-// the survivors (6 - 15 %) to a list in LDS; the list is then walked one task per thread - dense lanes instead of one
-// walker per eight.  The nearest hit of an (env, ray) is an LDS word updated with atomicMin on the float's bit pattern
+// the survivors (6 - 15 %) to a queue in LDS; the queue is then walked one entry per thread - dense lanes instead of one
+// walker per eight - and walkers hand far subtrees to waiting lanes through the same queue (SharingStack below).  The nearest hit of an (env, ray) is an LDS word updated with atomicMin on the float's bit pattern
 // (non-negative floats order like unsigned integers); walkers read it as their pruning bound, exactly as k_rays' group
 // bound.  The per-env LDS blocks are dead by then and hold the list, the hit words and the traversal stacks.
 struct SlotBound {
@@ -284,27 +284,77 @@ struct SlotBound {
 };
 constexpr int WG_RAY_TASKS = NRAY * (NGEOM - 1);                       // per env
 constexpr int WG_SNAP = 97;                                            // body poses of an env (96 floats), odd stride
-__host__ __device__ constexpr int wg_rays_words(int epw) { return epw * NRAY + 4 + epw * WG_RAY_TASKS + RAY_STACK * WG + epw * WG_SNAP; }
+// the walk queue: every surviving (env, ray, geom) task + the subtrees that busy walkers hand to idle lanes
+__host__ __device__ constexpr int wg_ray_queue(int epw) { return epw * WG_RAY_TASKS + 64 * epw; }
+__host__ __device__ constexpr int wg_rays_words(int epw) { return epw * NRAY + 8 + 2 * wg_ray_queue(epw) + RAY_STACK * WG + epw * WG_SNAP; }
 // ... followed by what wg_obs adds: the final ray distances [epw][NRAY + 1] and an auto-reset's kinematics scratch [epw][SCR_CON + 1]
 __host__ __device__ constexpr int wg_obs_words(int epw) { return epw * (NRAY + 1) + epw * (SCR_CON + 1); }
 struct LdsSnap {
     KS_LDS const float* base;
     __device__ float operator()(int k) const { return base[k]; }
 };
+// A walker's pending subtrees: its own stack in LDS (LdsStack) - or, while lanes of the workgroup wait for work, the shared queue.
+// The busiest lane of a workgroup used to visit ~23 nodes while the average lane visits 4.5 (170 surviving tasks on 256 lanes): the
+// pass lasted as long as the longest walk.  ctl[0] = entries appended, ctl[1] = tickets taken (a lane takes ONE ticket and waits for
+// that entry: appends reach the waiting lanes in ticket order, nothing is polled twice), ctl[2] = walks not yet finished.  An entry is
+// two words: the LdsStack word (entry parameter | node) and task + 1, written last (0 = not there yet).  The nearest hit of an (env, ray)
+// is shared through its LDS word (SlotBound) anyway, so a subtree walked by another lane prunes and is pruned exactly as before, and
+// the minimum over the same set of triangles does not depend on who visits them.
+struct SharedWalks {
+    KS_LDS unsigned* ctl;
+    KS_LDS unsigned* q;
+    int cap;
+};
+struct SharingStack {
+    LdsStack<float> own;
+    SharedWalks sh;
+    unsigned task1;
+    __device__ void push(int n, float tt) {
+        if (*(volatile KS_LDS unsigned*)(sh.ctl + 1) > *(volatile KS_LDS unsigned*)sh.ctl) {       // somebody holds a ticket for an entry that does not exist yet
+            const unsigned i = atomicAdd((unsigned*)sh.ctl, 1u);
+            if (i < (unsigned)sh.cap) {
+                atomicAdd((unsigned*)(sh.ctl + 2), 1u);
+                unsigned b = (unsigned)__float_as_int(tt);
+                b = b >= 0x10000u ? b - 0x10000u : 0u;
+                sh.q[2 * i] = (b & 0xffff0000u) | (unsigned)n;
+                __threadfence_block();
+                *(volatile KS_LDS unsigned*)(sh.q + 2 * i + 1) = task1;
+                return;
+            }
+        }
+        own.push(n, tt);
+    }
+    __device__ bool pop(int& n, float& tt) { return own.pop(n, tt); }
+};
 
-__device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>& b, int N, int slot0, int epw, KS_LDS unsigned* w) {
+#ifdef KS_ROLLOUT_STAMP
+#define KS_RAY_PROF_PARAM , long long* rprof
+#define KS_RAY_PROF_ARG(p) , p
+#define KS_RP(i) { const long long t1_ = wall_clock64(); if (rprof && threadIdx.x == 0) atomicAdd((unsigned long long*)&rprof[i], (unsigned long long)(t1_ - rtk)); rtk = t1_; }
+#else
+#define KS_RAY_PROF_PARAM
+#define KS_RAY_PROF_ARG(p)
+#define KS_RP(i)
+#endif
+__device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>& b, int N, int slot0, int epw, KS_LDS unsigned* w KS_RAY_PROF_PARAM) {
+#ifdef KS_ROLLOUT_STAMP
+    long long rtk = wall_clock64();
+    int my_visits = 0;
+#endif
     KS_LDS unsigned* hit = w;                                          // [epw][17] nearest hit so far (float bits), big = none
-    KS_LDS unsigned* count = w + epw * NRAY;
-    KS_LDS unsigned* list = count + 4;                                 // surviving task ids
-    KS_LDS unsigned* stk = list + epw * WG_RAY_TASKS;                  // [RAY_STACK][WG]
+    KS_LDS unsigned* ctl = w + epw * NRAY;                             // [8]: queue tail, tickets, unfinished walks
+    KS_LDS unsigned* q = ctl + 8;                                      // [cap][2] the walk queue
+    const int cap = wg_ray_queue(epw);
+    KS_LDS unsigned* stk = q + 2 * cap;                                // [RAY_STACK][WG]
     KS_LDS float* snaps = (KS_LDS float*)(stk + RAY_STACK * WG);       // [epw][WG_SNAP] body poses (one global read round for everything)
     const int tid = threadIdx.x, total = epw * WG_RAY_TASKS;
     for (int i = tid; i < epw * NRAY; i += WG) hit[i] = (unsigned)__float_as_int(Lim<float>::big);
+    for (int i = tid; i < cap; i += WG) q[2 * i + 1] = 0u;
     for (int i = tid; i < epw * 96; i += WG) {
         const int e = i / 96, k = i % 96, env = b.slot_env[slot0 + e];
         snaps[e * WG_SNAP + k] = env >= 0 ? b.snap[(long)(SNAP_BP + k) * N + env] : 0.f;
     }
-    if (tid == 0) { count[0] = 0; count[1] = 0; }
+    if (tid < 8) ctl[tid] = 0;
     __syncthreads();
     for (int task = tid; task < total; task += WG) {
         const int e = task / WG_RAY_TASKS, r = (task % WG_RAY_TASKS) >> 3, g = 1 + (task & 7), env = b.slot_env[slot0 + e];
@@ -316,38 +366,79 @@ __device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>
             const float tg = ray_ground(m, pnt, vec);
             if (tg >= 0) atomicMin((unsigned*)(hit + e * NRAY + r), (unsigned)__float_as_int(tg));
         }
-        if (m.geom_body[g] != sb && ray_may_hit_geom(m, snap, g, pnt, vec)) list[atomicAdd((unsigned*)count, 1u)] = (unsigned)task;
+        if (m.geom_body[g] != sb && ray_may_hit_geom(m, snap, g, pnt, vec)) {
+            const unsigned i = atomicAdd((unsigned*)ctl, 1u);           // (at most `total` <= cap of these)
+            q[2 * i] = 0u;                                              // the root, entry parameter 0
+            q[2 * i + 1] = (unsigned)task + 1u;
+        }
     }
     __syncthreads();
-    // The walks, one node visit per loop iteration: a lane whose walk has ended takes the next task from the list in the
-    // SAME loop, so the lanes of a wave do not wait for the longest walk of a round - the pass lasts about as long as the
-    // single longest walk (or the total number of visits / 256, whichever is more).
-    const unsigned nlist = *count;
-    KS_LDS unsigned* next = count + 1;
-    RayWalk<float, SlotBound, LdsStack<float>> walk;
+    if (tid == 0) ctl[2] = ctl[0];
+    __syncthreads();
+    KS_RP(0)                             // snapshot load + culling pass
+    // The walks, one node visit per loop iteration: a lane whose walk has ended takes the next entry of the queue in the SAME loop, so
+    // the lanes of a wave do not wait for the longest walk of a round.
+#ifdef KS_ROLLOUT_STAMP
+    const unsigned nlist = ctl[0];
+#endif
+    const SharedWalks sh{ctl, q, cap};
+    RayWalk<float, SlotBound, SharingStack> walk;
     KS_LDS unsigned* slot = hit;
     bool busy = false;
-    for (;;) {
+    unsigned ticket = 0xffffffffu;
+    // ONE loop for the whole wave, left by all of its lanes together when no walk of the workgroup is unfinished (the same LDS word
+    // for every lane: a uniform branch).  A lane without work makes one attempt per iteration and falls through - it must never spin
+    // in a loop of its own: the entry it waits for may have to be appended by a lane of its own wave.
+    while (*(volatile KS_LDS unsigned*)(ctl + 2) != 0u) {
         if (!busy) {
-            const unsigned i = atomicAdd((unsigned*)next, 1u);
-            if (i >= nlist) break;
-            const int task = (int)list[i];
-            const int e = task / WG_RAY_TASKS, r = (task % WG_RAY_TASKS) >> 3, g = 1 + (task & 7);
-            LdsSnap snap{snaps + e * WG_SNAP - SNAP_BP};
-            float pnt[3], vec[3], lp[3], lv[3];
-            ray_origin(m, snap, r, pnt, vec);
-            ray_to_geom(m, snap, g, pnt, vec, lp, lv);
-            slot = hit + e * NRAY + r;
-            const int mesh = m.geom_mesh[g];
-            busy = walk.start(m.mesh_tri[mesh], m.mesh_bvh_box[mesh], m.geom_size[g], lp, lv, SlotBound{slot}, LdsStack<float>{stk + tid, WG});
-            if (!busy) continue;
+            if (ticket == 0xffffffffu) ticket = atomicAdd((unsigned*)(ctl + 1), 1u);
+            const unsigned t1 = ticket < (unsigned)cap ? *(volatile KS_LDS unsigned*)(q + 2 * ticket + 1) : 0u;
+            if (t1 != 0u) {
+                const unsigned w0 = *(volatile KS_LDS unsigned*)(q + 2 * ticket);     // (written before the task word)
+                ticket = 0xffffffffu;
+                const int task = (int)t1 - 1, node = (int)(w0 & 0xffffu);
+                const int e = task / WG_RAY_TASKS, r = (task % WG_RAY_TASKS) >> 3, g = 1 + (task & 7);
+                LdsSnap snap{snaps + e * WG_SNAP - SNAP_BP};
+                float pnt[3], vec[3], lp[3], lv[3];
+                ray_origin(m, snap, r, pnt, vec);
+                ray_to_geom(m, snap, g, pnt, vec, lp, lv);
+                slot = hit + e * NRAY + r;
+                const int mesh = m.geom_mesh[g];
+                SharingStack st{LdsStack<float>{stk + tid, WG}, sh, t1};
+                busy = walk.start(m.mesh_tri[mesh], m.mesh_bvh_box[mesh], m.geom_size[g], lp, lv, SlotBound{slot}, st);
+                if (node != 0) {                                         // a subtree handed over by another walker: still in front of the nearest hit?
+                    const float te = __int_as_float((int)(w0 & 0xffff0000u));
+                    const float best = __int_as_float((int)*(volatile KS_LDS unsigned*)slot);
+                    busy = busy && te <= best;
+                    walk.node = node;
+                }
+                if (!busy) atomicSub((unsigned*)(ctl + 2), 1u);
+            }
+        } else {
+#ifdef KS_ROLLOUT_STAMP
+            my_visits++;
+#endif
+            if (!walk.step()) {
+                if (walk.best >= 0) atomicMin((unsigned*)slot, (unsigned)__float_as_int(walk.best));
+                atomicSub((unsigned*)(ctl + 2), 1u);
+                busy = false;
+            }
         }
-        if (!walk.step()) {
-            if (walk.best >= 0) atomicMin((unsigned*)slot, (unsigned)__float_as_int(walk.best));
-            busy = false;
-        }
+        if (__builtin_amdgcn_ballot_w64(busy) == 0ull) __builtin_amdgcn_s_sleep(1);   // a wave with nothing to do: leave the LDS to the others
     }
+#ifdef KS_ROLLOUT_STAMP
+    if (rprof) {                          // [2] surviving tasks, [3] node visits in total, [4] sum over workgroups of the busiest lane's visits
+        if (tid == 0) { atomicAdd((unsigned long long*)&rprof[2], (unsigned long long)nlist); ctl[4] = 0; }
+        __syncthreads();
+        atomicAdd((unsigned long long*)&rprof[3], (unsigned long long)my_visits);
+        atomicMax((unsigned*)&ctl[4], (unsigned)my_visits);
+    }
+#endif
     __syncthreads();
+    KS_RP(1)                             // the walks
+#ifdef KS_ROLLOUT_STAMP
+    if (rprof && tid == 0) { atomicAdd((unsigned long long*)&rprof[4], (unsigned long long)ctl[4]); atomicAdd((unsigned long long*)&rprof[5], (unsigned long long)(ctl[0] - nlist)); }
+#endif
     for (int i = tid; i < epw * NRAY; i += WG) {
         const int e = i / NRAY, r = i % NRAY, env = b.slot_env[slot0 + e];
         if (env >= 0) {
@@ -510,7 +601,7 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
             // reference to the by-value kernel arguments made every lane copy them to its stack, 224 bytes written through per launch)
             if (ray_pool) wg_ray_pool(models, m, *bdev, N, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)), n_wg, ray_pool == 2);
             else {
-                wg_rays(m, *bdev, N, blockIdx.x * epw, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)));
+                wg_rays(m, *bdev, N, blockIdx.x * epw, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)) KS_RAY_PROF_ARG(nullptr));
                 __threadfence_block();
                 __syncthreads();
             }
@@ -708,7 +799,7 @@ __device__ __forceinline__ void rollout_iter(const Model<float>& m, const Hulls<
     __threadfence_block();
     __syncthreads();
     KS_RS(1)
-    wg_rays(m, b, N, blockIdx.x * epw, epw, w);
+    wg_rays(m, b, N, blockIdx.x * epw, epw, w KS_RAY_PROF_ARG((long long*)&rap->counters[8 + 4 * 512]));
     __threadfence_block();
     __syncthreads();
     KS_RS(2)
@@ -729,7 +820,7 @@ __global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__
     using T = float;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef KS_ROLLOUT_STAMP
-    const long long wk_entry = wall_clock64();      // diagnostic build: counters[] is [8 + 4 * 512] there (pipeline.AsyncTrainer allocates that)
+    const long long wk_entry = wall_clock64();      // diagnostic build: counters[] is [8 + 4 * 512 + 8] there (pipeline.AsyncTrainer allocates that)
 #endif
     KS_LDS T* lds = (KS_LDS T*)smem;
     const Model<T>* mp = models + __builtin_amdgcn_readfirstlane(b.wg_model[blockIdx.x]);
@@ -1117,7 +1208,7 @@ __device__ __noinline__ void wg_ray_pool(const Model<float>* models, const Model
         if (t < 0) break;
         // (the same object as mine: my LDS copy of the model - a flat load that resolves to LDS costs a fraction of one that goes to L2)
         const int tm = b.wg_model[t];
-        wg_rays(tm == b.wg_model[own] ? mine : models[tm], b, N, t * epw, epw, w);
+        wg_rays(tm == b.wg_model[own] ? mine : models[tm], b, N, t * epw, epw, w KS_RAY_PROF_ARG(nullptr));
         __threadfence();
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(&state[t], 3, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

@@ -30,6 +30,45 @@ from __future__ import annotations
 import torch
 
 
+def _concurrent_stream(main, dev, tries=8):
+    """A second stream whose work really runs BESIDE `main`'s.  Streams share the GPU's few hardware queues (4 by default,
+    GPU_MAX_HW_QUEUES) and torch hands out pooled streams round-robin: in a process that has created streams before, a new stream
+    can land on `main`'s queue - its kernels then start only when `main`'s have finished, the learner would run BEHIND the stepping
+    kernel instead of beside it and the free-running rollout would drop the episodes the learner's stream does not collect in time.
+    Probe: a spin kernel on `main`, an event behind a trivial op on the candidate; returns (stream, overlapped)."""
+    import time
+    import warnings
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(main):
+        e0.record(main)
+        torch.cuda._sleep(1000000)
+        e1.record(main)
+    torch.cuda.synchronize(dev)
+    ms = max(1e-3, e0.elapsed_time(e1))
+    spin = int(1000000 * min(1e4, 25.0 / ms))               # ~25 ms
+    flag = torch.zeros(1, device=dev)
+    cand = None
+    for _ in range(tries):
+        cand = torch.cuda.Stream(dev)
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(main):
+            torch.cuda._sleep(spin)
+        with torch.cuda.stream(cand):
+            flag.add_(1.0)
+            ev.record(cand)
+        t0 = time.perf_counter()
+        while not ev.query() and time.perf_counter() - t0 < 0.010:
+            pass
+        ok = ev.query()
+        torch.cuda.synchronize(dev)
+        if ok:
+            return cand, True
+    warnings.warn("no stream found whose work overlaps the current stream's (GPU_MAX_HW_QUEUES too small?): the learner will run behind the stepping "
+                  "kernels, not beside them", RuntimeWarning)
+    return cand, False
+
+
 class GraphedTrainer:
     def __init__(self, sim, policy, replay, engine, batch_episodes=64, overlap=True, learn_after=31, expert_replay=None, expert_prob=0.3):
         """expert_replay (a DeviceEpisodeReplay filled by demonstrators.run_controller_episodes or loaded from a reference replay
@@ -51,7 +90,7 @@ class GraphedTrainer:
         except Exception:
             pass
         self.main = torch.cuda.current_stream(self.dev)
-        self.side = torch.cuda.Stream(self.dev)
+        self.side, self.streams_overlap = _concurrent_stream(self.main, self.dev) if overlap else (torch.cuda.Stream(self.dev), None)
         self.acted = torch.cuda.Event()
         self.head_done = torch.cuda.Event()
         self.g_pre = self.g_post = self.g_commit = None
@@ -323,7 +362,7 @@ class AsyncTrainer(GraphedTrainer):
         self.pub[0, :flat.numel()].copy_(flat)
         replay.enable_async()
         self.steps_total = torch.zeros(eng.n, dtype=torch.long, device=dev)
-        self.counters = torch.zeros(8 + 4 * 512, dtype=torch.long, device=dev)      # episodes finished, lifted, kept, dropped (+ 4 phase timers and 4 x 512
+        self.counters = torch.zeros(8 + 4 * 512 + 8, dtype=torch.long, device=dev)      # episodes finished, lifted, kept, dropped (+ 4 phase timers and 4 x 512
                                                                           # per-workgroup stamps of the -DKS_ROLLOUT_STAMP diagnostic build)
         P = lambda t: t.data_ptr()
         a = KsRolloutArgs()

@@ -121,7 +121,7 @@ def test_episodes_committed_beside_the_running_kernel_are_whole():
     tr.flush(finish_update=True)
     torch.cuda.synchronize()
     c = tr.counts()
-    assert c["episodes_dropped"] == 0 and c["episodes_kept"] >= 6 * n and replay.count == min(c["episodes_kept"], replay.capacity)
+    assert c["episodes_dropped"] == 0 and c["episodes_kept"] >= 6 * n and replay.count == min(c["episodes_kept"], replay.capacity), (c, replay.count)
     L = replay.ep_len[: replay.count]
     S, NX, R, ND = replay.ep_state[: replay.count], replay.ep_next[: replay.count], replay.ep_reward[: replay.count], replay.ep_not_done[: replay.count]
     H = S.shape[1]

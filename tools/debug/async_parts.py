@@ -58,13 +58,16 @@ if sum(ph):
     nwg = n // 16
     for label, fn in (("rollout alone", lambda: tr.run(chunk, learn=False)), ("rollout + learner", lambda: tr.run(chunk))):
         tr.flush(); torch.cuda.synchronize()
-        ph0, st0 = tr.counters[4:8].clone(), tr.env_steps
+        ph0, st0, rp0 = tr.counters[4:8].clone(), tr.env_steps, tr.counters[8 + 4 * 512:].clone()
         for _ in range(3):
             fn()
         tr.flush(); torch.cuda.synchronize()
         dph = ((tr.counters[4:8] - ph0).double() / ((tr.env_steps - st0) * nwg) / 100.0).tolist()
         print(f"{label}: phases, mean per workgroup and env-step [us]: policy %.1f  15 substeps %.1f  rays %.1f  observation + replay write %.1f" % tuple(dph))
-        raw = tr.counters[8:].cpu().numpy().reshape(4, 512)[:, :nwg].astype(np.float64)
+        rp = ((tr.counters[8 + 4 * 512:] - rp0).double() / ((tr.env_steps - st0) * nwg)).tolist()
+        print(f"{label}: rays per workgroup and env-step: snapshot + culling %.1f us, walks %.1f us; surviving (ray, geom) tasks %.0f of 2176, node visits %.0f "
+              f"(= %.1f per lane), the busiest lane's visits %.0f, subtrees handed to waiting lanes %.0f" % (rp[0] / 100.0, rp[1] / 100.0, rp[2], rp[3], rp[3] / 256.0, rp[4], rp[5]))
+        raw = tr.counters[8:8 + 4 * 512].cpu().numpy().reshape(4, 512)[:, :nwg].astype(np.float64)
         mhz = raw[3] / (raw[2] / 100.0)
         print(f"{label}: shader clock during the loop (cycles / wall time) mean {mhz.mean():.0f} MHz  min {mhz.min():.0f}  max {mhz.max():.0f}")
         c = raw[:3] / 100.0          # us
