@@ -1,6 +1,6 @@
 #!/bin/bash
-# final measurement set of round 3 (the free-running default with launches of <= 60 env-steps): bench lines, kernel stats + the per-env-step join, k_rollout counters
-tag=r03_c
+# final measurement set of round 3 (usage: tools/r03_final_set.sh [tag]): bench lines, kernel stats + the per-env-step join, k_rollout counters
+tag=${1:-r03_d}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
