@@ -1,3 +1,5 @@
+#!/bin/bash
+# experiment (round 2): ray pool on / off (KS_RAY_POOL), alternating runs of the bench on one box
 for val in 0 unset 0 unset; do
   if [ $val = unset ]; then unset KS_RAY_POOL; else export KS_RAY_POOL=$val; fi
   python bench.py --no-cpu-baseline --steady-updates 600 2>/dev/null | tail -1 | python -c "

@@ -1,3 +1,4 @@
+"""Dev tool (GPU box): prints the LDS budget of the stepping kernel (KS_DEBUG line) for every shape and for the 14-shape mixed context."""
 import os, sys
 sys.path.insert(0, '.')
 os.environ["KS_DEBUG"] = "1"

@@ -1,3 +1,5 @@
+#!/bin/bash
+# which rocprofv3 counter-collection forms survive (kernel filter x HIP graphs): the ones that segfault are why tools/pmc_run.sh ddpg uses --eager
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc_probe
 rocprofv3 --kernel-trace --kernel-include-regex k_env_step --pmc SQ_WAVES SQ_INSTS_VALU --output-format csv -d gpurun_out/pmc_probe/a -- python3 bench.py --mode sim --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/pmc_probe/a.log 2>&1; echo "sim+regex rc $?"

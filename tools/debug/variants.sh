@@ -1,3 +1,5 @@
+#!/bin/bash
+# experiment (round 2): bench with build variants kinovagrasping_amd/libkinova_sim_<NAME>.so (tools/debug/build_variant.sh) against the product library
 for n in SC SD ALL SOLVER; do
   KS_LIB=$PWD/kinovagrasping_amd/libkinova_sim_$n.so python bench.py --no-cpu-baseline --steady-updates 600 2>/dev/null > gpurun_out/bench_$n.json
   python -c "
