@@ -422,6 +422,12 @@ __device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>
                 if (walk.best >= 0) atomicMin((unsigned*)slot, (unsigned)__float_as_int(walk.best));
                 atomicSub((unsigned*)(ctl + 2), 1u);
                 busy = false;
+            } else if (walk.stack.own.sp > 0 && *(volatile KS_LDS unsigned*)(ctl + 1) > *(volatile KS_LDS unsigned*)ctl) {
+                // lanes have run out of work since this walker stacked its subtrees: give one away (push() keeps it if nobody waits any more)
+                int pn;
+                float pt;
+                walk.stack.own.pop(pn, pt);
+                walk.stack.push(pn, pt);
             }
         }
         if (__builtin_amdgcn_ballot_w64(busy) == 0ull) __builtin_amdgcn_s_sleep(1);   // a wave with nothing to do: leave the LDS to the others
