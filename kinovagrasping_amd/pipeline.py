@@ -448,7 +448,10 @@ class AsyncTrainer(GraphedTrainer):
     def run(self, n_steps: int, learn: bool = True):
         """n_steps env-steps of EVERY env (one persistent launch on the main stream) and, beside it on the learner's stream, n_steps
         updates: [episodes published so far -> ring, actor step + targets + sampling, publish the actor, body].  Returns after
-        ENQUEUEING both; synchronise (or call again) to wait.  The two streams only meet at the start of the next run()."""
+        ENQUEUEING both; synchronise (or call again) to wait.  The two streams only meet at the start of the next run().
+        Keep n_steps <= ~60: the learner's stream is the faster one and collects no published episodes once its n_steps updates
+        are done - an env that finishes more episodes than it has open buffers (2) before the launch ends drops them
+        (counts()["episodes_dropped"])."""
         main, side = self.main, self.side
         side.wait_stream(main)
         main.wait_stream(side)
