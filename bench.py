@@ -188,9 +188,9 @@ def main():
                          "learner is LDS-free (256-256) and the envs fit the GPU's CUs in one round of workgroups (<= 16 envs x CUs: config 3 / 4) - "
                          "else lockstep (config 5's 8192 envs, 400-300, --eager, --serial-learner).  The JSON line says which (`config.launch`).")
     ap.add_argument("--chunk", type=int, default=60, help="free-running rollout: at most this many env-steps per launch (learner and rollout streams meet between launches); "
-                    "a launch lasts as long as its slowest workgroup, whose lead over the mean workgroup shrinks with the square root of the steps per launch - but the "
-                    "learner's stream (0.9 ms per update) finishes its share of a launch ahead of the rollout (1.1 ms per env-step) and collects no episodes after that: "
-                    "at 120 / 240 env-steps per launch envs finish more episodes in that window than they have open buffers (8 / 61 episodes dropped in 240 steps)")
+                    "a launch lasts as long as its slowest workgroup, whose lead over the mean workgroup shrinks with the square root of the steps per launch; the "
+                    "learner's stream is paced on the envs' step counters (pipeline.AsyncTrainer.run, kr_wait_min), so finished episodes are collected all the way whatever the length; 60 is kept as the default because the launch pattern of the pre-training decides which policy emerges "
+                    "(launches of 100: ~10 % of the episodes end in a lift and the step is 8 % cheaper; launches of 60 + 40: 37 %, the regime all of this round's numbers are in)")
     ap.add_argument("--expert-prob", type=float, default=0.0,
                     help="ddpg mode: DDPGfD's demonstration mix (DDPGfD.py:232-254) - an expert ring is filled with one scripted 'combined'-controller "
                          "episode per env before training and every update samples int(64 (1 - p)) agent + the rest expert episodes (reference: 0.3)")

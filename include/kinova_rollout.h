@@ -51,6 +51,11 @@ int kr_store_transition(int32_t n, int32_t horizon, int32_t n_steps, int32_t aut
 
 /* rank [n] int64: number of kept episodes among envs 0..i (inclusive); total int64 [1] */
 int kr_rank_episodes(int32_t n, const uint8_t *keep, int64_t *rank, int64_t *total, void *stream);
+/* Stream-side pacing for the free-running rollout (no reference counterpart: main_DDPGfD.py:424-486 alternates acting and learning on one
+ * thread): a one-wave, LDS-free kernel on `stream` that returns when min_i values[i] >= target (ks_rollout_args.steps_total: every env has
+ * done that many env-steps of the persistent rollout launch) or after timeout_s of wall clock - whatever follows on the stream (the
+ * learner's next update, the commit of published episodes) then stays within a bounded distance of the SLOWEST env however long the launch is. */
+int kr_wait_min(const int64_t *values, int32_t n, int64_t target, double timeout_s, void *stream);
 
 /* ring rows ep_* [capacity(+), H, ...], ep_len int64; kept env i goes to slot (head + rank[i] - 1) % capacity */
 int kr_commit_episodes(int32_t n, int32_t horizon, int32_t capacity, const uint8_t *keep, const int64_t *rank, const int64_t *head,

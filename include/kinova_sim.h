@@ -172,7 +172,7 @@ typedef struct {
     /* engine state (kinovagrasping_amd.rollout.RolloutEngine) */
     float *obs, *prev_obs;           /* [n, 82] */
     uint8_t *has_prev, *ready, *lifting;
-    int64_t *t, *steps_total;        /* [n] steps in the episode / since the start (the noise counter) */
+    int64_t *t, *steps_total;        /* [n] steps in the episode / since the start (the noise counter; stored device-visibly: kr_wait_min paces the learner's stream on it) */
     float *action, *action_t;        /* [n, 4], [4, n] */
     float *reward_out; uint8_t *done_out;
     /* ks_step's outputs (as passed to ks_step) */

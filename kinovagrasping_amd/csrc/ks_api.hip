@@ -734,7 +734,7 @@ __device__ __noinline__ void rollout_store(const ks_rollout_args* __restrict__ r
     }
     ra.has_prev[i] = !done;
     ra.t[i] = done ? 0 : ra.t[i] + 1;
-    ra.steps_total[i] += 1;
+    __hip_atomic_store(&ra.steps_total[i], ra.steps_total[i] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (device-visible: kr_wait_min polls it from another stream)
     ra.ready[i] = (ra.ready[i] != 0) && !done;
     ra.reward_out[i] = rew;
     ra.done_out[i] = done;

@@ -307,6 +307,25 @@ __global__ __launch_bounds__(256) void k_soft_update(long count, const float* __
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) tp[i] = tau * p[i] + (1.0f - tau) * tp[i];
 }
 
+// one wave, no LDS: every lane scans its share of the values (agent-scope loads: the writers' stores are device-visible), the wave takes
+// the minimum with shuffles; the launch ends when it has reached the target or the wall clock runs out
+__global__ __launch_bounds__(64) void k_wait_min(const int64_t* __restrict__ values, int n, int64_t target, long long ticks) {
+    const long long t0 = wall_clock64();
+    for (;;) {
+        long long m = 0x7fffffffffffffffll;
+        for (int i = threadIdx.x; i < n; i += 64) {
+            const long long v = __hip_atomic_load(values + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            m = v < m ? v : m;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long other = __shfl_xor(m, o);
+            m = other < m ? other : m;
+        }
+        if (m >= target || (ticks > 0 && wall_clock64() - t0 > ticks)) break;      // (wave-uniform)
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
 inline int grid_for(long count) { long b = (count + 255) / 256; return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
 
 inline int launched() { return hipGetLastError() == hipSuccess ? KS_OK : KS_ERR_HIP; }
@@ -336,6 +355,12 @@ int kr_store_transition(int32_t n, int32_t horizon, int32_t n_steps, int32_t aut
     hipLaunchKernelGGL(k_store_transition, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, n, horizon, n_steps, auto_reset, with_replay, sim_obs,
                        sim_final_obs, sim_reward, sim_done, obs, prev_obs, has_prev, t, ready, lifting, action, cur_state, cur_next, cur_action,
                        cur_reward, cur_not_done, cur_len, reward_out, done_out, keep);
+    return launched();
+}
+
+int kr_wait_min(const int64_t* values, int32_t n, int64_t target, double timeout_s, void* stream) {
+    if (!values || n <= 0) return KS_ERR_INVALID;
+    hipLaunchKernelGGL(k_wait_min, dim3(1), dim3(64), 0, (hipStream_t)stream, values, n, target, (long long)(timeout_s * 1e8));   // wall_clock64: 100 MHz
     return launched();
 }
 

@@ -27,6 +27,8 @@ that is a whole episode old (100 updates at the end of each episode, main_DDPGfD
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 
@@ -107,7 +109,6 @@ class GraphedTrainer:
         # cannot (its kernels need LDS).  Self-tested against the process group at start-up; KS_P2P=0 keeps the library path.
         self.exchange_note = "none (single rank)"
         if self.distributed:
-            import os
             import torch.distributed as dist
             backend = dist.get_backend(policy.process_group)
             want = os.environ.get("KS_P2P", "1" if backend == "nccl" else "0") != "0"
@@ -158,7 +159,6 @@ class GraphedTrainer:
         # The learner's GEMMs are small and skinny (M = 1600 / 8000 rows, N, K <= 256): let PyTorch's TunableOp time the
         # hipBLASLt / rocBLAS candidates for each shape during the eager warm-up and keep the fastest; tuning is
         # switched off again before the captures (the selections stay in use).  KS_TUNABLEOP=0 skips it.
-        import os
         tune = os.environ.get("KS_TUNABLEOP", "1") != "0" and hasattr(torch.cuda, "tunable")
         if tune:
             torch.cuda.tunable.enable(True)
@@ -343,7 +343,6 @@ class AsyncTrainer(GraphedTrainer):
             raise ValueError("AsyncTrainer needs the LDS-free learner kernels (hidden widths 256-256 / 128-128 / 64-64): the persistent rollout kernel "
                              "holds every CU's LDS for the whole launch, a learner built on library GEMMs could only run behind it")
         if self.distributed and self.native.exchange is None:
-            import os
             import torch.distributed as dist
             if dist.get_backend(policy.process_group) == "nccl" and os.environ.get("KS_ASYNC_LIBRARY_ALLREDUCE", "0") == "0":
                 # (a host-side backend such as gloo has no kernels to starve; KS_ASYNC_LIBRARY_ALLREDUCE=1 overrides)
@@ -380,6 +379,12 @@ class AsyncTrainer(GraphedTrainer):
         a.cur_state, a.cur_next, a.cur_action = P(replay.a_state), P(replay.a_next), P(replay.a_action)
         a.cur_reward, a.cur_not_done, a.cur_len = P(replay.a_reward), P(replay.a_not_done), P(replay.a_len)
         a.cur_sel, a.pub_len, a.counters = P(replay.a_sel), P(replay.pub_len), P(self.counters)
+        # pacing: the learner's stream waits (kr_wait_min on the envs' step counters) so that update k of a launch starts when EVERY env
+        # has done k - lead env-steps.  Without it the learner (0.9 ms per update) finishes its share of a long launch far ahead of the
+        # rollout (1.1 ms per env-step) and nobody collects the episodes published after that.
+        from .sim import load_library
+        self._lib = load_library()
+        self.pace_lead = int(os.environ.get("KS_ASYNC_LEAD", "8"))           # < 0: no pacing
         self.args = a
         self.env_steps = 0
 
@@ -393,7 +398,6 @@ class AsyncTrainer(GraphedTrainer):
 
     def capture(self, warmup_updates=2):
         """captures the learner's update (head + body); the rollout is a single launch and needs no graph"""
-        import os
         # the learner's LDS-free kernels must fit beside the persistent kernel's waves: 368 of the 512 registers per lane are taken
         # for the whole launch, the 4-wave split forward / backward (160) does not fit, the one-wave variants (128) do - the choice
         # (mlp._split_waves reads KS_MLP_SPLIT at every call) is baked into the captured graphs
@@ -449,15 +453,19 @@ class AsyncTrainer(GraphedTrainer):
         """n_steps env-steps of EVERY env (one persistent launch on the main stream) and, beside it on the learner's stream, n_steps
         updates: [episodes published so far -> ring, actor step + targets + sampling, publish the actor, body].  Returns after
         ENQUEUEING both; synchronise (or call again) to wait.  The two streams only meet at the start of the next run().
-        Keep n_steps <= ~60: the learner's stream is the faster one and collects no published episodes once its n_steps updates
-        are done - an env that finishes more episodes than it has open buffers (2) before the launch ends drops them
-        (counts()["episodes_dropped"])."""
+        The learner's stream is the faster one; it is paced on the envs' step counters (update k starts when every env has done
+        k - KS_ASYNC_LEAD env-steps, default 8), so published episodes keep being collected until a launch of any length
+        ends (an env that finishes more episodes than it has open buffers (2) while nobody collects drops them:
+        counts()["episodes_dropped"])."""
         main, side = self.main, self.side
         side.wait_stream(main)
         main.wait_stream(side)
         self.sim.rollout(n_steps, self.args)
+        n, done = self.eng.n, self.env_steps
         with torch.cuda.stream(side):
-            for _ in range(n_steps):
+            for k in range(n_steps):
+                if self.pace_lead >= 0 and k > self.pace_lead:
+                    self._lib.kr_wait_min(self.steps_total.data_ptr(), n, done + k - self.pace_lead, 5.0, torch.cuda.current_stream(self.dev).cuda_stream)
                 self.g_commit.replay()
                 if learn:
                     self.g_head.replay()

@@ -135,3 +135,24 @@ def test_episodes_committed_beside_the_running_kernel_are_whole():
     assert ((R == 0) | ~inner).all()
     print(f"{replay.count} committed episodes whole; lengths {L.min().item()}..{L.max().item()}, lifted {c['lifted']}")
     sim.close()
+
+
+def test_long_launches_drop_no_episode():
+    """One launch of 240 env-steps with the learner beside it: the learner's stream (the faster one) is paced on the envs' step
+    counters (kr_wait_min), so the episodes published late in the launch are still collected - without pacing the learner is done
+    ~45 env-steps before the rollout and envs run out of open buffers (61 episodes dropped in the bench's 240-step run)."""
+    from kinovagrasping_amd.pipeline import AsyncTrainer
+    n = 4096
+    sim, policy, replay, eng = _setup(n, 30)
+    tr = AsyncTrainer(sim, policy, replay, eng, batch_episodes=64)
+    tr.capture()
+    tr.run(36, learn=False)
+    tr.flush()
+    tr.run(240)
+    tr.flush(finish_update=True)
+    torch.cuda.synchronize()
+    c = tr.counts()
+    print("240-step launch:", c)
+    assert torch.equal(tr.steps_total, torch.full_like(tr.steps_total, 276)) and tr.updates == 240
+    assert c["episodes_dropped"] == 0 and c["episodes_finished"] >= 9 * n
+    sim.close()
