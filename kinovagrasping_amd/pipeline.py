@@ -464,7 +464,7 @@ class AsyncTrainer(GraphedTrainer):
         n, done = self.eng.n, self.env_steps
         with torch.cuda.stream(side):
             for k in range(n_steps):
-                if self.pace_lead >= 0 and k > self.pace_lead:
+                if self.pace_lead >= 0 and k > self.pace_lead and (k - self.pace_lead) % 4 == 1:      # (every 4th update: the lead varies between 8 and 11)
                     self._lib.kr_wait_min(self.steps_total.data_ptr(), n, done + k - self.pace_lead, 5.0, torch.cuda.current_stream(self.dev).cuda_stream)
                 self.g_commit.replay()
                 if learn:
