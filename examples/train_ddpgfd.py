@@ -29,7 +29,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from kinovagrasping_amd import scenarios                       # noqa: E402
 from kinovagrasping_amd.ddpgfd import DDPGfD                   # noqa: E402
-from kinovagrasping_amd.demonstrators import run_controller_episodes, run_naive_episodes  # noqa: E402
+from kinovagrasping_amd.demonstrators import run_controller_episodes  # noqa: E402
 from kinovagrasping_amd.evaluate import eval_policy            # noqa: E402
 from kinovagrasping_amd.replay import DeviceEpisodeReplay      # noqa: E402
 from kinovagrasping_amd.rollout import RolloutEngine           # noqa: E402

@@ -6,7 +6,6 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-import numpy as np
 import torch
 
 from . import build as _build
