@@ -156,3 +156,53 @@ def test_long_launches_drop_no_episode():
     assert torch.equal(tr.steps_total, torch.full_like(tr.steps_total, 276)) and tr.updates == 240
     assert c["episodes_dropped"] == 0 and c["episodes_finished"] >= 9 * n
     sim.close()
+
+
+def test_wait_min_kernel_holds_its_stream_until_every_counter_has_arrived_or_the_clock_runs_out():
+    """kr_wait_min (include/kinova_rollout.h): what follows it on a stream starts when min(values) >= target - or after the time-out."""
+    import time
+    from kinovagrasping_amd.sim import load_library
+    L = load_library()
+    dev = torch.device("cuda", 0)
+    vals = torch.zeros(300, dtype=torch.long, device=dev)
+    flag = torch.zeros(1, device=dev)
+    waiter, writer = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(waiter):
+        assert L.kr_wait_min(vals.data_ptr(), 300, 5, 20.0, waiter.cuda_stream) == 0
+        flag.add_(1.0)
+        done = torch.cuda.Event()
+        done.record(waiter)
+    time.sleep(0.05)
+    assert not done.query()                                   # still waiting: nobody has counted yet
+    with torch.cuda.stream(writer):
+        vals[:299] += 7                                       # all but one
+    writer.synchronize()
+    time.sleep(0.05)
+    assert not done.query()                                   # the minimum is what counts
+    with torch.cuda.stream(writer):
+        vals[299:] += 5
+    writer.synchronize()
+    t0 = time.perf_counter()
+    while not done.query() and time.perf_counter() - t0 < 5.0:
+        time.sleep(0.001)
+    assert done.query() and flag.item() == 1.0
+    # the time-out: a target that never arrives releases the stream after ~0.2 s
+    t0 = time.perf_counter()
+    with torch.cuda.stream(waiter):
+        assert L.kr_wait_min(vals.data_ptr(), 300, 1000, 0.2, waiter.cuda_stream) == 0
+    waiter.synchronize()
+    assert 0.15 < time.perf_counter() - t0 < 2.0
+    assert L.kr_wait_min(None, 300, 1, 1.0, None) != 0 and L.kr_wait_min(vals.data_ptr(), 0, 1, 1.0, None) != 0
+
+
+def test_trainer_picks_a_learner_stream_that_overlaps_the_rollout_stream():
+    """torch hands out pooled streams round-robin and the GPU has few hardware queues: after other code has created streams, a new one can
+    share the rollout stream's queue and the learner would run BEHIND the persistent kernel (episodes dropped).  The trainers probe."""
+    from kinovagrasping_amd.pipeline import AsyncTrainer
+    junk = [torch.cuda.Stream(torch.device("cuda", 0)) for _ in range(37)]          # shift the pool's round-robin
+    sim, policy, replay, eng = _setup(256, 30)
+    tr = AsyncTrainer(sim, policy, replay, eng, batch_episodes=16)
+    assert tr.streams_overlap is True
+    del junk
+    sim.close()
