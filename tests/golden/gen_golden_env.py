@@ -23,7 +23,7 @@ from types import SimpleNamespace
 
 import numpy as np
 
-REPO = Path(__file__).resolve().parents[1]
+REPO = Path(__file__).resolve().parents[2]
 REF = Path("/root/reference/gym-kinova-gripper")
 sys.path.insert(0, str(REPO))
 

@@ -245,7 +245,7 @@ def test_free_running_episode_observations_in_every_pose(orientation):
 
 
 def test_env_layer_golden_vectors_through_the_hip_observation_kernel():
-    """tests/golden/env_layer.npz holds what the REFERENCE's own _get_obs / _get_reward returned (tools/gen_golden_env.py
+    """tests/golden/env_layer.npz holds what the REFERENCE's own _get_obs / _get_reward returned (tests/golden/gen_golden_env.py
     ran kinova_gripper_env.py) for 72 engine states x 4 shapes x 3 hand poses, both palm-sensor branches, the lift
     threshold straddled.  The same engine states (body poses + the 26 sensor values) go through the HIP observation
     kernel (ks_obs_from_snapshot -> k_obs -> build_obs) in both precisions."""

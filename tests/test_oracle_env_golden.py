@@ -1,5 +1,5 @@
 """The oracle's env layer (oracle/ko_env.c) against golden vectors produced by the reference's own
-Python (tools/gen_golden_env.py -> tests/golden/env_layer.npz).  CPU only."""
+Python (tests/golden/gen_golden_env.py -> tests/golden/env_layer.npz).  CPU only."""
 import numpy as np
 import pytest
 

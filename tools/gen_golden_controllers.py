@@ -3,7 +3,7 @@
 (expert_data.get_action with ExpertPIDController / NaiveController, expert_data.py:318-671) on random inputs.
 
 Only the input/output vectors are committed; the reference is read from /root/reference by absolute path
-(same stub modules as tools/gen_golden_env.py).  The controllers look at obs[21] (object x in the palm frame),
+(same stub modules as tests/golden/gen_golden_env.py).  The controllers look at obs[21] (object x in the palm frame),
 obs[78], obs[79] (distal finger / object alignment), obs[81] (object / palm alignment), the controller's
 initial obs[21], obs[81] and the lift flag.
 """
@@ -18,7 +18,7 @@ import numpy as np
 
 REPO = Path(__file__).resolve().parents[1]
 REF = Path("/root/reference/gym-kinova-gripper")
-sys.path.insert(0, str(REPO / "tools"))
+sys.path.insert(0, str(REPO / "tests" / "golden"))
 from gen_golden_env import install_stubs  # noqa: E402
 
 

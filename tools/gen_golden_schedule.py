@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dev-only: known answers of the reference's object scheduling (Generate_Latin_Square, kinova_gripper_env.py:895-964)
 and orientation selection (select_orienation, 1180-1222) -> tests/golden/schedule.npz.  Same stub import as
-tools/gen_golden_env.py; the env object is built with __new__ (no MuJoCo)."""
+tests/golden/gen_golden_env.py; the env object is built with __new__ (no MuJoCo)."""
 import os
 import sys
 import tempfile
@@ -11,7 +11,7 @@ import numpy as np
 
 REPO = Path(__file__).resolve().parents[1]
 REF = Path("/root/reference/gym-kinova-gripper")
-sys.path.insert(0, str(REPO / "tools"))
+sys.path.insert(0, str(REPO / "tests" / "golden"))
 from gen_golden_env import install_stubs  # noqa: E402
 
 
