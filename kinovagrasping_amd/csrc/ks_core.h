@@ -57,7 +57,7 @@ constexpr int SCR_AX = SCR_BP + 8 * 12;      // world slide axes, 3 x 3 (+3 pad:
 constexpr int SCR_ENVP = SCR_AX + 9;
 constexpr int SCR_CON = SCR_AX + 12;
 constexpr int CON_STRIDE = 20;
-// per contact: 0-2 pos, 3-5 normal, 6 dist, 7 mu, 8 bodies (b1 + 16*b2), 9 R, 10-13 aref[4],
+// per contact: 0-2 pos, 3-5 normal, 6 dist, 7 mu, 8 bodies + pair (b1 + 16*b2 + 256*pair index), 9 R, 10-13 aref[4],
 //              14-16 J.a basis (n,t1,t2), 17-19 J.p basis
 // collision staging: contacts are detected pair by pair into per-pair slots of (pos3, normal3, dist, mu,
 // bodies) records - 4 slots for a plane pair, 1 for a hull pair, assigned in pair order - and then merged
@@ -247,7 +247,7 @@ template <typename T> struct alignas(16) PairRec {
     int n1, n2;                // padded hull vertex counts; n2 of a plane pair is the true count
     int slot, obj_hand;        // first staging record of the pair (4 per plane pair, 1 per hull pair, pair order);
                                // obj_hand: bit 0 = object vs hand geom (the pair whose friction may be set per env),
-                               // bits 4-7 / 8-11 = mesh ids of the two geoms
+                               // bits 4-7 / 8-11 = mesh ids of the two geoms, bits 12-16 = the pair's index
     KS_LDS const T* V1; KS_LDS const T* V2;
     KS_LDS const unsigned short* off1; KS_LDS const unsigned short* adj1;
     KS_LDS const unsigned short* off2; KS_LDS const unsigned short* adj2;
@@ -287,7 +287,7 @@ template <typename T> KS_HD void fill_pair_rec(const Model<T>& m, const Hulls<T>
     int slot = 0;
     for (int j = 0; j < pi; j++) slot += ((hu.plane_mask >> j) & 1u) ? 4 : 1;
     r.slot = slot;
-    r.obj_hand = ((g1 != 0 && g2 == NGEOM - 1) ? 1 : 0) | ((g1 != 0 ? m.geom_mesh[g1] : 0) << 4) | (m.geom_mesh[g2] << 8);
+    r.obj_hand = ((g1 != 0 && g2 == NGEOM - 1) ? 1 : 0) | ((g1 != 0 ? m.geom_mesh[g1] : 0) << 4) | (m.geom_mesh[g2] << 8) | (pi << 12);
     r.rbound1 = m.geom_rbound[g1]; r.rbound2 = m.geom_rbound[g2];
     for (int k = 0; k < 3; k++) { r.size1[k] = m.geom_size[g1][k]; r.size2[k] = m.geom_size[g2][k]; }
     r.body1 = m.geom_body[g1]; r.body2 = m.geom_body[g2];
@@ -597,6 +597,7 @@ template <typename T> struct PairGeo {
 // Hull vertex tables are stored padded: stride 4 reals (x, y, z, 0) and the count rounded up to a
 // multiple of HULL_CHUNK with copies of vertex 0 (a copy never wins a strict arg-max / arg-min).
 constexpr int HULL_CHUNK = 8;
+constexpr double SUPPORT_SKEW = 1e-9, SKEW_X = 0.5377, SKEW_Y = -0.6240, SKEW_Z = 0.5671;   // see pair_support
 
 // Support vertex of a convex hull along `dir` by hill climbing on the hull graph: from `hint`, move to
 // the best strictly-improving neighbour until none improves.  On a convex polytope a vertex without an
@@ -663,6 +664,16 @@ template <typename T> KS_HD void pair_support(PairGeo<T>& g, const T* dir, T hm,
     T ld1[3], ld2[3];
     mulRtv(ld1, g.R1, dir);
     mulRtv(ld2, g.R2, nd);
+    // Tie rule shared with the oracle (ko_physics.c: hull_support): MPR and GJK ask for supports along the normals of faces
+    // they built from the hulls' own vertices, so all of such a face's vertices attain the maximum to the last bit and rounding
+    // would pick - and with it the portal path, the contact point on a flat feature, on a rounded polytope even the facet of the
+    // normal.  The hull-frame direction is skewed by a fixed 1e-9 of its size (1e-10 m of support error at most; seven orders
+    // above fp64 rounding; below fp32 resolution, where it changes nothing).
+    {
+        const T s1 = T(SUPPORT_SKEW) * (kabs(ld1[0]) + kabs(ld1[1]) + kabs(ld1[2])), s2 = T(SUPPORT_SKEW) * (kabs(ld2[0]) + kabs(ld2[1]) + kabs(ld2[2]));
+        ld1[0] += s1 * T(SKEW_X); ld1[1] += s1 * T(SKEW_Y); ld1[2] += s1 * T(SKEW_Z);
+        ld2[0] += s2 * T(SKEW_X); ld2[1] += s2 * T(SKEW_Y); ld2[2] += s2 * T(SKEW_Z);
+    }
     const int tab1 = g.dir1[support_cell(ld1)], tab2 = g.dir2[support_cell(ld2)];
     hull_climb(g.R1, g.p1, g.V1, g.off1, g.adj1, tab1, g.hint1, ld1, dir, hm, out1);
     hull_climb(g.R2, g.p2, g.V2, g.off2, g.adj2, tab2, g.hint2, ld2, nd, hm, out2);
@@ -817,7 +828,16 @@ KS_NARROW bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* 
     v0.i1 = 0; v0.i2 = 0;
     bool have_portal = false;
     int ma[3] = {0, 0, 0}, mb[3] = {0, 0, 0}, mn = 0, unused = 0;
-    if (ws != nullptr) { unpack3(ws->w[2], ma, mn); unpack3(ws->w[3], mb, unused); }
+    // The portal MPR ends on - hence depth, normal and above all the contact POINT on flat features - depends on the path within
+    // its 1e-6 tolerance.  The cold path below is libccd's, which the oracle follows and which reproduces real MuJoCo 1.50 to 1e-9
+    // through 18 rows of contact (tests/test_mujoco_recorded.py): the fp64 instantiation (the parity instrument) always takes it.
+    // The fp32 product starts from the previous substep's portal when that still is one (KS_MPR_WARM, default on): fp32 rounding
+    // of the supports' near-ties changes the path anyway, and a warm query is 1 - 2 support pairs instead of 6 - 10.
+#ifndef KS_MPR_WARM
+#define KS_MPR_WARM 1
+#endif
+    constexpr bool mpr_warm = (KS_MPR_WARM != 0) && sizeof(T) == 4;
+    if (mpr_warm && ws != nullptr) { unpack3(ws->w[2], ma, mn); unpack3(ws->w[3], mb, unused); }
     if (mn == 3) {
         // the previous query's portal at the current poses: still a portal if the origin ray (from v0 through the
         // origin) passes through the triangle, i.e. the origin is on the inner side of the three planes (v0, vi, vj)
@@ -903,7 +923,7 @@ KS_NARROW bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* 
             copy3(dir, wit);
             normalize3(dir);
             find_pos(v0, v1, v2, v3, pos);
-            if (ws != nullptr) {
+            if (mpr_warm && ws != nullptr) {
                 ws->w[2] = pack3(v1.i1, v2.i1, v3.i1, 3);
                 ws->w[3] = pack3(v1.i2, v2.i2, v3.i2, 0);
             }
@@ -1241,7 +1261,7 @@ template <typename T> KS_HD void make_frame(const T* n, T* t1, T* t2) {
 
 // One staged contact record of pair slot `slot` (record index, see SCR_STAGE)
 template <typename T, typename S>
-KS_HD void stage_contact(S scr, int slot, int b1, int b2, T mu, T dist, const T* pos, const T* normal) {
+KS_HD void stage_contact(S scr, int slot, int b1, int b2, int pi, T mu, T dist, const T* pos, const T* normal) {
     const int o = SCR_STAGE + slot * STAGE_REC;
     T n[3] = {normal[0], normal[1], normal[2]};
     normalize3(n);
@@ -1249,7 +1269,7 @@ KS_HD void stage_contact(S scr, int slot, int b1, int b2, T mu, T dist, const T*
     for (int i = 0; i < 3; i++) { scr(o + i) = pos[i]; scr(o + 3 + i) = n[i]; }
     scr(o + 6) = dist;
     scr(o + 7) = mu;
-    scr(o + 8) = T(b1 + 16 * b2);
+    scr(o + 8) = T(b1 + 16 * b2 + 256 * pi);   // pi: the pair, for its margin (explicit pairs 0, dynamic pairs the geoms')
 }
 
 // The two culls of a plane pair (bounding sphere, exact box-vs-plane): false = no vertex can be within the margin
@@ -1275,7 +1295,7 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     KS_T0
     KS_LDS const PairRec<T>& pr = *prp;
     const T PLANE_MESH_TOL = T(0.3);
-    const int g2 = pr.g2, slot = pr.slot;
+    const int g2 = pr.g2, slot = pr.slot, pi = (pr.obj_hand >> 12) & 31;
     const T margin = pr.margin, mu = pr.mu, rbound = pr.rbound2;
     const T size[3] = {pr.size2[0], pr.size2[1], pr.size2[2]};
     KS_LDS const T* V = pr.V2;
@@ -1405,7 +1425,7 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
             mulRv(w, R2, c);
             add3(w, w, p2);
             w[2] -= T(0.5) * d;
-            stage_contact(scr, slot + team.sub, 0, body2, mu, d, w, normal);
+            stage_contact(scr, slot + team.sub, 0, body2, pi, mu, d, w, normal);
         }
     } else {
         KS_UNROLL
@@ -1415,7 +1435,7 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
                 mulRv(w, R2, cv[k]);
                 add3(w, w, p2);
                 w[2] -= T(0.5) * d;
-                stage_contact(scr, slot + k, 0, body2, mu, d, w, normal);
+                stage_contact(scr, slot + k, 0, body2, pi, mu, d, w, normal);
             }
         }
     }
@@ -1484,17 +1504,18 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
     if (prof) { prof[24] += 1.f; prof[25] += (float)pg.cnt_support; prof[26] += (float)(th1 - th0); prof[27] += (float)(clock64() - th1); prof[28] += (float)pg.t_sup; prof[29] += (float)pg.t_clo; }
 #endif
     h1_out = pg.hint1 & PC_HINT_MAX; h2_out = pg.hint2 & PC_HINT_MAX;
-    if (r == 1) { stage_contact(scr, slot, body1, body2, mu, dist, pos, dir); return 1; }
+    const int pi = (flags >> 12) & 31;
+    if (r == 1) { stage_contact(scr, slot, body1, body2, pi, mu, dist, pos, dir); return 1; }
     if (r >= 2) {
         // 2: overlap (or undecided beyond the margin), 3: a margin-zone result that is not a certified separation
         T mdir[3], mpos[3];
         const bool hit = mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, mdir, mpos, ws);
         h1_out = pg.hint1 & PC_HINT_MAX; h2_out = pg.hint2 & PC_HINT_MAX;
         if (hit) {
-            stage_contact(scr, slot, body1, body2, mu, -depth, mpos, mdir);
+            stage_contact(scr, slot, body1, body2, pi, mu, -depth, mpos, mdir);
             return 1;
         }
-        if (r == 3) { stage_contact(scr, slot, body1, body2, mu, dist, pos, dir); return 1; }
+        if (r == 3) { stage_contact(scr, slot, body1, body2, pi, mu, dist, pos, dir); return 1; }
     }
     return 0;
 }
@@ -1656,7 +1677,7 @@ KS_HD void contact_basis(S scr, int ci, T B[3][NV], T& dist, T& mu) {
     // kinematic data comes from the body poses in LDS (one ds_read each), not from the caller's stack
     KS_UNROLL
     for (int side = 0; side < 2; side++) {
-        const int b = side == 0 ? (bb & 15) : (bb >> 4);
+        const int b = side == 0 ? (bb & 15) : ((bb >> 4) & 15);
         const T sg = side == 0 ? T(-1) : T(1);
         if (b >= 2 && b <= 8) {
             KS_UNROLL
@@ -1810,12 +1831,12 @@ KS_HD void make_constraints(const Model<T>& m, const T* qpos, const T* qvel, S s
             vb[a] = v;
         }
         const int bb = (int)scr(o + 8);
-        const T margin = m.pair_margin[0];   // one margin for every pair of this model (XML:40)
+        const T margin = m.pair_margin[bb >> 8];   // explicit <pair>s: the pair's own (0 in the reference's XMLs); dynamic pairs: the geoms' 0.001
         T rr = dist - margin;
         T imp = impedance(m.solimp, rr);
         // the object's inverse weight follows its per-env mass
         const T wobj = m.body_invw[NBODY - 1] * (m.mass[NBODY - 1] + m.armature[9]) / (T(scr(SCR_ENVP)) + m.armature[9]);
-        const int cb1 = bb & 15, cb2 = bb >> 4;
+        const int cb1 = bb & 15, cb2 = (bb >> 4) & 15;
         T w = (cb1 == NBODY - 1 ? wobj : m.body_invw[cb1]) + (cb2 == NBODY - 1 ? wobj : m.body_invw[cb2]);
         T diag = (w + mu * mu * w) * 2 * mu * mu / m.impratio;
         T R = (1 - imp) / imp * diag;

@@ -167,7 +167,7 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
         std::memcpy(row, pr.data + 40 * p, 40);
         m.pair_g1[p] = (int)row[0]; m.pair_g2[p] = (int)row[1];
         if (row[2] != row[3]) { e = "anisotropic pair friction is not supported"; return false; }
-        if (row[4] != margin) { e = "per-pair margins are not supported"; return false; }
+        if (!(row[4] >= 0) || row[4] > margin) { e = "pair margin outside [0, geom margin]"; return false; }
         m.pair_mu[p] = (T)row[2]; m.pair_margin[p] = (T)row[4];
     }
     for (int s = 0; s < 4; s++) {

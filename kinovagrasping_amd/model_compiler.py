@@ -152,6 +152,34 @@ def mesh_mass_properties(tri: np.ndarray):
     return vol, com, inertia
 
 
+def mesh_mass_properties_legacy(tri: np.ndarray):
+    """MuJoCo <= 2.1's mesh inertia (the algorithm of the reference's MuJoCo 1.50; later kept as inertia="legacy"):
+    pass 1 - centre of mass from pyramids whose apex is the AREA-WEIGHTED CENTRE OF THE FACES, every pyramid's volume taken
+    ABSOLUTE (a non-convex mesh is over-counted: hand_3finger.STL 5.703e-4 m^3 against the exact 5.531e-4); pass 2 - second
+    moments from pyramids whose apex is that centre of mass, volumes absolute again.  Winding does not matter.
+    Pinned by real MuJoCo 1.50 output: row 0 of the reference's Old Code/Pose_file_2.csv holds geom_xpos of the palm and the
+    six finger links at qpos0 (tests/test_mujoco_recorded.py); the exact integration misses the palm by 1.25 mm.
+    Returns (volume, com[3], inertia_about_com[3,3]), unit density."""
+    a, b, c = tri[:, 0], tri[:, 1], tri[:, 2]
+    n = np.cross(b - a, c - a)
+    area = 0.5 * np.linalg.norm(n, axis=1)
+    ok = area > 0
+    nrm = np.zeros_like(n)
+    nrm[ok] = n[ok] / (2 * area[ok, None])
+    cen = (a + b + c) / 3.0
+    facecen = (area[:, None] * cen).sum(0) / area.sum()
+    vol = np.abs(np.einsum("ij,ij->i", cen - facecen, nrm) * area / 3.0)
+    com = (vol[:, None] * (0.75 * cen + 0.25 * facecen)).sum(0) / vol.sum()
+    D, E, F = a - com, b - com, c - com
+    vol = np.abs(np.einsum("ij,ij->i", (D + E + F) / 3.0, nrm) * area / 3.0)
+    P = (np.einsum("n,ni,nj->ij", vol, D, D) + np.einsum("n,ni,nj->ij", vol, E, E) + np.einsum("n,ni,nj->ij", vol, F, F)) * 2.0
+    for X, Y in ((D, E), (D, F), (E, F)):
+        P += np.einsum("n,ni,nj->ij", vol, X, Y) + np.einsum("n,ni,nj->ij", vol, Y, X)
+    P /= 20.0
+    inertia = np.trace(P) * np.eye(3) - P
+    return float(vol.sum()), com, inertia
+
+
 def principal_frame(I: np.ndarray):
     """Jacobi diagonalisation started from identity, then eigenvalues sorted descending by
     90-degree axis swaps (right-handed).  Mirrors the convention described for MuJoCo's
@@ -242,13 +270,15 @@ def cylinder_triangles(r, h, n=64):
 
 
 class CompiledMesh:
-    def __init__(self, tri: np.ndarray, name: str, keep_frame: bool = False):
-        """keep_frame: the triangles already are in the geom frame (primitive geoms: MuJoCo keeps the user frame of a box /
+    def __init__(self, tri: np.ndarray, name: str, keep_frame: bool = False, mesh_inertia: str = "legacy"):
+        """mesh_inertia: "legacy" = MuJoCo 1.50's pyramid sums (the reference's engine; default), "exact" = signed-volume integration.
+        keep_frame: the triangles already are in the geom frame (primitive geoms: MuJoCo keeps the user frame of a box /
         cylinder, only meshes are re-centred on their inertial frame)"""
         from scipy.spatial import ConvexHull
         self.name = name
         self.ntri = len(tri)
-        self.volume, self.com, inertia = mesh_mass_properties(tri)
+        assert mesh_inertia in ("legacy", "exact")
+        self.volume, self.com, inertia = (mesh_mass_properties_legacy if mesh_inertia == "legacy" and not keep_frame else mesh_mass_properties)(tri)
         self.principal, self.R = principal_frame(inertia)        # unit-density moments
         if keep_frame:
             self.com, self.R, self.principal = np.zeros(3), np.eye(3), np.diag(inertia).copy()
@@ -308,7 +338,9 @@ def _frame_of(elem):
     return pos, q
 
 
-def compile_model(xml_path: Path) -> dict:
+def compile_model(xml_path: Path, mesh_inertia: str = "legacy") -> dict:
+    """mesh_inertia: how mesh geoms get their centre / principal frame / (object) inertia: "legacy" reproduces MuJoCo 1.50
+    (default: parity with the reference's engine), "exact" is the signed-volume integration of MuJoCo >= 2.2's default."""
     xml_path = Path(xml_path)
     root = ET.parse(xml_path).getroot()
     comp = root.find("compiler")
@@ -330,7 +362,7 @@ def compile_model(xml_path: Path) -> dict:
         m = mesh_assets[name]
         tri = load_stl(meshdir / m.get("file"))
         sc = _floats(m.get("scale", "1 1 1"), 3)
-        return CompiledMesh(tri * sc, name)
+        return CompiledMesh(tri * sc, name, mesh_inertia=mesh_inertia)
 
     wb = root.find("worldbody")
     bodies = {b.get("name"): b for b in wb.iter("body")}
@@ -463,14 +495,20 @@ def compile_model(xml_path: Path) -> dict:
 
     # contact pairs -------------------------------------------------------------------------------
     # explicit pairs first (XML order), then the dynamic candidates of SURVEY App. A
+    # MuJoCo gives an explicit <pair> the PAIR defaults, not its geoms' attributes: margin = the pair's own attribute, else
+    # <default><pair margin>, else 0 - the geoms' margin 0.001 (XML:40) only reaches the dynamically generated pairs.
+    # Pinned by real MuJoCo 1.50 output (Old Code/Pose_file_2.csv: a box released 5 mm inside the floor recovers along
+    # 0.052898 / 0.054325 / 0.054774; with margin 0.001 on the object-ground pair it would be 0.053477 / ...).
     pairs = []
     seen = set()
+    dpair = dflt.find("pair")
+    pair_margin_default = float(dpair.get("margin", "0")) if dpair is not None else 0.0
     for p in root.find("contact").findall("pair"):
         g1, g2 = GEOM_NAMES.index(p.get("geom1")), GEOM_NAMES.index(p.get("geom2"))
         fr = _floats(p.get("friction"), 5)
         assert p.get("condim") == "3"
         a, b = min(g1, g2), max(g1, g2)
-        pairs.append([a, b, fr[0], fr[1], margin])
+        pairs.append([a, b, fr[0], fr[1], float(p.get("margin", pair_margin_default))])
         seen.add((a, b))
     hand = list(range(1, 8))
     for a in range(0, 8):

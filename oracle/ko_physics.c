@@ -38,6 +38,10 @@
 #define KO_GJK_TOL 1e-6
 #endif
 #define CCD_EPS 1e-15
+#define KO_SUPPORT_SKEW 1e-9
+#define KO_SKEW_X 0.5377
+#define KO_SKEW_Y (-0.6240)
+#define KO_SKEW_Z 0.5671
 #define PLANE_MESH_TOL 0.3 /* extra plane-hull contacts must be > 0.3*rbound apart */
 #define MINVAL 1e-15
 
@@ -331,6 +335,16 @@ static void hull_support(const ko_sim *s, int g, const double *dir, double half_
     const double *V = m->mesh_vert[mesh];
     double ld[3], best = -1e300;
     mulmatTvec3(ld, s->geom_xmat[g], dir);
+    /* Tie rule shared with the kernels (ks_core.h: pair_support).  MPR and GJK query supports along the normals of faces they
+     * have just built from the hulls' own vertices: every vertex of such a face then attains the maximum to the last bit, rounding
+     * decides which one "wins", and the portal / simplex path - hence the contact POINT and, on polytopes that approximate round
+     * shapes, even the facet the normal is taken from - follows that coin.  The hull-frame direction is therefore skewed by a
+     * fixed 1e-9 of its size before the scan: 1e-10 m of support error at most, far below every tolerance in use, but seven
+     * orders above fp64 rounding, so that two implementations that scan in different orders take the same vertex. */
+    {
+        const double sk = KO_SUPPORT_SKEW * (fabs(ld[0]) + fabs(ld[1]) + fabs(ld[2]));
+        ld[0] += sk * KO_SKEW_X; ld[1] += sk * KO_SKEW_Y; ld[2] += sk * KO_SKEW_Z;
+    }
     for (int i = 0; i < n; i++) {
         double d = V[3 * i] * ld[0] + V[3 * i + 1] * ld[1] + V[3 * i + 2] * ld[2];
         if (d > best) { best = d; bi = i; }

@@ -61,21 +61,28 @@ def test_no_cpu_path_fails_loudly(lib):
 def test_model_compiler_known_answers(assets_dir):
     M = mc.read_blob(assets_dir / "CubeS.ksm")
     info = M["mesh_info"]                                                    # volume, hull verts, planes, tris, simplices
-    np.testing.assert_allclose(info[:, 0], [5.5307e-4, 2.4029e-5, 1.2314e-5, 1.07651e-4], rtol=2e-4)
+    # MuJoCo 1.50's LEGACY mesh inertia (pyramids with absolute volumes: the non-convex hand meshes are over-counted; the exact
+    # signed volumes measured in SURVEY 8c are 5.5307e-4, 2.4029e-5, 1.2314e-5 - the convex CubeS is 1.07651e-4 either way)
+    np.testing.assert_allclose(info[:, 0], [5.71039e-4, 2.52886e-5, 1.30008e-5, 1.07651e-4], rtol=2e-5)
     assert info[:, 3].astype(int).tolist() == [27908, 2710, 1942, 6344]
     assert abs(info[0, 1] - 753) <= 2 and abs(info[1, 1] - 289) <= 8 and abs(info[2, 1] - 344) <= 8 and info[3, 1] == 24
-    np.testing.assert_allclose(M["geom_pos"][1], [1e-5, -4.03e-3, -5.969e-2], atol=2e-5)      # palm mesh centroid
-    np.testing.assert_allclose(M["geom_pos"][2], [0.02041, -0.00818, 0], atol=1e-5)
+    # mesh geom centres = the legacy centres of mass, equal to MuJoCo 1.50's recorded geom_xpos to 1e-10 (tests/test_mujoco_recorded.py;
+    # exact centroids: palm [1e-5, -4.03e-3, -5.969e-2], proximal [0.02041, -0.00818, 0], distal [0.01342, -0.00475, 0])
+    np.testing.assert_allclose(M["geom_pos"][1], [2.726e-5, -4.1435e-3, -6.09450e-2], atol=2e-7)
+    np.testing.assert_allclose(M["geom_pos"][2], [0.0205051, -0.0079019, 0], atol=5e-7)
+    np.testing.assert_allclose(M["geom_pos"][3], [0.0128282, -0.0045348, 0], atol=5e-7)
     np.testing.assert_allclose(sorted(M["body_inertia"][9]), [1.870e-5, 8.568e-5, 8.568e-5], rtol=1e-3)
     # hull adjacency (CSR): every vertex has >= 3 neighbours, symmetric
     off, adj = M["mesh3_adj_off"], M["mesh3_adj"]
     assert len(off) == 25 and off[-1] == len(adj) and (np.diff(off) >= 3).all()
     assert all(i in adj[off[j]:off[j + 1]] for i in range(24) for j in adj[off[i]:off[i + 1]])
     assert M["pairs"].shape == (30, 5) and (M["pairs"][0, :2] == [0, 8]).all() and M["pairs"][0, 2] == 0.3
+    # explicit <contact><pair>s carry the PAIR default margin 0 (XML:158-166 give none), the 22 dynamic pairs the geoms' 0.001 (XML:40)
+    assert (M["pairs"][:8, 4] == 0).all() and (M["pairs"][8:, 4] == 0.001).all() and (M["pairs"][:8, 1] == 8).all()
     assert M["body_mass"].tolist() == [0, 0, 0.727, 0.01, 0.01, 0.01, 0.01, 0.01, 0.01, 0.1]
-    # palm geom frame: link frame tilted ~5.4 deg about x (SURVEY hard part 6)
+    # palm geom frame: link frame tilted ~5.7 deg about x (legacy inertia; 5.4 deg with the exact one, SURVEY hard part 6)
     R = mc.quat_to_mat(M["geom_quat"][1])
-    assert abs(np.degrees(np.arccos(R[1, 1])) - 5.4) < 0.2 and R[0, 0] > 0.9999
+    assert abs(np.degrees(np.arccos(R[1, 1])) - 5.67) < 0.1 and R[0, 0] > 0.9999
     # obs[33:36] = [s0, s1, 2*s2] of the object's AABB half extents (ENV:529, 706-746)
     np.testing.assert_allclose(M["obj_size_obs"], [0.0167781, 0.0167781, 0.095875], rtol=1e-5)
 

@@ -30,18 +30,40 @@ def grasp_states(blob, n_sub=330, iters=SOLVER_ITERATIONS):
         yield before, ctrl.copy(), (s.view("qpos").copy(), s.view("qvel").copy(), s.view("qacc_warmstart").copy()), s.s.ncon, hq
 
 
+def same_contact_points(con, contacts, tol=1e-9):
+    """Do the lane's contact records sit where the oracle's contacts do?  A penetrating hull pair gets ONE point from MPR; on parallel
+    features (a finger pad flat on a box face) the support queries along the face normal tie between the face's vertices to the
+    last bit, rounding decides which one comes back, and the portal MPR ends on - the same plane, another triangle of the face - puts
+    the point elsewhere on the face (same normal, depth within 1e-7); where the origin ray leaves a polytope that approximates a round
+    surface (the 64-gon cylinders) near an edge, the final portal can also sit on the neighbouring facet (normal a few degrees off).
+    MuJoCo's own result is decided by ITS rounding there.  Oracle and kernels share a tie rule since round 4 (a fixed 1e-9 skew of
+    the hull-frame support direction), so that no such state is left between the two in fp64; the tests count them and assert 0."""
+    return all(np.abs(con[k][:3] - c["pos"]).max() < tol and np.abs(con[k][3:6] - c["frame"][:3]).max() < 1e-7 for k, c in enumerate(contacts))
+
+
 def test_fp64_lane_reproduces_oracle_substeps(blob):
     """two independent formulations (dense generic oracle vs specialised analytic kernel) agree to round-off"""
     lane = Lane(blob, 64)
-    worst = 0
+    worst, ties, n = 0, 0, 0
+    m = ko.OracleModel(blob)
     for before, ctrl, after, ncon, hq in grasp_states(blob):
         qp, qv, qw, nc, con, st = lane.substep(*before, ctrl, hq)
         assert nc == ncon and st == 0
+        o = ko.OracleSim(m, hq, solver_iterations=SOLVER_ITERATIONS)
+        o.s.rays_enabled = 0
+        o.set_state(*before)
+        o.forward()
+        n += 1
+        if not same_contact_points(con, o.contacts()):
+            ties += 1
+            assert np.abs(qp - after[0]).max() < 1e-4 and all(abs(con[k][6] - c["dist"]) < 1e-6 for k, c in enumerate(o.contacts()))
+            continue
         worst = max(worst, np.abs(qp - after[0]).max())
         assert np.abs(qp - after[0]).max() < 1e-9
         assert np.abs(qv - after[1]).max() < 1e-7
         assert np.abs(qw - after[2]).max() < 1e-5
-    print("fp64 lane vs oracle, worst one-step qpos error", worst)
+    print(f"fp64 lane vs oracle, worst one-step qpos error {worst:.2e}; contact point elsewhere on a flat feature in {ties} of {n} states")
+    assert ties == 0        # since the shared support tie rule (ko_physics.c: hull_support, ks_core.h: pair_support)
 
 
 def test_fp32_lane_one_step_error_distribution(blob):
@@ -147,6 +169,7 @@ def test_primitive_objects_drop_rest_and_grasp(assets_dir, shape, n_ground):
     o.env_reset(q0)
     lane = Lane(blob, 64)
     ctrl = np.zeros(9); ctrl[5] = 0.2932
+    ties = 0
     for i in range(300):
         if i == 60:
             ctrl[6:9] = 0.6
@@ -154,12 +177,15 @@ def test_primitive_objects_drop_rest_and_grasp(assets_dir, shape, n_ground):
         o.step(ctrl)
         qp, qv, qw, nc, con, st = lane.substep(*before, ctrl, hq)
         assert nc == o.s.ncon and st == 0
-        assert np.abs(qp - o.view("qpos")).max() < 1e-9, (shape, i)
+        tie = not same_contact_points(con, o.contacts())
+        ties += tie
+        assert np.abs(qp - o.view("qpos")).max() < (1e-4 if tie else 1e-9), (shape, i)
         if i == 59:
             f = o.contact_forces()
             ground = [k for k, c in enumerate(o.contacts()) if c["geom1"] == 0 and c["geom2"] == 8]
             assert len(ground) == n_ground and abs(f[ground, 0].sum() - 0.1 * 9.81) < 1e-4 * 0.981
-            assert abs(o.view("qpos")[11] - half_h) < 1.1e-3                    # resting inside the 1 mm margin
+            assert -1e-5 < o.view("qpos")[11] - half_h < 0                      # resting 1 - 4 um INSIDE the floor (pair margin 0)
+    assert ties == 0, ties
     assert any(c["geom2"] == 8 and c["geom1"] in (2, 3, 4, 5, 6, 7) for c in o.contacts())      # the fingers reached the object
 
 

@@ -8,6 +8,12 @@
      distal joint lags q_prox / 2 by 1.35 mrad after the first row, ratio 0.4754 -> 0.4996), gravity on the finger links
      in the 'normal' hand orientation (finger 2 sags 1.5e-5 rad per row against its servo), and the fact that the jointpos
      sensors are evaluated BEFORE the integration of their substep (row r is qpos after 4 r - 1 substeps).
+  1b. Old Code/Pose_file_2.csv - 63 rows x 48 columns of the same env's state while a policy closes the hand on a box that finger 1
+     pushes across the floor, grasps and lifts: the ONLY contact trajectory of real MuJoCo in the tree (tests/old_env.py explains the
+     emulation of the old model and how the un-recorded commands are recovered from the four actuated joints).  Row 0 pins the mesh
+     geoms' frames (MuJoCo 1.50's legacy mesh inertia) to 1e-10 m; rows 1-3 (a box released 5 mm inside the floor) pin the explicit
+     pairs' margin 0 and the soft-contact arithmetic to round-off; rows 4-21 (84 substeps, finger-box edge contact with sliding
+     friction on the floor, the box hopping) agree in ALL 48 columns to 1.1e-9; row 22 is the first beyond 1e-6.
   2. expert_plots/*.npy - ten recorded demonstrations (expert_data.py:690-921): palm-frame start, outcome, env-steps.
   3. expert_plots/heatmap_plots/*.png - naive-controller success / failure rate per start cell for CubeS.
 
@@ -17,7 +23,9 @@ import pytest
 import torch
 
 from kinovagrasping_amd import demonstrators, scenarios
+from kinovagrasping_amd import model_compiler as mc
 from kinovagrasping_amd.sim import SOLVER_ITERATIONS
+from tests import old_env
 from tests.oracle_vec import OracleVecSim, place_at_palm_xy
 
 FREE_ROWS = 27           # rows 0..26: before finger 2 is commanded
@@ -104,16 +112,18 @@ def _demo_episodes(sim, rec, mode="naive"):
     return out["success"].cpu().numpy().astype(int), out["steps"].cpu().numpy()
 
 
-def _check_demos(succ, steps, rec):
+def _check_demos(succ, steps, rec, min_exact=6):
     ref_s, ref_t = rec["demo_success"], rec["demo_steps"]
     print("recorded outcome", ref_s, "steps", ref_t, "\nours     outcome", succ, "steps", steps)
-    # the eight recorded successes are successes here, six of them within 2 env-steps of the recorded duration
-    assert (succ[ref_s == 1] == 1).all()
-    d = np.abs(steps - ref_t)[ref_s == 1]
-    assert (d <= 3).sum() >= 7 and (d <= 2).sum() >= 6, d
-    # the two recorded failures sit in the near-palm centre zone where MuJoCo's naive controller fails (heat map); this
-    # simulator grasps there - a known behavioural deviation, asserted so that a change of it is noticed
+    # judged against the RECORDED outcomes only: at least 8 of the 10 agree, and the demonstrations that succeed in both last
+    # exactly as long as recorded in at least 6 cases (round 4, explicit pairs at margin 0 + MuJoCo 1.50's mesh frames: durations
+    # 23 24 . 23 23 . 28 24 equal the recorded ones).  The two disagreements are the pair of starts 2 mm apart deep in the hand
+    # (0.0106, 0.0312: recorded lift in 21 steps; 0.0089, 0.0336: recorded time-out) whose outcomes come out swapped - the edge of
+    # the near-palm failure zone of the recorded heat map.
     assert (succ == ref_s).sum() >= 8
+    both = (ref_s == 1) & (succ == 1)
+    d = np.abs(steps - ref_t)[both]
+    assert both.sum() >= 7 and (d == 0).sum() >= min_exact and (d <= 1).sum() >= min_exact, d
 
 
 def test_oracle_replays_the_recorded_demonstrations(rec):
@@ -123,14 +133,80 @@ def test_oracle_replays_the_recorded_demonstrations(rec):
 
 
 def test_recorded_demonstrations_under_mujocos_own_narrow_phase_scheme(rec):
-    """The oracle's study mode narrow_phase = 1 (libccd-style MPR on hulls inflated by margin / 2 in the margin zone AND on overlap:
-    MuJoCo 1.50's scheme; the product uses closest-feature GJK in the margin zone) replays the recorded demonstrations with the same
-    outcomes as the product scheme - the deviation is quantified in profiles/r03_narrow_phase.txt and does not change behaviour."""
+    """The oracle's study mode narrow_phase = 1 (libccd-style MPR on hulls inflated by margin / 2, in the margin zone AND on overlap:
+    MuJoCo 1.50's scheme).  Since the explicit object pairs carry margin 0 (round 4) the two schemes only differ for the hand's own
+    dynamic pairs (margin 0.001: closest-feature GJK in the product); the recorded demonstrations replay alike under both."""
     sim = OracleVecSim(10, "CubeS", solver_iterations=100, rays=False, narrow_phase=1)
     succ, steps = _demo_episodes(sim, rec)
-    _check_demos(succ, steps, rec)
-    ref_s, ref_t = rec["demo_success"], rec["demo_steps"]
-    assert (np.abs(steps - ref_t)[ref_s == 1] <= 1).sum() >= 6
+    _check_demos(succ, steps, rec, min_exact=5)
+
+
+# ---------------------------------------------------------------------------------- the recorded contact trajectory
+HEAT_MIN_SUCCESS_BAND, HEAT_MIN_CENTRE_FAIL, HEAT_MIN_CORNER_FAIL = 0.9, 0.5, 0.7      # measured: see profiles/r04_naive_heatmap.txt
+ROWS_EXACT = 22          # rows 0..21 of Pose_file_2: every column within 2e-9 (the dot product: 4e-9) of real MuJoCo
+
+
+def test_mesh_geom_frames_and_sites_match_mujocos_recorded_row_0(rec):
+    """qpos0 in the 'normal' pose: MuJoCo 1.50's geom_xpos of the six finger links and the palm (mesh geoms: centre = the LEGACY
+    mesh-inertia centre of mass, model_compiler.mesh_mass_properties_legacy), 13 site-object distances, the dot product."""
+    pf2 = rec["pose_file_2"]
+    s = old_env.new_oracle_sim()
+    s.set_state(old_env.start_qpos(pf2[0]))
+    s.forward()
+    e = np.abs(old_env.oracle_row(s) - pf2[0])
+    assert e[:21].max() < 2e-10, e[:21].reshape(7, 3)          # float32 mesh vertices: 1e-10 m
+    assert e[21:].max() < 1e-12
+    # the exact signed-volume centroid (MuJoCo >= 2.2's default, rounds 1-3 here) sits 1.25 mm from the recorded palm centre
+    M = mc.read_blob(scenarios.model_blob("mbox"))
+    # (legacy: link-local z = -0.060945, the non-convex hand mesh over-counted as 5.71e-4 m^3; exact: -0.05969, 5.53e-4 m^3)
+    assert abs(M["geom_pos"][1][2] - (-0.060945)) < 1e-6 and abs(M["mesh_info"][0, 0] - 5.7104e-4) < 1e-7
+
+
+def test_box_released_inside_the_floor_recovers_as_in_mujoco(rec):
+    """Rows 1-3: nothing touches the box but the floor (4 corner contacts of the explicit object-ground pair, pyramidal rows,
+    impedance d(r) inside its width from row 2 on, implicit damping, the sensors' one-substep lag): equal to round-off.  With the
+    geoms' margin 0.001 on that pair - rounds 1-3 - the same run misses MuJoCo by 0.6 - 1 mm."""
+    pf2 = rec["pose_file_2"]
+
+    def heights(edit=None):
+        s = old_env.new_oracle_sim(edit)
+        s.set_state(old_env.start_qpos(pf2[0]))
+        z = []
+        for k in range(12):
+            s.step(np.zeros(9))
+            z.append(s.view("geom_xpos").reshape(9, 3)[8, 2])
+        return np.array(z)[[3, 7, 11]]          # forward pass of the row's 4th substep
+
+    assert np.abs(heights() - pf2[1:4, 23]).max() < 1e-13
+    assert np.abs(pf2[1:4, 23] - [0.052898, 0.054325, 0.054774]).max() < 1e-6
+
+    def geom_margin(M):
+        M["pairs"][:8, 4] = 0.001
+    assert np.abs(heights(geom_margin) - pf2[1:4, 23]).min() > 5e-4
+
+
+def test_oracle_replays_the_recorded_mujoco_contact_trajectory(rec):
+    pf2 = rec["pose_file_2"]
+    rows, us, _ = old_env.replay_recording(pf2)
+    err = np.abs(rows - pf2)
+    # rows 0-21: every one of the 48 columns.  The box is pushed 2.2 cm by then (finger 1 on its vertical edge, 18 rows of contact)
+    assert err[:ROWS_EXACT, :47].max() < 2e-9, np.argwhere(err[:ROWS_EXACT] >= 2e-9)
+    assert err[:ROWS_EXACT, 47].max() < 4e-9                     # a cosine to the 20th power
+    assert pf2[0, 21] - pf2[21, 21] > 0.02 and np.abs(pf2[4:22, 28] - 0.5 * pf2[4:22, 25]).max() > 3e-4   # the soft tendon under load
+    beyond = np.nonzero(err.max(1) > 1e-6)[0]
+    r0, c0 = int(beyond[0]), 21 + int(err[beyond[0], 21:24].argmax())
+    print(f"first row / column beyond 1e-6: row {r0}, column {c0} ({err[r0, c0]:.2e}); rows 0-{ROWS_EXACT - 1} max {err[:ROWS_EXACT].max():.1e}")
+    assert (r0, c0) == (22, 22) and 1e-4 < err[22, 22] < 3e-4     # the object's y, 1.8e-4 (and with it the site-object distances)
+    # after the divergence the replay stays a bounded distance from the recording through grasp and lift (rows 22-62):
+    # object within 5 mm (4.3 mm along y, reached before the grasp closes and kept through the lift), its height within 0.8 mm
+    # (the lift: 0.055 -> 0.196 m at 5.6 mm per row), finger-link centres 0.6 mm, distal joints 5 mrad; commands that reproduce the
+    # actuated joints exist in all but the rows where a finger is blocked by the grasped box (a bounded command cannot move it)
+    assert err[:, 21:24].max() < 5e-3 and err[:, 23].max() < 8e-4
+    assert err[:, :21].max() < 6e-4 and err[:, 28:31].max() < 5e-3
+    assert np.median(err[:, 24:28].max(1)) < 1e-9 and err[:, 24:28].max() < 8e-3
+    assert pf2[62, 23] > 0.195 and abs(rows[62, 23] - pf2[62, 23]) < 3e-4
+    # the commands of the lift saturate the wrist servo as the old driver's "go" action does (main_DDPGfD_OG.py:45-48)
+    assert (us[45:, 0] > 0.199).all()
 
 
 # ------------------------------------------------------------------------------------------------------------ GPU
@@ -157,6 +233,71 @@ def test_gpu_free_closing_matches_recorded_mujoco_joint_traces(rec, precision):
     sim.close()
 
 
+def _gpu_old_env_sim(precision, n=16):
+    from kinovagrasping_amd.sim import KinovaSim
+    sim = KinovaSim(n, old_env.old_env_blob(), precision=precision, solver_iterations=SOLVER_ITERATIONS)
+    return sim
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [64, 32])
+def test_gpu_box_released_inside_the_floor_recovers_as_in_mujoco(rec, precision):
+    pf2 = rec["pose_file_2"]
+    n = 16
+    sim = _gpu_old_env_sim(precision, n)
+    sim.reset(torch.as_tensor(np.repeat(old_env.start_qpos(pf2[0])[:, None], n, 1)), torch.as_tensor(np.repeat(scenarios.hand_quat_for("normal")[:, None], n, 1)))
+    ctrl = torch.zeros(9, n, dtype=torch.float64)
+    z = []
+    for k in range(11):
+        sim.substep(ctrl)
+        z.append(sim.get_state()["qpos"].double().cpu().numpy()[11])
+    z = np.array(z)[[2, 6, 10]]                   # qpos after 4 r - 1 integrations = what row r's forward pass saw
+    assert np.abs(z - z[:, :1]).max() == 0.0
+    err = np.abs(z[:, 0] - pf2[1:4, 23])
+    print(f"fp{precision}: box height after rows 1-3 vs recorded MuJoCo: {err}")
+    assert err.max() < (1e-12 if precision == 64 else 2e-7)
+    sim.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [64, 32])
+def test_gpu_replays_the_recorded_mujoco_contact_trajectory(rec, precision):
+    """The HIP kernels, open loop, under the commands the oracle recovered from the recording (tests/old_env.py): joint angles and
+    the object's path against REAL MuJoCo 1.50.  fp64 = the oracle's replay to round-off (rows 0-21: 2e-9 of MuJoCo); the fp32
+    product follows MuJoCo through the 18 contact rows to fp32 accuracy until the hopping box amplifies its rounding."""
+    pf2 = rec["pose_file_2"]
+    rows_o, us, _ = old_env.replay_recording(pf2)
+    n = 16
+    sim = _gpu_old_env_sim(precision, n)
+    sim.reset(torch.as_tensor(np.repeat(old_env.start_qpos(pf2[0])[:, None], n, 1)), torch.as_tensor(np.repeat(scenarios.hand_quat_for("normal")[:, None], n, 1)))
+    cols = [2, 3, 5, 7, 4, 6, 8, 9, 10, 11]       # wrist, three proximal, three distal joints, object x y z  (recording: 24-30, 21-23)
+    ref_cols = list(range(24, 31)) + [21, 22, 23]
+    got = [np.zeros(10)]
+    for r in range(1, len(pf2)):
+        ctrl = torch.as_tensor(np.repeat(old_env.ctrl_of(us[r])[:, None], n, 1))
+        for k in range(old_env.FRAME_SKIP):
+            sim.substep(ctrl)
+            if k == old_env.FRAME_SKIP - 2:
+                qp = sim.get_state()["qpos"].double().cpu().numpy()
+                assert np.abs(qp - qp[:, :1]).max() == 0.0
+                got.append(qp[cols, 0])
+    got = np.array(got)
+    err = np.abs(got - pf2[:, ref_cols])[1:]
+    e_exact = err[:ROWS_EXACT - 1]
+    first = int(np.nonzero(err.max(1) > 1e-6)[0][0]) + 1
+    print(f"fp{precision}: rows 1-{ROWS_EXACT - 1} max |joint| {e_exact[:, :7].max():.2e} max |object| {e_exact[:, 7:].max():.2e}; first row beyond 1e-6: {first}; "
+          f"all rows: joints {err[:, :7].max():.2e} object {err[:, 7:].max():.2e} final height error {err[-1, 9]:.2e}")
+    if precision == 64:
+        assert e_exact.max() < 2e-9 and first == 22
+        assert np.abs(got - rows_o[:, ref_cols])[1:].max() < 1e-9          # = the oracle's replay, every row
+    else:
+        assert e_exact[:4].max() < 1e-6                                     # before and at first touch
+        assert np.median(e_exact.max(1)) < 1e-5
+    assert err[:, 7:].max() < 6e-3 and err[:, 9].max() < 1.5e-3 and err[:, :7].max() < 1.5e-2
+    assert got[-1, 9] > 0.19
+    sim.close()
+
+
 @pytest.mark.gpu
 def test_gpu_replays_the_recorded_demonstrations(rec):
     from kinovagrasping_amd.sim import KinovaSim
@@ -169,9 +310,9 @@ def test_gpu_replays_the_recorded_demonstrations(rec):
 @pytest.mark.gpu
 def test_gpu_naive_controller_success_map_vs_recorded_heatmap(rec):
     """One naive-controller episode from the centre of every cell for which the reference's heat maps hold trials (1000+
-    cells); the outcome is compared with the recorded majority outcome of the cell.  The numbers asserted are the ones
-    measured in round 3 (profiles/r03_naive_heatmap.txt) with a margin - the map agrees on the outer success band and on the
-    far corners' failures, and DISAGREES on the near-palm centre blob, where MuJoCo fails and this simulator grasps."""
+    cells); the outcome is compared with the recorded majority outcome of the cell: the outer success band, the far corners the
+    hand cannot reach, and the near-palm centre zone where MuJoCo's naive controller FAILS (with the explicit pairs' margin at the
+    geoms' 0.001 - rounds 1-3 - this simulator lifted from every cell of that zone: the "near-palm blob")."""
     from kinovagrasping_amd.sim import KinovaSim
     hs, hf, hx, hy = rec["heat_success"], rec["heat_fail"], rec["heat_x"], rec["heat_y"]
     has = (hs > 0) | (hf > 0)
@@ -185,8 +326,8 @@ def test_gpu_naive_controller_success_map_vs_recorded_heatmap(rec):
     ref_ok, ref_bad = ref_rate >= 0.75, ref_rate <= 0.25
     centre = ref_bad & (np.abs(hx[ii]) < 0.04) & (hy[jj] < 0.055)
     corners = ref_bad & ~centre
-    agree_ok = ours[ref_ok].mean()
+    agree_ok, fail_corners, fail_centre = ours[ref_ok].mean(), 1 - ours[corners].mean(), 1 - ours[centre].mean()
     print(f"cells {len(jj)}: recorded success cells {ref_ok.sum()} -> ours succeed in {agree_ok:.3f}; recorded failure cells: "
-          f"far corners {corners.sum()} -> ours fail in {1 - ours[corners].mean():.3f}; near-palm centre {centre.sum()} -> ours fail in {1 - ours[centre].mean():.3f}")
-    assert agree_ok > 0.9
+          f"far corners {corners.sum()} -> ours fail in {fail_corners:.3f}; near-palm centre {centre.sum()} -> ours fail in {fail_centre:.3f}")
+    assert agree_ok > HEAT_MIN_SUCCESS_BAND and fail_centre > HEAT_MIN_CENTRE_FAIL and fail_corners > HEAT_MIN_CORNER_FAIL
     sim.close()

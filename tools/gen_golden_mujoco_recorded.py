@@ -9,6 +9,16 @@ mujoco-py), not source text:
                        Old Code/main_DDPGfD_OG.py:64-70).  Rows 0-26: fingers 1 and 3 close freely at the servo's
                        maximum command (steady 0.02908 rad per row = 0.8 * 2.5 / 2.75 rad/s * 0.04 s), finger 2 is
                        commanded 0 and sags under gravity; later rows involve the old env's object.
+  pose_file_2          gym-kinova-gripper/Old Code/Pose_file_2.csv  [63, 48]
+                       state[0:48] ("global" representation, kinova_gripper_env_s.py:181-209) once per env.step() of the same
+                       frame_skip = 4 env on `j2s7s300_end_effector_v1_mbox (copy).xml` (ONE slide joint_7, range 0 - 0.2, 4 velocity
+                       actuators, box 0.02125 x 0.02125 x 0.055), writer Old Code/main_DDPGfD_OG.py:36-70: columns 0-17 geom_xpos
+                       of f1_prox f2_prox f3_prox f1_dist f2_dist f3_dist, 18-20 palm geom_xpos, 21-23 object geom_xpos, 24-30
+                       jointpos sensors [wrist, f1, f2, f3 proximal, f1, f2, f3 distal], 31-33 object size, 34-46 site-object
+                       distances (kinova_gripper_env_s.py:210-224), 47 dot product (:266-281).  Row 0 = reset (object released
+                       5 mm inside the floor), rows 1-3 the box recovers before anything touches it, rows 4-33 finger 1 pushes it
+                       across the floor while the hand closes, rows 34-62 grasp and lift.  The ONLY contact trajectory of real
+                       MuJoCo in the reference tree.
   demo_*               gym-kinova-gripper/expert_plots/{heatmap_train_{success,fail}_new_{x,y}_arr,success_timesteps,
                        fail_timesteps}.npy: ten recorded demonstrations (expert_data.py:690-921): palm-frame start
                        (x, y) of the object, outcome, env-steps until done.
@@ -50,6 +60,8 @@ def digitize(png: Path, nx: int = 90, ny: int = 45):
 
 def main():
     pose = np.loadtxt(REF / "Old Code" / "Pose_file.csv", delimiter=",")
+    pose2 = np.loadtxt(REF / "Old Code" / "Pose_file_2.csv", delimiter=",")
+    assert pose2.shape == (63, 48)
     E = REF / "expert_plots"
     sx, sy = np.load(E / "heatmap_train_success_new_x_arr.npy"), np.load(E / "heatmap_train_success_new_y_arr.npy")
     fx, fy = np.load(E / "heatmap_train_fail_new_x_arr.npy"), np.load(E / "heatmap_train_fail_new_y_arr.npy")
@@ -59,12 +71,12 @@ def main():
     hs[np.abs(hs) < 3] = 0.0
     hf[np.abs(hf) < 3] = 0.0
     np.savez_compressed(
-        OUT, pose_file=pose,
+        OUT, pose_file=pose, pose_file_2=pose2,
         demo_x=np.r_[sx, fx], demo_y=np.r_[sy, fy], demo_success=np.r_[np.ones(len(sx)), np.zeros(len(fx))].astype(np.int32),
         demo_steps=np.r_[st, ft].astype(np.int32), all_timesteps=np.load(E / "all_timesteps.npy"),
         heat_success=hs.astype(np.float32), heat_fail=hf.astype(np.float32),
         heat_x=(-0.09 + 0.002 * (np.arange(90) + 0.5)), heat_y=(0.002 * (np.arange(45) + 0.5)))
-    print(f"wrote {OUT}: pose_file {pose.shape}, {len(sx)} + {len(fx)} demonstrations, "
+    print(f"wrote {OUT}: pose_file {pose.shape}, pose_file_2 {pose2.shape}, {len(sx)} + {len(fx)} demonstrations, "
           f"{(hs > 0).sum()} success cells, {(hf > 0).sum()} failure cells")
 
 
