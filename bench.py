@@ -374,6 +374,33 @@ def main():
     advance(args.warmup)
     barrier()
     clock_hist = torch.bincount(eng.t.clamp(0, 29), minlength=30).cpu().tolist() if args.mode == "ddpg" else None
+
+    def ring_mark():
+        """(committed episodes' ring head) - the regime of a window is read off the episodes that entered the replay ring during it"""
+        return replay.head if args.mode == "ddpg" and not args.eager and trainer is not None else None
+
+    def window_regime(head0, head1, count0=None, count1=None):
+        """What the policy did in a window, so that rounds can be compared at equal regime (the throughput of this workload follows the
+        policy: contact-rich grasps cost more): share of the episodes committed in the window that ended in a lift (their last stored
+        reward carries the lift reward 50, main_DDPGfD.py:285-288), their mean stored length, and the contacts per env at its end."""
+        if head0 is None:
+            return None
+        cap = replay.capacity
+        k = (head1 - head0) % cap
+        idx = (head0 + torch.arange(k, device=dev)) % cap
+        L = replay.ep_len[idx].clamp(min=1)
+        last = replay.ep_reward[idx, L - 1]
+        ncon = sim.get_state()["ncon"].float()
+        out = {"episodes_committed": int(k), "lift_fraction": round(float((last >= 50).float().mean()), 4) if k else None,
+               "mean_stored_episode_length": round(float(L.float().mean()), 2) if k else None,
+               "mean_contacts_per_env_at_end": round(float(ncon.mean()), 3), "max_contacts_per_env_at_end": int(ncon.max())}
+        if count0 is not None:
+            fin = count1["episodes_finished"] - count0["episodes_finished"]
+            out["lift_fraction_all_finished_episodes"] = round((count1["lifted"] - count0["lifted"]) / max(1, fin), 4)
+        return out
+
+    head_t0 = ring_mark()
+    cnt_t0 = trainer.counts() if free_running else None
     sim.kernel_time(reset=True)
     upd0 = updates
     t0 = time.perf_counter()
@@ -384,6 +411,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kern_ms, launches = sim.kernel_time()
+    regime_timed = window_regime(head_t0, ring_mark(), cnt_t0, trainer.counts() if free_running else None) if args.mode == "ddpg" else None
     if free_running:                     # per env-step: the persistent launches' durations / their env-steps
         tot = sum(e0.elapsed_time(e1) for e0, e1, _ in rollout_ms)
         kern_ms, launches = tot / max(1, sum(c for _, _, c in rollout_ms)), len(rollout_ms)
@@ -426,11 +454,13 @@ def main():
             advance(min(100, args.steady_updates - updates))
         barrier()
         sim.kernel_time(reset=True)
+        head_s0, cnt_s0 = ring_mark(), (trainer.counts() if free_running else None)
         u0, t2 = updates, time.perf_counter()
         advance(args.steady_steps, timed=True)
         trainer.flush()
         barrier()
         dts = time.perf_counter() - t2
+        regime_steady = window_regime(head_s0, ring_mark(), cnt_s0, trainer.counts() if free_running else None)
         ks_ms, ks_n = sim.kernel_time()
         if free_running:
             tot = sum(e0.elapsed_time(e1) for e0, e1, _ in rollout_ms)
@@ -441,7 +471,7 @@ def main():
             dts = tt.item()
         steady = {"value": round(n * world * args.steady_steps / dts, 1), "unit": "env-steps/s", "steps": args.steady_steps,
                   "after_updates": u0, "learner_updates_timed": updates - u0, "ms_per_step": round(dts / args.steady_steps * 1e3, 4),
-                  "k_env_step_avg_launch_ms": round(ks_ms, 4), "launches_timed": ks_n}
+                  "k_env_step_avg_launch_ms": round(ks_ms, 4), "launches_timed": ks_n, "regime": regime_steady}
     status = sim.get_state()["status"]
     bad = int((status & 2).ne(0).sum().item())
     # replicas must hold bit-identical weights after the all-reduced updates: spread of two checksums over the ranks
@@ -488,6 +518,10 @@ def main():
                                     "env-step (BASELINE config 3; config 4 when n_gpus=8)") if args.mode == "ddpg" else
                                    (f"{n} envs/GPU CubeS normal-pose grasp sim, PCG64(1000+i) random-action rollout (BASELINE config 2 at the "
                                     "metric's env count); sim kernels only"),
+                       "reset": ("every env restarts from its own row of the reference's no_noise start table (obj_hand_coords/no_noise/train_coords), no orientation "
+                                 "noise; hand slide offsets of the pose ('pose' mode)  [reference defaults: with_noise=True - tables SURVEY N5 shows to be "
+                                 "biased and swapped between classes - and, in its training driver, zero hand offsets: vec_env.KinovaGripperVecEnv(hand_offsets="
+                                 "'fresh-env'), reset(with_noise=True) select those]"),
                        "mode": args.mode, "envs_per_gpu": n, "frame_skip": 15, "solver": f"newton, <= {iters} iterations per substep (early exit on convergence)", "hidden": list(args.hidden),
                        "learner_updates_timed": timed_updates if args.mode == "ddpg" else 0, "priming_steps": priming,
                        "launch": (("eager" if args.eager else ("free-running rollout kernel (ks_rollout), <= %d env-steps per launch (timed region: %s) + learner graphs" % (args.chunk, timed_launches)
@@ -506,7 +540,7 @@ def main():
             # every env runs the same 30-step episode clock (auto-reset), and an env-step costs more late in an episode (hands
             # closed, more contacts) than early: a window that is not whole episodes is not an average
             "timed_window": {"after_learner_updates": upd0, "pretrain_updates": pretrained, "steps": args.steps,
-                             "episode_clock_histogram": clock_hist,
+                             "episode_clock_histogram": clock_hist, "regime": regime_timed,
                              "note": ("timed after the untimed pre-training: trained policy, contact-rich grasps, env episode clocks spread over the 30 "
                                       "phases (histogram = envs per episode step at the start of the window) - the same regime as `steady_state`"
                                       if pretrained else

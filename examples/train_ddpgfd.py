@@ -55,6 +55,12 @@ def main():
     ap.add_argument("--expert-prob", type=float, default=0.3, help="share of expert episodes in a batch (DDPGfD.py:232-254); 0: plain DDPG, no demonstrations")
     ap.add_argument("--eval-every", type=int, default=600, help="env-steps between evaluations without exploration noise (0: none)")
     ap.add_argument("--free-running", action="store_true", help="the persistent rollout kernel (ks_rollout) instead of one launch per env-step")
+    ap.add_argument("--batch-episodes", type=int, default=64, help="episodes per update (x 25 five-step windows each); the reference: 64")
+    ap.add_argument("--updates-per-step", type=int, default=1, help="learner updates per env-step of the whole batch of envs")
+    ap.add_argument("--actor-lr", type=float, default=1e-4, help="reference: 1e-4 (DDPGfD.py:57)")
+    ap.add_argument("--critic-lr", type=float, default=1e-3, help="reference: Adam's default 1e-3 (DDPGfD.py:61)")
+    ap.add_argument("--expl-noise", type=float, default=0.1, help="exploration noise, std = 0.8 x this (main_DDPGfD.py:443-446: 0.1)")
+    ap.add_argument("--save", default=None, help="write the trained policy as the reference's 4-file checkpoint with this prefix")
     args = ap.parse_args()
     torch.manual_seed(args.seed)
     rng = np.random.RandomState(args.seed)
@@ -78,12 +84,15 @@ def main():
     from kinovagrasping_amd.pipeline import AsyncTrainer, GraphedTrainer
     sim = KinovaSim(n, args.shape, auto_reset=True, horizon=30)
     q0, hq = start_states(n, args.shape, rng)
-    policy = DDPGfD(82, 4, 0.8, 5, batch_size=64, hidden=tuple(args.hidden), device=dev)
+    policy = DDPGfD(82, 4, 0.8, 5, batch_size=args.batch_episodes, hidden=tuple(args.hidden), device=dev)
+    policy.actor_optimizer.param_groups[0]["lr"] = args.actor_lr
+    policy.critic_optimizer.param_groups[0]["lr"] = args.critic_lr
     agent = DeviceEpisodeReplay(n, capacity=max(4 * n, 4096), device=dev)
-    eng = RolloutEngine(sim, policy, agent)
+    eng = RolloutEngine(sim, policy, agent, expl_noise=args.expl_noise)
     eng.start(sim.reset(torch.as_tensor(q0), torch.as_tensor(hq)))
     Trainer = AsyncTrainer if args.free_running else GraphedTrainer
-    tr = Trainer(sim, policy, agent, eng, batch_episodes=64, expert_replay=expert, expert_prob=args.expert_prob if expert is not None else 0.3)
+    tr = Trainer(sim, policy, agent, eng, batch_episodes=args.batch_episodes, expert_replay=expert, expert_prob=args.expert_prob if expert is not None else 0.3,
+                 updates_per_step=args.updates_per_step)
     tr.capture()
     if args.free_running:
         tr.run(36, learn=False)
@@ -119,6 +128,10 @@ def main():
             ev = f"  eval (no noise, 1024 starts): lift success {res['num_success'] / 1024:.3f}"
             t_eval += time.perf_counter() - te
         print(f"step {it + 60:5d}  episodes {d_ep:7d}  training lift rate {d_lift / max(1, d_ep):.3f}  critic loss {ls[0]:9.3f}  {n * (it + 60) / dt:9.0f} env-steps/s{ev}")
+    if args.save:
+        tr.flush(finish_update=True)
+        policy.save(args.save)
+        print("saved", args.save + "_{actor,critic,actor_optimizer,critic_optimizer}")
     sim.close()
     sim_eval.close()
 

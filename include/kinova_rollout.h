@@ -54,8 +54,12 @@ int kr_rank_episodes(int32_t n, const uint8_t *keep, int64_t *rank, int64_t *tot
 /* Stream-side pacing for the free-running rollout (no reference counterpart: main_DDPGfD.py:424-486 alternates acting and learning on one
  * thread): a one-wave, LDS-free kernel on `stream` that returns when min_i values[i] >= target (ks_rollout_args.steps_total: every env has
  * done that many env-steps of the persistent rollout launch) or after timeout_s of wall clock - whatever follows on the stream (the
- * learner's next update, the commit of published episodes) then stays within a bounded distance of the SLOWEST env however long the launch is. */
+ * learner's next update, the commit of published episodes) then stays within a bounded distance of the SLOWEST env however long the launch is.
+ * timeout_s <= 0 waits for ever (like a library collective: only for values that are certain to arrive).  kr_wait_min_counted also adds 1
+ * to *timeouts (device int64, may be NULL) when the wait ended on the clock instead of the target, so that a paced run that degrades - e.g.
+ * more stepping workgroups than resident slots, whose second round only starts when the first has finished its whole launch - is visible. */
 int kr_wait_min(const int64_t *values, int32_t n, int64_t target, double timeout_s, void *stream);
+int kr_wait_min_counted(const int64_t *values, int32_t n, int64_t target, double timeout_s, int64_t *timeouts, void *stream);
 
 /* ring rows ep_* [capacity(+), H, ...], ep_len int64; kept env i goes to slot (head + rank[i] - 1) % capacity */
 int kr_commit_episodes(int32_t n, int32_t horizon, int32_t capacity, const uint8_t *keep, const int64_t *rank, const int64_t *head,

@@ -112,7 +112,11 @@ int ks_reset_objects(ks_ctx *ctx, const int32_t *env_ids, int32_t n, const void 
 /* One env.step() for every env.  action: [4, N] (wrist, finger1..3), obs: N x 82, reward: [N],
  * done: uint8 [N] (bit0 lifted, bit1 time limit), info: [3, N] (finger, grasp, lift reward).
  * final_obs (optional): with auto_reset, rows of envs that finished hold their terminal
- * observation while `obs` already holds the observation after the reset. */
+ * observation while `obs` already holds the observation after the reset.
+ * Stream capture: ks_step / ks_rollout may be recorded into a HIP graph.  The library then records a host-to-device copy
+ * of the call's output-pointer record from pinned memory it owns for the life of the context (one record per captured call,
+ * never recycled), so any number of captured graphs with different output buffers can be replayed in any order; the
+ * buffers themselves are borrowed for as long as the graph may be replayed. */
 int ks_step(ks_ctx *ctx, const void *action, void *obs, void *reward, uint8_t *done, void *info, void *final_obs, void *stream);
 
 /* Parity taps; any pointer may be NULL.  contact: [KS_NCON_MAX*KS_CONTACT_STRIDE, N] records of the

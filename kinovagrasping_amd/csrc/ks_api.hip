@@ -655,6 +655,16 @@ __device__ __noinline__ void rollout_policy(const ks_rollout_args* __restrict__ 
         const bool mine = kmlp::mlp3_rows16<NT1, NT2, true>(wave, lane, (long)row_env, S, 0, ra.h1, ra.h2, A, ra.obs, S, nullptr, 0, pw + ra.off_w1,
                                                             pw + ra.off_b1, pw + ra.off_w2, pw + ra.off_b2, pw + ra.off_w3, nullptr, nullptr, H1, H2, Pp,
                                                             z4);
+        // the last words read from buffer ver % 3 - the layer-3 bias - are taken BEFORE the staleness check below, and a fence keeps
+        // the check's load behind them: everything the action is computed from has then been read when the counter is looked at
+        float y[4] = {0.f, 0.f, 0.f, 0.f};
+        if (mine) {
+            const float z[4] = {z4.x, z4.y, z4.z, z4.w};
+            const float* b3 = pw + ra.off_b3;
+#pragma unroll
+            for (int i = 0; i < 4; i++) y[i] = ra.max_action / (1.f + __expf(-(z[i] + b3[i])));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         // buffer ver % 3 is rewritten by publish ver + 3, which starts once ver + 2 is complete: if the counter has advanced by two
         // while this forward ran, the weights just read may be torn - repeat with the newest ones (two update periods, > 1 ms,
         // against a 25 us forward: never seen; the check makes it a protocol instead of a timing assumption)
@@ -663,11 +673,7 @@ __device__ __noinline__ void rollout_policy(const ks_rollout_args* __restrict__ 
         const bool stale = vbox[1] >= 2;
         if (!stale) {
             if (mine) {
-                const float z[4] = {z4.x, z4.y, z4.z, z4.w};
-                const float* b3 = pw + ra.off_b3;
-                float y[4], nz[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) y[i] = ra.max_action / (1.f + __expf(-(z[i] + b3[i])));
+                float nz[4];
                 krsel::normal4(ra.seed, (unsigned long long)ra.steps_total[row_env], (uint32_t)row_env, nz);
                 krsel::select_one(row_env, N, y, nz, ra.obs, ra.prev_obs, ra.has_prev, ra.t, ra.ready, ra.sigma, ra.max_action, ra.skip_steps, ra.action,
                                   ra.action_t, ra.lifting);
@@ -1277,6 +1283,21 @@ template <typename T> struct Ctx : CtxBase {
     int h_out_next = 0;                   // graph): a ring, so that a change does not overwrite a copy that is still queued
     static constexpr int H_OUT_RING = 16;
     bool out_valid = false;
+    // A CAPTURED copy reads its pinned source at every replay of the graph, long after this call: captured calls therefore get a
+    // record of their own that is never recycled (freed with the context), not a slot of the rings above.
+    // (allocated with the rings: no allocation is allowed while a stream captures; CAPTURE_RECORDS captured calls per context)
+    static constexpr int CAPTURE_RECORDS = 128;
+    int captured_out = 0, captured_ra = 0;
+    template <typename R> R* pinned_record(bool capturing, R* ring, unsigned slot_index, int& used) {
+        if (!capturing) return ring + (slot_index % H_OUT_RING);
+        if (used >= CAPTURE_RECORDS) return nullptr;
+        return ring + H_OUT_RING + used++;
+    }
+    static bool stream_is_capturing(hipStream_t s) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        return cap != hipStreamCaptureStatusNone;
+    }
     Model<T>* d_model = nullptr;          // [n_models] model table
     int n_models = 0, n_wg = 0;
     std::map<std::pair<size_t, uint64_t>, void*> shared;      // uploaded arrays by (bytes, content hash): the hand's meshes are
@@ -1422,7 +1443,9 @@ template <typename T> struct Ctx : CtxBase {
         HIPCHK(hipDeviceSynchronize());
         if ((r = alloc(&d_b, (size_t)1))) return r;
         if ((r = alloc(&d_out, (size_t)1))) return r;
-        HIPCHK(hipHostMalloc((void**)&h_out, H_OUT_RING * sizeof(ObsOut<T>), hipHostMallocDefault));
+        if (!h_out) HIPCHK(hipHostMalloc((void**)&h_out, (H_OUT_RING + CAPTURE_RECORDS) * sizeof(ObsOut<T>), hipHostMallocDefault));
+        if (!d_ra) HIPCHK(hipMalloc((void**)&d_ra, sizeof(ks_rollout_args)));
+        if (!h_ra) HIPCHK(hipHostMalloc((void**)&h_ra, sizeof(ks_rollout_args) * (H_OUT_RING + CAPTURE_RECORDS), hipHostMallocDefault));
         HIPCHK(hipMemcpy(d_b, &b, sizeof b, hipMemcpyHostToDevice));
         model_loaded = true;
         return KS_OK;
@@ -1489,13 +1512,12 @@ template <typename T> struct Ctx : CtxBase {
                           out.env_major == out_sent.env_major;
         // Under stream capture the copy below is only RECORDED (it runs at every replay of the graph, not now): the device copy
         // cannot be taken as current afterwards, so a capturing call always records the copy and never marks it as sent.
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-        const bool capturing = cap != hipStreamCaptureStatusNone;
+        const bool capturing = stream_is_capturing(s);
         if (obs_in_step && (capturing || !(same && out_valid))) {
             out_valid = !capturing;
             out_sent = out;
-            ObsOut<T>* slot = h_out + (h_out_next++ % H_OUT_RING);
+            ObsOut<T>* slot = pinned_record(capturing, h_out, (unsigned)h_out_next++, captured_out);
+            if (!slot) { error = "ks_step: more captured calls than the context keeps output records for"; return KS_ERR_STATE; }
             *slot = out;
             HIPCHK(hipMemcpyAsync(d_out, slot, sizeof out, hipMemcpyHostToDevice, s));
         }
@@ -1525,15 +1547,14 @@ template <typename T> struct Ctx : CtxBase {
             if ((size_t)(((ra->h1 + 15) / 16 + (ra->h2 + 15) / 16) * 4 + 4) * 16 * 16 + 16 > (size_t)SCR_TOTAL * lpw * sizeof(T)) { error = "ks_rollout: no LDS for the policy"; return KS_ERR_STATE; }
             const int N = cfg.n_envs;
             const ObsOut<T> out{(T*)ra->sim_obs, (T*)ra->sim_reward, ra->sim_done, (T*)ra->sim_info, (T*)ra->sim_final_obs, cfg.horizon, cfg.auto_reset, cfg.obs_env_major};
-            ObsOut<T>* slot = h_out + (h_out_next++ % H_OUT_RING);
+            const bool capturing = stream_is_capturing(s);
+            ObsOut<T>* slot = pinned_record(capturing, h_out, (unsigned)h_out_next++, captured_out);
+            if (!slot) { error = "ks_rollout: more captured calls than the context keeps output records for"; return KS_ERR_STATE; }
             *slot = out;
             out_valid = false;                                     // a following ks_step re-sends its own record
             HIPCHK(hipMemcpyAsync(d_out, slot, sizeof out, hipMemcpyHostToDevice, s));
-            if (!d_ra) {
-                HIPCHK(hipMalloc((void**)&d_ra, sizeof(ks_rollout_args)));
-                HIPCHK(hipHostMalloc((void**)&h_ra, sizeof(ks_rollout_args) * H_OUT_RING));
-            }
-            ks_rollout_args* rslot = h_ra + (h_ra_next++ % H_OUT_RING);
+            ks_rollout_args* rslot = pinned_record(capturing, h_ra, h_ra_next++, captured_ra);
+            if (!rslot) { error = "ks_rollout: more captured calls than the context keeps argument records for"; return KS_ERR_STATE; }
             *rslot = *ra;
             HIPCHK(hipMemcpyAsync(d_ra, rslot, sizeof *ra, hipMemcpyHostToDevice, s));
 #define KS_ROLLOUT_CASE(A, B)                                                                                                                         \

@@ -597,7 +597,12 @@ template <typename T> struct PairGeo {
 // Hull vertex tables are stored padded: stride 4 reals (x, y, z, 0) and the count rounded up to a
 // multiple of HULL_CHUNK with copies of vertex 0 (a copy never wins a strict arg-max / arg-min).
 constexpr int HULL_CHUNK = 8;
-constexpr double SUPPORT_SKEW = 1e-9, SKEW_X = 0.5377, SKEW_Y = -0.6240, SKEW_Z = 0.5671;   // see pair_support
+#ifdef KS_SUPPORT_SKEW_OVERRIDE
+constexpr double SUPPORT_SKEW = KS_SUPPORT_SKEW_OVERRIDE;
+#else
+constexpr double SUPPORT_SKEW = 1e-6;
+#endif
+constexpr double SKEW_X = 0.5377, SKEW_Y = -0.6240, SKEW_Z = 0.5671;   // see pair_support
 
 // Support vertex of a convex hull along `dir` by hill climbing on the hull graph: from `hint`, move to
 // the best strictly-improving neighbour until none improves.  On a convex polytope a vertex without an
@@ -667,8 +672,8 @@ template <typename T> KS_HD void pair_support(PairGeo<T>& g, const T* dir, T hm,
     // Tie rule shared with the oracle (ko_physics.c: hull_support): MPR and GJK ask for supports along the normals of faces
     // they built from the hulls' own vertices, so all of such a face's vertices attain the maximum to the last bit and rounding
     // would pick - and with it the portal path, the contact point on a flat feature, on a rounded polytope even the facet of the
-    // normal.  The hull-frame direction is skewed by a fixed 1e-9 of its size (1e-10 m of support error at most; seven orders
-    // above fp64 rounding; below fp32 resolution, where it changes nothing).
+    // normal.  The hull-frame direction is skewed by a fixed 1e-6 of its size: 1e-7 m of support error at most (a tenth of MPR's
+    // tolerance), an order above the rounding of an fp32 direction, so that fp32 and fp64 mostly take the same vertex too.
     {
         const T s1 = T(SUPPORT_SKEW) * (kabs(ld1[0]) + kabs(ld1[1]) + kabs(ld1[2])), s2 = T(SUPPORT_SKEW) * (kabs(ld2[0]) + kabs(ld2[1]) + kabs(ld2[2]));
         ld1[0] += s1 * T(SKEW_X); ld1[1] += s1 * T(SKEW_Y); ld1[2] += s1 * T(SKEW_Z);
@@ -1313,6 +1318,9 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     T bd = T(1e30);
     int best = nv;
     unsigned long long cand = 0;                    // bit r: this lane's vertex of round r (index r SUBS + sub) is within the margin
+    unsigned long long near = 0;                    // (fp64 only) bit r: ... was within the tie band of the lane's running minimum when it was seen
+    constexpr bool TIE_RULE = sizeof(T) == 8;       // see below
+    constexpr T TIE_EPS = T(1e-12);
     for (int base0 = 0; base0 < nv; base0 += 4 * SUBS) {
         T dd[4];
         KS_UNROLL
@@ -1323,17 +1331,42 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
         KS_UNROLL
         for (int u = 0; u < 4; u++) {
             const int i = base0 + u * SUBS + team.sub;
-            if (i < nv && dd[u] < bd) { bd = dd[u]; best = i; }
-            if constexpr (SUBS == 16)
+            if constexpr (SUBS == 16) {
                 if (i < nv && dd[u] <= margin) cand |= 1ull << (base0 / SUBS + u);
+                if constexpr (TIE_RULE)
+                    if (i < nv && dd[u] <= bd + TIE_EPS) near |= 1ull << (base0 / SUBS + u);
+            }
+            if (i < nv && dd[u] < bd) { bd = dd[u]; best = i; }
         }
     }
     KS_TICK(12)
+    const T bd_lane = bd;
     team.argmin(bd, best);
     if (bd > margin) return 0;
-    // Ties (the oracle's rule, ko_physics.c collide_plane_hull): the first contact is the LOWEST-INDEX vertex within 1 um of the
-    // deepest one - a standing cylinder's 64 rim vertices or a landing cube's four corners are equally deep to the last bits and
-    // "the deepest" would be decided by rounding, differently in fp32 and fp64, and with it the greedy choice of the other three.
+    // Ties between equally deep vertices (a standing cylinder's rim, a landing cube's four corners) are decided by rounding.  The fp64
+    // instantiation - the parity instrument - shares the oracle's rule (ko_physics.c collide_plane_hull): the first contact is the
+    // LOWEST-INDEX vertex within 1e-12 m of the deepest one, so that the two agree whatever the order of their arithmetic; in fp32 the
+    // band is below the rounding of these distances and the team's arg-min stands.  (A physical dead band of 1 um was measured in round 3
+    // and NOT kept: tools/experiments/r03_plane_tie_rule.patch)
+    if constexpr (TIE_RULE) {
+        const T lim = bd + TIE_EPS;
+        int first = 0x7fffffff;
+        if constexpr (SUBS == 16) {
+            // this lane's vertices that can be within the band of the team's minimum, lowest round first (`near` is a superset)
+            unsigned long long c2 = bd_lane <= lim ? near : 0ull;
+            while (c2 != 0) {
+                const int i = __builtin_ctzll(c2) * SUBS + team.sub;
+                if (cdist + V[4 * i] * ln[0] + V[4 * i + 1] * ln[1] + V[4 * i + 2] * ln[2] <= lim) { first = i; break; }
+                c2 &= c2 - 1;
+            }
+            T key = T(0);
+            team.argmin(key, first);
+        } else {
+            for (int i = 0; i < nv; i++)
+                if (cdist + V[4 * i] * ln[0] + V[4 * i + 1] * ln[1] + V[4 * i + 2] * ln[2] <= lim) { first = i; break; }
+        }
+        if (first != 0x7fffffff) best = first;
+    }
     KS_TICK(4)
     T cv[4][3];
     int nc = 1;
@@ -1499,7 +1532,17 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
 #ifdef KS_STAMP_HULL
     const long long th1 = clock64();
 #endif
-    const int r = gjk_distance(pg, margin, &dist, dir, pos, ws);
+    // A pair without margin (the explicit object pairs) that PENETRATED in the previous substep goes straight to the penetration
+    // query (fp32 product only, KS_MPR_FIRST): since round 4 every object contact is a penetration contact, and the distance query in
+    // front of it - whose only job for such a pair is to say "overlap" - needs the most iterations of the wave to do so (it must
+    // enclose the origin), while the lanes with separated pairs confirm their cached separation in one.  MPR decides overlap itself;
+    // the two can only disagree within their tolerances of touching.  The fp64 instantiation keeps the oracle's order.
+#ifndef KS_MPR_FIRST
+#define KS_MPR_FIRST 1
+#endif
+    const bool mpr_first = (KS_MPR_FIRST != 0) && (KS_MPR_WARM != 0) && sizeof(T) == 4 && ws != nullptr && (ws->w[2] >> 30) == 3u && !(margin > T(0));
+    int r = 2;
+    if (!mpr_first) r = gjk_distance(pg, margin, &dist, dir, pos, ws);
 #ifdef KS_STAMP_HULL
     if (prof) { prof[24] += 1.f; prof[25] += (float)pg.cnt_support; prof[26] += (float)(th1 - th0); prof[27] += (float)(clock64() - th1); prof[28] += (float)pg.t_sup; prof[29] += (float)pg.t_clo; }
 #endif

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void k_soft_update(long count, const float* __
 
 // one wave, no LDS: every lane scans its share of the values (agent-scope loads: the writers' stores are device-visible), the wave takes
 // the minimum with shuffles; the launch ends when it has reached the target or the wall clock runs out
-__global__ __launch_bounds__(64) void k_wait_min(const int64_t* __restrict__ values, int n, int64_t target, long long ticks) {
+__global__ __launch_bounds__(64) void k_wait_min(const int64_t* __restrict__ values, int n, int64_t target, long long ticks, int64_t* timeouts) {
     const long long t0 = wall_clock64();
     for (;;) {
         long long m = 0x7fffffffffffffffll;
@@ -321,7 +321,11 @@ __global__ __launch_bounds__(64) void k_wait_min(const int64_t* __restrict__ val
             const long long other = __shfl_xor(m, o);
             m = other < m ? other : m;
         }
-        if (m >= target || (ticks > 0 && wall_clock64() - t0 > ticks)) break;      // (wave-uniform)
+        if (m >= target) break;                                                    // (wave-uniform)
+        if (ticks > 0 && wall_clock64() - t0 > ticks) {
+            if (timeouts && threadIdx.x == 0) atomicAdd((unsigned long long*)timeouts, 1ull);   // a time-out is never silent
+            break;
+        }
         __builtin_amdgcn_s_sleep(64);
     }
 }
@@ -358,10 +362,14 @@ int kr_store_transition(int32_t n, int32_t horizon, int32_t n_steps, int32_t aut
     return launched();
 }
 
-int kr_wait_min(const int64_t* values, int32_t n, int64_t target, double timeout_s, void* stream) {
+int kr_wait_min_counted(const int64_t* values, int32_t n, int64_t target, double timeout_s, int64_t* timeouts, void* stream) {
     if (!values || n <= 0) return KS_ERR_INVALID;
-    hipLaunchKernelGGL(k_wait_min, dim3(1), dim3(64), 0, (hipStream_t)stream, values, n, target, (long long)(timeout_s * 1e8));   // wall_clock64: 100 MHz
+    hipLaunchKernelGGL(k_wait_min, dim3(1), dim3(64), 0, (hipStream_t)stream, values, n, target, (long long)(timeout_s * 1e8), timeouts);   // wall_clock64: 100 MHz
     return launched();
+}
+
+int kr_wait_min(const int64_t* values, int32_t n, int64_t target, double timeout_s, void* stream) {
+    return kr_wait_min_counted(values, n, target, timeout_s, nullptr, stream);
 }
 
 int kr_rank_episodes(int32_t n, const uint8_t* keep, int64_t* rank, int64_t* total, void* stream) {

@@ -72,8 +72,15 @@ def _concurrent_stream(main, dev, tries=8):
 
 
 class GraphedTrainer:
-    def __init__(self, sim, policy, replay, engine, batch_episodes=64, overlap=True, learn_after=31, expert_replay=None, expert_prob=0.3):
-        """expert_replay (a DeviceEpisodeReplay filled by demonstrators.run_controller_episodes or loaded from a reference replay
+    def __init__(self, sim, policy, replay, engine, batch_episodes=64, overlap=True, learn_after=31, expert_replay=None, expert_prob=0.3,
+                 updates_per_step=1):
+        """updates_per_step U / batch_episodes: the update-to-data knobs.  The reference makes 100 updates per 30-step episode of ONE
+        env (main_DDPGfD.py:474-486: ~3 per stored transition); BASELINE config 3 - bench.py's workload - is ONE update on 64 episodes
+        per env-step of 4096 envs.  U > 1 replays the captured update U times per env-step (the step becomes learner-bound beyond
+        U = 1); a larger batch is nearly free instead: the LDS-free learner kernels are one wave per 16 rows and latency-bound, so as
+        long as a pass fits the SIMDs' spare wave slots beside the stepping kernel (~1000 workgroups = 640 episodes) its duration
+        hardly grows with the rows.
+        expert_replay (a DeviceEpisodeReplay filled by demonstrators.run_controller_episodes or loaded from a reference replay
         bundle) turns the update into DDPGfD proper: every batch is int(batch_episodes * (1 - expert_prob)) agent episodes + the rest
         expert episodes (DDPGfD.train_batch, DDPGfD.py:232-254), sampled by ONE launch inside the captured update."""
         assert engine.gen is None, "graph capture uses the default CUDA generator"
@@ -82,6 +89,7 @@ class GraphedTrainer:
         if expert_replay is not None and not (replay.native and expert_replay.native):
             raise ValueError("GraphedTrainer: the expert mix needs device rings (DeviceEpisodeReplay on the GPU)")
         self.batch_episodes, self.overlap, self.learn_after = batch_episodes, overlap, learn_after
+        self.updates_per_step = max(1, int(updates_per_step))
         self.dev = sim.device
         self.steps = 0
         self.updates = 0
@@ -126,6 +134,7 @@ class GraphedTrainer:
         import os as _os
         self.check_every = int(_os.environ.get("KS_REPLICA_CHECK_EVERY", "500")) if self.distributed else 0
         self.replica_checks = 0
+        self.check_in_body = True              # AsyncTrainer checks at the end of a launch instead (its rollout kernel holds every CU's LDS)
 
     # -- learner phases on the static batch -------------------------------------------------------------
     def _sample(self):
@@ -239,7 +248,7 @@ class GraphedTrainer:
             self.g_learn[1].replay()
             self.native.allreduce("actor")
         self.updates += 1
-        if self.check_every and self.updates % self.check_every == 0:
+        if self.check_every and self.check_in_body and self.updates % self.check_every == 0:
             self.check_replicas()
 
     def replica_checksum_spread(self) -> float:
@@ -288,10 +297,14 @@ class GraphedTrainer:
                     self.head_done.record(side)
                     if learn:
                         self._body()
+                        for _ in range(self.updates_per_step - 1):       # further updates of this env-step: behind the first, beside the simulator
+                            self.g_head.replay()
+                            self._body()
                 main.wait_event(self.head_done)    # ring updated, windows sampled, actor weights settled: the body runs on its own
         elif learn:
-            self.g_head.replay()
-            self._body()
+            for _ in range(self.updates_per_step):
+                self.g_head.replay()
+                self._body()
         if self.direct_post:
             self.eng.post(commit=False)
         else:
@@ -335,8 +348,9 @@ class AsyncTrainer(GraphedTrainer):
     path).  Per env the arithmetic and the noise stream are the lock-step ones (tests/test_gpu_async.py: identical trajectories
     for fixed weights).  The reference's own loop acts with a policy that is a whole episode old (main_DDPGfD.py:466-486)."""
 
-    def __init__(self, sim, policy, replay, engine, batch_episodes=64, expert_replay=None, expert_prob=0.3):
-        super().__init__(sim, policy, replay, engine, batch_episodes=batch_episodes, overlap=True, expert_replay=expert_replay, expert_prob=expert_prob)
+    def __init__(self, sim, policy, replay, engine, batch_episodes=64, expert_replay=None, expert_prob=0.3, updates_per_step=1):
+        super().__init__(sim, policy, replay, engine, batch_episodes=batch_episodes, overlap=True, expert_replay=expert_replay, expert_prob=expert_prob,
+                         updates_per_step=updates_per_step)
         from .sim import KsRolloutArgs
         eng, dev = engine, self.dev
         if not self.native.lds_free:
@@ -384,9 +398,19 @@ class AsyncTrainer(GraphedTrainer):
         # rollout (1.1 ms per env-step) and nobody collects the episodes published after that.
         from .sim import load_library
         self._lib = load_library()
+        self.check_in_body = False
         self.pace_lead = int(os.environ.get("KS_ASYNC_LEAD", "8"))           # < 0: no pacing
+        self.pace_timeouts = torch.zeros(1, dtype=torch.long, device=dev)    # waits of the pacing kernel that ended on the clock (counts())
         self.args = a
         self.env_steps = 0
+        # every stepping workgroup of the persistent launch must be RESIDENT at once: a workgroup that does not fit only starts when a
+        # first-round workgroup has finished all of its env-steps, the minimum over the envs' step counters then stands still for a
+        # whole launch and the paced learner stream with it (episodes are dropped meanwhile)
+        n_wg = (eng.n + 15) // 16 + max(0, len(getattr(sim, "models", [1])) - 1)
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        if n_wg > cus and os.environ.get("KS_ASYNC_ALLOW_ROUNDS", "0") == "0":
+            raise ValueError(f"AsyncTrainer: {n_wg} stepping workgroups (16 envs each, one per object group) do not fit the {cus} compute units in one "
+                             "round - use GraphedTrainer (lock step) for this many envs, or KS_ASYNC_ALLOW_ROUNDS=1 to run in rounds anyway")
 
     def publish(self):
         """make the actor's current weights the newest published version: copy into the buffer two behind the one in use, then
@@ -457,6 +481,8 @@ class AsyncTrainer(GraphedTrainer):
         k - KS_ASYNC_LEAD env-steps, default 8), so published episodes keep being collected until a launch of any length
         ends (an env that finishes more episodes than it has open buffers (2) while nobody collects drops them:
         counts()["episodes_dropped"])."""
+        if self.g_commit is None:
+            raise RuntimeError("AsyncTrainer.run before capture(): the learner's graphs do not exist yet")
         main, side = self.main, self.side
         side.wait_stream(main)
         main.wait_stream(side)
@@ -465,13 +491,19 @@ class AsyncTrainer(GraphedTrainer):
         with torch.cuda.stream(side):
             for k in range(n_steps):
                 if self.pace_lead >= 0 and k > self.pace_lead and (k - self.pace_lead) % 4 == 1:      # (every 4th update: the lead varies between 8 and 11)
-                    self._lib.kr_wait_min(self.steps_total.data_ptr(), n, done + k - self.pace_lead, 5.0, torch.cuda.current_stream(self.dev).cuda_stream)
+                    self._lib.kr_wait_min_counted(self.steps_total.data_ptr(), n, done + k - self.pace_lead, 5.0, self.pace_timeouts.data_ptr(),
+                                                  torch.cuda.current_stream(self.dev).cuda_stream)
                 self.g_commit.replay()
                 if learn:
-                    self.g_head.replay()
-                    self.publish()
-                    self._body()
+                    for _ in range(self.updates_per_step):
+                        self.g_head.replay()
+                        self.publish()
+                        self._body()
         self.env_steps += n_steps
+        # the replica check (process-group collectives + a host read: kernels that need LDS, which the persistent launch holds) runs
+        # at the end of a launch, not from inside the update path
+        if learn and self.check_every and self.updates // self.check_every != (self.updates - n_steps * self.updates_per_step) // self.check_every:
+            self.check_replicas()
 
     def step(self):
         self.run(1)
@@ -490,4 +522,4 @@ class AsyncTrainer(GraphedTrainer):
 
     def counts(self):
         c = self.counters[:4].tolist()
-        return {"episodes_finished": c[0], "lifted": c[1], "episodes_kept": c[2], "episodes_dropped": c[3]}
+        return {"episodes_finished": c[0], "lifted": c[1], "episodes_kept": c[2], "episodes_dropped": c[3], "pacing_timeouts": int(self.pace_timeouts.item())}

@@ -46,7 +46,7 @@ class KsRolloutArgs(C.Structure):
 EXPORTS = ["ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_load_model", "ks_load_models", "ks_reset", "ks_reset_objects", "ks_step",
            "ks_get_state", "ks_set_state", "ks_set_env_params", "ks_substep", "ks_rollout", "ks_obs_from_snapshot", "ks_kernel_time", "ks_version"]
 # include/kinova_rollout.h
-ROLLOUT_EXPORTS = ["kr_select_action", "kr_store_transition", "kr_rank_episodes", "kr_wait_min", "kr_commit_episodes", "kr_advance_ring",
+ROLLOUT_EXPORTS = ["kr_select_action", "kr_store_transition", "kr_rank_episodes", "kr_wait_min", "kr_wait_min_counted", "kr_commit_episodes", "kr_advance_ring",
                    "kr_sample_windows", "kr_sample_windows_draw", "kr_sample_windows_mixed", "kr_xchg_create", "kr_xchg_connect", "kr_xchg_allreduce_mean", "kr_xchg_status",
                    "kr_xchg_destroy", "kr_critic_grad", "kr_update_prologue", "kr_relu_backward", "kr_sigmoid_scale_backward", "kr_adam_step", "kr_soft_update",
                    "kr_mlp3_forward", "kr_mlp3_forward_shadow", "kr_mlp3_forward_split", "kr_mlp3_backward_shadow", "kr_mlp3_backward_split", "kr_weight_grad_shadow",
@@ -89,6 +89,7 @@ def load_library(path: Path | None = None):
     L.kr_store_transition.argtypes = [i32] * 5 + [vp] * 21
     L.kr_rank_episodes.argtypes = [i32, vp, vp, vp, vp]
     L.kr_wait_min.argtypes = [vp, i32, C.c_int64, C.c_double, vp]
+    L.kr_wait_min_counted.argtypes = [vp, i32, C.c_int64, C.c_double, vp, vp]
     L.kr_commit_episodes.argtypes = [i32, i32, i32] + [vp] * 16
     L.kr_advance_ring.argtypes = [i32, i32] + [vp] * 6
     L.kr_sample_windows.argtypes = [i32, i32, i32, vp, vp, i32] + [vp] * 15

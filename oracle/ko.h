@@ -13,10 +13,12 @@
  *     third-party binary that is NOT under /root/reference and not installable here.  The
  *     restatement follows MuJoCo's published algorithm (Computation chapter) on the compiled
  *     model data.  The reference's TESTS hold no golden vectors at the mj_step boundary (SURVEY.md
- *     sec. 4, 8c); its tree does hold three sets of recorded MuJoCo 1.50 output (finger joint
- *     traces, ten demonstrations, success / failure maps): the physics is PINNED IN PART to those
- *     (tests/test_mujoco_recorded.py) and UNPINNED for contact forces and
- *     velocities, of which no recording exists.
+ *     sec. 4, 8c); its tree does hold four sets of recorded MuJoCo 1.50 output (a 63-row x 48-column
+ *     contact trajectory - box pushed, grasped and lifted -, finger joint traces, ten demonstrations,
+ *     success / failure maps): the physics is PINNED to those (tests/test_mujoco_recorded.py,
+ *     the contact trajectory to 1.9e-10 in every column for its first 22 rows,
+ *     84 substeps with 18 rows of finger-box contact; first row beyond 1e-6: row 22).  Contact
+ *     forces and velocities of real MuJoCo were never recorded.
  */
 #ifndef KO_H
 #define KO_H

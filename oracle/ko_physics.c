@@ -38,7 +38,12 @@
 #define KO_GJK_TOL 1e-6
 #endif
 #define CCD_EPS 1e-15
-#define KO_SUPPORT_SKEW 1e-9
+#define PLANE_TIE_EPS 1e-12 /* plane-hull: vertices within this of the deepest one count as equally deep, lowest index first */
+#ifdef KO_SUPPORT_SKEW_OVERRIDE
+#define KO_SUPPORT_SKEW KO_SUPPORT_SKEW_OVERRIDE
+#else
+#define KO_SUPPORT_SKEW 1e-6
+#endif
 #define KO_SKEW_X 0.5377
 #define KO_SKEW_Y (-0.6240)
 #define KO_SKEW_Z 0.5671
@@ -339,8 +344,11 @@ static void hull_support(const ko_sim *s, int g, const double *dir, double half_
      * have just built from the hulls' own vertices: every vertex of such a face then attains the maximum to the last bit, rounding
      * decides which one "wins", and the portal / simplex path - hence the contact POINT and, on polytopes that approximate round
      * shapes, even the facet the normal is taken from - follows that coin.  The hull-frame direction is therefore skewed by a
-     * fixed 1e-9 of its size before the scan: 1e-10 m of support error at most, far below every tolerance in use, but seven
-     * orders above fp64 rounding, so that two implementations that scan in different orders take the same vertex. */
+     * fixed 1e-6 of its size before the scan: 1e-7 m of support error at most (a tenth of MPR's tolerance), but an order above the
+     * rounding of an fp32 direction and ten above fp64's, so that the fp64 oracle, the fp64 kernels and - mostly - the fp32 product
+     * take the same vertex.  Measured: with 1e-6 and 1e-5 the replay of the recorded MuJoCo 1.50 contact trajectory is unchanged
+     * (rows 0-21 to 1.9e-10), with 1e-4 it leaves the recording at row 15; fp32 lane vs oracle on 330 CubeS grasp states: contact
+     * points agree 0.994 -> 1.000, worst one-step |dqpos| 2.6e-4 -> 2.2e-5. */
     {
         const double sk = KO_SUPPORT_SKEW * (fabs(ld[0]) + fabs(ld[1]) + fabs(ld[2]));
         ld[0] += sk * KO_SKEW_X; ld[1] += sk * KO_SKEW_Y; ld[2] += sk * KO_SKEW_Z;
@@ -749,6 +757,15 @@ static void collide_plane_hull(ko_sim *s, int g2, const double *pair) {
         if (d < bd) { bd = d; best = i; }
     }
     if (bd > margin) return;
+    /* Ties: a cylinder standing on its base has 64 rim vertices at the same depth to the last bits, a landing cube four - "the
+     * deepest" is then decided by rounding, differently in every arithmetic, and with it the greedy choice of the other three
+     * contacts.  Rule (shared with the fp64 instantiation of the kernels): the first contact is the LOWEST-INDEX vertex within
+     * PLANE_TIE_EPS of the deepest one.  1e-12 m is four orders above fp64 rounding of these distances and has no physical effect
+     * (the 1 um dead band tried in round 3 kept round objects rocking: tools/experiments/r03_plane_tie_rule.patch). */
+    for (int i = 0; i < nv; i++) {
+        double d = cdist + V[3 * i] * ln[0] + V[3 * i + 1] * ln[1] + V[3 * i + 2] * ln[2];
+        if (d <= bd + PLANE_TIE_EPS) { best = i; break; }
+    }
     int chosen[4], nc = 0;
     chosen[nc++] = best;
     double thr2 = PLANE_MESH_TOL * m->geom_rbound[g2];

@@ -13,7 +13,7 @@ over the substeps up to the divergence.
 
 Batches: (a) BASELINE config 2 - CubeS, 'normal' pose, start rows 2 + i, PCG64(1000 + i) action streams; (b) the README's 14
 shapes x 3 hand poses x `per` starts with the closing-grasp + lift action script of the one-step tests.
-usage (GPU box): python -m tests.studies.long_horizon > profiles/r03_long_horizon.txt"""
+usage (GPU box): python -m tests.studies.long_horizon > profiles/r04_long_horizon.txt"""
 import sys
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -88,7 +88,7 @@ def run_batch(shape, q0, hq, actions, n_sub, workers=32):
         dqv[k] = np.abs(vg - vo).max(0)
         phase[k] = [r[2] for r in res]
         fn_o[k] = [r[3] for r in res]
-        bodies = con[:, 8, :].astype(int)
+        bodies = con[:, 8, :].astype(int) & 255              # (bits 8+: the pair's index)
         live = np.arange(24)[:, None] < ncon[None, :]
         on_obj = live & ((bodies // 16 == 9) | (bodies % 16 == 9)) & (bodies % 16 != 0) & (bodies // 16 != 0)
         fn_g[k] = (con[:, 14, :] * on_obj).sum(0)

@@ -134,7 +134,9 @@ def test_eight_ranks_config5_dry_run_on_one_gpu():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 8 and line["config"]["envs_per_gpu"] == 256 and "14 README shapes" in line["config"]["workload"]
     assert line["rccl"]["ranks"] == 8 and line["rccl"]["exchange"].startswith("peer-mapped memory"), line["rccl"]
-    assert line["replica_weight_checksum_spread"] == 0.0 and line["replica_checks_during_run"] >= 2 and line["nonfinite_envs"] == 0
+    # (free-running ranks check their replicas at the END of a rollout launch that crossed a multiple of KS_REPLICA_CHECK_EVERY, not
+    # from inside the update path - the persistent kernel holds the LDS the check's collectives need: one 45-step launch = one check)
+    assert line["replica_weight_checksum_spread"] == 0.0 and line["replica_checks_during_run"] >= 1 and line["nonfinite_envs"] == 0
 
 
 @pytest.mark.gpu
