@@ -175,10 +175,15 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch the rollout / learner ops one by one instead of replaying HIP graphs")
     ap.add_argument("--envs-per-gpu", type=int, default=None, help="default 4096 (the metric's env count); 8192 for --config 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pretrain-updates", type=int, default=1500,
+    ap.add_argument("--init-policy", default="auto",
+                    help="ddpg mode: start from a committed pre-trained 256-256 policy (the reference's 4-file checkpoint format, DDPGfD.py:371-382; default: "
+                         "kinovagrasping_amd/assets/bench_policy/ddpg_256_256_* when present and the widths match) so that the untimed phase and the timed window start "
+                         "from the SAME contact-rich regime in every run and every round - the throughput of this workload follows what the policy does "
+                         "(`timed_window.regime`); 'none': random initialisation as in rounds 1-3")
+    ap.add_argument("--pretrain-updates", type=int, default=None,
                     help="ddpg mode: untimed env-steps with learner updates BEFORE the warm-up, so that the timed steps see the trained policy's "
                          "contact-rich grasps and de-synchronised episode clocks instead of the cheap first episodes of a random policy (0 = time the "
-                         "first episodes, as rounds 1-2 did)")
+                         "first episodes, as rounds 1-2 did); default 1500, or 300 when a pre-trained policy is loaded")
     ap.add_argument("--steady-updates", type=int, default=0, help="further learner updates before the steady_state window (whole episodes)")
     ap.add_argument("--rollout", choices=["auto", "lockstep", "free"], default="auto",
                     help="ddpg mode: 'free' = the free-running rollout kernel (ks_rollout / pipeline.AsyncTrainer, round 3): every stepping workgroup "
@@ -205,6 +210,8 @@ def main():
 
     if args.config == 2:
         args.mode = "sim"
+    if args.mode == "sim" and args.pretrain_updates is None:
+        args.pretrain_updates = 0
     mixed = args.config == 5
     if args.envs_per_gpu is None:
         args.envs_per_gpu = 8192 if mixed else 4096
@@ -233,7 +240,8 @@ def main():
     sl = slice(rank * n, (rank + 1) * n)
     if mixed:
         # config 5: 14 shapes x {normal, rotated, top} x mass / friction per env, all in ONE context and one stepping launch
-        oid_all, pose_all, q0_all, hq_all, mf_all = scenarios.config5_states(n * world, seed=5)
+        # (objects drawn per 16-env cohort: every shape's env count is a multiple of the stepping kernel's group size, see config5_states)
+        oid_all, pose_all, q0_all, hq_all, mf_all = scenarios.config5_states(n * world, seed=5, cohort=16)
         sim = KinovaSim(n, scenarios.SHAPES, device=local_rank, auto_reset=True, horizon=30, solver_iterations=iters)
         reset_all = lambda: sim.reset(torch.as_tensor(q0_all[:, sl]), torch.as_tensor(hq_all[:, sl]), object_id=oid_all[sl], mass_friction=mf_all[:, sl])
     else:
@@ -261,6 +269,16 @@ def main():
         from kinovagrasping_amd.rollout import RolloutEngine
         torch.manual_seed(2)                                   # reference default seed (main_DDPGfD.py:884): identical replicas
         policy = DDPGfD(82, 4, 0.8, 5, batch_size=64, hidden=tuple(args.hidden), device=dev, capturable=not args.eager)
+        init_policy = None
+        if args.init_policy != "none":
+            prefix = ROOT / "kinovagrasping_amd" / "assets" / "bench_policy" / "ddpg_256_256" if args.init_policy == "auto" else Path(args.init_policy)
+            if Path(str(prefix) + "_actor").exists() and (args.init_policy != "auto" or tuple(args.hidden) == (256, 256)):
+                policy.load(str(prefix), sync_targets=True)       # identical on every rank
+                init_policy = str(prefix.relative_to(ROOT)) if prefix.is_relative_to(ROOT) else str(prefix)
+            elif args.init_policy != "auto":
+                sys.exit(f"bench.py: --init-policy {args.init_policy}: no such checkpoint ({prefix}_actor)")
+        if args.pretrain_updates is None:
+            args.pretrain_updates = 300 if init_policy else 1500
         torch.manual_seed(2 + rank)                            # exploration noise / window sampling differ per rank
         replay = DeviceEpisodeReplay(n, capacity=max(4 * n, 1024), horizon=30, device=dev)
         expert, expert_info = None, None
@@ -279,7 +297,8 @@ def main():
             eng = RolloutEngine(sim, policy, replay, expl_noise=0.1)
             eng.start(obs0)
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
-            fits = (n + 15) // 16 + (len(scenarios.SHAPES) - 1 if mixed else 0) <= cus           # one round of stepping workgroups
+            groups = (n + 15) // 16 if not mixed else int(sum((np.bincount(oid_all[sl], minlength=len(scenarios.SHAPES)) + 15) // 16))
+            fits = groups <= cus or groups % cus == 0            # every persistent workgroup steps the same number of 16-env groups
             free_running = not args.serial_learner and (args.rollout == "free" or (args.rollout == "auto" and fits and tuple(args.hidden) in ((256, 256), (128, 128), (64, 64))))
             if free_running:
                 try:
@@ -511,7 +530,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{n} envs/GPU DDPG training on the domain-randomised object set: 14 README shapes x {{normal, rotated, top}} hand "
                                     "poses (reference thresholds, no-noise tables, pose hand offsets), per-env mass U[0.05,0.15] kg and friction "
-                                    "U[0.5,1.0], one simulator context / one stepping launch; 256-256 actor/critic, one DDPGfD update per env-step "
+                                    "U[0.5,1.0] (shape drawn per 16-env cohort, everything else per env), one simulator context / one stepping launch; 256-256 actor/critic, one DDPGfD update per env-step "
                                     "(BASELINE config 5; 65536 envs when n_gpus=8)") if mixed else
                                    (f"{n} envs/GPU DDPG training, 256-256 actor/critic, CubeS normal pose: actor inference + exploration noise + "
                                     "scripted lift in the loop, device replay, one DDPGfD update (64 episodes x 25 five-step windows) per "
@@ -527,6 +546,7 @@ def main():
                        "launch": (("eager" if args.eager else ("free-running rollout kernel (ks_rollout), <= %d env-steps per launch (timed region: %s) + learner graphs" % (args.chunk, timed_launches)
                                                                 if free_running else "hip-graphs, one stepping launch per env-step")) if args.mode == "ddpg" else "direct"),
                        "free_running": (dict(trainer.counts(), launch_steps=all_launches, first_timed_launch=timed_first, timed_launches=launches) if free_running else None),
+                       "init_policy": (init_policy if args.mode == "ddpg" else None),
                        "learner": learner_form, "learner_stream_overlaps_rollout_stream": (getattr(trainer, "streams_overlap", None) if trainer is not None else None), "expert_mix": (expert_info if args.mode == "ddpg" else None),
                        "parallelism": f"env-shard x{world}" + (" + grad all-reduce" if world > 1 and args.mode == "ddpg" else "")},
             "roofline": {"bound": "hbm", "kernel": "k_rollout (per env-step)" if free_running else "k_env_step", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--updates-per-step", type=int, default=1, help="learner updates per env-step of the whole batch of envs")
     ap.add_argument("--actor-lr", type=float, default=1e-4, help="reference: 1e-4 (DDPGfD.py:57)")
     ap.add_argument("--critic-lr", type=float, default=1e-3, help="reference: Adam's default 1e-3 (DDPGfD.py:61)")
+    ap.add_argument("--tau", type=float, default=0.0005, help="soft target update rate (reference: 0.0005, main_DDPGfD.py:894)")
+    ap.add_argument("--target-every", type=int, default=10, help="target networks follow every this many updates (reference: 10, DDPGfD.py:64-66,360-366)")
     ap.add_argument("--expl-noise", type=float, default=0.1, help="exploration noise, std = 0.8 x this (main_DDPGfD.py:443-446: 0.1)")
     ap.add_argument("--save", default=None, help="write the trained policy as the reference's 4-file checkpoint with this prefix")
     args = ap.parse_args()
@@ -84,7 +86,8 @@ def main():
     from kinovagrasping_amd.pipeline import AsyncTrainer, GraphedTrainer
     sim = KinovaSim(n, args.shape, auto_reset=True, horizon=30)
     q0, hq = start_states(n, args.shape, rng)
-    policy = DDPGfD(82, 4, 0.8, 5, batch_size=args.batch_episodes, hidden=tuple(args.hidden), device=dev)
+    policy = DDPGfD(82, 4, 0.8, 5, tau=args.tau, batch_size=args.batch_episodes, hidden=tuple(args.hidden), device=dev)
+    policy.network_repl_freq = args.target_every
     policy.actor_optimizer.param_groups[0]["lr"] = args.actor_lr
     policy.critic_optimizer.param_groups[0]["lr"] = args.critic_lr
     agent = DeviceEpisodeReplay(n, capacity=max(4 * n, 4096), device=dev)

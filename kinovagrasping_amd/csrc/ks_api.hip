@@ -750,13 +750,14 @@ __device__ __noinline__ void rollout_store(const ks_rollout_args* __restrict__ r
 template <int NT1, int NT2>
 __device__ __forceinline__ void rollout_iter(const Model<float>& m, const Hulls<float>& hu, const Buffers<float>* __restrict__ bdev, int N, int frame_skip,
                                           int iters, int epw, int pair_memory, const ObsOut<float>* __restrict__ out,
-                                          const ks_rollout_args* __restrict__ rap, KS_LDS float* blocks) {
+                                          const ks_rollout_args* __restrict__ rap, KS_LDS float* blocks, int grp) {
     using T = float;
     const Buffers<T>& b = *bdev;
     const int e = threadIdx.x / LANE_STRIDE;
     const Team<SUBS> team{(int)threadIdx.x % LANE_STRIDE};
     // (the env ids are re-read from the slot list in every iteration rather than kept in registers across the stepping phase)
-    const int env = e < epw ? b.slot_env[blockIdx.x * epw + e] : -1;
+    // grp: the 16-env group of the slot list this workgroup steps now (its own, blockIdx.x, unless the launch has fewer workgroups than groups)
+    const int env = e < epw ? b.slot_env[grp * epw + e] : -1;
     const bool active = !(team.sub >= SUBS || env < 0);
     KS_LDS unsigned* w = (KS_LDS unsigned*)blocks;
 #ifdef KS_ROLLOUT_STAMP
@@ -768,7 +769,7 @@ __device__ __forceinline__ void rollout_iter(const Model<float>& m, const Hulls<
 #endif
     {
         const int nn = threadIdx.x & 15;
-        const int row_env = nn < epw ? b.slot_env[blockIdx.x * epw + nn] : -1;   // the policy row of this lane (the same in all four waves)
+        const int row_env = nn < epw ? b.slot_env[grp * epw + nn] : -1;   // the policy row of this lane (the same in all four waves)
         rollout_policy<NT1, NT2>(rap, N, row_env, blocks);
     }
     __threadfence_block();
@@ -811,11 +812,11 @@ __device__ __forceinline__ void rollout_iter(const Model<float>& m, const Hulls<
     __threadfence_block();
     __syncthreads();
     KS_RS(1)
-    wg_rays(m, b, N, blockIdx.x * epw, epw, w KS_RAY_PROF_ARG((long long*)&rap->counters[8 + 4 * 512]));
+    wg_rays(m, b, N, grp * epw, epw, w KS_RAY_PROF_ARG((long long*)&rap->counters[8 + 4 * 512]));
     __threadfence_block();
     __syncthreads();
     KS_RS(2)
-    wg_obs(m, b, N, blockIdx.x * epw, epw, w, *out);
+    wg_obs(m, b, N, grp * epw, epw, w, *out);
     __threadfence_block();
     __syncthreads();
     if (active) rollout_store(rap, N, env, team.sub);
@@ -825,21 +826,38 @@ __device__ __forceinline__ void rollout_iter(const Model<float>& m, const Hulls<
 #undef KS_RS
 }
 
+// another object's model constants and hull tables into the workgroup's LDS (out of line: nothing of it may stay in registers across
+// the stepping phase); returns the offset of the env blocks behind the tables, in words
+__device__ __noinline__ int rollout_restage(const Model<float>* __restrict__ mp, KS_LDS float* lds0, Hulls<float>* hup) {
+    __syncthreads();
+    const Model<float>* ml = stage_model_and_tables<float, WG>(mp, lds0);
+    int hull_words = 0;
+    __syncthreads();
+    stage_hulls<float, true>(*ml, lds0 + model_words<float>(), hull_words, *hup, true);
+    return (hull_words >> 2) << 2;
+}
+
 template <int NT1, int NT2>
 __global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__ models, Buffers<float> b, const Buffers<float>* __restrict__ bdev, int N,
                                                 int frame_skip, int iters, int epw, int pair_memory, const ObsOut<float>* __restrict__ out,
-                                                const ks_rollout_args* __restrict__ rap, int n_iter) {
+                                                const ks_rollout_args* __restrict__ rap, int n_iter, int n_groups) {
     using T = float;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef KS_ROLLOUT_STAMP
     const long long wk_entry = wall_clock64();      // diagnostic build: counters[] is [8 + 4 * 512 + 8] there (pipeline.AsyncTrainer allocates that)
 #endif
-    KS_LDS T* lds = (KS_LDS T*)smem;
-    const Model<T>* mp = models + __builtin_amdgcn_readfirstlane(b.wg_model[blockIdx.x]);
-    const Model<T>* ml = stage_model_and_tables<T, WG>(mp, lds);
-    lds += model_words<T>();
+    // The 16-env groups of the slot list [n_groups] are dealt to the launch's workgroups in contiguous runs (the list is sorted by
+    // object, so a workgroup's groups mostly share their hull tables): one group per workgroup when they all fit the GPU at once
+    // (4096 envs on 256 CUs), two or three when they do not (BASELINE config 5: 8192 envs) - a persistent workgroup then takes its
+    // groups' env-steps in turn, every group always on the same CU (its state never changes caches), instead of a second round of
+    // workgroups that could only start when a first-round workgroup had finished ALL its env-steps.
+    const int g0 = (int)((long)blockIdx.x * n_groups / gridDim.x), g1 = (int)((long)(blockIdx.x + 1) * n_groups / gridDim.x);
+    KS_LDS T* const lds0 = (KS_LDS T*)smem;
+    KS_LDS T* const lds = lds0 + model_words<T>();
+    Hulls<T>* const hup = (Hulls<T>*)(smem + (sizeof(Model<T>) + 15) / 16 * 16);
+    int staged = __builtin_amdgcn_readfirstlane(b.wg_model[g0]);
+    const Model<T>* ml = stage_model_and_tables<T, WG>(models + staged, lds0);
     int hull_words = 0;
-    Hulls<T>* hup = (Hulls<T>*)(smem + (sizeof(Model<T>) + 15) / 16 * 16);
     __syncthreads();
     stage_hulls<T, true>(*ml, lds, hull_words, *hup, true);
     KS_LDS T* blocks = lds + ((hull_words >> 2) << 2);                 // the 16 env blocks; scratch of the tails between the steps
@@ -853,15 +871,27 @@ __global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__
     // 1.5 KB per lane) - and the learner's waves (<= 168 registers) must fit beside this kernel on every SIMD.
 #pragma clang loop unroll(disable)
     for (int it = 0; it < n_iter; it++) {
-        const Model<T>* mi = ml;
-        Hulls<T>* hi = hup;
-        const Buffers<T>* bi = bdev;
-        const ObsOut<T>* oi = out;
-        const ks_rollout_args* ri = rap;
-        KS_LDS T* ki = blocks;
-        asm volatile("" : "+s"(mi), "+s"(hi), "+s"(bi), "+s"(oi), "+s"(ri));
-        asm volatile("" : "+v"(ki));
-        rollout_iter<NT1, NT2>(*mi, *hi, bi, N, frame_skip, iters, epw, pair_memory, oi, ri, ki);
+#pragma clang loop unroll(disable)
+        for (int grp = g0; grp < g1; grp++) {
+            if (g1 - g0 > 1) {
+                // another group of this workgroup: restage the tables when its object differs from the one in LDS (~10 us)
+                const int want = __builtin_amdgcn_readfirstlane(bdev->wg_model[grp]);
+                if (want != staged) {
+                    staged = want;
+                    blocks = lds + rollout_restage(models + staged, lds0, hup);
+                }
+            }
+            const Model<T>* mi = ml;
+            Hulls<T>* hi = hup;
+            const Buffers<T>* bi = bdev;
+            const ObsOut<T>* oi = out;
+            const ks_rollout_args* ri = rap;
+            KS_LDS T* ki = blocks;
+            int gi = grp;
+            asm volatile("" : "+s"(mi), "+s"(hi), "+s"(bi), "+s"(oi), "+s"(ri), "+s"(gi));
+            asm volatile("" : "+v"(ki));
+            rollout_iter<NT1, NT2>(*mi, *hi, bi, N, frame_skip, iters, epw, pair_memory, oi, ri, ki, gi);
+        }
     }
 #ifdef KS_ROLLOUT_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 512) {
@@ -1452,12 +1482,20 @@ template <typename T> struct Ctx : CtxBase {
     }
     int blocks() const { return (cfg.n_envs + WAVE - 1) / WAVE; }
     // envs per wave and dynamic LDS bytes of the stepping kernels
+    int resident_wgs = 256;
     int lpw = WAVE;
     bool rays_in_step = false, obs_in_step = false;
     int ray_pool = 0;                     // 0 every workgroup casts its own envs' rays, 1 pooled, 2 pooled + early finishers linger
     size_t step_lds = 0;
     int hull_words = 0;
     int plan_launch() {
+        {
+            // workgroups of the persistent rollout kernel that are resident at once: one per compute unit (each takes all of a CU's LDS)
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+            if (const char* e = getenv("KS_ROLLOUT_WGS")) { const int v = atoi(e); if (v > 0) cus = v; }
+            resident_wgs = cus;
+        }
         const size_t lds_max = 160 * 1024;
         const size_t hull_bytes = (size_t)hull_words * sizeof(T) + (USE_LDS ? (size_t)model_words<T>() * sizeof(T) : 0);
         const size_t per_env = USE_LDS ? (size_t)SCR_TOTAL * sizeof(T) : 0;
@@ -1560,8 +1598,8 @@ template <typename T> struct Ctx : CtxBase {
 #define KS_ROLLOUT_CASE(A, B)                                                                                                                         \
     if ((ra->h1 + 15) / 16 == A && (ra->h2 + 15) / 16 == B) {                                                                                                 \
         HIPCHK(hipFuncSetAttribute((const void*)k_rollout<A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));                        \
-        hipLaunchKernelGGL((k_rollout<A, B>), dim3(n_wg), dim3(WG), step_lds, s, d_model, b, (const Buffers<T>*)d_b, N, cfg.frame_skip,              \
-                           cfg.solver_iterations, lpw, (int)cfg.pair_memory, (const ObsOut<T>*)d_out, (const ks_rollout_args*)d_ra, n_iter);                                \
+        hipLaunchKernelGGL((k_rollout<A, B>), dim3(n_wg < resident_wgs ? n_wg : resident_wgs), dim3(WG), step_lds, s, d_model, b, (const Buffers<T>*)d_b, N, cfg.frame_skip,              \
+                           cfg.solver_iterations, lpw, (int)cfg.pair_memory, (const ObsOut<T>*)d_out, (const ks_rollout_args*)d_ra, n_iter, n_wg);                                \
         HIPCHK(hipGetLastError());                                                                                                                    \
         return KS_OK;                                                                                                                                 \
     }

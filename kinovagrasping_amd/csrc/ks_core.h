@@ -1532,14 +1532,14 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
 #ifdef KS_STAMP_HULL
     const long long th1 = clock64();
 #endif
-    // A pair without margin (the explicit object pairs) that PENETRATED in the previous substep goes straight to the penetration
-    // query (fp32 product only, KS_MPR_FIRST): since round 4 every object contact is a penetration contact, and the distance query in
+    // (Experiment, off by default.)  A pair without margin (the explicit object pairs) that PENETRATED in the previous substep goes straight
+    // to the penetration query (fp32 product only, KS_MPR_FIRST): since round 4 every object contact is a penetration contact, and the distance query in
     // front of it - whose only job for such a pair is to say "overlap" - needs the most iterations of the wave to do so (it must
     // enclose the origin), while the lanes with separated pairs confirm their cached separation in one.  MPR decides overlap itself;
     // the two can only disagree within their tolerances of touching.  The fp64 instantiation keeps the oracle's order.
 #ifndef KS_MPR_FIRST
-#define KS_MPR_FIRST 1
-#endif
+#define KS_MPR_FIRST 0          // measured in round 4 (one box, A/B): sim-only 4.28 M with it, 4.36 M without - the waves run in lockstep, the lanes
+#endif                          // that skip the distance query wait for those that do not, and the extra branch costs more than it saves: off
     const bool mpr_first = (KS_MPR_FIRST != 0) && (KS_MPR_WARM != 0) && sizeof(T) == 4 && ws != nullptr && (ws->w[2] >> 30) == 3u && !(margin > T(0));
     int r = 2;
     if (!mpr_first) r = gjk_distance(pg, margin, &dist, dir, pos, ws);

@@ -403,14 +403,17 @@ class AsyncTrainer(GraphedTrainer):
         self.pace_timeouts = torch.zeros(1, dtype=torch.long, device=dev)    # waits of the pacing kernel that ended on the clock (counts())
         self.args = a
         self.env_steps = 0
-        # every stepping workgroup of the persistent launch must be RESIDENT at once: a workgroup that does not fit only starts when a
-        # first-round workgroup has finished all of its env-steps, the minimum over the envs' step counters then stands still for a
-        # whole launch and the paced learner stream with it (episodes are dropped meanwhile)
-        n_wg = (eng.n + 15) // 16 + max(0, len(getattr(sim, "models", [1])) - 1)
+        # The persistent launch has one workgroup per compute unit at most; with more 16-env groups than CUs (BASELINE config 5: 8192 envs)
+        # every workgroup steps two or three groups in turn (k_rollout).  Balanced only when the groups divide evenly over the CUs: a
+        # workgroup with one group more than the others sets the launch's pace - say so.
+        n_groups = (eng.n + 15) // 16 + max(0, len(getattr(sim, "models", [1])) - 1)       # upper bound (one partly filled group per object)
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        if n_wg > cus and os.environ.get("KS_ASYNC_ALLOW_ROUNDS", "0") == "0":
-            raise ValueError(f"AsyncTrainer: {n_wg} stepping workgroups (16 envs each, one per object group) do not fit the {cus} compute units in one "
-                             "round - use GraphedTrainer (lock step) for this many envs, or KS_ASYNC_ALLOW_ROUNDS=1 to run in rounds anyway")
+        self.groups_per_workgroup = (n_groups + cus - 1) // cus
+        if n_groups > cus and n_groups % cus:
+            import warnings
+            warnings.warn(f"AsyncTrainer: up to {n_groups} env groups on {cus} compute units: some persistent workgroups step {self.groups_per_workgroup} groups per "
+                          f"env-step, others {self.groups_per_workgroup - 1} - the launch runs at the pace of the former (GraphedTrainer's lock-step launches balance "
+                          "such a batch dynamically)", RuntimeWarning)
 
     def publish(self):
         """make the actor's current weights the newest published version: copy into the buffer two behind the one in use, then

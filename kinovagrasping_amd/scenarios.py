@@ -80,14 +80,20 @@ def hand_slide_offsets(orientation: str, shape: str, mode: str = "pose") -> np.n
     return np.array([-v[0], -v[1], v[2]])
 
 
-def config5_states(n_envs: int, seed: int = 5, hand_offsets: str = "pose"):
-    """BASELINE config 5: env i holds one of the README's 14 shapes drawn uniformly, an orientation class from
+def config5_states(n_envs: int, seed: int = 5, hand_offsets: str = "pose", cohort: int = 1):
+    """cohort > 1: the object is drawn once per `cohort` consecutive envs instead of per env (every env's shape is still uniform over
+    the 14, orientation / start row / mass / friction stay per env).  With cohort = 16 every shape's env count is a multiple of the
+    stepping kernel's 16-env groups: N / 16 groups instead of up to N / 16 + 13, so that each of the free-running rollout's 256
+    persistent workgroups steps exactly two groups of an 8192-env batch (bench.py --config 5).
+    BASELINE config 5: env i holds one of the README's 14 shapes drawn uniformly, an orientation class from
     the reference's thresholds (ENV:1212-1220: t = rand(); < 0.333 normal, > 0.667 top, else rotated) with the env's
     no-noise Euler constants and hand offsets (ENV:1267-1273, 1286-1307), the object at a row of the matching no_noise
     table, mass ~ U[0.05, 0.15] kg and finger-object friction ~ U[0.5, 1.0]; Generator(PCG64(seed)).
     Returns object_id [N] int32, orientation names [N], qpos0 [16, N], hand_quat [4, N], mass_friction [2, N]."""
     rng = np.random.Generator(np.random.PCG64(seed))
     oid = rng.integers(0, len(SHAPES), n_envs).astype(np.int32)
+    if cohort > 1:
+        oid = np.repeat(oid[:(n_envs + cohort - 1) // cohort], cohort)[:n_envs].copy()      # (same stream: cohort = 1 is the draw of rounds 2-3)
     t = rng.random(n_envs)
     names = ["normal" if x < 0.333 else ("top" if x > 0.667 else "rotated") for x in t]
     q = np.zeros((16, n_envs))

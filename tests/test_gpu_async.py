@@ -11,13 +11,13 @@ from kinovagrasping_amd import scenarios
 pytestmark = pytest.mark.gpu
 
 
-def _setup(n, horizon, seed=2, hidden=(256, 256), mixed=False):
+def _setup(n, horizon, seed=2, hidden=(256, 256), mixed=False, cohort=1):
     from kinovagrasping_amd.ddpgfd import DDPGfD
     from kinovagrasping_amd.replay import DeviceEpisodeReplay
     from kinovagrasping_amd.rollout import RolloutEngine
     from kinovagrasping_amd.sim import KinovaSim
     if mixed:            # BASELINE config 5's start states: 14 objects x 3 hand poses x mass / friction in one context
-        oid, _, q0, hq, mf = scenarios.config5_states(n, seed=5)
+        oid, _, q0, hq, mf = scenarios.config5_states(n, seed=5, cohort=cohort)
         sim = KinovaSim(n, scenarios.SHAPES, horizon=horizon, auto_reset=True)
         obs0 = sim.reset(torch.as_tensor(q0), torch.as_tensor(hq), object_id=oid, mass_friction=mf)
     else:
@@ -41,15 +41,21 @@ def _ring_episodes(replay):
 
 
 @pytest.mark.parametrize("hidden,mixed,horizon,per,n", [((256, 256), False, 12, 9, 272), ((64, 64), False, 12, 9, 272), ((256, 256), True, 12, 9, 272),
-                                                        ((256, 256), False, 30, 13, 272), ((256, 256), False, 30, 12, 4096)])
+                                                        ((256, 256), False, 30, 13, 272), ((256, 256), False, 30, 12, 4096),
+                                                        ((256, 256), "cohort", 30, 7, 8192), ((256, 256), True, 12, 5, 4400)])
 def test_free_running_rollout_equals_the_lock_step_calls(hidden, mixed, horizon, per, n):
     """horizon 12: every env runs into the time limit three times in 45 env-steps; horizon 30, 65 env-steps: the (bias-pushed) actor closes
     the hand, check_grasp fires, the scripted lift ends episodes early - the un-stored lift steps and the overwrite of the last stored
-    transition (utils.py:309-343) are part of what must match.  n = 4096: the bench's shape (BASELINE config 3: one workgroup on every CU)."""
+    transition (utils.py:309-343) are part of what must match.  n = 4096: the bench's shape (BASELINE config 3: one workgroup on every CU).
+    n = 8192, 14 shapes in 16-env cohorts: BASELINE config 5's per-GPU shape as bench.py runs it - 512 groups, every one of the 256 persistent
+    workgroups steps two of them in turn and restages another object's tables in between; n = 4400 mixed: 288 groups that do NOT divide
+    evenly (some workgroups step two groups, most one)."""
     from kinovagrasping_amd.pipeline import AsyncTrainer
+    import warnings
     chunks = 5                                           # n = 272: 17 workgroups
+    cohort, mixed = (16 if mixed == "cohort" else 1), bool(mixed)
     # lock step: the three calls per env-step
-    sim, policy, replay, eng = _setup(n, horizon, hidden=hidden, mixed=mixed)
+    sim, policy, replay, eng = _setup(n, horizon, hidden=hidden, mixed=mixed, cohort=cohort)
     for _ in range(chunks * per):
         eng.step()
     torch.cuda.synchronize()
@@ -57,8 +63,10 @@ def test_free_running_rollout_equals_the_lock_step_calls(hidden, mixed, horizon,
                status=sim.get_state()["status"].clone(), eps=_ring_episodes(replay), count=replay.count, done=eng.done_out.clone())
     sim.close()
     # free running: 5 launches of 9 env-steps, episodes handed over between the launches
-    sim, policy, replay, eng = _setup(n, horizon, hidden=hidden, mixed=mixed)
-    tr = AsyncTrainer(sim, policy, replay, eng, batch_episodes=16)
+    sim, policy, replay, eng = _setup(n, horizon, hidden=hidden, mixed=mixed, cohort=cohort)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)          # (the uneven 4400-env case warns about its imbalance)
+        tr = AsyncTrainer(sim, policy, replay, eng, batch_episodes=16)
     for _ in range(chunks):
         sim.rollout(per, tr.args)
         replay.commit_published()
@@ -66,8 +74,8 @@ def test_free_running_rollout_equals_the_lock_step_calls(hidden, mixed, horizon,
     st = sim.get_state()
     c = tr.counts()
     print(f"free-running {hidden} mixed={mixed}: {c}, ring {replay.count} episodes; lock step ring {ref['count']}")
-    assert c["episodes_dropped"] == 0 and c["episodes_finished"] >= (3 if horizon == 12 else 2) * n
-    if horizon == 30:
+    assert c["episodes_dropped"] == 0 and c["episodes_finished"] >= ((3 if per >= 9 else 2) if horizon == 12 else (2 if per >= 12 else 1)) * n
+    if horizon == 30 and not mixed:
         assert c["lifted"] > 0.05 * n
     assert torch.equal(st["qpos"], ref["qpos"]) and torch.equal(st["status"], ref["status"])
     assert torch.equal(eng.obs, ref["obs"]) and torch.equal(eng.prev_obs, ref["prev"]) and torch.equal(eng.t, ref["t"]) and torch.equal(eng.ready, ref["ready"])

@@ -195,12 +195,23 @@ def test_batch_config2_first_steps(cube):
     sim.close()
 
 
+# share of each shape's 12 grasp-and-lift envs (3 poses x 4 starts) within 1e-4 relative at substep 200, measured in round 4 with the
+# explicit pairs at margin 0 and the shared support tie rule (profiles/r04_long_horizon.txt); the test asserts two envs of slack
+LONG_HORIZON_MEASURED = {"CubeS": 11, "CubeB": 11, "CylinderS": 4, "CylinderB": 4, "Cube45S": 8, "Cube45B": 10, "Cone1S": 8, "Cone1B": 8, "Cone2S": 9,
+                         "Cone2B": 5, "Vase1S": 9, "Vase1B": 5, "Vase2S": 3, "Vase2B": 4}
+
+
 def test_batched_long_horizon_parity_200_substeps():
     """north_star's bar, batched: 256 BASELINE config-2 envs (random +-0.8 actions) free-running for 200 consecutive
-    substeps, fp32 kernels vs fp64 oracle, every substep compared; plus two shapes x 3 poses x 4 starts with the grasp-and-lift
-    script.  Asserted: the share of envs that is within 1e-4 relative at substep 200 and never left it on the way (measured in
-    round 3 over 512 envs: 0.992 - tests/studies/long_horizon.py, profiles/r03_long_horizon.txt has the per-phase histogram of
-    the first divergences with qvel / normal-force traces); the median stays at round-off level."""
+    substeps, fp32 kernels vs fp64 oracle, every substep compared; plus ALL 14 shapes x 3 poses x 4 starts with the grasp-and-lift
+    script, asserted PER SHAPE (tests/studies/long_horizon.py; profiles/r04_long_horizon.txt has the per-phase histogram of the first
+    divergences with qvel / normal-force traces).
+    Random actions: >= 97 % of the envs are within 1e-4 at substep 200 and never left it on the way (measured 0.994 of 512).
+    Grasp-and-lift scripts: 99 of 168 in round 4.  Cubes: 11 of 12.  Round shapes (67-gon cylinders / vases, cones) are where MuJoCo's own
+    contact model is discontinuous: the single MPR contact of a finger on a polygonal "round" surface jumps from one facet to the next
+    (normals 5.4 degrees apart) and a resting rim has 67 equally deep vertices - an fp32 state error of 1e-7 decides such an event one
+    substep earlier or later and the trajectories then differ by 1e-3 - 1e-2.  (Real MuJoCo is equally sensitive there: in the recorded
+    trajectory one such event at row 22 separates a 1e-10 replay from a 1e-4 one)"""
     from tests.studies import long_horizon as lh
     res = lh.config2_batch(256, 200)
     rel = res["rel"]
@@ -209,14 +220,16 @@ def test_batched_long_horizon_parity_200_substeps():
     print(lh.summarize("config 2 x 256", res))
     assert (res["status"] == 0).all()
     assert never >= 0.97 and np.median(rel[199]) < 1e-6 and np.percentile(rel[199], 90) < 1e-5
-    shapes = lh.shapes_batches(4, 200, shapes=["CubeS", "CylinderB"])
+    shapes = lh.shapes_batches(4, 200)
+    within = {}
     for sh, r in shapes.items():
         print(lh.summarize(sh, r))
         assert np.isfinite(r["rel"]).all() and (r["status"] & 2 == 0).all()
-    # grasp-and-lift scripts are harder than random actions: every env goes through a light first touch where the contact
-    # toggles from substep to substep; one toggle decided differently in fp32 (state error ~1e-7 against a threshold) is a
-    # |dqvel| ~ 5e-2 kick.  Measured: 111 of 168 envs (14 shapes x 3 poses x 4 starts) within 1e-4 at substep 200.
-    assert np.mean(shapes["CubeS"]["rel"][199] <= 1e-4) >= 0.65 and np.median(shapes["CubeS"]["rel"][199]) < 1e-4
+        within[sh] = int((r["rel"][199] <= 1e-4).sum())
+    print("envs of 12 within 1e-4 at substep 200:", within, "total", sum(within.values()), "of", 12 * len(within))
+    short = {sh: (k, LONG_HORIZON_MEASURED[sh]) for sh, k in within.items() if k < LONG_HORIZON_MEASURED[sh] - 2}
+    assert not short, short
+    assert sum(within.values()) >= 90 and np.median(shapes["CubeS"]["rel"][199]) < 1e-4
 
 
 def test_time_limit_done_and_auto_reset():
