@@ -722,6 +722,20 @@ __device__ __noinline__ void rollout_store(const ks_rollout_args* __restrict__ r
             const bool keep = len1 - ra.n_steps > 1;
             const long bo = (long)(sel ^ 1) * N + i;
             const bool free_other = __hip_atomic_load(&ra.pub_len[bo], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0;
+#ifdef KS_DEBUG_DROPS
+            // diagnostic build: counters[] has N more words behind its 8 + 4 * 512 + 8; [4] sum of env-steps since the env's last publication at a
+            // drop, [5] drops, [6] smallest such gap, [7] drops whose other buffer reads as free on a second, later look
+            int64_t* dbg = ra.counters + 8 + 4 * 512 + 8;
+            if (keep && !free_other) {
+                const long long gap = (long long)ra.steps_total[i] - (long long)dbg[i];
+                atomicAdd((unsigned long long*)&ra.counters[4], (unsigned long long)gap);
+                atomicAdd((unsigned long long*)&ra.counters[5], 1ull);
+                atomicMin((long long*)&ra.counters[6], gap);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (__hip_atomic_load(&ra.pub_len[bo], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicAdd((unsigned long long*)&ra.counters[7], 1ull);
+            }
+            if (keep && free_other) dbg[i] = ra.steps_total[i];
+#endif
             if (keep && free_other) {
                 __threadfence();                                                // (the team's row stores were fenced by the caller)
                 __hip_atomic_store(&ra.pub_len[bi], (int64_t)len1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -851,7 +865,13 @@ __global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__
     // (4096 envs on 256 CUs), two or three when they do not (BASELINE config 5: 8192 envs) - a persistent workgroup then takes its
     // groups' env-steps in turn, every group always on the same CU (its state never changes caches), instead of a second round of
     // workgroups that could only start when a first-round workgroup had finished ALL its env-steps.
-    const int g0 = (int)((long)blockIdx.x * n_groups / gridDim.x), g1 = (int)((long)(blockIdx.x + 1) * n_groups / gridDim.x);
+    // (n_groups < 0: the groups are dealt round-robin instead - workgroup w steps groups w, w + G, w + 2 G ... - which mixes objects
+    // within a workgroup: more table restaging, but cheap and expensive objects average out over a workgroup's groups)
+    const bool deal_rr = n_groups < 0;
+    if (deal_rr) n_groups = -n_groups;
+    const int g0 = deal_rr ? (int)blockIdx.x : (int)((long)blockIdx.x * n_groups / gridDim.x);
+    const int g1 = deal_rr ? n_groups : (int)((long)(blockIdx.x + 1) * n_groups / gridDim.x);
+    const int gstep = deal_rr ? (int)gridDim.x : 1;
     KS_LDS T* const lds0 = (KS_LDS T*)smem;
     KS_LDS T* const lds = lds0 + model_words<T>();
     Hulls<T>* const hup = (Hulls<T>*)(smem + (sizeof(Model<T>) + 15) / 16 * 16);
@@ -872,8 +892,8 @@ __global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__
 #pragma clang loop unroll(disable)
     for (int it = 0; it < n_iter; it++) {
 #pragma clang loop unroll(disable)
-        for (int grp = g0; grp < g1; grp++) {
-            if (g1 - g0 > 1) {
+        for (int grp = g0; grp < g1; grp += gstep) {
+            if (g1 - g0 > gstep) {
                 // another group of this workgroup: restage the tables when its object differs from the one in LDS (~10 us)
                 const int want = __builtin_amdgcn_readfirstlane(bdev->wg_model[grp]);
                 if (want != staged) {
@@ -1483,6 +1503,7 @@ template <typename T> struct Ctx : CtxBase {
     int blocks() const { return (cfg.n_envs + WAVE - 1) / WAVE; }
     // envs per wave and dynamic LDS bytes of the stepping kernels
     int resident_wgs = 256;
+    bool rollout_round_robin = false;     // how k_rollout deals the env groups to its persistent workgroups: contiguous runs (default) or round-robin (KS_ROLLOUT_DEAL=rr)
     int lpw = WAVE;
     bool rays_in_step = false, obs_in_step = false;
     int ray_pool = 0;                     // 0 every workgroup casts its own envs' rays, 1 pooled, 2 pooled + early finishers linger
@@ -1495,6 +1516,10 @@ template <typename T> struct Ctx : CtxBase {
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
             if (const char* e = getenv("KS_ROLLOUT_WGS")) { const int v = atoi(e); if (v > 0) cus = v; }
             resident_wgs = cus;
+            // mixed-object contexts: round-robin (cheap and expensive objects average out over a workgroup's groups: BASELINE config 5 with the
+            // trained policy 2.89 M env-steps/s against 2.02 M with contiguous runs, round 4); one object: contiguous (nothing to restage)
+            rollout_round_robin = n_models > 1;
+            if (const char* e = getenv("KS_ROLLOUT_DEAL")) rollout_round_robin = strcmp(e, "rr") == 0;
         }
         const size_t lds_max = 160 * 1024;
         const size_t hull_bytes = (size_t)hull_words * sizeof(T) + (USE_LDS ? (size_t)model_words<T>() * sizeof(T) : 0);
@@ -1599,7 +1624,7 @@ template <typename T> struct Ctx : CtxBase {
     if ((ra->h1 + 15) / 16 == A && (ra->h2 + 15) / 16 == B) {                                                                                                 \
         HIPCHK(hipFuncSetAttribute((const void*)k_rollout<A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));                        \
         hipLaunchKernelGGL((k_rollout<A, B>), dim3(n_wg < resident_wgs ? n_wg : resident_wgs), dim3(WG), step_lds, s, d_model, b, (const Buffers<T>*)d_b, N, cfg.frame_skip,              \
-                           cfg.solver_iterations, lpw, (int)cfg.pair_memory, (const ObsOut<T>*)d_out, (const ks_rollout_args*)d_ra, n_iter, n_wg);                                \
+                           cfg.solver_iterations, lpw, (int)cfg.pair_memory, (const ObsOut<T>*)d_out, (const ks_rollout_args*)d_ra, n_iter, rollout_round_robin ? -n_wg : n_wg);                                \
         HIPCHK(hipGetLastError());                                                                                                                    \
         return KS_OK;                                                                                                                                 \
     }

@@ -5,7 +5,6 @@
 // coalesced 256-byte bursts.  No LDS, no atomics; the only cross-env step (FIFO ranks of the kept episodes) is a
 // single-block scan.  The torch implementations in rollout.py / replay.py are the checkers of these kernels.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include "../../include/kinova_rollout.h"
 #include "../../include/kinova_sim.h"
@@ -224,17 +223,24 @@ __global__ __launch_bounds__(WAVE) void k_sample_windows(int B, int B_agent, int
 }
 
 // ---- learner glue: plain grid-stride elementwise kernels, no fma contraction where the torch expression has none
-__global__ __launch_bounds__(256) void k_critic_grad(int R, int n, const float* __restrict__ q, const float* __restrict__ tq1,
-                                                     const float* __restrict__ tqn, const float* __restrict__ reward,
-                                                     const float* __restrict__ weight, const float* __restrict__ wsum, float discount,
-                                                     float* __restrict__ dq, float* losses) {
+// (ONE wave, no LDS: the update's body must be able to start beside a stepping kernel that holds ALL of a CU's LDS - with the larger hull
+// tables of a mixed-object context not even the 1 KB of a block reduction is left, and a learner whose first kernel waits for LDS only
+// runs when persistent workgroups exit: the episodes published meanwhile were dropped, round 4.  The sums are wave butterflies.)
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+__global__ __launch_bounds__(WAVE) void k_critic_grad(int R, int n, const float* __restrict__ q, const float* __restrict__ tq1,
+                                                      const float* __restrict__ tqn, const float* __restrict__ reward,
+                                                      const float* __restrict__ weight, const float* __restrict__ wsum, float discount,
+                                                      float* __restrict__ dq, float* losses) {
 #pragma clang fp contract(off)
-    // single workgroup: the batch is a few thousand rows; the three masked means are block reductions
-    using Reduce = hipcub::BlockReduce<float, 256>;
-    __shared__ typename Reduce::TempStorage tmp;
+    // single wave: the batch is a few thousand rows; the masked means are wave reductions
     const float inv = wsum[0] > 0.0f ? 1.0f / wsum[0] : 0.0f;     // an all-padding batch (empty replay) has zero loss and gradient
     float l1 = 0, ln = 0;
-    for (int r = threadIdx.x; r < R; r += 256) {
+    for (int r = threadIdx.x; r < R; r += WAVE) {
         const float t1 = reward[(long)r * n] + discount * tq1[r];
         float ret = 0, g = 1.0f;
         for (int i = 0; i < n; i++) { ret += g * reward[(long)r * n + i]; g *= discount; }
@@ -244,31 +250,26 @@ __global__ __launch_bounds__(256) void k_critic_grad(int R, int n, const float* 
         ln += w * en * en;
         dq[r] = w * inv * (2.0f * e1 + 0.5f * 2.0f * en);
     }
-    l1 = Reduce(tmp).Sum(l1);
-    __syncthreads();
-    ln = Reduce(tmp).Sum(ln);
+    l1 = wave_sum(l1);
+    ln = wave_sum(ln);
     if (threadIdx.x == 0) { losses[1] = l1 * inv; losses[2] = ln * inv; losses[0] = l1 * inv + 0.5f * (ln * inv); }
 }
 
 // start of an update's body: what used to be eight tiny library launches (sum, clamp, mul, div, copy, add, fill, copy)
-__global__ __launch_bounds__(256) void k_update_prologue(int R, int n, const float* __restrict__ weight, float* __restrict__ wsum,
-                                                         float* __restrict__ dq_actor, int64_t* it, int64_t* it_head, int pipelined) {
+__global__ __launch_bounds__(WAVE) void k_update_prologue(int R, int n, const float* __restrict__ weight, float* __restrict__ wsum,
+                                                          float* __restrict__ dq_actor, int64_t* it, int64_t* it_head, int pipelined) {
 #pragma clang fp contract(off)
-    using Reduce = hipcub::BlockReduce<float, 256>;
-    __shared__ typename Reduce::TempStorage tmp;
-    __shared__ float total;
     float s = 0;
-    for (int r = threadIdx.x; r < R; r += 256) s += weight ? weight[r] : 1.0f;
-    s = Reduce(tmp).Sum(s);
+    for (int r = threadIdx.x; r < R; r += WAVE) s += weight ? weight[r] : 1.0f;
+    s = wave_sum(s);                                  // (0 / 1 weights: exact in any order; every lane holds the total)
+    const float total = s > 1.0f ? s : 1.0f;          // exact unless the batch is all padding
     if (threadIdx.x == 0) {
-        total = s > 1.0f ? s : 1.0f;                  // 0 / 1 weights: exact unless the batch is all padding
         wsum[0] = total;
         it[0] += 1;                                   // this update's number (Adam bias correction, soft-update phase)
         if (pipelined) it_head[0] = it[0];            // its actor step is applied by the NEXT update's head
     }
-    __syncthreads();
     const float scale = -1.0f / (total * (float)n);   // d(-sum_r w_r sum_k Q_rk / (sum(w) n)) / dQ_rk
-    for (int i = threadIdx.x; i < R * n; i += 256) dq_actor[i] = (weight ? weight[i / n] : 1.0f) * scale;
+    for (int i = threadIdx.x; i < R * n; i += WAVE) dq_actor[i] = (weight ? weight[i / n] : 1.0f) * scale;
 }
 
 __global__ __launch_bounds__(256) void k_relu_backward(long count, const float* __restrict__ act, float* __restrict__ grad) {
@@ -446,7 +447,7 @@ int kr_sample_windows_mixed(int32_t batch, int32_t batch_agent, int32_t horizon,
 int kr_critic_grad(int32_t rows, int32_t n_steps, const float* q, const float* tq1, const float* tqn, const float* reward, const float* weight,
                    const float* weight_sum, float discount, float* dq, float* losses, void* stream) {
     if (rows <= 0 || n_steps <= 0 || !q || !tq1 || !tqn || !reward || !weight_sum || !dq || !losses) return KS_ERR_INVALID;
-    hipLaunchKernelGGL(k_critic_grad, dim3(1), dim3(256), 0, (hipStream_t)stream, rows, n_steps, q, tq1, tqn, reward, weight, weight_sum, discount, dq,
+    hipLaunchKernelGGL(k_critic_grad, dim3(1), dim3(WAVE), 0, (hipStream_t)stream, rows, n_steps, q, tq1, tqn, reward, weight, weight_sum, discount, dq,
                        losses);
     return launched();
 }
@@ -454,7 +455,7 @@ int kr_critic_grad(int32_t rows, int32_t n_steps, const float* q, const float* t
 int kr_update_prologue(int32_t rows, int32_t n_steps, const float* weight, float* weight_sum, float* dq_actor, int64_t* it, int64_t* it_head,
                        int32_t pipelined, void* stream) {
     if (rows <= 0 || n_steps <= 0 || !weight_sum || !dq_actor || !it || !it_head) return KS_ERR_INVALID;
-    hipLaunchKernelGGL(k_update_prologue, dim3(1), dim3(256), 0, (hipStream_t)stream, rows, n_steps, weight, weight_sum, dq_actor, it, it_head, pipelined);
+    hipLaunchKernelGGL(k_update_prologue, dim3(1), dim3(WAVE), 0, (hipStream_t)stream, rows, n_steps, weight, weight_sum, dq_actor, it, it_head, pipelined);
     return launched();
 }
 

@@ -375,7 +375,7 @@ class AsyncTrainer(GraphedTrainer):
         self.pub[0, :flat.numel()].copy_(flat)
         replay.enable_async()
         self.steps_total = torch.zeros(eng.n, dtype=torch.long, device=dev)
-        self.counters = torch.zeros(8 + 4 * 512 + 8, dtype=torch.long, device=dev)      # episodes finished, lifted, kept, dropped (+ 4 phase timers and 4 x 512
+        self.counters = torch.zeros(8 + 4 * 512 + 8 + (eng.n if os.environ.get("KS_DEBUG_DROPS") else 0), dtype=torch.long, device=dev)      # episodes finished, lifted, kept, dropped (+ 4 phase timers and 4 x 512
                                                                           # per-workgroup stamps of the -DKS_ROLLOUT_STAMP diagnostic build)
         P = lambda t: t.data_ptr()
         a = KsRolloutArgs()

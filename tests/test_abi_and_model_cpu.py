@@ -206,6 +206,22 @@ def test_free_running_rollout_kernel_leaves_registers_for_the_learners_one_wave_
     assert up8(v) + up8(a) + widest <= 512, (v, a, widest)
 
 
+def test_learner_and_rollout_glue_kernels_use_no_lds():
+    """Everything the learner's stream launches must be able to start beside a stepping kernel that holds ALL of a CU's LDS (a mixed-object
+    context's larger hull tables leave less than 1 KB): one glue kernel with a 1 KB block reduction stalled the whole update until
+    persistent workgroups exited, and the episodes published meanwhile were dropped (round 4).  ks_rollout.hip (rollout / replay /
+    learner glue) and ks_xchg.hip (gradient exchange) declare no LDS at all; ks_mlp.hip only in the one kernel that is allowed to
+    (k_mlp3, the lock-step actor launch between two stepping launches)."""
+    import re
+    from pathlib import Path
+    csrc = Path(__file__).resolve().parents[1] / "kinovagrasping_amd" / "csrc"
+    for f in ("ks_rollout.hip", "ks_xchg.hip"):
+        src = re.sub(r"//.*", "", (csrc / f).read_text())
+        assert "__shared__" not in src and "hipcub" not in src, f
+    mlp = re.sub(r"//.*", "", (csrc / "ks_mlp.hip").read_text())
+    assert len(re.findall(r"__shared__", mlp)) == 3          # H1, H2, P of k_mlp3
+
+
 def test_orientation_noise_is_zero_mean_truncated_and_seeded():
     """reset(with_noise=True) (SURVEY note N5's extension): class Euler constants + zero-mean N(0, 0.087), then the reference's
     5-character truncation (ENV:870-874); without an rng exactly the class quaternion."""
