@@ -661,6 +661,30 @@ KS_HD void hull_climb(const T* R, const T* p, KS_LDS const T* V, KS_LDS const un
     addscl3(out, dir, hm);
 }
 
+// exhaustive support of a small hull (n = padded count, a multiple of HULL_CHUNK; the padding repeats vertex 0 and never wins)
+#ifndef KS_SCAN_MAX
+#define KS_SCAN_MAX 0           // experiment (round 4), OFF: with 32 the cubes' 24 vertices are scanned - sim-only 4.24 M against 4.30 M with the climb
+#endif
+constexpr int SCAN_MAX = KS_SCAN_MAX;
+template <typename T>
+KS_HD void hull_scan(const T* R, const T* p, KS_LDS const T* V, int n, int& hint, const T* ld, const T* dir, T hm, T* out) {
+    int cur = 0;
+    T best = V[0] * ld[0] + V[1] * ld[1] + V[2] * ld[2];
+    for (int i0 = 0; i0 < n; i0 += HULL_CHUNK) {
+        T d[HULL_CHUNK];
+        KS_UNROLL
+        for (int q = 0; q < HULL_CHUNK; q++) d[q] = V[4 * (i0 + q)] * ld[0] + V[4 * (i0 + q) + 1] * ld[1] + V[4 * (i0 + q) + 2] * ld[2];
+        KS_UNROLL
+        for (int q = 0; q < HULL_CHUNK; q++)
+            if (d[q] > best) { best = d[q]; cur = i0 + q; }
+    }
+    hint = cur;
+    T v[3] = {V[4 * cur], V[4 * cur + 1], V[4 * cur + 2]};
+    mulRv(out, R, v);
+    add3(out, out, p);
+    addscl3(out, dir, hm);
+}
+
 // Support points of BOTH hulls of a pair along dir / -dir.  The two cube-map reads (global memory, L2 resident, ~10x
 // the latency of an LDS round) are issued first, back to back, so that the second one is in flight while the first
 // hull is climbed.
@@ -679,9 +703,15 @@ template <typename T> KS_HD void pair_support(PairGeo<T>& g, const T* dir, T hm,
         ld1[0] += s1 * T(SKEW_X); ld1[1] += s1 * T(SKEW_Y); ld1[2] += s1 * T(SKEW_Z);
         ld2[0] += s2 * T(SKEW_X); ld2[1] += s2 * T(SKEW_Y); ld2[2] += s2 * T(SKEW_Z);
     }
-    const int tab1 = g.dir1[support_cell(ld1)], tab2 = g.dir2[support_cell(ld2)];
-    hull_climb(g.R1, g.p1, g.V1, g.off1, g.adj1, tab1, g.hint1, ld1, dir, hm, out1);
-    hull_climb(g.R2, g.p2, g.V2, g.off2, g.adj2, tab2, g.hint2, ld2, nd, hm, out2);
+    // (Experiment, off: SCAN_MAX = 0.)  A hull of at most SCAN_MAX vertices (the cubes: 24) scanned outright - its reads are independent
+    // and pipeline through the LDS, a climb is a chain of dependent rounds plus a table read from L2; same vertex.  Measured slower: a warm
+    // climb is one hop, and a wave whose lanes mix small and large hulls runs both code paths.
+    const bool scan1 = g.n1 <= SCAN_MAX, scan2 = g.n2 <= SCAN_MAX;
+    const int tab1 = scan1 ? 0 : g.dir1[support_cell(ld1)], tab2 = scan2 ? 0 : g.dir2[support_cell(ld2)];
+    if (scan1) hull_scan(g.R1, g.p1, g.V1, g.n1, g.hint1, ld1, dir, hm, out1);
+    else hull_climb(g.R1, g.p1, g.V1, g.off1, g.adj1, tab1, g.hint1, ld1, dir, hm, out1);
+    if (scan2) hull_scan(g.R2, g.p2, g.V2, g.n2, g.hint2, ld2, nd, hm, out2);
+    else hull_climb(g.R2, g.p2, g.V2, g.off2, g.adj2, tab2, g.hint2, ld2, nd, hm, out2);
 }
 
 template <typename T> KS_HD void mpr_support(PairGeo<T>& g, const T* dir, Supp<T>& o) {
