@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/<tag>_pmc_k_env_step_summary.txt (tools/pmc_run.sh) -> profiles/<round>_pmc.json, the file bench.py reads for
-`roofline.traffic` and the issue-bound figures.  Usage: tools/pmc_to_json.py profiles/r03_a_pmc_sim_summary.txt profiles/r03_pmc_sim.json sim|ddpg|free"""
+`roofline.traffic` and the issue-bound figures.  Usage: tools/pmc_to_json.py profiles/r04_a_pmc_sim_summary.txt profiles/r04_pmc_sim.json sim|ddpg|free"""
 import json
 import re
 import sys
@@ -19,7 +19,7 @@ out = {
     "kernel": "k_rollout" if workload == "free" else "k_env_step",
     "workload": ("bench.py --mode sim, 4096 envs, CubeS" if workload == "sim" else
                  "bench.py --rollout free (config 3: DDPG training, 4096 envs, free-running rollout kernel, learner HIP graphs; counters on every dispatch, "
-                 "dispatches serialised by the collector so k_rollout runs alone; per-launch figures divided by the 10 env-steps of a launch) after 150 pre-training updates (the collector segfaults with 600)" if workload == "free" else
+                 "dispatches serialised by the collector so k_rollout runs alone; per-launch figures divided by the 10 env-steps of a launch) after 150 pre-training updates from the committed bench policy (the collector segfaults with 600)" if workload == "free" else
                  "bench.py --eager (config 3: DDPG training, 4096 envs, learner launched op by op - counter collection with the kernel filter segfaults when the learner runs from HIP graphs) after 600 pre-training updates") +
                 " (tools/pmc_run.sh: rocprofv3 --kernel-trace --pmc, one counter set per pass, last 40 launches of each pass; free: last 2 launches = 20 env-steps)",
     "source": src,
@@ -34,8 +34,9 @@ out = {
     "hbm_bytes_per_launch": (per.get("FETCH_SIZE", 0) + per.get("WRITE_SIZE", 0)) * kib,
     "note": ("per env-step of k_rollout: fetch = the actor's weights for every workgroup and env-step (L2 hits) + env state + pair memory + the rays' mesh nodes + "
              "1/10 of the per-launch staging of the hull / model tables; write = state + body-pose snapshot + rays + observation (x3: output, next policy input, "
-             "terminal) + replay row + pair memory (2.3 MB), stored as 4-byte columns of [field][env] arrays (DESIGN section 5: ~12 MB of stores per env-step + "
-             "partial-line write-backs); no private-memory frame in this kernel.  The counters sit on the L2's memory side: Infinity-Cache hits are included, "
+             "terminal) + replay row + pair memory, stored as 4-byte columns of [field][env] arrays (~12 MB of output stores per env-step) + write-backs of the "
+             "private-memory frame: ~53 scratch stores per lane and substep around the out-of-line `collision` (8 warm words, contact count, status in the caller; "
+             "40 callee-saved registers in `collision`), DESIGN section 5a.  The counters sit on the L2's memory side: Infinity-Cache hits are included, "
              "so this is an upper bound on HBM traffic.") if workload == "free" else
             "fetch = per-workgroup staging of the hull / model tables (256 workgroups x ~50 KB, L2 / MALL hits count) + env state + "
             "pair memory + the in-step rays' mesh nodes; write = state + snapshot + rays + pair memory (4.9 MB) + write-through of the "
