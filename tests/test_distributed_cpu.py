@@ -66,3 +66,23 @@ def test_env_sharding_is_independent_of_world_size():
         a = np.concatenate([scenarios.config_actions(n, 3, base_seed=1000 + r * n) for r in range(world)], 2)
         np.testing.assert_array_equal(q, q_all)
         np.testing.assert_array_equal(a, a_all)
+
+
+def test_config5_cohort_draw_gives_whole_groups_and_keeps_the_iid_stream():
+    """scenarios.config5_states(cohort=16): every shape's env count is a multiple of the stepping kernel's 16-env groups (N / 16 groups, which the
+    free-running rollout deals evenly to its persistent workgroups), each env's shape is still uniform over the 14, and orientation / start rows /
+    mass / friction are the per-env draws of cohort = 1 (same generator stream); a rank's shard is a slice of the global draw."""
+    import numpy as np
+    from kinovagrasping_amd import scenarios
+    n = 8192
+    o1, names1, q1, hq1, mf1 = scenarios.config5_states(n, seed=5)
+    o16, names16, q16, hq16, mf16 = scenarios.config5_states(n, seed=5, cohort=16)
+    cnt = np.bincount(o16, minlength=14)
+    assert (cnt % 16 == 0).all() and cnt.sum() == n and int(((cnt + 15) // 16).sum()) == n // 16
+    assert (o16.reshape(-1, 16) == o16.reshape(-1, 16)[:, :1]).all() and (o16[::16] == o1[:n // 16]).all()
+    assert names16 == names1 and np.array_equal(mf16, mf1) and np.array_equal(hq16, hq1)
+    assert cnt.min() >= 0.5 * n / 14 and cnt.max() <= 1.6 * n / 14            # uniform over the shapes (512 cohort draws)
+    # cohorts of a 2-rank run: every rank's shard [r n, (r + 1) n) keeps whole groups too
+    o2 = scenarios.config5_states(2 * 4096, seed=5, cohort=16)[0]
+    for r in range(2):
+        assert (np.bincount(o2[r * 4096:(r + 1) * 4096], minlength=14) % 16 == 0).all()
