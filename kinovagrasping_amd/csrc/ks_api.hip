@@ -77,7 +77,7 @@ template <typename T> struct LdsScratch { using type = Scratch<T, KS_LDS T*>; };
 // The model constants (about 3 KB) are copied to the head of LDS as well: the physics stages are out-of-line
 // device functions that reach the model through a generic reference, and a flat load that resolves to LDS costs
 // a fraction of one that goes to L2.  Returns the words (of T) used; visibility comes with stage_hulls' barrier.
-constexpr int HULLS_BYTES = 256;   // the Hulls descriptor (LDS pointers, counts) sits behind the model copy
+constexpr int HULLS_BYTES = MULTI_GEOM ? 1024 : 256;   // the Hulls descriptor (table pointers, counts) sits behind the model copy
 template <typename T> constexpr int model_words() { return (int)(((sizeof(Model<T>) + 15) / 16 * 16 + HULLS_BYTES) / sizeof(T)); }
 template <typename T> __device__ __forceinline__ const Model<T>* stage_model(const Model<T>* __restrict__ mp, KS_LDS T* lds) {
     const unsigned* src = (const unsigned*)mp;
@@ -87,7 +87,7 @@ template <typename T> __device__ __forceinline__ const Model<T>* stage_model(con
 }
 
 // size of a PairRec in DEVICE code (LDS pointers are 4 bytes there; the host pass of this file sees 8)
-template <typename T> constexpr int pair_rec_bytes() { return sizeof(T) == 4 ? 96 : 144; }
+template <typename T> constexpr int pair_rec_bytes() { return MULTI_GEOM ? (sizeof(T) == 4 ? 128 : 160) : (sizeof(T) == 4 ? 96 : 144); }   // (multi-geom: generic table pointers, 8 bytes)
 
 // Global -> LDS copy of a table by the whole workgroup in B-byte words (both ends B-byte aligned, `bytes` a multiple of B), four
 // loads in flight per thread: the tables of a workgroup are ~50 KB, and copied element by element (floats, 16-bit ids) the
@@ -183,6 +183,16 @@ template <typename T, int NT> __device__ __forceinline__ const Model<T>* stage_m
 // otherwise `hu` is the calling thread's own.
 template <typename T, bool SHARED> __device__ __forceinline__ void stage_hulls(const Model<T>& m, KS_LDS T* lds, int& used, Hulls<T>& hu, bool prestaged = false) {
     const bool writer = !SHARED || threadIdx.x == 0;
+#ifdef KS_MULTI_GEOM
+    // multi-geom build: the hull tables stay in global memory (ks_math.h: KS_TAB) - the descriptor points at the model's arrays
+    (void)prestaged;
+    if (writer)
+        for (int s = 0; s < NMESH; s++) {
+            hu.vert[s] = m.mesh_vert[s]; hu.nvert[s] = m.mesh_nvert[s]; hu.nvert_pad[s] = m.mesh_nvert_pad[s];
+            hu.adj_off[s] = m.mesh_adj_off[s]; hu.adj[s] = m.mesh_adj[s];
+        }
+    used = 0;
+#else
     const bool packed = m.hull_pack != nullptr;
     if (packed && !prestaged) stage_tables(lds, m.hull_pack, m.hull_pack_bytes);
     int off = 0;
@@ -211,6 +221,7 @@ template <typename T, bool SHARED> __device__ __forceinline__ void stage_hulls(c
     }
     const int iwords = (uoff * (int)sizeof(unsigned short) + (int)sizeof(T) - 1) / (int)sizeof(T);
     used = off + ((iwords + 3) & ~3);
+#endif
     // pair records behind the adjacency tables, one thread per pair
     if (writer) {
         hulls_set_pairs(m, hu);
@@ -220,7 +231,7 @@ template <typename T, bool SHARED> __device__ __forceinline__ void stage_hulls(c
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(sizeof(PairRec<T>) == pair_rec_bytes<T>(), "device size of a pair record");
 #endif
-    if ((int)threadIdx.x < m.npair) fill_pair_rec(m, hu, threadIdx.x, *(PairRec<T>*)((KS_LDS const PairRec<T>*)(lds + used) + threadIdx.x));
+    for (int pi = threadIdx.x; pi < m.npair; pi += blockDim.x) fill_pair_rec(m, hu, pi, *(PairRec<T>*)((KS_LDS const PairRec<T>*)(lds + used) + pi));
     used += NPAIR_MAX * pair_rec_bytes<T>() / (int)sizeof(T);
     __syncthreads();
 }
@@ -282,7 +293,9 @@ struct SlotBound {
         return __int_as_float((int)*(volatile KS_LDS unsigned*)slot);
     }
 };
-constexpr int WG_RAY_TASKS = NRAY * (NGEOM - 1);                       // per env
+constexpr int RG_BITS = MULTI_GEOM ? 4 : 3, RG = 1 << RG_BITS;        // mesh geom slots of an env in the ray kernels (geoms 1 .. RG)
+static_assert(RG == NGEOM - 1, "ray tasks: one slot per mesh geom");
+constexpr int WG_RAY_TASKS = NRAY * RG;                                // per env
 constexpr int WG_SNAP = 97;                                            // body poses of an env (96 floats), odd stride
 // the walk queue: every surviving (env, ray, geom) task + the subtrees that busy walkers hand to idle lanes
 __host__ __device__ constexpr int wg_ray_queue(int epw) { return epw * WG_RAY_TASKS + 64 * epw; }
@@ -357,8 +370,8 @@ __device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>
     if (tid < 8) ctl[tid] = 0;
     __syncthreads();
     for (int task = tid; task < total; task += WG) {
-        const int e = task / WG_RAY_TASKS, r = (task % WG_RAY_TASKS) >> 3, g = 1 + (task & 7), env = b.slot_env[slot0 + e];
-        if (env < 0) continue;
+        const int e = task / WG_RAY_TASKS, r = (task % WG_RAY_TASKS) >> RG_BITS, g = 1 + (task & (RG - 1)), env = b.slot_env[slot0 + e];
+        if (env < 0 || g >= m.ngeom) continue;
         LdsSnap snap{snaps + e * WG_SNAP - SNAP_BP};
         float pnt[3], vec[3];
         const int sb = ray_origin(m, snap, r, pnt, vec);
@@ -397,7 +410,7 @@ __device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>
                 const unsigned w0 = *(volatile KS_LDS unsigned*)(q + 2 * ticket);     // (written before the task word)
                 ticket = 0xffffffffu;
                 const int task = (int)t1 - 1, node = (int)(w0 & 0xffffu);
-                const int e = task / WG_RAY_TASKS, r = (task % WG_RAY_TASKS) >> 3, g = 1 + (task & 7);
+                const int e = task / WG_RAY_TASKS, r = (task % WG_RAY_TASKS) >> RG_BITS, g = 1 + (task & (RG - 1));
                 LdsSnap snap{snaps + e * WG_SNAP - SNAP_BP};
                 float pnt[3], vec[3], lp[3], lv[3];
                 ray_origin(m, snap, r, pnt, vec);
@@ -1054,22 +1067,21 @@ __global__ __launch_bounds__(SLOT_THREADS) void k_slots(const int32_t* __restric
 // pruning distance shared by the eight lanes of one (env, ray): the minimum of their nearest hits so far, published in
 // LDS (lanes that have left the traversal keep their final value there; a stale read only prunes less).
 template <typename T> struct GroupBound {
-    KS_LDS T* group;   // the eight published distances of this (env, ray)
+    KS_LDS T* group;   // the RG published distances of this (env, ray)
     int me;
     __device__ T operator()(T best) const {
         if (best >= 0 && best < group[me]) group[me] = best;
         T b = group[0];
         KS_UNROLL
-        for (int k = 1; k < 8; k++) { const T o = group[k]; b = o < b ? o : b; }
+        for (int k = 1; k < RG; k++) { const T o = group[k]; b = o < b ? o : b; }
         return b;
     }
 };
 
-constexpr int RAY_ENVS = WAVE / (NGEOM - 1);
-static_assert(NGEOM - 1 == 8, "k_rays: eight mesh geoms per env, one per lane");
+constexpr int RAY_ENVS = WAVE / RG;
 template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model<T>* __restrict__ models, Buffers<T> b, int N, int masked) {
-    const int g = 1 + (threadIdx.x & 7);
-    const int env = blockIdx.x * RAY_ENVS + (threadIdx.x >> 3), ray = blockIdx.y;
+    const int g = 1 + (threadIdx.x & (RG - 1));
+    const int env = blockIdx.x * RAY_ENVS + (threadIdx.x >> RG_BITS), ray = blockIdx.y;
     const bool live = env < N && !(masked && !b.flag[env]);
     T best = T(-1);
     __shared__ T pub[WAVE];
@@ -1087,20 +1099,20 @@ template <typename T> __global__ __launch_bounds__(WAVE) void k_rays(const Model
 #ifdef KS_RAY_COUNT
         // diagnostic build: ray_mesh returns its node visits; they go to the contact tap buffer, rows ray * 8 + (g - 1)
         T cnt = T(0);
-        if (m.geom_body[g] != sb) {
-            cnt = ray_geom(m, snap, g, pnt, vec, GroupBound<T>{(KS_LDS T*)pub + (threadIdx.x & ~7), (int)(threadIdx.x & 7)},
+        if (g < m.ngeom && m.geom_body[g] != sb) {
+            cnt = ray_geom(m, snap, g, pnt, vec, GroupBound<T>{(KS_LDS T*)pub + (threadIdx.x & ~(RG - 1)), (int)(threadIdx.x & (RG - 1))},
                            LdsStack<T>{(KS_LDS unsigned*)stk + threadIdx.x, WAVE});
             if (cnt < 0) cnt = T(0);
         }
-        b.contact[((long)ray * 8 + (g - 1)) * N + env] = cnt;
+        b.contact[((long)ray * RG + (g - 1)) * N + env] = cnt;
 #else
-        if (m.geom_body[g] != sb)
-            best = ray_nearer(best, ray_geom(m, snap, g, pnt, vec, GroupBound<T>{(KS_LDS T*)pub + (threadIdx.x & ~7), (int)(threadIdx.x & 7)},
+        if (g < m.ngeom && m.geom_body[g] != sb)
+            best = ray_nearer(best, ray_geom(m, snap, g, pnt, vec, GroupBound<T>{(KS_LDS T*)pub + (threadIdx.x & ~(RG - 1)), (int)(threadIdx.x & (RG - 1))},
                                               LdsStack<T>{(KS_LDS unsigned*)stk + threadIdx.x, WAVE}));
 #endif
     }
     KS_UNROLL
-    for (int mask = 1; mask < 8; mask <<= 1) best = ray_nearer(best, (T)__shfl_xor(best, mask));
+    for (int mask = 1; mask < RG; mask <<= 1) best = ray_nearer(best, (T)__shfl_xor(best, mask));
     if (live && g == 1) b.rays[(long)ray * N + env] = best;
 }
 
@@ -1427,13 +1439,10 @@ template <typename T> struct Ctx : CtxBase {
         for (int k = 0; k < nm; k++) {
             HostModel<T> hm;
             if (!parse_model<T>(blobs[k], sizes[k], hm)) { error = "ks_load_model: " + hm.error; return KS_ERR_MODEL; }
-            // the stepping kernel gives every lane of an env's team at most two hull pairs (ks_core.h, collision)
-            const unsigned planes = plane_pair_mask(hm.m);
-            int nh = 0;
-            for (int pi = 0; pi < hm.m.npair; pi++) nh += ((planes >> pi) & 1u) ? 0 : 1;
-            if (nh > 2 * SUBS) { error = "ks_load_model: more than 32 hull-hull contact pairs"; return KS_ERR_MODEL; }
+            // the stepping kernel gives every lane of an env's team at most HPL hull pairs (ks_core.h, collision)
+            if (hull_pair_count(hm.m) > HPL * SUBS || hm.m.npair - hull_pair_count(hm.m) > 32) { error = "ks_load_model: too many contact pairs for this build"; return KS_ERR_MODEL; }
             int words = 0, adj_ints = 0, r;
-            for (int s = 0; s < 4; s++) {
+            for (int s = 0; s < hm.m.nmesh; s++) {
                 if ((r = upload(hm.vert[s], &hm.m.mesh_vert[s]))) return r;
                 if ((r = upload(hm.tri[s], &hm.m.mesh_tri[s]))) return r;
                 if ((r = upload(hm.bvh_box[s], &hm.m.mesh_bvh_box[s]))) return r;
@@ -1444,12 +1453,12 @@ template <typename T> struct Ctx : CtxBase {
                 adj_ints += ((hm.m.mesh_nvert[s] + 1 + 3) & ~3) + hm.m.mesh_nchunk[s] * 4;
             }
             if ((r = upload(hm.dirtab, &hm.m.mesh_dirtab))) return r;
-            {
+            if (!MULTI_GEOM) {
                 // the LDS image of the hull tables (stage_hulls' layout) as one block
                 std::vector<unsigned char> pack;
                 auto put = [&](const void* p, size_t bytes) { pack.insert(pack.end(), (const unsigned char*)p, (const unsigned char*)p + bytes); };
-                for (int s = 0; s < 4; s++) put(hm.vert[s].data(), hm.vert[s].size() * sizeof(T));
-                for (int s = 0; s < 4; s++) {
+                for (int s = 0; s < hm.m.nmesh; s++) put(hm.vert[s].data(), hm.vert[s].size() * sizeof(T));
+                for (int s = 0; s < hm.m.nmesh; s++) {
                     put(hm.adj_off[s].data(), hm.adj_off[s].size() * sizeof(unsigned short));
                     put(hm.adj[s].data(), hm.adj[s].size() * sizeof(unsigned short));
                 }
@@ -1458,6 +1467,8 @@ template <typename T> struct Ctx : CtxBase {
                 if ((r = upload(pack, &d))) return r;
                 hm.m.hull_pack = d;
                 hm.m.hull_pack_bytes = (int)pack.size();
+            } else {
+                words = 0; adj_ints = 0;          // the tables stay in global memory: only the pair records take LDS
             }
             const int iwords = (adj_ints * (int)sizeof(unsigned short) + (int)sizeof(T) - 1) / (int)sizeof(T);
             words += (iwords + 3) & ~3;

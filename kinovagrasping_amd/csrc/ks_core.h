@@ -62,7 +62,7 @@ constexpr int CON_STRIDE = 20;
 // collision staging: contacts are detected pair by pair into per-pair slots of (pos3, normal3, dist, mu,
 // bodies) records - 4 slots for a plane pair, 1 for a hull pair, assigned in pair order - and then merged
 // in pair order with the per-pair counts in SCR_PC.
-constexpr int NSTAGE = 80, STAGE_REC = 9, STAGE_WORDS = 720;   // 80 x 9 = 720 = 15 cached bases
+constexpr int NSTAGE = MULTI_GEOM ? 160 : 80, STAGE_REC = 9, STAGE_WORDS = NSTAGE * STAGE_REC;   // 80 x 9 = 720 = 15 cached bases (multi-geom: 16 plane pairs x 4 + 78 hull pairs)
 constexpr int SCR_PC = SCR_CON + NCON_MAX * CON_STRIDE;
 constexpr int SCR_STAGE = SCR_PC + NPAIR_MAX;
 // smooth dynamics of the substep, written by the role lanes (fingers, object, slides) and read by row:
@@ -247,37 +247,38 @@ template <typename T> struct alignas(16) PairRec {
     int n1, n2;                // padded hull vertex counts; n2 of a plane pair is the true count
     int slot, obj_hand;        // first staging record of the pair (4 per plane pair, 1 per hull pair, pair order);
                                // obj_hand: bit 0 = object vs hand geom (the pair whose friction may be set per env),
-                               // bits 4-7 / 8-11 = mesh ids of the two geoms, bits 12-16 = the pair's index
-    KS_LDS const T* V1; KS_LDS const T* V2;
-    KS_LDS const unsigned short* off1; KS_LDS const unsigned short* adj1;
-    KS_LDS const unsigned short* off2; KS_LDS const unsigned short* adj2;
+                               // bits 4-7 / 8-11 = mesh ids of the two geoms, bits 12-18 = the pair's index
+    KS_TAB const T* V1; KS_TAB const T* V2;
+    KS_TAB const unsigned short* off1; KS_TAB const unsigned short* adj1;
+    KS_TAB const unsigned short* off2; KS_TAB const unsigned short* adj2;
 };
+constexpr int PAIR_INDEX_MASK = 127;
 
 template <typename T> struct Hulls {
-    KS_LDS const T* vert[4];   // [nvert_pad][4]
-    int nvert[4], nvert_pad[4];
-    KS_LDS const unsigned short* adj_off[4];   // hull graph, 4-neighbour chunks (hill-climbing support queries)
-    KS_LDS const unsigned short* adj[4];
-    unsigned plane_mask;   // bit pi set: pair pi is ground plane vs hull (pair_g1 == 0)
+    KS_TAB const T* vert[NMESH];   // [nvert_pad][4]
+    int nvert[NMESH], nvert_pad[NMESH];
+    KS_TAB const unsigned short* adj_off[NMESH];   // hull graph, 4-neighbour chunks (hill-climbing support queries)
+    KS_TAB const unsigned short* adj[NMESH];
     int npair, nhull;
     KS_LDS const PairRec<T>* pair;             // [npair]
     unsigned char hull_pi[NPAIR_MAX];          // pair index of the k-th hull-hull pair
     int nplane;
     unsigned char plane_pi[NPAIR_MAX];         // pair index of the k-th plane pair
 };
-template <typename T> KS_HD unsigned plane_pair_mask(const Model<T>& m) {
-    unsigned mask = 0;
-    for (int pi = 0; pi < m.npair; pi++) mask |= (m.pair_g1[pi] == 0) ? (1u << pi) : 0u;
-    return mask;
+// pair pi is ground plane vs hull
+template <typename T> KS_HD bool is_plane_pair(const Model<T>& m, int pi) { return m.pair_g1[pi] == 0; }
+template <typename T> KS_HD int hull_pair_count(const Model<T>& m) {
+    int nh = 0;
+    for (int pi = 0; pi < m.npair; pi++) nh += is_plane_pair(m, pi) ? 0 : 1;
+    return nh;
 }
-// pair bookkeeping of the descriptor (mask, counts, hull pair list); `pair` is set by the caller
+// pair bookkeeping of the descriptor (counts, plane / hull pair lists); `pair` is set by the caller
 template <typename T> KS_HD void hulls_set_pairs(const Model<T>& m, Hulls<T>& hu) {
-    hu.plane_mask = plane_pair_mask(m);
     hu.npair = m.npair;
     hu.nhull = 0;
     hu.nplane = 0;
     for (int pi = 0; pi < m.npair; pi++) {
-        if ((hu.plane_mask >> pi) & 1u) hu.plane_pi[hu.nplane++] = (unsigned char)pi;
+        if (is_plane_pair(m, pi)) hu.plane_pi[hu.nplane++] = (unsigned char)pi;
         else hu.hull_pi[hu.nhull++] = (unsigned char)pi;
     }
 }
@@ -285,9 +286,9 @@ template <typename T> KS_HD void fill_pair_rec(const Model<T>& m, const Hulls<T>
     const int g1 = m.pair_g1[pi], g2 = m.pair_g2[pi];
     r.g1 = g1; r.g2 = g2; r.margin = m.pair_margin[pi]; r.mu = m.pair_mu[pi];
     int slot = 0;
-    for (int j = 0; j < pi; j++) slot += ((hu.plane_mask >> j) & 1u) ? 4 : 1;
+    for (int j = 0; j < pi; j++) slot += is_plane_pair(m, j) ? 4 : 1;
     r.slot = slot;
-    r.obj_hand = ((g1 != 0 && g2 == NGEOM - 1) ? 1 : 0) | ((g1 != 0 ? m.geom_mesh[g1] : 0) << 4) | (m.geom_mesh[g2] << 8) | (pi << 12);
+    r.obj_hand = ((g1 != 0 && g2 >= OBJ_GEOM) ? 1 : 0) | ((g1 != 0 ? m.geom_mesh[g1] : 0) << 4) | (m.geom_mesh[g2] << 8) | (pi << 12);
     r.rbound1 = m.geom_rbound[g1]; r.rbound2 = m.geom_rbound[g2];
     for (int k = 0; k < 3; k++) { r.size1[k] = m.geom_size[g1][k]; r.size2[k] = m.geom_size[g2][k]; }
     r.body1 = m.geom_body[g1]; r.body2 = m.geom_body[g2];
@@ -383,7 +384,7 @@ template <typename T> KS_HD void nominal_env_params(const Model<T>& m, T& mass, 
     mass = m.mass[NBODY - 1];
     mu = T(1);
     for (int pi = 0; pi < m.npair; pi++)
-        if (m.pair_g1[pi] != 0 && m.pair_g2[pi] == NGEOM - 1) { mu = m.pair_mu[pi]; break; }
+        if (m.pair_g1[pi] != 0 && m.pair_g2[pi] >= OBJ_GEOM) { mu = m.pair_mu[pi]; break; }
 }
 
 // world pose of geom g (1..8) as stored by dynamics_rows
@@ -543,7 +544,7 @@ KS_FN_DYNAMICS void dynamics_rows(const Model<T>& m, const T* qpos, const T* qve
     }
     team.sync();
     // world poses of the collision geoms, one geom per lane
-    for (int g = 1 + team.sub; g < NGEOM; g += SUBS) {
+    for (int g = 1 + team.sub; g < m.ngeom; g += SUBS) {
         T R[9], p[3];
         geom_pose(m, scr, g, R, p);
         const int o = SCR_GP + (g - 1) * 12;
@@ -581,9 +582,9 @@ template <typename T> struct Supp {
 
 template <typename T> struct PairGeo {
     T R1[9], p1[3], R2[9], p2[3];
-    KS_LDS const T* V1; KS_LDS const T* V2;
-    KS_LDS const unsigned short* off1; KS_LDS const unsigned short* adj1;
-    KS_LDS const unsigned short* off2; KS_LDS const unsigned short* adj2;
+    KS_TAB const T* V1; KS_TAB const T* V2;
+    KS_TAB const unsigned short* off1; KS_TAB const unsigned short* adj1;
+    KS_TAB const unsigned short* off2; KS_TAB const unsigned short* adj2;
     const unsigned short* dir1; const unsigned short* dir2;   // cube-map support start tables of the two hulls (global memory)
     int n1, n2;
     int hint1, hint2;          // last support vertex of each shape: start of the next hill climb
@@ -626,7 +627,7 @@ template <typename T> KS_HD int support_cell(const T* ld) {
 // the climb: from the better of `hint` (the previous support vertex) and `tab` (the support vertex of the cube-map cell
 // the direction falls in) to the support vertex along the hull-frame direction ld
 template <typename T>
-KS_HD void hull_climb(const T* R, const T* p, KS_LDS const T* V, KS_LDS const unsigned short* off, KS_LDS const unsigned short* adj, int tab, int& hint,
+KS_HD void hull_climb(const T* R, const T* p, KS_TAB const T* V, KS_TAB const unsigned short* off, KS_TAB const unsigned short* adj, int tab, int& hint,
                       const T* ld, const T* dir, T hm, T* out) {
     int cur = hint;
     T best = V[4 * cur] * ld[0] + V[4 * cur + 1] * ld[1] + V[4 * cur + 2] * ld[2];
@@ -667,7 +668,7 @@ KS_HD void hull_climb(const T* R, const T* p, KS_LDS const T* V, KS_LDS const un
 #endif
 constexpr int SCAN_MAX = KS_SCAN_MAX;
 template <typename T>
-KS_HD void hull_scan(const T* R, const T* p, KS_LDS const T* V, int n, int& hint, const T* ld, const T* dir, T hm, T* out) {
+KS_HD void hull_scan(const T* R, const T* p, KS_TAB const T* V, int n, int& hint, const T* ld, const T* dir, T hm, T* out) {
     int cur = 0;
     T best = V[0] * ld[0] + V[1] * ld[1] + V[2] * ld[2];
     for (int i0 = 0; i0 < n; i0 += HULL_CHUNK) {
@@ -838,6 +839,8 @@ struct PairWarm {
     unsigned w[WARM_WORDS];
 };
 KS_HD unsigned pack3(int a, int b, int c, int top) { return (unsigned)a | ((unsigned)b << 10) | ((unsigned)c << 20) | ((unsigned)top << 30); }
+// ids that do not fit the 10-bit fields (hulls of more than 1024 vertices, multi-geom build) are simply not remembered: a cold start
+KS_HD bool packable(int a, int b, int c, int d, int e, int f) { return !MULTI_GEOM || (a | b | c | d | e | f) < 1024; }
 KS_HD void unpack3(unsigned w, int* ids, int& top) {
     ids[0] = (int)(w & 1023u); ids[1] = (int)((w >> 10) & 1023u); ids[2] = (int)((w >> 20) & 1023u);
     top = (int)(w >> 30);
@@ -846,7 +849,7 @@ KS_HD void unpack3(unsigned w, int* ids, int& top) {
 // Minkowski Portal Refinement penetration query (same decision structure as the oracle's mpr_penetration, i.e. the
 // published algorithm of libccd's ccdMPRPenetration - libccd is (c) D. Fiser, BSD-3; it is a dependency of MuJoCo, not
 // part of /root/reference, and no code of it is used here).  Returns true on overlap.
-template <typename T> KS_HD void hull_point(const T* R, const T* p, KS_LDS const T* V, int i, T* out) {
+template <typename T> KS_HD void hull_point(const T* R, const T* p, KS_TAB const T* V, int i, T* out) {
     const T v[3] = {V[4 * i], V[4 * i + 1], V[4 * i + 2]};
     mulRv(out, R, v);
     add3(out, out, p);
@@ -958,7 +961,7 @@ KS_NARROW bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* 
             copy3(dir, wit);
             normalize3(dir);
             find_pos(v0, v1, v2, v3, pos);
-            if (mpr_warm && ws != nullptr) {
+            if (mpr_warm && ws != nullptr && packable(v1.i1, v2.i1, v3.i1, v1.i2, v2.i2, v3.i2)) {
                 ws->w[2] = pack3(v1.i1, v2.i1, v3.i1, 3);
                 ws->w[3] = pack3(v1.i2, v2.i2, v3.i2, 0);
             }
@@ -1112,6 +1115,7 @@ template <typename T> KS_HD bool gjk_closest(Simplex<T>& S, T* lam, T* v) {
 // 0: separated by >= margin, 1: contact in the margin zone, 2: overlap (fall back to MPR)
 template <typename T> KS_HD void gjk_remember(PairWarm* ws, const Simplex<T>& S) {
     if (ws == nullptr) return;
+    if (!packable(S.ia[0], S.ia[1], S.ia[2], S.ib[0], S.ib[1], S.ib[2])) { ws->w[0] = 0; ws->w[1] = 0; return; }
     ws->w[0] = pack3(S.ia[0], S.ia[1], S.ia[2], S.n < 3 ? S.n : 3);
     ws->w[1] = pack3(S.ib[0], S.ib[1], S.ib[2], 0);
 }
@@ -1330,10 +1334,13 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     KS_T0
     KS_LDS const PairRec<T>& pr = *prp;
     const T PLANE_MESH_TOL = T(0.3);
-    const int g2 = pr.g2, slot = pr.slot, pi = (pr.obj_hand >> 12) & 31;
+    const int g2 = pr.g2, slot = pr.slot, pi = (pr.obj_hand >> 12) & PAIR_INDEX_MASK;
     const T margin = pr.margin, mu = pr.mu, rbound = pr.rbound2;
     const T size[3] = {pr.size2[0], pr.size2[1], pr.size2[2]};
-    KS_LDS const T* V = pr.V2;
+    KS_TAB const T* V = pr.V2;
+    // the 16-lane team remembers, per lane, in which of its <= 64 rounds its vertex was within the margin (hulls of <= 1024 vertices:
+    // the standard build); larger hulls (multi-geom build) are walked a second time instead
+    constexpr bool MASKED = SUBS == 16 && HULL_VERT_MAX <= 1024;
     const int nv = pr.n2, body2 = pr.body2;
     T R2[9], p2[3];
     geom_pose_cached(scr, g2, R2, p2);
@@ -1361,7 +1368,7 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
         KS_UNROLL
         for (int u = 0; u < 4; u++) {
             const int i = base0 + u * SUBS + team.sub;
-            if constexpr (SUBS == 16) {
+            if constexpr (MASKED) {
                 if (i < nv && dd[u] <= margin) cand |= 1ull << (base0 / SUBS + u);
                 if constexpr (TIE_RULE)
                     if (i < nv && dd[u] <= bd + TIE_EPS) near |= 1ull << (base0 / SUBS + u);
@@ -1381,7 +1388,7 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     if constexpr (TIE_RULE) {
         const T lim = bd + TIE_EPS;
         int first = 0x7fffffff;
-        if constexpr (SUBS == 16) {
+        if constexpr (MASKED) {
             // this lane's vertices that can be within the band of the team's minimum, lowest round first (`near` is a superset)
             unsigned long long c2 = bd_lane <= lim ? near : 0ull;
             while (c2 != 0) {
@@ -1392,8 +1399,13 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
             T key = T(0);
             team.argmin(key, first);
         } else {
-            for (int i = 0; i < nv; i++)
+            // every lane walks its share of the vertices in index order, the team takes the lowest hit
+            for (int i = team.sub; i < nv; i += SUBS)
                 if (cdist + V[4 * i] * ln[0] + V[4 * i + 1] * ln[1] + V[4 * i + 2] * ln[2] <= lim) { first = i; break; }
+            if constexpr (SUBS > 1) {
+                T key = T(0);
+                team.argmin(key, first);
+            }
         }
         if (first != 0x7fffffff) best = first;
     }
@@ -1409,7 +1421,7 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     // lowest index) and resumes behind it: at most nv/SUBS + 3 rounds in total, however many vertices lie within
     // the margin (a palm lying flat on the ground has hundreds).
     int start = 0;
-    if constexpr (SUBS == 16) {
+    if constexpr (MASKED) {
         // The first pass has seen every vertex: each lane kept the rounds in which its vertex was within the margin (nv <=
         // 1024, checked when the model is loaded: 64 rounds).  The walk then only touches those - a finger tip or a cube
         // corner on the ground has a handful, and the old search for a vertex that is not there was a second full scan of the
@@ -1510,6 +1522,8 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
 // substep (two 10-bit vertex ids packed above the 3-bit contact count in the pair's SCR_PC word): the climb is
 // then a handful of steps instead of a walk across the hull.  The support vertex found does not depend on the start.
 constexpr int PC_COUNT_MASK = 7, PC_HINT_BITS = 10, PC_HINT_MAX = (1 << PC_HINT_BITS) - 1;
+// hull pairs per lane of a 16-lane team: standard 22 pairs -> 2; multi-geom 15 + 7 + 7 x 8 = 78 -> 5 (capacity NPAIR_MAX - 8 plane pairs at least)
+constexpr int HPL = MULTI_GEOM ? 6 : 2;
 KS_HD int pc_pack(int count, int h1, int h2) { return count + 8 * (h1 + (1 << PC_HINT_BITS) * h2); }
 
 // The two culls of a hull pair (bounding spheres, exact OBB test): false = the hulls are further apart than the margin
@@ -1577,7 +1591,7 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
     if (prof) { prof[24] += 1.f; prof[25] += (float)pg.cnt_support; prof[26] += (float)(th1 - th0); prof[27] += (float)(clock64() - th1); prof[28] += (float)pg.t_sup; prof[29] += (float)pg.t_clo; }
 #endif
     h1_out = pg.hint1 & PC_HINT_MAX; h2_out = pg.hint2 & PC_HINT_MAX;
-    const int pi = (flags >> 12) & 31;
+    const int pi = (flags >> 12) & PAIR_INDEX_MASK;
     if (r == 1) { stage_contact(scr, slot, body1, body2, pi, mu, dist, pos, dir); return 1; }
     if (r >= 2) {
         // 2: overlap (or undecided beyond the margin), 3: a margin-zone result that is not a certified separation
@@ -1604,7 +1618,6 @@ template <typename T, typename S, int SUBS>
 KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> team, int& ncon, int& status, PairWarm* warm = nullptr,
                      float* prof = nullptr) {
     KS_T0
-    const unsigned plane_mask = hu.plane_mask;
     const int npair = hu.npair, nhull = hu.nhull;
     KS_LDS const PairRec<T>* pairs = hu.pair;
     const unsigned short* dirtab = m.mesh_dirtab;
@@ -1630,12 +1643,12 @@ KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Tea
         if (team.sub == 0) scr(SCR_PC + pi) = T(c);
     }
     KS_TICK(8)
-    // Hull pairs.  Every lane owns up to two of them (pair `sub`, and - the last lanes - one of the nhull - SUBS pairs
-    // beyond the first SUBS), culls both, and then runs the narrow phase in two passes: pass A takes the lane's first
-    // live pair, pass B the second one of a lane whose pairs are BOTH live.  A narrow phase is a few thousand dependent
-    // instructions and the wave waits for its slowest lane, so what matters is the number of passes that have any
-    // work in them: pass B is empty unless one lane of the wave has two live pairs at once (round-robin dealing ran
-    // two full passes whenever a pair of the second round was live anywhere in the wave).  nhull <= 2 SUBS is checked
+    // Hull pairs.  Every lane owns up to HPL of them - round 0: pair `sub`; round r >= 1: the pairs r SUBS .. of the list, dealt to
+    // the LAST lanes when the round is not full (standard build: two rounds, the nhull - SUBS pairs beyond the first SUBS) - culls
+    // them all, and then runs the narrow phase in as many passes as the busiest lane of the wave has live pairs.  A narrow phase is a
+    // few thousand dependent instructions and the wave waits for its slowest lane, so what matters is the number of passes that have
+    // any work in them: a second pass is empty unless one lane of the wave has two live pairs at once (round-robin dealing ran
+    // two full passes whenever a pair of the second round was live anywhere in the wave).  nhull <= HPL SUBS is checked
     // when the model is loaded.
     if constexpr (SUBS == 1) {
         for (int hk = 0; hk < nhull; hk++) {
@@ -1646,28 +1659,36 @@ KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Tea
             scr(SCR_PC + pi) = T(pc_pack(c, h1, h2));
         }
     } else {
-        const int n2 = nhull > SUBS ? nhull - SUBS : 0;
-        int pi_[2] = {0, 0}, word_[2] = {0, 0};
-        bool live_[2] = {false, false}, have_[2];
-        have_[0] = team.sub < nhull;
-        have_[1] = team.sub >= SUBS - n2;
+        int pi_[HPL], word_[HPL];
+        unsigned todo = 0;
         KS_UNROLL
-        for (int r = 0; r < 2; r++) {
-            if (have_[r]) {
-                pi_[r] = hu.hull_pi[r == 0 ? team.sub : team.sub + n2];
+        for (int r = 0; r < HPL; r++) {
+            const int left = nhull - r * SUBS, cnt = left < SUBS ? left : SUBS;           // pairs of this round (<= 0: none)
+            const bool have = r == 0 ? team.sub < cnt : team.sub >= SUBS - cnt;
+            pi_[r] = 0; word_[r] = 0;
+            if (have) {
+                bool live_r = false;
+                pi_[r] = hu.hull_pi[r == 0 ? team.sub : r * SUBS + team.sub - (SUBS - cnt)];
                 word_[r] = (int)scr(SCR_PC + pi_[r]);
-                if (pairs[pi_[r]].slot + 1 <= NSTAGE) live_[r] = hull_pair_may_touch(scr, pairs + pi_[r]);
+                if (pairs[pi_[r]].slot + 1 <= NSTAGE) live_r = hull_pair_may_touch(scr, pairs + pi_[r]);
                 else status |= ST_CONTACT_OVERFLOW;
-                if (!live_[r]) scr(SCR_PC + pi_[r]) = T(word_[r] & ~PC_COUNT_MASK);     // no contact, hints kept
+                if (!live_r) scr(SCR_PC + pi_[r]) = T(word_[r] & ~PC_COUNT_MASK);     // no contact, hints kept
+                todo |= live_r ? (1u << r) : 0u;
             }
         }
         // one call site: as many turns as the busiest lane of the wave has live pairs
-        unsigned todo = (live_[0] ? 1u : 0u) | (live_[1] ? 2u : 0u);
         while (todo != 0) {
-            const int r = (todo & 1u) ? 0 : 1;
+            int r = 0, pi_r = pi_[0], word_r = word_[0];
+            if constexpr (HPL == 2) { r = (todo & 1u) ? 0 : 1; pi_r = r ? pi_[1] : pi_[0]; word_r = r ? word_[1] : word_[0]; }
+            else {
+                r = kctz(todo);
+                KS_UNROLL
+                for (int q = 1; q < HPL; q++)
+                    if (q == r) { pi_r = pi_[q]; word_r = word_[q]; }
+            }
             int h1 = 0, h2 = 0;
-            const int c = collide_hull_hull(m, dirtab, scr, pairs + pi_[r], word_[r], h1, h2, warm ? warm + r : nullptr, prof);
-            scr(SCR_PC + pi_[r]) = T(pc_pack(c, h1, h2));
+            const int c = collide_hull_hull(m, dirtab, scr, pairs + pi_r, word_r, h1, h2, warm ? warm + r : nullptr, prof);
+            scr(SCR_PC + pi_r) = T(pc_pack(c, h1, h2));
             todo &= todo - 1;
         }
     }
@@ -1678,14 +1699,14 @@ KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Tea
     int total = 0;
     int before[(NPAIR_MAX + SUBS - 1) / SUBS];
     if constexpr (SUBS == 16) {
-        // lane `sub` owns pairs sub and sub + 16: two row scans give every pair the number of contacts before it
-        static_assert(NPAIR_MAX <= 32, "two pairs per lane");
-        const int c0 = team.sub < npair ? ((int)scr(SCR_PC + team.sub) & PC_COUNT_MASK) : 0;
-        const int c1 = team.sub + 16 < npair ? ((int)scr(SCR_PC + team.sub + 16) & PC_COUNT_MASK) : 0;
-        int t0, t1;
-        before[0] = team.scan(c0, t0);
-        before[1] = t0 + team.scan(c1, t1);
-        total = t0 + t1;
+        // lane `sub` owns pairs sub, sub + 16, ..: a row scan per round gives every pair the number of contacts before it
+        KS_UNROLL
+        for (int q = 0; q < (NPAIR_MAX + SUBS - 1) / SUBS; q++) {
+            const int cq = team.sub + q * SUBS < npair ? ((int)scr(SCR_PC + team.sub + q * SUBS) & PC_COUNT_MASK) : 0;
+            int tq;
+            before[q] = total + team.scan(cq, tq);
+            total += tq;
+        }
     } else {
         T cnt[NPAIR_MAX];
         KS_UNROLL
@@ -1908,9 +1929,9 @@ KS_HD void make_constraints(const Model<T>& m, const T* qpos, const T* qvel, S s
         T rr = dist - margin;
         T imp = impedance(m.solimp, rr);
         // the object's inverse weight follows its per-env mass
-        const T wobj = m.body_invw[NBODY - 1] * (m.mass[NBODY - 1] + m.armature[9]) / (T(scr(SCR_ENVP)) + m.armature[9]);
-        const int cb1 = bb & 15, cb2 = (bb >> 4) & 15;
-        T w = (cb1 == NBODY - 1 ? wobj : m.body_invw[cb1]) + (cb2 == NBODY - 1 ? wobj : m.body_invw[cb2]);
+        // (the object geoms' share follows a per-env object mass)
+        const T wobj = m.pair_invw[bb >> 8][1] * (m.mass[NBODY - 1] + m.armature[9]) / (T(scr(SCR_ENVP)) + m.armature[9]);
+        T w = m.pair_invw[bb >> 8][0] + wobj;
         T diag = (w + mu * mu * w) * 2 * mu * mu / m.impratio;
         T R = (1 - imp) / imp * diag;
         // rows with dist >= margin are inactive: flag with R < 0

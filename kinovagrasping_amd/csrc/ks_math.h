@@ -17,6 +17,15 @@
 #define KS_LDS
 #endif
 
+// Where the convex-hull tables of the collision code live.  Standard build (one object hull of a few hundred vertices beside the hand's):
+// staged in LDS by the stepping kernels, KS_TAB = KS_LDS.  Multi-geom build (KS_MULTI_GEOM: the welded-piece objects, 2 - 3.5 k hull
+// vertices, 50 - 105 KB of tables): read from global memory (L2), KS_TAB = generic.
+#ifdef KS_MULTI_GEOM
+#define KS_TAB
+#else
+#define KS_TAB KS_LDS
+#endif
+
 #include <math.h>
 #include <string.h>
 

@@ -6,8 +6,20 @@
 
 namespace ks {
 
-constexpr int NQ = 16, NV = 15, NU = 9, NBODY = 10, NGEOM = 9, NSITE = 17, NSENSOR = 26, NOBS = 82;
-constexpr int NPAIR_MAX = 32;
+constexpr int NQ = 16, NV = 15, NU = 9, NBODY = 10, NSITE = 17, NSENSOR = 26, NOBS = 82;
+// Collision topology CAPACITIES of this build (a model brings its counts: Model::ngeom, npair, nmesh).
+//  standard   : ground + 7 hand geoms + `object`; 8 explicit + 22 dynamic pairs; hulls of palm / proximal / distal / object.
+//  multi-geom : (-DKS_MULTI_GEOM, libkinova_sim_mg.so) `object` + up to 8 jointless child bodies welded to it, one mesh geom each - the
+//               reference's Bottle / TBottle / Bowl / RBowl models (kinova_description/..._sbottle.xml:158-186): 17 geoms, 30 + 8 x 8 pairs,
+//               3 + 9 hulls of up to 2048 vertices.  The welded pieces are geoms of body 9 (one rigid body, composite inertial).
+#ifdef KS_MULTI_GEOM
+constexpr bool MULTI_GEOM = true;
+constexpr int NGEOM = 17, NPAIR_MAX = 96, NMESH = 12, HULL_VERT_MAX = 2048;
+#else
+constexpr bool MULTI_GEOM = false;
+constexpr int NGEOM = 9, NPAIR_MAX = 32, NMESH = 4, HULL_VERT_MAX = 1024;
+#endif
+constexpr int OBJ_GEOM = 8;     // the geom named `object` (pieces of a multi-geom object follow it)
 constexpr int RAY_STACK = 24;   // pending-node bound of the ray-casting hierarchies (ks_obs.h: ray_mesh), checked at load
 constexpr int RAY_EMPTY = (int)0x80000000;   // unused child slot of a 4-wide node
 constexpr int NCON_MAX = 24;   // contacts kept per env per substep (oracle: KO_NCON_MAX)
@@ -39,29 +51,34 @@ template <typename T> struct Model {
     int geom_body[NGEOM], geom_mesh[NGEOM];
     T site_pos[NSITE][3], site_z[NSITE][3];
     int site_body[NSITE];
+    int ngeom, nmesh;          // counts of this model (<= NGEOM, NMESH)
     int npair, pair_g1[NPAIR_MAX], pair_g2[NPAIR_MAX];
     T pair_mu[NPAIR_MAX], pair_margin[NPAIR_MAX];
+    // translational inverse weights behind a contact's regularisation (MuJoCo: body_invweight0 of the two bodies that own the geoms),
+    // per pair: [0] the hand / ground geom's share, [1] the object geoms' share (scaled with a per-env object mass).  A piece of a
+    // multi-geom object is a body of its own in MuJoCo and brings its own value (blob record geom_invweight0).
+    T pair_invw[NPAIR_MAX][2];
     T tendon_coef[3][2];
     T act[5];                  // kv_slide, gear_motor, ctrlrange_slide, kv_finger, ctrlrange_finger
     T dof_invw[NV], body_invw[NBODY], tendon_invw[3];
     T obj_size_obs[3];
-    int mesh_nvert[4], mesh_nvert_pad[4], mesh_ntri[4], mesh_nnode[4];
-    const T* mesh_vert[4];     // [nvert_pad][4] (x,y,z,0) in the geom frame; rows >= nvert repeat vertex 0
+    int mesh_nvert[NMESH], mesh_nvert_pad[NMESH], mesh_ntri[NMESH], mesh_nnode[NMESH];
+    const T* mesh_vert[NMESH]; // [nvert_pad][4] (x,y,z,0) in the geom frame; rows >= nvert repeat vertex 0
     // rangefinder geometry: the original mesh triangles (geom frame) under a bounding-volume hierarchy
-    const float* mesh_tri[4];      // [ntri][9], leaf ranges contiguous
-    const float* mesh_bvh_box[4];  // [wide nodes][32] 4-wide ray hierarchy: 4 child boxes (min xyz, max xyz), 4 child words, padding (ks_model_host.h)
+    const float* mesh_tri[NMESH];      // [ntri][9], leaf ranges contiguous
+    const float* mesh_bvh_box[NMESH];  // [wide nodes][32] 4-wide ray hierarchy: 4 child boxes (min xyz, max xyz), 4 child words, padding (ks_model_host.h)
                                    // (int bits; leaf: first triangle, -count), 2 pad
-    const int* mesh_bvh_lr[4];     // [nnode][2] internal: (left, right); leaf: (first triangle, -count)
+    const int* mesh_bvh_lr[NMESH]; // [nnode][2] internal: (left, right); leaf: (first triangle, -count)
     // vertex adjacency of the hull graph in chunks of 4 neighbour ids (uint16, ascending, padded with the
     // vertex itself, which never wins a strict comparison): one 8-byte read yields four neighbours
-    int mesh_nchunk[4];
-    const unsigned short* mesh_adj_off[4];  // [nvert+1] first chunk of every vertex
-    const unsigned short* mesh_adj[4];      // [nchunk][4]
+    int mesh_nchunk[NMESH];
+    const unsigned short* mesh_adj_off[NMESH];  // [nvert+1] first chunk of every vertex
+    const unsigned short* mesh_adj[NMESH];      // [nchunk][4]
     // support vertex of every hull for the centre direction of every cell of a cube map (6 faces x R x R): where a
-    // hill climb towards an arbitrary direction starts, [4][SUPPORT_CELLS]; global memory (12 KB, L1/L2 resident)
+    // hill climb towards an arbitrary direction starts, [nmesh][SUPPORT_CELLS]; global memory (48 KB per hull, L1/L2 resident)
     const unsigned short* mesh_dirtab;
     // the hull tables once more as ONE block in the order the stepping kernels keep them in LDS ([vert 0..3][adj_off 0 | adj 0 | ..
-    // | adj_off 3 | adj 3], padded to 16 bytes): staged with a single copy (ks_api.hip, stage_tables); device contexts only
+    // | adj_off 3 | adj 3], padded to 16 bytes): staged with a single copy (ks_api.hip, stage_tables); device contexts of the standard build only
     const void* hull_pack;
     int hull_pack_bytes;
 };

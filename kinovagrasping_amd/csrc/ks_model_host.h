@@ -44,11 +44,11 @@ inline bool blob_find(const unsigned char* blob, size_t n, const char* name, Blo
 
 template <typename T> struct HostModel {
     Model<T> m;
-    std::vector<T> vert[4];
-    std::vector<float> tri[4], bvh_box[4];
-    std::vector<int> bvh_lr[4];
-    std::vector<unsigned short> adj_off[4], adj[4];
-    std::vector<unsigned short> dirtab;     // [4][SUPPORT_CELLS]
+    std::vector<T> vert[NMESH];
+    std::vector<float> tri[NMESH], bvh_box[NMESH];
+    std::vector<int> bvh_lr[NMESH];
+    std::vector<unsigned short> adj_off[NMESH], adj[NMESH];
+    std::vector<unsigned short> dirtab;     // [nmesh][SUPPORT_CELLS]
     std::string error;
 };
 
@@ -84,24 +84,42 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
     BlobRec probe;
     if (!blob_find(b, n, "opt", probe)) { e = "not a KSMB v5 model blob (merge <shape>.ksm with hand_raymesh.kst: model_compiler.load_model_blob)"; return false; }
     double opt[11], body_pos[30], body_quat[40], body_mass[10], body_ipos[30], body_iquat[40], body_inertia[30];
-    double geom_pos[27], geom_quat[36], geom_size[27], geom_rbound[9], site_pos[NSITE * 3], site_quat[NSITE * 4];
+    double geom_pos[3 * NGEOM], geom_quat[4 * NGEOM], geom_size[3 * NGEOM], geom_rbound[NGEOM], geom_invw[NGEOM], site_pos[NSITE * 3], site_quat[NSITE * 4];
     double hl[6], binvw[20];
     bool ok = true;
+    // geoms: the fixed nine, or - multi-geom objects, KS_MULTI_GEOM builds only - `object` plus its welded pieces (all of body 9)
+    if (!blob_find(b, n, "geom_body", probe) || probe.code != 1 || probe.count < 9) { e = "bad or missing record 'geom_body'"; return false; }
+    if (probe.count > (uint32_t)NGEOM) {
+        e = MULTI_GEOM ? "more object geoms than this build holds" : "a multi-geom object (welded pieces) needs the multi-geom build of the library (libkinova_sim_mg.so)";
+        return false;
+    }
+    const size_t ng = probe.count;
+    m.ngeom = (int)ng;
+    m.nmesh = (int)ng - 5;
     ok = ok && get_f64(b, n, "opt", opt, 11, e) && get_f64(b, n, "body_pos", body_pos, 30, e) && get_f64(b, n, "body_quat", body_quat, 40, e);
     ok = ok && get_f64(b, n, "body_mass", body_mass, 10, e) && get_f64(b, n, "body_ipos", body_ipos, 30, e);
     ok = ok && get_f64(b, n, "body_iquat", body_iquat, 40, e) && get_f64(b, n, "body_inertia", body_inertia, 30, e);
     ok = ok && get_f64(b, n, "slide_axis", &m.slide_axis[0][0], 9, e) && get_f64(b, n, "slide_range", &m.slide_range[0][0], 6, e);
     ok = ok && get_f64(b, n, "hinge_range", &m.hinge_range[0][0], 12, e) && get_f64(b, n, "hinge_limited", hl, 6, e);
     ok = ok && get_f64(b, n, "dof_damping", m.damping, NV, e) && get_f64(b, n, "dof_armature", m.armature, NV, e);
-    ok = ok && get_f64(b, n, "geom_pos", geom_pos, 27, e) && get_f64(b, n, "geom_quat", geom_quat, 36, e);
-    ok = ok && get_f64(b, n, "geom_size", geom_size, 27, e) && get_f64(b, n, "geom_rbound", geom_rbound, 9, e);
-    ok = ok && get_i32(b, n, "geom_body", m.geom_body, 9, e) && get_i32(b, n, "geom_mesh", m.geom_mesh, 9, e);
+    ok = ok && get_f64(b, n, "geom_pos", geom_pos, 3 * ng, e) && get_f64(b, n, "geom_quat", geom_quat, 4 * ng, e);
+    ok = ok && get_f64(b, n, "geom_size", geom_size, 3 * ng, e) && get_f64(b, n, "geom_rbound", geom_rbound, ng, e);
+    ok = ok && get_i32(b, n, "geom_body", m.geom_body, ng, e) && get_i32(b, n, "geom_mesh", m.geom_mesh, ng, e);
     ok = ok && get_f64(b, n, "site_pos", site_pos, NSITE * 3, e) && get_f64(b, n, "site_quat", site_quat, NSITE * 4, e);
     ok = ok && get_i32(b, n, "site_body", m.site_body, NSITE, e);
     ok = ok && get_f64(b, n, "tendon_coef", &m.tendon_coef[0][0], 6, e) && get_f64(b, n, "actuator", m.act, 5, e);
     ok = ok && get_f64(b, n, "dof_invweight0", m.dof_invw, NV, e) && get_f64(b, n, "body_invweight0", binvw, 20, e);
     ok = ok && get_f64(b, n, "tendon_invweight0", m.tendon_invw, 3, e) && get_f64(b, n, "obj_size_obs", m.obj_size_obs, 3, e);
     if (!ok) return false;
+    for (int g = (int)ng; g < NGEOM; g++) { m.geom_body[g] = 0; m.geom_mesh[g] = 0; }
+    for (int g = 0; g < (int)ng; g++) {
+        const bool obj = g >= OBJ_GEOM;
+        if (m.geom_body[g] != (g == 0 ? 0 : (obj ? 9 : g + 1)) || m.geom_mesh[g] != (g == 0 ? -1 : (obj ? g - 5 : (g == 1 ? 0 : 1 + (g & 1))))) {
+            e = "geom_body / geom_mesh outside the supported topology"; return false;
+        }
+        geom_invw[g] = binvw[2 * m.geom_body[g]];
+    }
+    if (blob_find(b, n, "geom_invweight0", probe) && !get_f64(b, n, "geom_invweight0", geom_invw, ng, e)) return false;
     m.dt = (T)opt[0]; m.impratio = (T)opt[1]; m.gravity_z = (T)opt[2];
     const double margin = opt[3];
     double tc = opt[4] < 2 * opt[0] ? 2 * opt[0] : opt[4], dr = opt[5], dmax = opt[7];
@@ -149,6 +167,12 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
     }
     for (int g = 0; g < NGEOM; g++) {
         double R[9];
+        if (g >= (int)ng) {             // unused capacity: identity poses, nothing collides with them
+            for (int k = 0; k < 9; k++) m.geom_R[g][k] = (T)(k % 4 == 0);
+            for (int k = 0; k < 3; k++) { m.geom_pos[g][k] = T(0); m.geom_size[g][k] = T(0); }
+            m.geom_rbound[g] = T(0);
+            continue;
+        }
         q2m(&geom_quat[4 * g], R);
         for (int k = 0; k < 9; k++) m.geom_R[g][k] = (T)R[k];
         for (int k = 0; k < 3; k++) { m.geom_pos[g][k] = (T)geom_pos[3 * g + k]; m.geom_size[g][k] = (T)geom_size[3 * g + k]; }
@@ -162,23 +186,36 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
     BlobRec pr;
     if (!blob_find(b, n, "pairs", pr) || pr.shape[1] != 5 || pr.shape[0] > (uint32_t)NPAIR_MAX) { e = "bad 'pairs' record"; return false; }
     m.npair = (int)pr.shape[0];
+    for (int p = m.npair; p < NPAIR_MAX; p++) { m.pair_g1[p] = m.pair_g2[p] = 0; m.pair_mu[p] = m.pair_margin[p] = m.pair_invw[p][0] = m.pair_invw[p][1] = T(0); }
     for (int p = 0; p < m.npair; p++) {
         double row[5];
         std::memcpy(row, pr.data + 40 * p, 40);
         m.pair_g1[p] = (int)row[0]; m.pair_g2[p] = (int)row[1];
+        if (m.pair_g1[p] < 0 || m.pair_g1[p] >= m.pair_g2[p] || m.pair_g2[p] >= (int)ng) { e = "pair geoms out of range"; return false; }
+        {
+            const T w1 = (T)geom_invw[m.pair_g1[p]], w2 = (T)geom_invw[m.pair_g2[p]];
+            const bool o1 = m.pair_g1[p] >= OBJ_GEOM, o2 = m.pair_g2[p] >= OBJ_GEOM;
+            m.pair_invw[p][0] = (o1 ? T(0) : w1) + (o2 ? T(0) : w2);
+            m.pair_invw[p][1] = (o1 ? w1 : T(0)) + (o2 ? w2 : T(0));
+        }
         if (row[2] != row[3]) { e = "anisotropic pair friction is not supported"; return false; }
         if (!(row[4] >= 0) || row[4] > margin) { e = "pair margin outside [0, geom margin]"; return false; }
         m.pair_mu[p] = (T)row[2]; m.pair_margin[p] = (T)row[4];
     }
-    for (int s = 0; s < 4; s++) {
+    for (int s = m.nmesh; s < NMESH; s++) {
+        m.mesh_nvert[s] = m.mesh_nvert_pad[s] = m.mesh_ntri[s] = m.mesh_nnode[s] = m.mesh_nchunk[s] = 0;
+        m.mesh_vert[s] = nullptr; m.mesh_tri[s] = nullptr; m.mesh_bvh_box[s] = nullptr; m.mesh_bvh_lr[s] = nullptr;
+        m.mesh_adj_off[s] = nullptr; m.mesh_adj[s] = nullptr;
+    }
+    for (int s = 0; s < m.nmesh; s++) {
         char nm[24];
         BlobRec r;
         std::snprintf(nm, sizeof nm, "mesh%d_vert", s);
         if (!blob_find(b, n, nm, r) || r.code != 0) { e = std::string("missing ") + nm; return false; }
         {
             const int nv = (int)r.shape[0], npad = (nv + 7) / 8 * 8;   // HULL_CHUNK
-            // 10-bit vertex ids in the pair memory (ks_core.h PairWarm), 64 rounds of 16 in the plane scan's candidate mask
-            if (nv < 1 || nv > 1024) { e = std::string(nm) + ": a hull has 1 .. 1024 vertices"; return false; }
+            // standard build: 10-bit vertex ids in the pair memory (ks_core.h PairWarm), 64 rounds of 16 in the plane scan's candidate mask
+            if (nv < 1 || nv > HULL_VERT_MAX) { e = std::string(nm) + ": a hull has 1 .. " + std::to_string(HULL_VERT_MAX) + " vertices"; return false; }
             hm.vert[s].assign((size_t)npad * 4, T(0));
             for (int i = 0; i < npad; i++)
                 for (int c = 0; c < 3; c++) { double v; std::memcpy(&v, r.data + 8 * (3 * (i < nv ? i : 0) + c), 8); hm.vert[s][4 * i + c] = (T)v; }
@@ -279,8 +316,8 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
         m.mesh_adj[s] = hm.adj[s].data();
     }
     // support vertex of the centre direction of every cube-map cell (exhaustive scans, once per model)
-    hm.dirtab.assign(4 * SUPPORT_CELLS, 0);
-    for (int s = 0; s < 4; s++)
+    hm.dirtab.assign((size_t)m.nmesh * SUPPORT_CELLS, 0);
+    for (int s = 0; s < m.nmesh; s++)
         for (int c = 0; c < SUPPORT_CELLS; c++) {
             const int face = c / (SUPPORT_R * SUPPORT_R), iu = (c / SUPPORT_R) % SUPPORT_R, iv = c % SUPPORT_R, axis = face >> 1;
             double dir[3];

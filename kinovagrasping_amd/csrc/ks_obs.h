@@ -294,7 +294,7 @@ template <typename T, typename C> KS_HD T rangefinder(const Model<T>& m, C snap,
     T pnt[3], vec[3];
     const int sb = ray_origin(m, snap, si, pnt, vec);
     T best = ray_ground(m, pnt, vec);
-    for (int g = 1; g < NGEOM; g++) {
+    for (int g = 1; g < m.ngeom; g++) {
         if (m.geom_body[g] == sb) continue;
         best = ray_nearer(best, ray_geom(m, snap, g, pnt, vec));
     }

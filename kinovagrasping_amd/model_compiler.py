@@ -33,6 +33,7 @@ VERSION = 5
 # fixed topology ------------------------------------------------------------------------------
 NQ, NV, NU = 16, 15, 9
 NBODY, NGEOM, NSITE = 10, 9, 17
+NGEOM_MAX, NPAIR_MAX_MG = 17, 96     # multi-geom objects: up to 8 welded pieces beside `object` (RoundBowl), 30 + 8 * 8 pairs
 BODY_NAMES = ["world", "root", "j2s7s300_link_7",
               "j2s7s300_link_finger_1", "j2s7s300_link_finger_tip_1",
               "j2s7s300_link_finger_2", "j2s7s300_link_finger_tip_2",
@@ -415,19 +416,33 @@ def compile_model(xml_path: Path, mesh_inertia: str = "legacy") -> dict:
     M["dof_armature"] = np.full(NV, armature)
 
     # geoms + meshes ---------------------------------------------------------------------------
-    meshes = [None] * 4
-    geom_pos = np.zeros((NGEOM, 3))
-    geom_quat = np.tile(np.array([1.0, 0, 0, 0]), (NGEOM, 1))
-    geom_size = np.zeros((NGEOM, 3))
-    geom_rbound = np.zeros(NGEOM)
+    # Multi-geom objects (Bottle / TBottle / Bowl / RBowl, e.g. ..._sbottle.xml:158-186): the `object` body carries jointless
+    # child bodies with one mesh geom each.  MuJoCo welds them to the object (one rigid body); their geoms collide dynamically
+    # (default contype / conaffinity 1) with the ground and the hand.  Compiled as: extra geoms 9.. of body 9 with a mesh slot
+    # each, the object's inertial = the composite of the pieces, the dynamic pairs appended, and the per-geom inverse weight of
+    # the MuJoCo body that owns the geom (`geom_invweight0`, see _invweights).
+    pieces = [c for c in bodies["object"] if c.tag == "body"]
+    for c in pieces:
+        assert c.find("joint") is None and len(c.findall("geom")) == 1 and c.find("body") is None, f"{xml_path.name}: object child {c.get('name')}"
+        assert np.allclose(_frame_of(c)[0], 0) and np.allclose(_frame_of(c)[1], [1, 0, 0, 0]), "welded object pieces sit in the object's frame"
+    geom_names = GEOM_NAMES + [c.find("geom").get("name") for c in pieces]
+    ngeom = len(geom_names)
+    geom_mesh_slot = GEOM_MESH + [4 + k for k in range(len(pieces))]
+    assert ngeom <= NGEOM_MAX
+    meshes = [None] * (4 + len(pieces))
+    geom_pos = np.zeros((ngeom, 3))
+    geom_quat = np.tile(np.array([1.0, 0, 0, 0]), (ngeom, 1))
+    geom_size = np.zeros((ngeom, 3))
+    geom_rbound = np.zeros(ngeom)
     geom_elems = {g.get("name"): g for g in wb.iter("geom")}
-    for gi, gname in enumerate(GEOM_NAMES):
+    assert len(geom_elems) == ngeom, f"{xml_path.name}: geoms {sorted(geom_elems)} "
+    for gi, gname in enumerate(geom_names):
         g = geom_elems[gname]
         if gi == 0:
             assert g.get("class") == "ground"
             geom_size[gi] = _floats(g.get("size"), 3)
             continue
-        slot = GEOM_MESH[gi]
+        slot = geom_mesh_slot[gi]
         gtype = g.get("type", "sphere")
         if gtype in ("box", "cylinder"):
             # Primitive object geoms (the env's default model is ..._mbox.xml, ENV:62; bbox / scyl / mcyl / bcyl likewise):
@@ -435,7 +450,7 @@ def compile_model(xml_path: Path, mesh_inertia: str = "legacy") -> dict:
             # 64-gon prism (radial deviation <= r (1 - cos(pi/64)) = 1.2e-3 r; the README's CylinderS/B meshes are 67-gons) -
             # so that one narrow phase (GJK / MPR on hulls, plane-hull) and one ray caster serve every object.
             # Inertia and the sizes the observation reports are the primitive's own (analytic), not the polytope's.
-            assert gi == 8, "only the object may be a primitive"
+            assert gi == 8 and not pieces, "only a single-geom object may be a primitive"
             raw = _floats(g.get("size"))
             if gtype == "box":
                 assert len(raw) == 3
@@ -468,11 +483,30 @@ def compile_model(xml_path: Path, mesh_inertia: str = "legacy") -> dict:
     body_ipos[9] = geom_pos[8]
     body_iquat[9] = geom_quat[8]
     body_inertia[9] = cm.principal * (omass / cm.volume) if prim is None else prim["inertia"] * omass
+    if pieces:
+        # the welded pieces: MuJoCo keeps them as bodies 10.. with the inertial of their geom; one rigid body with the composite
+        # inertial (parallel axes about the composite centre of mass, then its principal frame) has the same dynamics
+        pm = [omass] + [float(geom_elems[n].get("mass")) for n in geom_names[9:]]
+        pc = [geom_pos[8 + k] for k in range(len(pm))]                       # centres of mass of the pieces, object frame
+        pI = []
+        for k in range(len(pm)):
+            c_ = meshes[3 + k]
+            Rk = quat_to_mat(geom_quat[8 + k])
+            pI.append(Rk @ np.diag(c_.principal * (pm[k] / c_.volume)) @ Rk.T)
+        mtot = float(np.sum(pm))
+        com = np.sum([m_ * c_ for m_, c_ in zip(pm, pc)], axis=0) / mtot
+        Ic = np.zeros((3, 3))
+        for m_, c_, I_ in zip(pm, pc, pI):
+            r_ = c_ - com
+            Ic += I_ + m_ * (r_ @ r_ * np.eye(3) - np.outer(r_, r_))
+        pr_, Rc = principal_frame(Ic)
+        body_mass[9], body_ipos[9], body_iquat[9], body_inertia[9] = mtot, com, mat_to_quat(Rc), pr_
+        M["piece_mass"] = np.array(pm)
     M["body_pos"], M["body_quat"], M["body_mass"] = body_pos, body_quat, body_mass
     M["body_ipos"], M["body_iquat"], M["body_inertia"] = body_ipos, body_iquat, body_inertia
     M["geom_pos"], M["geom_quat"], M["geom_size"], M["geom_rbound"] = geom_pos, geom_quat, geom_size, geom_rbound
-    M["geom_body"] = np.array(GEOM_BODY, dtype=np.int32)
-    M["geom_mesh"] = np.array(GEOM_MESH, dtype=np.int32)
+    M["geom_body"] = np.array(GEOM_BODY + [9] * len(pieces), dtype=np.int32)
+    M["geom_mesh"] = np.array(geom_mesh_slot, dtype=np.int32)
     for s, cm in enumerate(meshes):
         M[f"mesh{s}_vert"] = cm.verts
         M[f"mesh{s}_tri"] = cm.tri
@@ -504,7 +538,7 @@ def compile_model(xml_path: Path, mesh_inertia: str = "legacy") -> dict:
     dpair = dflt.find("pair")
     pair_margin_default = float(dpair.get("margin", "0")) if dpair is not None else 0.0
     for p in root.find("contact").findall("pair"):
-        g1, g2 = GEOM_NAMES.index(p.get("geom1")), GEOM_NAMES.index(p.get("geom2"))
+        g1, g2 = geom_names.index(p.get("geom1")), geom_names.index(p.get("geom2"))
         fr = _floats(p.get("friction"), 5)
         assert p.get("condim") == "3"
         a, b = min(g1, g2), max(g1, g2)
@@ -523,8 +557,13 @@ def compile_model(xml_path: Path, mesh_inertia: str = "legacy") -> dict:
                 if (ba == 2 and bb in (3, 5, 7)) or (bb == ba + 1 and ba in (3, 5, 7)):
                     continue
             pairs.append([a, b, 1.0, 1.0, margin])     # geom default friction 1 0.005 0.0001, condim 3
-    M["pairs"] = np.array(pairs)
     assert len(pairs) == 30, len(pairs)
+    # the welded pieces of a multi-geom object: dynamic candidates with the ground and the seven hand geoms (geom order); not with each
+    # other nor with `object` (bodies welded together are never tested, MuJoCo's body_weldid filter)
+    for b in range(9, ngeom):
+        for a in range(0, 8):
+            pairs.append([a, b, 1.0, 1.0, margin])
+    M["pairs"] = np.array(pairs)
 
     # tendons / equality / actuators -----------------------------------------------------------------
     tend = root.find("tendon").findall("fixed")
@@ -543,24 +582,34 @@ def compile_model(xml_path: Path, mesh_inertia: str = "legacy") -> dict:
     # inverse weights at qpos0 ------------------------------------------------------------------------
     M.update(_invweights(M))
     # the observation's object size comes from MuJoCo's geom_size: AABB half extents of a mesh, the size attribute of a primitive
-    M["obj_size_obs"] = object_size_obs(geom_size[8] if prim is None else prim["raw"], xml_path.name)
+    M["obj_size_obs"] = object_size_obs(geom_size[8] if prim is None else prim["raw"], xml_path.name, geom_size[9:])
     return M
 
 
-def object_size_obs(size, filename):
-    """Restatement of KinovaGripper_Env._get_obj_size (kinova_gripper_env.py:706-746) for a
-    single object geom; the observation stores [s0, s1, 2*s2] (kinova_gripper_env.py:529)."""
-    size = np.array(size, dtype=np.float64).copy()
+def object_size_obs(size, filename, piece_sizes=()):
+    """Restatement of KinovaGripper_Env._get_obj_size (kinova_gripper_env.py:706-746); the observation stores
+    [s0, s1, 2*s2] (kinova_gripper_env.py:529).  `size`: geom_size of `object`; `piece_sizes`: geom_size of the welded pieces of a
+    multi-geom object in geom order (the reference walks the object's geoms from the LAST one back to `object`: widths by maximum,
+    heights summed; the bowls get constants scaled by the size letter of the file name)."""
     final = np.zeros(3)
-    if size[2] == 0:
-        size[2] = size[1]
-        size[1] = size[0]
-    diffs = [abs(size[0] - size[1]), abs(size[1] - size[2]), abs(size[0] - size[2])]
-    if ("lemon" in filename) or (int(np.argmin(diffs)) != 0):
-        size[0], size[2] = size[2], size[0]
-    final[0] = max(size[0], final[0])
-    final[1] = max(size[1], final[1])
-    final[2] += size[2]
+    letter = re.search(r"_v1_([a-zA-Z])", filename)
+    for size in [np.array(p_, dtype=np.float64) for p_ in list(piece_sizes)[::-1]] + [np.array(size, dtype=np.float64)]:
+        size = size.copy()
+        if size[2] == 0:
+            size[2] = size[1]
+            size[1] = size[0]
+        diffs = [abs(size[0] - size[1]), abs(size[1] - size[2]), abs(size[0] - size[2])]
+        if ("lemon" in filename) or (int(np.argmin(diffs)) != 0):
+            size[0], size[2] = size[2], size[0]
+        if "Bowl" in filename:
+            final[:] = [0.17, 0.17, 0.075] if "Rect" in filename else [0.175, 0.175, 0.07]
+            scale = {"m": 0.85, "s": 0.7}.get(letter.group(1) if letter else "b", 1.0)
+            if scale != 1.0:
+                final *= scale         # (the reference multiplies component by component: same products)
+        else:
+            final[0] = max(size[0], final[0])
+            final[1] = max(size[1], final[1])
+            final[2] += size[2]
     return np.array([final[0], final[1], final[2] * 2.0])
 
 
@@ -623,8 +672,17 @@ def _invweights(M):
         Jt[3 + 2 * t] = M["tendon_coef"][t, 0]
         Jt[4 + 2 * t] = M["tendon_coef"][t, 1]
         tinv[t] = Jt @ Minv @ Jt
-    return {"dof_invweight0": dof_inv, "body_invweight0": body_inv, "tendon_invweight0": tinv,
-            "M0": Mm}
+    out = {"dof_invweight0": dof_inv, "body_invweight0": body_inv, "tendon_invweight0": tinv, "M0": Mm}
+    if len(M["geom_body"]) > NGEOM:
+        # Multi-geom object: MuJoCo keeps every welded piece as a body of its own, and a contact's regularisation takes the inverse
+        # weight of the bodies that own its two geoms - for a piece: the translational inverse weight at THAT piece's centre of mass
+        # (mj_setConst: J at the body's xipos).  Hand geoms: their body's value.
+        ginv = np.array([body_inv[b, 0] for b in M["geom_body"]])
+        for g in range(8, len(ginv)):
+            Jp, _ = jac(9, p[9] + R[9] @ M["geom_pos"][g])
+            ginv[g] = np.trace(Jp @ Minv @ Jp.T) / 3
+        out["geom_invweight0"] = ginv
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
@@ -670,6 +728,21 @@ def read_blob(path_or_bytes) -> dict:
         out[name] = arr.reshape(shape) if shape else arr.reshape(())
         off += size * isz + ((-size * isz) % 8)
     return out
+
+
+def blob_record_shape(raw: bytes, name: str):
+    """shape of one record of a model blob without decoding the arrays (None if absent)"""
+    assert raw[:4] == MAGIC, "not a KSMB model blob"
+    _, n = struct.unpack("<II", raw[4:12])
+    off = 16
+    for _ in range(n):
+        nm = raw[off:off + 24].rstrip(b"\0").decode()
+        code, size, s0, s1, s2, s3 = struct.unpack("<II4I", raw[off + 24:off + 48])
+        if nm == name:
+            return tuple(x for x in (s0, s1, s2, s3) if x > 0)
+        isz = 8 if code == 0 else 4
+        off += 48 + size * isz + ((-size * isz) % 8)
+    return None
 
 
 HAND_RAY_KEYS = [f"mesh{s}_{k}" for s in range(3) for k in ("tri", "bvh_box", "bvh_lr")]

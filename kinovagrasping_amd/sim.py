@@ -53,11 +53,23 @@ ROLLOUT_EXPORTS = ["kr_select_action", "kr_store_transition", "kr_rank_episodes"
                    "kr_actor_select"]
 
 _lib = None
+_lib_mg = None
 
 
-def load_library(path: Path | None = None):
-    """Load libkinova_sim.so (must have been built: kinovagrasping_amd.build.build()).  Fails loudly."""
-    global _lib
+def load_library(path: Path | None = None, multi_geom: bool = False):
+    """Load libkinova_sim.so - or, multi_geom=True, libkinova_sim_mg.so: the same simulator C ABI (include/kinova_sim.h) compiled with
+    the capacities of the multi-geom objects (Bottle / TBottle / Bowl / RBowl: csrc/ks_model.h).  Must have been built
+    (kinovagrasping_amd.build.build()).  Fails loudly."""
+    global _lib, _lib_mg
+    if multi_geom:
+        if _lib_mg is None:
+            import os
+            mpath = Path(path) if path else Path(os.environ.get("KS_LIB_MG", _build.LIB_MG))
+            if not mpath.exists():
+                raise RuntimeError(f"{mpath} is missing: build it with kinovagrasping_amd.build.build() (hipcc, gfx950, -DKS_MULTI_GEOM). "
+                                   "There is no fallback implementation.")
+            _lib_mg = _bind(C.CDLL(str(mpath)))
+        return _lib_mg
     if _lib is not None:
         return _lib
     import os
@@ -65,7 +77,17 @@ def load_library(path: Path | None = None):
     if not path.exists():
         raise RuntimeError(f"{path} is missing: build it with kinovagrasping_amd.build.build() (hipcc, gfx950). "
                            "There is no fallback implementation.")
-    L = C.CDLL(str(path))
+    _lib = _bind(C.CDLL(str(path)))
+    return _lib
+
+
+def blob_is_multi_geom(blob: bytes) -> bool:
+    """does the model blob hold a multi-geom object (welded pieces beside `object`: more than the nine geoms of the fixed topology)?"""
+    from .model_compiler import blob_record_shape
+    return blob_record_shape(blob, "geom_body")[0] > 9
+
+
+def _bind(L):
     vp, i32p = C.c_void_p, C.c_void_p
     L.ks_default_config.argtypes = [C.POINTER(KsConfig)]
     L.ks_create.argtypes = [C.POINTER(KsConfig), C.c_int, C.POINTER(vp)]
@@ -115,7 +137,6 @@ def load_library(path: Path | None = None):
     L.kr_mlp3_backward_split.argtypes = [i32] * 5 + [vp] * 8 + [i32, i32, vp, f32, vp, vp, C.c_int64, i32, vp]
     L.kr_weight_grad_shadow.argtypes = [i32] * 4 + [vp, vp, i32, vp, i32, i32, vp, vp, vp, vp]
     L.kr_actor_select.argtypes = [i32] * 3 + [vp] * 12 + [C.c_uint64, vp, f32, f32, i32] + [vp] * 5
-    _lib = L
     return L
 
 
@@ -129,9 +150,16 @@ class KinovaSim:
     def __init__(self, n_envs: int, model: str | bytes = "CubeS", device: int | torch.device = 0, precision: int = 32,
                  frame_skip: int = 15, horizon: int = 30, solver_iterations: int = SOLVER_ITERATIONS, auto_reset: bool = False,
                  obs_env_major: bool = True, envs_per_wave: int = 0, contact_tap: bool = False, pair_memory: bool = True):
-        self.lib = load_library()
         if not torch.cuda.is_available():
             raise RuntimeError("KinovaSim needs a HIP GPU (torch.cuda.is_available() is False); there is no CPU path")
+        from .model_compiler import load_model_blob
+        as_blob = lambda m: bytes(m) if isinstance(m, (bytes, bytearray)) else bytes(load_model_blob(m, ASSETS))
+        self.models = list(model) if isinstance(model, (list, tuple)) else [model]
+        blobs = [as_blob(m) for m in self.models]
+        # a context with a multi-geom object (welded pieces: Bottle / TBottle / Bowl / RBowl) runs on the library built with those
+        # capacities; it holds single-geom objects as well (slower than the standard library: hull tables in L2, not LDS)
+        self.multi_geom = any(blob_is_multi_geom(b) for b in blobs)
+        self.lib = load_library(multi_geom=self.multi_geom)
         self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))
         self.n_envs = int(n_envs)
         self.dtype = torch.float32 if precision == 32 else torch.float64
@@ -146,19 +174,13 @@ class KinovaSim:
         rc = self.lib.ks_create(C.byref(cfg), self.device.index, C.byref(self.ctx))
         if rc != 0:
             raise RuntimeError(f"ks_create failed ({rc}): {self.lib.ks_last_error(None).decode()}")
-        from .model_compiler import load_model_blob
-        as_blob = lambda m: bytes(m) if isinstance(m, (bytes, bytearray)) else bytes(load_model_blob(m, ASSETS))
         if isinstance(model, (list, tuple)):
             # mixed-object context (BASELINE config 5): object k of reset(object_id=...) is model[k]
-            self.models = list(model)
-            blobs = [as_blob(m) for m in model]
             arr = (C.c_char_p * len(blobs))(*blobs)
             sizes = (C.c_size_t * len(blobs))(*[len(b) for b in blobs])
             self._check(self.lib.ks_load_models(self.ctx, len(blobs), arr, sizes))
         else:
-            self.models = [model]
-            blob = as_blob(model)
-            self._check(self.lib.ks_load_model(self.ctx, blob, len(blob)))
+            self._check(self.lib.ks_load_model(self.ctx, blobs[0], len(blobs[0])))
         N, dt, dev = self.n_envs, self.dtype, self.device
         self.obs = torch.zeros((N, NOBS) if obs_env_major else (NOBS, N), dtype=dt, device=dev)
         self.final_obs = torch.zeros_like(self.obs)

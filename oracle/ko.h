@@ -33,10 +33,12 @@ extern "C" {
 #define KO_NV 15
 #define KO_NU 9
 #define KO_NBODY 10
-#define KO_NGEOM 9
+#define KO_NGEOM 17   /* capacity: ground, 7 hand geoms, `object` + up to 8 welded pieces (multi-geom objects); ko_model.ngeom is the count */
+#define KO_OBJ_GEOM 8 /* the geom named `object` */
+#define KO_NMESH 12   /* capacity: palm, proximal, distal + one hull per object geom; ko_model.nmesh */
 #define KO_NSITE 17
 #define KO_NSENSOR 26
-#define KO_NPAIR_MAX 32
+#define KO_NPAIR_MAX 96
 #define KO_NCON_MAX 24
 #define KO_NEFC_MAX (3 + 9 + 4 * KO_NCON_MAX)
 #define KO_NOBS 82
@@ -52,8 +54,9 @@ typedef struct {
     double dof_damping[KO_NV], dof_armature[KO_NV];
     double geom_pos[KO_NGEOM][3], geom_quat[KO_NGEOM][4], geom_size[KO_NGEOM][3], geom_rbound[KO_NGEOM];
     int geom_body[KO_NGEOM], geom_mesh[KO_NGEOM];
-    int mesh_nvert[4], mesh_ntri[4];
-    double *mesh_vert[4], *mesh_tri[4]; /* hull vertices [nvert][3]; original triangles [ntri][9], geom frame */
+    int ngeom, nmesh;
+    int mesh_nvert[KO_NMESH], mesh_ntri[KO_NMESH];
+    double *mesh_vert[KO_NMESH], *mesh_tri[KO_NMESH]; /* hull vertices [nvert][3]; original triangles [ntri][9], geom frame */
     double site_pos[KO_NSITE][3], site_quat[KO_NSITE][4];
     int site_body[KO_NSITE];
     int npair;
@@ -61,6 +64,9 @@ typedef struct {
     double tendon_coef[3][2];
     double actuator[5]; /* kv_slide, gear_motor, ctrlrange_slide, kv_finger, ctrlrange_finger */
     double dof_invweight0[KO_NV], body_invweight0[KO_NBODY][2], tendon_invweight0[3];
+    /* translational inverse weight of the MuJoCo body that owns geom g: body_invweight0[geom_body[g]][0], except for the pieces of a
+     * multi-geom object - MuJoCo keeps each welded piece as a body of its own with its own value (blob record geom_invweight0) */
+    double geom_invweight0[KO_NGEOM];
     double obj_size_obs[3];
 } ko_model;
 

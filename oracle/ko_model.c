@@ -79,12 +79,17 @@ ko_model *ko_model_load(const void *vblob, size_t n) {
     for (int i = 0; i < 6; i++) m->hinge_limited[i] = hl[i] != 0.0;
     bad |= get_f64(blob, n, "dof_damping", m->dof_damping, 15);
     bad |= get_f64(blob, n, "dof_armature", m->dof_armature, 15);
-    bad |= get_f64(blob, n, "geom_pos", &m->geom_pos[0][0], 27);
-    bad |= get_f64(blob, n, "geom_quat", &m->geom_quat[0][0], 36);
-    bad |= get_f64(blob, n, "geom_size", &m->geom_size[0][0], 27);
-    bad |= get_f64(blob, n, "geom_rbound", m->geom_rbound, 9);
-    bad |= get_i32(blob, n, "geom_body", m->geom_body, 9);
-    bad |= get_i32(blob, n, "geom_mesh", m->geom_mesh, 9);
+    rec_hdr gh;
+    if (!find_rec(blob, n, "geom_body", &gh) || gh.count < 9 || gh.count > KO_NGEOM) { fprintf(stderr, "ko_model_load: bad geom count\n"); free(m); return NULL; }
+    const size_t ng = gh.count;
+    m->ngeom = (int)ng;
+    m->nmesh = (int)ng - 5;    /* palm, proximal, distal + one hull per object geom */
+    bad |= get_f64(blob, n, "geom_pos", &m->geom_pos[0][0], 3 * ng);
+    bad |= get_f64(blob, n, "geom_quat", &m->geom_quat[0][0], 4 * ng);
+    bad |= get_f64(blob, n, "geom_size", &m->geom_size[0][0], 3 * ng);
+    bad |= get_f64(blob, n, "geom_rbound", m->geom_rbound, ng);
+    bad |= get_i32(blob, n, "geom_body", m->geom_body, ng);
+    bad |= get_i32(blob, n, "geom_mesh", m->geom_mesh, ng);
     bad |= get_f64(blob, n, "site_pos", &m->site_pos[0][0], KO_NSITE * 3);
     bad |= get_f64(blob, n, "site_quat", &m->site_quat[0][0], KO_NSITE * 4);
     bad |= get_i32(blob, n, "site_body", m->site_body, KO_NSITE);
@@ -94,6 +99,11 @@ ko_model *ko_model_load(const void *vblob, size_t n) {
     bad |= get_f64(blob, n, "body_invweight0", &m->body_invweight0[0][0], 20);
     bad |= get_f64(blob, n, "tendon_invweight0", m->tendon_invweight0, 3);
     bad |= get_f64(blob, n, "obj_size_obs", m->obj_size_obs, 3);
+    if (!bad) {
+        rec_hdr wh;
+        for (int g = 0; g < m->ngeom; g++) m->geom_invweight0[g] = m->body_invweight0[m->geom_body[g]][0];
+        if (find_rec(blob, n, "geom_invweight0", &wh)) bad |= get_f64(blob, n, "geom_invweight0", m->geom_invweight0, ng);
+    }
     rec_hdr h;
     const unsigned char *p = find_rec(blob, n, "pairs", &h);
     if (!p || h.shape[1] != 5 || h.shape[0] > KO_NPAIR_MAX) bad = 1;
@@ -101,7 +111,7 @@ ko_model *ko_model_load(const void *vblob, size_t n) {
         m->npair = (int)h.shape[0];
         memcpy(m->pairs, p, (size_t)h.count * 8);
     }
-    for (int s = 0; s < 4 && !bad; s++) {
+    for (int s = 0; s < m->nmesh && !bad; s++) {
         char nm[24];
         snprintf(nm, sizeof nm, "mesh%d_vert", s);
         p = find_rec(blob, n, nm, &h);
@@ -125,7 +135,7 @@ ko_model *ko_model_load(const void *vblob, size_t n) {
 
 void ko_model_free(ko_model *m) {
     if (!m) return;
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < KO_NMESH; s++) {
         free(m->mesh_vert[s]);
         free(m->mesh_tri[s]);
     }

@@ -150,7 +150,7 @@ void ko_kinematics(ko_sim *s) {
         quat2mat(Ri, m->body_iquat[b]);
         mulmat3(s->ximat[b], s->xmat[b], Ri);
     }
-    for (int g = 0; g < KO_NGEOM; g++) {
+    for (int g = 0; g < m->ngeom; g++) {
         int b = m->geom_body[g];
         double t[3], Rg[9];
         mulmatvec3(t, s->xmat[b], m->geom_pos[g]);
@@ -203,9 +203,11 @@ static void jac_point(const ko_sim *s, int body, const double *x, double Jp[3][K
 /* mass of body b and the factor on its inertia: the object's may be replaced per sim (config 5) */
 static double body_mass_of(const ko_sim *s, int b) { return (b == KO_NBODY - 1 && s->obj_mass > 0) ? s->obj_mass : s->m->body_mass[b]; }
 static double inertia_scale_of(const ko_sim *s, int b) { return body_mass_of(s, b) / s->m->body_mass[b]; }
-static double body_invweight_of(const ko_sim *s, int b) {
+/* translational inverse weight of the MuJoCo body that owns geom g (the pieces of a multi-geom object: their own, ko.h) */
+static double geom_invweight_of(const ko_sim *s, int g) {
     const ko_model *m = s->m;
-    double w = m->body_invweight0[b][0];
+    const int b = m->geom_body[g];
+    double w = m->geom_invweight0[g];
     if (b == KO_NBODY - 1 && s->obj_mass > 0) w *= (m->body_mass[b] + m->dof_armature[9]) / (s->obj_mass + m->dof_armature[9]);
     return w;
 }
@@ -729,7 +731,7 @@ static void add_contact(ko_sim *s, int g1, int g2, const double *pair, double di
     ko_contact *c = &s->contact[s->ncon++];
     c->dist = dist; c->geom1 = g1; c->geom2 = g2;
     c->mu[0] = pair[2]; c->mu[1] = pair[3]; c->margin = pair[4];
-    if (s->obj_mu > 0 && g1 != 0 && g2 == KO_NGEOM - 1) c->mu[0] = c->mu[1] = s->obj_mu; /* object-hand pairs */
+    if (s->obj_mu > 0 && g1 != 0 && g2 >= KO_OBJ_GEOM) c->mu[0] = c->mu[1] = s->obj_mu; /* object-hand pairs */
     copy3(c->pos, pos);
     copy3(c->frame, normal);
     make_frame(c->frame);
@@ -890,7 +892,7 @@ static void make_constraint(ko_sim *s) {
             for (int j = 0; j < KO_NV; j++)
                 Jd[a][j] = c->frame[3 * a] * (Jp2[0][j] - Jp1[0][j]) + c->frame[3 * a + 1] * (Jp2[1][j] - Jp1[1][j]) +
                            c->frame[3 * a + 2] * (Jp2[2][j] - Jp1[2][j]);
-        double w = body_invweight_of(s, b1) + body_invweight_of(s, b2), mu = c->mu[0];
+        double w = geom_invweight_of(s, c->geom1) + geom_invweight_of(s, c->geom2), mu = c->mu[0];
         double diag = (w + mu * mu * w) * 2 * mu * mu / m->impratio;
         for (int k = 0; k < 4; k++) {
             double sgn = (k & 1) ? -1.0 : 1.0, muk = c->mu[k >> 1];
@@ -1149,7 +1151,7 @@ static void sensors(ko_sim *s) {
     for (int i = 0; i < KO_NSITE; i++) {
         const double *pnt = s->site_xpos[i];
         double vec[3] = {s->site_xmat[i][2], s->site_xmat[i][5], s->site_xmat[i][8]}, best = -1;
-        for (int g = 0; g < KO_NGEOM; g++) {
+        for (int g = 0; g < m->ngeom; g++) {
             if (m->geom_body[g] == m->site_body[i]) continue;
             double d = -1;
             if (g == 0) { /* ground plane z=0, finite half-size (XML:148).  mju_rayGeom's plane case: a ray whose local z component

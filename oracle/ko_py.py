@@ -9,7 +9,7 @@ from pathlib import Path
 import numpy as np
 
 HERE = Path(__file__).resolve().parent
-NQ, NV, NU, NBODY, NGEOM, NSITE, NSENSOR = 16, 15, 9, 10, 9, 17, 26
+NQ, NV, NU, NBODY, NGEOM, NSITE, NSENSOR = 16, 15, 9, 10, 17, 17, 26      # NGEOM: capacity (ko.h KO_NGEOM); single-geom objects use the first 9
 NCON_MAX = 24
 NEFC_MAX = 3 + 9 + 4 * NCON_MAX
 NOBS, NOBS_GLOBAL = 82, 74
@@ -193,7 +193,7 @@ def _contact_forces(self):
 
 
 OracleSim.contact_forces = _contact_forces
-GEOM_BODY = [0, 2, 3, 4, 5, 6, 7, 8, 9]        # body of geom g (ground, palm, f1_prox, f1_dist, ..., object)
+GEOM_BODY = [0, 2, 3, 4, 5, 6, 7, 8, 9] + [9] * 8        # body of geom g (ground, palm, f1_prox, f1_dist, ..., object, welded object pieces)
 
 
 def env_obs_from_inputs(inputs: dict):

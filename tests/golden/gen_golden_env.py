@@ -80,8 +80,8 @@ SITE_NAMES = ["palm", "palm_1", "palm_2", "palm_3", "palm_4", "f1_prox", "f1_pro
 
 
 def snapshot(sim, geom_size):
-    gx = sim.view("geom_xpos").reshape(9, 3).copy()
-    gm = sim.view("geom_xmat").reshape(9, 9).copy()
+    gx = sim.view("geom_xpos").reshape(-1, 3).copy()
+    gm = sim.view("geom_xmat").reshape(-1, 9).copy()
     sx = sim.view("site_xpos").reshape(17, 3).copy()
     return {
         "geom_xpos": {n: gx[i] for i, n in enumerate(GEOM_NAMES)},

@@ -19,7 +19,7 @@ struct LC {
 
 template <typename T> static Hulls<T> host_hulls(const Model<T>& m) {
     Hulls<T> h;
-    for (int s = 0; s < 4; s++) { h.vert[s] = m.mesh_vert[s]; h.nvert[s] = m.mesh_nvert[s]; h.nvert_pad[s] = m.mesh_nvert_pad[s]; h.adj_off[s] = m.mesh_adj_off[s]; h.adj[s] = m.mesh_adj[s]; }
+    for (int s = 0; s < NMESH; s++) { h.vert[s] = m.mesh_vert[s]; h.nvert[s] = m.mesh_nvert[s]; h.nvert_pad[s] = m.mesh_nvert_pad[s]; h.adj_off[s] = m.mesh_adj_off[s]; h.adj[s] = m.mesh_adj[s]; }
     hulls_set_pairs(m, h);
     static thread_local std::vector<PairRec<T>> table;
     table.assign(NPAIR_MAX, PairRec<T>{});

@@ -12,11 +12,12 @@ CSRC = Path(__file__).resolve().parents[1] / "kinovagrasping_amd" / "csrc"
 dp = C.POINTER(C.c_double)
 
 
-def lanecheck_lib():
-    so, src = HERE / "libks_lanecheck.so", HERE / "ks_lanecheck.cpp"
+def lanecheck_lib(multi_geom: bool = False):
+    """multi_geom: the kernel source compiled with -DKS_MULTI_GEOM (the topology capacities of libkinova_sim_mg.so)"""
+    so, src = HERE / ("libks_lanecheck_mg.so" if multi_geom else "libks_lanecheck.so"), HERE / "ks_lanecheck.cpp"
     deps = [src] + sorted(CSRC.glob("*.h"))
     if not so.exists() or any(d.stat().st_mtime > so.stat().st_mtime for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(so), str(src)])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared"] + (["-DKS_MULTI_GEOM"] if multi_geom else []) + ["-o", str(so), str(src)])
     L = C.CDLL(str(so))
     L.lc_create.restype = C.c_void_p
     L.lc_create.argtypes = [C.c_char_p, C.c_size_t]
@@ -34,10 +35,10 @@ def P(a):
 class Lane:
     """one lane of the kernel source on the CPU, fp32 or fp64"""
 
-    def __init__(self, blob: bytes, prec: int, iters: int = SOLVER_ITERATIONS):
-        self.L = lanecheck_lib()
+    def __init__(self, blob: bytes, prec: int, iters: int = SOLVER_ITERATIONS, multi_geom: bool = False):
+        self.L = lanecheck_lib(multi_geom)
         self.h = self.L.lc_create(blob, len(blob))
-        assert self.h
+        assert self.h, "lc_create failed (see stderr)"
         self.prec, self.iters = prec, iters
 
     def substep(self, qpos, qvel, warm, ctrl, hq):

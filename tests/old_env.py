@@ -64,7 +64,7 @@ def start_qpos(row0):
 def row_from_kinematics(geom_xpos, site_xpos, link7_xpos, jointpos):
     """the 48 recorded columns (kinova_gripper_env_s.py:181-209, state_rep "global") from one forward pass:
     geom_xpos [9, 3], site_xpos [17, 3], link7_xpos [3], jointpos sensors [9] (slide x y z, three proximal, three distal)"""
-    gx, sx, sd = np.asarray(geom_xpos).reshape(9, 3), np.asarray(site_xpos).reshape(17, 3), np.asarray(jointpos)
+    gx, sx, sd = np.asarray(geom_xpos).reshape(-1, 3), np.asarray(site_xpos).reshape(17, 3), np.asarray(jointpos)
     obj = gx[8]
     dists = []
     for i in _SITE_IDX:                                                      # _get_finger_obj_dist, :210-224

@@ -74,7 +74,7 @@ def run_batch(shape, q0, hq, actions, n_sub, workers=32):
         if k % 15 == 0:
             a = actions[k // 15]
             for i, o in enumerate(orc):           # the env layer's action -> ctrl map (hand rotation is constant: same for both sides)
-                ctrl[:, i] = ko.env_ctrl(o.view("geom_xpos").reshape(9, 3)[1], o.view("geom_xmat").reshape(9, 9)[1], a[:, i])[2]
+                ctrl[:, i] = ko.env_ctrl(o.view("geom_xpos").reshape(-1, 3)[1], o.view("geom_xmat").reshape(-1, 9)[1], a[:, i])[2]
             ctrl_t = torch.as_tensor(ctrl)
         sim.substep(ctrl_t)
         res = list(pool.map(ostep, range(n)))

@@ -42,8 +42,8 @@ def scenario(args):
     out = dict(ddist=[], dang=[], dpos=[], only_a=0, only_b=0, both=0, drift=[])
     for t in range(22):
         a = np.array([0.0, 0.6, 0.5, 0.7]) if t < 14 else np.array([0.6, 0.5, 0.5, 0.5])
-        ctrl_a = ko.env_ctrl(A.view("geom_xpos").reshape(9, 3)[1], A.view("geom_xmat").reshape(9, 9)[1], a)[2]
-        ctrl_c = ko.env_ctrl(Cc.view("geom_xpos").reshape(9, 3)[1], Cc.view("geom_xmat").reshape(9, 9)[1], a)[2]
+        ctrl_a = ko.env_ctrl(A.view("geom_xpos").reshape(-1, 3)[1], A.view("geom_xmat").reshape(-1, 9)[1], a)[2]
+        ctrl_c = ko.env_ctrl(Cc.view("geom_xpos").reshape(-1, 3)[1], Cc.view("geom_xmat").reshape(-1, 9)[1], a)[2]
         for _ in range(15):
             B.set_state(A.view("qpos").copy(), A.view("qvel").copy(), A.view("qacc_warmstart").copy())
             B.view("ctrl")[:] = ctrl_a

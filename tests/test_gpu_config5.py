@@ -163,7 +163,7 @@ def test_vec_env_mixed_objects_and_reference_accessors(tmp_path):
         q0 = np.zeros(16); q0[9:12] = env.get_obj_coords()[e]; q0[12] = 1
         q0[0:3] = scenarios.hand_slide_offsets(env.get_orientation()[e], env.get_random_shape()[e])     # the env's default: "pose"
         ob = o.env_reset(q0)
-        Tfw_o = ko.env_ctrl(o.view("geom_xpos").reshape(9, 3)[1], o.view("geom_xmat").reshape(9, 9)[1], np.zeros(4))[0]
+        Tfw_o = ko.env_ctrl(o.view("geom_xpos").reshape(-1, 3)[1], o.view("geom_xmat").reshape(-1, 9)[1], np.zeros(4))[0]
         np.testing.assert_allclose(T[e], Tfw_o, rtol=0, atol=1e-7)             # the slide positions come back from the fp32 state
         np.testing.assert_allclose(obs[e].double().cpu().numpy(), ob, rtol=2e-4, atol=2e-5)
     # the objects really differ per env: the object-size slots of the observation follow the env's shape

@@ -1,0 +1,152 @@
+"""GPU parity of the MULTI-GEOM objects (the reference's Bottle / TBottle / Bowl / RBowl models: `object` plus jointless child bodies
+welded to it, kinova_description/j2s7s300_end_effector_v1_sbottle.xml:158-186 and siblings) - the HIP kernels of
+libkinova_sim_mg.so (the simulator C ABI compiled with the multi-geom capacities, csrc/ks_model.h) against the fp64 CPU oracle.
+
+The ladder is the one of the primitive objects: (1) one mj_step from the oracle's own states, teacher forced, through the whole of
+a scripted grasp (plane contacts of the pieces, finger-piece hull pairs, lift): fp64 kernels <= 1e-9, fp32 median <= 1e-7;
+(2) whole env.step()s - 15 substeps, the 17 rangefinders over all pieces' triangles, the 82-d observation, reward and done -
+against the oracle's env_step; (3) a single-geom object inside the same context (the multi-geom library holds both).
+
+Where the objects are: the reference's STL pieces carry their CAD origin (the short bottle's centre of mass sits 0.19 m from the
+body origin), so the scripted grasps below place the MAIN piece's centre where a cube would start instead of using the start tables."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ko_py as ko
+from kinovagrasping_amd import model_compiler as mc, scenarios
+from kinovagrasping_amd.sim import SOLVER_ITERATIONS
+
+pytestmark = pytest.mark.gpu
+SHAPES = ["BottleS", "TBottleM", "BowlS", "RBowlB"]
+
+
+def _sim(*a, **k):
+    from kinovagrasping_amd.sim import KinovaSim
+    return KinovaSim(*a, **k)
+
+
+def in_hand_start(shape, z=0.0):
+    """qpos0 [16] with the centre of the geom named `object` above the world origin (where the hand closes), the body at height z"""
+    M = mc.read_blob(scenarios.model_blob(shape))
+    q = np.zeros(16)
+    q[12] = 1.0
+    q[9:12] = -M["geom_pos"][8] * np.array([1.0, 1.0, 0.0])
+    q[11] = z
+    return q
+
+
+def oracle_grasp(shape, n_sub=320, iters=SOLVER_ITERATIONS):
+    m = ko.OracleModel(scenarios.model_blob(shape))
+    hq = scenarios.hand_quat_for("normal")
+    s = ko.OracleSim(m, hq, solver_iterations=iters)
+    s.s.rays_enabled = 0
+    s.set_state(in_hand_start(shape))
+    s.forward()
+    ctrl = np.zeros(9); ctrl[6:9] = 0.6
+    rec = []
+    for i in range(n_sub):
+        if i == 200:
+            ctrl[4] = 0.4
+        before = (s.view("qpos").copy(), s.view("qvel").copy(), s.view("qacc_warmstart").copy())
+        s.step(ctrl)
+        rec.append((before, ctrl.copy(), (s.view("qpos").copy(), s.view("qvel").copy()), s.s.ncon, sorted({(c["geom1"], c["geom2"]) for c in s.contacts()})))
+    return hq, rec
+
+
+def teacher_forced(shape, precision, hq, rec):
+    n = len(rec)
+    sim = _sim(n, shape, precision=precision)
+    assert sim.multi_geom
+    q0 = np.stack([r[0][0] for r in rec], 1)
+    sim.reset(torch.as_tensor(q0), torch.as_tensor(np.repeat(hq[:, None], n, 1)))
+    sim.set_state(torch.as_tensor(q0), torch.as_tensor(np.stack([r[0][1] for r in rec], 1)), torch.as_tensor(np.stack([r[0][2] for r in rec], 1)))
+    sim.substep(torch.as_tensor(np.stack([r[1] for r in rec], 1)))
+    st = sim.get_state()
+    torch.cuda.synchronize()
+    eq = np.abs(st["qpos"].double().cpu().numpy() - np.stack([r[2][0] for r in rec], 1)).max(0)
+    ev = np.abs(st["qvel"].double().cpu().numpy() - np.stack([r[2][1] for r in rec], 1)).max(0)
+    ncon, status = st["ncon"].cpu().numpy(), st["status"].cpu().numpy()
+    sim.close()
+    return eq, ev, ncon, np.array([r[3] for r in rec]), status
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_multi_geom_one_step_matches_oracle(shape):
+    hq, rec = oracle_grasp(shape)
+    pairs = sorted({p for r in rec for p in r[4]})
+    assert any(b > 8 for a, b in pairs), "the scripted grasp must touch welded pieces (geoms 9..)"
+    eq, ev, ncon, onc, status = teacher_forced(shape, 64, hq, rec)
+    print(f"{shape}: contact pairs seen {pairs}; fp64 one-step |dqpos| max {eq.max():.2e}, |dqvel| max {ev.max():.2e}")
+    assert (status == 0).all() and (ncon == onc).all()
+    assert eq.max() < 1e-9 and ev.max() < 1e-7
+    eq, ev, ncon, onc, status = teacher_forced(shape, 32, hq, rec)
+    print(f"{shape}: fp32 one-step |dqpos| median {np.median(eq):.2e} p95 {np.percentile(eq, 95):.2e} max {eq.max():.2e}; contact-count mismatches {int((ncon != onc).sum())}/{len(onc)}")
+    assert (status == 0).all()
+    assert np.median(eq) <= 2e-7 and np.percentile(eq, 90) <= 2e-6 and eq.max() <= 3e-3
+    assert (ncon != onc).mean() <= 0.03
+
+
+@pytest.mark.parametrize("shape,precision,tol", [("BottleS", 64, 1e-8), ("RBowlS", 64, 1e-8), ("TBottleS", 32, 2e-3), ("BowlM", 32, 2e-3)])
+def test_multi_geom_env_steps_rays_and_observation(shape, precision, tol):
+    """reset + 6 env.step()s of a closing-and-lifting action stream: observation (incl. the 17 rangefinder slots, which see every piece),
+    reward and done of every step against the oracle's env_step"""
+    hq = scenarios.hand_quat_for("normal")
+    q0 = in_hand_start(shape)
+    m = ko.OracleModel(scenarios.model_blob(shape))
+    o = ko.OracleSim(m, hq, solver_iterations=SOLVER_ITERATIONS)
+    sim = _sim(2, shape, precision=precision)
+    obs = sim.reset(torch.as_tensor(np.stack([q0, q0], 1)), torch.as_tensor(np.repeat(hq[:, None], 2, 1))).double().cpu().numpy()
+    ref = o.env_reset(q0)
+    worst = np.abs(obs[0] - ref).max()
+    assert np.abs(obs[0] - ref).max() < max(tol * 1e-2, 1e-9 if precision == 64 else 2e-5), np.abs(obs[0] - ref).max()
+    for t in range(6):
+        a = np.array([0.0, 0.6, 0.6, 0.6]) if t < 4 else np.array([0.6, 0.6, 0.6, 0.6])
+        ob, rew, done, info = sim.step(torch.as_tensor(np.stack([a, a], 1)))
+        ro, rr, rd, ri = o.env_step(a)
+        got = ob.double().cpu().numpy()
+        assert np.array_equal(got[0], got[1])                       # two envs, same inputs: identical
+        err = np.abs(got[0] - ro)
+        worst = max(worst, err.max())
+        assert err.max() < tol, (t, int(err.argmax()), err.max())
+        assert float(rew[0]) == rr and bool(done[0] & 1) == rd
+    st = sim.get_state()
+    assert (st["status"].cpu().numpy() == 0).all()
+    print(f"{shape} fp{precision}: worst observation error over reset + 6 env-steps {worst:.2e}")
+    sim.close()
+
+
+def test_single_geom_object_in_the_multi_geom_library():
+    """a context of the multi-geom library holds single-geom objects too (mixed batches of a curriculum stage): CubeS next to BottleS,
+    each env against its own oracle"""
+    hq = scenarios.hand_quat_for("normal")
+    shapes = ["CubeS", "BottleS"]
+    q = np.stack([scenarios.config1_state("CubeS")[0], in_hand_start("BottleS")], 1)
+    sim = _sim(2, shapes, precision=64)
+    assert sim.multi_geom
+    obs = sim.reset(torch.as_tensor(q), torch.as_tensor(np.repeat(hq[:, None], 2, 1)), object_id=torch.tensor([0, 1], dtype=torch.int32)).double().cpu().numpy()
+    oracles = [ko.OracleSim(ko.OracleModel(scenarios.model_blob(s)), hq, solver_iterations=SOLVER_ITERATIONS) for s in shapes]
+    for i, o in enumerate(oracles):
+        assert np.abs(obs[i] - o.env_reset(q[:, i].copy())).max() < 1e-9
+    for t in range(4):
+        a = np.array([0.0, 0.6, 0.6, 0.6])
+        ob = sim.step(torch.as_tensor(np.stack([a, a], 1)))[0].double().cpu().numpy()
+        for i, o in enumerate(oracles):
+            ro = o.env_step(a)[0]
+            assert np.abs(ob[i] - ro).max() < 1e-8, (t, shapes[i], np.abs(ob[i] - ro).max())
+    sim.close()
+
+
+def test_multi_geom_blob_is_refused_by_the_standard_library():
+    from kinovagrasping_amd import sim as ks
+    import ctypes as C
+    L = ks.load_library()
+    cfg = ks.KsConfig()
+    L.ks_default_config(C.byref(cfg))
+    cfg.n_envs = 4
+    ctx = C.c_void_p()
+    assert L.ks_create(C.byref(cfg), 0, C.byref(ctx)) == 0
+    blob = scenarios.model_blob("BottleS")
+    rc = L.ks_load_model(ctx, blob, len(blob))
+    assert rc != 0 and b"multi-geom" in L.ks_last_error(ctx)
+    L.ks_destroy(ctx)

@@ -55,7 +55,7 @@ def pose_start(shape, orientation, row):
 
 def ctrl_of(o, action):
     """the 9 controls the env layer derives from a 4-d action at the oracle's current palm pose (ENV:1495-1535)"""
-    return ko.env_ctrl(o.view("geom_xpos").reshape(9, 3)[1], o.view("geom_xmat").reshape(9, 9)[1], action)[2]
+    return ko.env_ctrl(o.view("geom_xpos").reshape(-1, 3)[1], o.view("geom_xmat").reshape(-1, 9)[1], action)[2]
 
 
 def oracle_substep_records(model, shape, orientation, row, n_env_steps=22):

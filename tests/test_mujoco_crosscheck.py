@@ -86,7 +86,7 @@ def test_config1_against_real_mujoco_reports_first_divergence():
     mujoco.mj_forward(m, d)
     first = None
     for t in range(30):
-        ctrl = ko.env_ctrl(o.view("geom_xpos").reshape(9, 3)[1], o.view("geom_xmat").reshape(9, 9)[1], acts[t].astype(np.float64))[2]
+        ctrl = ko.env_ctrl(o.view("geom_xpos").reshape(-1, 3)[1], o.view("geom_xmat").reshape(-1, 9)[1], acts[t].astype(np.float64))[2]
         d.ctrl[:] = ctrl
         for k in range(15):
             mujoco.mj_step(m, d)

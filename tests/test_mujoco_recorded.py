@@ -174,7 +174,7 @@ def test_box_released_inside_the_floor_recovers_as_in_mujoco(rec):
         z = []
         for k in range(12):
             s.step(np.zeros(9))
-            z.append(s.view("geom_xpos").reshape(9, 3)[8, 2])
+            z.append(s.view("geom_xpos").reshape(-1, 3)[8, 2])
         return np.array(z)[[3, 7, 11]]          # forward pass of the row's 4th substep
 
     assert np.abs(heights() - pf2[1:4, 23]).max() < 1e-13
