@@ -103,8 +103,10 @@ def run_stage(plan, policy, n_envs: int = 1024, rounds: int = 10, updates_per_ro
     The reference runs max_episode episodes one at a time, objects in Latin-square order, and 100 updates at the end
     of each (main_DDPGfD.py:466-486).  Here a ROUND is one episode of every env (the envs are split over the stage's
     shapes, orientation classes drawn per env by the reference's rule) followed by `updates_per_round` updates.
-    Shapes without a compiled asset (the reference's Bottle / Bowl / TBottle meshes are not among the README's 14
-    objects) are listed in the result under `skipped_shapes`.  Returns a dict (num_success, num_total, paths, ...)."""
+    Every shape key of the reference's stages has a compiled asset since round 4 - the multi-geom Bottle / Bowl / TBottle / RBowl
+    objects included (a stage that holds one runs on libkinova_sim_mg.so, sim.KinovaSim picks it) -; a key without one would be
+    listed under `skipped_shapes`.  Where the reference has no start-coordinate file for a (shape, orientation) - Normal/BowlS - the
+    start is drawn by the reference's empty-file rule (scenarios.fallback_start).  Returns a dict (num_success, num_total, paths, ...)."""
     import torch
 
     from .evaluate import eval_policy
@@ -113,8 +115,9 @@ def run_stage(plan, policy, n_envs: int = 1024, rounds: int = 10, updates_per_ro
     from .rollout import RolloutEngine
 
     dirs = plan["dirs"]
-    shapes = [s for s in plan["requested_shapes"] if s in scenarios.SHAPES]
-    skipped = [s for s in plan["requested_shapes"] if s not in scenarios.SHAPES]
+    known = scenarios.SHAPES + scenarios.MULTI_GEOM_SHAPES
+    shapes = [s for s in plan["requested_shapes"] if s in known]
+    skipped = [s for s in plan["requested_shapes"] if s not in known]
     if not shapes:
         raise ValueError(f"none of the stage's shapes {plan['requested_shapes']} has a compiled asset")
     rng = np.random.RandomState(seed)
@@ -141,8 +144,11 @@ def run_stage(plan, policy, n_envs: int = 1024, rounds: int = 10, updates_per_ro
         for e in range(count):
             shape = the_sim.shapes[shape_ids[e]]
             o = scenarios.select_orientation(shape, plan["requested_orientation"], rng) if plan["requested_orientation"] == "random" else "normal"
-            tab = scenarios.start_coord_table(shape, o)
-            q[9:12, e] = tab[rng.randint(0, len(tab))]
+            if scenarios.has_start_table(shape, o):
+                tab = scenarios.start_coord_table(shape, o)
+                q[9:12, e] = tab[rng.randint(0, len(tab))]
+            else:
+                q[9:12, e] = scenarios.fallback_start(shape, o, rng)
             hq[:, e] = scenarios.hand_quat_for(o)
             classes.append(o)
         return the_sim.reset(torch.as_tensor(q), torch.as_tensor(hq)), classes

@@ -12,6 +12,9 @@ ASSETS = Path(__file__).resolve().parent / "assets"
 # hand orientation classes, kinova_gripper_env.py:1267-1273 (all non-default xml files)
 ORIENTATION_EULER = {"normal": (-1.57, 0.0, -1.57), "rotated": (-1.2, 0.0, 0.0), "top": (0.0, 0.0, 0.0)}
 SHAPES = [s + z for s in ["Cube", "Cylinder", "Cube45", "Cone1", "Cone2", "Vase1", "Vase2"] for z in "SB"]  # README.md:59
+# the multi-geom objects of the experiment stages (main_DDPGfD.py:1270-1281; shape keys of kinova_gripper_env.py:189-208): `object` plus
+# welded pieces.  They run on libkinova_sim_mg.so (sim.KinovaSim picks the library from the model blob).
+MULTI_GEOM_SHAPES = [s + z for s in ["Bottle", "Bowl", "TBottle", "RBowl"] for z in "SMB"]
 
 _tables = None
 
@@ -28,6 +31,32 @@ def start_coord_table(shape: str, orientation: str = "normal") -> np.ndarray:
     if _tables is None:
         _tables = np.load(ASSETS / "start_coords_no_noise_train.npz")
     return _tables[f"{orientation.capitalize()}/{shape}"].astype(np.float64)
+
+
+def has_start_table(shape: str, orientation: str = "normal") -> bool:
+    global _tables
+    if _tables is None:
+        _tables = np.load(ASSETS / "start_coords_no_noise_train.npz")
+    return f"{orientation.capitalize()}/{shape}" in _tables.files
+
+
+def fallback_start(shape: str, orientation: str, rng=np.random) -> np.ndarray:
+    """Object start (x, y, z) where the reference has NO coordinate file for (shape, orientation) - e.g. Normal/BowlS, which the
+    `shapes` stage asks for: KinovaGripper_Env.randomize_initial_pos_data_collection (kinova_gripper_env.py:821-849), the
+    reference's own rule for an EMPTY file (determine_obj_hand_coords, :1243-1249; for a MISSING file its check_obj_file_empty
+    returns False and the open() that follows raises - the stage cannot run there at all).  size = _get_obj_size(): 'rotated'
+    starts at the origin, every other class ('normal', 'top' - the old 'side' branch is never selected by name) on a disc of
+    radius size[0] / 2; z = size[2] / 2."""
+    from .model_compiler import read_blob
+    so = read_blob(ASSETS / f"{shape}.ksm")["obj_size_obs"]
+    size = np.array([so[0], so[1], so[2] / 2.0])                 # the observation stores [s0, s1, 2 s2] (kinova_gripper_env.py:529)
+    if orientation == "rotated":
+        x, y = 0.0, 0.0
+    else:
+        theta = rng.uniform(low=0, high=2 * np.pi)
+        r = rng.uniform(low=0, high=size[0] / 2)
+        x, y = np.sin(theta) * r, np.cos(theta) * r
+    return np.array([x, y, size[-1] / 2])
 
 
 def hand_quat_for(orientation: str) -> np.ndarray:

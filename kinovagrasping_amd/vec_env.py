@@ -7,7 +7,7 @@ step(action) -> (obs, reward, done, info) with info keys finger_reward / grasp_r
 get_obj_coords / get_orientation (main_DDPGfD.py:167,253), Tfw (main_DDPGfD.py:170,406), get_orientation_idx
 (main_DDPGfD.py:411), get_coords_filename (main_DDPGfD.py:161), Generate_Latin_Square / check_obj_file_empty
 (main_DDPGfD.py:387-388).  Batched: every quantity gains a leading env dimension and lives on the GPU as a torch tensor;
-the compute is libkinova_sim.so.  With a LIST of shapes the env holds all those objects in one simulator context and
+the compute is libkinova_sim.so (libkinova_sim_mg.so when a multi-geom object - Bottle / TBottle / Bowl / RBowl - is among the shapes).  With a LIST of shapes the env holds all those objects in one simulator context and
 every reset picks each env's object the way the reference's reset() does per episode (select_object, ENV:986-1005).
 """
 from __future__ import annotations
@@ -182,11 +182,15 @@ class KinovaGripperVecEnv:
             if start_pos is not None:
                 q[9:12, k] = np.asarray(start_pos)[k][:3]
                 self.orientation_idx[e] = -1
-            else:
+            elif scenarios.has_start_table(shape, o):
                 tab = scenarios.start_coord_table(shape, o)
                 row = self.np_random.randint(0, len(tab))
                 q[9:12, k] = tab[row]
                 self.orientation_idx[e] = row
+            else:
+                # no coordinate file for this (shape, orientation) in the reference (Normal/BowlS ...): its empty-file rule (ENV:1243-1249, 821-849)
+                q[9:12, k] = scenarios.fallback_start(shape, o, self.np_random)
+                self.orientation_idx[e] = -1
             q[0:3, k] = scenarios.hand_slide_offsets(o, shape, self.hand_offsets)
             self.obj_coords[e] = q[9:12, k]
             self.hand_quat[:, e] = hq[:, k]

@@ -150,3 +150,61 @@ def test_multi_geom_blob_is_refused_by_the_standard_library():
     rc = L.ks_load_model(ctx, blob, len(blob))
     assert rc != 0 and b"multi-geom" in L.ks_last_error(ctx)
     L.ks_destroy(ctx)
+
+
+@pytest.mark.parametrize("shapes,n", [(["BottleS"], 208), (["CubeS", "BowlS", "TBottleB"], 320)])
+def test_multi_geom_free_running_rollout_equals_the_lock_step_calls(shapes, n):
+    """the persistent rollout kernel of the multi-geom library (ks_rollout: in-kernel actor, 15 substeps, rays over all pieces,
+    observation, replay write) against the three lock-step calls per env-step: same trajectories, same stored episodes, bit for bit"""
+    from kinovagrasping_amd.ddpgfd import DDPGfD
+    from kinovagrasping_amd.pipeline import AsyncTrainer
+    from kinovagrasping_amd.replay import DeviceEpisodeReplay
+    from kinovagrasping_amd.rollout import RolloutEngine
+    import warnings
+    horizon, per, chunks = 12, 9, 4
+
+    def setup():
+        sim = _sim(n, shapes if len(shapes) > 1 else shapes[0], horizon=horizon, auto_reset=True)
+        assert sim.multi_geom
+        oid = (np.arange(n) * len(shapes) // n).astype(np.int32)
+        q = np.zeros((16, n)); q[12] = 1
+        for e in range(n):
+            sh = shapes[oid[e]]
+            q[:, e] = in_hand_start(sh) if sh in scenarios.MULTI_GEOM_SHAPES else scenarios.config1_state(sh)[0]
+            q[9, e] += 0.02 * np.sin(1.7 * e); q[10, e] += 0.01 * np.cos(2.3 * e)
+        hq = np.repeat(scenarios.hand_quat_for("normal")[:, None], n, 1)
+        obs0 = sim.reset(torch.as_tensor(q), torch.as_tensor(hq), object_id=oid if len(shapes) > 1 else None)
+        torch.manual_seed(3)
+        policy = DDPGfD(82, 4, 0.8, 5, batch_size=64, hidden=(256, 256), device=sim.device)
+        with torch.no_grad():
+            policy.actor.l3.bias.add_(torch.tensor([-6.0, 1.0, 0.8, 1.2], device=sim.device))
+        replay = DeviceEpisodeReplay(n, capacity=8 * n, horizon=horizon, device=sim.device)
+        eng = RolloutEngine(sim, policy, replay, expl_noise=0.1)
+        eng.start(obs0)
+        return sim, policy, replay, eng
+
+    def ring(replay):
+        key = lambda e: (len(e["reward"]), e["state"].tobytes(), e["action"].tobytes(), e["next_state"].tobytes(), e["reward"].tobytes(), e["not_done"].tobytes())
+        return sorted(key(e) for e in replay.host_episodes())
+
+    sim, policy, replay, eng = setup()
+    for _ in range(chunks * per):
+        eng.step()
+    torch.cuda.synchronize()
+    ref = dict(qpos=sim.get_state()["qpos"].clone(), status=sim.get_state()["status"].clone(), eps=ring(replay), count=replay.count, obs=eng.obs.clone())
+    sim.close()
+    sim, policy, replay, eng = setup()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        tr = AsyncTrainer(sim, policy, replay, eng, batch_episodes=16)
+    for _ in range(chunks):
+        sim.rollout(per, tr.args)
+        replay.commit_published()
+    torch.cuda.synchronize()
+    st, c = sim.get_state(), tr.counts()
+    print(f"multi-geom free-running {shapes}: {c}, ring {replay.count} episodes; lock step ring {ref['count']}")
+    assert c["episodes_dropped"] == 0 and c["episodes_finished"] >= 2 * n
+    assert (st["status"].cpu().numpy() & ~8 == 0).all()
+    assert torch.equal(st["qpos"], ref["qpos"]) and torch.equal(st["status"], ref["status"]) and torch.equal(eng.obs, ref["obs"])
+    assert replay.count == ref["count"] and ring(replay) == ref["eps"]
+    sim.close()

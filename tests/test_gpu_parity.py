@@ -895,11 +895,18 @@ def test_curriculum_stage_runs_and_hands_over_to_the_next(tmp_path):
     assert not torch.equal(fresh.actor.l1.weight, w_saved)
     p4 = curriculum.experiment_plan(4, root=tmp_path)
     assert p4["dirs"]["prev_policy_dir"] == p1["dirs"]["policy_dir"]
-    r4 = curriculum.run_stage(p4, fresh, n_envs=96, rounds=1, updates_per_round=1, save=False)
-    # Bottle / Bowl / TBottle have no compiled asset; the other 8 size x shape keys run, in all three orientation classes
-    assert r4["shapes"] == ["CubeS", "CylinderS", "Cube45S", "Vase2S", "CubeB", "CylinderB", "Cube45B", "Vase2B"]
-    assert sorted(r4["skipped_shapes"]) == ["BottleB", "BottleS", "BowlB", "BowlS", "TBottleB", "TBottleS"]
+    r4 = curriculum.run_stage(p4, fresh, n_envs=112, rounds=1, updates_per_round=1, save=False)
+    # all 14 size x shape keys of the stage run, the multi-geom Bottle / Bowl / TBottle objects included (one context of the
+    # multi-geom library holds all of them), in all three orientation classes
+    assert r4["shapes"] == ["CubeS", "CylinderS", "Cube45S", "Vase2S", "BottleS", "BowlS", "TBottleS", "CubeB", "CylinderB", "Cube45B", "Vase2B", "BottleB", "BowlB",
+                            "TBottleB"]
+    assert r4["skipped_shapes"] == [] and r4["num_total"] == 112
     assert set(r4["orientation_counts"]) == {"normal", "rotated", "top"} and r4["updates"] == 1
+    # a test-mode stage (TEST_SHAPES: Vase1, RBowl) on the multi-geom library: RBowl never takes the 'normal' class
+    pt = curriculum.experiment_plan(3, exp_mode="test", root=tmp_path)
+    pt["requested_shapes"] = ["Vase1S", "RBowlS"]
+    rt = curriculum.run_stage(pt, fresh, n_envs=32, rounds=1, updates_per_round=1, save=False, load_previous=False)
+    assert rt["shapes"] == ["Vase1S", "RBowlS"] and rt["skipped_shapes"] == [] and rt["num_total"] == 32
 
 
 @pytest.mark.parametrize("split", ["0", "2", "4", None])
