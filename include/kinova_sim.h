@@ -46,7 +46,8 @@ extern "C" {
 #define KS_NACT 4
 #define KS_NOBS 82
 #define KS_NINFO 3
-#define KS_NCON_MAX 24
+#define KS_NCON_MAX 24      /* libkinova_sim.so; the multi-geom build (libkinova_sim_mg.so) keeps KS_NCON_MAX_MG */
+#define KS_NCON_MAX_MG 40
 #define KS_CONTACT_STRIDE 20
 
 typedef enum {

@@ -11,6 +11,7 @@ import torch
 from . import build as _build
 
 NQ, NV, NACT, NOBS, NINFO, NCON_MAX, CONTACT_STRIDE = 16, 15, 4, 82, 3, 24, 20
+NCON_MAX_MG = 40
 # Newton iteration cap per substep (ks_config.solver_iterations).  MuJoCo's own cap is 100 with an early exit; the kernels exit
 # as soon as the step is below 1e-5 of the solution or crossed no constraint row.  Over 13 200 grasp / lift substeps (3 hand
 # poses, 14 shapes) no problem needs more than 10 iterations, while a cap of 6 - rounds 1 and 2 - truncated 2.3 % of the
@@ -160,6 +161,7 @@ class KinovaSim:
         # capacities; it holds single-geom objects as well (slower than the standard library: hull tables in L2, not LDS)
         self.multi_geom = any(blob_is_multi_geom(b) for b in blobs)
         self.lib = load_library(multi_geom=self.multi_geom)
+        self.ncon_max = NCON_MAX_MG if self.multi_geom else NCON_MAX           # contact records of the parity tap (include/kinova_sim.h)
         self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))
         self.n_envs = int(n_envs)
         self.dtype = torch.float32 if precision == 32 else torch.float64
@@ -260,11 +262,11 @@ class KinovaSim:
         out = dict(qpos=torch.empty((NQ, N), dtype=dt, device=dev), qvel=torch.empty((NV, N), dtype=dt, device=dev),
                    qacc_warmstart=torch.empty((NV, N), dtype=dt, device=dev),
                    ncon=torch.empty(N, dtype=torch.int32, device=dev), status=torch.empty(N, dtype=torch.int32, device=dev))
-        con = torch.empty((NCON_MAX * CONTACT_STRIDE, N), dtype=dt, device=dev) if contacts else None
+        con = torch.empty((self.ncon_max * CONTACT_STRIDE, N), dtype=dt, device=dev) if contacts else None
         self._check(self.lib.ks_get_state(self.ctx, _ptr(out["qpos"]), _ptr(out["qvel"]), _ptr(out["qacc_warmstart"]), _ptr(con),
                                           _ptr(out["ncon"]), _ptr(out["status"]), self._stream()))
         if contacts:
-            out["contact"] = con.view(NCON_MAX, CONTACT_STRIDE, N)
+            out["contact"] = con.view(self.ncon_max, CONTACT_STRIDE, N)
         return out
 
     def set_state(self, qpos=None, qvel=None, qacc_warmstart=None):

@@ -39,7 +39,7 @@ extern "C" {
 #define KO_NSITE 17
 #define KO_NSENSOR 26
 #define KO_NPAIR_MAX 96
-#define KO_NCON_MAX 24
+#define KO_NCON_MAX 40 /* capacity; ko_sim.ncon_max = contacts kept per substep: 24 (nine-geom models), 40 (multi-geom objects) */
 #define KO_NEFC_MAX (3 + 9 + 4 * KO_NCON_MAX)
 #define KO_NOBS 82
 #define KO_NOBS_GLOBAL 74

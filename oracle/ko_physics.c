@@ -1227,7 +1227,7 @@ ko_sim *ko_sim_new(const ko_model *m, const double hand_quat[4]) {
     s->solver = 0;
     s->solver_iterations = 8;
     s->solver_tolerance = 1e-5;
-    s->ncon_max = KO_NCON_MAX;
+    s->ncon_max = m->ngeom > 9 ? 40 : 24; /* = the product kernels' NCON_MAX (csrc/ks_model.h) */
     s->rays_enabled = 1;
     s->qpos[12] = 1.0;
     return s;

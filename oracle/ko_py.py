@@ -10,7 +10,7 @@ import numpy as np
 
 HERE = Path(__file__).resolve().parent
 NQ, NV, NU, NBODY, NGEOM, NSITE, NSENSOR = 16, 15, 9, 10, 17, 17, 26      # NGEOM: capacity (ko.h KO_NGEOM); single-geom objects use the first 9
-NCON_MAX = 24
+NCON_MAX = 40       # capacity (ko.h KO_NCON_MAX); Sim.ncon_max is the number kept: 24, multi-geom objects 40
 NEFC_MAX = 3 + 9 + 4 * NCON_MAX
 NOBS, NOBS_GLOBAL = 82, 74
 d = C.c_double

@@ -122,4 +122,5 @@ int lc_reset_obs(void* h, int prec, double* qpos, double* qvel, double* warm, co
                       : env_step_t<float>(l->f.m, qpos, qvel, warm, hq, nullptr, 0, 0, obs, reward, done, rays, 1);
 }
 int lc_con_stride() { return CON_STRIDE; }
+int lc_ncon_max() { return NCON_MAX; }
 }

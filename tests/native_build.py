@@ -44,10 +44,11 @@ class Lane:
     def substep(self, qpos, qvel, warm, ctrl, hq):
         a, b, c = (np.array(x, dtype=np.float64) for x in (qpos, qvel, warm))
         nc = C.c_int(0)
-        con = np.zeros(24 * 20)
+        ncm = self.L.lc_ncon_max()
+        con = np.zeros(ncm * 20)
         st = self.L.lc_substep(self.h, self.prec, P(a), P(b), P(c), P(np.array(ctrl, dtype=np.float64)), P(np.array(hq, dtype=np.float64)),
                                self.iters, C.byref(nc), P(con))
-        return a, b, c, nc.value, con.reshape(24, 20), st
+        return a, b, c, nc.value, con.reshape(ncm, 20), st
 
     def env_step(self, qpos, qvel, warm, hq, act, frame_skip=15):
         a, b, c = (np.array(x, dtype=np.float64) for x in (qpos, qvel, warm))
