@@ -31,6 +31,11 @@
  *   - One context per GPU per process; a context is not thread safe.
  *   - Return value: 0 on success, negative ks_status otherwise; ks_last_error gives a message.
  *   - There is NO CPU path: ks_create fails when no HIP device is available.
+ *   - Two builds of this ABI exist.  libkinova_sim.so: the reference's fixed topology (ground, 7 hand geoms, ONE object geom) - every
+ *     single-geom object, the fast path.  libkinova_sim_mg.so: the same sources with the capacities of the multi-geom objects (the
+ *     Bottle / TBottle / Bowl / RBowl models, `object` + welded child bodies: kinova_description/j2s7s300_end_effector_v1_sbottle.xml
+ *     :158-186, shape keys ENV:189-208); it also loads single-geom models (a curriculum stage mixes both), more slowly.  A caller binds
+ *     the library its models need: ks_load_model of libkinova_sim.so refuses a multi-geom blob with a message that says so.
  */
 #ifndef KINOVA_SIM_H
 #define KINOVA_SIM_H
