@@ -62,9 +62,14 @@ constexpr int CON_STRIDE = 20;
 // collision staging: contacts are detected pair by pair into per-pair slots of (pos3, normal3, dist, mu,
 // bodies) records - 4 slots for a plane pair, 1 for a hull pair, assigned in pair order - and then merged
 // in pair order with the per-pair counts in SCR_PC.
-constexpr int NSTAGE = MULTI_GEOM ? 160 : 80, STAGE_REC = 9, STAGE_WORDS = NSTAGE * STAGE_REC;   // 80 x 9 = 720 = 15 cached bases (multi-geom: 16 plane pairs x 4 + 78 hull pairs)
+// The multi-geom build (16 plane pairs x 4 + 78 hull pairs = 142 static slots = 5 KB per env) hands the slots out per substep to the pairs
+// that passed the culls instead (DYNAMIC_SLOTS: a pair's slot of this substep is kept in SCR_SLOT), so that 16 env blocks still fit a
+// compute unit's LDS beside the 96 pair records.
+constexpr bool DYNAMIC_SLOTS = MULTI_GEOM;
+constexpr int NSTAGE = MULTI_GEOM ? 72 : 80, STAGE_REC = 9, STAGE_WORDS = NSTAGE * STAGE_REC;   // 80 x 9 = 720 = 15 cached bases
 constexpr int SCR_PC = SCR_CON + NCON_MAX * CON_STRIDE;
-constexpr int SCR_STAGE = SCR_PC + NPAIR_MAX;
+constexpr int SCR_SLOT = SCR_PC + NPAIR_MAX;                                   // [NPAIR_MAX] (dynamic slots only)
+constexpr int SCR_STAGE = SCR_SLOT + (DYNAMIC_SLOTS ? NPAIR_MAX : 0);
 // smooth dynamics of the substep, written by the role lanes (fingers, object, slides) and read by row:
 // hand mass matrix 9x9, object mass matrix 6x6, qfrc_smooth (slide entries without the finger links' bias),
 // per-finger bias on the three slides
@@ -1330,11 +1335,11 @@ KS_HD bool plane_may_touch(S scr, KS_LDS const PairRec<T>* prp) {
 // its first pass found within the margin).
 // Returns the number of contacts staged at record `slot`.
 template <typename T, typename S, int SUBS>
-KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* prp, float* prof = nullptr) {
+KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* prp, int slot, float* prof = nullptr) {
     KS_T0
     KS_LDS const PairRec<T>& pr = *prp;
     const T PLANE_MESH_TOL = T(0.3);
-    const int g2 = pr.g2, slot = pr.slot, pi = (pr.obj_hand >> 12) & PAIR_INDEX_MASK;
+    const int g2 = pr.g2, pi = (pr.obj_hand >> 12) & PAIR_INDEX_MASK;
     const T margin = pr.margin, mu = pr.mu, rbound = pr.rbound2;
     const T size[3] = {pr.size2[0], pr.size2[1], pr.size2[2]};
     KS_TAB const T* V = pr.V2;
@@ -1546,7 +1551,7 @@ KS_HD bool hull_pair_may_touch(S scr, KS_LDS const PairRec<T>* prp) {
 
 // narrow phase of a hull pair that passed hull_pair_may_touch
 template <typename T, typename S>
-KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S scr, KS_LDS const PairRec<T>* prp, int packed_in, int& h1_out,
+KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S scr, KS_LDS const PairRec<T>* prp, int slot, int packed_in, int& h1_out,
                             int& h2_out, PairWarm* ws, float* prof = nullptr) {
     KS_LDS const PairRec<T>& pr = *prp;
     PairGeo<T> pg;
@@ -1556,7 +1561,7 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
     h1_out = (packed_in >> 3) & PC_HINT_MAX;
     h2_out = (packed_in >> (3 + PC_HINT_BITS)) & PC_HINT_MAX;
     // the whole record first: one burst of LDS reads, one wait
-    const int g1 = pr.g1, g2 = pr.g2, slot = pr.slot, body1 = pr.body1, body2 = pr.body2;
+    const int g1 = pr.g1, g2 = pr.g2, body1 = pr.body1, body2 = pr.body2;
     const int flags = pr.obj_hand;
     const T margin = pr.margin, mu = (flags & 1) ? T(scr(SCR_ENVP + 1)) : pr.mu;
     pg.V1 = pr.V1; pg.n1 = pr.n1; pg.off1 = pr.off1; pg.adj1 = pr.adj1;
@@ -1630,16 +1635,24 @@ KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Tea
         bool pass = false;
         if (k < nplane) {
             const int pi = hu.plane_pi[k];
-            if (pairs[pi].slot + 4 <= NSTAGE) pass = plane_may_touch(scr, pairs + pi);
+            if (DYNAMIC_SLOTS || pairs[pi].slot + 4 <= NSTAGE) pass = plane_may_touch(scr, pairs + pi);
             else status |= ST_CONTACT_OVERFLOW;
             if (!pass) scr(SCR_PC + pi) = T(0);
         }
         live |= team.ballot(pass) << k0;
     }
     KS_TICK(11)
+    int next_slot = 0;                                  // (dynamic slots) first free staging record, team-uniform
     for (unsigned mk = live; mk != 0; mk &= mk - 1) {
         const int pi = hu.plane_pi[kctz(mk)];
-        const int c = collide_plane_hull(scr, team, pairs + pi, prof);
+        int slot = pairs[pi].slot;
+        if constexpr (DYNAMIC_SLOTS) {
+            slot = next_slot;
+            if (slot + 4 > NSTAGE) { status |= ST_CONTACT_OVERFLOW; if (team.sub == 0) scr(SCR_PC + pi) = T(0); continue; }
+            next_slot += 4;
+            if (team.sub == 0) scr(SCR_SLOT + pi) = T(slot);
+        }
+        const int c = collide_plane_hull(scr, team, pairs + pi, slot, prof);
         if (team.sub == 0) scr(SCR_PC + pi) = T(c);
     }
     KS_TICK(8)
@@ -1654,40 +1667,63 @@ KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Tea
         for (int hk = 0; hk < nhull; hk++) {
             const int pi = hu.hull_pi[hk], word = (int)scr(SCR_PC + pi);
             int c = 0, h1 = (word >> 3) & PC_HINT_MAX, h2 = (word >> (3 + PC_HINT_BITS)) & PC_HINT_MAX;
-            if (pairs[pi].slot + 1 > NSTAGE) status |= ST_CONTACT_OVERFLOW;
-            else if (hull_pair_may_touch(scr, pairs + pi)) c = collide_hull_hull(m, dirtab, scr, pairs + pi, word, h1, h2, warm ? warm + hk : nullptr, prof);
+            if constexpr (DYNAMIC_SLOTS) {
+                if (hull_pair_may_touch(scr, pairs + pi)) {
+                    if (next_slot + 1 > NSTAGE) status |= ST_CONTACT_OVERFLOW;
+                    else {
+                        scr(SCR_SLOT + pi) = T(next_slot);
+                        c = collide_hull_hull(m, dirtab, scr, pairs + pi, next_slot, word, h1, h2, warm ? warm + hk : nullptr, prof);
+                        next_slot++;
+                    }
+                }
+            } else {
+                if (pairs[pi].slot + 1 > NSTAGE) status |= ST_CONTACT_OVERFLOW;
+                else if (hull_pair_may_touch(scr, pairs + pi)) c = collide_hull_hull(m, dirtab, scr, pairs + pi, pairs[pi].slot, word, h1, h2, warm ? warm + hk : nullptr, prof);
+            }
             scr(SCR_PC + pi) = T(pc_pack(c, h1, h2));
         }
     } else {
-        int pi_[HPL], word_[HPL];
+        int pi_[HPL], word_[HPL], slot_[HPL];
         unsigned todo = 0;
         KS_UNROLL
         for (int r = 0; r < HPL; r++) {
             const int left = nhull - r * SUBS, cnt = left < SUBS ? left : SUBS;           // pairs of this round (<= 0: none)
             const bool have = r == 0 ? team.sub < cnt : team.sub >= SUBS - cnt;
-            pi_[r] = 0; word_[r] = 0;
+            pi_[r] = 0; word_[r] = 0; slot_[r] = 0;
+            bool live_r = false;
             if (have) {
-                bool live_r = false;
                 pi_[r] = hu.hull_pi[r == 0 ? team.sub : r * SUBS + team.sub - (SUBS - cnt)];
                 word_[r] = (int)scr(SCR_PC + pi_[r]);
-                if (pairs[pi_[r]].slot + 1 <= NSTAGE) live_r = hull_pair_may_touch(scr, pairs + pi_[r]);
+                if (DYNAMIC_SLOTS || pairs[pi_[r]].slot + 1 <= NSTAGE) live_r = hull_pair_may_touch(scr, pairs + pi_[r]);
                 else status |= ST_CONTACT_OVERFLOW;
+            }
+            if constexpr (DYNAMIC_SLOTS) {
+                // the pairs that passed the culls take the next free staging records, in (round, lane) order
+                if (left > 0) {                                                         // (team-uniform)
+                    int taken;
+                    slot_[r] = next_slot + team.scan(live_r ? 1 : 0, taken);
+                    next_slot += taken;
+                    if (live_r && slot_[r] + 1 > NSTAGE) { live_r = false; status |= ST_CONTACT_OVERFLOW; }
+                    if (live_r) scr(SCR_SLOT + pi_[r]) = T(slot_[r]);
+                }
+            }
+            if (have) {
                 if (!live_r) scr(SCR_PC + pi_[r]) = T(word_[r] & ~PC_COUNT_MASK);     // no contact, hints kept
                 todo |= live_r ? (1u << r) : 0u;
             }
         }
         // one call site: as many turns as the busiest lane of the wave has live pairs
         while (todo != 0) {
-            int r = 0, pi_r = pi_[0], word_r = word_[0];
-            if constexpr (HPL == 2) { r = (todo & 1u) ? 0 : 1; pi_r = r ? pi_[1] : pi_[0]; word_r = r ? word_[1] : word_[0]; }
+            int r = 0, pi_r = pi_[0], word_r = word_[0], slot_r = slot_[0];
+            if constexpr (HPL == 2) { r = (todo & 1u) ? 0 : 1; pi_r = r ? pi_[1] : pi_[0]; word_r = r ? word_[1] : word_[0]; slot_r = r ? slot_[1] : slot_[0]; }
             else {
                 r = kctz(todo);
                 KS_UNROLL
                 for (int q = 1; q < HPL; q++)
-                    if (q == r) { pi_r = pi_[q]; word_r = word_[q]; }
+                    if (q == r) { pi_r = pi_[q]; word_r = word_[q]; slot_r = slot_[q]; }
             }
             int h1 = 0, h2 = 0;
-            const int c = collide_hull_hull(m, dirtab, scr, pairs + pi_r, word_r, h1, h2, warm ? warm + r : nullptr, prof);
+            const int c = collide_hull_hull(m, dirtab, scr, pairs + pi_r, DYNAMIC_SLOTS ? slot_r : pairs[pi_r].slot, word_r, h1, h2, warm ? warm + r : nullptr, prof);
             scr(SCR_PC + pi_r) = T(pc_pack(c, h1, h2));
             todo &= todo - 1;
         }
@@ -1725,7 +1761,8 @@ KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Tea
     for (int q = 0; q < (NPAIR_MAX + SUBS - 1) / SUBS; q++) {
         const int pi = team.sub + q * SUBS;
         if (pi < npair) {
-            const int c = (int)scr(SCR_PC + pi) & PC_COUNT_MASK, slot = pairs[pi].slot;
+            const int c = (int)scr(SCR_PC + pi) & PC_COUNT_MASK;
+            const int slot = (DYNAMIC_SLOTS && c > 0) ? (int)scr(SCR_SLOT + pi) : pairs[pi].slot;
             for (int k = 0; k < c; k++) {
                 const int src = SCR_STAGE + (slot + k) * STAGE_REC, dst = SCR_CON + (before[q] + k) * CON_STRIDE;
                 if (before[q] + k < NCON_MAX) {
