@@ -9,4 +9,4 @@ python bench.py --no-cpu-baseline --config 5 > $out/bench_cfg5_free.log 2>&1
 python bench.py --no-cpu-baseline --config 5 --rollout lockstep > $out/bench_cfg5_lock.log 2>&1
 python bench.py --no-cpu-baseline > $out/bench_default.log 2>&1
 grep "done" $out/overlap_4096_mixed3.txt; grep "^launch" $out/drops_8192_mixed_c16.txt | tail -3; tail -2 $out/gputests_learner.log
-bash tools/r04_sixth.sh
+bash tools/rounds/r04_sixth.sh
