@@ -15,6 +15,7 @@ int main(int argc, char** argv) {
             double qpos[16] = {0}, qvel[15] = {0}, warm[15] = {0}, hq[4] = {0.5, -0.5, -0.5, -0.5}, obs[82], rew, rays[17];
             int done;
             qpos[9] = 0.03 * (start - 1); qpos[10] = 0.01; qpos[11] = 0.0654; qpos[12] = 1;
+            if (argc > 4) { qpos[9] += atof(argv[2]); qpos[10] += atof(argv[3]); qpos[11] = atof(argv[4]); }   // object offset (multi-geom pieces carry their CAD origin)
             if (start == 2) { hq[0] = 1; hq[1] = hq[2] = hq[3] = 0; qpos[2] = -0.05; }     // hand flat near the ground
             lc_reset_obs(h, prec, qpos, qvel, warm, hq, obs, &rew, &done, rays);
             for (int t = 0; t < 24; t++) {
