@@ -208,3 +208,41 @@ def test_multi_geom_free_running_rollout_equals_the_lock_step_calls(shapes, n):
     assert torch.equal(st["qpos"], ref["qpos"]) and torch.equal(st["status"], ref["status"]) and torch.equal(eng.obs, ref["obs"])
     assert replay.count == ref["count"] and ring(replay) == ref["eps"]
     sim.close()
+
+
+def test_vec_env_with_multi_geom_shapes_of_a_stage():
+    """KinovaGripperVecEnv on the shape keys of the reference's `shapes` stage (main_DDPGfD.py:1270-1281: single- and multi-geom objects
+    together): object, orientation class and start per env as the reference's reset() picks them - from the shape's coordinate file where
+    the reference ships one, by its empty-file rule where it does not (Normal/BowlS: scenarios.fallback_start) -, the object-size slots
+    of the observation follow _get_obj_size's walk over the pieces, and every env's reset observation equals its own oracle's."""
+    from kinovagrasping_amd.vec_env import KinovaGripperVecEnv
+    shapes = ["CubeS", "Vase2S", "BottleS", "BowlS", "TBottleS"]
+    n = 40
+    env = KinovaGripperVecEnv(n, shapes, seed=5, auto_reset=False)
+    assert env.sim.multi_geom
+    obs = env.reset(shape_keys=shapes, hand_orientation="random", mode="train")
+    torch.cuda.synchronize()
+    assert tuple(obs.shape) == (n, 82) and torch.isfinite(obs).all()
+    names, poses = env.get_random_shape(), env.get_orientation()
+    assert set(names) == set(shapes)
+    sizes = {sh: mc.read_blob(scenarios.model_blob(sh))["obj_size_obs"] for sh in shapes}
+    seen_fallback = 0
+    for e in range(n):
+        assert np.allclose(obs[e, 33:36].cpu().numpy(), sizes[names[e]], rtol=1e-6)
+        if scenarios.has_start_table(names[e], poses[e]):
+            assert np.array_equal(scenarios.start_coord_table(names[e], poses[e])[env.get_orientation_idx()[e]], env.get_obj_coords()[e])
+        else:
+            seen_fallback += 1
+            assert env.get_orientation_idx()[e] == -1 and names[e] == "BowlS" and poses[e] == "normal"
+            assert np.hypot(*env.get_obj_coords()[e][:2]) <= sizes["BowlS"][0] / 2 and abs(env.get_obj_coords()[e][2] - sizes["BowlS"][2] / 4) < 1e-12
+    assert seen_fallback >= 1
+    for e in (0, 7, 19, n - 1):
+        o = ko.OracleSim(ko.OracleModel(scenarios.model_blob(names[e])), scenarios.hand_quat_for(poses[e]), solver_iterations=SOLVER_ITERATIONS)
+        q0 = np.zeros(16); q0[9:12] = env.get_obj_coords()[e]; q0[12] = 1
+        q0[0:3] = scenarios.hand_slide_offsets(poses[e], names[e])
+        np.testing.assert_allclose(obs[e].double().cpu().numpy(), o.env_reset(q0), rtol=2e-4, atol=2e-5)
+    a = torch.zeros(n, 4); a[:, 1:] = 0.4
+    for _ in range(3):
+        obs2, rew, done, info = env.step(a)
+    assert torch.isfinite(obs2).all() and (env.sim.get_state()["status"].cpu().numpy() & 2 == 0).all()
+    env.close()
