@@ -246,3 +246,23 @@ def test_vec_env_with_multi_geom_shapes_of_a_stage():
         obs2, rew, done, info = env.step(a)
     assert torch.isfinite(obs2).all() and (env.sim.get_state()["status"].cpu().numpy() & 2 == 0).all()
     env.close()
+
+
+def test_multi_geom_fp64_kernels_track_the_oracle_free_running_for_200_substeps():
+    """free running (no teacher forcing), 200 consecutive substeps of a closing grasp + lift with the main piece in the hand, 6 starts per
+    object: the fp64 instantiation of the multi-geom kernels stays within 1e-9 relative of the oracle in every env at every substep
+    (measured worst 1e-12; profiles/r04_multi_geom.txt section 5 has the fp32 figures: 37 of 48 within 1e-4)"""
+    from tests.studies import long_horizon as lh
+    script = np.array([[0.0, 0.6, 0.5, 0.7]] * 9 + [[0.6, 0.5, 0.5, 0.5]] * 5)
+    offs = [(0, 0), (0.02, 0), (-0.02, 0.005), (0.01, -0.01), (0.03, 0.01), (-0.03, -0.005)]
+    worst = {}
+    for sh in ("BottleB", "TBottleS", "BowlB", "RBowlM"):
+        q0 = np.stack([in_hand_start(sh)] * len(offs), 1)
+        for i, (dx, dy) in enumerate(offs):
+            q0[9, i] += dx; q0[10, i] += dy
+        hq = np.repeat(scenarios.hand_quat_for("normal")[:, None], len(offs), 1)
+        res = lh.run_batch(sh, q0, hq, np.repeat(script[:, :, None], len(offs), 2), 200, precision=64)
+        assert (res["status"] == 0).all()
+        worst[sh] = float(res["rel"].max())
+    print("multi-geom fp64 kernels vs oracle, free running 200 substeps, worst relative qpos error:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert max(worst.values()) < 1e-9, worst
