@@ -47,14 +47,30 @@ ALGO_BYTES_PER_ENV_STEP = 768          # read 236 B + write 532 B p
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 
 
-def cpu_baseline(n_cores: int, budget_s: float = 12.0):
+def shape_states(n: int, shape: str):
+    """start states of the single-object workloads: BASELINE config 2's rows of the shape's no_noise table; for a multi-geom object
+    (--shape BottleS ...: libkinova_sim_mg.so) its main piece placed in the hand - the reference's tables leave those objects 0.19 m
+    from the hand (CAD origins of the STL pieces)"""
+    import numpy as np
+    from kinovagrasping_amd import scenarios
+    if shape not in scenarios.MULTI_GEOM_SHAPES:
+        return scenarios.config2_states(n, shape)
+    from kinovagrasping_amd.model_compiler import read_blob
+    g = read_blob(scenarios.model_blob(shape))["geom_pos"][8]
+    i = np.arange(n)
+    q = np.zeros((16, n))
+    q[9], q[10], q[12] = -g[0] + 0.03 * np.sin(1.7 * i), -g[1] + 0.015 * np.cos(2.3 * i), 1.0
+    return q, np.repeat(scenarios.hand_quat_for("normal")[:, None], n, axis=1)
+
+
+def cpu_baseline(n_cores: int, budget_s: float = 12.0, shape: str = "CubeS"):
     """fp64 oracle ("port"), one env per thread, same workload (config-2 start rows / action streams)."""
     import numpy as np
     from kinovagrasping_amd import scenarios
     from kinovagrasping_amd.sim import SOLVER_ITERATIONS
     from oracle import ko_py as ko
-    model = ko.OracleModel(scenarios.model_blob("CubeS"))
-    q0, hq = scenarios.config2_states(n_cores)
+    model = ko.OracleModel(scenarios.model_blob(shape))
+    q0, hq = shape_states(n_cores, shape)
     acts = scenarios.config_actions(n_cores, 30)
 
     def worker(i):
@@ -72,7 +88,7 @@ def cpu_baseline(n_cores: int, budget_s: float = 12.0):
         res = list(ex.map(worker, range(n_cores)))
     total = sum(s / dt for s, dt in res)
     return {"value": round(total, 2), "unit": "env-steps/s", "cores": n_cores, "kind": "port",
-            "sample": f"{n_cores} threads x ~{budget_s:.0f} s of 30-step CubeS episodes (config-2 rows/actions), fp64 oracle, "
+            "sample": f"{n_cores} threads x ~{budget_s:.0f} s of 30-step {shape} episodes (config-2 rows/actions), fp64 oracle, "
                       f"{sum(s for s, _ in res)} env-steps total"}
 
 
@@ -170,6 +186,8 @@ def main():
     ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=None,
                     help="BASELINE config: 2 = --mode sim, 3 / 4 = DDPG training (4: with --gpus 8), 5 = DDPG training on the domain-"
                          "randomised set: 14 shapes x 3 hand poses, per-env mass / friction, 8192 envs per GPU")
+    ap.add_argument("--shape", default="CubeS", help="object of the single-object workloads (configs 2 - 4; default CubeS = the metric's).  Any asset name: "
+                    "the 14 README shapes, the primitives, or a multi-geom object (BottleS ... RBowlB: runs on libkinova_sim_mg.so)")
     ap.add_argument("--hidden", type=int, nargs=2, default=[256, 256])
     ap.add_argument("--serial-learner", action="store_true", help="run the learner update after the sim step instead of beside it")
     ap.add_argument("--eager", action="store_true", help="launch the rollout / learner ops one by one instead of replaying HIP graphs")
@@ -245,8 +263,8 @@ def main():
         sim = KinovaSim(n, scenarios.SHAPES, device=local_rank, auto_reset=True, horizon=30, solver_iterations=iters)
         reset_all = lambda: sim.reset(torch.as_tensor(q0_all[:, sl]), torch.as_tensor(hq_all[:, sl]), object_id=oid_all[sl], mass_friction=mf_all[:, sl])
     else:
-        q0_all, hq_all = scenarios.config2_states(n * world)
-        sim = KinovaSim(n, "CubeS", device=local_rank, auto_reset=True, horizon=30, solver_iterations=iters)
+        q0_all, hq_all = shape_states(n * world, args.shape)
+        sim = KinovaSim(n, args.shape, device=local_rank, auto_reset=True, horizon=30, solver_iterations=iters)
         reset_all = lambda: sim.reset(torch.as_tensor(q0_all[:, sl]), torch.as_tensor(hq_all[:, sl]))
     obs0 = reset_all()
 
@@ -512,7 +530,7 @@ def main():
         # the committed summary applies to the 4096-env workload only
         traffic, traffic_note, issue = None, "no PMC summary for this workload", None
         pmc = ROOT / "profiles" / ("r04_pmc_sim.json" if args.mode == "sim" else "r04_pmc_free.json" if free_running else "r04_pmc_ddpg.json")     # counters of THIS workload and THIS kernel (k_rollout's are per env-step)
-        if pmc.exists() and n == 4096 and not mixed:
+        if pmc.exists() and n == 4096 and not mixed and args.shape == "CubeS":
             pj = json.loads(pmc.read_text())
             traffic, traffic_note = pj["hbm_bytes_per_launch"], pj["note"]
             pl = pj["per_launch"]
@@ -532,12 +550,14 @@ def main():
                                     "poses (reference thresholds, no-noise tables, pose hand offsets), per-env mass U[0.05,0.15] kg and friction "
                                     "U[0.5,1.0] (shape drawn per 16-env cohort, everything else per env), one simulator context / one stepping launch; 256-256 actor/critic, one DDPGfD update per env-step "
                                     "(BASELINE config 5; 65536 envs when n_gpus=8)") if mixed else
-                                   (f"{n} envs/GPU DDPG training, 256-256 actor/critic, CubeS normal pose: actor inference + exploration noise + "
+                                   (f"{n} envs/GPU DDPG training, 256-256 actor/critic, {args.shape} normal pose: actor inference + exploration noise + "
                                     "scripted lift in the loop, device replay, one DDPGfD update (64 episodes x 25 five-step windows) per "
                                     "env-step (BASELINE config 3; config 4 when n_gpus=8)") if args.mode == "ddpg" else
-                                   (f"{n} envs/GPU CubeS normal-pose grasp sim, PCG64(1000+i) random-action rollout (BASELINE config 2 at the "
+                                   (f"{n} envs/GPU {args.shape} normal-pose grasp sim, PCG64(1000+i) random-action rollout (BASELINE config 2 at the "
                                     "metric's env count); sim kernels only"),
-                       "reset": ("every env restarts from its own row of the reference's no_noise start table (obj_hand_coords/no_noise/train_coords), no orientation "
+                       "reset": ("multi-geom object: main piece placed in the hand (+-3 cm), not the reference's start tables - they leave these objects 0.19 m from the hand (DESIGN.md 2a); "
+                                 if (not mixed and args.shape in scenarios.MULTI_GEOM_SHAPES) else "") +
+                                ("every env restarts from its own row of the reference's no_noise start table (obj_hand_coords/no_noise/train_coords), no orientation "
                                  "noise; hand slide offsets of the pose ('pose' mode)  [reference defaults: with_noise=True - tables SURVEY N5 shows to be "
                                  "biased and swapped between classes - and, in its training driver, zero hand offsets: vec_env.KinovaGripperVecEnv(hand_offsets="
                                  "'fresh-env'), reset(with_noise=True) select those]"),
@@ -581,7 +601,7 @@ def main():
             "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 4),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1, shape="CubeS" if mixed else args.shape)
             mj = cpu_baseline_mujoco()                     # None unless the third-party mujoco package happens to be installed
             if mj is not None:
                 out["cpu_baseline_mujoco"] = mj
