@@ -1589,7 +1589,11 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
 #ifndef KS_MPR_FIRST
 #define KS_MPR_FIRST 0          // measured in round 4 (one box, A/B): sim-only 4.28 M with it, 4.36 M without - the waves run in lockstep, the lanes
 #endif                          // that skip the distance query wait for those that do not, and the extra branch costs more than it saves: off
-    const bool mpr_first = (KS_MPR_FIRST != 0) && (KS_MPR_WARM != 0) && sizeof(T) == 4 && ws != nullptr && (ws->w[2] >> 30) == 3u && !(margin > T(0));
+    // (KS_MPR_FIRST=2: EVERY margin-0 pair, penetrating before or not - no distance query at all for the object pairs.  Measured, A/B on one
+    // box: training 2.71 M against 3.03 M env-steps/s, sim-only 3.94 against 4.31 M: a separated pair costs the distance query one iteration
+    // (its cached separating simplex), the penetration query a cold portal discovery.)
+    const bool mpr_first = (KS_MPR_FIRST == 2) ? (sizeof(T) == 4 && !(margin > T(0)))
+                                               : ((KS_MPR_FIRST != 0) && (KS_MPR_WARM != 0) && sizeof(T) == 4 && ws != nullptr && (ws->w[2] >> 30) == 3u && !(margin > T(0)));
     int r = 2;
     if (!mpr_first) r = gjk_distance(pg, margin, &dist, dir, pos, ws);
 #ifdef KS_STAMP_HULL
