@@ -125,8 +125,8 @@ int ks_reset_objects(ks_ctx *ctx, const int32_t *env_ids, int32_t n, const void 
  * buffers themselves are borrowed for as long as the graph may be replayed. */
 int ks_step(ks_ctx *ctx, const void *action, void *obs, void *reward, uint8_t *done, void *info, void *final_obs, void *stream);
 
-/* Parity taps; any pointer may be NULL.  contact: [KS_NCON_MAX*KS_CONTACT_STRIDE, N] records of the
- * last substep (pos3 normal3 dist mu bodies R aref4 force3(normal,t1,t2) active-row-mask D spare; needs cfg.contact_tap), ncon: int32 [N],
+/* Parity taps; any pointer may be NULL.  contact: [KS_NCON_MAX*KS_CONTACT_STRIDE, N] (libkinova_sim_mg.so: KS_NCON_MAX_MG) records of the
+ * last substep (pos3 normal3 dist mu bodies+pair (b1 + 16 b2 + 256 pair index) R aref4 force3(normal,t1,t2) active-row-mask D spare; needs cfg.contact_tap), ncon: int32 [N],
  * status: int32 [N] sticky bit flags (1 contact overflow, 2 non-finite state, 4 the env's rays were not delivered in time by the
  * stepping launch's ray pool - a wait ran out; never seen in practice, reported instead of hanging; 8 a substep's Newton iteration
  * ended at cfg.solver_iterations before its stop rule fired: that substep used a truncated iterate). */
