@@ -108,17 +108,21 @@ def in_hand_start(shape):
     return q
 
 
-@pytest.mark.parametrize("shape", ["BottleS", "TBottleM", "BowlS", "RBowlB"])
-def test_multi_geom_kernel_source_reproduces_oracle_substeps(shape):
+@pytest.mark.parametrize("shape,pose", [("BottleS", "normal"), ("TBottleM", "normal"), ("BowlS", "normal"), ("RBowlB", "normal"),
+                                        ("BottleS", "top"), ("TBottleS", "top"), ("BowlS", "rotated"), ("RBowlS", "rotated")])
+def test_multi_geom_kernel_source_reproduces_oracle_substeps(shape, pose):
     """the kernel source with the multi-geom capacities, one lane on the host, against the oracle through a scripted grasp that touches
-    welded pieces (plane contacts of the pieces, finger-piece hull pairs, lift): fp64 to round-off, fp32 within its one-step bounds"""
+    welded pieces (plane contacts of the pieces, finger- and palm-piece hull pairs, lift) in the three hand poses: fp64 to round-off, fp32
+    within its one-step bounds"""
     blob = scenarios.model_blob(shape)
     m = ko.OracleModel(blob)
-    hq = scenarios.hand_quat_for("normal")
+    hq = scenarios.hand_quat_for(pose)
     lane64, lane32 = Lane(blob, 64, multi_geom=True), Lane(blob, 32, multi_geom=True)
     s = ko.OracleSim(m, hq, solver_iterations=SOLVER_ITERATIONS)
     s.s.rays_enabled = 0
-    s.set_state(in_hand_start(shape))
+    q0 = in_hand_start(shape)
+    q0[0:3] = scenarios.hand_slide_offsets(pose, shape, "pose")
+    s.set_state(q0)
     s.forward()
     ctrl = np.zeros(9); ctrl[6:9] = 0.6
     e64, e32, pairs = [], [], set()
@@ -134,7 +138,7 @@ def test_multi_geom_kernel_source_reproduces_oracle_substeps(shape):
         qp, qv, qw, nc, con, st = lane32.substep(*before, ctrl, hq)
         assert st == 0
         e32.append(np.abs(qp - s.view("qpos")).max())
-    print(f"{shape}: pairs {sorted(pairs)}; fp64 lane worst {max(e64):.2e}; fp32 lane median {np.median(e32):.2e} max {max(e32):.2e}")
+    print(f"{shape} {pose}: pairs {sorted(pairs)}; fp64 lane worst {max(e64):.2e}; fp32 lane median {np.median(e32):.2e} max {max(e32):.2e}")
     assert any(b > 8 for a, b in pairs) and any(a > 0 and b >= 8 for a, b in pairs)
     assert max(e64) < 1e-9
     assert np.median(e32) < 2e-7 and max(e32) < 3e-3
