@@ -36,12 +36,14 @@ def in_hand_start(shape, z=0.0):
     return q
 
 
-def oracle_grasp(shape, n_sub=320, iters=SOLVER_ITERATIONS):
+def oracle_grasp(shape, n_sub=320, iters=SOLVER_ITERATIONS, pose="normal"):
     m = ko.OracleModel(scenarios.model_blob(shape))
-    hq = scenarios.hand_quat_for("normal")
+    hq = scenarios.hand_quat_for(pose)
     s = ko.OracleSim(m, hq, solver_iterations=iters)
     s.s.rays_enabled = 0
-    s.set_state(in_hand_start(shape))
+    q0 = in_hand_start(shape)
+    q0[0:3] = scenarios.hand_slide_offsets(pose, shape, "pose")
+    s.set_state(q0)
     s.forward()
     ctrl = np.zeros(9); ctrl[6:9] = 0.6
     rec = []
@@ -71,13 +73,13 @@ def teacher_forced(shape, precision, hq, rec):
     return eq, ev, ncon, np.array([r[3] for r in rec]), status
 
 
-@pytest.mark.parametrize("shape", SHAPES)
-def test_multi_geom_one_step_matches_oracle(shape):
-    hq, rec = oracle_grasp(shape)
+@pytest.mark.parametrize("shape,pose", [(s_, "normal") for s_ in SHAPES] + [("BottleS", "top"), ("BowlS", "rotated")])
+def test_multi_geom_one_step_matches_oracle(shape, pose):
+    hq, rec = oracle_grasp(shape, pose=pose)
     pairs = sorted({p for r in rec for p in r[4]})
     assert any(b > 8 for a, b in pairs), "the scripted grasp must touch welded pieces (geoms 9..)"
     eq, ev, ncon, onc, status = teacher_forced(shape, 64, hq, rec)
-    print(f"{shape}: contact pairs seen {pairs}; fp64 one-step |dqpos| max {eq.max():.2e}, |dqvel| max {ev.max():.2e}")
+    print(f"{shape} {pose}: contact pairs seen {pairs}; fp64 one-step |dqpos| max {eq.max():.2e}, |dqvel| max {ev.max():.2e}")
     assert (status == 0).all() and (ncon == onc).all()
     assert eq.max() < 1e-9 and ev.max() < 1e-7
     eq, ev, ncon, onc, status = teacher_forced(shape, 32, hq, rec)
