@@ -19,6 +19,11 @@
  *     the contact trajectory to 1.9e-10 in every column for its first 22 rows,
  *     84 substeps with 18 rows of finger-box contact; first row beyond 1e-6: row 22).  Contact
  *     forces and velocities of real MuJoCo were never recorded.
+ *   - multi-geom objects (Bottle / TBottle / Bowl / RBowl: `object` + jointless child bodies, ..._sbottle.xml:158-186): PARITY
+ *     UNPINNED for what is specific to them - the reference tree holds no MuJoCo output of these models.  The restatement follows
+ *     MuJoCo's documented semantics (welded children = one rigid body with the composite inertial; their geoms collide dynamically
+ *     at the geom margin / default friction, never with each other; a contact's regularisation uses the inverse weight of the body
+ *     that owns the geom) on top of the single-geom pipeline that IS pinned.
  */
 #ifndef KO_H
 #define KO_H
