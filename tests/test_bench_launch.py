@@ -168,3 +168,16 @@ def test_two_ranks_free_running_rollout(p2p):
     assert line["replica_weight_checksum_spread"] == 0.0 and line["replica_checks_during_run"] >= 2 and line["nonfinite_envs"] == 0
     assert line["config"]["free_running"]["episodes_dropped"] == 0 and line["config"]["learner_updates_timed"] == 10
     assert line["rccl"]["exchange"].startswith("peer-mapped memory" if p2p == "1" else "gloo all_reduce")
+
+
+@pytest.mark.gpu
+def test_bench_line_on_a_multi_geom_object():
+    """`bench.py --shape TBottleS`: the single-object workload on a multi-geom object (libkinova_sim_mg.so) - free-running rollout kernel
+    with the learner beside it; the line names the object, carries no PMC block of another workload, and no env raised a status flag"""
+    r = run_bench(["--shape", "TBottleS", "--steps", "20", "--warmup", "10", "--init-policy", "none", "--pretrain-updates", "60", "--steady-steps", "30", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "TBottleS" in d["config"]["workload"] and "multi-geom object" in d["config"]["reset"]
+    assert d["config"]["free_running"] is not None and d["config"]["free_running"]["episodes_dropped"] == 0
+    assert d["roofline"]["traffic"] is None and d["value"] > 1e6
+    assert all(v == 0 for v in d["status_counts"].values()) and d["nonfinite_envs"] == 0
