@@ -33,6 +33,22 @@ def start_coord_table(shape: str, orientation: str = "normal") -> np.ndarray:
     return _tables[f"{orientation.capitalize()}/{shape}"].astype(np.float64)
 
 
+_noisy_tables = None
+
+
+def noisy_start_table(shape: str, orientation: str = "normal"):
+    """Rows of the reference's obj_hand_coords/with_noise/train_coords/<orient>/<shape>.txt (its DEFAULT start states,
+    kinova_gripper_env.py:1310, 1019-1021): object x, y, z and the hand's Euler triple of that row (patched into the XML through the
+    5-character truncation, :1254-1255, 870-874).  float64 [rows, 6], or None where the reference ships no such file.  SURVEY note N5: the
+    Euler columns are biased by -0.087 rad and swapped between the normal / top classes relative to the object columns - shipped as data
+    so that `KinovaGripperVecEnv.reset(with_noise="tables")` reproduces the reference's default as it is."""
+    global _noisy_tables
+    if _noisy_tables is None:
+        _noisy_tables = np.load(ASSETS / "start_coords_with_noise_train.npz")
+    key = f"{orientation}/{shape}"
+    return _noisy_tables[key].astype(np.float64) if key in _noisy_tables.files else None
+
+
 def has_start_table(shape: str, orientation: str = "normal") -> bool:
     global _tables
     if _tables is None:

@@ -80,7 +80,8 @@ class KinovaGripperVecEnv:
     def get_coords_filename(self):
         """the coordinate file of every env's (orientation, shape), the path the reference builds at ENV:1245"""
         names = self.random_shape if isinstance(self.random_shape, list) else [self.random_shape] * self.n_envs
-        return [COORDS_DIR + "no_noise/train_coords/" + o + "/" + sh + ".txt" for o, sh in zip(self.orientation, names)]
+        noise_dir = "with_noise" if self.with_noise == "tables" else "no_noise"
+        return [COORDS_DIR + noise_dir + "/train_coords/" + o + "/" + sh + ".txt" for o, sh in zip(self.orientation, names)]
 
     @property
     def Tfw(self):
@@ -156,9 +157,14 @@ class KinovaGripperVecEnv:
         (ENV:870-874, model_compiler.truncated_euler); object coordinates still come from the no_noise tables.  An EXTENSION, not the
         reference's behaviour: its with_noise tables (ENV:1254-1255; generator rotation_generation.py:20-25) carry Euler triples
         that are swapped between the normal / top classes and biased by -0.087 (N5), so they are not reproduced.  The reference's
-        default is with_noise=True; the default here is False (the self-consistent no-noise branch)."""
-        from .model_compiler import euler_to_quat
-        self.with_noise = bool(with_noise)
+        default is with_noise=True; the default here is False (the self-consistent no-noise branch).
+        with_noise="tables": the reference's default AS IT IS - object position AND hand Euler triple of a random row of the shape's
+        with_noise coordinate file (ENV:1019-1021, 1254-1255; `scenarios.noisy_start_table`), bias, class swap and all (N5); where the
+        reference ships no such file the no-noise path applies."""
+        from .model_compiler import euler_to_quat, truncated_euler
+        if with_noise not in (False, True, "tables"):
+            raise ValueError('reset: with_noise is False, True (zero-mean extension) or "tables" (the reference\'s with_noise files)')
+        self.with_noise = with_noise if with_noise == "tables" else bool(with_noise)
         self.set_with_grasp_reward(with_grasp)
         ids = np.arange(self.n_envs) if env_ids is None else np.asarray(env_ids)
         n = len(ids)
@@ -176,10 +182,18 @@ class KinovaGripperVecEnv:
             shape = self.random_shape[e] if multi else self.random_shape
             o = self.select_orienation(hand_orientation, shape)
             self.orientation[e] = o
-            eul = scenarios.hand_euler_for(o, self.np_random if with_noise else None)
+            noisy = scenarios.noisy_start_table(shape, o) if (with_noise == "tables" and start_pos is None) else None
+            if noisy is not None:
+                row = self.np_random.randint(0, len(noisy))
+                eul = truncated_euler(noisy[row, 3:6])
+            else:
+                eul = scenarios.hand_euler_for(o, self.np_random if with_noise is True else None)
             self.hand_euler[e] = eul
             hq[:, k] = euler_to_quat(eul)
-            if start_pos is not None:
+            if noisy is not None:
+                q[9:12, k] = noisy[row, :3]
+                self.orientation_idx[e] = row
+            elif start_pos is not None:
                 q[9:12, k] = np.asarray(start_pos)[k][:3]
                 self.orientation_idx[e] = -1
             elif scenarios.has_start_table(shape, o):

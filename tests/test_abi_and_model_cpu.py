@@ -237,3 +237,24 @@ def test_orientation_noise_is_zero_mean_truncated_and_seeded():
         assert all(len(repr(float(v))) <= 5 or abs(v) < 1e-4 or float(repr(float(v))[:5]) == v for v in e[:50].ravel())
         rng2 = np.random.RandomState(11)
         assert np.array_equal(e[0], scenarios.hand_euler_for(o, rng2))
+
+
+def test_reference_with_noise_tables_are_shipped_as_they_are():
+    """obj_hand_coords/with_noise/train_coords/<class>/<shape>.txt (the reference's DEFAULT start states, kinova_gripper_env.py:1310,
+    1019-1021, 1254-1255): object x, y, z + hand Euler triple per row, first line consumed by the delimiter sniffer (:1012).  Known rows of the
+    files, and the statistics SURVEY note N5 measured on them: the Euler columns are noise of std 0.087 around a -0.087 BIAS, about the
+    identity in `normal/` and about (-1.57, 0, -1.57) in `top/` - swapped relative to the env's own class constants (ENV:1267-1273)."""
+    from kinovagrasping_amd import scenarios
+    t = scenarios.noisy_start_table("CubeS", "normal")
+    assert t.shape == (4499, 6)
+    assert np.allclose(t[0], [0.009388, 0.043207, 0.0654, 0.13371021, -0.00540045, -0.21338375], atol=1e-7)      # line 2 of the file
+    assert np.allclose(t[1], [-0.002896, 0.019442, 0.0654, -0.10531564, -0.12903301, -0.12173909], atol=1e-7)
+    top = scenarios.noisy_start_table("CubeS", "top")
+    assert np.allclose(top[0], [0.033995, 0.024185, 0.05, -1.71440852, -0.08557746, -1.65729666], atol=1e-6)
+    for tab, centre in ((t, [0.0, 0.0, 0.0]), (top, [-1.57, 0.0, -1.57]), (scenarios.noisy_start_table("CubeS", "rotated"), [-1.2, 0.0, 0.0])):
+        e = tab[:, 3:6]
+        assert np.allclose(e.mean(0), np.array(centre) - 0.087, atol=0.006) and np.allclose(e.std(0), 0.087, atol=0.003)
+    assert len([s for s in scenarios.SHAPES for o in ("normal", "rotated", "top") if scenarios.noisy_start_table(s, o) is not None]) == 42
+    assert scenarios.noisy_start_table("BowlS", "normal") is None
+    # the truncation the reference applies when it patches a row's Euler triple into the XML (ENV:870-874)
+    assert np.allclose(mc.truncated_euler(top[0, 3:6]), [-1.71, -0.08, -1.65])

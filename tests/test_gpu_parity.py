@@ -724,6 +724,40 @@ def test_vec_env_keeps_the_reference_interface():
     env.close()
 
 
+def test_vec_env_reference_with_noise_tables_mode():
+    """reset(with_noise="tables"): the reference's DEFAULT start states as they are (ENV:1310, 1019-1021, 1254-1255) - object position AND hand
+    Euler triple of a random row of the shape's with_noise file, truncated to 5 characters; every env's reset observation equals the oracle's
+    at that pose.  (With hand_offsets="fresh-env" - what the reference's training driver ends up with - the 'normal' class of these tables puts
+    the hand at the IDENTITY orientation + noise: SURVEY N5.)"""
+    from kinovagrasping_amd.vec_env import KinovaGripperVecEnv
+    from kinovagrasping_amd.model_compiler import euler_to_quat, truncated_euler
+    n = 36
+    env = KinovaGripperVecEnv(n, "Cube45B", seed=4, auto_reset=False, hand_offsets="fresh-env")
+    obs = env.reset(hand_orientation="random", with_noise="tables").double().cpu().numpy().copy()
+    assert set(env.get_orientation()) == {"normal", "rotated", "top"} and all("with_noise/train_coords" in f for f in env.get_coords_filename())
+    model = ko.OracleModel(scenarios.model_blob("Cube45B"))
+    for e in range(n):
+        tab = scenarios.noisy_start_table("Cube45B", env.get_orientation()[e])
+        row = tab[env.get_orientation_idx()[e]]
+        assert np.array_equal(row[:3], env.get_obj_coords()[e]) and np.array_equal(truncated_euler(row[3:6]), env.hand_euler[e])
+        assert np.allclose(env.hand_quat[:, e], euler_to_quat(env.hand_euler[e]))
+    worst = 0.0
+    for e in range(0, n, 4):
+        o = ko.OracleSim(model, env.hand_quat[:, e].copy(), solver_iterations=SOLVER_ITERATIONS)
+        q0 = np.zeros(16); q0[9:12] = env.get_obj_coords()[e]; q0[12] = 1
+        ref = o.env_reset(q0)
+        tol = 2e-4 * np.maximum(1.0, np.abs(ref)) * np.where(np.isin(np.arange(82), [48, 49] + list(range(75, 82))), 50, 1)
+        assert (np.abs(obs[e] - ref) <= tol + 2e-5).all(), (e, np.abs(obs[e] - ref).max())
+        worst = max(worst, np.abs(obs[e] - ref).max())
+    # the class swap of N5, seen through the env: the 'normal' rows hold near-identity hand orientations
+    normal = [e for e in range(n) if env.get_orientation()[e] == "normal"]
+    assert normal and all(np.abs(env.hand_euler[e]).max() < 0.5 for e in normal)
+    print(f"with_noise='tables': worst reset-observation error vs oracle {worst:.1e}")
+    env.close()
+    with pytest.raises(ValueError):
+        KinovaGripperVecEnv(4, "CubeS", auto_reset=False).reset(with_noise="yes")
+
+
 def test_vec_env_with_noise_resets_to_noisy_poses_that_match_the_oracle():
     """reset(with_noise=True): zero-mean N(0, 0.087) Euler noise through the 5-character truncation (scenarios.hand_euler_for,
     SURVEY N5 extension).  Every env's reset observation and its state after two env-steps equal the oracle run on the SAME noisy

@@ -37,6 +37,17 @@ def main():
                 tables[f"{orient}/{shape}"] = mc.load_coords_table(p)[:, :3].astype(np.float32)
     np.savez_compressed(OUT / "start_coords_no_noise_train.npz", **tables)
     print("tables:", {k: v.shape for k, v in list(tables.items())[:4]}, "...", len(tables))
+    # the reference's with_noise tables (its default, kinova_gripper_env.py:1310): object x, y, z + the hand's Euler triple per row
+    # (kinova_gripper_env.py:1019-1021, 1254-1255; lower-case class directories).  SURVEY note N5 shows them to be biased and swapped
+    # between classes; they are shipped so that reset(with_noise="tables") can reproduce the reference's default start states as they are.
+    noisy = {}
+    for orient in ["normal", "rotated", "top"]:
+        for shape in SHAPES:
+            p = KD / "obj_hand_coords" / "with_noise" / "train_coords" / orient / f"{shape}.txt"
+            if p.exists():
+                noisy[f"{orient}/{shape}"] = mc.load_coords_table(p)[:, :6].astype(np.float32)
+    np.savez_compressed(OUT / "start_coords_with_noise_train.npz", **noisy)
+    print("with_noise tables:", {k: v.shape for k, v in list(noisy.items())[:3]}, "...", len(noisy))
 
 
 if __name__ == "__main__":
