@@ -15,6 +15,8 @@ SHAPES = [s + z for s in ["Cube", "Cylinder", "Cube45", "Cone1", "Cone2", "Vase1
 # the multi-geom objects of the experiment stages (main_DDPGfD.py:1270-1281; shape keys of kinova_gripper_env.py:189-208): `object` plus
 # welded pieces.  They run on libkinova_sim_mg.so (sim.KinovaSim picks the library from the model blob).
 MULTI_GEOM_SHAPES = [s + z for s in ["Bottle", "Bowl", "TBottle", "RBowl"] for z in "SMB"]
+# the medium size of the README shapes: the experiment mode's test size (main_DDPGfD.py:1280-1281; kinova_gripper_env.py:150-180)
+MEDIUM_SHAPES = [s + "M" for s in ["Cube", "Cylinder", "Cube45", "Cone1", "Cone2", "Vase1", "Vase2"]]
 
 _tables = None
 

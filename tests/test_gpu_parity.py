@@ -952,10 +952,10 @@ def test_curriculum_stage_runs_and_hands_over_to_the_next(tmp_path):
     assert r4["skipped_shapes"] == [] and r4["num_total"] == 112
     assert set(r4["orientation_counts"]) == {"normal", "rotated", "top"} and r4["updates"] == 1
     # a test-mode stage (TEST_SHAPES: Vase1, RBowl) on the multi-geom library: RBowl never takes the 'normal' class
-    pt = curriculum.experiment_plan(3, exp_mode="test", root=tmp_path)
-    pt["requested_shapes"] = ["Vase1S", "RBowlS"]
+    pt = curriculum.experiment_plan(5, exp_mode="test", root=tmp_path)
+    assert pt["requested_shapes"] == ["Vase1M", "RBowlM"] and pt["requested_orientation"] == "random"
     rt = curriculum.run_stage(pt, fresh, n_envs=32, rounds=1, updates_per_round=1, save=False, load_previous=False)
-    assert rt["shapes"] == ["Vase1S", "RBowlS"] and rt["skipped_shapes"] == [] and rt["num_total"] == 32
+    assert rt["shapes"] == ["Vase1M", "RBowlM"] and rt["skipped_shapes"] == [] and rt["num_total"] == 32
 
 
 @pytest.mark.parametrize("split", ["0", "2", "4", None])
