@@ -11,10 +11,10 @@ constexpr int NQ = 16, NV = 15, NU = 9, NBODY = 10, NSITE = 17, NSENSOR = 26, NO
 //  standard   : ground + 7 hand geoms + `object`; 8 explicit + 22 dynamic pairs; hulls of palm / proximal / distal / object.
 //  multi-geom : (-DKS_MULTI_GEOM, libkinova_sim_mg.so) `object` + up to 8 jointless child bodies welded to it, one mesh geom each - the
 //               reference's Bottle / TBottle / Bowl / RBowl models (kinova_description/..._sbottle.xml:158-186): 17 geoms, 30 + 8 x 8 pairs,
-//               3 + 9 hulls of up to 2048 vertices.  The welded pieces are geoms of body 9 (one rigid body, composite inertial).
+//               3 + 9 hulls of up to 4096 vertices (hull tables in global memory, so it also takes single-geom objects whose hull exceeds the standard build's 1024: Lemon).  The welded pieces are geoms of body 9 (one rigid body, composite inertial).
 #ifdef KS_MULTI_GEOM
 constexpr bool MULTI_GEOM = true;
-constexpr int NGEOM = 17, NPAIR_MAX = 96, NMESH = 12, HULL_VERT_MAX = 2048;
+constexpr int NGEOM = 17, NPAIR_MAX = 96, NMESH = 12, HULL_VERT_MAX = 4096;   // (4096: the Lemon stand-in's hull has 2434 vertices, the short bottle's base 1546)
 #else
 constexpr bool MULTI_GEOM = false;
 constexpr int NGEOM = 9, NPAIR_MAX = 32, NMESH = 4, HULL_VERT_MAX = 1024;

@@ -115,7 +115,7 @@ def run_stage(plan, policy, n_envs: int = 1024, rounds: int = 10, updates_per_ro
     from .rollout import RolloutEngine
 
     dirs = plan["dirs"]
-    known = scenarios.SHAPES + scenarios.MEDIUM_SHAPES + scenarios.MULTI_GEOM_SHAPES
+    known = scenarios.SHAPES + scenarios.MEDIUM_SHAPES + scenarios.EXTRA_SHAPES + scenarios.MULTI_GEOM_SHAPES
     shapes = [s for s in plan["requested_shapes"] if s in known]
     skipped = [s for s in plan["requested_shapes"] if s not in known]
     if not shapes:

@@ -343,7 +343,10 @@ def compile_model(xml_path: Path, mesh_inertia: str = "legacy") -> dict:
     """mesh_inertia: how mesh geoms get their centre / principal frame / (object) inertia: "legacy" reproduces MuJoCo 1.50
     (default: parity with the reference's engine), "exact" is the signed-volume integration of MuJoCo >= 2.2's default."""
     xml_path = Path(xml_path)
-    root = ET.parse(xml_path).getroot()
+    text = xml_path.read_text()
+    end = text.find("</mujoco>")
+    # (one of the reference's files, ..._v1_mhg.xml, carries a stray "oco>" behind its closing tag: everything behind the root element is dropped)
+    root = ET.fromstring(text[:end + len("</mujoco>")] if end >= 0 else text)
     comp = root.find("compiler")
     assert comp.get("angle") == "radian"
     meshdir = xml_path.parent / comp.get("meshdir", "")

@@ -14,9 +14,12 @@ ORIENTATION_EULER = {"normal": (-1.57, 0.0, -1.57), "rotated": (-1.2, 0.0, 0.0),
 SHAPES = [s + z for s in ["Cube", "Cylinder", "Cube45", "Cone1", "Cone2", "Vase1", "Vase2"] for z in "SB"]  # README.md:59
 # the multi-geom objects of the experiment stages (main_DDPGfD.py:1270-1281; shape keys of kinova_gripper_env.py:189-208): `object` plus
 # welded pieces.  They run on libkinova_sim_mg.so (sim.KinovaSim picks the library from the model blob).
-MULTI_GEOM_SHAPES = [s + z for s in ["Bottle", "Bowl", "TBottle", "RBowl"] for z in "SMB"]
+MULTI_GEOM_SHAPES = [s + z for s in ["Bottle", "Bowl", "TBottle", "RBowl", "Hour"] for z in "SMB"]         # (Hour: the hourglass, `object` + top + bottom)
 # the medium size of the README shapes: the experiment mode's test size (main_DDPGfD.py:1280-1281; kinova_gripper_env.py:150-180)
 MEDIUM_SHAPES = [s + "M" for s in ["Cube", "Cylinder", "Cube45", "Cone1", "Cone2", "Vase1", "Vase2"]]
+# the remaining single-geom families of the env's object table (kinova_gripper_env.py:181-200): vase, lemon stand-in.  The Lemon hull
+# (2434 vertices) is beyond the standard library's 1024 and runs on libkinova_sim_mg.so (hull tables in global memory; sim.blob_needs_mg_library)
+EXTRA_SHAPES = [s + z for s in ["Vase", "Lemon"] for z in "SMB"]
 
 _tables = None
 

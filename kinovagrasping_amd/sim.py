@@ -88,6 +88,12 @@ def blob_is_multi_geom(blob: bytes) -> bool:
     return blob_record_shape(blob, "geom_body")[0] > 9
 
 
+def blob_needs_mg_library(blob: bytes) -> bool:
+    """a multi-geom object, or a single-geom one whose hull has more vertices than the standard library keeps in LDS (1024: the Lemon stand-in has 2434)"""
+    from .model_compiler import blob_record_shape
+    return blob_is_multi_geom(blob) or blob_record_shape(blob, "mesh3_vert")[0] > 1024
+
+
 def _bind(L):
     vp, i32p = C.c_void_p, C.c_void_p
     L.ks_default_config.argtypes = [C.POINTER(KsConfig)]
@@ -159,7 +165,7 @@ class KinovaSim:
         blobs = [as_blob(m) for m in self.models]
         # a context with a multi-geom object (welded pieces: Bottle / TBottle / Bowl / RBowl) runs on the library built with those
         # capacities; it holds single-geom objects as well (slower than the standard library: hull tables in L2, not LDS)
-        self.multi_geom = any(blob_is_multi_geom(b) for b in blobs)
+        self.multi_geom = any(blob_needs_mg_library(b) for b in blobs)
         self.lib = load_library(multi_geom=self.multi_geom)
         self.ncon_max = NCON_MAX_MG if self.multi_geom else NCON_MAX           # contact records of the parity tap (include/kinova_sim.h)
         self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))

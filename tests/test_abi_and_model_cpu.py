@@ -106,7 +106,8 @@ def test_all_shapes_have_blobs(assets_dir):
     # every shape key the reference's experiment stages can ask for has a compiled model (main_DDPGfD.py:1270-1281)
     from kinovagrasping_amd import curriculum
     keys = {s + z for s in curriculum.TRAIN_SHAPES for z in curriculum.TRAIN_SIZES} | {s + z for s in curriculum.TEST_SHAPES for z in curriculum.TEST_SIZES + ["S"]}
-    known = set(scenarios.SHAPES + scenarios.MEDIUM_SHAPES + scenarios.MULTI_GEOM_SHAPES)
+    known = set(scenarios.SHAPES + scenarios.MEDIUM_SHAPES + scenarios.EXTRA_SHAPES + scenarios.MULTI_GEOM_SHAPES)      # = the 42 keys of KinovaGripper_Env.all_objects (ENV:150-208)
+    assert len(known) == 42
     assert keys <= known, keys - known
     assert all((assets_dir / f"{k}.ksm").exists() for k in known)
 

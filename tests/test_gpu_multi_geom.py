@@ -73,11 +73,11 @@ def teacher_forced(shape, precision, hq, rec):
     return eq, ev, ncon, np.array([r[3] for r in rec]), status
 
 
-@pytest.mark.parametrize("shape,pose", [(s_, "normal") for s_ in SHAPES] + [("BottleS", "top"), ("BowlS", "rotated")])
+@pytest.mark.parametrize("shape,pose", [(s_, "normal") for s_ in SHAPES] + [("BottleS", "top"), ("BowlS", "rotated"), ("HourB", "normal"), ("LemonS", "normal")])
 def test_multi_geom_one_step_matches_oracle(shape, pose):
     hq, rec = oracle_grasp(shape, pose=pose)
     pairs = sorted({p for r in rec for p in r[4]})
-    assert any(b > 8 for a, b in pairs), "the scripted grasp must touch welded pieces (geoms 9..)"
+    assert any(b > 8 for a, b in pairs) or shape.startswith("Lemon"), "the scripted grasp must touch welded pieces (geoms 9..)"     # (Lemon: one geom, 2434-vertex hull)
     eq, ev, ncon, onc, status = teacher_forced(shape, 64, hq, rec)
     print(f"{shape} {pose}: contact pairs seen {pairs}; fp64 one-step |dqpos| max {eq.max():.2e}, |dqvel| max {ev.max():.2e}")
     assert (status == 0).all() and (ncon == onc).all()

@@ -110,7 +110,8 @@ def test_env_step_and_observation(blob, prec, tol):
 
 def test_shapes_load_and_rest(assets_dir):
     """every README shape: kernel-source lane and oracle agree on a drop-and-rest run (fp64)"""
-    for shape in ("CylinderB", "Cone1S", "Vase2B", "Cube45S", "Vase1M", "Cone2M"):          # (the M size: the experiment mode's test objects)
+    for shape in ("CylinderB", "Cone1S", "Vase2B", "Cube45S", "Vase1M", "Cone2M", "VaseM", "VaseS"):     # (M size: the experiment mode's test objects; Vase: another
+                                                                                                        # single-geom families of the env's object table)
         blob = scenarios.model_blob(shape)
         m = ko.OracleModel(blob)
         hq = scenarios.hand_quat_for("normal")

@@ -10,7 +10,7 @@ from kinovagrasping_amd import model_compiler as mc, scenarios
 from kinovagrasping_amd.sim import SOLVER_ITERATIONS
 from tests.native_build import Lane
 
-PIECES = {"Bottle": 5, "TBottle": 5, "Bowl": 9, "RBowl": 5}
+PIECES = {"Bottle": 5, "TBottle": 5, "Bowl": 9, "RBowl": 5, "Hour": 3}
 
 
 def kind(shape):
@@ -87,7 +87,7 @@ def test_hull_graphs_of_the_pieces_have_no_local_maxima(assets_dir):
     every vertex that is not the maximiser of a direction has a strictly better neighbour - checked on 300 directions per hull
     (with the support skew of ko_physics.c / ks_core.h applied, as both do)"""
     rng = np.random.default_rng(0)
-    for shape in ("BottleS", "TBottleS", "BowlS", "RBowlS"):
+    for shape in ("BottleS", "TBottleS", "BowlS", "RBowlS", "LemonS", "HourS", "VaseB"):
         M = mc.read_blob(assets_dir / f"{shape}.ksm")
         for s in range(3, len(M["geom_body"]) - 5):
             V, off, adj = M[f"mesh{s}_vert"], M[f"mesh{s}_adj_off"], M[f"mesh{s}_adj"]
@@ -109,7 +109,8 @@ def in_hand_start(shape):
 
 
 @pytest.mark.parametrize("shape,pose", [("BottleS", "normal"), ("TBottleM", "normal"), ("BowlS", "normal"), ("RBowlB", "normal"),
-                                        ("BottleS", "top"), ("TBottleS", "top"), ("BowlS", "rotated"), ("RBowlS", "rotated")])
+                                        ("BottleS", "top"), ("TBottleS", "top"), ("BowlS", "rotated"), ("RBowlS", "rotated"),
+                                        ("HourM", "normal"), ("LemonM", "normal"), ("LemonS", "top")])     # (Lemon: ONE geom, but a 2434-vertex hull: the multi-geom library's tables in global memory)
 def test_multi_geom_kernel_source_reproduces_oracle_substeps(shape, pose):
     """the kernel source with the multi-geom capacities, one lane on the host, against the oracle through a scripted grasp that touches
     welded pieces (plane contacts of the pieces, finger- and palm-piece hull pairs, lift) in the three hand poses: fp64 to round-off, fp32
@@ -139,7 +140,7 @@ def test_multi_geom_kernel_source_reproduces_oracle_substeps(shape, pose):
         assert st == 0
         e32.append(np.abs(qp - s.view("qpos")).max())
     print(f"{shape} {pose}: pairs {sorted(pairs)}; fp64 lane worst {max(e64):.2e}; fp32 lane median {np.median(e32):.2e} max {max(e32):.2e}")
-    assert any(b > 8 for a, b in pairs) and any(a > 0 and b >= 8 for a, b in pairs)
+    assert (any(b > 8 for a, b in pairs) or shape.startswith("Lemon")) and any(a > 0 and b >= 8 for a, b in pairs)
     assert max(e64) < 1e-9
     assert np.median(e32) < 2e-7 and max(e32) < 3e-3
 
@@ -169,6 +170,12 @@ def test_standard_build_refuses_a_multi_geom_blob(capfd):
     with pytest.raises(AssertionError):
         Lane(scenarios.model_blob("BowlS"), 64, multi_geom=False)
     assert "multi-geom" in capfd.readouterr().err
+    with pytest.raises(AssertionError):                              # ... and a single-geom object whose hull is beyond its 1024 vertices
+        Lane(scenarios.model_blob("LemonS"), 64, multi_geom=False)
+    assert "1 .. 1024 vertices" in capfd.readouterr().err
+    from kinovagrasping_amd import sim as ks
+    assert ks.blob_needs_mg_library(scenarios.model_blob("LemonB")) and not ks.blob_is_multi_geom(scenarios.model_blob("LemonB"))
+    assert ks.blob_is_multi_geom(scenarios.model_blob("HourM")) and not ks.blob_needs_mg_library(scenarios.model_blob("VaseS"))
 
 
 def test_multi_geom_library_exports_the_simulator_abi():

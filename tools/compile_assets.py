@@ -16,13 +16,15 @@ SHAPES = [s + z for s in ["Cube", "Cylinder", "Cube45", "Cone1", "Cone2", "Vase1
 MEDIUM = [s + "M" for s in ["Cube", "Cylinder", "Cube45", "Cone1", "Cone2", "Vase1", "Vase2"]]   # the experiment mode's test size (main_DDPGfD.py:1280-1281)
 PRIMITIVES = ["mbox", "bbox", "scyl", "mcyl", "bcyl"]      # the env's default model (ENV:62) and its primitive siblings
 # multi-geom objects (welded pieces), the reference's shape keys -> files (kinova_gripper_env.py:189-208)
-MULTI_GEOM = {f"{key}{z}": f"{z.lower()}{stem}" for key, stem in [("Bottle", "bottle"), ("Bowl", "RoundBowl"), ("TBottle", "tbottle"), ("RBowl", "RectBowl")] for z in "SMB"}
+# the other single-geom families of KinovaGripper_Env.all_objects (kinova_gripper_env.py:181-200): vase, lemon stand-in
+EXTRA = {f"{key}{z}": f"{z.lower()}{stem}" for key, stem in [("Vase", "vase"), ("Lemon", "lemon")] for z in "SMB"}
+MULTI_GEOM = {f"{key}{z}": f"{z.lower()}{stem}" for key, stem in [("Bottle", "bottle"), ("Bowl", "RoundBowl"), ("TBottle", "tbottle"), ("RBowl", "RectBowl"), ("Hour", "hg")] for z in "SMB"}    # (Hour: the hourglass, three pieces)
 
 
 def main():
     OUT.mkdir(exist_ok=True)
-    for shape in SHAPES + MEDIUM + PRIMITIVES + list(MULTI_GEOM):
-        M = mc.compile_model(KD / f"j2s7s300_end_effector_v1_{MULTI_GEOM.get(shape, shape)}.xml")
+    for shape in SHAPES + MEDIUM + PRIMITIVES + list(EXTRA) + list(MULTI_GEOM):
+        M = mc.compile_model(KD / f"j2s7s300_end_effector_v1_{MULTI_GEOM.get(shape, EXTRA.get(shape, shape))}.xml")
         hand = {k: M.pop(k) for k in mc.HAND_RAY_KEYS}          # identical for every object: stored once
         if shape == SHAPES[0]:
             mc.write_blob(hand, OUT / "hand_raymesh.kst")
@@ -32,7 +34,7 @@ def main():
     # start-coordinate tables (no_noise; SURVEY note N5), float64 [rows,3]
     tables = {}
     for orient in ["Normal", "Rotated", "Top"]:
-        for shape in SHAPES + MEDIUM + list(MULTI_GEOM):
+        for shape in SHAPES + MEDIUM + list(EXTRA) + list(MULTI_GEOM):
             p = KD / "obj_hand_coords" / "no_noise" / "train_coords" / orient / f"{shape}.txt"
             if p.exists():
                 tables[f"{orient}/{shape}"] = mc.load_coords_table(p)[:, :3].astype(np.float32)
@@ -43,7 +45,7 @@ def main():
     # between classes; they are shipped so that reset(with_noise="tables") can reproduce the reference's default start states as they are.
     noisy = {}
     for orient in ["normal", "rotated", "top"]:
-        for shape in SHAPES + MEDIUM:
+        for shape in SHAPES + MEDIUM + list(EXTRA):
             p = KD / "obj_hand_coords" / "with_noise" / "train_coords" / orient / f"{shape}.txt"
             if p.exists():
                 noisy[f"{orient}/{shape}"] = mc.load_coords_table(p)[:, :6].astype(np.float32)
