@@ -49,8 +49,8 @@ HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/
 
 def shape_states(n: int, shape: str):
     """start states of the single-object workloads: BASELINE config 2's rows of the shape's no_noise table; for a multi-geom object
-    (--shape BottleS ...: libkinova_sim_mg.so) its main piece placed in the hand - the reference's tables leave those objects 0.19 m
-    from the hand (CAD origins of the STL pieces)"""
+    (--shape BottleS ...: libkinova_sim_mg.so) its main piece placed in the hand at body height 0 - the reference's reset moves the `object`
+    geom's centre onto the table row in ALL three coordinates, which buries these objects in the floor"""
     import numpy as np
     from kinovagrasping_amd import scenarios
     if shape not in scenarios.MULTI_GEOM_SHAPES:
@@ -555,7 +555,7 @@ def main():
                                     "env-step (BASELINE config 3; config 4 when n_gpus=8)") if args.mode == "ddpg" else
                                    (f"{n} envs/GPU {args.shape} normal-pose grasp sim, PCG64(1000+i) random-action rollout (BASELINE config 2 at the "
                                     "metric's env count); sim kernels only"),
-                       "reset": ("multi-geom object: main piece placed in the hand (+-3 cm), not the reference's start tables - they leave these objects 0.19 m from the hand (DESIGN.md 2a); "
+                       "reset": ("multi-geom object: main piece placed in the hand (+-3 cm) at body height 0, not the reference's reset (table row + its 5 cm correction buries these objects in the floor, DESIGN.md 2a); "
                                  if (not mixed and args.shape in scenarios.MULTI_GEOM_SHAPES) else "") +
                                 ("every env restarts from its own row of the reference's no_noise start table (obj_hand_coords/no_noise/train_coords), no orientation "
                                  "noise; hand slide offsets of the pose ('pose' mode)  [reference defaults: with_noise=True - tables SURVEY N5 shows to be "

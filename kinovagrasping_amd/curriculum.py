@@ -149,6 +149,7 @@ def run_stage(plan, policy, n_envs: int = 1024, rounds: int = 10, updates_per_ro
                 q[9:12, e] = tab[rng.randint(0, len(tab))]
             else:
                 q[9:12, e] = scenarios.fallback_start(shape, o, rng)
+            q[9:12, e] = scenarios.reset_body_position(shape, q[9:12, e])          # the reference reset's 5 cm correction (ENV:1379-1386)
             hq[:, e] = scenarios.hand_quat_for(o)
             classes.append(o)
         return the_sim.reset(torch.as_tensor(q), torch.as_tensor(hq)), classes

@@ -80,6 +80,24 @@ def fallback_start(shape: str, orientation: str, rng=np.random) -> np.ndarray:
     return np.array([x, y, size[-1] / 2])
 
 
+_object_geom_offset = {}
+
+
+def reset_body_position(shape: str, commanded_xyz) -> np.ndarray:
+    """Where KinovaGripper_Env.reset leaves the object's BODY for a commanded start (x, y, z) (kinova_gripper_env.py:1367-1386): it writes
+    the commanded coordinates into the free joint, reads back the pose of the geom named `object` (`_get_obj_pose`, :564-566), and when
+    that lies more than 5 cm from the commanded point it writes `commanded + (commanded - geom pose)` instead - i.e. it moves the `object`
+    geom's CENTRE onto the commanded point, in all three coordinates.  That is what brings the objects whose STL files carry a CAD origin
+    (the bottles' main piece sits 0.19 m from its body origin, the hourglass 7.5 cm, the lemon 5.3 cm) into the hand - and, with the start
+    tables' z values that were chosen for the body origin (Bottle: -0.01), what buries them in the floor.  README shapes: offset ~0, unchanged."""
+    if shape not in _object_geom_offset:
+        from .model_compiler import read_blob
+        _object_geom_offset[shape] = read_blob(ASSETS / f"{shape}.ksm")["geom_pos"][8].copy()
+    g = _object_geom_offset[shape]                       # the reset quaternion is the identity: geom pose = body position + g
+    c = np.asarray(commanded_xyz, dtype=np.float64)
+    return c - g if np.linalg.norm(g) > 0.05 else c.copy()
+
+
 def hand_quat_for(orientation: str) -> np.ndarray:
     """Quaternion of j2s7s300_link_7 for an orientation class, including the 5-character string
     truncation the reference applies when patching the XML (kinova_gripper_env.py:870-874)."""

@@ -206,7 +206,8 @@ class KinovaGripperVecEnv:
                 q[9:12, k] = scenarios.fallback_start(shape, o, self.np_random)
                 self.orientation_idx[e] = -1
             q[0:3, k] = scenarios.hand_slide_offsets(o, shape, self.hand_offsets)
-            self.obj_coords[e] = q[9:12, k]
+            self.obj_coords[e] = q[9:12, k]                                   # what the reference records: the COMMANDED point (ENV:1394)
+            q[9:12, k] = scenarios.reset_body_position(shape, q[9:12, k])     # ... and where its 5 cm correction leaves the body (ENV:1379-1386)
             self.hand_quat[:, e] = hq[:, k]
         t_ids = None if env_ids is None else torch.as_tensor(ids, dtype=torch.int32)
         obs = self.sim.reset(torch.as_tensor(q), torch.as_tensor(hq), t_ids, object_id=self.shape_id[ids].copy() if multi else None,

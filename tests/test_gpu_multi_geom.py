@@ -7,8 +7,10 @@ a scripted grasp (plane contacts of the pieces, finger-piece hull pairs, lift): 
 (2) whole env.step()s - 15 substeps, the 17 rangefinders over all pieces' triangles, the 82-d observation, reward and done -
 against the oracle's env_step; (3) a single-geom object inside the same context (the multi-geom library holds both).
 
-Where the objects are: the reference's STL pieces carry their CAD origin (the short bottle's centre of mass sits 0.19 m from the
-body origin), so the scripted grasps below place the MAIN piece's centre where a cube would start instead of using the start tables."""
+Where the objects are: the reference's STL pieces carry their CAD origin (the short bottle's main piece sits 0.19 m from the body origin);
+the reference's reset compensates by moving the `object` geom's centre onto the commanded point in all three coordinates
+(scenarios.reset_body_position, ENV:1379-1386) - which, with the start tables' z values, buries these objects in the floor.  The scripted
+grasps below place the MAIN piece's centre over the world origin at body height 0 instead."""
 import numpy as np
 import pytest
 import torch
@@ -240,9 +242,12 @@ def test_vec_env_with_multi_geom_shapes_of_a_stage():
     assert seen_fallback >= 1
     for e in (0, 7, 19, n - 1):
         o = ko.OracleSim(ko.OracleModel(scenarios.model_blob(names[e])), scenarios.hand_quat_for(poses[e]), solver_iterations=SOLVER_ITERATIONS)
-        q0 = np.zeros(16); q0[9:12] = env.get_obj_coords()[e]; q0[12] = 1
+        q0 = np.zeros(16); q0[9:12] = scenarios.reset_body_position(names[e], env.get_obj_coords()[e]); q0[12] = 1     # (the reference reset's 5 cm correction)
         q0[0:3] = scenarios.hand_slide_offsets(poses[e], names[e])
-        np.testing.assert_allclose(obs[e].double().cpu().numpy(), o.env_reset(q0), rtol=2e-4, atol=2e-5)
+        ref = o.env_reset(q0)
+        np.testing.assert_allclose(obs[e].double().cpu().numpy(), ref, rtol=2e-4, atol=2e-5)
+        if names[e] in scenarios.MULTI_GEOM_SHAPES:                      # the `object` geom's centre sits ON the commanded point (world frame)
+            assert np.abs(o.view("geom_xpos").reshape(-1, 3)[8] - env.get_obj_coords()[e]).max() < 1e-12
     a = torch.zeros(n, 4); a[:, 1:] = 0.4
     for _ in range(3):
         obs2, rew, done, info = env.step(a)

@@ -199,3 +199,22 @@ def test_start_tables_and_the_fallback_rule():
     p = np.array([scenarios.fallback_start("BowlS", "normal", rng) for _ in range(200)])
     assert np.hypot(p[:, 0], p[:, 1]).max() <= 0.1225 / 2 and np.allclose(p[:, 2], 0.049 / 2)
     assert np.allclose(scenarios.fallback_start("BowlS", "rotated", rng), [0, 0, 0.0245])
+
+
+def test_reset_correction_of_the_reference_moves_the_object_geom_onto_the_commanded_point():
+    """KinovaGripper_Env.reset (kinova_gripper_env.py:1367-1386): commanded point -> free joint, read the `object` geom's pose back, and if it is
+    more than 5 cm off write commanded + (commanded - pose).  Restated literally on the oracle and compared with scenarios.reset_body_position."""
+    cmd = np.array([0.0425, 0.004, -0.01])
+    for shape, moved in (("CubeS", False), ("Vase2B", False), ("BottleS", True), ("BowlM", True), ("HourS", True), ("LemonS", True), ("RBowlB", True)):
+        o = ko.OracleSim(ko.OracleModel(scenarios.model_blob(shape)), scenarios.hand_quat_for("normal"), solver_iterations=SOLVER_ITERATIONS)
+        q = np.zeros(16); q[12] = 1.0; q[9:12] = cmd
+        o.set_state(q); o.forward()
+        pose = o.view("geom_xpos").reshape(-1, 3)[8].copy()
+        deltas = cmd - pose
+        expect = cmd + deltas if np.linalg.norm(deltas) > 0.05 else cmd
+        got = scenarios.reset_body_position(shape, cmd)
+        assert np.abs(got - expect).max() < 1e-12 and (np.abs(got - cmd).max() > 0.01) == moved, shape
+        q[9:12] = got
+        o.set_state(q); o.forward()
+        if moved:
+            assert np.abs(o.view("geom_xpos").reshape(-1, 3)[8] - cmd).max() < 1e-12

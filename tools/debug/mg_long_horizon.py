@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Dev-only (GPU box): free-running long-horizon parity of the MULTI-GEOM objects - the main piece placed in the hand (the reference's
-start tables leave the bottles 0.19 m from the hand: CAD origins), 6 starts per object, closing grasp + lift script, 210 substeps;
+"""Dev-only (GPU box): free-running long-horizon parity of the MULTI-GEOM objects - the main piece placed in the hand at body height 0 (the reference's
+reset: see scenarios.reset_body_position), 6 starts per object, closing grasp + lift script, 210 substeps;
 fp32 and fp64 instantiations of libkinova_sim_mg.so against the fp64 oracle (tests/studies/long_horizon.py machinery)."""
 import sys
 from pathlib import Path
