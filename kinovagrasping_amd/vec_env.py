@@ -130,6 +130,10 @@ class KinovaGripperVecEnv:
             return self.obj_keys.pop()
         return shape_keys[self.np_random.randint(0, len(shape_keys))]
 
+    def _obj_size_last(self, shape):
+        """_get_obj_size()[-1] of a shape (the observation's third size slot is twice that, ENV:529)"""
+        return float(read_blob(scenarios.model_blob(shape))["obj_size_obs"][2]) / 2.0
+
     def set_with_grasp_reward(self, with_grasp):
         if with_grasp:
             raise NotImplementedError("the grasp-classifier reward needs gc_model.pkl, which the reference does not ship "
@@ -146,10 +150,17 @@ class KinovaGripperVecEnv:
 
     def reset(self, shape_keys=None, hand_orientation="normal", with_grasp=False, env_name="env", mode="train", start_pos=None,
               obj_params=None, qpos=None, obj_coord_region=None, with_noise=False, env_ids=None):
-        """Reset all envs (or `env_ids`).  start_pos: optional [n,3] object positions; otherwise rows are
+        """Reset all envs (or `env_ids`).  start_pos: optional per-env rows as the reference's test hook takes them (ENV:1347-1363): 3 values =
+        object x, y, z; 2 values = object x, y at height _get_obj_size()[-1]; 9 values = the three slides, the three proximal
+        joints, object x, y, z.  Otherwise rows are
         sampled from the no_noise start-coordinate table of the shape (ENV:1008-1054, SURVEY note N5).
-        obj_params: the reference's [shape, size] test hook is not supported; a [2, n] ARRAY here is the config-5
-        extension (per-env object mass, object-hand friction).  With several objects loaded every reset env draws its
+        obj_coord_region (ENV:1032-1046): "left" / "center" / "target" / "right" = a random row among those whose x
+        lies in the region - indexed, as the reference does, into the WHOLE file with the index it drew from the region's rows -; "origin" = (0, 0)
+        at the height of the file's first row.
+        obj_params: the reference's [shape, size] test hook (ENV:1171-1178: every reset env gets object shape + size, which must be among the
+        env's objects); a [2, n] ARRAY here is the config-5
+        extension (per-env object mass, object-hand friction).  qpos: [n, 16] full joint vectors written as they are (`set_sim_state`, ENV:349-353).
+        With several objects loaded every reset env draws its
         object from `shape_keys` (default: all loaded) - Latin-square queue first, see select_object.
         Slide offsets of the 'rotated' / 'top' hands: see `hand_offsets` of the constructor.
         with_noise=True: orientation noise as SURVEY note N5 prescribes - the class's no-noise Euler constants (ENV:1267-1273) plus
@@ -173,41 +184,74 @@ class KinovaGripperVecEnv:
         q[12] = 1.0
         multi = isinstance(self.random_shape, list)
         keys = [k for k in (shape_keys or self.shapes)]
+        forced = None
+        if isinstance(obj_params, (list, tuple)):
+            if len(obj_params) != 2 or not all(isinstance(x, str) for x in obj_params):
+                raise ValueError("reset: obj_params is [shape, size] (e.g. ['Cube', 'S']) or a [2, n] array of mass / friction")
+            forced = obj_params[0] + obj_params[1]
+            if forced not in self.shapes:
+                raise ValueError(f"reset: obj_params {obj_params} -> {forced}, not among the env's objects {self.shapes}")
+        regions = {"left": (-.09, -.03), "center": (-.03, .03), "target": (-.01, .01), "right": (.03, .09)}
+        if obj_coord_region is not None and obj_coord_region != "origin" and obj_coord_region not in regions:
+            raise ValueError(f"reset: obj_coord_region {obj_coord_region!r}")
         if multi and any(k not in self.shapes for k in keys):
             raise ValueError(f"shape_keys {keys} not all among the env's objects {self.shapes}")
         for k, e in enumerate(ids):
             if multi:
-                name = self.select_object(keys)
+                name = forced if forced is not None else self.select_object(keys)
                 self.random_shape[e], self.shape_id[e] = name, self.shapes.index(name)
             shape = self.random_shape[e] if multi else self.random_shape
             o = self.select_orienation(hand_orientation, shape)
             self.orientation[e] = o
+            def pick_row(tab):
+                """row index as sample_initial_object_hand_pos draws it (ENV:1029-1048); -1 = the "origin" region"""
+                if obj_coord_region == "origin":
+                    return -1
+                if obj_coord_region is not None:
+                    lo, hi = regions[obj_coord_region]
+                    return self.np_random.randint(0, int(((tab[:, 0] >= lo) & (tab[:, 0] <= hi)).sum()))     # (sic: an index INTO the region's rows,
+                return self.np_random.randint(0, len(tab))                                                 #  used on the whole file)
+
             noisy = scenarios.noisy_start_table(shape, o) if (with_noise == "tables" and start_pos is None) else None
             if noisy is not None:
-                row = self.np_random.randint(0, len(noisy))
-                eul = truncated_euler(noisy[row, 3:6])
+                row = pick_row(noisy)
+                eul = truncated_euler(noisy[row, 3:6]) if row >= 0 else np.zeros(3)                          # (origin: hand Euler 0, 0, 0, ENV:1040)
             else:
                 eul = scenarios.hand_euler_for(o, self.np_random if with_noise is True else None)
             self.hand_euler[e] = eul
             hq[:, k] = euler_to_quat(eul)
             if noisy is not None:
-                q[9:12, k] = noisy[row, :3]
+                q[9:12, k] = noisy[row, :3] if row >= 0 else [0.0, 0.0, noisy[0, 2]]
                 self.orientation_idx[e] = row
             elif start_pos is not None:
-                q[9:12, k] = np.asarray(start_pos)[k][:3]
+                sp = np.asarray(start_pos[k], dtype=np.float64)
+                if len(sp) == 3:
+                    q[9:12, k] = sp
+                elif len(sp) == 2:                                                    # z = _get_obj_size()[-1] (the observation stores twice that)
+                    q[9:12, k] = [sp[0], sp[1], self._obj_size_last(shape)]
+                elif len(sp) == 9:
+                    q[9:12, k] = sp[6:9]
+                else:
+                    raise ValueError("reset: a start_pos row has 3, 2 or 9 values")
                 self.orientation_idx[e] = -1
             elif scenarios.has_start_table(shape, o):
                 tab = scenarios.start_coord_table(shape, o)
-                row = self.np_random.randint(0, len(tab))
-                q[9:12, k] = tab[row]
+                row = pick_row(tab)
+                q[9:12, k] = tab[row] if row >= 0 else [0.0, 0.0, tab[0][2]]
                 self.orientation_idx[e] = row
             else:
                 # no coordinate file for this (shape, orientation) in the reference (Normal/BowlS ...): its empty-file rule (ENV:1243-1249, 821-849)
                 q[9:12, k] = scenarios.fallback_start(shape, o, self.np_random)
                 self.orientation_idx[e] = -1
             q[0:3, k] = scenarios.hand_slide_offsets(o, shape, self.hand_offsets)
+            if start_pos is not None and len(start_pos[k]) == 9:
+                sp = np.asarray(start_pos[k], dtype=np.float64)
+                q[0:3, k] = sp[0:3]
+                q[[3, 5, 7], k] = sp[3:6]
             self.obj_coords[e] = q[9:12, k]                                   # what the reference records: the COMMANDED point (ENV:1394)
             q[9:12, k] = scenarios.reset_body_position(shape, q[9:12, k])     # ... and where its 5 cm correction leaves the body (ENV:1379-1386)
+            if qpos is not None:                                              # set_sim_state: the given joint vector, as it is
+                q[:, k] = np.asarray(qpos[k], dtype=np.float64)
             self.hand_quat[:, e] = hq[:, k]
         t_ids = None if env_ids is None else torch.as_tensor(ids, dtype=torch.int32)
         obs = self.sim.reset(torch.as_tensor(q), torch.as_tensor(hq), t_ids, object_id=self.shape_id[ids].copy() if multi else None,

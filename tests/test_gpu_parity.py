@@ -724,6 +724,46 @@ def test_vec_env_keeps_the_reference_interface():
     env.close()
 
 
+def test_vec_env_reset_test_hooks_of_the_reference():
+    """reset()'s test hooks as the reference has them (ENV:1310-1363, 1029-1048, 1171-1178, 349-353): obj_params [shape, size], start_pos rows of 3 / 2 /
+    9 values, obj_coord_region (incl. the reference's index slip: the row index is drawn among the region's rows and used on the whole file), qpos."""
+    from kinovagrasping_amd.vec_env import KinovaGripperVecEnv
+    n = 12
+    env = KinovaGripperVecEnv(n, ["CubeS", "CylinderB", "Vase2S"], seed=21, auto_reset=False)
+    env.reset(obj_params=["Cylinder", "B"])
+    assert env.get_random_shape() == ["CylinderB"] * n
+    with pytest.raises(ValueError):
+        env.reset(obj_params=["Cone1", "S"])
+    size_b = float(mc_read("CylinderB")["obj_size_obs"][2]) / 2
+    sp = [[0.01, 0.02, 0.07]] * 4 + [[-0.02, 0.03]] * 4 + [[0.0, 0.0, 0.01, 0.3, 0.2, 0.1, 0.02, 0.01, 0.066]] * 4
+    env.reset(obj_params=["Cylinder", "B"], start_pos=sp)
+    q = env.sim.get_state()["qpos"].double().cpu().numpy()
+    assert np.allclose(q[9:12, 0], [0.01, 0.02, 0.07], atol=1e-6) and np.allclose(q[9:12, 5], [-0.02, 0.03, size_b], atol=1e-6)
+    assert np.allclose(q[[0, 1, 2, 3, 5, 7], 9], [0.0, 0.0, 0.01, 0.3, 0.2, 0.1], atol=1e-6) and np.allclose(q[9:12, 9], [0.02, 0.01, 0.066], atol=1e-6)
+    assert np.allclose(env.get_obj_coords()[5], [-0.02, 0.03, size_b])
+    # regions
+    tab = scenarios.start_coord_table("CubeS", "normal")
+    for region, (lo, hi) in {"left": (-.09, -.03), "center": (-.03, .03), "target": (-.01, .01), "right": (.03, .09)}.items():
+        env.reset(obj_params=["Cube", "S"], obj_coord_region=region)
+        count = int(((tab[:, 0] >= lo) & (tab[:, 0] <= hi)).sum())
+        idx = np.asarray(env.get_orientation_idx())
+        assert (idx >= 0).all() and (idx < count).all()                          # drawn among the region's rows ...
+        assert all(np.array_equal(env.get_obj_coords()[e], tab[idx[e]]) for e in range(n))      # ... and used on the whole file (sic)
+    env.reset(obj_params=["Cube", "S"], obj_coord_region="origin")
+    assert np.allclose(env.get_obj_coords(), np.array([0.0, 0.0, tab[0][2]])[None])
+    # qpos: the given joint vector as it is
+    qq = np.zeros((n, 16)); qq[:, 12] = 1; qq[:, 9:12] = [0.0, 0.01, 0.08]; qq[:, 3] = 0.25; qq[:, 4] = 0.125
+    obs = env.reset(obj_params=["Cube", "S"], qpos=qq, start_pos=[[0.0, 0.01, 0.08]] * n)
+    q = env.sim.get_state()["qpos"].double().cpu().numpy()
+    assert np.allclose(q, qq.T, atol=1e-6) and torch.isfinite(obs).all()
+    env.close()
+
+
+def mc_read(shape):
+    from kinovagrasping_amd import model_compiler
+    return model_compiler.read_blob(scenarios.model_blob(shape))
+
+
 def test_vec_env_reference_with_noise_tables_mode():
     """reset(with_noise="tables"): the reference's DEFAULT start states as they are (ENV:1310, 1019-1021, 1254-1255) - object position AND hand
     Euler triple of a random row of the shape's with_noise file, truncated to 5 characters; every env's reset observation equals the oracle's
