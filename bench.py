@@ -48,18 +48,20 @@ HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/
 
 
 def shape_states(n: int, shape: str):
-    """start states of the single-object workloads: BASELINE config 2's rows of the shape's no_noise table; for a multi-geom object
-    (--shape BottleS ...: libkinova_sim_mg.so) its main piece placed in the hand at body height 0 - the reference's reset moves the `object`
-    geom's centre onto the table row in ALL three coordinates, which buries these objects in the floor"""
+    """start states of the single-object workloads: BASELINE config 2's rows of the shape's no_noise table ('normal' class), through the
+    reference reset's 5 cm correction (scenarios.reset_body_position: it moves the `object` geom's centre of a multi-geom object onto
+    the row; a no-op for the README shapes) - or, where the reference ships no 'normal' table (the bowls), its empty-file rule."""
     import numpy as np
     from kinovagrasping_amd import scenarios
-    if shape not in scenarios.MULTI_GEOM_SHAPES:
+    if shape in scenarios.SHAPES:
         return scenarios.config2_states(n, shape)
-    from kinovagrasping_amd.model_compiler import read_blob
-    g = read_blob(scenarios.model_blob(shape))["geom_pos"][8]
-    i = np.arange(n)
     q = np.zeros((16, n))
-    q[9], q[10], q[12] = -g[0] + 0.03 * np.sin(1.7 * i), -g[1] + 0.015 * np.cos(2.3 * i), 1.0
+    q[12] = 1.0
+    rng = np.random.RandomState(2)
+    tab = scenarios.start_coord_table(shape) if scenarios.has_start_table(shape, "normal") else None
+    for i in range(n):
+        cmd = tab[i % (len(tab) - 1)] if tab is not None else scenarios.fallback_start(shape, "normal", rng)
+        q[9:12, i] = scenarios.reset_body_position(shape, cmd)
     return q, np.repeat(scenarios.hand_quat_for("normal")[:, None], n, axis=1)
 
 
@@ -555,8 +557,8 @@ def main():
                                     "env-step (BASELINE config 3; config 4 when n_gpus=8)") if args.mode == "ddpg" else
                                    (f"{n} envs/GPU {args.shape} normal-pose grasp sim, PCG64(1000+i) random-action rollout (BASELINE config 2 at the "
                                     "metric's env count); sim kernels only"),
-                       "reset": ("multi-geom object: main piece placed in the hand (+-3 cm) at body height 0, not the reference's reset (table row + its 5 cm correction buries these objects in the floor, DESIGN.md 2a); "
-                                 if (not mixed and args.shape in scenarios.MULTI_GEOM_SHAPES) else "") +
+                       "reset": ("the reference reset's 5 cm correction moves the `object` geom's centre onto the table row (scenarios.reset_body_position: a bottle starts "
+                                  "buried and is lifted out by its floor contacts within an env-step); " if (not mixed and args.shape not in scenarios.SHAPES) else "") +
                                 ("every env restarts from its own row of the reference's no_noise start table (obj_hand_coords/no_noise/train_coords), no orientation "
                                  "noise; hand slide offsets of the pose ('pose' mode)  [reference defaults: with_noise=True - tables SURVEY N5 shows to be "
                                  "biased and swapped between classes - and, in its training driver, zero hand offsets: vec_env.KinovaGripperVecEnv(hand_offsets="

@@ -177,7 +177,7 @@ def test_bench_line_on_a_multi_geom_object():
     r = run_bench(["--shape", "TBottleS", "--steps", "20", "--warmup", "10", "--init-policy", "none", "--pretrain-updates", "60", "--steady-steps", "30", "--no-cpu-baseline"])
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert "TBottleS" in d["config"]["workload"] and "multi-geom object" in d["config"]["reset"]
+    assert "TBottleS" in d["config"]["workload"] and "5 cm correction" in d["config"]["reset"]
     assert d["config"]["free_running"] is not None and d["config"]["free_running"]["episodes_dropped"] == 0
     assert d["roofline"]["traffic"] is None and d["value"] > 1e6
     assert all(v == 0 for v in d["status_counts"].values()) and d["nonfinite_envs"] == 0
