@@ -58,6 +58,7 @@ class KinovaGripperVecEnv:
         M = read_blob(scenarios.model_blob(self.shapes[0]))        # hand constants for Tfw (the same in every object's blob)
         self._l7_pos, self._slide_axis = M["body_pos"][2], M["slide_axis"]
         self._palm_pos, self._palm_quat = M["geom_pos"][1], M["geom_quat"][1]
+        self._obj_geom_pos = {}
 
     # -- reference-compatible accessors -----------------------------------------------------------
     def seed(self, seed=None):
@@ -101,6 +102,38 @@ class KinovaGripperVecEnv:
             wrist = pp + T.T @ np.array([-0.009, 0.048, 0.0])
             out[e, :3, :3], out[e, :3, 3], out[e, 3, 3] = T, -T @ wrist, 1.0
         return out
+
+    def _get_obj_pose(self):
+        """[N, 3] world position of the geom named `object` at the envs' current state (ENV:564-566; the demonstration drivers read it,
+        expert_data.py:207-208, 249)"""
+        from .model_compiler import quat_to_mat
+        qpos = self.sim.get_state()["qpos"].double().cpu().numpy()
+        names = self.random_shape if isinstance(self.random_shape, list) else [self.random_shape] * self.n_envs
+        out = np.zeros((self.n_envs, 3))
+        for e in range(self.n_envs):
+            if names[e] not in self._obj_geom_pos:
+                self._obj_geom_pos[names[e]] = read_blob(scenarios.model_blob(names[e]))["geom_pos"][8].copy()
+            qn = qpos[12:16, e] / np.linalg.norm(qpos[12:16, e])
+            out[e] = qpos[9:12, e] + quat_to_mat(qn) @ self._obj_geom_pos[names[e]]
+        return out
+
+    def _get_dot_product(self, obj_state=None):
+        """[N] ENV:591-609: 20th power of the dot product of the unit vectors |object - link_7| and |origin - link_7| in the world x-y plane (absolute components, as
+        the reference takes them); obj_state: [N, 3] object positions, default the current ones"""
+        from .model_compiler import quat_to_mat
+        obj = self._get_obj_pose() if obj_state is None else np.asarray(obj_state, dtype=np.float64).reshape(self.n_envs, -1)
+        qpos = self.sim.get_state()["qpos"].double().cpu().numpy()
+        out = np.zeros(self.n_envs)
+        for e in range(self.n_envs):
+            R7 = quat_to_mat(self.hand_quat[:, e] / np.linalg.norm(self.hand_quat[:, e]))
+            hand = self._l7_pos + R7 @ (self._slide_axis.T @ qpos[0:3, e])
+            ov, cv = np.abs(obj[e, :2] - hand[:2]), np.abs(0.0 - hand[:2])
+            out[e] = float((ov / np.linalg.norm(ov)) @ (cv / np.linalg.norm(cv))) ** 20            # "cuspy to get distinct reward" (ENV:608)
+        return out
+
+    def get_all_objects(self):
+        """the reference's object table (ENV:150-208, main_DDPGfD.py:1269): shape key -> model; here the compiled asset of each of the 42 keys"""
+        return {k: str(scenarios.ASSETS / f"{k}.ksm") for k in scenarios.SHAPES + scenarios.MEDIUM_SHAPES + scenarios.EXTRA_SHAPES + scenarios.MULTI_GEOM_SHAPES}
 
     # -- object schedule (ENV:884-1005) --------------------------------------------------------------
     def check_obj_file_empty(self, filename):

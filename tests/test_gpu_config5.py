@@ -171,6 +171,17 @@ def test_vec_env_mixed_objects_and_reference_accessors(tmp_path):
     a = torch.zeros(n, 4); a[:, 1:] = 0.4
     obs2, rew, done, info = env.step(a)
     assert torch.isfinite(obs2).all() and len({tuple(np.round(obs2[e, 33:36].cpu().numpy(), 6)) for e in range(n)}) == len(shapes)
+    # the private accessors the demonstration drivers read (expert_data.py:207-208, 249) against the oracle's kinematics
+    pose, dots = env._get_obj_pose(), env._get_dot_product()
+    qpos = env.sim.get_state()["qpos"].double().cpu().numpy()
+    for e in (0, 5, 31, n - 1):
+        o = ko.OracleSim(ko.OracleModel(scenarios.model_blob(env.get_random_shape()[e])), scenarios.hand_quat_for(env.get_orientation()[e]), solver_iterations=SOLVER_ITERATIONS)
+        o.set_state(qpos[:, e].copy()); o.forward()
+        gx, hand = o.view("geom_xpos").reshape(-1, 3)[8], o.view("xpos").reshape(10, 3)[2]
+        assert np.abs(pose[e] - gx).max() < 1e-6
+        ov, cv = np.abs(gx[:2] - hand[:2]), np.abs(hand[:2])
+        assert abs(dots[e] - float((ov / np.linalg.norm(ov)) @ (cv / np.linalg.norm(cv))) ** 20) < 1e-4
+    assert len(env.get_all_objects()) == 42 and env.get_all_objects()["RBowlM"].endswith("RBowlM.ksm")
     # a partial reset without a queue draws uniformly from the given keys
     env.reset(shape_keys=["Vase2S"], hand_orientation="normal", env_ids=[2, 9])
     assert env.get_random_shape()[2] == "Vase2S" and env.get_random_shape()[9] == "Vase2S"
