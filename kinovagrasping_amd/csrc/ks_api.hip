@@ -1032,7 +1032,7 @@ __global__ void k_store_init(Buffers<T> b, const int32_t* __restrict__ env_ids, 
 
 // The stepping kernel's work list: envs grouped by object model (stable: ascending env id inside a group), every group
 // padded to whole workgroups with -1.  One workgroup of 256 threads; thread t owns a contiguous chunk of envs.
-constexpr int SLOT_THREADS = 256, MODELS_MAX = 32;
+constexpr int SLOT_THREADS = 256, MODELS_MAX = 48;      // (48: the reference's whole object table - 42 keys - fits one context)
 __global__ __launch_bounds__(SLOT_THREADS) void k_slots(const int32_t* __restrict__ obj_id, int N, int n_models, int epw, int n_wg,
                                                           int32_t* __restrict__ slot_env, int32_t* __restrict__ wg_model) {
     __shared__ int cnt[SLOT_THREADS][MODELS_MAX + 1];     // +1: odd stride
@@ -1432,7 +1432,7 @@ template <typename T> struct Ctx : CtxBase {
     }
     int load_models(int nm, const void* const* blobs, const size_t* sizes) override {
         if (model_loaded) { error = "ks_load_model: a context loads its model(s) once"; return KS_ERR_STATE; }
-        if (nm <= 0 || nm > MODELS_MAX) { error = "ks_load_models: between 1 and 32 object models"; return KS_ERR_INVALID; }
+        if (nm <= 0 || nm > MODELS_MAX) { error = "ks_load_models: between 1 and 48 object models"; return KS_ERR_INVALID; }
         std::vector<Model<T>> table(nm);
         std::vector<T> nominal(2 * (size_t)nm);
         hull_words = 0;

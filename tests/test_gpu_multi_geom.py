@@ -273,3 +273,27 @@ def test_multi_geom_fp64_kernels_track_the_oracle_free_running_for_200_substeps(
         worst[sh] = float(res["rel"].max())
     print("multi-geom fp64 kernels vs oracle, free running 200 substeps, worst relative qpos error:", {k: f"{v:.1e}" for k, v in worst.items()})
     assert max(worst.values()) < 1e-9, worst
+
+
+def test_every_object_of_the_reference_in_one_context():
+    """all 42 keys of KinovaGripper_Env.all_objects (ENV:150-208) in ONE context of the multi-geom library, 8 envs each: reset through the
+    reference's reset rule (table row / empty-file rule + the 5 cm correction), three env-steps; every env's reset observation carries its own
+    object's size slots, nothing non-finite, no status flag but the solver cap"""
+    from kinovagrasping_amd.vec_env import KinovaGripperVecEnv
+    shapes = scenarios.SHAPES + scenarios.MEDIUM_SHAPES + scenarios.EXTRA_SHAPES + scenarios.MULTI_GEOM_SHAPES
+    assert len(shapes) == 42
+    n = 8 * len(shapes)
+    env = KinovaGripperVecEnv(n, shapes, seed=1, auto_reset=False)
+    env.Generate_Latin_Square(n, "/tmp/ks_objects_all.csv", shape_keys=shapes)
+    obs = env.reset(shape_keys=shapes, hand_orientation="random")
+    names = env.get_random_shape()
+    assert sorted(set(names)) == sorted(shapes) and all(names.count(s) == 8 for s in shapes)
+    sizes = {sh: mc.read_blob(scenarios.model_blob(sh))["obj_size_obs"] for sh in shapes}
+    got = obs[:, 33:36].cpu().numpy()
+    assert all(np.allclose(got[e], sizes[names[e]], rtol=1e-6) for e in range(n))
+    a = torch.zeros(n, 4); a[:, 1:] = 0.5
+    for _ in range(3):
+        obs, rew, done, info = env.step(a)
+    st = env.sim.get_state()
+    assert torch.isfinite(obs).all() and torch.isfinite(st["qpos"]).all() and (st["status"].cpu().numpy() & ~8 == 0).all()
+    env.close()
