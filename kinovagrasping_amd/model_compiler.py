@@ -593,9 +593,12 @@ def object_size_obs(size, filename, piece_sizes=()):
     """Restatement of KinovaGripper_Env._get_obj_size (kinova_gripper_env.py:706-746); the observation stores
     [s0, s1, 2*s2] (kinova_gripper_env.py:529).  `size`: geom_size of `object`; `piece_sizes`: geom_size of the welded pieces of a
     multi-geom object in geom order (the reference walks the object's geoms from the LAST one back to `object`: widths by maximum,
-    heights summed; the bowls get constants scaled by the size letter of the file name)."""
+    heights summed; the bowls get constants scaled by the env's size letter - 'm' on the drivers' path, see below)."""
     final = np.zeros(3)
-    letter = re.search(r"_v1_([a-zA-Z])", filename)
+    # the size letter the bowls' constants are scaled by is `self.obj_size`, which only __init__ ('m': the default model, ENV:62) and the
+    # obj_params hook (obj_shape_generator, ENV:1057-1147) ever set: an object that comes from the object schedule - every training and
+    # evaluation episode of main_DDPGfD.py (select_object -> get_object, ENV:1171-1172, 986-1005) - is seen with 'm', whatever its file says
+    letter = None
     for size in [np.array(p_, dtype=np.float64) for p_ in list(piece_sizes)[::-1]] + [np.array(size, dtype=np.float64)]:
         size = size.copy()
         if size[2] == 0:
@@ -606,7 +609,7 @@ def object_size_obs(size, filename, piece_sizes=()):
             size[0], size[2] = size[2], size[0]
         if "Bowl" in filename:
             final[:] = [0.17, 0.17, 0.075] if "Rect" in filename else [0.175, 0.175, 0.07]
-            scale = {"m": 0.85, "s": 0.7}.get(letter.group(1) if letter else "b", 1.0)
+            scale = {"m": 0.85, "s": 0.7}.get(letter.group(1) if letter else "m", 1.0)
             if scale != 1.0:
                 final *= scale         # (the reference multiplies component by component: same products)
         else:

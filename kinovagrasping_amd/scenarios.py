@@ -126,7 +126,9 @@ def hand_slide_offsets(orientation: str, shape: str, mode: str = "pose") -> np.n
     Z = 0.13 / 0.15 for S / B objects) with T = Tfw[:3, :3], the world -> palm rotation.
 
     mode "pose": T is the palm rotation of the orientation itself - what the authors intended and what a persistent env
-    (the evaluation loops) uses once it has seen the pose: the hand hovers above / beside the object.
+    (the evaluation loops) uses once it has seen the pose: the hand hovers above / beside the object.  Z follows the SHAPE's size letter,
+    as intended; a reference env whose object came from the object schedule keeps `self.obj_size` at its __init__ value 'm' (ENV:62; only the
+    obj_params hook updates it), i.e. computes Z = 0.14 for every object there (a 1 cm difference in the 'top' hover height of S / B objects).
     mode "fresh-env": zeros - what the training driver actually gets, because it builds a new env for every episode
     (main_DDPGfD.py:381) whose Tfw is still the zero matrix of __init__ (ENV:110) when reset() multiplies by it; the
     'rotated' / 'top' hands then start inside the floor and larger objects inside the hand (SURVEY note N5)."""

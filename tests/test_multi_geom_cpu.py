@@ -62,11 +62,12 @@ def test_multi_geom_asset_structure(shape, assets_dir):
 
 
 def test_object_size_of_multi_geom_objects_follows_the_reference_rule(assets_dir):
-    """_get_obj_size (kinova_gripper_env.py:706-746): bowls are constants scaled by the size letter, bottles the widest piece and the
+    """_get_obj_size (kinova_gripper_env.py:706-746): bowls are constants scaled by the env's size letter, bottles the widest piece and the
     SUM of the pieces' heights; the observation doubles the last entry (:529)"""
-    for z, f in (("S", 0.7), ("M", 0.85), ("B", 1.0)):
-        assert np.allclose(mc.read_blob(assets_dir / f"Bowl{z}.ksm")["obj_size_obs"], [0.175 * f, 0.175 * f, 2 * 0.07 * f])
-        assert np.allclose(mc.read_blob(assets_dir / f"RBowl{z}.ksm")["obj_size_obs"], [0.17 * f, 0.17 * f, 2 * 0.075 * f])
+    # the bowls' constants are scaled by the env's size letter - which the object schedule never updates: 'm' (0.85) for every bowl on the drivers' path
+    for z in "SMB":
+        assert np.allclose(mc.read_blob(assets_dir / f"Bowl{z}.ksm")["obj_size_obs"], [0.175 * 0.85, 0.175 * 0.85, 2 * 0.07 * 0.85])
+        assert np.allclose(mc.read_blob(assets_dir / f"RBowl{z}.ksm")["obj_size_obs"], [0.17 * 0.85, 0.17 * 0.85, 2 * 0.075 * 0.85])
     # bottles: per piece (walked from the last geom back to `object`) the extents are reordered so that the two most similar ones come
     # first - swap of the first and last unless the first two already are the closest pair -, then widths by maximum, heights summed
     for shape in ("BottleS", "TBottleB"):
@@ -197,8 +198,8 @@ def test_start_tables_and_the_fallback_rule():
     assert scenarios.has_start_table("BowlM", "rotated") and not scenarios.has_start_table("BowlS", "normal") and not scenarios.has_start_table("RBowlS", "normal")
     rng = np.random.RandomState(0)
     p = np.array([scenarios.fallback_start("BowlS", "normal", rng) for _ in range(200)])
-    assert np.hypot(p[:, 0], p[:, 1]).max() <= 0.1225 / 2 and np.allclose(p[:, 2], 0.049 / 2)
-    assert np.allclose(scenarios.fallback_start("BowlS", "rotated", rng), [0, 0, 0.0245])
+    assert np.hypot(p[:, 0], p[:, 1]).max() <= 0.14875 / 2 and np.allclose(p[:, 2], 0.0595 / 2)
+    assert np.allclose(scenarios.fallback_start("BowlS", "rotated", rng), [0, 0, 0.02975])
 
 
 def test_reset_correction_of_the_reference_moves_the_object_geom_onto_the_commanded_point():
