@@ -1,0 +1,73 @@
+"""The host-side reset helpers (kinovagrasping_amd/scenarios.py, model_compiler.object_size_obs, vec_env's row sampling) against the REFERENCE's own
+code: tests/golden/reset_helpers.npz was written by tests/golden/gen_golden_reset.py, which imports kinova_gripper_env.py with stubbed third-party
+modules and calls _get_obj_size, determine_hand_location, randomize_initial_pos_data_collection and sample_initial_object_hand_pos."""
+import numpy as np
+import pytest
+
+from kinovagrasping_amd import model_compiler as mc, scenarios
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(golden_dir / "reset_helpers.npz")
+
+
+def test_object_size_of_every_object_equals_the_reference(G, assets_dir):
+    """_get_obj_size (ENV:706-746) on the compiled models' geom_size arrays, all 42 objects, with the env's size letter as the object schedule leaves
+    it ('m'): the observation's size slots (ENV:529 doubles the last one).  The obj_params hook sets the file's own letter: only the S / B bowls differ."""
+    keys, sched, hook = [str(k) for k in G["size_keys"]], G["size_schedule_path"], G["size_obj_params_path"]
+    assert len(keys) == 42
+    for k, s, h in zip(keys, sched, hook):
+        M = mc.read_blob(assets_dir / f"{k}.ksm")
+        assert np.allclose(M["obj_size_obs"], s * np.array([1.0, 1.0, 2.0]), rtol=0, atol=1e-15), k
+        differs = not np.allclose(s, h)
+        assert differs == (("Bowl" in k) and not k.endswith("M")), k
+    i = keys.index("BowlB")
+    assert np.allclose(hook[i], [0.175, 0.175, 0.07]) and np.allclose(sched[i], np.array([0.175, 0.175, 0.07]) * 0.85)
+
+
+def test_hand_location_of_the_three_classes_equals_the_reference(G):
+    """determine_hand_location (ENV:1286-1307) with the reference's own Tfw of each class's palm pose: scenarios.hand_slide_offsets(mode="pose") for the
+    shape's own size letter (a persistent env whose object came from the schedule keeps 'm': the 'm' rows)"""
+    for cls, letter, x, y, z, f1, f2, f3 in G["hand_location"]:
+        o, size = ("normal", "rotated", "top")[int(cls)], "SMB"[int(letter)]
+        got = scenarios.hand_slide_offsets(o, "Cube" + size, "pose")
+        assert np.abs(got - [x, y, z]).max() < 1e-12, (o, size, got, (x, y, z))
+        assert (f1, f2, f3) == (0, 0, 0)
+    top = G["hand_location"][G["hand_location"][:, 0] == 2]
+    assert len({round(float(r[4]), 9) for r in top}) == 3                       # three hover heights, 1 cm apart
+
+
+def test_start_of_an_object_without_coordinate_file_equals_the_reference(G):
+    """randomize_initial_pos_data_collection (ENV:821-849), np.random seeded: scenarios.fallback_start with the same generator state"""
+    for key, xyz in zip(G["fallback_keys"], G["fallback_xyz"]):
+        shape, o = str(key).split("/")
+        if o == "side":
+            continue                                                             # (the old class name: never selected by name today)
+        np.random.seed(11)
+        got = scenarios.fallback_start(shape, o, np.random)
+        assert np.abs(got - xyz).max() < 1e-12, (key, got, xyz)
+
+
+def test_row_sampling_equals_the_reference(G):
+    """sample_initial_object_hand_pos (ENV:1008-1054) on the reference's own files, np.random seeded: the row the vec env draws - whole file, the
+    four x-regions (the index drawn among the region's rows is used on the whole file: reproduced), "origin"; no_noise and with_noise files"""
+    regions = {"left": (-.09, -.03), "center": (-.03, .03), "target": (-.01, .01), "right": (.03, .09)}
+    for key, vals, idx in zip(G["sample_keys"], G["sample_xyz_hand"], G["sample_idx"]):
+        noise, cls, shape, region = str(key).split("/")
+        tab = scenarios.start_coord_table(shape, cls.lower()) if noise == "no_noise" else scenarios.noisy_start_table(shape, cls.lower())
+        np.random.seed(5)
+        if region == "origin":
+            assert idx == -1 and np.allclose(vals[:3], [0.0, 0.0, tab[0][2]], atol=1e-7) and np.allclose(vals[3:], 0)
+            continue
+        if region == "None":
+            row = np.random.randint(0, len(tab))
+        else:
+            lo, hi = regions[region]
+            row = np.random.randint(0, int(((tab[:, 0] >= lo) & (tab[:, 0] <= hi)).sum()))
+        assert row == idx, (key, row, idx)
+        assert np.allclose(tab[row][:3], vals[:3], atol=1e-7)                    # (the tables are stored as float32)
+        if noise == "with_noise":
+            assert np.allclose(tab[row][3:6], vals[3:], atol=1e-7)
+        else:
+            assert np.allclose(vals[3:], 0)
