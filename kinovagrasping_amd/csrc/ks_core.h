@@ -66,7 +66,10 @@ constexpr int CON_STRIDE = 20;
 // that passed the culls instead (DYNAMIC_SLOTS: a pair's slot of this substep is kept in SCR_SLOT), so that 16 env blocks still fit a
 // compute unit's LDS beside the 96 pair records.
 constexpr bool DYNAMIC_SLOTS = MULTI_GEOM;
-constexpr int NSTAGE = MULTI_GEOM ? 72 : 80, STAGE_REC = 9, STAGE_WORDS = NSTAGE * STAGE_REC;   // 80 x 9 = 720 = 15 cached bases
+#ifndef KS_MG_NSTAGE
+#define KS_MG_NSTAGE 80         // (>= 4 x live plane pairs + live hull pairs of a substep - a bowl pressed by the hand: ~40 -; the rest of the region is what the solver's
+#endif                          //  contact-basis cache gets: 80 records = 720 words = 16 bases of 45)
+constexpr int NSTAGE = MULTI_GEOM ? KS_MG_NSTAGE : 80, STAGE_REC = 9, STAGE_WORDS = NSTAGE * STAGE_REC;   // 80 x 9 = 720 = 15 cached bases
 constexpr int SCR_PC = SCR_CON + NCON_MAX * CON_STRIDE;
 constexpr int SCR_SLOT = SCR_PC + NPAIR_MAX;                                   // [NPAIR_MAX] (dynamic slots only)
 constexpr int SCR_STAGE = SCR_SLOT + (DYNAMIC_SLOTS ? NPAIR_MAX : 0);
@@ -89,9 +92,13 @@ constexpr int SCR_TOTAL = SCR_STATE + 64;
 // Newton iteration; contacts that do not fit are rebuilt on the fly.
 constexpr int SCR_BCACHE = SCR_STAGE;
 #ifndef KS_BC_STRIDE
+#ifdef KS_MULTI_GEOM
+#define KS_BC_STRIDE 45         // unpadded: 16 cached bases instead of 15 - a round bowl rests on 16 contacts, and a contact beyond the cache is rebuilt twice per Newton
+#else                           // iteration (measured, 4096 envs: BowlS 3.64 -> 2.85 ms per env-step, BowlB 5.4 -> 4.7, RBowlS 2.02 -> 1.83; bottles and cubes unchanged)
 #define KS_BC_STRIDE 48
 #endif
-constexpr int BC_STRIDE = KS_BC_STRIDE;                // 3 x 15 values, padded to whole 16-byte vectors
+#endif
+constexpr int BC_STRIDE = KS_BC_STRIDE;                // 3 x 15 values (standard build: padded to whole 16-byte vectors)
 constexpr int NBCACHE = (SCR_MH - SCR_STAGE) / BC_STRIDE;
 static_assert(SCR_CON % 4 == 0 && SCR_STAGE % 4 == 0 && SCR_TOTAL % 4 == 0 && CON_STRIDE % 4 == 0, "16-byte aligned scratch regions");
 

@@ -22,7 +22,10 @@ constexpr int NGEOM = 9, NPAIR_MAX = 32, NMESH = 4, HULL_VERT_MAX = 1024;
 constexpr int OBJ_GEOM = 8;     // the geom named `object` (pieces of a multi-geom object follow it)
 // contacts kept per env per substep, in pair order (oracle: ko_sim.ncon_max, same values): 24 for the nine-geom models; 40 for the
 // multi-geom objects (a bowl lying on the floor rests on up to five pieces x 4 plane contacts before a finger touches it)
-constexpr int NCON_MAX = MULTI_GEOM ? 40 : 24;
+#ifndef KS_MG_NCON
+#define KS_MG_NCON 40
+#endif
+constexpr int NCON_MAX = MULTI_GEOM ? KS_MG_NCON : 24;
 constexpr int RAY_STACK = 24;   // pending-node bound of the ray-casting hierarchies (ks_obs.h: ray_mesh), checked at load
 constexpr int RAY_EMPTY = (int)0x80000000;   // unused child slot of a 4-wide node
 constexpr int NRAY = 17;
