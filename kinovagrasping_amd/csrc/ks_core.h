@@ -1586,12 +1586,28 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
     const int g1 = pr.g1, g2 = pr.g2, body1 = pr.body1, body2 = pr.body2;
     const int flags = pr.obj_hand;
     const T margin = pr.margin, mu = (flags & 1) ? T(scr(SCR_ENVP + 1)) : pr.mu;
-    pg.V1 = pr.V1; pg.n1 = pr.n1; pg.off1 = pr.off1; pg.adj1 = pr.adj1;
-    pg.V2 = pr.V2; pg.n2 = pr.n2; pg.off2 = pr.off2; pg.adj2 = pr.adj2;
-    pg.dir1 = dirtab + SUPPORT_CELLS * ((flags >> 4) & 15);
-    pg.dir2 = dirtab + SUPPORT_CELLS * ((flags >> 8) & 15);
-    geom_pose_cached(scr, g1, pg.R1, pg.p1);
-    geom_pose_cached(scr, g2, pg.R2, pg.p2);
+    // Operand order of the convex queries = MuJoCo's (oracle/ko_physics.c: collide_hull_hull): an explicit <pair geom1="object" geom2=hand geom>
+    // reaches libccd with the OBJECT as obj1; the model stores the pair as (hand geom, object).  MPR is not symmetric in its operands
+    // (within its 1e-6 tolerance the portal path - the contact point of a pad-on-face contact - depends on the order): rows 35-45 of the
+    // recorded MuJoCo 1.50 trajectory agree to 2e-10 / 8e-8 with the object first, to 1.3e-6 with the hand geom first.  For these pairs
+    // the queries run on the exchanged operands (hull 1 of `pg` = the object) and the direction is flipped back to g1 -> g2; the
+    // hints and the warm words then describe `pg`'s order, consistently from one substep to the next.
+    const bool obj_first = (g2 == OBJ_GEOM);
+    if (obj_first) {
+        pg.V1 = pr.V2; pg.n1 = pr.n2; pg.off1 = pr.off2; pg.adj1 = pr.adj2;
+        pg.V2 = pr.V1; pg.n2 = pr.n1; pg.off2 = pr.off1; pg.adj2 = pr.adj1;
+        pg.dir1 = dirtab + SUPPORT_CELLS * ((flags >> 8) & 15);
+        pg.dir2 = dirtab + SUPPORT_CELLS * ((flags >> 4) & 15);
+        geom_pose_cached(scr, g2, pg.R1, pg.p1);
+        geom_pose_cached(scr, g1, pg.R2, pg.p2);
+    } else {
+        pg.V1 = pr.V1; pg.n1 = pr.n1; pg.off1 = pr.off1; pg.adj1 = pr.adj1;
+        pg.V2 = pr.V2; pg.n2 = pr.n2; pg.off2 = pr.off2; pg.adj2 = pr.adj2;
+        pg.dir1 = dirtab + SUPPORT_CELLS * ((flags >> 4) & 15);
+        pg.dir2 = dirtab + SUPPORT_CELLS * ((flags >> 8) & 15);
+        geom_pose_cached(scr, g1, pg.R1, pg.p1);
+        geom_pose_cached(scr, g2, pg.R2, pg.p2);
+    }
     // hints are only meaningful when they index the pair's own hulls (always, unless a hull has > 1024 vertices)
     pg.hint1 = h1_out < pg.n1 ? h1_out : 0;
     pg.hint2 = h2_out < pg.n2 ? h2_out : 0;
@@ -1623,6 +1639,7 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
 #endif
     h1_out = pg.hint1 & PC_HINT_MAX; h2_out = pg.hint2 & PC_HINT_MAX;
     const int pi = (flags >> 12) & PAIR_INDEX_MASK;
+    if (obj_first && (r == 1 || r == 3)) { dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
     if (r == 1) { stage_contact(scr, slot, body1, body2, pi, mu, dist, pos, dir); return 1; }
     if (r >= 2) {
         // 2: overlap (or undecided beyond the margin), 3: a margin-zone result that is not a certified separation
@@ -1630,6 +1647,7 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
         const bool hit = mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, mdir, mpos, ws);
         h1_out = pg.hint1 & PC_HINT_MAX; h2_out = pg.hint2 & PC_HINT_MAX;
         if (hit) {
+            if (obj_first) { mdir[0] = -mdir[0]; mdir[1] = -mdir[1]; mdir[2] = -mdir[2]; }
             stage_contact(scr, slot, body1, body2, pi, mu, -depth, mpos, mdir);
             return 1;
         }

@@ -804,19 +804,38 @@ static void collide_hull_hull(ko_sim *s, int g1, int g2, const double *pair) {
         /* study mode (tests/studies/narrow_phase.py): MuJoCo 1.50's own scheme - libccd MPR on hulls inflated by margin / 2 each, in
          * the margin zone and in overlap alike; distance = margin - (penetration of the inflated hulls).  NOT what the product does
          * (DESIGN.md section 2): kept to quantify that deviation. */
-        mpr_ctx ci = {s, g1, g2, 0.5 * margin};
+        const int of = (g2 == KO_OBJ_GEOM); /* operand order: see below */
+        mpr_ctx ci = {s, of ? g2 : g1, of ? g1 : g2, 0.5 * margin};
         double depth_i, dir_i[3], pos_i[3];
-        if (mpr_penetration(&ci, &depth_i, dir_i, pos_i) == 0) add_contact(s, g1, g2, pair, margin - depth_i, pos_i, dir_i);
+        if (mpr_penetration(&ci, &depth_i, dir_i, pos_i) == 0) {
+            if (of) scl3(dir_i, dir_i, -1.0);
+            add_contact(s, g1, g2, pair, margin - depth_i, pos_i, dir_i);
+        }
         return;
     }
-    mpr_ctx c = {s, g1, g2, 0.0};
-    double depth, dist, dir[3], pos[3];
+    /* Operand order of the convex queries = MuJoCo's.  mj_collideGeoms hands the narrow phase the geoms of an explicit <pair> in
+     * the XML's order (geom1 = "object", geom2 = the hand geom: XML:159-166) unless geom1's TYPE is the larger one (never here:
+     * mesh 7 / box 6 / cylinder 5 object against a mesh): the OBJECT is libccd's obj1.  The model stores every pair as
+     * (lower geom id, higher geom id), i.e. (hand geom, object): for those pairs the queries run with the operands exchanged and
+     * the direction is flipped back to the stored pair's g1 -> g2.  MPR is not symmetric in its operands (portal discovery and
+     * expansion use cross products, which a point reflection does not mirror): within its 1e-6 tolerance the path - depth,
+     * normal, contact point of a pad-on-face contact - depends on the order.  Pinned by the recorded MuJoCo 1.50 trajectory
+     * (tests/test_mujoco_recorded.py): rows 35-45 (two and three finger pads on the box's faces, grasp and lift) agree to 2e-10 /
+     * 8e-8 with the object first and only to 1.3e-6 with the hand geom first; edge contacts (rows 4-34) do not depend on it.
+     * Dynamically generated pairs (hand vs hand, hand vs welded object pieces) reach the narrow phase in body / geom order:
+     * lower id first, as stored. */
+    const int obj_first = (g2 == KO_OBJ_GEOM);
+    mpr_ctx c = {s, obj_first ? g2 : g1, obj_first ? g1 : g2, 0.0};
+    double depth, dist = 0, dir[3] = {0, 0, 0}, pos[3] = {0, 0, 0};
     int r = gjk_distance(&c, margin, &dist, dir, pos);
+    if (obj_first) scl3(dir, dir, -1.0);
     if (r == 1) add_contact(s, g1, g2, pair, dist, pos, dir);
     else if (r >= 2) {
         double mdir[3], mpos[3];
-        if (mpr_penetration(&c, &depth, mdir, mpos) == 0) add_contact(s, g1, g2, pair, -depth, mpos, mdir);
-        else if (r == 3) add_contact(s, g1, g2, pair, dist, pos, dir);
+        if (mpr_penetration(&c, &depth, mdir, mpos) == 0) {
+            if (obj_first) scl3(mdir, mdir, -1.0);
+            add_contact(s, g1, g2, pair, -depth, mpos, mdir);
+        } else if (r == 3) add_contact(s, g1, g2, pair, dist, pos, dir);
     }
 }
 

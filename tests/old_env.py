@@ -15,7 +15,8 @@ ctrl[0] = action[0] / 0.8 * 0.2 (0 if negative), ctrl[1:4] = action[1:4] (0 if n
 The recording holds no actions (a policy network produced them, Old Code/main_DDPGfD_OG.py:36-56).  They are recovered row by
 row from the four ACTUATED joint angles the recording does hold: the command of row r is constant over its 4 substeps and
 row r's sensors are evaluated in the forward pass of the 4th, i.e. after 3 integrations under it - a square, monotone, almost
-diagonal 4 x 4 problem per row (velocity servos), solved by a bounded Newton iteration on the oracle.  The other 44 columns of a row
+diagonal 4 x 4 problem per row (velocity servos) - until the box is grasped, and not one-to-one where a finger rubs on the box while
+the wrist servo lifts the hand (`replay_recording`) - solved by a bounded Newton iteration on the oracle.  The other 44 columns of a row
 are then predictions: the three distal joints (soft tendons under contact load), the object's pushed path, six finger-link
 centres, the palm, 13 site-object distances, the dot product."""
 from __future__ import annotations
@@ -95,10 +96,60 @@ def new_oracle_sim(edit=None, solver_iterations=100):
     return s
 
 
-def replay_recording(rec, s=None, n_rows=None):
+PREDICTED_COLS = [c for c in range(47) if c not in (24, 25, 26, 27, 31, 32, 33)]   # everything but the 4 actuated joints and the constant box size
+
+
+def _run_row(s, st, u):
+    s.set_state(*st)
+    for _ in range(FRAME_SKIP):
+        s.step(ctrl_of(u))
+    return oracle_row(s)
+
+
+def recover_commands(s, st, tgt, u, iters=14):
+    """Newton iteration on the row's four commands for the four actuated joint angles `tgt` (recording columns 24-27), from the
+    start `u`: FULL 4 x 4 finite-difference Jacobian (once the box is grasped the fingers couple through it: a diagonal
+    iteration stalls at 1e-6), commands that want to leave their range are held at the bound and the others re-solved."""
+    u = np.array(u, dtype=np.float64)
+    for _ in range(iters):
+        row = _run_row(s, st, u)
+        res = row[24:28] - tgt
+        if np.abs(res).max() < 1e-12:
+            break
+        J = np.zeros((4, 4))
+        for k in range(4):
+            h = 1e-6 if u[k] < U_HI[k] - 1e-6 else -1e-6
+            u2 = u.copy()
+            u2[k] += h
+            J[:, k] = (_run_row(s, st, u2)[24:28] - row[24:28]) / h
+        free, du = np.ones(4, bool), np.zeros(4)
+        for _ in range(4):
+            du = np.zeros(4)
+            du[free] = np.linalg.lstsq(J[:, free], -res, rcond=None)[0]
+            out = free & ((u + du < U_LO - 1e-15) | (u + du > U_HI + 1e-15))
+            if not out.any():
+                break
+            free &= ~out
+        un = np.clip(u + du, U_LO, U_HI)
+        if np.abs(un - u).max() < 1e-14:
+            break
+        u = un
+    return u, _run_row(s, st, u)
+
+
+def replay_recording(rec, s=None, n_rows=None, branch_tol=1e-8, grid=17):
     """Replays pose_file_2 on the oracle: returns (rows [R, 48], controls [R, 4], states) where states[r] = (qpos, qvel, warm)
     after the 4 r integrations of rows 1..r; rows[0] is the reset row.  controls[r] reproduce the four actuated joint angles of
-    row r (columns 24-27) wherever a command inside the servo ranges can."""
+    row r (columns 24-27) wherever a command inside the servo ranges can.
+
+    The map command -> actuated joint angle is NOT one-to-one (round 5; rounds 3-4 assumed it was and left the recording at row
+    22): the wrist servo carries the hand UP while finger 1 rubs on the box, the friction of that contact (up to 1 N on a 0.8 kg
+    hand) changes direction with the sign of the relative vertical velocity, and two wrist commands - 0.0382 and 0.0512 in row
+    22 - put the wrist slide at the SAME recorded position after the row's three integrations, with the friction pointing up in
+    one and down in the other.  The other 44 columns tell them apart (the box: 1.8e-4 against 1e-10).  So: Newton from the
+    previous row's commands; if the predicted columns then miss the recording by more than `branch_tol`, restart it from a grid
+    over each command's range and keep the solution whose actuated AND predicted columns are closest to the recording.  The
+    selection uses the recording only to choose between solutions of the 4 x 4 problem; nothing but the 4 commands is fitted."""
     if s is None:
         s = new_oracle_sim()
     n_rows = len(rec) if n_rows is None else n_rows
@@ -107,31 +158,29 @@ def replay_recording(rec, s=None, n_rows=None):
     rows, us, states = [oracle_row(s)], [np.zeros(4)], [oracle_state(s)]
     u = np.array([0.0, 0.8, 0.0, 0.8])
 
-    def run_row(st, u):
-        s.set_state(*st)
-        for _ in range(FRAME_SKIP):
-            s.step(ctrl_of(u))
-        return oracle_row(s)
+    def miss(row, r):
+        return np.abs(row[24:28] - rec[r, 24:28]).max() + np.abs(row[PREDICTED_COLS] - rec[r, PREDICTED_COLS]).max()
 
     for r in range(1, n_rows):
         st, tgt = states[-1], rec[r, 24:28]
-        for _ in range(12):
-            row = run_row(st, u)
-            res = row[24:28] - tgt
-            if np.abs(res).max() < 1e-11:
-                break
-            J = np.zeros(4)
+        best_u, best_row = recover_commands(s, st, tgt, u)
+        best = miss(best_row, r)
+        if best > branch_tol:
+            u1 = best_u.copy()
             for k in range(4):
-                h = 1e-4 if u[k] < U_HI[k] - 1e-4 else -1e-4
-                u2 = u.copy()
-                u2[k] += h
-                J[k] = (run_row(st, u2)[24 + k] - row[24 + k]) / h
-            ok = np.abs(J) > 1e-9
-            un = np.clip(u - np.where(ok, res / np.where(ok, J, 1.0), 0.0), U_LO, U_HI)
-            if np.abs(un - u).max() < 1e-12:
-                break
-            u = un
-        rows.append(run_row(st, u))
+                for v in np.linspace(U_LO[k], U_HI[k], grid):
+                    u0 = u1.copy()
+                    u0[k] = v
+                    u2, row2 = recover_commands(s, st, tgt, u0, iters=8)
+                    e = miss(row2, r)
+                    if e < best:
+                        best, best_u, best_row = e, u2, row2
+                    if best <= branch_tol:
+                        break
+                if best <= branch_tol:
+                    break
+        u = best_u
+        rows.append(_run_row(s, st, u))
         us.append(u.copy())
         states.append(oracle_state(s))
     return np.array(rows), np.array(us), states
