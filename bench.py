@@ -193,6 +193,8 @@ def main():
     ap.add_argument("--hidden", type=int, nargs=2, default=[256, 256])
     ap.add_argument("--serial-learner", action="store_true", help="run the learner update after the sim step instead of beside it")
     ap.add_argument("--eager", action="store_true", help="launch the rollout / learner ops one by one instead of replaying HIP graphs")
+    ap.add_argument("--cohort", type=int, default=1, help="--config 5: draw the object once per this many consecutive envs (1 = per env, BASELINE's definition and "
+                    "the headline; 16 = every shape's env count a multiple of the stepping kernel's group size: a labelled variant, not comparable)")
     ap.add_argument("--envs-per-gpu", type=int, default=None, help="default 4096 (the metric's env count); 8192 for --config 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--init-policy", default="auto",
@@ -260,8 +262,8 @@ def main():
     sl = slice(rank * n, (rank + 1) * n)
     if mixed:
         # config 5: 14 shapes x {normal, rotated, top} x mass / friction per env, all in ONE context and one stepping launch
-        # (objects drawn per 16-env cohort: every shape's env count is a multiple of the stepping kernel's group size, see config5_states)
-        oid_all, pose_all, q0_all, hq_all, mf_all = scenarios.config5_states(n * world, seed=5, cohort=16)
+        # (object drawn per env - BASELINE config 5 / SURVEY 8d; --cohort 16 is the labelled variant of round 4, see config5_states)
+        oid_all, pose_all, q0_all, hq_all, mf_all = scenarios.config5_states(n * world, seed=5, cohort=args.cohort)
         sim = KinovaSim(n, scenarios.SHAPES, device=local_rank, auto_reset=True, horizon=30, solver_iterations=iters)
         reset_all = lambda: sim.reset(torch.as_tensor(q0_all[:, sl]), torch.as_tensor(hq_all[:, sl]), object_id=oid_all[sl], mass_friction=mf_all[:, sl])
     else:
@@ -550,7 +552,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{n} envs/GPU DDPG training on the domain-randomised object set: 14 README shapes x {{normal, rotated, top}} hand "
                                     "poses (reference thresholds, no-noise tables, pose hand offsets), per-env mass U[0.05,0.15] kg and friction "
-                                    "U[0.5,1.0] (shape drawn per 16-env cohort, everything else per env), one simulator context / one stepping launch; 256-256 actor/critic, one DDPGfD update per env-step "
+                                    "U[0.5,1.0] (" + ("everything drawn per env" if args.cohort == 1 else f"VARIANT: shape drawn per {args.cohort}-env cohort, everything else per env") + "), one simulator context / one stepping launch; 256-256 actor/critic, one DDPGfD update per env-step "
                                     "(BASELINE config 5; 65536 envs when n_gpus=8)") if mixed else
                                    (f"{n} envs/GPU DDPG training, 256-256 actor/critic, {args.shape} normal pose: actor inference + exploration noise + "
                                     "scripted lift in the loop, device replay, one DDPGfD update (64 episodes x 25 five-step windows) per "
@@ -560,9 +562,9 @@ def main():
                        "reset": ("the reference reset's 5 cm correction moves the `object` geom's centre onto the table row (scenarios.reset_body_position: a bottle starts "
                                   "buried and is lifted out by its floor contacts within an env-step); " if (not mixed and args.shape not in scenarios.SHAPES) else "") +
                                 ("every env restarts from its own row of the reference's no_noise start table (obj_hand_coords/no_noise/train_coords), no orientation "
-                                 "noise; hand slide offsets of the pose ('pose' mode)  [reference defaults: with_noise=True - tables SURVEY N5 shows to be "
-                                 "biased and swapped between classes - and, in its training driver, zero hand offsets: vec_env.KinovaGripperVecEnv(hand_offsets="
-                                 "'fresh-env'), reset(with_noise=True) select those]"),
+                                 "noise; hand slide offsets of the pose (hand_offsets='pose'): the workload SURVEY 8d defines, requested explicitly  [the env class's DEFAULTS are the "
+                                 "reference's: KinovaGripperVecEnv.reset(with_noise=True) = its with_noise tables - which SURVEY N5 shows to be biased and swapped "
+                                 "between classes - and hand_offsets='fresh-env' = the zero offsets its drivers end up with]"),
                        "mode": args.mode, "envs_per_gpu": n, "frame_skip": 15, "solver": f"newton, <= {iters} iterations per substep (early exit on convergence)", "hidden": list(args.hidden),
                        "learner_updates_timed": timed_updates if args.mode == "ddpg" else 0, "priming_steps": priming,
                        "launch": (("eager" if args.eager else ("free-running rollout kernel (ks_rollout), <= %d env-steps per launch (timed region: %s) + learner graphs" % (args.chunk, timed_launches)

@@ -122,7 +122,8 @@ int ks_reset_objects(ks_ctx *ctx, const int32_t *env_ids, int32_t n, const void 
  * Stream capture: ks_step / ks_rollout may be recorded into a HIP graph.  The library then records a host-to-device copy
  * of the call's output-pointer record from pinned memory it owns for the life of the context (one record per captured call,
  * never recycled), so any number of captured graphs with different output buffers can be replayed in any order; the
- * buffers themselves are borrowed for as long as the graph may be replayed. */
+ * buffers themselves are borrowed for as long as the graph may be replayed.  Eager calls may be mixed with replays: once a context
+ * holds a captured call, every eager ks_step re-sends its own output record (the "same pointers as the last call" shortcut is off). */
 int ks_step(ks_ctx *ctx, const void *action, void *obs, void *reward, uint8_t *done, void *info, void *final_obs, void *stream);
 
 /* Parity taps; any pointer may be NULL.  contact: [KS_NCON_MAX*KS_CONTACT_STRIDE, N] (libkinova_sim_mg.so: KS_NCON_MAX_MG) records of the

@@ -677,7 +677,11 @@ __device__ __noinline__ void rollout_policy(const ks_rollout_args* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 4; i++) y[i] = ra.max_action / (1.f + __expf(-(z[i] + b3[i])));
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        // ALL FOUR waves' reads of buffer ver % 3 must be complete before the counter is looked at again: the barrier waits for every
+        // wave to reach this point (each wave's loads are consumed by the arithmetic above, so they have returned), and the agent-scope
+        // acquire fence keeps thread 0's second load of the counter - written by another kernel - behind it.
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         // buffer ver % 3 is rewritten by publish ver + 3, which starts once ver + 2 is complete: if the counter has advanced by two
         // while this forward ran, the weights just read may be torn - repeat with the newest ones (two update periods, > 1 ms,
         // against a 25 us forward: never seen; the check makes it a protocol instead of a timing assumption)
@@ -1586,8 +1590,11 @@ template <typename T> struct Ctx : CtxBase {
                           out.env_major == out_sent.env_major;
         // Under stream capture the copy below is only RECORDED (it runs at every replay of the graph, not now): the device copy
         // cannot be taken as current afterwards, so a capturing call always records the copy and never marks it as sent.
+        // Once the context holds ANY captured record (captured_out > 0) a replayed graph may have overwritten d_out with its own
+        // pinned record since the last eager call - replays are invisible here - so the "same pointers as last time" shortcut is
+        // off for good and every eager call re-sends its record (eager + captured calls with different buffers).
         const bool capturing = stream_is_capturing(s);
-        if (obs_in_step && (capturing || !(same && out_valid))) {
+        if (obs_in_step && (capturing || captured_out > 0 || !(same && out_valid))) {
             out_valid = !capturing;
             out_sent = out;
             ObsOut<T>* slot = pinned_record(capturing, h_out, (unsigned)h_out_next++, captured_out);

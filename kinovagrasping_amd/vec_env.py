@@ -30,11 +30,17 @@ class KinovaGripperVecEnv:
     metadata = {"render.modes": []}
 
     def __init__(self, n_envs: int, shape="CubeS", device: int = 0, frame_skip: int = 15, max_episode_steps: int = 30,
-                 auto_reset: bool = True, solver_iterations: int = SOLVER_ITERATIONS, seed: int = 0, hand_offsets: str = "pose"):
+                 auto_reset: bool = True, solver_iterations: int = SOLVER_ITERATIONS, seed: int = 0, hand_offsets: str = "fresh-env",
+                 host_only: bool = False):
         """shape: one object name, or a list of them (mixed-object batches, BASELINE config 5).
-        hand_offsets: where the 'rotated' / 'top' hands start (determine_hand_location, ENV:1286-1307) - "pose": with the
-        pose's own palm rotation, as intended; "fresh-env": zero, as the reference's training driver ends up doing because it
-        recreates the env (zero Tfw) for every episode (scenarios.hand_slide_offsets)."""
+        hand_offsets: where the 'rotated' / 'top' hands start (determine_hand_location, ENV:1286-1307) - "fresh-env" (default: what the
+        reference's drivers do): zero, because main_DDPGfD.py:381 / expert_data.py recreate the env for every episode and a fresh env's
+        Tfw is zero; "pose": with the pose's own palm rotation - what determine_hand_location is written to do, the hand hovers over
+        the object - (scenarios.hand_slide_offsets; BASELINE config 5 and bench.py ask for "pose" explicitly).
+        host_only: no device, no simulator - reset() then RETURNS the start states it drew ({"qpos": [16, n], "hand_quat": [4, n]}) instead
+        of observations: the reset's sampling is host code and is pinned against the reference's on CPU (tests/test_reset_golden.py)."""
+        if hand_offsets not in ("fresh-env", "pose"):
+            raise ValueError('KinovaGripperVecEnv: hand_offsets is "fresh-env" (the reference drivers\' zero offsets) or "pose"')
         self.hand_offsets = hand_offsets
         self.n_envs = n_envs
         self.shapes = [shape] if isinstance(shape, str) else list(shape)
@@ -44,15 +50,15 @@ class KinovaGripperVecEnv:
         self._max_episode_steps = max_episode_steps
         self.action_space = SimpleNamespace(low=np.full(4, -0.8, np.float32), high=np.full(4, 0.8, np.float32), shape=(4,), dtype=np.float32)
         self.observation_dim = NOBS
-        self.sim = KinovaSim(n_envs, shape if isinstance(shape, str) else self.shapes, device=device, frame_skip=frame_skip, horizon=max_episode_steps,
-                             solver_iterations=solver_iterations, auto_reset=auto_reset, obs_env_major=True)
+        self.sim = None if host_only else KinovaSim(n_envs, shape if isinstance(shape, str) else self.shapes, device=device, frame_skip=frame_skip,
+                                                    horizon=max_episode_steps, solver_iterations=solver_iterations, auto_reset=auto_reset, obs_env_major=True)
         self.np_random = np.random.RandomState(seed)
         self.orientation = ["normal"] * n_envs
         self.obj_coords = np.zeros((n_envs, 3))
         self.orientation_idx = np.zeros(n_envs, dtype=np.int64)
         self.hand_quat = np.repeat(scenarios.hand_quat_for("normal")[:, None], n_envs, 1)
         self.hand_euler = np.repeat(np.asarray(scenarios.ORIENTATION_EULER["normal"])[None], n_envs, 0)   # as patched into the XML (truncated)
-        self.with_noise = False
+        self.with_noise = "tables"
         self.obj_keys = []                       # Latin-square object queue (Generate_Latin_Square); reset() pops from its end
         self.with_grasp_reward = False
         M = read_blob(scenarios.model_blob(self.shapes[0]))        # hand constants for Tfw (the same in every object's blob)
@@ -182,7 +188,7 @@ class KinovaGripperVecEnv:
         return scenarios.select_orientation(shape if shape is not None else self.random_shape, hand_orientation, self.np_random)
 
     def reset(self, shape_keys=None, hand_orientation="normal", with_grasp=False, env_name="env", mode="train", start_pos=None,
-              obj_params=None, qpos=None, obj_coord_region=None, with_noise=False, env_ids=None):
+              obj_params=None, qpos=None, obj_coord_region=None, with_noise=True, env_ids=None):
         """Reset all envs (or `env_ids`).  start_pos: optional per-env rows as the reference's test hook takes them (ENV:1347-1363): 3 values =
         object x, y, z; 2 values = object x, y at height _get_obj_size()[-1]; 9 values = the three slides, the three proximal
         joints, object x, y, z.  Otherwise rows are
@@ -196,19 +202,21 @@ class KinovaGripperVecEnv:
         With several objects loaded every reset env draws its
         object from `shape_keys` (default: all loaded) - Latin-square queue first, see select_object.
         Slide offsets of the 'rotated' / 'top' hands: see `hand_offsets` of the constructor.
-        with_noise=True: orientation noise as SURVEY note N5 prescribes - the class's no-noise Euler constants (ENV:1267-1273) plus
-        ZERO-MEAN N(0, 0.087 rad) per axis drawn from the env's np_random, then the reference's 5-character truncation
-        (ENV:870-874, model_compiler.truncated_euler); object coordinates still come from the no_noise tables.  An EXTENSION, not the
-        reference's behaviour: its with_noise tables (ENV:1254-1255; generator rotation_generation.py:20-25) carry Euler triples
-        that are swapped between the normal / top classes and biased by -0.087 (N5), so they are not reproduced.  The reference's
-        default is with_noise=True; the default here is False (the self-consistent no-noise branch).
-        with_noise="tables": the reference's default AS IT IS - object position AND hand Euler triple of a random row of the shape's
-        with_noise coordinate file (ENV:1019-1021, 1254-1255; `scenarios.noisy_start_table`), bias, class swap and all (N5); where the
-        reference ships no such file the no-noise path applies."""
+        with_noise=True (the default, as in the reference, ENV:1310): the reference's start states AS THEY ARE - object position AND hand
+        Euler triple of a random row of the shape's with_noise coordinate file (ENV:1019-1021, 1254-1255; `scenarios.noisy_start_table`),
+        the Euler triple through the reference's 5-character truncation (ENV:870-874); the tables' bias of -0.087 rad and the swap
+        between the normal / top classes (SURVEY note N5; generator rotation_generation.py:20-25) are the reference's and are kept.
+        Where the reference ships no such file the no-noise path applies.  ("tables" is accepted as an alias.)
+        with_noise=False: the class's no-noise Euler constants (ENV:1267-1273) and a row of the no_noise table.
+        with_noise="zero-mean": an EXTENSION (what SURVEY note N5 prescribes instead of the biased tables) - the no-noise constants plus
+        ZERO-MEAN N(0, 0.087 rad) per axis drawn from the env's np_random, then the 5-character truncation; object coordinates from the
+        no_noise tables."""
         from .model_compiler import euler_to_quat, truncated_euler
-        if with_noise not in (False, True, "tables"):
-            raise ValueError('reset: with_noise is False, True (zero-mean extension) or "tables" (the reference\'s with_noise files)')
-        self.with_noise = with_noise if with_noise == "tables" else bool(with_noise)
+        if with_noise is True:
+            with_noise = "tables"
+        if with_noise not in (False, "tables", "zero-mean"):
+            raise ValueError('reset: with_noise is True (the reference\'s with_noise files; alias "tables"), False or "zero-mean" (extension)')
+        self.with_noise = with_noise
         self.set_with_grasp_reward(with_grasp)
         ids = np.arange(self.n_envs) if env_ids is None else np.asarray(env_ids)
         n = len(ids)
@@ -250,7 +258,7 @@ class KinovaGripperVecEnv:
                 row = pick_row(noisy)
                 eul = truncated_euler(noisy[row, 3:6]) if row >= 0 else np.zeros(3)                          # (origin: hand Euler 0, 0, 0, ENV:1040)
             else:
-                eul = scenarios.hand_euler_for(o, self.np_random if with_noise is True else None)
+                eul = scenarios.hand_euler_for(o, self.np_random if with_noise == "zero-mean" else None)
             self.hand_euler[e] = eul
             hq[:, k] = euler_to_quat(eul)
             if noisy is not None:
@@ -286,6 +294,8 @@ class KinovaGripperVecEnv:
             if qpos is not None:                                              # set_sim_state: the given joint vector, as it is
                 q[:, k] = np.asarray(qpos[k], dtype=np.float64)
             self.hand_quat[:, e] = hq[:, k]
+        if self.sim is None:                                                  # host_only: the draw itself
+            return {"qpos": q, "hand_quat": hq}
         t_ids = None if env_ids is None else torch.as_tensor(ids, dtype=torch.int32)
         obs = self.sim.reset(torch.as_tensor(q), torch.as_tensor(hq), t_ids, object_id=self.shape_id[ids].copy() if multi else None,
                              mass_friction=obj_params if (obj_params is not None and not isinstance(obj_params, (list, tuple))) else None)
@@ -304,4 +314,5 @@ class KinovaGripperVecEnv:
         return obs, reward, done.bool(), infod
 
     def close(self):
-        self.sim.close()
+        if self.sim is not None:
+            self.sim.close()

@@ -231,7 +231,7 @@ def test_learner_and_rollout_glue_kernels_use_no_lds():
 
 
 def test_orientation_noise_is_zero_mean_truncated_and_seeded():
-    """reset(with_noise=True) (SURVEY note N5's extension): class Euler constants + zero-mean N(0, 0.087), then the reference's
+    """reset(with_noise="zero-mean") (SURVEY note N5's extension): class Euler constants + zero-mean N(0, 0.087), then the reference's
     5-character truncation (ENV:870-874); without an rng exactly the class quaternion."""
     import numpy as np
     from kinovagrasping_amd import scenarios

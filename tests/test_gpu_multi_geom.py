@@ -222,9 +222,9 @@ def test_vec_env_with_multi_geom_shapes_of_a_stage():
     from kinovagrasping_amd.vec_env import KinovaGripperVecEnv
     shapes = ["CubeS", "Vase2S", "BottleS", "BowlS", "TBottleS"]
     n = 40
-    env = KinovaGripperVecEnv(n, shapes, seed=5, auto_reset=False)
+    env = KinovaGripperVecEnv(n, shapes, seed=5, auto_reset=False, hand_offsets="pose")
     assert env.sim.multi_geom
-    obs = env.reset(shape_keys=shapes, hand_orientation="random", mode="train")
+    obs = env.reset(shape_keys=shapes, hand_orientation="random", mode="train", with_noise=False)
     torch.cuda.synchronize()
     assert tuple(obs.shape) == (n, 82) and torch.isfinite(obs).all()
     names, poses = env.get_random_shape(), env.get_orientation()
@@ -283,9 +283,9 @@ def test_every_object_of_the_reference_in_one_context():
     shapes = scenarios.SHAPES + scenarios.MEDIUM_SHAPES + scenarios.EXTRA_SHAPES + scenarios.MULTI_GEOM_SHAPES
     assert len(shapes) == 42
     n = 8 * len(shapes)
-    env = KinovaGripperVecEnv(n, shapes, seed=1, auto_reset=False)
+    env = KinovaGripperVecEnv(n, shapes, seed=1, auto_reset=False, hand_offsets="pose")
     env.Generate_Latin_Square(n, "/tmp/ks_objects_all.csv", shape_keys=shapes)
-    obs = env.reset(shape_keys=shapes, hand_orientation="random")
+    obs = env.reset(shape_keys=shapes, hand_orientation="random", with_noise=False)
     names = env.get_random_shape()
     assert sorted(set(names)) == sorted(shapes) and all(names.count(s) == 8 for s in shapes)
     sizes = {sh: mc.read_blob(scenarios.model_blob(sh))["obj_size_obs"] for sh in shapes}

@@ -210,8 +210,9 @@ def test_batched_long_horizon_parity_200_substeps():
     Grasp-and-lift scripts: 99 of 168 in round 4.  Cubes: 11 of 12.  Round shapes (67-gon cylinders / vases, cones) are where MuJoCo's own
     contact model is discontinuous: the single MPR contact of a finger on a polygonal "round" surface jumps from one facet to the next
     (normals 5.4 degrees apart) and a resting rim has 67 equally deep vertices - an fp32 state error of 1e-7 decides such an event one
-    substep earlier or later and the trajectories then differ by 1e-3 - 1e-2.  (Real MuJoCo is equally sensitive there: in the recorded
-    trajectory one such event at row 22 separates a 1e-10 replay from a 1e-4 one)"""
+    substep earlier or later and the trajectories then differ by 1e-3 - 1e-2.  (What real MuJoCo does in such events is decided by ties of
+    its support functions - DESIGN.md section 2, rows 46-62 of the recorded trajectory; the earlier claim that row 22 of that recording was
+    such an event is retracted: it was the command recovery.)"""
     from tests.studies import long_horizon as lh
     res = lh.config2_batch(256, 200)
     rel = res["rel"]
@@ -699,8 +700,8 @@ def test_vec_env_keeps_the_reference_interface():
     (kinova_gripper_env.py:1310, 1495, 685), random orientation classes, partial resets."""
     from kinovagrasping_amd.vec_env import KinovaGripperVecEnv
     n = 96
-    env = KinovaGripperVecEnv(n, "CylinderB", seed=3, auto_reset=False)
-    obs = env.reset(shape_keys=["CylinderB"], hand_orientation="random", with_grasp=False, mode="train")
+    env = KinovaGripperVecEnv(n, "CylinderB", seed=3, auto_reset=False, hand_offsets="pose")
+    obs = env.reset(shape_keys=["CylinderB"], hand_orientation="random", with_grasp=False, mode="train", with_noise=False)
     assert tuple(obs.shape) == (n, 82) and torch.isfinite(obs).all()
     assert set(env.get_orientation()) == {"normal", "rotated", "top"}
     assert env.action_space.shape == (4,) and env._max_episode_steps == 30
@@ -715,7 +716,7 @@ def test_vec_env_keeps_the_reference_interface():
         assert (np.abs(tab - env.get_obj_coords()[e]).sum(1) < 1e-12).any()
     before = obs.clone()
     ids = [1, 5, 17]
-    env.reset(hand_orientation="normal", env_ids=ids)
+    env.reset(hand_orientation="normal", env_ids=ids, with_noise=False)
     torch.cuda.synchronize()
     changed = (env.sim.obs != before).any(1).cpu().numpy()
     assert changed[ids].all() and changed.sum() == len(ids)
@@ -730,7 +731,8 @@ def test_vec_env_reset_test_hooks_of_the_reference():
     from kinovagrasping_amd.vec_env import KinovaGripperVecEnv
     n = 12
     env = KinovaGripperVecEnv(n, ["CubeS", "CylinderB", "Vase2S"], seed=21, auto_reset=False)
-    env.reset(obj_params=["Cylinder", "B"])
+    env.reset(obj_params=["Cylinder", "B"])                          # (all defaults: the reference's with_noise tables, zero hand offsets)
+    assert all("with_noise/train_coords" in f for f in env.get_coords_filename())
     assert env.get_random_shape() == ["CylinderB"] * n
     with pytest.raises(ValueError):
         env.reset(obj_params=["Cone1", "S"])
@@ -744,12 +746,12 @@ def test_vec_env_reset_test_hooks_of_the_reference():
     # regions
     tab = scenarios.start_coord_table("CubeS", "normal")
     for region, (lo, hi) in {"left": (-.09, -.03), "center": (-.03, .03), "target": (-.01, .01), "right": (.03, .09)}.items():
-        env.reset(obj_params=["Cube", "S"], obj_coord_region=region)
+        env.reset(obj_params=["Cube", "S"], obj_coord_region=region, with_noise=False)
         count = int(((tab[:, 0] >= lo) & (tab[:, 0] <= hi)).sum())
         idx = np.asarray(env.get_orientation_idx())
         assert (idx >= 0).all() and (idx < count).all()                          # drawn among the region's rows ...
         assert all(np.array_equal(env.get_obj_coords()[e], tab[idx[e]]) for e in range(n))      # ... and used on the whole file (sic)
-    env.reset(obj_params=["Cube", "S"], obj_coord_region="origin")
+    env.reset(obj_params=["Cube", "S"], obj_coord_region="origin", with_noise=False)
     assert np.allclose(env.get_obj_coords(), np.array([0.0, 0.0, tab[0][2]])[None])
     # qpos: the given joint vector as it is
     qq = np.zeros((n, 16)); qq[:, 12] = 1; qq[:, 9:12] = [0.0, 0.01, 0.08]; qq[:, 3] = 0.25; qq[:, 4] = 0.125
@@ -765,15 +767,16 @@ def mc_read(shape):
 
 
 def test_vec_env_reference_with_noise_tables_mode():
-    """reset(with_noise="tables"): the reference's DEFAULT start states as they are (ENV:1310, 1019-1021, 1254-1255) - object position AND hand
+    """reset() with the DEFAULTS (with_noise=True, hand_offsets="fresh-env"): the reference's DEFAULT start states as they are (ENV:1310, 1019-1021, 1254-1255) - object position AND hand
     Euler triple of a random row of the shape's with_noise file, truncated to 5 characters; every env's reset observation equals the oracle's
     at that pose.  (With hand_offsets="fresh-env" - what the reference's training driver ends up with - the 'normal' class of these tables puts
     the hand at the IDENTITY orientation + noise: SURVEY N5.)"""
     from kinovagrasping_amd.vec_env import KinovaGripperVecEnv
     from kinovagrasping_amd.model_compiler import euler_to_quat, truncated_euler
     n = 36
-    env = KinovaGripperVecEnv(n, "Cube45B", seed=4, auto_reset=False, hand_offsets="fresh-env")
-    obs = env.reset(hand_orientation="random", with_noise="tables").double().cpu().numpy().copy()
+    env = KinovaGripperVecEnv(n, "Cube45B", seed=4, auto_reset=False)
+    assert env.hand_offsets == "fresh-env"
+    obs = env.reset(["Cube45B"], "random").double().cpu().numpy().copy()          # positional, no keywords: as the reference's drivers call it
     assert set(env.get_orientation()) == {"normal", "rotated", "top"} and all("with_noise/train_coords" in f for f in env.get_coords_filename())
     model = ko.OracleModel(scenarios.model_blob("Cube45B"))
     for e in range(n):
@@ -799,20 +802,20 @@ def test_vec_env_reference_with_noise_tables_mode():
 
 
 def test_vec_env_with_noise_resets_to_noisy_poses_that_match_the_oracle():
-    """reset(with_noise=True): zero-mean N(0, 0.087) Euler noise through the 5-character truncation (scenarios.hand_euler_for,
+    """reset(with_noise="zero-mean"): zero-mean N(0, 0.087) Euler noise through the 5-character truncation (scenarios.hand_euler_for,
     SURVEY N5 extension).  Every env's reset observation and its state after two env-steps equal the oracle run on the SAME noisy
     hand quaternion; the noise is there (quaternions differ from the class constant) and seeded."""
     from kinovagrasping_amd.vec_env import KinovaGripperVecEnv
     from kinovagrasping_amd.model_compiler import euler_to_quat
     n = 48
     env = KinovaGripperVecEnv(n, "CubeS", seed=9, auto_reset=False)
-    obs = env.reset(hand_orientation="normal", with_noise=True).double().cpu().numpy().copy()
+    obs = env.reset(hand_orientation="normal", with_noise="zero-mean").double().cpu().numpy().copy()
     base = scenarios.hand_quat_for("normal")
     ang = 2 * np.arccos(np.clip(np.abs(env.hand_quat.T @ base), 0, 1))
     assert ang.min() > 1e-3 and 0.05 < ang.mean() < 0.3                      # a few degrees of tilt in every env
     assert np.allclose(env.hand_quat, np.stack([euler_to_quat(e) for e in env.hand_euler], 1))
     env2 = KinovaGripperVecEnv(n, "CubeS", seed=9, auto_reset=False)
-    env2.reset(hand_orientation="normal", with_noise=True)
+    env2.reset(hand_orientation="normal", with_noise="zero-mean")
     assert np.array_equal(env.hand_euler, env2.hand_euler)
     env2.close()
     model = ko.OracleModel(scenarios.model_blob("CubeS"))

@@ -11,9 +11,9 @@ from oracle import ko_py
 pf2 = np.load(ROOT / "tests/golden/mujoco_recorded.npz")["pose_file_2"]
 rows, us, states = pickle.load(open("/tmp/replay_ms.pkl", "rb"))
 L = ko_py.lib()
-ctypes.c_int.in_dll(L, "ko_dbg_swap").value = 1
+ctypes.c_int.in_dll(L, "ko_dbg_obj_first").value = 1
 import os
-ctypes.c_int.in_dll(L, "ko_dbg_frot_g1").value = int(os.environ.get("G1", "3"))
+ctypes.c_int.in_dll(L, "ko_dbg_g1").value = int(os.environ.get("G1", "3"))
 s = old_env.new_oracle_sim()
 def var(name, n=None):
     return (ctypes.c_double * n).in_dll(L, name) if n else ctypes.c_double.in_dll(L, name)
