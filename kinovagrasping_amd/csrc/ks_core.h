@@ -1350,6 +1350,9 @@ KS_HD bool plane_may_touch(S scr, KS_LDS const PairRec<T>* prp) {
     return !(cdist - (kabs(ln[0]) * size[0] + kabs(ln[1]) * size[1] + kabs(ln[2]) * size[2]) > margin);
 }
 
+#if defined(KS_PLANE_HOOK) && !defined(__HIP_DEVICE_COMPILE__)
+inline int (*ks_plane_hook)(int g2, const double* R, const double* p, int coarse_best) = nullptr;
+#endif
 // Ground plane z = 0 (normal +z) vs the hull of geom g2, worked on by the WHOLE team: deepest vertex, then up
 // to 3 more within the margin that are > 0.3*rbound from every accepted vertex (index order).  The lanes
 // scan the vertex table SUBS rows at a time; the team then agrees on the deepest vertex and on the
@@ -1436,6 +1439,10 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
         }
         if (first != 0x7fffffff) best = first;
     }
+#if defined(KS_PLANE_HOOK) && !defined(__HIP_DEVICE_COMPILE__)
+    // host-only experiment (tests/studies/divergence_table.py): the first vertex chosen by an external fp64 evaluation on the lane's own pose
+    if (ks_plane_hook) { double R[9], pp[3]; for (int k = 0; k < 9; k++) R[k] = (double)R2[k]; for (int k = 0; k < 3; k++) pp[k] = (double)p2[k]; best = ks_plane_hook(g2, R, pp, best); }
+#endif
     KS_TICK(4)
     T cv[4][3];
     int nc = 1;
@@ -1592,7 +1599,10 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
     // recorded MuJoCo 1.50 trajectory agree to 2e-10 / 8e-8 with the object first, to 1.3e-6 with the hand geom first.  For these pairs
     // the queries run on the exchanged operands (hull 1 of `pg` = the object) and the direction is flipped back to g1 -> g2; the
     // hints and the warm words then describe `pg`'s order, consistently from one substep to the next.
-    const bool obj_first = (g2 == OBJ_GEOM);
+#ifndef KS_OBJ_FIRST
+#define KS_OBJ_FIRST 1          // 0: the operand order of rounds 1-4 (diagnostic A/B only: tools/r05/operand_order_fp32.py)
+#endif
+    const bool obj_first = (KS_OBJ_FIRST != 0) && (g2 == OBJ_GEOM);
     if (obj_first) {
         pg.V1 = pr.V2; pg.n1 = pr.n2; pg.off1 = pr.off2; pg.adj1 = pr.adj2;
         pg.V2 = pr.V1; pg.n2 = pr.n1; pg.off2 = pr.off1; pg.adj2 = pr.adj1;

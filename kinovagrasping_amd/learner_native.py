@@ -94,8 +94,32 @@ class NativeDDPGfDUpdate:
         # track_actor_loss it is evaluated from the Q of phase_actor's critic forward and kept in self.actor_loss
         self.track_actor_loss = False
         self.actor_loss = torch.zeros((), device=policy.device)
+        # Fork / join inside a phase (round 5, LDS-free path): the launches of an update that do not depend on each other - the target
+        # networks' pass beside the critic's forward, the three weight-gradient launches of a network beside its data-gradient pass -
+        # go to two side streams that leave from and rejoin the phase's stream (under stream capture: parallel branches of the graph).
+        # Every launch of the LDS-free update is one latency-bound wave per 16 rows (87 us whatever the batch, ks_mlp.hip) on a few
+        # hundred of the 1024 SIMDs: branches run at the same time instead of one after the other.
+        # OFF by default (KS_LEARNER_FORK=1 turns it on).  Measured, round 5, one MI355X: the update replayed ALONE 0.878 -> 0.733 ms
+        # (10.4 GFLOP: 7.5 % -> 9.0 % of the fp32 MFMA peak), bit-identical results (tests/test_gpu_learner_state.py) - but beside the
+        # persistent rollout kernel the training step went from 1.34 to 2.09 ms per env-step (3.05 -> 1.96 M env-steps/s) and episodes were
+        # dropped: three learner launches at a time compete with the rollout's waves for the SIMDs' issue slots, and the update is off
+        # the critical path at one update per env-step anyway.  Kept for learner-bound regimes (updates_per_step >= 2 in lock step).
+        self.fork = self.lds_free and os.environ.get("KS_LEARNER_FORK", "0") == "1"
+        self._sides = [torch.cuda.Stream(policy.device) for _ in range(2)] if self.fork else []
 
     # -- helpers ------------------------------------------------------------------------------------------------------
+    def _branch(self, k):
+        """context: side stream k, ordered behind everything enqueued on the current stream so far (a fork); _join() brings it back"""
+        cur = torch.cuda.current_stream(self.p.device)
+        side = self._sides[k]
+        side.wait_stream(cur)
+        return torch.cuda.stream(side)
+
+    def _join(self, *ks):
+        cur = torch.cuda.current_stream(self.p.device)
+        for k in ks:
+            cur.wait_stream(self._sides[k])
+
     def _st(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.p.device).cuda_stream)
 
@@ -199,6 +223,29 @@ class NativeDDPGfDUpdate:
         # both target evaluations (1-step: next_state[:, 0], n-step: next_state[:, -1]) in one pass of the target nets
         # (next_ends: the sampler's own [2R, S] block of exactly these rows, kr_sample_windows_draw)
         nx = torch.cat([next_state[:, 0], next_state[:, -1]], 0) if next_ends is None else next_ends
+        if self.fork:
+            # branch 0: the two target networks (3200 rows each); the critic's own forward runs beside them on the phase's stream
+            c = self.critic
+            cl = list(zip(c.W, c.b))
+            s0, a0 = state[:, 0], action[:, 0]
+            reward = reward.contiguous()
+            with self._branch(0):
+                ta = _mlp.mlp3_forward(list(zip(self.actor_t.W, self.actor_t.b)), nx, act=_mlp.ACT_SIGMOID, scale=pol.max_action, shadow=True)
+                tq = _mlp.mlp3_forward(list(zip(self.critic_t.W, self.critic_t.b)), nx, ta, act=_mlp.ACT_NONE, shadow=True)
+            h1, h2 = s0.new_empty(R, c.W[0].shape[0]), s0.new_empty(R, c.W[1].shape[0])
+            q = _mlp.mlp3_forward(cl, s0, a0, act=_mlp.ACT_NONE, h1_out=h1, h2_out=h2, shadow=True)
+            dq = torch.empty_like(q)
+            self._join(0)
+            self._chk(self.lib.kr_critic_grad(R, pol.n, P(q), P(tq), P(tq[R:]), P(reward), P(weight), P(self.wsum), pol.discount, P(dq), P(self.losses),
+                                              self._st()), "kr_critic_grad")
+            with self._branch(0):                              # the last layer's weight gradient needs dq only: beside the data-gradient pass
+                _mlp.weight_grad(dq, h2, None, c.gW[2], c.gb[2])
+            dz2, dz1, _ = _mlp.mlp3_backward(cl, dq, h1, h2)
+            with self._branch(1):
+                _mlp.weight_grad(dz2, h1, None, c.gW[1], c.gb[1])
+            _mlp.weight_grad(dz1, s0, a0, c.gW[0], c.gb[0])
+            self._join(0, 1)
+            return self.losses[0], self.losses[1], self.losses[2]
         if self.fused_targets:
             # forward-only networks: one fused fp32-MFMA launch each (mlp.mlp3_forward) instead of 3 GEMMs + glue
             ta = _mlp.mlp3_forward(list(zip(self.actor_t.W, self.actor_t.b)), nx, act=_mlp.ACT_SIGMOID, scale=pol.max_action, shadow=self.shadow)
@@ -258,6 +305,15 @@ class NativeDDPGfDUpdate:
             dq = self.dq_actor
             # dLoss/d(actor pre-activation): through the critic to its action inputs, then through 0.8 * sigmoid
             _, _, dz3 = _mlp.mlp3_backward(cl, dq, hc1, hc2, want_dz=False, dx_cols=(sa.shape[1], a.shape[1]), act_out=a, scale=pol.max_action)
+            if self.fork:
+                with self._branch(0):
+                    _mlp.weight_grad(dz3, ha2, None, a_.gW[2], a_.gb[2])
+                dz2, dz1, _ = _mlp.mlp3_backward(al, dz3, ha1, ha2)
+                with self._branch(1):
+                    _mlp.weight_grad(dz2, ha1, None, a_.gW[1], a_.gb[1])
+                _mlp.weight_grad(dz1, sa, None, a_.gW[0], a_.gb[0])
+                self._join(0, 1)
+                return None
             dz2, dz1, _ = _mlp.mlp3_backward(al, dz3, ha1, ha2)
             _mlp.weight_grad(dz3, ha2, None, a_.gW[2], a_.gb[2])
             _mlp.weight_grad(dz2, ha1, None, a_.gW[1], a_.gb[1])

@@ -94,6 +94,20 @@ static int env_step_t(const Model<T>& m, double* qpos, double* qvel, double* war
     return status;
 }
 
+#ifdef KS_PLANE_HOOK
+// experiment: the deepest vertex of a plane pair from the fp64 tables on the fp32 lane's pose (the oracle's rule: lowest index within 1e-12)
+static const Model<double>* g_hook_model = nullptr;
+static int plane_hook(int g2, const double* R, const double* p, int coarse) {
+    const Model<double>& m = *g_hook_model;
+    const int mesh = m.geom_mesh[g2], nv = m.mesh_nvert[mesh];
+    const double* V = m.mesh_vert[mesh];
+    const double ln[3] = {R[6], R[7], R[8]}, cdist = p[2];
+    double bd = 1e300;
+    for (int i = 0; i < nv; i++) { const double d = cdist + V[4 * i] * ln[0] + V[4 * i + 1] * ln[1] + V[4 * i + 2] * ln[2]; if (d < bd) bd = d; }
+    for (int i = 0; i < nv; i++) { const double d = cdist + V[4 * i] * ln[0] + V[4 * i + 1] * ln[1] + V[4 * i + 2] * ln[2]; if (d <= bd + 1e-12) return i; }
+    return coarse;
+}
+#endif
 extern "C" {
 void* lc_create(const void* blob, size_t n) {
     LC* h = new LC();
@@ -107,6 +121,9 @@ void* lc_create(const void* blob, size_t n) {
 void lc_destroy(void* h) { delete (LC*)h; }
 int lc_substep(void* h, int prec, double* qpos, double* qvel, double* warm, const double* ctrl, const double* hq, int iters, int* ncon, double* con) {
     LC* l = (LC*)h;
+#ifdef KS_PLANE_HOOK
+    g_hook_model = &l->d.m; ks::ks_plane_hook = prec == 64 ? nullptr : plane_hook;
+#endif
     return prec == 64 ? substep_t<double>(l->d.m, qpos, qvel, warm, ctrl, hq, iters, ncon, con)
                       : substep_t<float>(l->f.m, qpos, qvel, warm, ctrl, hq, iters, ncon, con);
 }

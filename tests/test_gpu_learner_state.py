@@ -329,3 +329,55 @@ def test_reference_goldens_through_the_device_code_paths(golden_dir, tmp_path):
     for i, e in enumerate(eps):
         for k, v in e.items():
             np.testing.assert_allclose(v, exp[f"ep{i}_{k}"], rtol=0, atol=1e-6)
+
+
+def test_forked_update_equals_the_single_stream_update_bit_for_bit(monkeypatch):
+    """Round 5: the LDS-free update's independent launches run on two side streams that leave from and rejoin the phase's stream
+    (learner_native: _branch / _join; opt-in, KS_LEARNER_FORK=1).  Same kernels, same inputs, deterministic reductions: after 8 updates - eager and replayed from a
+    captured graph - every parameter, gradient and Adam moment equals the single-stream run's (KS_LEARNER_FORK=0) bit for bit."""
+    from kinovagrasping_amd.ddpgfd import DDPGfD
+    from kinovagrasping_amd.learner_native import NativeDDPGfDUpdate
+    dev = torch.device("cuda", 0)
+    bs = _batches(dev, 8)
+
+    def run(fork, graph):
+        monkeypatch.setenv("KS_LEARNER_FORK", "1" if fork else "0")
+        torch.manual_seed(7)
+        pol = DDPGfD(82, 4, 0.8, 5, hidden=(256, 256), device=dev)
+        nat = NativeDDPGfDUpdate(pol)
+        assert nat.lds_free and nat.fork == fork
+        if not graph:
+            for b in bs:
+                nat.train_on_batch(*b)
+        else:
+            static = [t.clone() for t in bs[0]]
+            s = torch.cuda.Stream(dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                nat.train_on_batch(*static)                                   # warm-up outside the capture (allocations, library handles)
+            torch.cuda.current_stream(dev).wait_stream(s)
+            torch.cuda.synchronize()
+            torch.manual_seed(7)
+            pol2 = DDPGfD(82, 4, 0.8, 5, hidden=(256, 256), device=dev)
+            for k in pol._flat_params:
+                pol._flat_params[k].copy_(pol2._flat_params[k])
+            for net in (nat.actor, nat.critic):
+                net.grad.zero_(); net.exp_avg.zero_(); net.exp_avg_sq.zero_()
+            nat.it.zero_(); nat.it_head.zero_(); pol.total_it = 0
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                nat.train_on_batch(*static)
+            for b in bs:
+                for dst, src in zip(static, b):
+                    dst.copy_(src)
+                g.replay()
+        torch.cuda.synchronize()
+        return {k: v.clone() for k, v in pol._flat_params.items()}, [(n.grad.clone(), n.exp_avg.clone(), n.exp_avg_sq.clone()) for n in (nat.actor, nat.critic)]
+
+    ref_p, ref_o = run(False, False)
+    for fork, graph in ((True, False), (True, True), (False, True)):
+        p, o = run(fork, graph)
+        for k in ref_p:
+            assert torch.equal(p[k], ref_p[k]), (fork, graph, k, (p[k] - ref_p[k]).abs().max().item())
+        for a, b in zip(o, ref_o):
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), (fork, graph)

@@ -148,7 +148,7 @@ def test_recorded_demonstrations_under_mujocos_own_narrow_phase_scheme(rec):
 
 
 # ---------------------------------------------------------------------------------- the recorded contact trajectory
-HEAT_MIN_SUCCESS_BAND, HEAT_MIN_CENTRE_FAIL, HEAT_MIN_CORNER_FAIL = 0.9, 0.5, 0.7      # measured: see profiles/r04_naive_heatmap.txt
+HEAT_MIN_SUCCESS_BAND, HEAT_MIN_CENTRE_FAIL, HEAT_MIN_CORNER_FAIL = 0.938, 0.912, 0.804    # measured 0.988 / 0.962 / 0.854 (round 5, GPU) - 0.05
 ROWS_EXACT = 41          # rows 0..40 of Pose_file_2: every column within 1e-9 (the dot product: 4e-9) of real MuJoCo (measured 1.9e-10 / 2.3e-9)
 ROWS_CLOSE = 46          # rows 41..45: within 2e-7 (measured 8.2e-8): the third finger's first contact; finger 3's command saturated
 
@@ -316,10 +316,10 @@ def test_gpu_replays_the_recorded_mujoco_contact_trajectory(rec, precision):
         assert err[:ROWS_EXACT].max() < 1e-9 and err[ROWS_EXACT:ROWS_CLOSE].max() < 2e-7
         assert err[:, 7:].max() < 2e-4 and err[:, :7].max() < 8e-4
     else:
-        assert err[:5].max() < 1e-6                                          # before and at first touch
-        assert err[:22].max() < 5e-6                                         # per row, not a median
-        assert np.median(err[:ROWS_CLOSE].max(1)) < 1e-5
-        assert err[:, 7:].max() < 6e-3 and err[:, 9].max() < 1.5e-3 and err[:, :7].max() < 1.5e-2
+        # measured (round 5): rows 1-14 2e-7, rows 15-28 3e-6, rows 29-45 (grasp closed, lift to 0.10 m) 6.4e-6; rows 46-62 object 1.1e-4, joints 1.0e-3
+        assert err[:15].max() < 1e-6                                         # approach, first touch, the first ten rows of pushing
+        assert err[:ROWS_CLOSE].max() < 1.5e-5                               # per row, through push, grasp and the first 4.5 cm of the lift
+        assert err[:, 7:].max() < 3e-4 and err[:, 9].max() < 2e-4 and err[:, :7].max() < 2.5e-3
     assert got[-1, 9] > 0.19
     sim.close()
 

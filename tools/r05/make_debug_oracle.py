@@ -24,8 +24,16 @@ rep('#include <string.h>', '''#include <string.h>
 #include <stdio.h>
 int ko_trace = 0, ko_dbg_drop_g1 = -1, ko_dbg_drop_g2 = -1, ko_dbg_g1 = 3, ko_dbg_obj_first = 1, ko_dbg_pnormal = 0, ko_dbg_mjterm = 0;
 double ko_dbg_qfrc[15], ko_dbg_ddist = 0, ko_dbg_rotz = 0, ko_dbg_dpos[3] = {0, 0, 0}, ko_dbg_tilt = 0, ko_dbg_mu = 0, ko_dbg_Rscale = 1, ko_dbg_frot = 0,
-       ko_dbg_skew = 1e-6, ko_dbg_mjtol = 1e-8;''')
+       ko_dbg_skew = 1e-6, ko_dbg_mjtol = 1e-8;
+int ko_dbg_tie_mode = 0, ko_dbg_tie_n = 0, ko_dbg_tie_script[256] = {0}; /* mode 1: every near-zero component of a box support direction takes its sign from the next script entry */
+int ko_dbg_partner = 0, ko_dbg_tie_code[16] = {0}; /* tie study: sign pattern (bits 0-2 flip x y z) of the box's support skew, per partner geom */''')
 rep('const double sk = KO_SUPPORT_SKEW * (fabs(ld[0])', 'const double sk = ko_dbg_skew * (fabs(ld[0])')
+rep('ld[0] += sk * KO_SKEW_X; ld[1] += sk * KO_SKEW_Y; ld[2] += sk * KO_SKEW_Z;',
+    '''if (ko_dbg_tie_mode == 1 && g == 8) {
+          for (int k = 0; k < 3; k++) if (fabs(ld[k]) < 1e-9 * (fabs(ld[0]) + fabs(ld[1]) + fabs(ld[2]))) { ld[k] = (ko_dbg_tie_script[ko_dbg_tie_n & 255] ? -1e-12 : 1e-12); ko_dbg_tie_n++; }
+      } else
+      { const int code = (g == 8) ? ko_dbg_tie_code[ko_dbg_partner & 15] : 0;
+          ld[0] += sk * KO_SKEW_X * ((code & 1) ? -1 : 1); ld[1] += sk * KO_SKEW_Y * ((code & 2) ? -1 : 1); ld[2] += sk * KO_SKEW_Z * ((code & 4) ? -1 : 1); }''')
 rep('    mulmatTvec3(ld, s->geom_xmat[g], dir);', '''    mulmatTvec3(ld, s->geom_xmat[g], dir);
     if (ko_trace >= 2 && g == 8) { double mn = fabs(ld[0]); if (fabs(ld[1]) < mn) mn = fabs(ld[1]); if (fabs(ld[2]) < mn) mn = fabs(ld[2]);
         fprintf(stderr, "      box support local dir (%.3e %.3e %.3e)%s\\n", ld[0], ld[1], ld[2], mn < 1e-9 ? "  <-- TIE" : ""); }''')
@@ -57,6 +65,7 @@ rep('''    copy3(c->pos, pos);
         for (int i = 0; i < 3; i++) { c->frame[3 + i] = t1[i]; c->frame[6 + i] = t2[i]; }
     }''')
 rep('const int obj_first = (g2 == KO_OBJ_GEOM);', 'const int obj_first = ko_dbg_obj_first && (g2 == KO_OBJ_GEOM);')
+rep('    const int obj_first = ko_dbg_obj_first && (g2 == KO_OBJ_GEOM);', '    ko_dbg_partner = g1;\n    const int obj_first = ko_dbg_obj_first && (g2 == KO_OBJ_GEOM);')
 rep('''        int g1 = (int)m->pairs[p][0], g2 = (int)m->pairs[p][1];
         if (g1 == 0)''', '''        int g1 = (int)m->pairs[p][0], g2 = (int)m->pairs[p][1];
         if (g1 == ko_dbg_drop_g1 && g2 == ko_dbg_drop_g2) continue;
