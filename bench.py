@@ -572,7 +572,8 @@ def main():
                        "free_running": (dict(trainer.counts(), launch_steps=all_launches, first_timed_launch=timed_first, timed_launches=launches) if free_running else None),
                        "init_policy": (init_policy if args.mode == "ddpg" else None),
                        "learner": learner_form, "learner_stream_overlaps_rollout_stream": (getattr(trainer, "streams_overlap", None) if trainer is not None else None), "expert_mix": (expert_info if args.mode == "ddpg" else None),
-                       "parallelism": f"env-shard x{world}" + (" + grad all-reduce" if world > 1 and args.mode == "ddpg" else "")},
+                       "parallelism": f"env-shard x{world}" + ((" + replicas averaged per launch" if getattr(trainer, "replica_sync", "") == "average-per-launch" else " + grad all-reduce")
+                                                                    if world > 1 and args.mode == "ddpg" else "")},
             "roofline": {"bound": "hbm", "kernel": "k_rollout (per env-step)" if free_running else "k_env_step", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
@@ -597,6 +598,7 @@ def main():
             "rccl": ({"ranks": world, "backend": os.environ.get("KS_DIST_BACKEND", "nccl"), "NCCL_ALGO": os.environ.get("NCCL_ALGO", "default"), "NCCL_PROTO": os.environ.get("NCCL_PROTO", "default"),
                       "allreduces_per_update": 2, "bytes_per_allreduce": int(policy._flat_params["critic"].numel() * 4),
                       "exchange": getattr(trainer, "exchange_note", None),
+                      "replica_sync": getattr(trainer, "replica_sync", "per-update") if trainer is not None else None,   # "average-per-launch": pipeline.AsyncTrainer without peer mapping
                       "exchange_failed_call": (trainer.native.exchange.failed_epoch() if getattr(trainer, "native", None) is not None
                                                and trainer.native.exchange is not None else None)}
                      if world > 1 and args.mode == "ddpg" else None),

@@ -65,6 +65,7 @@ class NativeDDPGfDUpdate:
         # (before the first update, or after finish_pending() has applied it eagerly, e.g. ahead of a checkpoint).
         self.it_head = torch.zeros(1, dtype=torch.long, device=policy.device)
         self.exchange = None             # exchange.PeerExchange when the ranks can map each other's memory (pipeline.GraphedTrainer)
+        self.local_gradients = False     # pipeline.AsyncTrainer, replica_sync "average-per-launch": no per-update exchange, replicas averaged per launch
         self.pipelined = False        # set by pipeline.GraphedTrainer: the body marks its actor step pending for the next head
         policy._native = self                                                  # DDPGfD.save / load keep the Adam state in sync
         self.import_optimizer_state()
@@ -376,7 +377,7 @@ class NativeDDPGfDUpdate:
         if not (dist.is_available() and dist.is_initialized()):
             return
         world = dist.get_world_size(self.p.process_group)
-        if world == 1:
+        if world == 1 or self.local_gradients:
             return
         g = getattr(self, net).grad
         if self.exchange is not None:

@@ -356,12 +356,26 @@ class AsyncTrainer(GraphedTrainer):
         if not self.native.lds_free:
             raise ValueError("AsyncTrainer needs the LDS-free learner kernels (hidden widths 256-256 / 128-128 / 64-64): the persistent rollout kernel "
                              "holds every CU's LDS for the whole launch, a learner built on library GEMMs could only run behind it")
+        # How the replicas are kept together:
+        #   "per-update"         every update's two gradient buffers are averaged over the ranks before Adam (north_star's scheme): through the
+        #                        LDS-free peer exchange beside the persistent kernel, or through a host-side backend (gloo);
+        #   "average-per-launch" the ranks cannot map each other's memory and the process group's collectives are library KERNELS (RCCL) that need
+        #                        LDS - which the persistent rollout kernel holds on every CU until its launch ends.  Rather than falling back to lock
+        #                        step, each rank applies the updates of a launch (<= `chunk` env-steps) with its LOCAL gradients, beside its own
+        #                        free-running rollout, and at the END of the launch - where the library kernels can run - parameters, target
+        #                        parameters and Adam moments are averaged over the ranks (one all-reduce of 8 flat buffers, 5.6 MB at 256-256) and the
+        #                        averaged actor is published.  Replicas are bit-identical at every launch boundary and at most one launch of local
+        #                        updates apart in between (periodic model averaging / local SGD: NOT the per-update gradient all-reduce - stated in
+        #                        the bench line as config.replica_sync).  KS_ASYNC_SYNC=average forces it (tests), KS_ASYNC_LIBRARY_ALLREDUCE=1 keeps
+        #                        the per-update library all-reduce (it then only runs between launches: the learner lags a whole launch).
+        self.replica_sync = "per-update" if self.distributed else "single rank"
         if self.distributed and self.native.exchange is None:
             import torch.distributed as dist
-            if dist.get_backend(policy.process_group) == "nccl" and os.environ.get("KS_ASYNC_LIBRARY_ALLREDUCE", "0") == "0":
-                # (a host-side backend such as gloo has no kernels to starve; KS_ASYNC_LIBRARY_ALLREDUCE=1 overrides)
-                raise ValueError("AsyncTrainer needs the LDS-free peer exchange between the ranks (" + self.exchange_note + "): the library's all-reduce kernels "
-                                 "need LDS and would only run between the persistent rollout launches")
+            forced = os.environ.get("KS_ASYNC_SYNC", "")
+            if forced == "average" or (dist.get_backend(policy.process_group) == "nccl" and os.environ.get("KS_ASYNC_LIBRARY_ALLREDUCE", "0") == "0"):
+                self.replica_sync = "average-per-launch"
+                self.native.local_gradients = True                       # native.allreduce() becomes a no-op: the body applies local gradients
+                self.exchange_note += "; free-running rollout kept: local updates, replicas averaged at every launch boundary"
         if not (eng.native and eng.device_noise and eng._fused_actor_layers() is not None and sim.cfg.auto_reset and sim.obs_env_major):
             raise ValueError("AsyncTrainer needs the fused actor path (3-layer MLP at a supported width, in-kernel noise), auto_reset and env-major obs")
         flat = policy._flat_params["actor"]
@@ -503,10 +517,28 @@ class AsyncTrainer(GraphedTrainer):
                         self.publish()
                         self._body()
         self.env_steps += n_steps
+        if learn and self.replica_sync == "average-per-launch":
+            with torch.cuda.stream(side):
+                self.average_replicas()
         # the replica check (process-group collectives + a host read: kernels that need LDS, which the persistent launch holds) runs
         # at the end of a launch, not from inside the update path
         if learn and self.check_every and self.updates // self.check_every != (self.updates - n_steps * self.updates_per_step) // self.check_every:
             self.check_replicas()
+
+    def average_replicas(self):
+        """replica_sync == "average-per-launch": the pending (pipelined) actor step is applied, then the flat parameter buffers of the four
+        networks and the Adam moments of actor and critic are averaged over the process group (library collectives on the current stream: they
+        execute once the persistent launch has released the CUs' LDS), and the averaged actor becomes the newest published version."""
+        import torch.distributed as dist
+        nat, pol = self.native, self.policy
+        nat.finish_pending()
+        world = dist.get_world_size(pol.process_group)
+        bufs = [pol._flat_params[k] for k in ("actor", "critic", "actor_target", "critic_target")]
+        bufs += [b for net in (nat.actor, nat.critic) for b in (net.exp_avg, net.exp_avg_sq)]
+        for b in bufs:
+            dist.all_reduce(b, op=dist.ReduceOp.SUM, group=pol.process_group)
+            b.div_(world)
+        self.publish()
 
     def step(self):
         self.run(1)

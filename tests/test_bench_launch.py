@@ -171,6 +171,25 @@ def test_two_ranks_free_running_rollout(p2p):
 
 
 @pytest.mark.gpu
+def test_two_ranks_free_running_rollout_with_replicas_averaged_per_launch():
+    """The node-run fallback of round 5: when the ranks cannot map each other's memory and the process group's
+    collectives are library kernels (RCCL), AsyncTrainer keeps the free-running rollout, applies each launch's updates with LOCAL gradients
+    and averages parameters / targets / Adam moments at the launch boundary (KS_ASYNC_SYNC=average forces that mode here, over gloo, two
+    ranks sharing this box's GPU).  The ranks' shards differ, so their local updates differ - yet the replicas must be bit-identical
+    after every launch, the line must say which synchronisation ran, and no episode may be dropped."""
+    r = run_bench(["--gpus", "2", "--rollout", "free", "--chunk", "5", "--steps", "10", "--warmup", "5", "--envs-per-gpu", "512", "--no-cpu-baseline",
+                   "--pretrain-updates", "45", "--steady-steps", "0"],
+                  env={"KS_DIST_BACKEND": "gloo", "KS_VISIBLE_GPUS": "1", "KS_P2P": "0", "KS_ASYNC_SYNC": "average", "KS_REPLICA_CHECK_EVERY": "20"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["launch"].startswith("free-running rollout kernel")
+    assert line["rccl"]["replica_sync"] == "average-per-launch" and "replicas averaged per launch" in line["config"]["parallelism"]
+    assert "local updates" in line["rccl"]["exchange"]
+    assert line["replica_weight_checksum_spread"] == 0.0 and line["replica_checks_during_run"] >= 2 and line["nonfinite_envs"] == 0
+    assert line["config"]["free_running"]["episodes_dropped"] == 0 and line["config"]["learner_updates_timed"] == 10
+
+
+@pytest.mark.gpu
 def test_bench_line_on_a_multi_geom_object():
     """`bench.py --shape TBottleS`: the single-object workload on a multi-geom object (libkinova_sim_mg.so) - free-running rollout kernel
     with the learner beside it; the line names the object, carries no PMC block of another workload, and no env raised a status flag"""

@@ -25,4 +25,7 @@ timeout 1200 bash tools/pmc_run.sh sim gpurun_out/pmc_sim > $out/pmc_sim_summary
 timeout 1500 bash tools/pmc_run.sh ddpg gpurun_out/pmc_ddpg > $out/pmc_ddpg_summary.txt 2>&1
 python3 $B --no-cpu-baseline --init-policy none > $out/ddpg_noinit_bench.log 2>&1
 python3 $B --no-cpu-baseline --config 5 --cohort 16 --rollout lockstep > $out/config5_cohort16_lockstep_bench.log 2>&1
-for f in ddpg_noinit config5_cohort16_lockstep; do grep '^{' $out/${f}_bench.log | tail -1 | cut -c1-150; done
+KS_LEARNER_FORK=1 python3 $B --no-cpu-baseline --rollout lockstep > $out/ddpg_lockstep_fork_bench.log 2>&1
+KS_LEARNER_FORK=1 python3 $B --no-cpu-baseline --rollout lockstep --serial-learner > $out/ddpg_lockstep_serial_fork_bench.log 2>&1
+python3 $B --no-cpu-baseline --rollout lockstep --serial-learner > $out/ddpg_lockstep_serial_bench.log 2>&1
+for f in ddpg_noinit config5_cohort16_lockstep ddpg_lockstep_fork ddpg_lockstep_serial_fork ddpg_lockstep_serial; do grep '^{' $out/${f}_bench.log | tail -1 | cut -c1-150; done
