@@ -1647,7 +1647,7 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
 #ifdef KS_STAMP_HULL
     if (prof) { prof[24] += 1.f; prof[25] += (float)pg.cnt_support; prof[26] += (float)(th1 - th0); prof[27] += (float)(clock64() - th1); prof[28] += (float)pg.t_sup; prof[29] += (float)pg.t_clo; }
 #endif
-    h1_out = pg.hint1 & PC_HINT_MAX; h2_out = pg.hint2 & PC_HINT_MAX;
+    h1_out = pg.hint1 <= PC_HINT_MAX ? pg.hint1 : 0; h2_out = pg.hint2 <= PC_HINT_MAX ? pg.hint2 : 0;   // (a vertex id beyond the 10-bit field is not remembered: start 0, not a masked id)
     const int pi = (flags >> 12) & PAIR_INDEX_MASK;
     if (obj_first && (r == 1 || r == 3)) { dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
     if (r == 1) { stage_contact(scr, slot, body1, body2, pi, mu, dist, pos, dir); return 1; }
@@ -1655,7 +1655,7 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
         // 2: overlap (or undecided beyond the margin), 3: a margin-zone result that is not a certified separation
         T mdir[3], mpos[3];
         const bool hit = mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, mdir, mpos, ws);
-        h1_out = pg.hint1 & PC_HINT_MAX; h2_out = pg.hint2 & PC_HINT_MAX;
+        h1_out = pg.hint1 <= PC_HINT_MAX ? pg.hint1 : 0; h2_out = pg.hint2 <= PC_HINT_MAX ? pg.hint2 : 0;   // (a vertex id beyond the 10-bit field is not remembered: start 0, not a masked id)
         if (hit) {
             if (obj_first) { mdir[0] = -mdir[0]; mdir[1] = -mdir[1]; mdir[2] = -mdir[2]; }
             stage_contact(scr, slot, body1, body2, pi, mu, -depth, mpos, mdir);

@@ -597,8 +597,9 @@ def object_size_obs(size, filename, piece_sizes=()):
     final = np.zeros(3)
     # the size letter the bowls' constants are scaled by is `self.obj_size`, which only __init__ ('m': the default model, ENV:62) and the
     # obj_params hook (obj_shape_generator, ENV:1057-1147) ever set: an object that comes from the object schedule - every training and
-    # evaluation episode of main_DDPGfD.py (select_object -> get_object, ENV:1171-1172, 986-1005) - is seen with 'm', whatever its file says
-    letter = None
+    # evaluation episode of main_DDPGfD.py (select_object -> get_object, ENV:1171-1172, 986-1005) - is seen with 'm', whatever its file says:
+    # compiled with 'm' = x 0.85 (the obj_params hook's own letters, 's' x 0.7 / 'b' x 1, are pinned as data in tests/golden/reset_helpers.npz)
+    BOWL_SCALE_M = 0.85
     for size in [np.array(p_, dtype=np.float64) for p_ in list(piece_sizes)[::-1]] + [np.array(size, dtype=np.float64)]:
         size = size.copy()
         if size[2] == 0:
@@ -609,9 +610,7 @@ def object_size_obs(size, filename, piece_sizes=()):
             size[0], size[2] = size[2], size[0]
         if "Bowl" in filename:
             final[:] = [0.17, 0.17, 0.075] if "Rect" in filename else [0.175, 0.175, 0.07]
-            scale = {"m": 0.85, "s": 0.7}.get(letter.group(1) if letter else "m", 1.0)
-            if scale != 1.0:
-                final *= scale         # (the reference multiplies component by component: same products)
+            final *= BOWL_SCALE_M      # (the reference multiplies component by component: same products)
         else:
             final[0] = max(size[0], final[0])
             final[1] = max(size[1], final[1])

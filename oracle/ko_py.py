@@ -115,13 +115,18 @@ class OracleModel:
 class OracleSim:
     """One fp64 env.  Arrays returned by properties are live views into the C struct."""
 
-    def __init__(self, model: OracleModel, hand_quat, solver_iterations: int = 8, solver: int = 0):
+    def __init__(self, model: OracleModel, hand_quat, solver_iterations: int = 8, solver: int = 0, ncon_max: int | None = None):
+        """ncon_max: contacts kept per substep (ko_sim_new: 24, 40 for multi-geom objects = the two product libraries' NCON_MAX).  A test that
+        runs a SINGLE-geom object in a context of libkinova_sim_mg.so passes 40: that library keeps 40 for every model it loads."""
         self.model = model
         hq = np.ascontiguousarray(hand_quat, dtype=np.float64)
         self.p = lib().ko_sim_new(model.ptr, _p(hq))
         self.s = self.p.contents
         self.s.solver_iterations = solver_iterations
         self.s.solver = solver
+        if ncon_max is not None:
+            assert 0 < ncon_max <= NCON_MAX
+            self.s.ncon_max = ncon_max
 
     def __del__(self):
         try:

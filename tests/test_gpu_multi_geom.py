@@ -129,7 +129,7 @@ def test_single_geom_object_in_the_multi_geom_library():
     sim = _sim(2, shapes, precision=64)
     assert sim.multi_geom
     obs = sim.reset(torch.as_tensor(q), torch.as_tensor(np.repeat(hq[:, None], 2, 1)), object_id=torch.tensor([0, 1], dtype=torch.int32)).double().cpu().numpy()
-    oracles = [ko.OracleSim(ko.OracleModel(scenarios.model_blob(s)), hq, solver_iterations=SOLVER_ITERATIONS) for s in shapes]
+    oracles = [ko.OracleSim(ko.OracleModel(scenarios.model_blob(s)), hq, solver_iterations=SOLVER_ITERATIONS, ncon_max=40) for s in shapes]   # (the mg library keeps 40 contacts for every model)
     for i, o in enumerate(oracles):
         assert np.abs(obs[i] - o.env_reset(q[:, i].copy())).max() < 1e-9
     for t in range(4):
@@ -241,7 +241,7 @@ def test_vec_env_with_multi_geom_shapes_of_a_stage():
             assert np.hypot(*env.get_obj_coords()[e][:2]) <= sizes["BowlS"][0] / 2 and abs(env.get_obj_coords()[e][2] - sizes["BowlS"][2] / 4) < 1e-12
     assert seen_fallback >= 1
     for e in (0, 7, 19, n - 1):
-        o = ko.OracleSim(ko.OracleModel(scenarios.model_blob(names[e])), scenarios.hand_quat_for(poses[e]), solver_iterations=SOLVER_ITERATIONS)
+        o = ko.OracleSim(ko.OracleModel(scenarios.model_blob(names[e])), scenarios.hand_quat_for(poses[e]), solver_iterations=SOLVER_ITERATIONS, ncon_max=40)
         q0 = np.zeros(16); q0[9:12] = scenarios.reset_body_position(names[e], env.get_obj_coords()[e]); q0[12] = 1     # (the reference reset's 5 cm correction)
         q0[0:3] = scenarios.hand_slide_offsets(poses[e], names[e])
         ref = o.env_reset(q0)

@@ -357,3 +357,32 @@ def test_gpu_naive_controller_success_map_vs_recorded_heatmap(rec):
           f"far corners {corners.sum()} -> ours fail in {fail_corners:.3f}; near-palm centre {centre.sum()} -> ours fail in {fail_centre:.3f}")
     assert agree_ok > HEAT_MIN_SUCCESS_BAND and fail_centre > HEAT_MIN_CENTRE_FAIL and fail_corners > HEAT_MIN_CORNER_FAIL
     sim.close()
+
+
+def test_support_skew_is_not_what_matches_the_recording(rec, tmp_path):
+    """the 1e-6 skew of the hull-frame support direction (ko_physics.c: hull_support, ks_core.h: pair_support) is this repository's
+    tie rule, not MuJoCo's arithmetic.  The oracle rebuilt WITHOUT it (-DKO_SUPPORT_SKEW_OVERRIDE=0: ties fall by the order of the vertex
+    scan) replays the recorded MuJoCo trajectory just as well through row 45 - the pinned rows do not depend on the rule; it exists so that
+    fp32 and fp64 break ties alike."""
+    import subprocess, sys, textwrap
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    so = tmp_path / "libko_noskew.so"
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-std=c11", "-fno-fast-math", "-ffp-contract=off", "-DKO_SUPPORT_SKEW_OVERRIDE=0", "-shared", "-o", str(so)] +
+                          [str(root / "oracle" / f) for f in ("ko_model.c", "ko_physics.c", "ko_env.c")] + ["-lm"])
+    code = textwrap.dedent(f"""
+        import sys, ctypes
+        sys.path.insert(0, {str(root)!r})
+        import numpy as np
+        from oracle import ko_py
+        ko_py.build = lambda force=False: {str(so)!r}
+        from tests import old_env
+        pf2 = np.load({str(root / 'tests' / 'golden' / 'mujoco_recorded.npz')!r})["pose_file_2"]
+        rows, us, _ = old_env.replay_recording(pf2, n_rows=46)
+        err = np.abs(rows - pf2[:46])
+        print(err[:41, :47].max(), err[41:46].max())
+    """)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    e_exact, e_close = (float(x) for x in out.stdout.split()[-2:])
+    assert e_exact < 1e-9 and e_close < 2e-7, (e_exact, e_close)
