@@ -533,7 +533,7 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/pmc_run.sh);
         # the committed summary applies to the 4096-env workload only
         traffic, traffic_note, issue = None, "no PMC summary for this workload", None
-        pmc = ROOT / "profiles" / ("r04_pmc_sim.json" if args.mode == "sim" else "r04_pmc_free.json" if free_running else "r04_pmc_ddpg.json")     # counters of THIS workload and THIS kernel (k_rollout's are per env-step)
+        pmc = ROOT / "profiles" / ("r05_pmc_sim.json" if args.mode == "sim" else "r05_pmc_free.json" if free_running else "r05_pmc_ddpg.json")     # counters of THIS workload and THIS kernel (k_rollout's are per env-step)
         if pmc.exists() and n == 4096 and not mixed and args.shape == "CubeS":
             pj = json.loads(pmc.read_text())
             traffic, traffic_note = pj["hbm_bytes_per_launch"], pj["note"]
