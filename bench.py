@@ -320,7 +320,9 @@ def main():
             eng.start(obs0)
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
             groups = (n + 15) // 16 if not mixed else int(sum((np.bincount(oid_all[sl], minlength=len(scenarios.SHAPES)) + 15) // 16))
-            fits = groups <= cus or groups % cus == 0            # every persistent workgroup steps the same number of 16-env groups
+            # round 5: with more groups than compute units the persistent kernel takes them from a ready queue (k_rollout), so an uneven count - config 5
+            # drawn per env: 526 groups on 256 CUs - no longer paces the launch at its fullest workgroup; the fixed deals (KS_ROLLOUT_DEAL=static / rr) do
+            fits = groups <= cus or groups % cus == 0 or os.environ.get("KS_ROLLOUT_DEAL", "queue") == "queue"
             free_running = not args.serial_learner and (args.rollout == "free" or (args.rollout == "auto" and fits and tuple(args.hidden) in ((256, 256), (128, 128), (64, 64))))
             if free_running:
                 try:
@@ -475,6 +477,8 @@ def main():
             for _ in range(reps):
                 trainer.g_head.replay()
                 trainer._body()
+            if getattr(trainer, "replica_sync", "") == "average-per-launch":
+                trainer.average_replicas()                 # (these were local updates: the ranks meet again as they do at the end of a launch)
         trainer.main.wait_stream(trainer.side)
         barrier()
         upd_ms = (time.perf_counter() - t1) / reps * 1e3

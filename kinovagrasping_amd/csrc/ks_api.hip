@@ -777,6 +777,18 @@ __device__ __noinline__ void rollout_store(const ks_rollout_args* __restrict__ r
     ra.done_out[i] = done;
 }
 
+// k_rollout's ready queue (more groups than resident workgroups): [0] head ticket, [1] tail ticket, [ROLLOUT_Q_STEPS + g] env-steps group g has done in
+// this launch, [ROLLOUT_Q_RING ..] the ring of lap-tagged group ids
+constexpr int ROLLOUT_QCAP = 2048, ROLLOUT_Q_STEPS = 16, ROLLOUT_Q_RING = ROLLOUT_Q_STEPS + ROLLOUT_QCAP, ROLLOUT_Q_WORDS = ROLLOUT_Q_RING + ROLLOUT_QCAP;
+__global__ void k_rollout_queue_init(int* __restrict__ queue, int n_groups) {
+    for (int i = threadIdx.x; i < ROLLOUT_Q_WORDS; i += blockDim.x) {
+        int v = 0;
+        if (i == 1) v = n_groups;                                                                  // tail: the first push goes behind the initial fill
+        if (i >= ROLLOUT_Q_RING && i - ROLLOUT_Q_RING < n_groups) v = (1 << 12) | (i - ROLLOUT_Q_RING + 1);     // lap 1, group i
+        queue[i] = v;
+    }
+}
+
 // One env-step of the workgroup's envs (the body of k_rollout's loop).
 template <int NT1, int NT2>
 __device__ __forceinline__ void rollout_iter(const Model<float>& m, const Hulls<float>& hu, const Buffers<float>* __restrict__ bdev, int N, int frame_skip,
@@ -871,7 +883,7 @@ __device__ __noinline__ int rollout_restage(const Model<float>* __restrict__ mp,
 template <int NT1, int NT2>
 __global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__ models, Buffers<float> b, const Buffers<float>* __restrict__ bdev, int N,
                                                 int frame_skip, int iters, int epw, int pair_memory, const ObsOut<float>* __restrict__ out,
-                                                const ks_rollout_args* __restrict__ rap, int n_iter, int n_groups) {
+                                                const ks_rollout_args* __restrict__ rap, int n_iter, int n_groups, int* __restrict__ queue) {
     using T = float;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef KS_ROLLOUT_STAMP
@@ -902,6 +914,73 @@ __global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__
     const long long wk_loop = wall_clock64();
     const long long ck_loop = clock64();
 #endif
+    if (queue != nullptr) {
+        // ---- MORE GROUPS THAN RESIDENT WORKGROUPS, round 5: a FIFO of READY groups instead of a fixed deal.  The ring starts with every group
+        // (k_rollout_queue_init); a workgroup pops the group at the head, steps it ONCE, and - unless that was the group's last env-step of the
+        // launch - pushes it back at the tail.  A popped group is ready by construction (nobody waits for a predecessor), groups take turns in
+        // completion order (every env still does exactly n_iter env-steps per launch), and a workgroup is never idle while a group is ready: a
+        // launch costs sum(group-steps) / workgroups instead of (groups per workgroup) x the slowest group.  With the fixed deal 526 groups on 256
+        // CUs (BASELINE config 5 drawn per env: 14 partly filled groups) paced the launch at THREE group-steps per env-step, and a stage's bowls
+        // (4.5 ms per env-step against 1.3 ms for its cubes) paced every workgroup that held one.
+        // The group's state travels through global memory as before (rollout_iter loads it at the start and stores it at the end of every
+        // env-step); what is new is that the next env-step may run on another CU, possibly of another XCD: the workgroup that finishes a group
+        // releases at agent scope (every wave: its own stores; buffer_wbl2) before the push, the one that pops it acquires before its first load.
+        // Ring entries carry their lap ((ticket / QCAP + 1) << 12 | group + 1): a popper spins until ITS lap's entry is there - only when fewer
+        // groups are ready than workgroups free, i.e. when it would idle anyway.
+        __shared__ int s_grp;
+        int* const q_head = queue, * const q_tail = queue + 1, * const q_steps = queue + ROLLOUT_Q_STEPS;
+        unsigned* const ring = (unsigned*)(queue + ROLLOUT_Q_RING);
+        const int total = n_groups * n_iter;
+#pragma clang loop unroll(disable)
+        for (;;) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int t = atomicAdd(q_head, 1);
+                int grp = -1;
+                if (t < total) {
+                    const unsigned lap = (unsigned)(t / ROLLOUT_QCAP) + 1u;
+                    unsigned v = __hip_atomic_load(&ring[t % ROLLOUT_QCAP], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    while ((v >> 12) != lap) {
+                        __builtin_amdgcn_s_sleep(16);
+                        v = __hip_atomic_load(&ring[t % ROLLOUT_QCAP], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    grp = (int)(v & 4095u) - 1;
+                }
+                s_grp = grp;
+            }
+            __syncthreads();
+            const int grp = __builtin_amdgcn_readfirstlane(s_grp);
+            if (grp < 0) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");              // the group's state as its last env-step - on whatever CU - left it
+            const int want = __builtin_amdgcn_readfirstlane(bdev->wg_model[grp]);
+            if (want != staged) {
+                staged = want;
+                blocks = lds + rollout_restage(models + staged, lds0, hup);
+            }
+            const Model<T>* mi = ml;
+            Hulls<T>* hi = hup;
+            const Buffers<T>* bi = bdev;
+            const ObsOut<T>* oi = out;
+            const ks_rollout_args* ri = rap;
+            KS_LDS T* ki = blocks;
+            int gi = grp;
+            asm volatile("" : "+s"(mi), "+s"(hi), "+s"(bi), "+s"(oi), "+s"(ri), "+s"(gi));
+            asm volatile("" : "+v"(ki));
+            rollout_iter<NT1, NT2>(*mi, *hi, bi, N, frame_skip, iters, epw, pair_memory, oi, ri, ki, gi);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");              // every wave: its stores of this env-step, before the group is handed on
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int c = q_steps[gi] + 1;                               // (only the group's current owner touches its counter)
+                q_steps[gi] = c;
+                if (c < n_iter) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    const int t2 = atomicAdd(q_tail, 1);
+                    __hip_atomic_store(&ring[t2 % ROLLOUT_QCAP], (((unsigned)(t2 / ROLLOUT_QCAP) + 1u) << 12) | (unsigned)(gi + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        return;
+    }
     // The loop's pointers are laundered through empty asm statements at the top of every iteration: otherwise the compiler hoists
     // loop-invariant address arithmetic and model constants out of the loop and keeps them in registers for the whole launch
     // (388 registers per lane instead of ~344; as an out-of-line call the body saves its callee-saved registers to scratch:
@@ -1415,6 +1494,7 @@ template <typename T> struct Ctx : CtxBase {
         if (h_out) (void)hipHostFree(h_out);
         if (h_ra) (void)hipHostFree(h_ra);
         if (d_ra) (void)hipFree(d_ra);
+        if (d_queue) (void)hipFree(d_queue);
         for (auto& e : ev0) (void)hipEventDestroy(e);
         for (auto& e : ev1) (void)hipEventDestroy(e);
     }
@@ -1510,6 +1590,7 @@ template <typename T> struct Ctx : CtxBase {
         if ((r = alloc(&d_out, (size_t)1))) return r;
         if (!h_out) HIPCHK(hipHostMalloc((void**)&h_out, (H_OUT_RING + CAPTURE_RECORDS) * sizeof(ObsOut<T>), hipHostMallocDefault));
         if (!d_ra) HIPCHK(hipMalloc((void**)&d_ra, sizeof(ks_rollout_args)));
+        if (!d_queue) HIPCHK(hipMalloc((void**)&d_queue, ROLLOUT_Q_WORDS * sizeof(int)));        // (not at launch time: ks_rollout may be captured)
         if (!h_ra) HIPCHK(hipHostMalloc((void**)&h_ra, sizeof(ks_rollout_args) * (H_OUT_RING + CAPTURE_RECORDS), hipHostMallocDefault));
         HIPCHK(hipMemcpy(d_b, &b, sizeof b, hipMemcpyHostToDevice));
         model_loaded = true;
@@ -1518,6 +1599,8 @@ template <typename T> struct Ctx : CtxBase {
     int blocks() const { return (cfg.n_envs + WAVE - 1) / WAVE; }
     // envs per wave and dynamic LDS bytes of the stepping kernels
     int resident_wgs = 256;
+    int* d_queue = nullptr;               // k_rollout's ready queue (ROLLOUT_Q_WORDS ints), used when the context has more groups than resident workgroups
+    bool rollout_queue = true;            // KS_ROLLOUT_DEAL=static / rr: the fixed deals of rounds 3-4 instead
     bool rollout_round_robin = false;     // how k_rollout deals the env groups to its persistent workgroups: contiguous runs (default) or round-robin (KS_ROLLOUT_DEAL=rr)
     int lpw = WAVE;
     bool rays_in_step = false, obs_in_step = false;
@@ -1534,7 +1617,7 @@ template <typename T> struct Ctx : CtxBase {
             // mixed-object contexts: round-robin (cheap and expensive objects average out over a workgroup's groups: BASELINE config 5 with the
             // trained policy 2.89 M env-steps/s against 2.02 M with contiguous runs, round 4); one object: contiguous (nothing to restage)
             rollout_round_robin = n_models > 1;
-            if (const char* e = getenv("KS_ROLLOUT_DEAL")) rollout_round_robin = strcmp(e, "rr") == 0;
+            if (const char* e = getenv("KS_ROLLOUT_DEAL")) { rollout_round_robin = strcmp(e, "rr") == 0; rollout_queue = strcmp(e, "queue") == 0; }
         }
         const size_t lds_max = 160 * 1024;
         const size_t hull_bytes = (size_t)hull_words * sizeof(T) + (USE_LDS ? (size_t)model_words<T>() * sizeof(T) : 0);
@@ -1638,11 +1721,17 @@ template <typename T> struct Ctx : CtxBase {
             if (!rslot) { error = "ks_rollout: more captured calls than the context keeps argument records for"; return KS_ERR_STATE; }
             *rslot = *ra;
             HIPCHK(hipMemcpyAsync(d_ra, rslot, sizeof *ra, hipMemcpyHostToDevice, s));
+            // more groups than resident workgroups: the ready queue (k_rollout); else one group per workgroup, nothing to deal
+            const bool use_queue = rollout_queue && n_wg > resident_wgs && n_wg <= ROLLOUT_QCAP;
+            if (use_queue) {
+                hipLaunchKernelGGL(k_rollout_queue_init, dim3(1), dim3(256), 0, s, d_queue, n_wg);
+            }
 #define KS_ROLLOUT_CASE(A, B)                                                                                                                         \
     if ((ra->h1 + 15) / 16 == A && (ra->h2 + 15) / 16 == B) {                                                                                                 \
         HIPCHK(hipFuncSetAttribute((const void*)k_rollout<A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));                        \
         hipLaunchKernelGGL((k_rollout<A, B>), dim3(n_wg < resident_wgs ? n_wg : resident_wgs), dim3(WG), step_lds, s, d_model, b, (const Buffers<T>*)d_b, N, cfg.frame_skip,              \
-                           cfg.solver_iterations, lpw, (int)cfg.pair_memory, (const ObsOut<T>*)d_out, (const ks_rollout_args*)d_ra, n_iter, rollout_round_robin ? -n_wg : n_wg);                                \
+                           cfg.solver_iterations, lpw, (int)cfg.pair_memory, (const ObsOut<T>*)d_out, (const ks_rollout_args*)d_ra, n_iter,                                              \
+                           (use_queue || !rollout_round_robin) ? n_wg : -n_wg, use_queue ? d_queue : (int*)nullptr);                                                                       \
         HIPCHK(hipGetLastError());                                                                                                                    \
         return KS_OK;                                                                                                                                 \
     }
