@@ -1600,7 +1600,11 @@ template <typename T> struct Ctx : CtxBase {
     // envs per wave and dynamic LDS bytes of the stepping kernels
     int resident_wgs = 256;
     int* d_queue = nullptr;               // k_rollout's ready queue (ROLLOUT_Q_WORDS ints), used when the context has more groups than resident workgroups
-    bool rollout_queue = true;            // KS_ROLLOUT_DEAL=static / rr: the fixed deals of rounds 3-4 instead
+    bool rollout_queue = !MULTI_GEOM;     // KS_ROLLOUT_DEAL=static / rr: the fixed deals of rounds 3-4 instead.  Off in the multi-geom build: its hull tables
+                                          // live in global memory, L2-resident, and the queue's per-task agent-scope acquire (buffer_inv sc1) throws them out of
+                                          // the XCD's L2 every time ANY of its 32 workgroups takes a group: the 14-key stage context 0.87 -> 0.44 M env-steps/s
+                                          // (measured, round 5).  That context is bound by its slowest groups' SEQUENTIAL env-steps anyway (every env does the
+                                          // same number of env-steps per launch): no dealing helps it.  KS_ROLLOUT_DEAL=queue forces the queue.
     bool rollout_round_robin = false;     // how k_rollout deals the env groups to its persistent workgroups: contiguous runs (default) or round-robin (KS_ROLLOUT_DEAL=rr)
     int lpw = WAVE;
     bool rays_in_step = false, obs_in_step = false;

@@ -423,7 +423,8 @@ class AsyncTrainer(GraphedTrainer):
         n_groups = (eng.n + 15) // 16 + max(0, len(getattr(sim, "models", [1])) - 1)       # upper bound (one partly filled group per object)
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
         self.groups_per_workgroup = (n_groups + cus - 1) // cus
-        if n_groups > cus and n_groups % cus and os.environ.get("KS_ROLLOUT_DEAL", "queue") != "queue":      # (the ready queue of round 5 balances any count)
+        if n_groups > cus and n_groups % cus and os.environ.get("KS_ROLLOUT_DEAL", "rr" if getattr(sim, "multi_geom", False) else "queue") != "queue":
+            # (the ready queue of round 5 - the standard library's default - balances any count)
             import warnings
             warnings.warn(f"AsyncTrainer: up to {n_groups} env groups on {cus} compute units: some persistent workgroups step {self.groups_per_workgroup} groups per "
                           f"env-step, others {self.groups_per_workgroup - 1} - the launch runs at the pace of the former (GraphedTrainer's lock-step launches balance "
