@@ -160,6 +160,11 @@ int ks_obs_from_snapshot(ks_ctx *ctx, const void *snap, const void *rays, void *
  * A lock-step launch lasts as long as its slowest wave (1.6 - 1.9 x the median); here a workgroup starts its next env-step the
  * moment it has finished the last.  Per env the arithmetic, the noise stream (Philox keyed by seed, the env's own step count,
  * env) and therefore the trajectory are those of the lock-step calls for the same weights.
+ * A context with more 16-env groups than the GPU has compute units (8192 envs; many objects: one partly filled group per object)
+ * keeps one persistent workgroup per compute unit; the groups are taken from a ready queue - a workgroup steps the group at its
+ * head once and puts it back behind the others - so that no workgroup idles while a group is ready and every env still does
+ * exactly n_iter env-steps per launch (environment variable KS_ROLLOUT_DEAL=static / rr: fixed deals instead; the multi-geom
+ * build keeps the round-robin deal).
  *
  * Actor weights: `actor_pub` holds 3 parameter buffers of `actor_stride` floats (layout: offsets off_*, torch.nn.Linear
  * layout); `actor_ver` is a device counter that the learner increments AFTER it has completely written buffer

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Dev tool: rocprofv3 PMC passes over the bench (separate passes; --kernel-trace only, as the pool requires).
-# usage: bash tools/pmc_run.sh [sim|ddpg|free] [outdir]     - counters of the LAST 40 k_env_step launches of every pass are averaged
+# usage: bash tools/pmc_run.sh [sim|ddpg|free|mg] [outdir]     - counters of the LAST 40 k_env_step launches of every pass are averaged
 #   sim : bench.py --mode sim (config 2 at 4096 envs)          ddpg: bench.py --eager (config 3, learner launched op by op) after 600 untimed pre-training updates
 mode=${1:-sim}
 dir=${2:-gpurun_out/pmc_$mode}
@@ -12,6 +12,7 @@ if [ $mode = free ]; then
   # dispatch (the collector segfaults at 600 pre-training updates, 150 works), k_rollout launches of 10 env-steps each (divide the per-launch figures by 10)
   ARGS="bench.py --rollout free --chunk 10 --steps 20 --warmup 10 --no-cpu-baseline --pretrain-updates ${PMC_PRETRAIN:-150} --steady-steps 0"; KERNEL=k_rollout; FILTER=""
 elif [ $mode = sim ]; then ARGS="bench.py --mode sim --steps 40 --warmup 4 --no-cpu-baseline"
+elif [ $mode = mg ]; then ARGS="bench.py --mode sim --shape ${PMC_SHAPE:-BowlS} --steps 40 --warmup 4 --no-cpu-baseline"      # libkinova_sim_mg.so: a multi-geom object (round 5)
 else ARGS="bench.py --rollout lockstep --eager --steps 40 --warmup 5 --no-cpu-baseline --pretrain-updates 600 --steady-steps 0"; fi   # (--eager: counter collection + the kernel filter segfaults rocprofv3 when the learner runs from HIP graphs)
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM" \

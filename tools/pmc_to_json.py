@@ -18,6 +18,7 @@ if workload == "free":          # k_rollout launches advance 10 env-steps each: 
 out = {
     "kernel": "k_rollout" if workload == "free" else "k_env_step",
     "workload": ("bench.py --mode sim, 4096 envs, CubeS" if workload == "sim" else
+                 "bench.py --mode sim --shape BowlS, 4096 envs: libkinova_sim_mg.so (hull tables in global memory, 9 hulls on the floor, ~15 contacts per env at rest)" if workload == "mg" else
                  "bench.py --rollout free (config 3: DDPG training, 4096 envs, free-running rollout kernel, learner HIP graphs; counters on every dispatch, "
                  "dispatches serialised by the collector so k_rollout runs alone; per-launch figures divided by the 10 env-steps of a launch) after 150 pre-training updates from the committed bench policy (the collector segfaults with 600)" if workload == "free" else
                  "bench.py --eager (config 3: DDPG training, 4096 envs, learner launched op by op - counter collection with the kernel filter segfaults when the learner runs from HIP graphs) after 600 pre-training updates") +
