@@ -386,3 +386,31 @@ def test_support_skew_is_not_what_matches_the_recording(rec, tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     e_exact, e_close = (float(x) for x in out.stdout.split()[-2:])
     assert e_exact < 1e-9 and e_close < 2e-7, (e_exact, e_close)
+
+
+def test_kernel_source_replays_the_recorded_mujoco_contact_trajectory_on_the_host(rec):
+    """The kernel SOURCE (ks_core.h compiled for the host, one lane: tests/native_build.Lane) under the commands recovered from the recording, substep by
+    substep, open loop: the fp64 instantiation stays on the oracle's replay - hence on real MuJoCo 1.50: 1e-9 through row 40, 2e-7 through row 45 - without
+    a GPU (the gfx950 kernels do the same under -m gpu); the fp32 instantiation follows MuJoCo through push, grasp and lift to fp32 accuracy."""
+    from tests.native_build import Lane
+    pf2 = rec["pose_file_2"]
+    rows_o, us, _ = old_env.replay_recording(pf2)
+    hq = scenarios.hand_quat_for("normal")
+    ref_cols = list(range(24, 31)) + [21, 22, 23]
+    cols = [2, 3, 5, 7, 4, 6, 8, 9, 10, 11]
+    for prec, tol_exact, tol_close, tol_all in ((64, 1e-9, 2e-7, 8e-4), (32, 3e-5, 3e-5, 3e-3)):
+        lane = Lane(old_env.old_env_blob(), prec, iters=100)
+        st = (old_env.start_qpos(pf2[0]), np.zeros(15), np.zeros(15))
+        got = [np.zeros(10)]
+        for r in range(1, len(pf2)):
+            for k in range(old_env.FRAME_SKIP):
+                qp, qv, qw, nc, con, status = lane.substep(*st, old_env.ctrl_of(us[r]), hq)
+                st = (qp, qv, qw)
+                if k == old_env.FRAME_SKIP - 2:
+                    got.append(qp[cols].copy())
+        got = np.array(got)
+        err = np.abs(got - pf2[:, ref_cols]); err[0] = 0.0
+        print(f"host lane fp{prec}: rows 1-{ROWS_EXACT - 1} {err[:ROWS_EXACT].max():.2e}, rows {ROWS_EXACT}-{ROWS_CLOSE - 1} {err[ROWS_EXACT:ROWS_CLOSE].max():.2e}, all rows {err.max():.2e}")
+        assert err[:ROWS_EXACT].max() < tol_exact and err[ROWS_EXACT:ROWS_CLOSE].max() < tol_close and err.max() < tol_all
+        if prec == 64:
+            assert np.abs(got - rows_o[:, ref_cols])[1:].max() < 1e-9          # = the oracle's replay in every row
