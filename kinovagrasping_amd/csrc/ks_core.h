@@ -742,6 +742,34 @@ template <typename T> KS_HD void pair_support(PairGeo<T>& g, const T* dir, T hm,
     else hull_climb(g.R2, g.p2, g.V2, g.off2, g.adj2, tab2, g.hint2, ld2, nd, hm, out2);
 }
 
+// The Minkowski-difference point of a support pair.  EXPERIMENT of round 5 (KS_MINK_F64=1; default OFF): in fp32 v1 and v2 are world points of ~0.1 m, each
+// rounded to 7.5e-9 - their difference carries 1e-8 of noise that differs from one support point of a query to the next, and MPR's portal normals (cross
+// products of ~1 mm edge vectors between such points) turn it into ~5e-7 of noise on the dot products its 1e-6 tolerance tests decide on.  With the switch the
+// difference is formed in fp64 from the two hull-frame vertices and the (fp32) poses - R1 a - R2 b + (p1 - p2) - and rounded once, at the magnitude of the
+// difference itself.  Measured (host lane, tests/studies/divergence_table.py: 168 grasp-and-lift envs x 200 substeps within 1e-4 of the oracle): 104 -> 112;
+// the WHOLE collision stage in fp64 on the same fp32 poses: 157.  On the GPU the switch costs k_rollout 49 more registers (256 + 153): the learner's 128-register
+// waves would no longer fit beside it on a SIMD.  Not worth 8 envs: off.
+#ifndef KS_MINK_F64
+#define KS_MINK_F64 0
+#endif
+template <typename T> KS_HD void minkowski_point_ids(const PairGeo<T>& g, int i, int j, const T* v1, const T* v2, T* v);
+template <typename T> KS_HD void minkowski_point(const PairGeo<T>& g, const T* v1, const T* v2, T* v) { minkowski_point_ids(g, g.hint1, g.hint2, v1, v2, v); }
+template <typename T> KS_HD void minkowski_point_ids(const PairGeo<T>& g, int i, int j, const T* v1, const T* v2, T* v) {
+    if constexpr (sizeof(T) == 4 && (KS_MINK_F64 != 0)) {
+        const double a[3] = {(double)g.V1[4 * i], (double)g.V1[4 * i + 1], (double)g.V1[4 * i + 2]};
+        const double b[3] = {(double)g.V2[4 * j], (double)g.V2[4 * j + 1], (double)g.V2[4 * j + 2]};
+        KS_UNROLL
+        for (int k = 0; k < 3; k++) {
+            const double w1 = (double)g.R1[3 * k] * a[0] + (double)g.R1[3 * k + 1] * a[1] + (double)g.R1[3 * k + 2] * a[2];
+            const double w2 = (double)g.R2[3 * k] * b[0] + (double)g.R2[3 * k + 1] * b[1] + (double)g.R2[3 * k + 2] * b[2];
+            v[k] = (T)((w1 - w2) + ((double)g.p1[k] - (double)g.p2[k]));
+        }
+        (void)v1; (void)v2;
+    } else {
+        sub3(v, v1, v2);
+    }
+}
+
 template <typename T> KS_HD void mpr_support(PairGeo<T>& g, const T* dir, Supp<T>& o) {
 #ifdef KS_STAMP_HULL
     const int h1_ = g.hint1, h2_ = g.hint2;
@@ -751,7 +779,8 @@ template <typename T> KS_HD void mpr_support(PairGeo<T>& g, const T* dir, Supp<T
 #ifdef KS_STAMP_HULL
     g.cnt_support += 2; g.cnt_steps += (h1_ != g.hint1) + (h2_ != g.hint2);
 #endif
-    sub3(o.v, o.v1, o.v2);
+    if (g.half_margin == T(0)) minkowski_point(g, o.v1, o.v2, o.v);
+    else sub3(o.v, o.v1, o.v2);
 }
 
 template <typename T> KS_HD bool is_zero(T x) { return kabs(x) < T(1e-15); }
@@ -907,9 +936,9 @@ KS_NARROW bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* 
         // the previous query's portal at the current poses: still a portal if the origin ray (from v0 through the
         // origin) passes through the triangle, i.e. the origin is on the inner side of the three planes (v0, vi, vj)
         v1.i1 = ma[0]; v1.i2 = mb[0]; v2.i1 = ma[1]; v2.i2 = mb[1]; v3.i1 = ma[2]; v3.i2 = mb[2];
-        hull_point(g.R1, g.p1, g.V1, ma[0], v1.v1); hull_point(g.R2, g.p2, g.V2, mb[0], v1.v2); sub3(v1.v, v1.v1, v1.v2);
-        hull_point(g.R1, g.p1, g.V1, ma[1], v2.v1); hull_point(g.R2, g.p2, g.V2, mb[1], v2.v2); sub3(v2.v, v2.v1, v2.v2);
-        hull_point(g.R1, g.p1, g.V1, ma[2], v3.v1); hull_point(g.R2, g.p2, g.V2, mb[2], v3.v2); sub3(v3.v, v3.v1, v3.v2);
+        hull_point(g.R1, g.p1, g.V1, ma[0], v1.v1); hull_point(g.R2, g.p2, g.V2, mb[0], v1.v2); minkowski_point_ids(g, ma[0], mb[0], v1.v1, v1.v2, v1.v);
+        hull_point(g.R1, g.p1, g.V1, ma[1], v2.v1); hull_point(g.R2, g.p2, g.V2, mb[1], v2.v2); minkowski_point_ids(g, ma[1], mb[1], v2.v1, v2.v2, v2.v);
+        hull_point(g.R1, g.p1, g.V1, ma[2], v3.v1); hull_point(g.R2, g.p2, g.V2, mb[2], v3.v2); minkowski_point_ids(g, ma[2], mb[2], v3.v1, v3.v2, v3.v);
         T c13[3], c32[3], c21[3], e1[3], e2[3], nn[3];
         cross3(c13, v1.v, v3.v); cross3(c32, v3.v, v2.v); cross3(c21, v2.v, v1.v);
         sub3(e1, v2.v, v1.v); sub3(e2, v3.v, v1.v); cross3(nn, e1, e2);
@@ -983,11 +1012,42 @@ KS_NARROW bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* 
         mpr_support(g, d, v4);
         if (portal_reach_tol(v1, v2, v3, v4, d, tol) || it > max_iter) {
             T wit[3];
+#ifndef KS_REFINE_F64
+#define KS_REFINE_F64 1        // round 5, fp32 product: depth and direction of the FINAL portal recomputed in fp64 from its vertex ids (0: round 4's fp32 read-off)
+#endif
+            if constexpr (sizeof(T) == 4 && (KS_REFINE_F64 != 0)) {
+                // The portal is what the fp32 iteration ended on; what is READ OFF it - the distance of the origin from a triangle of ~1 mm edges
+                // ~0.03 m out in the Minkowski difference - lost ~1e-7 m to the fp32 rounding of the triangle's normal: a depth error of 0.1 % that
+                // does not average out (the same vertices for many substeps: a bias, x 2770 / s^2 of contact stiffness) and that decided more of the
+                // fp32 product's long-horizon drift from the oracle than every discrete event together (tests/studies/divergence_table.py: 104 -> 129
+                // of 168 grasp-and-lift envs within 1e-4 after 200 substeps on the host lane; an all-fp64 collision stage: 157).  Same three vertex
+                // pairs, fp64 arithmetic on the fp32 tables and poses, once per penetrating pair and substep; no register is added to k_rollout.
+                double P[3][3];
+                const Supp<T>* sv[3] = {&v1, &v2, &v3};
+                for (int q = 0; q < 3; q++) {
+                    const int i = sv[q]->i1, j = sv[q]->i2;
+                    for (int k = 0; k < 3; k++) {
+                        const double w1 = (double)g.R1[3 * k] * (double)g.V1[4 * i] + (double)g.R1[3 * k + 1] * (double)g.V1[4 * i + 1] + (double)g.R1[3 * k + 2] * (double)g.V1[4 * i + 2];
+                        const double w2 = (double)g.R2[3 * k] * (double)g.V2[4 * j] + (double)g.R2[3 * k + 1] * (double)g.V2[4 * j + 1] + (double)g.R2[3 * k + 2] * (double)g.V2[4 * j + 2];
+                        P[q][k] = (w1 - w2) + ((double)g.p1[k] - (double)g.p2[k]);
+                    }
+                }
+                double witd[3];
+                const double dd = origin_tri_dist2<double>(P[0], P[1], P[2], witd);
+                *depth = (T)std::sqrt(dd);
+                wit[0] = (T)witd[0]; wit[1] = (T)witd[1]; wit[2] = (T)witd[2];
+                if (vec_is_zero(wit)) return false;
+                const double nn = std::sqrt(witd[0] * witd[0] + witd[1] * witd[1] + witd[2] * witd[2]);
+                dir[0] = (T)(witd[0] / nn); dir[1] = (T)(witd[1] / nn); dir[2] = (T)(witd[2] / nn);
+                find_pos(v0, v1, v2, v3, pos);
+                goto refined_;
+            }
             *depth = ksqrt(origin_tri_dist2(v1.v, v2.v, v3.v, wit));
             if (vec_is_zero(wit)) return false;
             copy3(dir, wit);
             normalize3(dir);
             find_pos(v0, v1, v2, v3, pos);
+        refined_:
             if (mpr_warm && ws != nullptr && packable(v1.i1, v2.i1, v3.i1, v1.i2, v2.i2, v3.i2)) {
                 ws->w[2] = pack3(v1.i1, v2.i1, v3.i1, 3);
                 ws->w[3] = pack3(v1.i2, v2.i2, v3.i2, 0);
@@ -1017,7 +1077,7 @@ template <typename T> KS_HD void gjk_support(PairGeo<T>& g, const T* dir, T* y, 
     g.cnt_support += 2;
     g.t_sup += clock64() - ts0;
 #endif
-    sub3(y, a, b);
+    minkowski_point(g, a, b, y);
 }
 
 // closest point to the origin on the segment A + t (B - A), t clamped to [0, 1]; returns its squared norm
@@ -1180,7 +1240,7 @@ template <typename T> KS_NARROW int gjk_distance(PairGeo<T>& g, T margin, T* dis
                 S.ia[i] = wia[i]; S.ib[i] = wib[i];
                 hull_point(g.R1, g.p1, g.V1, S.ia[i], S.a[i]);
                 hull_point(g.R2, g.p2, g.V2, S.ib[i], S.b[i]);
-                sub3(S.y[i], S.a[i], S.b[i]);
+                minkowski_point_ids(g, S.ia[i], S.ib[i], S.a[i], S.b[i], S.y[i]);
             }
         }
         const bool inside = gjk_closest(S, lam, v);
@@ -1359,6 +1419,9 @@ inline int (*ks_plane_hook)(int g2, const double* R, const double* p, int coarse
 // vertices the oracle's greedy index-order rule accepts (see pass 2 below; the 16-lane team walks only the vertices
 // its first pass found within the margin).
 // Returns the number of contacts staged at record `slot`.
+#ifndef KS_PLANE_F64
+#define KS_PLANE_F64 0         // fp32 product: 1 = the staged contacts' depths in fp64, 2 = the vertex scans' distances too (selection and margin tests)
+#endif
 template <typename T, typename S, int SUBS>
 KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* prp, int slot, float* prof = nullptr) {
     KS_T0
@@ -1377,29 +1440,36 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     const T cdist = p2[2];
     if (cdist > rbound + margin) return 0;
     const T ln[3] = {R2[6], R2[7], R2[8]};          // R2^T e_z
+    // D: the type the vertices' signed distances are formed in, DS: the type of a STAGED contact's depth (KS_PLANE_F64, fp32 product: fp64
+    // arithmetic on the fp32 pose and table - the same resting vertex for hundreds of substeps makes the fp32 rounding of `cdist + v.ln`,
+    // ~4e-9 m on a depth of 1e-5 .. 1e-4 m, a bias like the one of MPR's read-off, see mpr_penetration)
+    using D = std::conditional_t<(sizeof(T) == 4 && KS_PLANE_F64 >= 2), double, T>;
+    using DS = std::conditional_t<(sizeof(T) == 4 && KS_PLANE_F64 >= 1), double, T>;
+    const D cdistD = (D)cdist, marginD = (D)margin, lnD[3] = {(D)ln[0], (D)ln[1], (D)ln[2]};
+    auto pdist = [&](int i) -> D { return cdistD + (D)V[4 * i] * lnD[0] + (D)V[4 * i + 1] * lnD[1] + (D)V[4 * i + 2] * lnD[2]; };
     // exact cull: lowest point of the geom's bounding box (half extents geom_size about the geom origin) is
     // above the margin -> every hull vertex is too
     if (cdist - (kabs(ln[0]) * size[0] + kabs(ln[1]) * size[1] + kabs(ln[2]) * size[2]) > margin) return 0;
     // Pass 1, SUBS consecutive vertices per round (lane k takes vertex base + k: adjacent lanes read adjacent
     // 16-byte rows, no LDS bank conflicts), four rounds of reads in flight: the deepest vertex.
-    T bd = T(1e30);
+    D bd = D(1e30);
     int best = nv;
     unsigned long long cand = 0;                    // bit r: this lane's vertex of round r (index r SUBS + sub) is within the margin
     unsigned long long near = 0;                    // (fp64 only) bit r: ... was within the tie band of the lane's running minimum when it was seen
-    constexpr bool TIE_RULE = sizeof(T) == 8;       // see below
-    constexpr T TIE_EPS = T(1e-12);
+    constexpr bool TIE_RULE = sizeof(D) == 8;       // see below
+    constexpr D TIE_EPS = D(1e-12);
     for (int base0 = 0; base0 < nv; base0 += 4 * SUBS) {
-        T dd[4];
+        D dd[4];
         KS_UNROLL
         for (int u = 0; u < 4; u++) {
             const int i = base0 + u * SUBS + team.sub, ii = i < nv ? i : 0;
-            dd[u] = cdist + V[4 * ii] * ln[0] + V[4 * ii + 1] * ln[1] + V[4 * ii + 2] * ln[2];
+            dd[u] = pdist(ii);
         }
         KS_UNROLL
         for (int u = 0; u < 4; u++) {
             const int i = base0 + u * SUBS + team.sub;
             if constexpr (MASKED) {
-                if (i < nv && dd[u] <= margin) cand |= 1ull << (base0 / SUBS + u);
+                if (i < nv && dd[u] <= marginD) cand |= 1ull << (base0 / SUBS + u);
                 if constexpr (TIE_RULE)
                     if (i < nv && dd[u] <= bd + TIE_EPS) near |= 1ull << (base0 / SUBS + u);
             }
@@ -1407,23 +1477,23 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
         }
     }
     KS_TICK(12)
-    const T bd_lane = bd;
+    const D bd_lane = bd;
     team.argmin(bd, best);
-    if (bd > margin) return 0;
+    if (bd > marginD) return 0;
     // Ties between equally deep vertices (a standing cylinder's rim, a landing cube's four corners) are decided by rounding.  The fp64
     // instantiation - the parity instrument - shares the oracle's rule (ko_physics.c collide_plane_hull): the first contact is the
     // LOWEST-INDEX vertex within 1e-12 m of the deepest one, so that the two agree whatever the order of their arithmetic; in fp32 the
     // band is below the rounding of these distances and the team's arg-min stands.  (A physical dead band of 1 um was measured in round 3
     // and NOT kept: tools/experiments/r03_plane_tie_rule.patch)
     if constexpr (TIE_RULE) {
-        const T lim = bd + TIE_EPS;
+        const D lim = bd + TIE_EPS;
         int first = 0x7fffffff;
         if constexpr (MASKED) {
             // this lane's vertices that can be within the band of the team's minimum, lowest round first (`near` is a superset)
             unsigned long long c2 = bd_lane <= lim ? near : 0ull;
             while (c2 != 0) {
                 const int i = __builtin_ctzll(c2) * SUBS + team.sub;
-                if (cdist + V[4 * i] * ln[0] + V[4 * i + 1] * ln[1] + V[4 * i + 2] * ln[2] <= lim) { first = i; break; }
+                if (pdist(i) <= lim) { first = i; break; }
                 c2 &= c2 - 1;
             }
             T key = T(0);
@@ -1431,7 +1501,7 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
         } else {
             // every lane walks its share of the vertices in index order, the team takes the lowest hit
             for (int i = team.sub; i < nv; i += SUBS)
-                if (cdist + V[4 * i] * ln[0] + V[4 * i + 1] * ln[1] + V[4 * i + 2] * ln[2] <= lim) { first = i; break; }
+                if (pdist(i) <= lim) { first = i; break; }
             if constexpr (SUBS > 1) {
                 T key = T(0);
                 team.argmin(key, first);
@@ -1500,7 +1570,7 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
             for (int u = 0; u < 2; u++) {
                 const int i = base + u * SUBS + team.sub, ii = i < nv ? i : 0;
                 v[u][0] = V[4 * ii]; v[u][1] = V[4 * ii + 1]; v[u][2] = V[4 * ii + 2];
-                ok[u] = i < nv && cdist + v[u][0] * ln[0] + v[u][1] * ln[1] + v[u][2] * ln[2] <= margin;
+                ok[u] = i < nv && pdist(ii) <= marginD;
                 KS_UNROLL
                 for (int k = 0; k < 3; k++) {
                     if (k < nc) {
@@ -1530,7 +1600,8 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
         for (int q = 1; q < 4; q++)
             if (team.sub == q) { c[0] = cv[q][0]; c[1] = cv[q][1]; c[2] = cv[q][2]; }
         if (team.sub < nc) {
-            T d = cdist + dot3(c, ln), w[3];
+            const DS dS = (DS)cdist + (DS)c[0] * (DS)ln[0] + (DS)c[1] * (DS)ln[1] + (DS)c[2] * (DS)ln[2];
+            T d = (T)dS, w[3];
             mulRv(w, R2, c);
             add3(w, w, p2);
             w[2] -= T(0.5) * d;
@@ -1540,7 +1611,8 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
         KS_UNROLL
         for (int k = 0; k < 4; k++) {
             if (k < nc) {
-                T d = cdist + dot3(cv[k], ln), w[3];
+                const DS dS = (DS)cdist + (DS)cv[k][0] * (DS)ln[0] + (DS)cv[k][1] * (DS)ln[1] + (DS)cv[k][2] * (DS)ln[2];
+                T d = (T)dS, w[3];
                 mulRv(w, R2, cv[k]);
                 add3(w, w, p2);
                 w[2] -= T(0.5) * d;

@@ -2,6 +2,7 @@
 // ks_env.h): runs ONE lane of the gfx950 kernels' code on the CPU so that `-m "not gpu"` tests can
 // check the kernel logic against the fp64 oracle without a GPU.  Not part of the product library:
 // libkinova_sim.so has no CPU path and fails loudly without a GPU.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -53,6 +54,92 @@ static int substep_t(const Model<T>& m, double* qpos, double* qvel, double* warm
     *ncon = nc;
     if (con)
         for (int i = 0; i < nc * CON_STRIDE; i++) con[i] = scrbuf[SCR_CON + i];
+    return status;
+}
+
+// EXPERIMENT (tests/studies/divergence_table.py): what a mixed-precision step would do - kinematics, mass matrix, smooth forces and the
+// whole collision stage in fp64 (the state is kept in fp64 between substeps), the constraint solver and the Euler step in fp32 on the rounded scratch.
+static int g_mixed_variant = 0;      // 0: fp64 state + kinematics + collision | 1: fp64 state + kinematics only (collision fp32 on the rounded poses) | 2: fp32 kinematics, fp64 collision on them | 3 / 4: as 2 for the hull pairs / the plane pairs only
+static int substep_mixed(const Model<double>& md, const Model<float>& mf, double* qpos, double* qvel, double* warm, const double* ctrl, const double* hq,
+                         int iters, int* ncon, double* con) {
+    std::vector<double> sd(SCR_TOTAL, 0.0);
+    std::vector<float> sf(SCR_TOTAL, 0.f);
+    Scratch<double> scrd{sd.data(), 1};
+    Scratch<float> scrf{sf.data(), 1};
+    { double mass, mu; nominal_env_params(md, mass, mu); scrd(SCR_ENVP) = mass; scrd(SCR_ENVP + 1) = mu; }
+    double q4[4], R7[9], c[NU];
+    for (int i = 0; i < 4; i++) q4[i] = hq[i];
+    for (int i = 0; i < NU; i++) c[i] = ctrl[i];
+    hand_rotation(q4, R7);
+    int status = 0, nc = 0;
+    if (g_mixed_variant == 0) {
+        mj_forward_step(md, host_hulls(md), qpos, qvel, warm, c, R7, scrd, Team<1>{0}, iters, false, nc, status);       // integrate = false: stops after collision
+        for (int i = 0; i < SCR_TOTAL; i++) sf[i] = (float)sd[i];
+    } else if (g_mixed_variant == 1) {
+        dynamics_rows(md, qpos, qvel, c, R7, scrd, Team<1>{0});
+        for (int i = 0; i < SCR_TOTAL; i++) sf[i] = (float)sd[i];
+        collision(mf, host_hulls(mf), scrf, Team<1>{0}, nc, status);
+        for (int i = 0; i < SCR_TOTAL; i++) sd[i] = (double)sf[i];
+    } else {
+        float qpf[NQ], qvf[NV], cf[NU], R7f[9];
+        for (int i = 0; i < NQ; i++) qpf[i] = (float)qpos[i];
+        for (int i = 0; i < NV; i++) qvf[i] = (float)qvel[i];
+        for (int i = 0; i < NU; i++) cf[i] = (float)c[i];
+        for (int i = 0; i < 9; i++) R7f[i] = (float)R7[i];
+        { float mass, mu; nominal_env_params(mf, mass, mu); scrf(SCR_ENVP) = mass; scrf(SCR_ENVP + 1) = mu; }
+        dynamics_rows(mf, qpf, qvf, cf, R7f, scrf, Team<1>{0});
+        for (int i = 0; i < SCR_TOTAL; i++) sd[i] = (double)sf[i];
+        if (g_mixed_variant == 2) {
+            collision(md, host_hulls(md), scrd, Team<1>{0}, nc, status);
+            for (int i = 0; i < SCR_TOTAL; i++) sf[i] = (float)sd[i];
+        } else {
+            // 3: hull pairs from the fp64 collision, plane pairs from the fp32 one | 4: the other way round (both on the same fp32 poses; the
+            // two contact lists are in pair order, field 8 of a record names its pair)
+            int ncd = 0, ncf = 0, st2 = 0;
+            collision(md, host_hulls(md), scrd, Team<1>{0}, ncd, status);
+            collision(mf, host_hulls(mf), scrf, Team<1>{0}, ncf, st2);
+            std::vector<float> out((size_t)NCON_MAX * CON_STRIDE, 0.f);
+            int id = 0, jf = 0, n = 0;
+            auto pair_of = [](double w) { return (int)w / 256; };
+            while ((id < ncd || jf < ncf) && n < NCON_MAX) {
+                const int pd = id < ncd ? pair_of(sd[SCR_CON + id * CON_STRIDE + 8]) : 1 << 30, pf = jf < ncf ? pair_of((double)sf[SCR_CON + jf * CON_STRIDE + 8]) : 1 << 30;
+                const bool take_d = pd <= pf;
+                const int pi = take_d ? pd : pf;
+                const bool want_d = is_plane_pair(md, pi) ? g_mixed_variant == 4 : g_mixed_variant == 3;
+                if (take_d) { if (want_d) { for (int f = 0; f < CON_STRIDE; f++) out[n * CON_STRIDE + f] = (float)sd[SCR_CON + id * CON_STRIDE + f]; n++; } id++; }
+                else        { if (!want_d) { for (int f = 0; f < CON_STRIDE; f++) out[n * CON_STRIDE + f] = sf[SCR_CON + jf * CON_STRIDE + f]; n++; } jf++; }
+            }
+            for (int i = 0; i < n * CON_STRIDE; i++) { sf[SCR_CON + i] = out[i]; sd[SCR_CON + i] = out[i]; }
+            nc = n;
+        }
+    }
+    float qp[NQ], qv[NV], qw[NV];
+    for (int i = 0; i < NQ; i++) qp[i] = (float)qpos[i];
+    for (int i = 0; i < NV; i++) { qv[i] = (float)qvel[i]; qw[i] = (float)warm[i]; }
+    float qv0[NV];
+    for (int i = 0; i < NV; i++) qv0[i] = qv[i];
+    constrained_step(mf, qp, qv, qw, scrf, Team<1>{0}, nc, iters, status);
+    // the state stays in fp64: the fp32 step's velocity INCREMENT is applied to the fp64 velocity, positions integrated in fp64 from it
+    const double h = (double)mf.dt;
+    for (int i = 0; i < NV; i++) { qvel[i] += (double)qv[i] - (double)qv0[i]; warm[i] = qw[i]; }
+    for (int i = 0; i < 12; i++) qpos[i] += h * qvel[i];
+    {   // free joint: quaternion advanced by the body-frame angular velocity, as ko_physics.c / constrained_step do
+        const double w3[3] = {qvel[12], qvel[13], qvel[14]};
+        const double ang = std::sqrt(w3[0] * w3[0] + w3[1] * w3[1] + w3[2] * w3[2]) * h;
+        if (ang > 1e-15) {
+            const double sa = std::sin(0.5 * ang) / (ang / h), ca = std::cos(0.5 * ang);
+            const double dq[4] = {ca, w3[0] * sa, w3[1] * sa, w3[2] * sa}, a0 = qpos[12], a1 = qpos[13], a2 = qpos[14], a3 = qpos[15];
+            qpos[12] = a0 * dq[0] - a1 * dq[1] - a2 * dq[2] - a3 * dq[3];
+            qpos[13] = a0 * dq[1] + a1 * dq[0] + a2 * dq[3] - a3 * dq[2];
+            qpos[14] = a0 * dq[2] - a1 * dq[3] + a2 * dq[0] + a3 * dq[1];
+            qpos[15] = a0 * dq[3] + a1 * dq[2] - a2 * dq[1] + a3 * dq[0];
+        }
+        const double nq = std::sqrt(qpos[12] * qpos[12] + qpos[13] * qpos[13] + qpos[14] * qpos[14] + qpos[15] * qpos[15]);
+        for (int i = 12; i < 16; i++) qpos[i] /= nq;
+    }
+    *ncon = nc;
+    if (con)
+        for (int i = 0; i < nc * CON_STRIDE; i++) con[i] = sd[SCR_CON + i];
     return status;
 }
 
@@ -124,6 +211,7 @@ int lc_substep(void* h, int prec, double* qpos, double* qvel, double* warm, cons
 #ifdef KS_PLANE_HOOK
     g_hook_model = &l->d.m; ks::ks_plane_hook = prec == 64 ? nullptr : plane_hook;
 #endif
+    if (prec == 6432) return substep_mixed(l->d.m, l->f.m, qpos, qvel, warm, ctrl, hq, iters, ncon, con);
     return prec == 64 ? substep_t<double>(l->d.m, qpos, qvel, warm, ctrl, hq, iters, ncon, con)
                       : substep_t<float>(l->f.m, qpos, qvel, warm, ctrl, hq, iters, ncon, con);
 }
@@ -138,6 +226,7 @@ int lc_reset_obs(void* h, int prec, double* qpos, double* qvel, double* warm, co
     return prec == 64 ? env_step_t<double>(l->d.m, qpos, qvel, warm, hq, nullptr, 0, 0, obs, reward, done, rays, 1)
                       : env_step_t<float>(l->f.m, qpos, qvel, warm, hq, nullptr, 0, 0, obs, reward, done, rays, 1);
 }
+void lc_set_mixed_variant(int v) { g_mixed_variant = v; }
 int lc_con_stride() { return CON_STRIDE; }
 int lc_ncon_max() { return NCON_MAX; }
 }

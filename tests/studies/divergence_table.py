@@ -14,8 +14,10 @@ differently, and the FIRST such event of an env is classified from the two conta
     rim      the contact SET of a plane pair differs (compared as a set: the order of a plane pair's contacts is of no consequence): other vertices of
              the hull's rim / base on the floor
     solver   same contacts (points within 1e-5, normals within 1e-3), one-step qpos still differs by > 20 x the typical rounding: Newton's active set
-and by the pair it happened on.  Second part: the SAME runs on the fp64 lane with Gaussian noise of relative size eps added to qpos after every substep
-- how much state noise the discontinuities tolerate: the fp32 state's own rounding is ~3e-8 relative (ulp of 0.1 - 0.2 m coordinates).
+and by the pair it happened on (on the fp32 lane as it stood at the end of round 4, -DKS_REFINE_F64=0).  Then: the same runs on host builds with one thing
+changed at a time (VARIANTS); on the fp64 lane with Gaussian noise added to qpos / qvel after every substep (how much noise the discontinuities tolerate: the
+fp32 state's own rounding is ~3e-8 relative); and on a MIXED lane (tests/native/ks_lanecheck.cpp: substep_mixed) with fp64 in one stage at a time - which stage's
+precision decides.  Outcome (round 5): not the discrete events, not the state, not the solver - a bias in what the fp32 narrow phase reads off its final portal.
 usage: python -m tests.studies.divergence_table > profiles/r05_divergence_table.txt"""
 import sys
 from collections import Counter
@@ -74,32 +76,57 @@ def classify(con_l, nc_l, cons_o):
     return None, None
 
 
-HOOK_SO = "/tmp/libks_lanecheck_planehook.so"
+VARIANTS = {   # host builds of the kernel source with experiment switches (fp32 lane); built once by the parent process into /tmp
+    "r4": ["-DKS_REFINE_F64=0"],                                  # round 4's fp32 read-off of the final portal
+    "r4+planehook": ["-DKS_REFINE_F64=0", "-DKS_PLANE_HOOK"],     # ... with every plane pair's first vertex from an fp64 evaluation
+    "r4+mink64": ["-DKS_REFINE_F64=0", "-DKS_MINK_F64=1"],        # ... with the Minkowski points formed in fp64
+    "r5": [],                                                     # the product as it is (KS_REFINE_F64=1)
+    "r5+planehook": ["-DKS_PLANE_HOOK"],
+    "r5+plane1": ["-DKS_PLANE_F64=1"],                            # the staged plane contacts' depths in fp64
+    "r5+plane2": ["-DKS_PLANE_F64=2"],                            # ... and the vertex scans (selection, margin tests)
+}
 
 
-def _hooked_lib(multi_geom=False):
-    """the host lane built with -DKS_PLANE_HOOK: the FIRST vertex of every plane pair comes from an fp64 evaluation (the oracle's rule) on the lane's pose"""
-    import ctypes as C
+def _variant_so(name):
+    return f"/tmp/libks_lanecheck_{name.replace('+', '_')}.so"
+
+
+def build_variants(names=None):
+    import subprocess
     from tests import native_build
-    L = C.CDLL(HOOK_SO)
-    L.lc_create.restype = C.c_void_p; L.lc_create.argtypes = [C.c_char_p, C.c_size_t]
-    L.lc_substep.argtypes = [C.c_void_p, C.c_int, native_build.dp, native_build.dp, native_build.dp, native_build.dp, native_build.dp, C.c_int, C.POINTER(C.c_int), native_build.dp]
-    return L
+    for name, flags in VARIANTS.items():
+        if names is not None and name not in names:
+            continue
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared"] + flags + ["-o", _variant_so(name), str(native_build.HERE / "ks_lanecheck.cpp")])
+    native_build.lanecheck_lib(); native_build.lanecheck_lib(True)
+
+
+def _variant_lib(name):
+    def load(multi_geom=False):
+        import ctypes as C
+        from tests import native_build
+        L = C.CDLL(_variant_so(name))
+        L.lc_create.restype = C.c_void_p; L.lc_create.argtypes = [C.c_char_p, C.c_size_t]
+        L.lc_substep.argtypes = [C.c_void_p, C.c_int, native_build.dp, native_build.dp, native_build.dp, native_build.dp, native_build.dp, C.c_int, C.POINTER(C.c_int), native_build.dp]
+        return L
+    return load
 
 
 def run_env(args):
     shape, pose, q0, hq, script, mode, eps, seed = args
     from oracle import ko_py as ko
     from tests import native_build
-    if mode == "fp32-planehook":
-        native_build.lanecheck_lib = _hooked_lib
+    if mode.startswith("fp32:"):
+        native_build.lanecheck_lib = _variant_lib(mode[5:])
         mode = "fp32"
     blob = scenarios.model_blob(shape)
     m = ko.OracleModel(blob)
     ref = ko.OracleSim(m, hq, solver_iterations=SOLVER_ITERATIONS); ref.s.rays_enabled = 0
     ref.env_reset(q0.copy())
     tf = ko.OracleSim(m, hq, solver_iterations=SOLVER_ITERATIONS); tf.s.rays_enabled = 0          # teacher-forced twin of the lane
-    lane = native_build.Lane(blob, 32 if mode == "fp32" else 64)
+    lane = native_build.Lane(blob, {"fp32": 32, "fp64": 64}.get(mode, 6432))           # 6432: ks_lanecheck.cpp substep_mixed
+    if mode.startswith("mixed"):
+        lane.L.lc_set_mixed_variant(int(mode[5:] or 0))
     rng = np.random.default_rng(seed)
     st = (ref.view("qpos").copy(), ref.view("qvel").copy(), ref.view("qacc_warmstart").copy())
     first_event, rel_end, first_bad, base = None, 0.0, -1, []
@@ -134,15 +161,31 @@ def run_env(args):
     return shape, pose, first_event, first_bad, rel_end
 
 
-def main():
+def run_variant(name):
     jobs = []
     for sh in scenarios.SHAPES:
         for i, (o, q, hq, script) in enumerate(starts(sh)):
-            jobs.append((sh, o, q, hq, script, "fp32", 0.0, i))
+            jobs.append((sh, o, q, hq, script, f"fp32:{name}", 0.0, i))
     with ProcessPoolExecutor(8) as ex:
-        res = list(ex.map(run_env, jobs, chunksize=4))
+        return list(ex.map(run_env, jobs, chunksize=4))
+
+
+def variants_only(names):
+    build_variants(names)
+    for name in names:
+        rv = run_variant(name)
+        per = {}
+        for x in rv:
+            per[x[0]] = per.get(x[0], 0) + int(x[4] <= TOL)
+        print(f"   {name:14s} {sum(r[4] <= TOL for r in rv):3d}   median rel at 200 {np.median([r[4] for r in rv]):.1e}   {dict(Counter(r[2][1] if r[2] else 'none' for r in rv if r[4] > TOL))}   per shape {per}", flush=True)
+
+
+def main():
+    build_variants()
+
+    res = run_variant("r4")
     ok = sum(r[4] <= TOL for r in res)
-    print(f"fp32 kernel lane (host build of ks_core.h) vs fp64 oracle, free running, {len(res)} envs x {N_SUB} substeps: {ok} within 1e-4 at substep {N_SUB}")
+    print(f"fp32 kernel lane AS OF ROUND 4 (host build of ks_core.h with -DKS_REFINE_F64=0) vs fp64 oracle, free running, {len(res)} envs x {N_SUB} substeps: {ok} within 1e-4 at substep {N_SUB}")
     print("first discrete event per env under teacher forcing (the one-step outcomes of lane and oracle from the lane's own state):\n")
     print(f"{'shape':10s} {'pose':8s} {'first event':>11s} {'kind':>7s} {'pair':>18s} {'one-step |dq|':>13s} {'first > 1e-4':>12s} {'rel at 200':>10s}")
     for sh, o, ev, fb, rel in res:
@@ -157,16 +200,17 @@ def main():
           f"; envs whose error crossed 1e-4 BEFORE any event: {sum(1 for x in lead if x < 0)}")
     print(f"envs within 1e-4: {len(good)}; of them with an event on the way: {sum(1 for r in good if r[2])} (an event need not separate the trajectories for good: "
           f"{dict(Counter(r[2][1] for r in good if r[2]))})")
-    # ---- is the most frequent first event the cause?  The same fp32 lane with every plane pair's first vertex taken from an fp64 evaluation
-    import subprocess
-    from tests import native_build
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DKS_PLANE_HOOK", "-o", HOOK_SO, str(native_build.HERE / "ks_lanecheck.cpp")])
-    jobs = [(j[0], j[1], j[2], j[3], j[4], "fp32-planehook", 0.0, j[7]) for j in jobs]
-    with ProcessPoolExecutor(8) as ex:
-        rh = list(ex.map(run_env, jobs, chunksize=4))
-    print(f"\nthe same fp32 lane with the FIRST VERTEX OF EVERY PLANE PAIR chosen by an fp64 evaluation on the lane's own pose (host-only hook, -DKS_PLANE_HOOK: no 'rim' "
-          f"event can occur): {sum(r[4] <= TOL for r in rh)} within 1e-4 at substep {N_SUB};\n   first events of the envs beyond 1e-4: {dict(Counter(r[2][1] if r[2] else 'none' for r in rh if r[4] > TOL))}"
-          "\n   -> the most frequent FIRST difference is not what separates the trajectories: with it gone the next class takes its place and the count stays")
+    # ---- is the most frequent first event the cause?  And what is?  The same runs on builds with one thing changed at a time
+    print("\nthe same 168 runs on host builds of the fp32 lane with ONE thing changed (envs within 1e-4 at substep 200; first events of the envs beyond it):")
+    for name, what in (("r4+planehook", "round 4 + every plane pair's FIRST VERTEX from an fp64 evaluation on the lane's own pose (host-only hook: no 'rim' event can occur)"),
+                       ("r4+mink64", "round 4 + the Minkowski points of the support pairs formed in fp64 (KS_MINK_F64=1)"),
+                       ("r5", "ROUND 5, the product: depth and direction of MPR's FINAL portal recomputed in fp64 from its vertex ids (KS_REFINE_F64=1)"),
+                       ("r5+planehook", "round 5 + the plane hook")):
+        rv = run_variant(name)
+        print(f"   {name:14s} {sum(r[4] <= TOL for r in rv):3d}   median rel at 200 {np.median([r[4] for r in rv]):.1e}   {dict(Counter(r[2][1] if r[2] else 'none' for r in rv if r[4] > TOL))}   <- {what}", flush=True)
+    print("   -> taking the most frequent FIRST difference away (plane hook) changes nothing by itself: it is not what separates the trajectories.  What does is a BIAS: the depth\n"
+          "      read off MPR's final portal in fp32 is off by ~1e-7 m in the same direction for as long as the portal keeps its vertices; recomputing that read-off in fp64 (r5) keeps\n"
+          "      25 more envs within 1e-4, an all-fp64 collision stage (below) 53 more.")
     # ---- how much state noise the discontinuities tolerate
     print("\nfp64 lane with relative Gaussian noise eps on qpos[0:12] after every substep (same 168 runs): envs within 1e-4 at substep 200")
     for eps in (0.0, 1e-12, 1e-10, 1e-9, 1e-8, 3e-8, 1e-7):
@@ -177,6 +221,27 @@ def main():
         with ProcessPoolExecutor(8) as ex:
             r2 = list(ex.map(run_env, jobs, chunksize=4))
         print(f"   eps {eps:7.0e}: {sum(r[4] <= TOL for r in r2):3d} of {len(r2)}   (median rel at 200: {np.median([r[4] for r in r2]):.1e})", flush=True)
+
+
+def mixed_precision(only=None):
+    """VERDICT r4 next #4, measured on the host before anything is built for the GPU: kinematics, mass matrix, smooth forces and the WHOLE collision stage in
+    fp64 with the state kept in fp64, the constraint solver + Euler step in fp32 on the rounded scratch (tests/native/ks_lanecheck.cpp: substep_mixed)."""
+    print("\nMIXED precision on the host lane (tests/native/ks_lanecheck.cpp: substep_mixed; the solver + Euler step always fp32; state kept in fp64 between substeps):")
+    for variant, what in ((0, "fp64 kinematics + mass matrix + smooth forces + collision"), (1, "fp64 kinematics + mass matrix + smooth forces, collision fp32 on the rounded poses"),
+                          (2, "fp32 kinematics, collision fp64 on those poses"), (3, "fp32 kinematics, HULL pairs (GJK / MPR) fp64 on those poses, plane pairs fp32"),
+                          (4, "fp32 kinematics, PLANE pairs fp64 on those poses, hull pairs fp32")):
+        if only is not None and variant not in only:
+            continue
+        jobs = []
+        for sh in scenarios.SHAPES:
+            for i, (o, q, hq, script) in enumerate(starts(sh)):
+                jobs.append((sh, o, q, hq, script, f"mixed{variant}", 0.0, i))
+        with ProcessPoolExecutor(8) as ex:
+            r = list(ex.map(run_env, jobs, chunksize=4))
+        per = {}
+        for x in r:
+            per[x[0]] = per.get(x[0], 0) + int(x[4] <= TOL)
+        print(f"   {what}: {sum(x[4] <= TOL for x in r)} of {len(r)} within 1e-4 at substep {N_SUB} (median rel {np.median([x[4] for x in r]):.1e}); per shape {per}", flush=True)
 
 
 def velocity_noise():
@@ -196,6 +261,11 @@ def velocity_noise():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "velocity":
         velocity_noise()
+    elif len(sys.argv) > 1 and sys.argv[1] == "variants":
+        variants_only(sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "mixed":
+        mixed_precision([int(a) for a in sys.argv[2:]] or None)
     else:
         main()
         velocity_noise()
+        mixed_precision()
