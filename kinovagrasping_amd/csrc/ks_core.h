@@ -1420,7 +1420,7 @@ inline int (*ks_plane_hook)(int g2, const double* R, const double* p, int coarse
 // its first pass found within the margin).
 // Returns the number of contacts staged at record `slot`.
 #ifndef KS_PLANE_F64
-#define KS_PLANE_F64 0         // fp32 product: 1 = the staged contacts' depths in fp64, 2 = the vertex scans' distances too (selection and margin tests)
+#define KS_PLANE_F64 2         // fp32 product: 1 = the staged contacts' depths in fp64, 2 = the vertex scans' distances too (selection and margin tests)
 #endif
 template <typename T, typename S, int SUBS>
 KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* prp, int slot, float* prof = nullptr) {

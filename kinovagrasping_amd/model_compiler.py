@@ -20,6 +20,7 @@ blobs are committed under kinovagrasping_amd/assets/ and are what travels to the
 """
 from __future__ import annotations
 
+import os
 import re
 import struct
 import xml.etree.ElementTree as ET
@@ -285,15 +286,22 @@ class CompiledMesh:
             self.com, self.R, self.principal = np.zeros(3), np.eye(3), np.diag(inertia).copy()
         self.quat = mat_to_quat(self.R)
         pts = np.unique(tri.reshape(-1, 3), axis=0)
-        hull = ConvexHull(pts)
-        hv = pts[np.sort(hull.vertices)]
-        # vertices in the geom frame (origin = com, axes = principal frame)
-        self.verts = (hv - self.com) @ self.R
+        # points in the geom frame (origin = com, axes = principal frame).  MuJoCo keeps a mesh's vertices as float32 (mjModel.mesh_vert),
+        # re-centred on the mesh's inertial frame by its compiler: the geom-frame vertices every convex query and plane scan sees are float32
+        # numbers, and the hull (its qhull graph) is the hull of THOSE.  Measured on the recorded MuJoCo 1.50 trajectory
+        # (tests/test_mujoco_recorded.py): rows 5-40 agree to 1.05e-10 - the recording's resolution - with float32 vertices, 1.9e-10
+        # without.  Primitive geoms (keep_frame) stay analytic.
         allv = (pts - self.com) @ self.R
+        if not keep_frame:
+            allv = allv.astype(np.float32).astype(np.float64)                    # (vertex order kept: ties go to the lowest index)
+        self.verts = allv[np.sort(ConvexHull(allv).vertices)]
+        h2 = ConvexHull(self.verts)
+        while len(h2.vertices) < len(self.verts):           # (points qhull merged into a facet of the rounded set: not vertices of its graph)
+            self.verts = self.verts[np.sort(h2.vertices)]
+            h2 = ConvexHull(self.verts)
         self.size = np.maximum(np.abs(allv.min(0)), np.abs(allv.max(0)))
         self.rbound = float(np.linalg.norm(self.verts, axis=1).max())
         # hull faces in geom frame: merge coplanar simplices into unique planes n.x <= d
-        h2 = ConvexHull(self.verts)
         eq = h2.equations                           # n.x + off <= 0 inside
         planes = np.concatenate([eq[:, :3], -eq[:, 3:4]], axis=1)
         key = np.round(planes / 1e-7).astype(np.int64)

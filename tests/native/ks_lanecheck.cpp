@@ -47,6 +47,11 @@ static int substep_t(const Model<T>& m, double* qpos, double* qvel, double* warm
     for (int i = 0; i < NU; i++) c[i] = (T)ctrl[i];
     for (int i = 0; i < 4; i++) q4[i] = (T)hq[i];
     hand_rotation(q4, R7);
+    if (std::getenv("KS_LC_EXACT_R7")) {          // experiment: the hand's rotation formed in fp64 and rounded once
+        double q4d[4] = {hq[0], hq[1], hq[2], hq[3]}, R7d[9];
+        hand_rotation(q4d, R7d);
+        for (int i = 0; i < 9; i++) R7[i] = (T)R7d[i];
+    }
     int status = 0, nc = 0;
     mj_forward_step(m, host_hulls(m), st.qpos, st.qvel, st.warm, c, R7, scr, Team<1>{0}, iters, true, nc, status);
     for (int i = 0; i < NQ; i++) qpos[i] = st.qpos[i];
@@ -60,6 +65,7 @@ static int substep_t(const Model<T>& m, double* qpos, double* qvel, double* warm
 // EXPERIMENT (tests/studies/divergence_table.py): what a mixed-precision step would do - kinematics, mass matrix, smooth forces and the
 // whole collision stage in fp64 (the state is kept in fp64 between substeps), the constraint solver and the Euler step in fp32 on the rounded scratch.
 static int g_mixed_variant = 0;      // 0: fp64 state + kinematics + collision | 1: fp64 state + kinematics only (collision fp32 on the rounded poses) | 2: fp32 kinematics, fp64 collision on them | 3 / 4: as 2 for the hull pairs / the plane pairs only
+static int g_state_rounding = 0;     // bit 0: qvel rounded to fp32 after every substep, bit 1: qpos (lc_set_mixed_variant(v + 10 * bits))
 static int substep_mixed(const Model<double>& md, const Model<float>& mf, double* qpos, double* qvel, double* warm, const double* ctrl, const double* hq,
                          int iters, int* ncon, double* con) {
     std::vector<double> sd(SCR_TOTAL, 0.0);
@@ -89,7 +95,11 @@ static int substep_mixed(const Model<double>& md, const Model<float>& mf, double
         { float mass, mu; nominal_env_params(mf, mass, mu); scrf(SCR_ENVP) = mass; scrf(SCR_ENVP + 1) = mu; }
         dynamics_rows(mf, qpf, qvf, cf, R7f, scrf, Team<1>{0});
         for (int i = 0; i < SCR_TOTAL; i++) sd[i] = (double)sf[i];
-        if (g_mixed_variant == 2) {
+        if (g_mixed_variant >= 5) {
+            // 5: everything fp32 but the ACCUMULATION of the state (below) | 6: qpos accumulated in fp64, qvel rounded to fp32 after every substep | 7: the other way round
+            collision(mf, host_hulls(mf), scrf, Team<1>{0}, nc, status);
+            for (int i = 0; i < SCR_TOTAL; i++) sd[i] = (double)sf[i];
+        } else if (g_mixed_variant == 2) {
             collision(md, host_hulls(md), scrd, Team<1>{0}, nc, status);
             for (int i = 0; i < SCR_TOTAL; i++) sf[i] = (float)sd[i];
         } else {
@@ -137,6 +147,8 @@ static int substep_mixed(const Model<double>& md, const Model<float>& mf, double
         const double nq = std::sqrt(qpos[12] * qpos[12] + qpos[13] * qpos[13] + qpos[14] * qpos[14] + qpos[15] * qpos[15]);
         for (int i = 12; i < 16; i++) qpos[i] /= nq;
     }
+    if (g_mixed_variant == 6 || (g_state_rounding & 1)) for (int i = 0; i < NV; i++) qvel[i] = (double)(float)qvel[i];
+    if (g_mixed_variant == 7 || (g_state_rounding & 2)) for (int i = 0; i < NQ; i++) qpos[i] = (double)(float)qpos[i];
     *ncon = nc;
     if (con)
         for (int i = 0; i < nc * CON_STRIDE; i++) con[i] = sd[SCR_CON + i];
@@ -203,6 +215,9 @@ void* lc_create(const void* blob, size_t n) {
         delete h;
         return nullptr;
     }
+    if (std::getenv("KS_LC_ROUND_TABLES"))        // experiment: the fp64 model's hull vertices rounded to fp32 (the tables the fp32 product holds)
+        for (int s = 0; s < NMESH; s++)
+            for (auto& v : h->d.vert[s]) v = (double)(float)v;
     return h;
 }
 void lc_destroy(void* h) { delete (LC*)h; }
@@ -226,7 +241,7 @@ int lc_reset_obs(void* h, int prec, double* qpos, double* qvel, double* warm, co
     return prec == 64 ? env_step_t<double>(l->d.m, qpos, qvel, warm, hq, nullptr, 0, 0, obs, reward, done, rays, 1)
                       : env_step_t<float>(l->f.m, qpos, qvel, warm, hq, nullptr, 0, 0, obs, reward, done, rays, 1);
 }
-void lc_set_mixed_variant(int v) { g_mixed_variant = v; }
+void lc_set_mixed_variant(int v) { g_mixed_variant = v % 10; g_state_rounding = v / 10; }
 int lc_con_stride() { return CON_STRIDE; }
 int lc_ncon_max() { return NCON_MAX; }
 }

@@ -229,7 +229,15 @@ def mixed_precision(only=None):
     print("\nMIXED precision on the host lane (tests/native/ks_lanecheck.cpp: substep_mixed; the solver + Euler step always fp32; state kept in fp64 between substeps):")
     for variant, what in ((0, "fp64 kinematics + mass matrix + smooth forces + collision"), (1, "fp64 kinematics + mass matrix + smooth forces, collision fp32 on the rounded poses"),
                           (2, "fp32 kinematics, collision fp64 on those poses"), (3, "fp32 kinematics, HULL pairs (GJK / MPR) fp64 on those poses, plane pairs fp32"),
-                          (4, "fp32 kinematics, PLANE pairs fp64 on those poses, hull pairs fp32")):
+                          (4, "fp32 kinematics, PLANE pairs fp64 on those poses, hull pairs fp32"),
+                          (5, "every stage fp32 (the product's arithmetic); only the ACCUMULATION of qpos and qvel over the substeps in fp64"),
+                          (6, "every stage fp32; qpos accumulated in fp64, qvel rounded to fp32 after every substep"),
+                          (7, "every stage fp32; qvel accumulated in fp64, qpos rounded to fp32 after every substep"),
+                          (35, "every stage fp32, qpos and qvel rounded to fp32 after every substep: the fp32 lane but for the Euler step's position / quaternion update formed in fp64"),
+                          (14, "PLANE pairs fp64; qpos accumulated in fp64, qvel rounded to fp32 after every substep"),
+                          (34, "PLANE pairs fp64; qpos and qvel rounded to fp32 after every substep (= the fp32 lane built with KS_PLANE_F64=2)"),
+                          (32, "collision fp64; qpos and qvel rounded to fp32 after every substep"),
+                          (12, "collision fp64; qpos accumulated in fp64, qvel rounded to fp32 after every substep")):
         if only is not None and variant not in only:
             continue
         jobs = []
