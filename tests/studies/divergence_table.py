@@ -77,13 +77,13 @@ def classify(con_l, nc_l, cons_o):
 
 
 VARIANTS = {   # host builds of the kernel source with experiment switches (fp32 lane); built once by the parent process into /tmp
-    "r4": ["-DKS_REFINE_F64=0"],                                  # round 4's fp32 read-off of the final portal
-    "r4+planehook": ["-DKS_REFINE_F64=0", "-DKS_PLANE_HOOK"],     # ... with every plane pair's first vertex from an fp64 evaluation
-    "r4+mink64": ["-DKS_REFINE_F64=0", "-DKS_MINK_F64=1"],        # ... with the Minkowski points formed in fp64
-    "r5": [],                                                     # the product as it is (KS_REFINE_F64=1)
-    "r5+planehook": ["-DKS_PLANE_HOOK"],
-    "r5+plane1": ["-DKS_PLANE_F64=1"],                            # the staged plane contacts' depths in fp64
-    "r5+plane2": ["-DKS_PLANE_F64=2"],                            # ... and the vertex scans (selection, margin tests)
+    "r4": ["-DKS_REFINE_F64=0", "-DKS_PLANE_F64=0"],                                  # round 4's fp32 read-offs
+    "r4+planehook": ["-DKS_REFINE_F64=0", "-DKS_PLANE_F64=0", "-DKS_PLANE_HOOK"],     # ... with every plane pair's first vertex from an fp64 evaluation
+    "r4+mink64": ["-DKS_REFINE_F64=0", "-DKS_PLANE_F64=0", "-DKS_MINK_F64=1"],        # ... with the Minkowski points formed in fp64
+    "r5a": ["-DKS_PLANE_F64=0"],                                  # depth / direction of MPR's final portal in fp64 (KS_REFINE_F64=1), plane pairs fp32
+    "r5a+plane1": ["-DKS_PLANE_F64=1"],                           # ... + the staged plane contacts' depths in fp64
+    "r5a+plane2": ["-DKS_PLANE_F64=2"],                           # ... + the plane pairs' vertex scans in fp64 (selection, margin tests)
+    "r5": [],                                                     # the product: the decisions of plane2 from an fp32 scan + fp64 on the band (KS_PLANE_F64=3)
 }
 
 
@@ -204,8 +204,10 @@ def main():
     print("\nthe same 168 runs on host builds of the fp32 lane with ONE thing changed (envs within 1e-4 at substep 200; first events of the envs beyond it):")
     for name, what in (("r4+planehook", "round 4 + every plane pair's FIRST VERTEX from an fp64 evaluation on the lane's own pose (host-only hook: no 'rim' event can occur)"),
                        ("r4+mink64", "round 4 + the Minkowski points of the support pairs formed in fp64 (KS_MINK_F64=1)"),
-                       ("r5", "ROUND 5, the product: depth and direction of MPR's FINAL portal recomputed in fp64 from its vertex ids (KS_REFINE_F64=1)"),
-                       ("r5+planehook", "round 5 + the plane hook")):
+                       ("r5a", "depth and direction of MPR's FINAL portal recomputed in fp64 from its vertex ids (KS_REFINE_F64=1)"),
+                       ("r5a+plane1", "... + the staged plane contacts' depths formed in fp64 (KS_PLANE_F64=1)"),
+                       ("r5a+plane2", "... + the plane pairs' vertex scans in fp64: which vertex is deepest, which are within the margin (KS_PLANE_F64=2)"),
+                       ("r5", "ROUND 5, THE PRODUCT: the same decisions from an fp32 scan + fp64 on the vertices within 2.5e-7 m of deciding one (KS_PLANE_F64=3)")):
         rv = run_variant(name)
         print(f"   {name:14s} {sum(r[4] <= TOL for r in rv):3d}   median rel at 200 {np.median([r[4] for r in rv]):.1e}   {dict(Counter(r[2][1] if r[2] else 'none' for r in rv if r[4] > TOL))}   <- {what}", flush=True)
     print("   -> taking the most frequent FIRST difference away (plane hook) changes nothing by itself: it is not what separates the trajectories.  What does is a BIAS: the depth\n"
