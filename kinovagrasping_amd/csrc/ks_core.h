@@ -1432,9 +1432,10 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     const T size[3] = {pr.size2[0], pr.size2[1], pr.size2[2]};
     KS_TAB const T* V = pr.V2;
     // the 16-lane team remembers, per lane, in which of its <= 64 rounds its vertex was within the margin (hulls of <= 1024 vertices:
-    // the standard build); larger hulls (multi-geom build) are walked a second time instead
-    constexpr bool MASKED = SUBS == 16 && HULL_VERT_MAX <= 1024;
+    // every hull of the standard build, all but the short bottle's base and the lemon in the multi-geom build - decided per pair there);
+    // larger hulls are walked a second time instead
     const int nv = pr.n2, body2 = pr.body2;
+    const bool MASKED = SUBS == 16 && (HULL_VERT_MAX <= 1024 || nv <= 1024);
     T R2[9], p2[3];
     geom_pose_cached(scr, g2, R2, p2);
     const T cdist = p2[2];
@@ -1468,7 +1469,7 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
         KS_UNROLL
         for (int u = 0; u < 4; u++) {
             const int i = base0 + u * SUBS + team.sub;
-            if constexpr (MASKED) {
+            if (MASKED) {
                 if (i < nv && dd[u] <= marginD) cand |= 1ull << (base0 / SUBS + u);
                 if constexpr (TIE_RULE)
                     if (i < nv && dd[u] <= bd + TIE_EPS) near |= 1ull << (base0 / SUBS + u);
@@ -1488,7 +1489,7 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     if constexpr (TIE_RULE) {
         const D lim = bd + TIE_EPS;
         int first = 0x7fffffff;
-        if constexpr (MASKED) {
+        if (MASKED) {
             // this lane's vertices that can be within the band of the team's minimum, lowest round first (`near` is a superset)
             unsigned long long c2 = bd_lane <= lim ? near : 0ull;
             while (c2 != 0) {
@@ -1525,7 +1526,7 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     // lowest index) and resumes behind it: at most nv/SUBS + 3 rounds in total, however many vertices lie within
     // the margin (a palm lying flat on the ground has hundreds).
     int start = 0;
-    if constexpr (MASKED) {
+    if (MASKED) {
         // The first pass has seen every vertex: each lane kept the rounds in which its vertex was within the margin (nv <=
         // 1024, checked when the model is loaded: 64 rounds).  The walk then only touches those - a finger tip or a cube
         // corner on the ground has a handful, and the old search for a vertex that is not there was a second full scan of the
