@@ -231,10 +231,10 @@ def mixed_precision(only=None):
     """VERDICT r4 next #4, measured on the host before anything is built for the GPU: kinematics, mass matrix, smooth forces and the WHOLE collision stage in
     fp64 with the state kept in fp64, the constraint solver + Euler step in fp32 on the rounded scratch (tests/native/ks_lanecheck.cpp: substep_mixed)."""
     print("\nMIXED precision on the host lane (tests/native/ks_lanecheck.cpp: substep_mixed; the solver + Euler step always fp32; state kept in fp64 between substeps):")
-    for variant, what in ((1, "fp64 kinematics + mass matrix + smooth forces (state kept in fp64), collision fp32 on the rounded poses"),
+    for variant, what in ((1, "fp64 kinematics + mass matrix + smooth forces (state kept in fp64), collision = the product's fp32 stage (with its fp64 read-offs) on the rounded poses"),
                           (32, "fp32 state and kinematics, the whole COLLISION stage fp64 on those poses"),
-                          (33, "fp32 state and kinematics, HULL pairs (GJK / MPR) fp64 on those poses, plane pairs fp32 (scan as KS_PLANE_F64=0)"),
-                          (34, "fp32 state and kinematics, PLANE pairs fp64 on those poses, hull pairs fp32 (= the product)"),
+                          (33, "fp32 state and kinematics, HULL pairs (GJK / MPR) from an fp64 collision on those poses, plane pairs the product's"),
+                          (34, "fp32 state and kinematics, PLANE pairs from an fp64 collision on those poses, hull pairs the product's (~ the product, 146 on the fp32 lane: rows that differ by < 8 differ by the noise of this count)"),
                           (2, "as 32 with qpos / qvel accumulated in fp64 over the substeps")):
         if only is not None and variant not in only:
             continue
