@@ -205,3 +205,53 @@ def test_primitive_object_compile_known_answers(assets_dir):
     np.testing.assert_allclose(C["obj_size_obs"], [r, r, 2 * h], rtol=1e-12)
     assert len(C["mesh3_vert"]) == 128 and np.allclose(np.hypot(C["mesh3_vert"][:, 0], C["mesh3_vert"][:, 1]), r)
     np.testing.assert_allclose(C["geom_size"][8], [r, r, h])
+
+
+def test_mesh_hull_tables_are_float32_numbers(assets_dir):
+    """MuJoCo keeps a mesh's geom-frame vertices as float32 (mjModel.mesh_vert); so does the model compiler since round 5 - the fp64 oracle and the
+    fp32 kernels then hold THE SAME hull tables.  Primitive objects (analytic in MuJoCo) keep fp64 corner coordinates."""
+    from kinovagrasping_amd import model_compiler as mc
+    for shape in ("CubeS", "CylinderB", "Vase2B", "Cone1S", "BowlS", "LemonS"):
+        M = mc.read_blob(assets_dir / f"{shape}.ksm")
+        n = 0
+        for k in sorted(M):
+            if k.startswith("mesh") and k.endswith("_vert"):
+                V = np.asarray(M[k], dtype=np.float64)
+                assert np.array_equal(V, V.astype(np.float32).astype(np.float64)), (shape, k)
+                n += 1
+        assert n >= 4
+    Vb = np.asarray(mc.read_blob(assets_dir / "mbox.ksm")["mesh3_vert"], dtype=np.float64)       # the primitive box: its half sizes as written in the XML
+    assert not np.array_equal(Vb, Vb.astype(np.float32).astype(np.float64))
+
+
+@pytest.mark.parametrize("shape", ["CylinderB", "Vase2B"])
+def test_fp32_lane_rests_a_round_base_on_the_oracles_rim_vertices(assets_dir, shape):
+    """A round base on the floor: 67 rim vertices whose heights differ in the 9th digit (float32 tables) and by the object's tilt.  Which of them carry
+    the (up to four) contacts is decided by distances that differ by ~1e-9 m - below the rounding of an fp32 `cdist + v.ln`, so the fp32 product forms
+    a plane pair's vertex distances in fp64 on its fp32 pose (KS_PLANE_F64, ks_core.h collide_plane_hull).  From the oracle's own states of a settling
+    and then pushed object, the fp32 lane's ground contacts sit on the oracle's vertices in every substep (133 / 138 measured; with fp32 distances 124 of 133
+    and 118 of 138 - and each miss is a different contact set for the solver)."""
+    blob = scenarios.model_blob(shape)
+    m = ko.OracleModel(blob)
+    hq = scenarios.hand_quat_for("normal")
+    s = ko.OracleSim(m, hq, solver_iterations=SOLVER_ITERATIONS)
+    s.s.rays_enabled = 0
+    q0 = np.zeros(16); q0[9:12] = scenarios.start_coord_table(shape, "normal")[7]; q0[12] = 1
+    s.env_reset(q0)
+    lane = Lane(blob, 32)
+    ctrl = np.zeros(9); ctrl[6:9] = 0.4
+    same = total = 0
+    for k in range(150):
+        st = (s.view("qpos").copy(), s.view("qvel").copy(), s.view("qacc_warmstart").copy())
+        _, _, _, nc, con, status = lane.substep(*st, ctrl, hq)
+        s.step(ctrl)
+        ground_o = np.array([c["pos"] for c in s.contacts() if c["geom1"] == 0 and c["geom2"] == 8])
+        ground_l = np.array([con[i, :3] for i in range(nc) if int(con[i, 8]) % 16 == 0 and (int(con[i, 8]) // 16) % 16 == 9])
+        if len(ground_o) == 0:
+            continue
+        total += 1
+        if len(ground_l) == len(ground_o):
+            d = np.abs(ground_o[:, None, :] - ground_l[None, :, :]).max(2)
+            same += int(d.min(1).max() < 1e-5 and d.min(0).max() < 1e-5)
+    print(f"{shape}: the fp32 lane's ground contacts on the oracle's vertices in {same} of {total} substeps")
+    assert total >= 100 and same >= total - 3
