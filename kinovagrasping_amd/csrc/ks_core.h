@@ -2670,7 +2670,25 @@ KS_HD void mj_forward_step(const Model<T>& m, const Hulls<T>& hu, T* qpos, T* qv
     after_kinematics();
     KS_TICK(0)
     int ncon = 0;
+#if defined(KS_SCRATCH_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+    // EXPERIMENT (tools/experiments/scratch_probe.sh): KS_SCRATCH_PROBE (a power of two) extra private-memory words per lane stored
+    // before the out-of-line `collision` and loaded after it - the pattern of the register frame that lives there ("no build
+    // without those stores exists to compare" - one WITH MORE of them does, and the slope of the run time over their number is what one of them costs).
+    // The array is indexed with a run-time offset (always 0) so that it stays in private memory; stores and loads are independent and issue back to back
+    // like a spill sequence.
+    T probe_[KS_SCRATCH_PROBE];
+    KS_UNROLL
+    for (int i = 0; i < KS_SCRATCH_PROBE; i++) probe_[(i + (status >> 30)) & (KS_SCRATCH_PROBE - 1)] = qvel[i % NV];
+#endif
     collision(m, hu, scr, team, ncon, status, gjk_warm, prof);
+#if defined(KS_SCRATCH_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+    {
+        T acc_ = T(0);
+        KS_UNROLL
+        for (int i = 0; i < KS_SCRATCH_PROBE; i++) acc_ += probe_[(i + (ncon >> 30)) & (KS_SCRATCH_PROBE - 1)];
+        if (acc_ == T(-12345.678)) status |= ST_CONTACT_OVERFLOW;       // (never: keeps the loads)
+    }
+#endif
     KS_TICK(1)
     ncon_out = ncon;
     if (!integrate) return;
