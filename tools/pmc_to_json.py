@@ -36,8 +36,8 @@ out = {
     "note": ("per env-step of k_rollout: fetch = the actor's weights for every workgroup and env-step (L2 hits) + env state + pair memory + the rays' mesh nodes + "
              "1/10 of the per-launch staging of the hull / model tables; write = state + body-pose snapshot + rays + observation (x3: output, next policy input, "
              "terminal) + replay row + pair memory, stored as 4-byte columns of [field][env] arrays (~12 MB of output stores per env-step) + write-backs of the "
-             "private-memory frame: ~53 scratch stores per lane and substep around the out-of-line `collision` (8 warm words, contact count, status in the caller; "
-             "40 callee-saved registers in `collision`), DESIGN section 5a.  The counters sit on the L2's memory side: Infinity-Cache hits are included, "
+             "private-memory frame (312 B per lane: spilled values of the inlined solver, a 12-word indexed array in `collision`; evicted lines, not a count of the "
+             "stores - what the frame costs is measured in profiles/r05_scratch_probe.txt), DESIGN section 5.  The counters sit on the L2's memory side: Infinity-Cache hits are included, "
              "so this is an upper bound on HBM traffic.") if workload == "free" else
             "fetch = per-workgroup staging of the hull / model tables (256 workgroups x ~50 KB, L2 / MALL hits count) + env state + "
             "pair memory + the in-step rays' mesh nodes; write = state + snapshot + rays + pair memory (4.9 MB) + write-through of the "
