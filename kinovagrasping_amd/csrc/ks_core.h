@@ -284,15 +284,18 @@ template <typename T> KS_HD int hull_pair_count(const Model<T>& m) {
     for (int pi = 0; pi < m.npair; pi++) nh += is_plane_pair(m, pi) ? 0 : 1;
     return nh;
 }
-// pair bookkeeping of the descriptor (counts, plane / hull pair lists); `pair` is set by the caller
+// pair bookkeeping of the descriptor (counts, plane / hull pair lists as the model holds them); `pair` is set by the caller
 template <typename T> KS_HD void hulls_set_pairs(const Model<T>& m, Hulls<T>& hu) {
     hu.npair = m.npair;
-    hu.nhull = 0;
-    hu.nplane = 0;
-    for (int pi = 0; pi < m.npair; pi++) {
-        if (is_plane_pair(m, pi)) hu.plane_pi[hu.nplane++] = (unsigned char)pi;
-        else hu.hull_pi[hu.nhull++] = (unsigned char)pi;
-    }
+    hu.nhull = m.nhull;
+    hu.nplane = m.nplane;
+    static_assert(NPAIR_MAX % 4 == 0, "pair lists copied as words");
+    const unsigned* sp = (const unsigned*)m.plane_order;
+    const unsigned* sh = (const unsigned*)m.hull_order;
+    unsigned* dp = (unsigned*)hu.plane_pi;
+    unsigned* dh = (unsigned*)hu.hull_pi;
+    KS_UNROLL
+    for (int k = 0; k < NPAIR_MAX / 4; k++) { dp[k] = sp[k]; dh[k] = sh[k]; }
 }
 template <typename T> KS_HD void fill_pair_rec(const Model<T>& m, const Hulls<T>& hu, int pi, PairRec<T>& r) {
     const int g1 = m.pair_g1[pi], g2 = m.pair_g2[pi];
@@ -1839,6 +1842,15 @@ KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Tea
                 todo |= live_r ? (1u << r) : 0u;
             }
         }
+#if defined(KS_STAMP) && defined(__HIP_DEVICE_COMPILE__)
+        if (prof) {     // diagnostic build: live hull pairs of this lane / of the busiest lane of the wave (= narrow-phase passes of the wave) / of the team
+            const int np = __builtin_popcount(todo);
+            int wm = np;
+            for (int msk = 32; msk >= 1; msk >>= 1) { const int o = __shfl_xor(wm, msk); wm = o > wm ? o : wm; }
+            prof[24] += (float)np; prof[25] += (float)wm; prof[26] += (float)__builtin_popcount(team.ballot(np > 0));
+            prof[27] += (float)(todo & 1u); prof[28] += (float)((todo >> 1) & 1u);      // this lane's pair of round 0 / round 1 live
+        }
+#endif
         // one call site: as many turns as the busiest lane of the wave has live pairs
         while (todo != 0) {
             int r = 0, pi_r = pi_[0], word_r = word_[0], slot_r = slot_[0];

@@ -58,6 +58,10 @@ template <typename T> struct Model {
     int site_body[NSITE];
     int ngeom, nmesh;          // counts of this model (<= NGEOM, NMESH)
     int npair, pair_g1[NPAIR_MAX], pair_g2[NPAIR_MAX];
+    // the pairs as the stepping kernels share them out (filled at load, model_pair_order): plane pairs in index order; hull pairs by how often
+    // they get past their culls - the ones that hardly ever do last, so that a lane that owns two hull pairs owns at most one busy one
+    int nplane, nhull;
+    unsigned char plane_order[NPAIR_MAX], hull_order[NPAIR_MAX];
     T pair_mu[NPAIR_MAX], pair_margin[NPAIR_MAX];
     // translational inverse weights behind a contact's regularisation (MuJoCo: body_invweight0 of the two bodies that own the geoms),
     // per pair: [0] the hand / ground geom's share, [1] the object geoms' share (scaled with a per-env object mass).  A piece of a
@@ -87,5 +91,33 @@ template <typename T> struct Model {
     const void* hull_pack;
     int hull_pack_bytes;
 };
+
+// How often a hull pair of the HAND's own geoms (1 palm, 2 / 4 / 6 the proximal, 3 / 5 / 7 the distal links of fingers 1 - 3; finger 1 opposes 2 and 3)
+// gets past its culls: 0 = often (the finger tips against each other, finger 1's proximal link against finger 2's tip), 1 = seldom, 2 = hardly ever
+// (proximal links against each other, finger 1's tip against the others' proximal links).  Measured in the bench's regime
+// (tools/experiments/hull_passes.py, profiles/r05_hull_passes.txt); everything else - the object's pairs - is class 0.
+KS_HD int hull_pair_rarity(int g1, int g2) {
+    constexpr unsigned long long bit = 1ull;
+    constexpr unsigned long long HARDLY = (bit << (2 * 8 + 4)) | (bit << (2 * 8 + 6)) | (bit << (4 * 8 + 6)) | (bit << (3 * 8 + 4)) | (bit << (3 * 8 + 6)) | (bit << (5 * 8 + 6));
+    constexpr unsigned long long SELDOM = (bit << (1 * 8 + 3)) | (bit << (1 * 8 + 5)) | (bit << (1 * 8 + 7)) | (bit << (3 * 8 + 7)) | (bit << (2 * 8 + 7)) | (bit << (4 * 8 + 7));
+    const bool hand = g1 >= 1 && g1 <= 7 && g2 >= 1 && g2 <= 7;
+    const int key = hand ? g1 * 8 + g2 : 0;                      // (bit 0 of both masks is clear)
+    return (int)((HARDLY >> key) & 1) * 2 + (int)((SELDOM >> key) & 1);
+}
+// The list of hull pairs is what the lanes of a team share out (lane k: list entries k, then - from the last lanes down - the entries beyond the first
+// 16): a lane with TWO live pairs costs its whole wave a second narrow-phase pass (measured with the index-order list in the bench's regime: 1.76 passes per
+// wave and substep, because the two busiest finger-tip pairs shared a lane; with this order 0.99).  The list therefore ends with the pairs that are hardly
+// ever live and has the seldom ones in front of them, so that in the standard model (22 hull pairs) the six lanes that own two pairs own a seldom and a
+// hardly-ever one.  Contacts are merged by pair INDEX: the order of this list changes no result.  Called once when a model is loaded.
+template <typename T> inline void model_pair_order(Model<T>& m) {
+    m.nplane = m.nhull = 0;
+    for (int pi = 0; pi < m.npair; pi++)
+        if (m.pair_g1[pi] == 0) m.plane_order[m.nplane++] = (unsigned char)pi;
+    for (int cls = 0; cls < 3; cls++)
+        for (int pi = 0; pi < m.npair; pi++)
+            if (m.pair_g1[pi] != 0 && hull_pair_rarity(m.pair_g1[pi], m.pair_g2[pi]) == cls) m.hull_order[m.nhull++] = (unsigned char)pi;
+    for (int k = m.nplane; k < NPAIR_MAX; k++) m.plane_order[k] = 0;
+    for (int k = m.nhull; k < NPAIR_MAX; k++) m.hull_order[k] = 0;
+}
 
 }  // namespace ks

@@ -202,6 +202,7 @@ template <typename T> bool parse_model(const void* vblob, size_t n, HostModel<T>
         if (!(row[4] >= 0) || row[4] > margin) { e = "pair margin outside [0, geom margin]"; return false; }
         m.pair_mu[p] = (T)row[2]; m.pair_margin[p] = (T)row[4];
     }
+    model_pair_order(m);
     for (int s = m.nmesh; s < NMESH; s++) {
         m.mesh_nvert[s] = m.mesh_nvert_pad[s] = m.mesh_ntri[s] = m.mesh_nnode[s] = m.mesh_nchunk[s] = 0;
         m.mesh_vert[s] = nullptr; m.mesh_tri[s] = nullptr; m.mesh_bvh_box[s] = nullptr; m.mesh_bvh_lr[s] = nullptr;
