@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4 soak runs: long timed regions, status counters (contact overflow, non-finite state, ray time-out, Newton cap), dropped episodes
-out=$GRAFT_REPO_ROOT/gpurun_out/r04_soak
+out=$GRAFT_REPO_ROOT/gpurun_out/${SOAK_TAG:-r04_soak}
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
 run() { name=$1; shift; timeout 1500 python3 bench.py --no-cpu-baseline "$@" > $out/$name.log 2>&1; tail -1 $out/$name.log | python3 -c "
