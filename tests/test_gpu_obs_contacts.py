@@ -150,12 +150,14 @@ def test_one_step_qvel_and_contact_forces_in_every_pose(orientation):
             # over to the penetration query at a sign decided by rounding: a few states per 330 with normals 0.2 degrees apart)
             # (round 4: every object contact is a penetration contact from MPR - explicit pairs have margin 0 - and 2 % of the states of
             # the 'normal' pose have a finger pad flat on a cube face, where the fp32 query ends on another triangle of that face)
-            assert (agree | tie)[same_n].mean() >= 0.97
-            assert eq[agree].max() <= 5e-6 and ev[agree].max() <= 5e-4
-            assert e_force.max() <= 2e-3
-            assert agree.mean() >= 0.93
+            # (measured at the end of round 5: counts equal 1.000, points agree 0.994 / 0.994 / 1.000, agreeing states |dqpos| <= 1.0e-6, |dqvel| <= 1.0e-4,
+            # force error <= 4.7e-4; the worst state of all 1.4e-4)
+            assert (agree | tie)[same_n].mean() >= 0.98
+            assert eq[agree].max() <= 3e-6 and ev[agree].max() <= 3e-4
+            assert e_force.max() <= 1.5e-3
+            assert agree.mean() >= 0.98
         # the tail (ties + flipped counts) stays bounded: a contact point moved along a flat feature, nothing else
-        assert eq.max() <= 5e-3
+        assert eq.max() <= (5e-3 if precision == 64 else 1.5e-3)
 
 
 @pytest.mark.parametrize("orientation", POSES)
@@ -196,7 +198,7 @@ def test_post_step_observation_reward_done_from_oracle_states(orientation):
         print(f"{orientation} fp{precision}: {n} env-steps, on-trajectory {on.mean():.3f}; obs slots beyond tolerance "
               f"(non-ray) {int(bad[on][:, NON_RAY].sum())}, (ray) {int(bad[on][:, RAY_SLOTS].sum())} of {int(on.sum()) * len(RAY_SLOTS)}; "
               f"|dqpos| median {np.median(eq):.2e} max {eq.max():.2e}; |dqvel| median {np.median(ev):.2e}")
-        assert on.mean() >= (0.95 if precision == 64 else 0.85)
+        assert on.mean() >= (0.95 if precision == 64 else 0.93)                 # (fp32 measured 0.969 / 1.000 / 1.000)
         assert not bad[on][:, NON_RAY].any(), np.argwhere(bad[on][:, NON_RAY])[:5]
         assert bad[on][:, RAY_SLOTS].mean() <= 0.01
         assert (ev[on] <= (1e-6 if precision == 64 else 2e-3)).all()
