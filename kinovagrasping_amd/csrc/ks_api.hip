@@ -299,7 +299,7 @@ constexpr int WG_RAY_TASKS = NRAY * RG;                                // per en
 constexpr int WG_SNAP = 97;                                            // body poses of an env (96 floats), odd stride
 // the walk queue: every surviving (env, ray, geom) task + the subtrees that busy walkers hand to idle lanes
 __host__ __device__ constexpr int wg_ray_queue(int epw) { return epw * WG_RAY_TASKS + 64 * epw; }
-__host__ __device__ constexpr int wg_rays_words(int epw) { return epw * NRAY + 8 + 2 * wg_ray_queue(epw) + RAY_STACK * WG + epw * WG_SNAP; }
+__host__ __device__ constexpr int wg_rays_words(int epw, int nth = WG) { return epw * NRAY + 8 + 2 * wg_ray_queue(epw) + RAY_STACK * nth + epw * WG_SNAP; }
 // ... followed by what wg_obs adds: the final ray distances [epw][NRAY + 1] and an auto-reset's kinematics scratch [epw][SCR_CON + 1]
 __host__ __device__ constexpr int wg_obs_words(int epw) { return epw * (NRAY + 1) + epw * (SCR_CON + 1); }
 struct LdsSnap {
@@ -349,7 +349,21 @@ struct SharingStack {
 #define KS_RAY_PROF_ARG(p)
 #define KS_RP(i)
 #endif
+// The threads that work together on a tail of the stepping kernels: the whole workgroup (k_env_step; k_rollout when its workgroups
+// step several groups), or ONE WAVE with its own four envs (k_rollout's free-running waves: no s_barrier anywhere in their loop - the
+// wave's LDS and memory operations are ordered by program order plus a fence).
+template <bool WAVE_SCOPE> struct Crew {
+    static constexpr int NTH = WAVE_SCOPE ? WAVE : WG;
+    static __device__ __forceinline__ int tid() { return WAVE_SCOPE ? (int)(threadIdx.x & (WAVE - 1)) : (int)threadIdx.x; }
+    static __device__ __forceinline__ void sync() {
+        if constexpr (WAVE_SCOPE) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    }
+};
+template <bool WAVE_SCOPE>
 __device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>& b, int N, int slot0, int epw, KS_LDS unsigned* w KS_RAY_PROF_PARAM) {
+    using C = Crew<WAVE_SCOPE>;
+    constexpr int NTH = C::NTH;
 #ifdef KS_ROLLOUT_STAMP
     long long rtk = wall_clock64();
     int my_visits = 0;
@@ -358,18 +372,18 @@ __device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>
     KS_LDS unsigned* ctl = w + epw * NRAY;                             // [8]: queue tail, tickets, unfinished walks
     KS_LDS unsigned* q = ctl + 8;                                      // [cap][2] the walk queue
     const int cap = wg_ray_queue(epw);
-    KS_LDS unsigned* stk = q + 2 * cap;                                // [RAY_STACK][WG]
-    KS_LDS float* snaps = (KS_LDS float*)(stk + RAY_STACK * WG);       // [epw][WG_SNAP] body poses (one global read round for everything)
-    const int tid = threadIdx.x, total = epw * WG_RAY_TASKS;
-    for (int i = tid; i < epw * NRAY; i += WG) hit[i] = (unsigned)__float_as_int(Lim<float>::big);
-    for (int i = tid; i < cap; i += WG) q[2 * i + 1] = 0u;
-    for (int i = tid; i < epw * 96; i += WG) {
+    KS_LDS unsigned* stk = q + 2 * cap;                                // [RAY_STACK][NTH]
+    KS_LDS float* snaps = (KS_LDS float*)(stk + RAY_STACK * NTH);       // [epw][WG_SNAP] body poses (one global read round for everything)
+    const int tid = C::tid(), total = epw * WG_RAY_TASKS;
+    for (int i = tid; i < epw * NRAY; i += NTH) hit[i] = (unsigned)__float_as_int(Lim<float>::big);
+    for (int i = tid; i < cap; i += NTH) q[2 * i + 1] = 0u;
+    for (int i = tid; i < epw * 96; i += NTH) {
         const int e = i / 96, k = i % 96, env = b.slot_env[slot0 + e];
         snaps[e * WG_SNAP + k] = env >= 0 ? b.snap[(long)(SNAP_BP + k) * N + env] : 0.f;
     }
     if (tid < 8) ctl[tid] = 0;
-    __syncthreads();
-    for (int task = tid; task < total; task += WG) {
+    C::sync();
+    for (int task = tid; task < total; task += NTH) {
         const int e = task / WG_RAY_TASKS, r = (task % WG_RAY_TASKS) >> RG_BITS, g = 1 + (task & (RG - 1)), env = b.slot_env[slot0 + e];
         if (env < 0 || g >= m.ngeom) continue;
         LdsSnap snap{snaps + e * WG_SNAP - SNAP_BP};
@@ -385,9 +399,9 @@ __device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>
             q[2 * i + 1] = (unsigned)task + 1u;
         }
     }
-    __syncthreads();
+    C::sync();
     if (tid == 0) ctl[2] = ctl[0];
-    __syncthreads();
+    C::sync();
     KS_RP(0)                             // snapshot load + culling pass
     // The walks, one node visit per loop iteration: a lane whose walk has ended takes the next entry of the queue in the SAME loop, so
     // the lanes of a wave do not wait for the longest walk of a round.
@@ -417,7 +431,7 @@ __device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>
                 ray_to_geom(m, snap, g, pnt, vec, lp, lv);
                 slot = hit + e * NRAY + r;
                 const int mesh = m.geom_mesh[g];
-                SharingStack st{LdsStack<float>{stk + tid, WG}, sh, t1};
+                SharingStack st{LdsStack<float>{stk + tid, NTH}, sh, t1};
                 busy = walk.start(m.mesh_tri[mesh], m.mesh_bvh_box[mesh], m.geom_size[g], lp, lv, SlotBound{slot}, st);
                 if (node != 0) {                                         // a subtree handed over by another walker: still in front of the nearest hit?
                     const float te = __int_as_float((int)(w0 & 0xffff0000u));
@@ -448,17 +462,17 @@ __device__ __noinline__ void wg_rays(const Model<float>& m, const Buffers<float>
 #ifdef KS_ROLLOUT_STAMP
     if (rprof) {                          // [2] surviving tasks, [3] node visits in total, [4] sum over workgroups of the busiest lane's visits
         if (tid == 0) { atomicAdd((unsigned long long*)&rprof[2], (unsigned long long)nlist); ctl[4] = 0; }
-        __syncthreads();
+        C::sync();
         atomicAdd((unsigned long long*)&rprof[3], (unsigned long long)my_visits);
         atomicMax((unsigned*)&ctl[4], (unsigned)my_visits);
     }
 #endif
-    __syncthreads();
+    C::sync();
     KS_RP(1)                             // the walks
 #ifdef KS_ROLLOUT_STAMP
     if (rprof && tid == 0) { atomicAdd((unsigned long long*)&rprof[4], (unsigned long long)ctl[4]); atomicAdd((unsigned long long*)&rprof[5], (unsigned long long)(ctl[0] - nlist)); }
 #endif
-    for (int i = tid; i < epw * NRAY; i += WG) {
+    for (int i = tid; i < epw * NRAY; i += NTH) {
         const int e = i / NRAY, r = i % NRAY, env = b.slot_env[slot0 + e];
         if (env >= 0) {
             const float t = __int_as_float((int)hit[i]);
@@ -472,6 +486,7 @@ template <typename T> struct ObsOut {
     T* obs; T* reward; uint8_t* done; T* info; T* final_obs;
     int horizon, auto_reset, env_major;
 };
+template <bool WAVE_SCOPE>
 __device__ void wg_obs(const Model<float>& m, const Buffers<float>& b, int N, int slot0, int epw, KS_LDS unsigned* w, const ObsOut<float>& o);
 __device__ void wg_ray_pool(const Model<float>* models, const Model<float>& mine, const Buffers<float>& b, int N, int epw, KS_LDS unsigned* w, int n_wg,
                             int linger);
@@ -620,11 +635,11 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
             // reference to the by-value kernel arguments made every lane copy them to its stack, 224 bytes written through per launch)
             if (ray_pool) wg_ray_pool(models, m, *bdev, N, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)), n_wg, ray_pool == 2);
             else {
-                wg_rays(m, *bdev, N, blockIdx.x * epw, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)) KS_RAY_PROF_ARG(nullptr));
+                wg_rays<false>(m, *bdev, N, blockIdx.x * epw, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)) KS_RAY_PROF_ARG(nullptr));
                 __threadfence_block();
                 __syncthreads();
             }
-            if (obs_in_step) wg_obs(m, *bdev, N, blockIdx.x * epw, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)), *out);
+            if (obs_in_step) wg_obs<false>(m, *bdev, N, blockIdx.x * epw, epw, (KS_LDS unsigned*)(lds + ((hull_words >> 2) << 2)), *out);
             if (ray_pool) {
                 // the last workgroup to leave clears the pool for the next launch
                 KS_LDS int* last = (KS_LDS int*)(lds + ((hull_words >> 2) << 2));
@@ -855,11 +870,11 @@ __device__ __forceinline__ void rollout_iter(const Model<float>& m, const Hulls<
     __threadfence_block();
     __syncthreads();
     KS_RS(1)
-    wg_rays(m, b, N, grp * epw, epw, w KS_RAY_PROF_ARG((long long*)&rap->counters[8 + 4 * 512]));
+    wg_rays<false>(m, b, N, grp * epw, epw, w KS_RAY_PROF_ARG((long long*)&rap->counters[8 + 4 * 512]));
     __threadfence_block();
     __syncthreads();
     KS_RS(2)
-    wg_obs(m, b, N, grp * epw, epw, w, *out);
+    wg_obs<false>(m, b, N, grp * epw, epw, w, *out);
     __threadfence_block();
     __syncthreads();
     if (active) rollout_store(rap, N, env, team.sub);
@@ -867,6 +882,121 @@ __device__ __forceinline__ void rollout_iter(const Model<float>& m, const Hulls<
     __syncthreads();
     KS_RS(3)
 #undef KS_RS
+}
+
+// ---- round 6: the waves of a workgroup run free.  rollout_iter above joins the four waves of a workgroup five times per env-step
+// (policy | 15 substeps | rays | observation | replay write), so every env-step costs the workgroup its SLOWEST wave (measured model,
+// profiles/r05_wave_sorting.txt: workgroup cost 1408 k cycles per env-step against 1091 k for the mean wave).  Nothing in an env-step
+// needs the other waves: per-env data is private to the wave's own four env blocks, the model and the hull tables are read-only.
+// Here the unit of the persistent loop is ONE WAVE with its four envs: the actor forward for its own four rows (a 16-column MFMA
+// tile a quarter full, bit-equal per row to the 4-wave tile), its own rays (the same work-sharing queue among 64 lanes), its own
+// observation and replay rows - and no s_barrier between kernel entry and exit.  Scratch of the tails: the wave's own four (then
+// dead) env blocks.
+__device__ __forceinline__ long long uniform64(long long v) {      // lane 0's value, in scalar registers
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+template <int NT1, int NT2>
+__device__ __noinline__ void rollout_policy_wave(const ks_rollout_args* __restrict__ rap, int N, int row_env, KS_LDS float* wblocks) {
+    const ks_rollout_args& ra = *rap;
+    const int S = krsel::S, A = krsel::A;
+    constexpr int NR = 4;
+    kmlp::f32x4(*H1)[NR] = (kmlp::f32x4(*)[NR])(float*)wblocks;
+    kmlp::f32x4(*H2)[NR] = H1 + NT1 * 4;
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        // (the wave's own look at the version counter: waves of a workgroup may act on different - each complete - weight versions)
+        const long long ver = uniform64(__hip_atomic_load(ra.actor_ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const float* pw = ra.actor_pub + (ver % 3) * ra.actor_stride;
+        kmlp::f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        const bool mine = kmlp::mlp3_rows_wave<NT1, NT2, true, NR>(lane, (long)row_env, S, ra.h1, ra.h2, A, ra.obs, S, pw + ra.off_w1, pw + ra.off_b1,
+                                                                     pw + ra.off_w2, pw + ra.off_b2, pw + ra.off_w3, H1, H2, z4);
+        float y[4] = {0.f, 0.f, 0.f, 0.f};
+        if (mine) {
+            const float z[4] = {z4.x, z4.y, z4.z, z4.w};
+            const float* b3 = pw + ra.off_b3;
+#pragma unroll
+            for (int i = 0; i < 4; i++) y[i] = ra.max_action / (1.f + __expf(-(z[i] + b3[i])));
+        }
+        // every read of buffer ver % 3 by this wave has been consumed by the arithmetic above; the acquire keeps the second look at
+        // the counter behind them (see rollout_policy: a buffer is rewritten two publications later)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const long long ver2 = uniform64(__hip_atomic_load(ra.actor_ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (ver2 - ver < 2) {
+            if (mine) {
+                float nz[4];
+                krsel::normal4(ra.seed, (unsigned long long)ra.steps_total[row_env], (uint32_t)row_env, nz);
+                krsel::select_one(row_env, N, y, nz, ra.obs, ra.prev_obs, ra.has_prev, ra.t, ra.ready, ra.sigma, ra.max_action, ra.skip_steps, ra.action,
+                                  ra.action_t, ra.lifting);
+            }
+            return;
+        }
+    }
+}
+
+// One env-step of ONE WAVE's four envs (slots grp * epw + 4 * wave ..): the body of k_rollout's barrier-free loop.
+template <int NT1, int NT2>
+__device__ __forceinline__ void rollout_iter_wave(const Model<float>& m, const Hulls<float>& hu, const Buffers<float>* __restrict__ bdev, int N, int frame_skip,
+                                               int iters, int epw, int pair_memory, const ObsOut<float>* __restrict__ out,
+                                               const ks_rollout_args* __restrict__ rap, KS_LDS float* blocks, int grp) {
+    using T = float;
+    using C = Crew<true>;
+    const Buffers<T>& b = *bdev;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int e = threadIdx.x / LANE_STRIDE;
+    const Team<SUBS> team{(int)threadIdx.x % LANE_STRIDE};
+    const int env = e < epw ? b.slot_env[grp * epw + e] : -1;
+    const bool active = env >= 0;
+    const int wslot0 = grp * epw + 4 * wave, wepw = epw - 4 * wave < 4 ? (epw - 4 * wave < 0 ? 0 : epw - 4 * wave) : 4;   // this wave's slots
+    KS_LDS T* wblocks = blocks + 4 * wave * SCR_TOTAL;
+    KS_LDS unsigned* w = (KS_LDS unsigned*)wblocks;
+    {
+        const int nn = lane & 15;
+        const int row_env = nn < wepw ? b.slot_env[wslot0 + nn] : -1;
+        rollout_policy_wave<NT1, NT2>(rap, N, row_env, wblocks);
+    }
+    C::sync();
+    if (active) {
+        T hq[4], act[4];
+        KS_UNROLL
+        for (int i = 0; i < 4; i++) { hq[i] = b.hand_quat[(long)i * N + env]; act[i] = rap->action_t[(long)i * N + env]; }
+        int ncon = 0, status = 0;
+        ColW<T> snap{b.snap + env, N};
+        KS_LDS T* blk = blocks + e * SCR_TOTAL;
+        ScratchC<T, KS_LDS T*> scr{blk};
+        T* stp = (T*)(blk + SCR_STATE);
+        load_state_team<T, SUBS>(b, env, N, stp, team.sub);
+        load_env_params(scr, team, b, env, N);
+        constexpr int WPL = (NPAIR_MAX + SUBS - 1) / SUBS;
+        PairWarm gw[WPL];
+        unsigned* pm = b.pairmem + ((long)env * SUBS + team.sub) * (WPL * WARM_WORDS);
+        KS_UNROLL
+        for (int q = 0; q < WPL; q++) {
+            KS_UNROLL
+            for (int j = 0; j < WARM_WORDS; j++) gw[q].w[j] = pair_memory ? pm[q * WARM_WORDS + j] : 0u;
+        }
+        lane_env_step(m, hu, *(LaneState<T>*)stp, hq, act, scr, team, snap, frame_skip, iters, ncon, status, (float*)nullptr, stp + NQ + 2 * NV, gw,
+                      []() {});
+        if (pair_memory) {
+            KS_UNROLL
+            for (int q = 0; q < WPL; q++) {
+                KS_UNROLL
+                for (int j = 0; j < WARM_WORDS; j++) pm[q * WARM_WORDS + j] = gw[q].w[j];
+            }
+        }
+        team.sync();
+        store_state_team<T, SUBS>(b, env, N, stp, team.sub);
+        if (status) atomicOr(&b.status[env], status);
+        if (team.sub == 0) b.ncon[env] = ncon;
+    }
+    C::sync();
+    wg_rays<true>(m, b, N, wslot0, wepw, w KS_RAY_PROF_ARG(nullptr));
+    C::sync();
+    wg_obs<true>(m, b, N, wslot0, wepw, w, *out);
+    C::sync();
+    if (active) rollout_store(rap, N, env, team.sub);
+    C::sync();
 }
 
 // another object's model constants and hull tables into the workgroup's LDS (out of line: nothing of it may stay in registers across
@@ -883,7 +1013,7 @@ __device__ __noinline__ int rollout_restage(const Model<float>* __restrict__ mp,
 template <int NT1, int NT2>
 __global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__ models, Buffers<float> b, const Buffers<float>* __restrict__ bdev, int N,
                                                 int frame_skip, int iters, int epw, int pair_memory, const ObsOut<float>* __restrict__ out,
-                                                const ks_rollout_args* __restrict__ rap, int n_iter, int n_groups, int* __restrict__ queue) {
+                                                const ks_rollout_args* __restrict__ rap, int n_iter, int n_groups, int* __restrict__ queue, int wave_free) {
     using T = float;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef KS_ROLLOUT_STAMP
@@ -914,6 +1044,24 @@ __global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__
     const long long wk_loop = wall_clock64();
     const long long ck_loop = clock64();
 #endif
+    if (wave_free) {
+        // ---- ONE GROUP PER WORKGROUP (4096 envs on 256 CUs, the metric's shape), round 6: from here on the four waves never meet again -
+        // each loops over its own four envs (rollout_iter_wave) and leaves when it has done its n_iter env-steps.
+#pragma clang loop unroll(disable)
+        for (int it = 0; it < n_iter; it++) {
+            const Model<T>* mi = ml;
+            Hulls<T>* hi = hup;
+            const Buffers<T>* bi = bdev;
+            const ObsOut<T>* oi = out;
+            const ks_rollout_args* ri = rap;
+            KS_LDS T* ki = blocks;
+            int gi = g0;
+            asm volatile("" : "+s"(mi), "+s"(hi), "+s"(bi), "+s"(oi), "+s"(ri), "+s"(gi));
+            asm volatile("" : "+v"(ki));
+            rollout_iter_wave<NT1, NT2>(*mi, *hi, bi, N, frame_skip, iters, epw, pair_memory, oi, ri, ki, gi);
+        }
+        return;
+    }
     if (queue != nullptr) {
         // ---- MORE GROUPS THAN RESIDENT WORKGROUPS, round 5: a FIFO of READY groups instead of a fixed deal.  The ring starts with every group
         // (k_rollout_queue_init); a workgroup pops the group at the head, steps it ONCE, and - unless that was the group's last env-step of the
@@ -1293,11 +1441,14 @@ __global__ __launch_bounds__(WAVE) void k_obs(const Model<T>* __restrict__ model
 // a finished episode - from the env's snapshot and ray distances in global memory (whoever cast the rays).  What leaves the
 // critical path against a k_obs launch is the launch, its gap and the wait for the slowest workgroup before ANY env's
 // observation could start.
+template <bool WAVE_SCOPE>
 __device__ __noinline__ void wg_obs(const Model<float>& m, const Buffers<float>& b, int N, int slot0, int epw, KS_LDS unsigned* w, const ObsOut<float>& o) {
-    KS_LDS float* rscr = (KS_LDS float*)(w + wg_rays_words(epw) + epw * (NRAY + 1));
+    using C = Crew<WAVE_SCOPE>;
+    KS_LDS float* rscr = (KS_LDS float*)(w + wg_rays_words(epw, C::NTH) + epw * (NRAY + 1));
     // team-parallel: wave p of the workgroup writes part p of the 82 slots (build_obs) of env e = lane, for the 16 envs at once -
-    // four instruction streams of a quarter of the length on the four SIMDs; then one thread per env finishes the step
-    const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
+    // four instruction streams of a quarter of the length on the four SIMDs; then one thread per env finishes the step.
+    // (One wave on its own: lane p of env e's DPP row takes part p - the four parts run one after the other, the wave's envs side by side.)
+    const int e = WAVE_SCOPE ? (int)(threadIdx.x & 63) >> 4 : (int)(threadIdx.x & 63), part = WAVE_SCOPE ? (int)(threadIdx.x & 15) : (int)(threadIdx.x >> 6);
     const int env = e < epw ? b.slot_env[slot0 + e] : -1;
     if (env >= 0 && part < 4) {
         float rays[NRAY];
@@ -1305,7 +1456,7 @@ __device__ __noinline__ void wg_obs(const Model<float>& m, const Buffers<float>&
         for (int r = 0; r < NRAY; r++) rays[r] = b.rays[(long)r * N + env];
         obs_write(m, b, env, N, 0, o, Col<float>{b.snap + env, N}, rays, part);
     }
-    __syncthreads();                                    // every part has read the snapshot (a restart overwrites it)
+    C::sync();                                          // every part has read the snapshot (a restart overwrites it)
     if (env >= 0 && part == 0)
         obs_finish(m, b, env, N, 0, o, Col<float>{b.snap + env, N}, ScratchC<float, KS_LDS float*>{rscr + e * (SCR_CON + 1)});
 }
@@ -1365,7 +1516,7 @@ __device__ __noinline__ void wg_ray_pool(const Model<float>* models, const Model
         if (t < 0) break;
         // (the same object as mine: my LDS copy of the model - a flat load that resolves to LDS costs a fraction of one that goes to L2)
         const int tm = b.wg_model[t];
-        wg_rays(tm == b.wg_model[own] ? mine : models[tm], b, N, t * epw, epw, w KS_RAY_PROF_ARG(nullptr));
+        wg_rays<false>(tm == b.wg_model[own] ? mine : models[tm], b, N, t * epw, epw, w KS_RAY_PROF_ARG(nullptr));
         __threadfence();
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(&state[t], 3, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1605,6 +1756,7 @@ template <typename T> struct Ctx : CtxBase {
                                           // the XCD's L2 every time ANY of its 32 workgroups takes a group: the 14-key stage context 0.87 -> 0.44 M env-steps/s
                                           // (measured, round 5).  That context is bound by its slowest groups' SEQUENTIAL env-steps anyway (every env does the
                                           // same number of env-steps per launch): no dealing helps it.  KS_ROLLOUT_DEAL=queue forces the queue.
+    bool rollout_waves = !(getenv("KS_ROLLOUT_WAVES") && getenv("KS_ROLLOUT_WAVES")[0] == '0');      // free-running waves (one group per workgroup)
     bool rollout_round_robin = false;     // how k_rollout deals the env groups to its persistent workgroups: contiguous runs (default) or round-robin (KS_ROLLOUT_DEAL=rr)
     int lpw = WAVE;
     bool rays_in_step = false, obs_in_step = false;
@@ -1727,6 +1879,10 @@ template <typename T> struct Ctx : CtxBase {
             HIPCHK(hipMemcpyAsync(d_ra, rslot, sizeof *ra, hipMemcpyHostToDevice, s));
             // more groups than resident workgroups: the ready queue (k_rollout); else one group per workgroup, nothing to deal
             const bool use_queue = rollout_queue && n_wg > resident_wgs && n_wg <= ROLLOUT_QCAP;
+            // one group per workgroup: its four waves run free (k_rollout, round 6); KS_ROLLOUT_WAVES=0 keeps them joined by barriers
+            const bool wave_free = rollout_waves && !use_queue && n_wg <= resident_wgs && lpw == EPW_MAX && LANE_STRIDE == SUBS &&
+                                   (size_t)(wg_rays_words(4, WAVE) + wg_obs_words(4) + 4) <= (size_t)SCR_TOTAL * 4 &&
+                                   (size_t)(((ra->h1 + 15) / 16 + (ra->h2 + 15) / 16) * 4) * 4 * 16 <= (size_t)SCR_TOTAL * 4 * sizeof(T);
             if (use_queue) {
                 hipLaunchKernelGGL(k_rollout_queue_init, dim3(1), dim3(256), 0, s, d_queue, n_wg);
             }
@@ -1735,7 +1891,7 @@ template <typename T> struct Ctx : CtxBase {
         HIPCHK(hipFuncSetAttribute((const void*)k_rollout<A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));                        \
         hipLaunchKernelGGL((k_rollout<A, B>), dim3(n_wg < resident_wgs ? n_wg : resident_wgs), dim3(WG), step_lds, s, d_model, b, (const Buffers<T>*)d_b, N, cfg.frame_skip,              \
                            cfg.solver_iterations, lpw, (int)cfg.pair_memory, (const ObsOut<T>*)d_out, (const ks_rollout_args*)d_ra, n_iter,                                              \
-                           (use_queue || !rollout_round_robin) ? n_wg : -n_wg, use_queue ? d_queue : (int*)nullptr);                                                                       \
+                           (use_queue || !rollout_round_robin) ? n_wg : -n_wg, use_queue ? d_queue : (int*)nullptr, (int)wave_free);                                                                       \
         HIPCHK(hipGetLastError());                                                                                                                    \
         return KS_OK;                                                                                                                                 \
     }

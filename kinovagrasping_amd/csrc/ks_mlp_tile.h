@@ -143,4 +143,96 @@ __device__ __forceinline__ bool mlp3_rows16(const int wave, const int lane, cons
     return false;
 }
 
+// The same three layers by ONE wave for the first NR rows of a tile (the free-running rollout kernel's waves each own four envs and
+// never meet a barrier): every output element is the chain of MFMAs mlp3_rows16 runs for it - same k order, the same two accumulators
+// per tile, layer 3 as NW partial sums added in wave order - so a row's result is the 4-wave kernel's bit for bit (an MFMA's output
+// column depends on its own B column only; columns >= NR read zeros and are discarded).  H1 / H2: the wave's own scratch,
+// [NT1 * 4][NR], [NT2 * 4][NR] float4.  Returns true on the lanes that hold a row's layer-3 sums (first quarter, row valid).
+template <int NT1, int NT2, bool VEC, int NR>
+__device__ __forceinline__ bool mlp3_rows_wave(const int lane, const long row, int in_dim, int h1, int h2, int out_dim, const float* __restrict__ xa, int lda,
+                                               const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+                                               const float* __restrict__ b2, const float* __restrict__ W3, f32x4 (*H1)[NR], f32x4 (*H2)[NR], f32x4& z4) {
+    const int nn = lane & 15, q = lane >> 4;
+    const bool row_ok = row >= 0, col_ok = nn < NR;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bx[KS_IN_MAX];
+#pragma unroll
+    for (int s = 0; s < KS_IN_MAX; s++) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = 16 * s + 4 * q + j;
+            v[j] = (row_ok && k < in_dim) ? xa[(long)row * lda + k] : 0.f;
+        }
+        bx[s] = f32x4{v[0], v[1], v[2], v[3]};
+    }
+    f32x4 w2[NT1];
+#pragma unroll
+    for (int s = 0; s < NT1; s++) w2[s] = load_w4<VEC>(W2, nn, h2, 16 * s + 4 * q, h1);
+    {
+        f32x4 w1[KS_IN_MAX];
+#pragma unroll
+        for (int s = 0; s < KS_IN_MAX; s++) w1[s] = load_w4<false>(W1, nn, h1, 16 * s + 4 * q, in_dim);
+        for (int t = 0; t < NT1; t++) {
+            f32x4 wn[KS_IN_MAX];
+#pragma unroll
+            for (int s = 0; s < KS_IN_MAX; s++) wn[s] = load_w4<false>(W1, (t + 1) * 16 + nn, t + 1 < NT1 ? h1 : 0, 16 * s + 4 * q, in_dim);
+            f32x4 acc0 = zero, acc1 = zero;
+#pragma unroll
+            for (int s = 0; s < KS_IN_MAX; s++) {
+                if (s & 1) acc1 = mfma4(w1[s], bx[s], acc1);
+                else acc0 = mfma4(w1[s], bx[s], acc0);
+            }
+            const f32x4 hq = bias_relu(acc0 + acc1, b1, t * 16 + 4 * q, h1);
+            if (col_ok) H1[t * 4 + q][nn] = hq;
+#pragma unroll
+            for (int s = 0; s < KS_IN_MAX; s++) w1[s] = wn[s];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // layer 2: the B operands are the same for every tile - read once
+    f32x4 hb[NT1];
+#pragma unroll
+    for (int s = 0; s < NT1; s++) hb[s] = col_ok ? H1[s * 4 + q][nn] : zero;
+    for (int t = 0; t < NT2; t++) {
+        f32x4 wn[NT1];
+#pragma unroll
+        for (int s = 0; s < NT1; s++) wn[s] = load_w4<VEC>(W2, (t + 1) * 16 + nn, t + 1 < NT2 ? h2 : 0, 16 * s + 4 * q, h1);
+        f32x4 acc0 = zero, acc1 = zero;
+#pragma unroll
+        for (int s = 0; s < NT1; s++) {
+            if (s & 1) acc1 = mfma4(w2[s], hb[s], acc1);
+            else acc0 = mfma4(w2[s], hb[s], acc0);
+        }
+        const f32x4 hq = bias_relu(acc0 + acc1, b2, t * 16 + 4 * q, h2);
+        if (col_ok) H2[t * 4 + q][nn] = hq;
+#pragma unroll
+        for (int s = 0; s < NT1; s++) w2[s] = wn[s];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // layer 3: the NW partial sums of the 4-wave kernel (tiles w, w + NW, ...), added in wave order
+    f32x4 part[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        f32x4 acc = zero;
+#pragma unroll
+        for (int j = 0; j < (NT2 + NW - 1) / NW; j++)
+            if (w + NW * j < NT2) acc = mfma4(load_w4<VEC>(W3, nn, out_dim, 16 * (w + NW * j) + 4 * q, h2), col_ok ? H2[(w + NW * j) * 4 + q][nn] : zero, acc);
+        part[w] = acc;
+    }
+    if (q == 0 && row_ok && col_ok) {
+        z4 = part[0];
+#pragma unroll
+        for (int w = 1; w < NW; w++) z4 += part[w];
+        return true;
+    }
+    return false;
+}
+
 }  // namespace kmlp
