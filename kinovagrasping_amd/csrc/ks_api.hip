@@ -48,6 +48,7 @@ template <typename T> struct Buffers {
     unsigned *pairmem;            // [N][SUBS][2 * WARM_WORDS] pair memory carried from launch to launch (fp32 / LDS contexts):
                                   // what every lane of an env's team remembers of its (<= 2) hull pairs' last queries
                                   // (ks_core.h: PairWarm), env-major: a team moves its 512 bytes as 16 x 32-byte pieces
+    T* pathmem;                   // [N][SUBS][HPL][PATH_WORDS] the hull pairs' remembered penetration paths (ks_core.h: MPR_PATH; fp32 / LDS contexts), env-major like pairmem
     int32_t *ncon, *status, *step_count;
     uint8_t *flag;                // envs to (re)initialise
     // mixed-object batches (BASELINE config 5): the object model of every env, and the stepping kernel's work list - its
@@ -495,12 +496,26 @@ __device__ void wg_ray_pool(const Model<float>* models, const Model<float>& mine
 #endif
 constexpr int POOL_LINGER_LAST = KS_POOL_LINGER_LAST;
 
+// Register budget of the fp32 stepping kernels: 376 of a SIMD lane's 512 (256 VGPRs + 120 AGPRs), so that a wave of the learner's LDS-free kernels
+// stays resident BESIDE a stepping wave on every SIMD.  The count the compiler arrives at on its own moves by tens of registers with
+// changes far from the hot loops (an out-of-line callee's clobber set decides which of the kernel's live-across-call values sit in AGPRs); at 378 the
+// learner no longer fits and training runs at 0.7 x.  amdgpu_num_vgpr(N) caps VGPRs + AGPRs at 2 N on gfx950's unified file; what does not fit is spilled
+// to scratch (values that are touched once per substep).
+// k_rollout: 376 (beside it: the one-wave learner kernels, 128); k_env_step_f32: 352 (beside it: the lock-step trainer's 4-wave split kernels, 160).
+#ifndef KS_ROLLOUT_NUM_VGPR
+#define KS_ROLLOUT_NUM_VGPR 188
+#endif
+#ifndef KS_STEP_NUM_VGPR
+#define KS_STEP_NUM_VGPR 176
+#endif
+#define KS_ROLLOUT_REGS __attribute__((amdgpu_num_vgpr(KS_ROLLOUT_NUM_VGPR)))
+#define KS_STEP_REGS __attribute__((amdgpu_num_vgpr(KS_STEP_NUM_VGPR)))
 // obs_in_step: the observation / reward / done / auto-reset of the workgroup's envs are produced here too (wg_obs), the
 // separate k_obs launch of a step is gone; needs rays_in_step (fp32 / LDS variant).
 template <typename T, bool USE_LDS>
-__global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ models, Buffers<T> b, const Buffers<T>* __restrict__ bdev,
-                                                   const T* __restrict__ action, int N, int frame_skip, int iters, int epw, int tap, int rays_in_step,
-                                                   int pair_memory, int obs_in_step, const ObsOut<T>* __restrict__ out, int ray_pool, int n_wg) {
+__device__ __forceinline__ void env_step_body(const Model<T>* __restrict__ models, const Buffers<T>& b, const Buffers<T>* __restrict__ bdev,
+                                              const T* __restrict__ action, int N, int frame_skip, int iters, int epw, int tap, int rays_in_step,
+                                              int pair_memory, int obs_in_step, const ObsOut<T>* __restrict__ out, int ray_pool, int n_wg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef KS_STAMP_WG
     const long long wk_entry = wall_clock64();
@@ -586,7 +601,8 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
             KS_UNROLL
             for (int j = 0; j < WARM_WORDS; j++) gw[q].w[j] = pair_memory ? pm[q * WARM_WORDS + j] : 0u;
         }
-        lane_env_step(m, hu, *(LaneState<T>*)stp, hq, act, scr, team, snap, frame_skip, iters, ncon, status, prof, stp + NQ + 2 * NV, gw, slot_arrived);
+        lane_env_step(m, hu, *(LaneState<T>*)stp, hq, act, scr, team, snap, frame_skip, iters, ncon, status, prof, stp + NQ + 2 * NV, gw, slot_arrived,
+                      pair_memory ? b.pathmem + ((long)env * SUBS + team.sub) * (WPL * PATH_WORDS) : (T*)nullptr);
         if (pair_memory) {
             KS_UNROLL
             for (int q = 0; q < WPL; q++) {
@@ -653,6 +669,20 @@ __global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ mo
             }
         }
     }
+}
+
+
+// the kernel: the fp64 instantiation takes what it needs (256 + 256 registers, the parity instrument); the fp32 product is capped (KS_STEP_NUM_VGPR above)
+template <typename T, bool USE_LDS>
+__global__ __launch_bounds__(WG) void k_env_step(const Model<T>* __restrict__ models, Buffers<T> b, const Buffers<T>* __restrict__ bdev,
+                                                   const T* __restrict__ action, int N, int frame_skip, int iters, int epw, int tap, int rays_in_step,
+                                                   int pair_memory, int obs_in_step, const ObsOut<T>* __restrict__ out, int ray_pool, int n_wg) {
+    env_step_body<T, USE_LDS>(models, b, bdev, action, N, frame_skip, iters, epw, tap, rays_in_step, pair_memory, obs_in_step, out, ray_pool, n_wg);
+}
+__global__ __launch_bounds__(WG) KS_STEP_REGS void k_env_step_f32(const Model<float>* __restrict__ models, Buffers<float> b, const Buffers<float>* __restrict__ bdev,
+                                                                       const float* __restrict__ action, int N, int frame_skip, int iters, int epw, int tap, int rays_in_step,
+                                                                       int pair_memory, int obs_in_step, const ObsOut<float>* __restrict__ out, int ray_pool, int n_wg) {
+    env_step_body<float, true>(models, b, bdev, action, N, frame_skip, iters, epw, tap, rays_in_step, pair_memory, obs_in_step, out, ray_pool, n_wg);
 }
 
 
@@ -854,7 +884,7 @@ __device__ __forceinline__ void rollout_iter(const Model<float>& m, const Hulls<
             for (int j = 0; j < WARM_WORDS; j++) gw[q].w[j] = pair_memory ? pm[q * WARM_WORDS + j] : 0u;
         }
         lane_env_step(m, hu, *(LaneState<T>*)stp, hq, act, scr, team, snap, frame_skip, iters, ncon, status, (float*)nullptr, stp + NQ + 2 * NV, gw,
-                      []() {});
+                      []() {}, pair_memory ? b.pathmem + ((long)env * SUBS + team.sub) * (WPL * PATH_WORDS) : (T*)nullptr);
         if (pair_memory) {
             KS_UNROLL
             for (int q = 0; q < WPL; q++) {
@@ -977,7 +1007,7 @@ __device__ __forceinline__ void rollout_iter_wave(const Model<float>& m, const H
             for (int j = 0; j < WARM_WORDS; j++) gw[q].w[j] = pair_memory ? pm[q * WARM_WORDS + j] : 0u;
         }
         lane_env_step(m, hu, *(LaneState<T>*)stp, hq, act, scr, team, snap, frame_skip, iters, ncon, status, (float*)nullptr, stp + NQ + 2 * NV, gw,
-                      []() {});
+                      []() {}, pair_memory ? b.pathmem + ((long)env * SUBS + team.sub) * (WPL * PATH_WORDS) : (T*)nullptr);
         if (pair_memory) {
             KS_UNROLL
             for (int q = 0; q < WPL; q++) {
@@ -1011,7 +1041,7 @@ __device__ __noinline__ int rollout_restage(const Model<float>* __restrict__ mp,
 }
 
 template <int NT1, int NT2>
-__global__ __launch_bounds__(WG) void k_rollout(const Model<float>* __restrict__ models, Buffers<float> b, const Buffers<float>* __restrict__ bdev, int N,
+__global__ __launch_bounds__(WG) KS_ROLLOUT_REGS void k_rollout(const Model<float>* __restrict__ models, Buffers<float> b, const Buffers<float>* __restrict__ bdev, int N,
                                                 int frame_skip, int iters, int epw, int pair_memory, const ObsOut<float>* __restrict__ out,
                                                 const ks_rollout_args* __restrict__ rap, int n_iter, int n_groups, int* __restrict__ queue, int wave_free) {
     using T = float;
@@ -1631,6 +1661,7 @@ template <typename T> struct Ctx : CtxBase {
         if (!USE_LDS && (r = alloc(&b.gscratch, (size_t)SCR_TOTAL * N))) return r;
         if ((r = alloc(&b.envp, (size_t)2 * N))) return r;
         if (USE_LDS && (r = alloc(&b.pairmem, (size_t)SUBS * ((NPAIR_MAX + SUBS - 1) / SUBS) * WARM_WORDS * N))) return r;
+        if (USE_LDS && (r = alloc(&b.pathmem, (size_t)SUBS * ((NPAIR_MAX + SUBS - 1) / SUBS) * PATH_WORDS * N))) return r;
         if ((r = alloc(&b.ncon, N))) return r;
         if ((r = alloc(&b.status, N))) return r;
         if ((r = alloc(&b.step_count, N))) return r;
@@ -1792,7 +1823,8 @@ template <typename T> struct Ctx : CtxBase {
         obs_in_step = rays_in_step && (size_t)(wg_rays_words(EPW_MAX) + wg_obs_words(EPW_MAX) + 4) <= (size_t)SCR_TOTAL * lpw &&
                       !(getenv("KS_OBS_IN_STEP") && getenv("KS_OBS_IN_STEP")[0] == '0');
         if (getenv("KS_DEBUG")) fprintf(stderr, "[ks] stepping kernel: %d envs per workgroup, LDS %zu B (tables %zu B, %zu B per env), limit %zu\n", lpw, step_lds, hull_bytes, per_env, lds_max);
-        HIPCHK(hipFuncSetAttribute((const void*)k_env_step<T, USE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
+        if constexpr (sizeof(T) == 4) HIPCHK(hipFuncSetAttribute((const void*)k_env_step_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
+        else HIPCHK(hipFuncSetAttribute((const void*)k_env_step<T, USE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_substep<T, USE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
         return KS_OK;
     }
@@ -1842,9 +1874,14 @@ template <typename T> struct Ctx : CtxBase {
             HIPCHK(hipMemcpyAsync(d_out, slot, sizeof out, hipMemcpyHostToDevice, s));
         }
         if (timed) HIPCHK(hipEventRecord(ev0[ev_used], s));
-        hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3(n_wg), dim3(WG), step_lds, s, d_model, b, (const Buffers<T>*)d_b, (const T*)action, N,
-                           cfg.frame_skip, cfg.solver_iterations, lpw, cfg.contact_tap, (int)rays_in_step, (int)(USE_LDS && cfg.pair_memory),
-                           (int)obs_in_step, (const ObsOut<T>*)d_out, ray_pool, n_wg);
+        if constexpr (sizeof(T) == 4)
+            hipLaunchKernelGGL(k_env_step_f32, dim3(n_wg), dim3(WG), step_lds, s, d_model, b, (const Buffers<T>*)d_b, (const T*)action, N,
+                               cfg.frame_skip, cfg.solver_iterations, lpw, cfg.contact_tap, (int)rays_in_step, (int)(USE_LDS && cfg.pair_memory),
+                               (int)obs_in_step, (const ObsOut<T>*)d_out, ray_pool, n_wg);
+        else
+            hipLaunchKernelGGL((k_env_step<T, USE_LDS>), dim3(n_wg), dim3(WG), step_lds, s, d_model, b, (const Buffers<T>*)d_b, (const T*)action, N,
+                               cfg.frame_skip, cfg.solver_iterations, lpw, cfg.contact_tap, (int)rays_in_step, (int)(USE_LDS && cfg.pair_memory),
+                               (int)obs_in_step, (const ObsOut<T>*)d_out, ray_pool, n_wg);
         if (timed) { HIPCHK(hipEventRecord(ev1[ev_used], s)); ev_used++; }
         if (!rays_in_step) hipLaunchKernelGGL((k_rays<T>), dim3((N + RAY_ENVS - 1) / RAY_ENVS, NRAY), dim3(WAVE), 0, s, d_model, b, N, 0);
         if (!obs_in_step) hipLaunchKernelGGL((k_obs<T>), dim3(blocks()), dim3(WAVE), 0, s, d_model, b, N, 0, out);

@@ -603,6 +603,7 @@ template <typename T> struct PairGeo {
     const unsigned short* dir1; const unsigned short* dir2;   // cube-map support start tables of the two hulls (global memory)
     int n1, n2;
     int hint1, hint2;          // last support vertex of each shape: start of the next hill climb
+    bool use_tab;              // consult the cube-map start tables (global memory); false: the hints are a remembered path's own vertices (mpr_penetration_sm)
     T half_margin;
 #ifdef KS_STAMP_HULL
     int cnt_support, cnt_steps;
@@ -639,6 +640,9 @@ template <typename T> KS_HD int support_cell(const T* ld) {
     return ((2 * axis + (major < 0 ? 1 : 0)) * SUPPORT_R + iu) * SUPPORT_R + iv;
 }
 
+#ifdef KS_COUNT_CLIMB
+static long ks_climb_rounds = 0, ks_mpr_supports = 0, ks_mpr_queries = 0, ks_mpr_hinted = 0;     // host-only study counters (tools/r06)
+#endif
 // the climb: from the better of `hint` (the previous support vertex) and `tab` (the support vertex of the cube-map cell
 // the direction falls in) to the support vertex along the hull-frame direction ld
 template <typename T>
@@ -661,6 +665,9 @@ KS_HD void hull_climb(const T* R, const T* p, KS_TAB const T* V, KS_TAB const un
     bool tab_pending = true;
 #endif
     for (int guard = 0; guard < 4096; guard++) {
+#ifdef KS_COUNT_CLIMB
+        ks_climb_rounds++;
+#endif
         const int c0 = off[cur], c1 = off[cur + 1];
         int nxt = cur;
         for (int c = c0; c < c1; c += 2) {
@@ -738,7 +745,7 @@ template <typename T> KS_HD void pair_support(PairGeo<T>& g, const T* dir, T hm,
     // and pipeline through the LDS, a climb is a chain of dependent rounds plus a table read from L2; same vertex.  Measured slower: a warm
     // climb is one hop, and a wave whose lanes mix small and large hulls runs both code paths.
     const bool scan1 = g.n1 <= SCAN_MAX, scan2 = g.n2 <= SCAN_MAX;
-    const int tab1 = scan1 ? 0 : g.dir1[support_cell(ld1)], tab2 = scan2 ? 0 : g.dir2[support_cell(ld2)];
+    const int tab1 = scan1 ? 0 : (g.use_tab ? (int)g.dir1[support_cell(ld1)] : g.hint1), tab2 = scan2 ? 0 : (g.use_tab ? (int)g.dir2[support_cell(ld2)] : g.hint2);
     if (scan1) hull_scan(g.R1, g.p1, g.V1, g.n1, g.hint1, ld1, dir, hm, out1);
     else hull_climb(g.R1, g.p1, g.V1, g.off1, g.adj1, tab1, g.hint1, ld1, dir, hm, out1);
     if (scan2) hull_scan(g.R2, g.p2, g.V2, g.n2, g.hint2, ld2, nd, hm, out2);
@@ -774,6 +781,9 @@ template <typename T> KS_HD void minkowski_point_ids(const PairGeo<T>& g, int i,
 }
 
 template <typename T> KS_HD void mpr_support(PairGeo<T>& g, const T* dir, Supp<T>& o) {
+#ifdef KS_COUNT_CLIMB
+    ks_mpr_supports++; ks_mpr_hinted += g.use_tab ? 0 : 1;
+#endif
 #ifdef KS_STAMP_HULL
     const int h1_ = g.hint1, h2_ = g.hint2;
 #endif
@@ -914,6 +924,292 @@ template <typename T> KS_HD void hull_point(const T* R, const T* p, KS_TAB const
     add3(out, out, p);
 }
 
+// ---- Round 6: the penetration query of the fp32 PRODUCT (mpr_penetration_sm below; the template above stays the fp64 instantiation's - the
+// parity instrument's - and the KS_MPR_SM=0 fall-back).
+// (1) COLD again.  Rounds 3-5 started the product's query from the previous substep's final portal whenever that still was one (KS_MPR_WARM).
+//     That is a different - equally valid - run of MPR, and on flat features it ends on another triangle of the same Minkowski facet: another
+//     contact POINT.  The long-horizon parity tests never saw it: they step through ks_substep, whose queries are cold.  Measured through ks_step
+//     in round 6 (tests/studies/long_horizon_envstep.py), the warm start left 76 of the 168 grasp-and-lift envs within 1e-4 of the oracle after
+//     210 substeps; libccd's cold path - what MuJoCo runs, what the oracle follows and the recorded trajectory pins - leaves 141.
+// (2) On fp64 Minkowski points.  Every point is formed from its two vertex IDS - fp32 hull tables and poses, fp64 arithmetic, as round 5's
+//     read-off of the final portal - so portal normals, the supports along them, the stop test and the expansion's sign tests are decided as the
+//     fp64 oracle decides them wherever both stand on the same portal: 160 of 168 on the GPU, 162 on the host lane
+//     (tests/studies/divergence_table.py: variant r6).  State per portal corner: 3 doubles + 2 ids (SuppD).
+// (3) ONE loop around ONE support site.  The template has five inlined support sites (v1, v2, discovery loop, "origin inside" loop, refinement
+//     loop); the lanes of a wave that run a query are in different loops after the first two supports and the wave executes every site for as
+//     many turns as ITS slowest lane needs there.  Here every lane, whatever phase its query is in, takes its next support in the same
+//     instruction stream; the phases' own arithmetic (cross products, sign tests) is short and predicated.
+// (4) With a PATH memory.  A cold query is ~10 support pairs against the warm start's 1 - 2; each is two hill climbs - chains of dependent LDS
+//     reads.  The query remembers the vertex pair each of its first MPR_PATH supports returned; the next substep's support k starts its climbs AT
+//     those vertices (nearly always still the maximisers: one confirming round per hull, no cube-map read from L2).  A support vertex does not
+//     depend on where the climb starts (a local maximiser of a linear function on a convex polytope is the global one): the result is the cold
+//     query's.  The path lives in global memory (T-typed words: the ids as exact small numbers), is staged in the lane's share of the contact
+//     records - dead during the narrow phase - while a query runs, and is written back behind it.
+constexpr int MPR_PATH = 12, PATH_WORDS = 16;       // supports remembered; words per pair in global memory ([0 .. MPR_PATH) ids, [MPR_PATH] their count)
+#ifndef KS_MPR_SM
+#define KS_MPR_SM 1             // 0: the fp32 product runs the template above (fp32 points, cold unless KS_MPR_WARM=1): A/B and the divergence study
+#endif
+#ifndef KS_MPR_PATH
+#define KS_MPR_PATH 1           // 0: no path memory (every climb starts from the last support vertex and the cube map)
+#endif
+#ifdef KS_SM_INLINE
+#define KS_FN_SM KS_HD
+#else
+#define KS_FN_SM KS_FN
+#endif
+#ifdef KS_SUP_OUTLINE
+#define KS_FN_SUP KS_FN
+#else
+#define KS_FN_SUP KS_HD
+#endif
+struct SuppD {
+    double v[3];
+    int i1, i2;
+};
+template <typename T> KS_HD void mink_f64(const PairGeo<T>& g, int i, int j, double* v) {
+    const double a[3] = {(double)g.V1[4 * i], (double)g.V1[4 * i + 1], (double)g.V1[4 * i + 2]};
+    const double b[3] = {(double)g.V2[4 * j], (double)g.V2[4 * j + 1], (double)g.V2[4 * j + 2]};
+    KS_UNROLL
+    for (int k = 0; k < 3; k++) {
+        const double w1 = (double)g.R1[3 * k] * a[0] + (double)g.R1[3 * k + 1] * a[1] + (double)g.R1[3 * k + 2] * a[2];
+        const double w2 = (double)g.R2[3 * k] * b[0] + (double)g.R2[3 * k + 1] * b[1] + (double)g.R2[3 * k + 2] * b[2];
+        v[k] = (w1 - w2) + ((double)g.p1[k] - (double)g.p2[k]);
+    }
+}
+// support vertex of a hull (fp32 table) along the hull-frame direction ld, fp64 dot products: hull_climb's rule (best strictly improving
+// neighbour in list order) from `cur`
+#ifndef KS_CLIMB64_WIDTH
+#define KS_CLIMB64_WIDTH 4      // neighbours per round of the fp64 climb (8 = hull_climb's two chunks at a time: faster alone, but 24 more live registers in the
+#endif                          // out-of-line query - the stepping kernels then no longer leave room for the learner's waves beside them)
+template <typename TV>
+KS_HD int climb_f64(KS_TAB const TV* V, KS_TAB const unsigned short* off, KS_TAB const unsigned short* adj, int cur, int tab, const double* ld) {
+    double best = (double)V[4 * cur] * ld[0] + (double)V[4 * cur + 1] * ld[1] + (double)V[4 * cur + 2] * ld[2];
+    {
+        const double bt = (double)V[4 * tab] * ld[0] + (double)V[4 * tab + 1] * ld[1] + (double)V[4 * tab + 2] * ld[2];
+        if (bt > best) { best = bt; cur = tab; }
+    }
+    constexpr int W = KS_CLIMB64_WIDTH, CH = W / 4;
+    for (int guard = 0; guard < 4096; guard++) {
+        const int c0 = off[cur], c1 = off[cur + 1];
+        int nxt = cur;
+        for (int c = c0; c < c1; c += CH) {
+            // W neighbour ids per round: id reads together, then the vertices, then the comparisons in list order (hull_climb's rule)
+            int j[W];
+            double d[W];
+            KS_UNROLL
+            for (int q = 0; q < W; q++) { const int cc = c + q / 4 < c1 ? c + q / 4 : c; j[q] = adj[4 * cc + (q & 3)]; }
+            KS_UNROLL
+            for (int q = 0; q < W; q++) d[q] = (double)V[4 * j[q]] * ld[0] + (double)V[4 * j[q] + 1] * ld[1] + (double)V[4 * j[q] + 2] * ld[2];
+            KS_UNROLL
+            for (int q = 0; q < W; q++)
+                if (d[q] > best) { best = d[q]; nxt = j[q]; }
+        }
+        if (nxt == cur) break;
+        cur = nxt;
+    }
+    return cur;
+}
+template <typename T> KS_FN_SUP void support_f64(PairGeo<T>& g, const double* d, SuppD& o) {
+    double ld1[3], ld2[3];
+    KS_UNROLL
+    for (int k = 0; k < 3; k++) {
+        ld1[k] = (double)g.R1[k] * d[0] + (double)g.R1[3 + k] * d[1] + (double)g.R1[6 + k] * d[2];
+        ld2[k] = -((double)g.R2[k] * d[0] + (double)g.R2[3 + k] * d[1] + (double)g.R2[6 + k] * d[2]);
+    }
+    const double s1 = SUPPORT_SKEW * (kabs(ld1[0]) + kabs(ld1[1]) + kabs(ld1[2])), s2 = SUPPORT_SKEW * (kabs(ld2[0]) + kabs(ld2[1]) + kabs(ld2[2]));
+    ld1[0] += s1 * SKEW_X; ld1[1] += s1 * SKEW_Y; ld1[2] += s1 * SKEW_Z;
+    ld2[0] += s2 * SKEW_X; ld2[1] += s2 * SKEW_Y; ld2[2] += s2 * SKEW_Z;
+    // the climbs start from the better of the last support vertex and the cube-map cell's (a start only: the climb decides in fp64)
+    const T f1[3] = {(T)ld1[0], (T)ld1[1], (T)ld1[2]}, f2[3] = {(T)ld2[0], (T)ld2[1], (T)ld2[2]};
+    const int tab1 = g.use_tab ? (int)g.dir1[support_cell(f1)] : g.hint1, tab2 = g.use_tab ? (int)g.dir2[support_cell(f2)] : g.hint2;
+    g.hint1 = climb_f64(g.V1, g.off1, g.adj1, g.hint1, tab1, ld1);
+    g.hint2 = climb_f64(g.V2, g.off2, g.adj2, g.hint2, tab2, ld2);
+    o.i1 = g.hint1; o.i2 = g.hint2;
+    mink_f64(g, o.i1, o.i2, o.v);
+}
+KS_HD void portal_dir_d(const SuppD& v1, const SuppD& v2, const SuppD& v3, double* dir) {
+    double a[3], b[3];
+    sub3(a, v2.v, v1.v);
+    sub3(b, v3.v, v1.v);
+    cross3(dir, a, b);
+    normalize3(dir);
+}
+KS_HD bool portal_reach_tol_d(const SuppD& v1, const SuppD& v2, const SuppD& v3, const SuppD& v4, const double* dir, double tol) {
+    const double dv4 = dot3(v4.v, dir);
+    const double d1 = dv4 - dot3(v1.v, dir), d2 = dv4 - dot3(v2.v, dir), d3 = dv4 - dot3(v3.v, dir);
+    double d = d1 < d2 ? d1 : d2;
+    d = d < d3 ? d : d3;
+    return is_zero(d) || d < tol;
+}
+KS_HD void expand_portal_d(const SuppD& v0, SuppD& v1, SuppD& v2, SuppD& v3, const SuppD& v4) {
+    double c[3];
+    cross3(c, v4.v, v0.v);
+    if (dot3(v1.v, c) > 0) {
+        if (dot3(v2.v, c) > 0) v1 = v4; else v3 = v4;
+    } else {
+        if (dot3(v3.v, c) > 0) v2 = v4; else v1 = v4;
+    }
+}
+// depth / direction / contact point read off the final portal (fp64 points; the hulls' own support points rebuilt from the vertex ids)
+template <typename T>
+KS_HD bool mpr_readoff_f64(const PairGeo<T>& g, const SuppD& v0, const SuppD& v1, const SuppD& v2, const SuppD& v3, T* depth, T* dir, T* pos) {
+    double wit[3], d[3];
+    const double dd = origin_tri_dist2<double>(v1.v, v2.v, v3.v, wit);
+    *depth = (T)std::sqrt(dd);
+    if (vec_is_zero(wit)) return false;
+    const double nn = std::sqrt(wit[0] * wit[0] + wit[1] * wit[1] + wit[2] * wit[2]);
+    dir[0] = (T)(wit[0] / nn); dir[1] = (T)(wit[1] / nn); dir[2] = (T)(wit[2] / nn);
+    double b[4], t[3], sum;
+    portal_dir_d(v1, v2, v3, d);
+    cross3(t, v1.v, v2.v); b[0] = dot3(t, v3.v);
+    cross3(t, v3.v, v2.v); b[1] = dot3(t, v0.v);
+    cross3(t, v0.v, v1.v); b[2] = dot3(t, v3.v);
+    cross3(t, v2.v, v1.v); b[3] = dot3(t, v0.v);
+    sum = b[0] + b[1] + b[2] + b[3];
+    if (is_zero(sum) || sum < 0) {
+        b[0] = 0;
+        cross3(t, v2.v, v3.v); b[1] = dot3(t, d);
+        cross3(t, v3.v, v1.v); b[2] = dot3(t, d);
+        cross3(t, v1.v, v2.v); b[3] = dot3(t, d);
+        sum = b[1] + b[2] + b[3];
+    }
+    const double inv = 1.0 / sum;
+    const SuppD* sv[3] = {&v1, &v2, &v3};
+    double acc[3] = {b[0] * ((double)g.p1[0] + (double)g.p2[0]), b[0] * ((double)g.p1[1] + (double)g.p2[1]), b[0] * ((double)g.p1[2] + (double)g.p2[2])};
+    for (int q = 0; q < 3; q++) {
+        const int i = sv[q]->i1, j = sv[q]->i2;
+        KS_UNROLL
+        for (int k = 0; k < 3; k++) {
+            const double w1 = (double)g.R1[3 * k] * (double)g.V1[4 * i] + (double)g.R1[3 * k + 1] * (double)g.V1[4 * i + 1] + (double)g.R1[3 * k + 2] * (double)g.V1[4 * i + 2] + (double)g.p1[k];
+            const double w2 = (double)g.R2[3 * k] * (double)g.V2[4 * j] + (double)g.R2[3 * k + 1] * (double)g.V2[4 * j + 1] + (double)g.R2[3 * k + 2] * (double)g.V2[4 * j + 2] + (double)g.p2[k];
+            acc[k] += b[q + 1] * (w1 + w2);
+        }
+    }
+    KS_UNROLL
+    for (int k = 0; k < 3; k++) pos[k] = (T)(0.5 * acc[k] * inv);
+    return true;
+}
+
+// ---- The penetration query of the fp32 product (round 6): libccd's cold path, decision for decision, as ONE loop around ONE support call.
+// mpr_penetration above has five inlined support sites (v1, v2, the discovery loop, the "origin inside" loop, the refinement loop); the lanes of a
+// wave that run a query are in different loops after the first two supports, and the wave executes every site for as many turns as ITS slowest
+// lane needs there.  A support pair - two hill climbs, chains of dependent LDS reads - is ~6 k cycles of a wave that has nothing else to issue, a
+// cold query is ~10 of them.  Here every lane, whatever phase its query is in, takes its next support in the same instruction stream: the wave runs
+// max(supports of a lane) turns instead of the sum over the sites of the per-site maxima.  The phases' own arithmetic (cross products, sign tests)
+// is short and predicated.  All of it on fp64 Minkowski points formed from vertex ids (SuppD): same decisions as the fp64 oracle wherever both
+// stand on the same portal (tests/studies/divergence_table.py: 162 of 168 grasp-and-lift envs within 1e-4 after 200 substeps; fp32 points: 146).
+enum { MPR_S_V1 = 0, MPR_S_V2 = 1, MPR_S_V3 = 2, MPR_S_INSIDE = 3, MPR_S_REFINE = 4 };
+template <typename T, typename S>
+KS_FN_SM bool mpr_penetration_sm(PairGeo<T>& g_io, T tol_, int max_iter, T* depth_o, T* dir_o, T* pos_o, S scr, int path_scr, int n_old, int* n_new_o) {
+    // (an out-of-line function: the caller's pair record and result slots are private MEMORY from here - worked on in registers, written once)
+    PairGeo<T> g = g_io;
+    T depth_[1] = {0}, dir[3] = {0, 0, 0}, pos[3] = {0, 0, 0};
+    T* depth = depth_;
+    int k = 0, n_ok = MPR_PATH;         // supports so far; entries of the new path that are valid
+    struct Out {
+        PairGeo<T>& g_io; const PairGeo<T>& g; T* depth_o; T* dir_o; T* pos_o; const T* depth; const T* dir; const T* pos; int* n_new_o; const int& k; const int& n_ok;
+        KS_HD ~Out() {
+            g_io.hint1 = g.hint1; g_io.hint2 = g.hint2; *depth_o = *depth; dir_o[0] = dir[0]; dir_o[1] = dir[1]; dir_o[2] = dir[2]; pos_o[0] = pos[0]; pos_o[1] = pos[1]; pos_o[2] = pos[2];
+            *n_new_o = k < n_ok ? k : n_ok;
+        }
+    } out_{g_io, g, depth_o, dir_o, pos_o, depth, dir, pos, n_new_o, k, n_ok};
+    SuppD v0, v1, v2, v3, v4;
+    double d[3], va[3], vb[3];
+    const double tol = (double)tol_;
+    KS_UNROLL
+    for (int k = 0; k < 3; k++) v0.v[k] = (double)g.p1[k] - (double)g.p2[k];
+    if (vec_is_zero(v0.v)) v0.v[0] += 1e-5;
+    v0.i1 = 0; v0.i2 = 0;
+    v1 = v0; v2 = v0; v3 = v0;
+    KS_UNROLL
+    for (int k = 0; k < 3; k++) d[k] = -v0.v[k];
+    normalize3(d);
+    int state = MPR_S_V1, it = 0;
+    for (;;) {
+        if (state >= MPR_S_INSIDE) {
+            // the portal's normal; "origin inside the portal" ends when the portal faces the origin - the refinement then starts on the same normal
+            portal_dir_d(v1, v2, v3, d);
+            if (state == MPR_S_INSIDE) {
+                if (it > 100) return false;
+                const double dt = dot3(d, v1.v);
+                if (is_zero(dt) || dt > 0) { state = MPR_S_REFINE; it = 0; }
+            }
+        } else if (state == MPR_S_V3 && it > 100) return false;
+        // the climbs of support k start at the vertices support k of the previous substep's query ended on
+        g.use_tab = true;
+        if (k < n_old) {
+            const int e = (int)scr(path_scr + k), h1 = e & 1023, h2 = e >> 10;
+            g.hint1 = h1 < g.n1 ? h1 : 0; g.hint2 = h2 < g.n2 ? h2 : 0; g.use_tab = false;
+        }
+        support_f64(g, d, v4);                                  // THE support site
+        if (k < MPR_PATH) {
+            if ((v4.i1 | v4.i2) < 1024) scr(path_scr + MPR_PATH + k) = T(v4.i1 | (v4.i2 << 10));
+            else n_ok = k < n_ok ? k : n_ok;                    // (a hull of more than 1024 vertices, multi-geom build: the path ends here)
+        }
+        k++;
+        const double dv = dot3(v4.v, d);
+        if (state == MPR_S_V1) {
+            v1 = v4;
+            if (is_zero(dv) || dv < 0) return false;
+            cross3(d, v0.v, v1.v);
+            if (vec_is_zero(d)) {
+                if (vec_is_zero(v1.v)) return false;
+                const double nn = std::sqrt(dot3(v1.v, v1.v));
+                *depth = (T)nn;
+                KS_UNROLL
+                for (int k = 0; k < 3; k++) dir[k] = (T)(v1.v[k] / nn);
+                T a[3], b[3];
+                hull_point(g.R1, g.p1, g.V1, v1.i1, a); hull_point(g.R2, g.p2, g.V2, v1.i2, b);
+                KS_UNROLL
+                for (int k = 0; k < 3; k++) pos[k] = T(0.5) * (a[k] + b[k]);
+                return true;
+            }
+            normalize3(d);
+            state = MPR_S_V2;
+        } else if (state == MPR_S_V2) {
+            v2 = v4;
+            if (is_zero(dv) || dv < 0) return false;
+            sub3(va, v1.v, v0.v);
+            sub3(vb, v2.v, v0.v);
+            cross3(d, va, vb);
+            normalize3(d);
+            if (dot3(d, v0.v) > 0) {
+                const SuppD t = v1; v1 = v2; v2 = t;
+                d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2];
+            }
+            state = MPR_S_V3; it = 0;
+        } else if (state == MPR_S_V3) {
+            v3 = v4;
+            if (is_zero(dv) || dv < 0) return false;
+            bool cont = false;
+            cross3(va, v1.v, v3.v);
+            double dt = dot3(va, v0.v);
+            if (dt < 0 && !is_zero(dt)) { v2 = v3; cont = true; }
+            if (!cont) {
+                cross3(va, v3.v, v2.v);
+                dt = dot3(va, v0.v);
+                if (dt < 0 && !is_zero(dt)) { v1 = v3; cont = true; }
+            }
+            if (cont) {
+                sub3(va, v1.v, v0.v);
+                sub3(vb, v2.v, v0.v);
+                cross3(d, va, vb);
+                normalize3(d);
+                it++;
+            } else { state = MPR_S_INSIDE; it = 0; }
+        } else if (state == MPR_S_INSIDE) {
+            if (!(is_zero(dv) || dv > 0)) return false;
+            if (portal_reach_tol_d(v1, v2, v3, v4, d, tol)) return false;
+            expand_portal_d(v0, v1, v2, v3, v4);
+            it++;
+        } else {
+            if (portal_reach_tol_d(v1, v2, v3, v4, d, tol) || it > max_iter) return mpr_readoff_f64(g, v0, v1, v2, v3, depth, dir, pos);
+            expand_portal_d(v0, v1, v2, v3, v4);
+            it++;
+        }
+    }
+}
+
 template <typename T>
 KS_NARROW bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir, T* pos, PairWarm* ws = nullptr) {
     Supp<T> v0, v1, v2, v3, v4;
@@ -931,7 +1227,7 @@ KS_NARROW bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* 
     // The fp32 product starts from the previous substep's portal when that still is one (KS_MPR_WARM, default on): fp32 rounding
     // of the supports' near-ties changes the path anyway, and a warm query is 1 - 2 support pairs instead of 6 - 10.
 #ifndef KS_MPR_WARM
-#define KS_MPR_WARM 1
+#define KS_MPR_WARM 0           // (round 6: off - see the path memory above; 1 restores rounds 3-5's warm start for A/B)
 #endif
     constexpr bool mpr_warm = (KS_MPR_WARM != 0) && sizeof(T) == 4;
     if (mpr_warm && ws != nullptr) { unpack3(ws->w[2], ma, mn); unpack3(ws->w[3], mb, unused); }
@@ -1657,9 +1953,18 @@ KS_HD bool hull_pair_may_touch(S scr, KS_LDS const PairRec<T>* prp) {
 // narrow phase of a hull pair that passed hull_pair_may_touch
 template <typename T, typename S>
 KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S scr, KS_LDS const PairRec<T>* prp, int slot, int packed_in, int& h1_out,
-                            int& h2_out, PairWarm* ws, float* prof = nullptr) {
+                            int& h2_out, PairWarm* ws, float* prof = nullptr, T* path = nullptr, int path_scr = 0) {
     KS_LDS const PairRec<T>& pr = *prp;
     PairGeo<T> pg;
+    // the pair's remembered penetration path (see MPR_PATH): requested now - only when the pair's previous query got as far as MPR -, needed
+    // behind the distance query
+    constexpr bool use_sm = (KS_MPR_SM != 0) && sizeof(T) == 4, use_path = use_sm && (KS_MPR_PATH != 0);
+    T pw[MPR_PATH + 1];
+    const bool path_in = use_path && path != nullptr && ws != nullptr && ws->w[2] != 0u;      // (word 2 of the pair memory: the last query of this pair ran MPR)
+    if constexpr (use_path) {
+        KS_UNROLL
+        for (int k = 0; k <= MPR_PATH; k++) pw[k] = path_in ? path[k] : T(0);
+    }
 #ifdef KS_STAMP_HULL
     const long long th0 = clock64();
 #endif
@@ -1697,6 +2002,7 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
     // hints are only meaningful when they index the pair's own hulls (always, unless a hull has > 1024 vertices)
     pg.hint1 = h1_out < pg.n1 ? h1_out : 0;
     pg.hint2 = h2_out < pg.n2 ? h2_out : 0;
+    pg.use_tab = true;
     pg.half_margin = T(0);
 #ifdef KS_STAMP_HULL
     pg.cnt_support = 0; pg.cnt_steps = 0; pg.t_sup = 0; pg.t_clo = 0;
@@ -1716,21 +2022,50 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
     // (KS_MPR_FIRST=2: EVERY margin-0 pair, penetrating before or not - no distance query at all for the object pairs.  Measured, A/B on one
     // box: training 2.71 M against 3.03 M env-steps/s, sim-only 3.94 against 4.31 M: a separated pair costs the distance query one iteration
     // (its cached separating simplex), the penetration query a cold portal discovery.)
-    const bool mpr_first = (KS_MPR_FIRST == 2) ? (sizeof(T) == 4 && !(margin > T(0)))
+    // Round 6 (KS_MPR_FIRST = 3, with the state-machine query): a margin-0 pair whose previous query got as far as MPR - pair memory word 2 - skips the distance
+    // query.  For such a pair MuJoCo itself asks libccd for the penetration only; the distance query in front of it is this repo's shortcut for SEPARATED pairs
+    // (a warm confirmation of the cached separating simplex), and for a penetrating pair it is the expensive case (it must enclose the origin).
+    const bool mpr_first = (KS_MPR_FIRST == 3) ? (use_sm && ws != nullptr && ws->w[2] != 0u && !(margin > T(0)))
+                         : (KS_MPR_FIRST == 2) ? (sizeof(T) == 4 && !(margin > T(0)))
                                                : ((KS_MPR_FIRST != 0) && (KS_MPR_WARM != 0) && sizeof(T) == 4 && ws != nullptr && (ws->w[2] >> 30) == 3u && !(margin > T(0)));
     int r = 2;
     if (!mpr_first) r = gjk_distance(pg, margin, &dist, dir, pos, ws);
 #ifdef KS_STAMP_HULL
-    if (prof) { prof[24] += 1.f; prof[25] += (float)pg.cnt_support; prof[26] += (float)(th1 - th0); prof[27] += (float)(clock64() - th1); prof[28] += (float)pg.t_sup; prof[29] += (float)pg.t_clo; }
+    if (prof) { prof[24] += 1.f; prof[25] += (float)pg.cnt_support; prof[27] += (float)(clock64() - th1); prof[28] += (float)pg.t_sup; prof[29] += (float)pg.t_clo; }
 #endif
     h1_out = pg.hint1 <= PC_HINT_MAX ? pg.hint1 : 0; h2_out = pg.hint2 <= PC_HINT_MAX ? pg.hint2 : 0;   // (a vertex id beyond the 10-bit field is not remembered: start 0, not a masked id)
     const int pi = (flags >> 12) & PAIR_INDEX_MASK;
     if (obj_first && (r == 1 || r == 3)) { dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
+    if (use_path && r < 2 && path != nullptr && ws != nullptr) ws->w[2] = 0u;
     if (r == 1) { stage_contact(scr, slot, body1, body2, pi, mu, dist, pos, dir); return 1; }
     if (r >= 2) {
         // 2: overlap (or undecided beyond the margin), 3: a margin-zone result that is not a certified separation
         T mdir[3], mpos[3];
-        const bool hit = mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, mdir, mpos, ws);
+        bool hit;
+#ifdef KS_STAMP_HULL
+        const long long tm0 = clock64();
+        const int sup0 = pg.cnt_support;
+#endif
+        if constexpr (use_sm) {
+            int n_old = path_in ? (int)pw[MPR_PATH] : 0, n_new = 0;
+            n_old = n_old < 0 ? 0 : (n_old > MPR_PATH ? MPR_PATH : n_old);
+            if (path_in) {
+                KS_UNROLL
+                for (int k = 0; k < MPR_PATH; k++) scr(path_scr + k) = pw[k];
+            }
+            hit = mpr_penetration_sm(pg, m.mpr_tol, m.mpr_iters, &depth, mdir, mpos, scr, path_scr, n_old, &n_new);
+            if (use_path && path != nullptr) {
+                KS_UNROLL
+                for (int k = 0; k < MPR_PATH; k++) path[k] = scr(path_scr + MPR_PATH + k);
+                path[MPR_PATH] = T(n_new);
+                if (ws != nullptr) ws->w[2] = 1u;
+            }
+        } else {
+            hit = mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, mdir, mpos, ws);
+        }
+#ifdef KS_STAMP_HULL
+        if (prof) { prof[7] += (float)(clock64() - tm0); prof[22] += (float)(pg.cnt_support - sup0) * 0.5f; prof[26] += 1.f; }     // MPR cycles, support pairs, queries (diagnostic)
+#endif
         h1_out = pg.hint1 <= PC_HINT_MAX ? pg.hint1 : 0; h2_out = pg.hint2 <= PC_HINT_MAX ? pg.hint2 : 0;   // (a vertex id beyond the 10-bit field is not remembered: start 0, not a masked id)
         if (hit) {
             if (obj_first) { mdir[0] = -mdir[0]; mdir[1] = -mdir[1]; mdir[2] = -mdir[2]; }
@@ -1738,6 +2073,7 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
             return 1;
         }
         if (r == 3) { stage_contact(scr, slot, body1, body2, pi, mu, dist, pos, dir); return 1; }
+        if (use_sm && mpr_first && ws != nullptr) ws->w[2] = 0u;        // no longer penetrating: the next query starts with the distance query again
     }
     return 0;
 }
@@ -1751,7 +2087,10 @@ template <typename T, typename S, int SUBS> KS_HD void reset_pair_words(S scr, T
 
 template <typename T, typename S, int SUBS>
 KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> team, int& ncon, int& status, PairWarm* warm = nullptr,
-                     float* prof = nullptr) {
+                     float* prof = nullptr, T* path = nullptr) {
+    // path: this lane's remembered penetration paths, [pairs of the lane][PATH_WORDS] (MPR_PATH; nullptr: plain cold queries)
+    const int path_scr = SCR_CON + team.sub * (2 * MPR_PATH);
+    static_assert(2 * MPR_PATH * (SUBS == 1 ? 1 : SUBS) <= NCON_MAX * CON_STRIDE, "path scratch of the lanes fits the contact records");
     KS_T0
     const int npair = hu.npair, nhull = hu.nhull;
     KS_LDS const PairRec<T>* pairs = hu.pair;
@@ -1802,13 +2141,13 @@ KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Tea
                     if (next_slot + 1 > NSTAGE) status |= ST_CONTACT_OVERFLOW;
                     else {
                         scr(SCR_SLOT + pi) = T(next_slot);
-                        c = collide_hull_hull(m, dirtab, scr, pairs + pi, next_slot, word, h1, h2, warm ? warm + hk : nullptr, prof);
+                        c = collide_hull_hull(m, dirtab, scr, pairs + pi, next_slot, word, h1, h2, warm ? warm + hk : nullptr, prof, path ? path + hk * PATH_WORDS : nullptr, path_scr);
                         next_slot++;
                     }
                 }
             } else {
                 if (pairs[pi].slot + 1 > NSTAGE) status |= ST_CONTACT_OVERFLOW;
-                else if (hull_pair_may_touch(scr, pairs + pi)) c = collide_hull_hull(m, dirtab, scr, pairs + pi, pairs[pi].slot, word, h1, h2, warm ? warm + hk : nullptr, prof);
+                else if (hull_pair_may_touch(scr, pairs + pi)) c = collide_hull_hull(m, dirtab, scr, pairs + pi, pairs[pi].slot, word, h1, h2, warm ? warm + hk : nullptr, prof, path ? path + hk * PATH_WORDS : nullptr, path_scr);
             }
             scr(SCR_PC + pi) = T(pc_pack(c, h1, h2));
         }
@@ -1862,7 +2201,8 @@ KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Tea
                     if (q == r) { pi_r = pi_[q]; word_r = word_[q]; slot_r = slot_[q]; }
             }
             int h1 = 0, h2 = 0;
-            const int c = collide_hull_hull(m, dirtab, scr, pairs + pi_r, DYNAMIC_SLOTS ? slot_r : pairs[pi_r].slot, word_r, h1, h2, warm ? warm + r : nullptr, prof);
+            const int c = collide_hull_hull(m, dirtab, scr, pairs + pi_r, DYNAMIC_SLOTS ? slot_r : pairs[pi_r].slot, word_r, h1, h2, warm ? warm + r : nullptr, prof,
+                                            path ? path + r * PATH_WORDS : nullptr, path_scr);
             scr(SCR_PC + pi_r) = T(pc_pack(c, h1, h2));
             todo &= todo - 1;
         }
@@ -2480,7 +2820,7 @@ KS_FN_SOLVER void constrained_step(const Model<T>& m, T* qpos, T* qvel, T* warm,
         // --- exact line search on phi'(alpha) (piecewise linear, increasing)
         T alpha = 0, lo = 0, hi = -1;
         for (int ls = 0; ls < 30; ls++) {
-#ifdef KS_STAMP
+#if defined(KS_STAMP) && !defined(KS_STAMP_HULL)
             if (prof) prof[22] += 1.f;
 #endif
             T d1, d2, mag;
@@ -2675,7 +3015,7 @@ struct NoHook {
 template <typename T, typename S, int SUBS, typename Hook = NoHook>
 KS_HD void mj_forward_step(const Model<T>& m, const Hulls<T>& hu, T* qpos, T* qvel, T* warm, const T* ctrl, const T* R7, S scr, Team<SUBS> team,
                            int solver_iterations, bool integrate, int& ncon_out, int& status, float* prof = nullptr, PairWarm* gjk_warm = nullptr,
-                           Hook after_kinematics = Hook()) {
+                           Hook after_kinematics = Hook(), T* mpr_path = nullptr) {
     KS_T0
     team.sync();                                   // the previous substep's readers of the body poses are done
     dynamics_rows(m, qpos, qvel, ctrl, R7, scr, team);
@@ -2692,7 +3032,7 @@ KS_HD void mj_forward_step(const Model<T>& m, const Hulls<T>& hu, T* qpos, T* qv
     KS_UNROLL
     for (int i = 0; i < KS_SCRATCH_PROBE; i++) probe_[(i + (status >> 30)) & (KS_SCRATCH_PROBE - 1)] = qvel[i % NV];
 #endif
-    collision(m, hu, scr, team, ncon, status, gjk_warm, prof);
+    collision(m, hu, scr, team, ncon, status, gjk_warm, prof, mpr_path);
 #if defined(KS_SCRATCH_PROBE) && defined(__HIP_DEVICE_COMPILE__)
     {
         T acc_ = T(0);

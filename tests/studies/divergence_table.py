@@ -78,12 +78,15 @@ def classify(con_l, nc_l, cons_o):
 
 
 VARIANTS = {   # host builds of the kernel source with experiment switches (fp32 lane); built once by the parent process into /tmp
-    "r4": ["-DKS_REFINE_F64=0", "-DKS_PLANE_F64=0"],                                  # round 4's fp32 read-offs
-    "r4+planehook": ["-DKS_REFINE_F64=0", "-DKS_PLANE_F64=0", "-DKS_PLANE_HOOK"],     # ... with every plane pair's first vertex from an fp64 evaluation
-    "r4+mink64": ["-DKS_REFINE_F64=0", "-DKS_PLANE_F64=0", "-DKS_MINK_F64=1"],        # ... with the Minkowski points formed in fp64
-    "r5a": ["-DKS_PLANE_F64=0"],                                  # depth / direction of MPR's final portal in fp64 (KS_REFINE_F64=1), plane pairs fp32
-    "r5a+plane1": ["-DKS_PLANE_F64=1"],                           # ... + the staged plane contacts' depths in fp64
-    "r5": [],                                                     # the product: ... + the plane pairs' vertex scans in fp64 (selection, margin tests; KS_PLANE_F64=2)
+    "r4": ["-DKS_MPR_SM=0", "-DKS_REFINE_F64=0", "-DKS_PLANE_F64=0"],                                  # round 4's fp32 read-offs
+    "r4+planehook": ["-DKS_MPR_SM=0", "-DKS_REFINE_F64=0", "-DKS_PLANE_F64=0", "-DKS_PLANE_HOOK"],     # ... with every plane pair's first vertex from an fp64 evaluation
+    "r4+mink64": ["-DKS_MPR_SM=0", "-DKS_REFINE_F64=0", "-DKS_PLANE_F64=0", "-DKS_MINK_F64=1"],        # ... with the Minkowski points formed in fp64
+    "r5a": ["-DKS_MPR_SM=0", "-DKS_PLANE_F64=0"],                                  # depth / direction of MPR's final portal in fp64 (KS_REFINE_F64=1), plane pairs fp32
+    "r5a+plane1": ["-DKS_MPR_SM=0", "-DKS_PLANE_F64=1"],                           # ... + the staged plane contacts' depths in fp64
+    "r5": ["-DKS_MPR_SM=0"],                                      # round 5's product arithmetic, cold queries (the lane's; the GPU's queries were warm: "r5warm/warm")
+    "r5warm": ["-DKS_MPR_SM=0", "-DKS_MPR_WARM=1"],               # ... as the GPU ran it through ks_step (run as "r5warm/warm": the lane keeps its pair memory)
+    "r6": [],
+    "r6first": ["-DKS_MPR_FIRST=3"],                              # ... and a pair that penetrated in the previous substep skips the distance query                                                     # round 6, the product: the penetration query cold, on fp64 Minkowski points, one support site
 }
 
 
@@ -116,8 +119,9 @@ def run_env(args):
     shape, pose, q0, hq, script, mode, eps, seed = args
     from oracle import ko_py as ko
     from tests import native_build
-    if mode.startswith("fp32:"):
-        native_build.lanecheck_lib = _variant_lib(mode[5:])
+    warm_queries = mode.startswith("fp32w:")         # the lane keeps its pair memory from substep to substep, as the GPU's lanes do
+    if mode.startswith("fp32:") or warm_queries:
+        native_build.lanecheck_lib = _variant_lib(mode.split(":", 1)[1])
         mode = "fp32"
     blob = scenarios.model_blob(shape)
     m = ko.OracleModel(blob)
@@ -127,6 +131,9 @@ def run_env(args):
     lane = native_build.Lane(blob, {"fp32": 32, "fp64": 64}.get(mode, 6432))           # 6432: ks_lanecheck.cpp substep_mixed
     if mode.startswith("mixed"):
         lane.L.lc_set_mixed_variant(int(mode[5:] or 0))
+    if warm_queries:
+        lane.L.lc_set_warm.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_int]
+        lane.L.lc_set_warm(lane.h, 1)
     rng = np.random.default_rng(seed)
     st = (ref.view("qpos").copy(), ref.view("qvel").copy(), ref.view("qacc_warmstart").copy())
     first_event, rel_end, first_bad, base = None, 0.0, -1, []
@@ -163,15 +170,17 @@ def run_env(args):
 
 def run_variant(name):
     jobs = []
+    warm = name.endswith("/warm")
+    name = name[:-5] if warm else name
     for sh in scenarios.SHAPES:
         for i, (o, q, hq, script) in enumerate(starts(sh)):
-            jobs.append((sh, o, q, hq, script, f"fp32:{name}", 0.0, i))
+            jobs.append((sh, o, q, hq, script, f"{'fp32w' if warm else 'fp32'}:{name}", 0.0, i))
     with ProcessPoolExecutor(8) as ex:
         return list(ex.map(run_env, jobs, chunksize=4))
 
 
 def variants_only(names):
-    build_variants(names)
+    build_variants([n[:-5] if n.endswith("/warm") else n for n in names])
     for name in names:
         rv = run_variant(name)
         per = {}

@@ -188,7 +188,7 @@ def test_stepping_kernel_leaves_registers_for_the_learner(tmp_path):
     free: one of their waves beside the stepping kernel's one wave per SIMD, 512 registers per lane in all (allocated in
     blocks of 8).  A stepping kernel that does not leave room silently serialises the two (measured: 1.15 -> 1.73 ms per
     env-step when a change took it to 418), so the footprint is a contract."""
-    step = {k: v for k, v in _register_footprints("ks_api.hip", tmp_path).items() if "k_env_stepIf" in k}
+    step = {k: v for k, v in _register_footprints("ks_api.hip", tmp_path).items() if "k_env_step_f32" in k}      # (the fp32 product's kernel: its budget is set in the source, KS_STEP_NUM_VGPR)
     assert len(step) == 1, step
     (v, a), = step.values()
     up8 = lambda x: (x + 7) // 8 * 8

@@ -205,9 +205,10 @@ def test_batch_config2_first_steps(cube):
 # (profiles/r05_long_horizon.txt: 146 of 168 = 87 %; round 4: 99).  What round 5 changed, in order: MuJoCo's operand order in the convex queries (106);
 # depth / direction of MPR's final portal read off in fp64 (KS_REFINE_F64: 130); the hulls' geom-frame vertices float32 in the MODEL as in
 # mjModel.mesh_vert - the oracle and the fp32 product now hold the same tables - with the plane pairs' vertex distances formed in fp64
-# (KS_PLANE_F64 = 2: 146).  The test asserts two envs of slack per shape and three in total
-LONG_HORIZON_MEASURED = {"CubeS": 10, "CubeB": 12, "CylinderS": 10, "CylinderB": 10, "Cube45S": 10, "Cube45B": 11, "Cone1S": 10, "Cone1B": 8, "Cone2S": 11,
-                         "Cone2B": 12, "Vase1S": 11, "Vase1B": 10, "Vase2S": 10, "Vase2B": 11}
+# (KS_PLANE_F64 = 2: 146).  Round 6: the penetration query on fp64 Minkowski points (ks_core.h: mpr_penetration_sm): 157 through ks_substep (this test),
+# 162 through ks_step (the next one).  One env of slack per shape and two in total (VERDICT r5 next #1a)
+LONG_HORIZON_MEASURED = {"CubeS": 12, "CubeB": 11, "CylinderS": 12, "CylinderB": 10, "Cube45S": 12, "Cube45B": 12, "Cone1S": 10, "Cone1B": 11, "Cone2S": 11,
+                         "Cone2B": 10, "Vase1S": 11, "Vase1B": 12, "Vase2S": 12, "Vase2B": 11}          # round 6: 157 of 168 (round 5: 146, round 4: 99)
 
 
 def test_batched_long_horizon_parity_200_substeps():
@@ -237,9 +238,36 @@ def test_batched_long_horizon_parity_200_substeps():
         assert np.isfinite(r["rel"]).all() and (r["status"] & 2 == 0).all()
         within[sh] = int((r["rel"][199] <= 1e-4).sum())
     print("envs of 12 within 1e-4 at substep 200:", within, "total", sum(within.values()), "of", 12 * len(within))
-    short = {sh: (k, LONG_HORIZON_MEASURED[sh]) for sh, k in within.items() if k < LONG_HORIZON_MEASURED[sh] - 2}
+    short = {sh: (k, LONG_HORIZON_MEASURED[sh]) for sh, k in within.items() if k < LONG_HORIZON_MEASURED[sh] - 1}       # (per-shape floors at measured - 1)
     assert not short, short
-    assert sum(within.values()) >= sum(LONG_HORIZON_MEASURED.values()) - 3 and np.median(shapes["CubeS"]["rel"][199]) < 1e-4
+    assert sum(within.values()) >= sum(LONG_HORIZON_MEASURED.values()) - 2 and np.median(shapes["CubeS"]["rel"][199]) < 1e-5
+
+
+# ... and THROUGH ks_step, the product's own stepping path (15 substeps per call, the lanes' pair memory carried from substep to substep and from call
+# to call): measured at the end of round 6 after env-step 14 (210 substeps).  Until round 6 this path was not covered - the test above drives
+# ks_substep, whose queries start cold - and its penetration queries started warm from the previous portal: 76 of 168 (tests/studies/long_horizon_envstep.py).
+ENVSTEP_LONG_HORIZON_MEASURED = {"CubeS": 12, "CubeB": 12, "CylinderS": 12, "CylinderB": 11, "Cube45S": 11, "Cube45B": 12, "Cone1S": 10, "Cone1B": 12,
+                                 "Cone2S": 11, "Cone2B": 11, "Vase1S": 12, "Vase1B": 12, "Vase2S": 12, "Vase2B": 12}
+
+
+def test_long_horizon_parity_through_the_env_step_path_210_substeps():
+    """The same 168 grasp-and-lift envs and the config-2 random-action batch, stepped with ks_step (what KinovaGripperVecEnv.step and - same device
+    code - the free-running rollout call) against the oracle's env_step: 14 env-steps = 210 substeps, compared after every env-step.  Per shape
+    at most one env below the measured count, two in total."""
+    from tests.studies import long_horizon_envstep as le
+    r = le.config2_batch(256, 14)
+    assert (r["status"] == 0).all()
+    never = float(np.mean((r["rel"] <= 1e-4).all(0)))
+    print(f"config 2 x 256 through ks_step: never beyond 1e-4 in 210 substeps {never:.3f}, median at the end {np.median(r['rel'][13]):.1e}")
+    assert never >= 0.98 and np.median(r["rel"][13]) < 3e-7                      # (measured 0.996 / 9.0e-8)
+    res = le.shapes_batches(4, 14)
+    within = {sh: int((x["rel"][13] <= 1e-4).sum()) for sh, x in res.items()}
+    print("through ks_step, envs of 12 within 1e-4 after 210 substeps:", within, "total", sum(within.values()))
+    for sh, x in res.items():
+        assert np.isfinite(x["rel"]).all() and (x["status"] & 2 == 0).all()
+    short = {sh: (k, ENVSTEP_LONG_HORIZON_MEASURED[sh]) for sh, k in within.items() if k < ENVSTEP_LONG_HORIZON_MEASURED[sh] - 1}
+    assert not short, short
+    assert sum(within.values()) >= sum(ENVSTEP_LONG_HORIZON_MEASURED.values()) - 2
 
 
 def test_fp64_kernels_track_the_oracle_free_running_for_200_substeps():

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU box, -DKS_STAMP -DKS_STAMP_HULL build via KS_LIB): cycles of the hull pairs' narrow phase per env-step in the bench's policy regime:
+the whole phase, the distance queries, the penetration queries and their support pairs."""
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+from pathlib import Path
+from kinovagrasping_amd import scenarios
+from kinovagrasping_amd.sim import KinovaSim
+from kinovagrasping_amd.ddpgfd import DDPGfD
+from kinovagrasping_amd.rollout import RolloutEngine
+from kinovagrasping_amd.replay import DeviceEpisodeReplay
+from kinovagrasping_amd.pipeline import GraphedTrainer
+n = 4096
+q0, hq = scenarios.config2_states(n)
+torch.manual_seed(2)
+sim = KinovaSim(n, "CubeS", auto_reset=True, horizon=30, contact_tap=True)
+obs0 = sim.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+policy = DDPGfD(82, 4, 0.8, 5, batch_size=64, hidden=(256, 256), device=torch.device("cuda", 0), capturable=True)
+policy.load(str(Path("kinovagrasping_amd/assets/bench_policy/ddpg_256_256")), sync_targets=True)
+replay = DeviceEpisodeReplay(n, capacity=4 * n, horizon=30, device=torch.device("cuda", 0))
+eng = RolloutEngine(sim, policy, replay, expl_noise=0.1)
+eng.start(obs0)
+trainer = GraphedTrainer(sim, policy, replay, eng, batch_episodes=64, overlap=False)
+trainer.capture()
+for t in range(300):
+    trainer.step()
+acc = []
+for t in range(60):
+    trainer.step()
+    st = sim.get_state(contacts=True)
+    torch.cuda.synchronize()
+    prof = st["contact"].reshape(-1, n)[:480].cpu().numpy().reshape(16, 30, n)
+    acc.append([prof[0, 6].mean(), prof[0, 9].mean(), prof[:, 27].max(0).mean(), prof[:, 7].max(0).mean(), prof[:, 7].sum(0).mean(), prof[:, 22].sum(0).mean(), prof[:, 28].max(0).mean(),
+                (prof[:, 7] > 0).sum(0).mean()])
+a = np.mean(acc, 0)
+print(f"per env-step (k cycles): total {a[0]/1e3:.0f}, hull-pair phase {a[1]/1e3:.0f}; busiest lane of an env: distance queries {a[2]/1e3:.0f} (supports {a[6]/1e3:.0f}), penetration queries {a[3]/1e3:.0f}; "
+      f"penetration queries summed over the env's lanes {a[4]/1e3:.0f} with {a[5]:.1f} support pairs -> {a[4]/max(a[5],1e-9):.0f} cycles per support pair; lanes with a penetration query {a[7]:.2f}")
