@@ -48,7 +48,6 @@ template <typename T> struct Buffers {
     unsigned *pairmem;            // [N][SUBS][2 * WARM_WORDS] pair memory carried from launch to launch (fp32 / LDS contexts):
                                   // what every lane of an env's team remembers of its (<= 2) hull pairs' last queries
                                   // (ks_core.h: PairWarm), env-major: a team moves its 512 bytes as 16 x 32-byte pieces
-    T* pathmem;                   // [N][SUBS][HPL][PATH_WORDS] the hull pairs' remembered penetration paths (ks_core.h: MPR_PATH; fp32 / LDS contexts), env-major like pairmem
     int32_t *ncon, *status, *step_count;
     uint8_t *flag;                // envs to (re)initialise
     // mixed-object batches (BASELINE config 5): the object model of every env, and the stepping kernel's work list - its
@@ -601,8 +600,7 @@ __device__ __forceinline__ void env_step_body(const Model<T>* __restrict__ model
             KS_UNROLL
             for (int j = 0; j < WARM_WORDS; j++) gw[q].w[j] = pair_memory ? pm[q * WARM_WORDS + j] : 0u;
         }
-        lane_env_step(m, hu, *(LaneState<T>*)stp, hq, act, scr, team, snap, frame_skip, iters, ncon, status, prof, stp + NQ + 2 * NV, gw, slot_arrived,
-                      pair_memory ? b.pathmem + ((long)env * SUBS + team.sub) * (WPL * PATH_WORDS) : (T*)nullptr);
+        lane_env_step(m, hu, *(LaneState<T>*)stp, hq, act, scr, team, snap, frame_skip, iters, ncon, status, prof, stp + NQ + 2 * NV, gw, slot_arrived);
         if (pair_memory) {
             KS_UNROLL
             for (int q = 0; q < WPL; q++) {
@@ -884,7 +882,7 @@ __device__ __forceinline__ void rollout_iter(const Model<float>& m, const Hulls<
             for (int j = 0; j < WARM_WORDS; j++) gw[q].w[j] = pair_memory ? pm[q * WARM_WORDS + j] : 0u;
         }
         lane_env_step(m, hu, *(LaneState<T>*)stp, hq, act, scr, team, snap, frame_skip, iters, ncon, status, (float*)nullptr, stp + NQ + 2 * NV, gw,
-                      []() {}, pair_memory ? b.pathmem + ((long)env * SUBS + team.sub) * (WPL * PATH_WORDS) : (T*)nullptr);
+                      []() {});
         if (pair_memory) {
             KS_UNROLL
             for (int q = 0; q < WPL; q++) {
@@ -1007,7 +1005,7 @@ __device__ __forceinline__ void rollout_iter_wave(const Model<float>& m, const H
             for (int j = 0; j < WARM_WORDS; j++) gw[q].w[j] = pair_memory ? pm[q * WARM_WORDS + j] : 0u;
         }
         lane_env_step(m, hu, *(LaneState<T>*)stp, hq, act, scr, team, snap, frame_skip, iters, ncon, status, (float*)nullptr, stp + NQ + 2 * NV, gw,
-                      []() {}, pair_memory ? b.pathmem + ((long)env * SUBS + team.sub) * (WPL * PATH_WORDS) : (T*)nullptr);
+                      []() {});
         if (pair_memory) {
             KS_UNROLL
             for (int q = 0; q < WPL; q++) {
@@ -1661,7 +1659,6 @@ template <typename T> struct Ctx : CtxBase {
         if (!USE_LDS && (r = alloc(&b.gscratch, (size_t)SCR_TOTAL * N))) return r;
         if ((r = alloc(&b.envp, (size_t)2 * N))) return r;
         if (USE_LDS && (r = alloc(&b.pairmem, (size_t)SUBS * ((NPAIR_MAX + SUBS - 1) / SUBS) * WARM_WORDS * N))) return r;
-        if (USE_LDS && (r = alloc(&b.pathmem, (size_t)SUBS * ((NPAIR_MAX + SUBS - 1) / SUBS) * PATH_WORDS * N))) return r;
         if ((r = alloc(&b.ncon, N))) return r;
         if ((r = alloc(&b.status, N))) return r;
         if ((r = alloc(&b.step_count, N))) return r;

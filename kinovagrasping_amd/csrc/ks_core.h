@@ -603,7 +603,6 @@ template <typename T> struct PairGeo {
     const unsigned short* dir1; const unsigned short* dir2;   // cube-map support start tables of the two hulls (global memory)
     int n1, n2;
     int hint1, hint2;          // last support vertex of each shape: start of the next hill climb
-    bool use_tab;              // consult the cube-map start tables (global memory); false: the hints are a remembered path's own vertices (mpr_penetration_sm)
     T half_margin;
 #ifdef KS_STAMP_HULL
     int cnt_support, cnt_steps;
@@ -745,7 +744,7 @@ template <typename T> KS_HD void pair_support(PairGeo<T>& g, const T* dir, T hm,
     // and pipeline through the LDS, a climb is a chain of dependent rounds plus a table read from L2; same vertex.  Measured slower: a warm
     // climb is one hop, and a wave whose lanes mix small and large hulls runs both code paths.
     const bool scan1 = g.n1 <= SCAN_MAX, scan2 = g.n2 <= SCAN_MAX;
-    const int tab1 = scan1 ? 0 : (g.use_tab ? (int)g.dir1[support_cell(ld1)] : g.hint1), tab2 = scan2 ? 0 : (g.use_tab ? (int)g.dir2[support_cell(ld2)] : g.hint2);
+    const int tab1 = scan1 ? 0 : g.dir1[support_cell(ld1)], tab2 = scan2 ? 0 : g.dir2[support_cell(ld2)];
     if (scan1) hull_scan(g.R1, g.p1, g.V1, g.n1, g.hint1, ld1, dir, hm, out1);
     else hull_climb(g.R1, g.p1, g.V1, g.off1, g.adj1, tab1, g.hint1, ld1, dir, hm, out1);
     if (scan2) hull_scan(g.R2, g.p2, g.V2, g.n2, g.hint2, ld2, nd, hm, out2);
@@ -782,7 +781,7 @@ template <typename T> KS_HD void minkowski_point_ids(const PairGeo<T>& g, int i,
 
 template <typename T> KS_HD void mpr_support(PairGeo<T>& g, const T* dir, Supp<T>& o) {
 #ifdef KS_COUNT_CLIMB
-    ks_mpr_supports++; ks_mpr_hinted += g.use_tab ? 0 : 1;
+    ks_mpr_supports++;
 #endif
 #ifdef KS_STAMP_HULL
     const int h1_ = g.hint1, h2_ = g.hint2;
@@ -933,35 +932,21 @@ template <typename T> KS_HD void hull_point(const T* R, const T* p, KS_TAB const
 //     210 substeps; libccd's cold path - what MuJoCo runs, what the oracle follows and the recorded trajectory pins - leaves 141.
 // (2) On fp64 Minkowski points.  Every point is formed from its two vertex IDS - fp32 hull tables and poses, fp64 arithmetic, as round 5's
 //     read-off of the final portal - so portal normals, the supports along them, the stop test and the expansion's sign tests are decided as the
-//     fp64 oracle decides them wherever both stand on the same portal: 160 of 168 on the GPU, 162 on the host lane
+//     fp64 oracle decides them wherever both stand on the same portal: 162 of 168 through ks_step on the GPU and on the host lane
 //     (tests/studies/divergence_table.py: variant r6).  State per portal corner: 3 doubles + 2 ids (SuppD).
 // (3) ONE loop around ONE support site.  The template has five inlined support sites (v1, v2, discovery loop, "origin inside" loop, refinement
 //     loop); the lanes of a wave that run a query are in different loops after the first two supports and the wave executes every site for as
 //     many turns as ITS slowest lane needs there.  Here every lane, whatever phase its query is in, takes its next support in the same
 //     instruction stream; the phases' own arithmetic (cross products, sign tests) is short and predicated.
-// (4) With a PATH memory.  A cold query is ~10 support pairs against the warm start's 1 - 2; each is two hill climbs - chains of dependent LDS
-//     reads.  The query remembers the vertex pair each of its first MPR_PATH supports returned; the next substep's support k starts its climbs AT
-//     those vertices (nearly always still the maximisers: one confirming round per hull, no cube-map read from L2).  A support vertex does not
-//     depend on where the climb starts (a local maximiser of a linear function on a convex polytope is the global one): the result is the cold
-//     query's.  The path lives in global memory (T-typed words: the ids as exact small numbers), is staged in the lane's share of the contact
-//     records - dead during the narrow phase - while a query runs, and is written back behind it.
-constexpr int MPR_PATH = 12, PATH_WORDS = 16;       // supports remembered; words per pair in global memory ([0 .. MPR_PATH) ids, [MPR_PATH] their count)
+// Measured and not kept (round 6): a PATH memory - the vertex pair each support of the previous substep's query returned, as the start of this
+// substep's climbs (one confirming round per hull, no cube-map read): +1 % in training, -3 % sim-only, 8 MB of state; skipping the distance query
+// for a pair that penetrated in the previous substep (KS_MPR_FIRST=3): nothing.  The cube map already puts a climb within a hop of its answer.
 #ifndef KS_MPR_SM
 #define KS_MPR_SM 1             // 0: the fp32 product runs the template above (fp32 points, cold unless KS_MPR_WARM=1): A/B and the divergence study
 #endif
-#ifndef KS_MPR_PATH
-#define KS_MPR_PATH 1           // 0: no path memory (every climb starts from the last support vertex and the cube map)
-#endif
-#ifdef KS_SM_INLINE
-#define KS_FN_SM KS_HD
-#else
-#define KS_FN_SM KS_FN
-#endif
-#ifdef KS_SUP_OUTLINE
-#define KS_FN_SUP KS_FN
-#else
-#define KS_FN_SUP KS_HD
-#endif
+// The query is an out-of-line function with the support inlined (KS_FN).  Inlined into `collision` it took the stepping kernels past their register
+// budget (the learner's waves no longer fit beside them: training at 0.7 x); with the SUPPORT out of line instead - the pair record then lives in
+// private memory - sim-only fell from 3.1 to 2.5 M env-steps/s.
 struct SuppD {
     double v[3];
     int i1, i2;
@@ -979,8 +964,8 @@ template <typename T> KS_HD void mink_f64(const PairGeo<T>& g, int i, int j, dou
 // support vertex of a hull (fp32 table) along the hull-frame direction ld, fp64 dot products: hull_climb's rule (best strictly improving
 // neighbour in list order) from `cur`
 #ifndef KS_CLIMB64_WIDTH
-#define KS_CLIMB64_WIDTH 4      // neighbours per round of the fp64 climb (8 = hull_climb's two chunks at a time: faster alone, but 24 more live registers in the
-#endif                          // out-of-line query - the stepping kernels then no longer leave room for the learner's waves beside them)
+#define KS_CLIMB64_WIDTH 8      // neighbours per round of the fp64 climb (hull_climb's two chunks at a time; 4: -2.6 % in training)
+#endif
 template <typename TV>
 KS_HD int climb_f64(KS_TAB const TV* V, KS_TAB const unsigned short* off, KS_TAB const unsigned short* adj, int cur, int tab, const double* ld) {
     double best = (double)V[4 * cur] * ld[0] + (double)V[4 * cur + 1] * ld[1] + (double)V[4 * cur + 2] * ld[2];
@@ -1009,7 +994,7 @@ KS_HD int climb_f64(KS_TAB const TV* V, KS_TAB const unsigned short* off, KS_TAB
     }
     return cur;
 }
-template <typename T> KS_FN_SUP void support_f64(PairGeo<T>& g, const double* d, SuppD& o) {
+template <typename T> KS_HD void support_f64(PairGeo<T>& g, const double* d, SuppD& o) {
     double ld1[3], ld2[3];
     KS_UNROLL
     for (int k = 0; k < 3; k++) {
@@ -1021,7 +1006,7 @@ template <typename T> KS_FN_SUP void support_f64(PairGeo<T>& g, const double* d,
     ld2[0] += s2 * SKEW_X; ld2[1] += s2 * SKEW_Y; ld2[2] += s2 * SKEW_Z;
     // the climbs start from the better of the last support vertex and the cube-map cell's (a start only: the climb decides in fp64)
     const T f1[3] = {(T)ld1[0], (T)ld1[1], (T)ld1[2]}, f2[3] = {(T)ld2[0], (T)ld2[1], (T)ld2[2]};
-    const int tab1 = g.use_tab ? (int)g.dir1[support_cell(f1)] : g.hint1, tab2 = g.use_tab ? (int)g.dir2[support_cell(f2)] : g.hint2;
+    const int tab1 = (int)g.dir1[support_cell(f1)], tab2 = (int)g.dir2[support_cell(f2)];
     g.hint1 = climb_f64(g.V1, g.off1, g.adj1, g.hint1, tab1, ld1);
     g.hint2 = climb_f64(g.V2, g.off2, g.adj2, g.hint2, tab2, ld2);
     o.i1 = g.hint1; o.i2 = g.hint2;
@@ -1099,20 +1084,18 @@ KS_HD bool mpr_readoff_f64(const PairGeo<T>& g, const SuppD& v0, const SuppD& v1
 // is short and predicated.  All of it on fp64 Minkowski points formed from vertex ids (SuppD): same decisions as the fp64 oracle wherever both
 // stand on the same portal (tests/studies/divergence_table.py: 162 of 168 grasp-and-lift envs within 1e-4 after 200 substeps; fp32 points: 146).
 enum { MPR_S_V1 = 0, MPR_S_V2 = 1, MPR_S_V3 = 2, MPR_S_INSIDE = 3, MPR_S_REFINE = 4 };
-template <typename T, typename S>
-KS_FN_SM bool mpr_penetration_sm(PairGeo<T>& g_io, T tol_, int max_iter, T* depth_o, T* dir_o, T* pos_o, S scr, int path_scr, int n_old, int* n_new_o) {
+template <typename T>
+KS_FN bool mpr_penetration_sm(PairGeo<T>& g_io, T tol_, int max_iter, T* depth_o, T* dir_o, T* pos_o) {
     // (an out-of-line function: the caller's pair record and result slots are private MEMORY from here - worked on in registers, written once)
     PairGeo<T> g = g_io;
     T depth_[1] = {0}, dir[3] = {0, 0, 0}, pos[3] = {0, 0, 0};
     T* depth = depth_;
-    int k = 0, n_ok = MPR_PATH;         // supports so far; entries of the new path that are valid
     struct Out {
-        PairGeo<T>& g_io; const PairGeo<T>& g; T* depth_o; T* dir_o; T* pos_o; const T* depth; const T* dir; const T* pos; int* n_new_o; const int& k; const int& n_ok;
+        PairGeo<T>& g_io; const PairGeo<T>& g; T* depth_o; T* dir_o; T* pos_o; const T* depth; const T* dir; const T* pos;
         KS_HD ~Out() {
             g_io.hint1 = g.hint1; g_io.hint2 = g.hint2; *depth_o = *depth; dir_o[0] = dir[0]; dir_o[1] = dir[1]; dir_o[2] = dir[2]; pos_o[0] = pos[0]; pos_o[1] = pos[1]; pos_o[2] = pos[2];
-            *n_new_o = k < n_ok ? k : n_ok;
         }
-    } out_{g_io, g, depth_o, dir_o, pos_o, depth, dir, pos, n_new_o, k, n_ok};
+    } out_{g_io, g, depth_o, dir_o, pos_o, depth, dir, pos};
     SuppD v0, v1, v2, v3, v4;
     double d[3], va[3], vb[3];
     const double tol = (double)tol_;
@@ -1135,18 +1118,7 @@ KS_FN_SM bool mpr_penetration_sm(PairGeo<T>& g_io, T tol_, int max_iter, T* dept
                 if (is_zero(dt) || dt > 0) { state = MPR_S_REFINE; it = 0; }
             }
         } else if (state == MPR_S_V3 && it > 100) return false;
-        // the climbs of support k start at the vertices support k of the previous substep's query ended on
-        g.use_tab = true;
-        if (k < n_old) {
-            const int e = (int)scr(path_scr + k), h1 = e & 1023, h2 = e >> 10;
-            g.hint1 = h1 < g.n1 ? h1 : 0; g.hint2 = h2 < g.n2 ? h2 : 0; g.use_tab = false;
-        }
         support_f64(g, d, v4);                                  // THE support site
-        if (k < MPR_PATH) {
-            if ((v4.i1 | v4.i2) < 1024) scr(path_scr + MPR_PATH + k) = T(v4.i1 | (v4.i2 << 10));
-            else n_ok = k < n_ok ? k : n_ok;                    // (a hull of more than 1024 vertices, multi-geom build: the path ends here)
-        }
-        k++;
         const double dv = dot3(v4.v, d);
         if (state == MPR_S_V1) {
             v1 = v4;
@@ -1953,18 +1925,10 @@ KS_HD bool hull_pair_may_touch(S scr, KS_LDS const PairRec<T>* prp) {
 // narrow phase of a hull pair that passed hull_pair_may_touch
 template <typename T, typename S>
 KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S scr, KS_LDS const PairRec<T>* prp, int slot, int packed_in, int& h1_out,
-                            int& h2_out, PairWarm* ws, float* prof = nullptr, T* path = nullptr, int path_scr = 0) {
+                            int& h2_out, PairWarm* ws, float* prof = nullptr) {
     KS_LDS const PairRec<T>& pr = *prp;
     PairGeo<T> pg;
-    // the pair's remembered penetration path (see MPR_PATH): requested now - only when the pair's previous query got as far as MPR -, needed
-    // behind the distance query
-    constexpr bool use_sm = (KS_MPR_SM != 0) && sizeof(T) == 4, use_path = use_sm && (KS_MPR_PATH != 0);
-    T pw[MPR_PATH + 1];
-    const bool path_in = use_path && path != nullptr && ws != nullptr && ws->w[2] != 0u;      // (word 2 of the pair memory: the last query of this pair ran MPR)
-    if constexpr (use_path) {
-        KS_UNROLL
-        for (int k = 0; k <= MPR_PATH; k++) pw[k] = path_in ? path[k] : T(0);
-    }
+    constexpr bool use_sm = (KS_MPR_SM != 0) && sizeof(T) == 4;
 #ifdef KS_STAMP_HULL
     const long long th0 = clock64();
 #endif
@@ -2002,7 +1966,6 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
     // hints are only meaningful when they index the pair's own hulls (always, unless a hull has > 1024 vertices)
     pg.hint1 = h1_out < pg.n1 ? h1_out : 0;
     pg.hint2 = h2_out < pg.n2 ? h2_out : 0;
-    pg.use_tab = true;
     pg.half_margin = T(0);
 #ifdef KS_STAMP_HULL
     pg.cnt_support = 0; pg.cnt_steps = 0; pg.t_sup = 0; pg.t_clo = 0;
@@ -2036,7 +1999,7 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
     h1_out = pg.hint1 <= PC_HINT_MAX ? pg.hint1 : 0; h2_out = pg.hint2 <= PC_HINT_MAX ? pg.hint2 : 0;   // (a vertex id beyond the 10-bit field is not remembered: start 0, not a masked id)
     const int pi = (flags >> 12) & PAIR_INDEX_MASK;
     if (obj_first && (r == 1 || r == 3)) { dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
-    if (use_path && r < 2 && path != nullptr && ws != nullptr) ws->w[2] = 0u;
+    if (use_sm && r < 2 && ws != nullptr) ws->w[2] = 0u;
     if (r == 1) { stage_contact(scr, slot, body1, body2, pi, mu, dist, pos, dir); return 1; }
     if (r >= 2) {
         // 2: overlap (or undecided beyond the margin), 3: a margin-zone result that is not a certified separation
@@ -2047,19 +2010,8 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
         const int sup0 = pg.cnt_support;
 #endif
         if constexpr (use_sm) {
-            int n_old = path_in ? (int)pw[MPR_PATH] : 0, n_new = 0;
-            n_old = n_old < 0 ? 0 : (n_old > MPR_PATH ? MPR_PATH : n_old);
-            if (path_in) {
-                KS_UNROLL
-                for (int k = 0; k < MPR_PATH; k++) scr(path_scr + k) = pw[k];
-            }
-            hit = mpr_penetration_sm(pg, m.mpr_tol, m.mpr_iters, &depth, mdir, mpos, scr, path_scr, n_old, &n_new);
-            if (use_path && path != nullptr) {
-                KS_UNROLL
-                for (int k = 0; k < MPR_PATH; k++) path[k] = scr(path_scr + MPR_PATH + k);
-                path[MPR_PATH] = T(n_new);
-                if (ws != nullptr) ws->w[2] = 1u;
-            }
+            hit = mpr_penetration_sm(pg, m.mpr_tol, m.mpr_iters, &depth, mdir, mpos);
+            if (ws != nullptr) ws->w[2] = 1u;                   // (pair memory word 2: the pair's last query got as far as MPR - KS_MPR_FIRST=3)
         } else {
             hit = mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, mdir, mpos, ws);
         }
@@ -2087,10 +2039,7 @@ template <typename T, typename S, int SUBS> KS_HD void reset_pair_words(S scr, T
 
 template <typename T, typename S, int SUBS>
 KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Team<SUBS> team, int& ncon, int& status, PairWarm* warm = nullptr,
-                     float* prof = nullptr, T* path = nullptr) {
-    // path: this lane's remembered penetration paths, [pairs of the lane][PATH_WORDS] (MPR_PATH; nullptr: plain cold queries)
-    const int path_scr = SCR_CON + team.sub * (2 * MPR_PATH);
-    static_assert(2 * MPR_PATH * (SUBS == 1 ? 1 : SUBS) <= NCON_MAX * CON_STRIDE, "path scratch of the lanes fits the contact records");
+                     float* prof = nullptr) {
     KS_T0
     const int npair = hu.npair, nhull = hu.nhull;
     KS_LDS const PairRec<T>* pairs = hu.pair;
@@ -2141,13 +2090,13 @@ KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Tea
                     if (next_slot + 1 > NSTAGE) status |= ST_CONTACT_OVERFLOW;
                     else {
                         scr(SCR_SLOT + pi) = T(next_slot);
-                        c = collide_hull_hull(m, dirtab, scr, pairs + pi, next_slot, word, h1, h2, warm ? warm + hk : nullptr, prof, path ? path + hk * PATH_WORDS : nullptr, path_scr);
+                        c = collide_hull_hull(m, dirtab, scr, pairs + pi, next_slot, word, h1, h2, warm ? warm + hk : nullptr, prof);
                         next_slot++;
                     }
                 }
             } else {
                 if (pairs[pi].slot + 1 > NSTAGE) status |= ST_CONTACT_OVERFLOW;
-                else if (hull_pair_may_touch(scr, pairs + pi)) c = collide_hull_hull(m, dirtab, scr, pairs + pi, pairs[pi].slot, word, h1, h2, warm ? warm + hk : nullptr, prof, path ? path + hk * PATH_WORDS : nullptr, path_scr);
+                else if (hull_pair_may_touch(scr, pairs + pi)) c = collide_hull_hull(m, dirtab, scr, pairs + pi, pairs[pi].slot, word, h1, h2, warm ? warm + hk : nullptr, prof);
             }
             scr(SCR_PC + pi) = T(pc_pack(c, h1, h2));
         }
@@ -2201,8 +2150,7 @@ KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Tea
                     if (q == r) { pi_r = pi_[q]; word_r = word_[q]; slot_r = slot_[q]; }
             }
             int h1 = 0, h2 = 0;
-            const int c = collide_hull_hull(m, dirtab, scr, pairs + pi_r, DYNAMIC_SLOTS ? slot_r : pairs[pi_r].slot, word_r, h1, h2, warm ? warm + r : nullptr, prof,
-                                            path ? path + r * PATH_WORDS : nullptr, path_scr);
+            const int c = collide_hull_hull(m, dirtab, scr, pairs + pi_r, DYNAMIC_SLOTS ? slot_r : pairs[pi_r].slot, word_r, h1, h2, warm ? warm + r : nullptr, prof);
             scr(SCR_PC + pi_r) = T(pc_pack(c, h1, h2));
             todo &= todo - 1;
         }
@@ -3015,7 +2963,7 @@ struct NoHook {
 template <typename T, typename S, int SUBS, typename Hook = NoHook>
 KS_HD void mj_forward_step(const Model<T>& m, const Hulls<T>& hu, T* qpos, T* qvel, T* warm, const T* ctrl, const T* R7, S scr, Team<SUBS> team,
                            int solver_iterations, bool integrate, int& ncon_out, int& status, float* prof = nullptr, PairWarm* gjk_warm = nullptr,
-                           Hook after_kinematics = Hook(), T* mpr_path = nullptr) {
+                           Hook after_kinematics = Hook()) {
     KS_T0
     team.sync();                                   // the previous substep's readers of the body poses are done
     dynamics_rows(m, qpos, qvel, ctrl, R7, scr, team);
@@ -3032,7 +2980,7 @@ KS_HD void mj_forward_step(const Model<T>& m, const Hulls<T>& hu, T* qpos, T* qv
     KS_UNROLL
     for (int i = 0; i < KS_SCRATCH_PROBE; i++) probe_[(i + (status >> 30)) & (KS_SCRATCH_PROBE - 1)] = qvel[i % NV];
 #endif
-    collision(m, hu, scr, team, ncon, status, gjk_warm, prof, mpr_path);
+    collision(m, hu, scr, team, ncon, status, gjk_warm, prof);
 #if defined(KS_SCRATCH_PROBE) && defined(__HIP_DEVICE_COMPILE__)
     {
         T acc_ = T(0);

@@ -31,7 +31,7 @@ template <typename T, typename S, typename SnapW> KS_HD void write_snapshot(S sc
 template <typename T, typename S, typename SnapW, int SUBS, typename OnSnap = NoHook>
 KS_HD void lane_env_step(const Model<T>& m, const Hulls<T>& hu, LaneState<T>& st, const T* hand_quat, const T* act4, S scr, Team<SUBS> team,
                          SnapW snap_put, int frame_skip, int solver_iterations, int& ncon, int& status, float* prof = nullptr,
-                         T* ws = nullptr, PairWarm* warm = nullptr, OnSnap on_snapshot = OnSnap(), T* mpr_path = nullptr) {
+                         T* ws = nullptr, PairWarm* warm = nullptr, OnSnap on_snapshot = OnSnap()) {
     // ws (optional, 18 reals shared by the team): where the per-step constants live; the GPU passes LDS
     T Rpalm[9], T3[9], wrist[3], R7_[9], ctrl_[NU];
     T* R7 = ws ? ws : R7_;
@@ -52,7 +52,7 @@ KS_HD void lane_env_step(const Model<T>& m, const Hulls<T>& hu, LaneState<T>& st
                 if (team.sub == 0) write_snapshot<T>(scr, jq, snap_put);
                 on_snapshot();
             }
-        }, mpr_path);
+        });
     }
 }
 

@@ -19,7 +19,6 @@ struct LC {
     // lc_set_warm(1): the lane remembers its hull pairs' last queries from one lc_substep call to the next, as a lane of the stepping kernel does
     // across substeps and launches (ks_core.h: PairWarm); default: cold queries
     PairWarm gw[NPAIR_MAX];
-    float path[NPAIR_MAX * PATH_WORDS];      // ... and the penetration queries' remembered paths (ks_core.h: MPR_PATH)
     bool warm = false;
 };
 
@@ -41,7 +40,7 @@ template <typename T> struct SnapPut {
 
 template <typename T>
 static int substep_t(const Model<T>& m, double* qpos, double* qvel, double* warm, const double* ctrl, const double* hq, int iters, int* ncon,
-                     double* con, PairWarm* gw = nullptr, T* path = nullptr) {
+                     double* con, PairWarm* gw = nullptr) {
     std::vector<T> scrbuf(SCR_TOTAL, T(0));
     Scratch<T> scr{scrbuf.data(), 1};
     { T mass, mu; nominal_env_params(m, mass, mu); scr(SCR_ENVP) = mass; scr(SCR_ENVP + 1) = mu; }
@@ -58,7 +57,7 @@ static int substep_t(const Model<T>& m, double* qpos, double* qvel, double* warm
         for (int i = 0; i < 9; i++) R7[i] = (T)R7d[i];
     }
     int status = 0, nc = 0;
-    mj_forward_step(m, host_hulls(m), st.qpos, st.qvel, st.warm, c, R7, scr, Team<1>{0}, iters, true, nc, status, nullptr, gw, NoHook(), path);
+    mj_forward_step(m, host_hulls(m), st.qpos, st.qvel, st.warm, c, R7, scr, Team<1>{0}, iters, true, nc, status, nullptr, gw);
     for (int i = 0; i < NQ; i++) qpos[i] = st.qpos[i];
     for (int i = 0; i < NV; i++) { qvel[i] = st.qvel[i]; warm[i] = st.warm[i]; }
     *ncon = nc;
@@ -233,7 +232,7 @@ int lc_substep(void* h, int prec, double* qpos, double* qvel, double* warm, cons
 #endif
     if (prec == 6432) return substep_mixed(l->d.m, l->f.m, qpos, qvel, warm, ctrl, hq, iters, ncon, con);
     return prec == 64 ? substep_t<double>(l->d.m, qpos, qvel, warm, ctrl, hq, iters, ncon, con)
-                      : substep_t<float>(l->f.m, qpos, qvel, warm, ctrl, hq, iters, ncon, con, l->warm ? l->gw : nullptr, l->warm ? l->path : nullptr);
+                      : substep_t<float>(l->f.m, qpos, qvel, warm, ctrl, hq, iters, ncon, con, l->warm ? l->gw : nullptr);
 }
 int lc_env_step(void* h, int prec, double* qpos, double* qvel, double* warm, const double* hq, const double* act, int frame_skip, int iters,
                 double* obs, double* reward, int* done, double* rays) {
@@ -246,7 +245,7 @@ int lc_reset_obs(void* h, int prec, double* qpos, double* qvel, double* warm, co
     return prec == 64 ? env_step_t<double>(l->d.m, qpos, qvel, warm, hq, nullptr, 0, 0, obs, reward, done, rays, 1)
                       : env_step_t<float>(l->f.m, qpos, qvel, warm, hq, nullptr, 0, 0, obs, reward, done, rays, 1);
 }
-void lc_set_warm(void* h, int on) { LC* l = (LC*)h; l->warm = on != 0; std::memset(l->gw, 0, sizeof l->gw); std::memset(l->path, 0, sizeof l->path); }
+void lc_set_warm(void* h, int on) { LC* l = (LC*)h; l->warm = on != 0; std::memset(l->gw, 0, sizeof l->gw); }
 #ifdef KS_COUNT_CLIMB
 void lc_counters(long* out) { out[0] = ks_climb_rounds; out[1] = ks_mpr_supports; out[2] = ks_mpr_queries; out[3] = ks_mpr_hinted; }
 #endif
