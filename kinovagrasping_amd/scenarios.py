@@ -21,7 +21,6 @@ MEDIUM_SHAPES = [s + "M" for s in ["Cube", "Cylinder", "Cube45", "Cone1", "Cone2
 # (2434 vertices) is beyond the standard library's 1024 and runs on libkinova_sim_mg.so (hull tables in global memory; sim.blob_needs_mg_library)
 EXTRA_SHAPES = [s + z for s in ["Vase", "Lemon"] for z in "SMB"]
 
-_tables = None
 
 
 def model_blob(shape: str) -> bytes:
@@ -29,36 +28,38 @@ def model_blob(shape: str) -> bytes:
     return load_model_blob(shape, ASSETS)
 
 
-def start_coord_table(shape: str, orientation: str = "normal") -> np.ndarray:
-    """Rows of obj_hand_coords/no_noise/train_coords/<Orient>/<shape>.txt as the reference's sampler
+def _coord_tables(noise: str, mode: str):
+    """the re-encoded coordinate files of one (noise kind, split): obj_hand_coords/<noise>/<mode>_coords (tools/compile_assets.py: coordinate_tables)"""
+    if mode not in ("train", "test"):
+        raise ValueError(f"start coordinates: mode is 'train' or 'test' (kinova_gripper_env.py:1241-1245), not {mode!r}")
+    key = (noise, mode)
+    if key not in _table_cache:
+        _table_cache[key] = np.load(ASSETS / f"start_coords_{noise}_{mode}.npz")
+    return _table_cache[key]
+
+
+_table_cache = {}
+
+
+def start_coord_table(shape: str, orientation: str = "normal", mode: str = "train") -> np.ndarray:
+    """Rows of obj_hand_coords/no_noise/<mode>_coords/<Orient>/<shape>.txt as the reference's sampler
     sees them (first line consumed by the delimiter sniffer, kinova_gripper_env.py:1012)."""
-    global _tables
-    if _tables is None:
-        _tables = np.load(ASSETS / "start_coords_no_noise_train.npz")
-    return _tables[f"{orientation.capitalize()}/{shape}"].astype(np.float64)
+    return _coord_tables("no_noise", mode)[f"{orientation.capitalize()}/{shape}"].astype(np.float64)
 
 
-_noisy_tables = None
-
-
-def noisy_start_table(shape: str, orientation: str = "normal"):
-    """Rows of the reference's obj_hand_coords/with_noise/train_coords/<orient>/<shape>.txt (its DEFAULT start states,
+def noisy_start_table(shape: str, orientation: str = "normal", mode: str = "train"):
+    """Rows of the reference's obj_hand_coords/with_noise/<mode>_coords/<orient>/<shape>.txt (its DEFAULT start states,
     kinova_gripper_env.py:1310, 1019-1021): object x, y, z and the hand's Euler triple of that row (patched into the XML through the
     5-character truncation, :1254-1255, 870-874).  float64 [rows, 6], or None where the reference ships no such file.  SURVEY note N5: the
     Euler columns are biased by -0.087 rad and swapped between the normal / top classes relative to the object columns - shipped as data
-    so that `KinovaGripperVecEnv.reset(with_noise="tables")` reproduces the reference's default as it is."""
-    global _noisy_tables
-    if _noisy_tables is None:
-        _noisy_tables = np.load(ASSETS / "start_coords_with_noise_train.npz")
+    so that `KinovaGripperVecEnv.reset(with_noise=True)` reproduces the reference's default as it is."""
+    t = _coord_tables("with_noise", mode)
     key = f"{orientation}/{shape}"
-    return _noisy_tables[key].astype(np.float64) if key in _noisy_tables.files else None
+    return t[key].astype(np.float64) if key in t.files else None
 
 
-def has_start_table(shape: str, orientation: str = "normal") -> bool:
-    global _tables
-    if _tables is None:
-        _tables = np.load(ASSETS / "start_coords_no_noise_train.npz")
-    return f"{orientation.capitalize()}/{shape}" in _tables.files
+def has_start_table(shape: str, orientation: str = "normal", mode: str = "train") -> bool:
+    return f"{orientation.capitalize()}/{shape}" in _coord_tables("no_noise", mode).files
 
 
 def fallback_start(shape: str, orientation: str, rng=np.random) -> np.ndarray:

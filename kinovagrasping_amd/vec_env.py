@@ -88,7 +88,7 @@ class KinovaGripperVecEnv:
         """the coordinate file of every env's (orientation, shape), the path the reference builds at ENV:1245"""
         names = self.random_shape if isinstance(self.random_shape, list) else [self.random_shape] * self.n_envs
         noise_dir = "with_noise" if self.with_noise == "tables" else "no_noise"
-        return [COORDS_DIR + noise_dir + "/train_coords/" + o + "/" + sh + ".txt" for o, sh in zip(self.orientation, names)]
+        return [COORDS_DIR + noise_dir + "/" + getattr(self, "mode", "train") + "_coords/" + o + "/" + sh + ".txt" for o, sh in zip(self.orientation, names)]
 
     @property
     def Tfw(self):
@@ -202,7 +202,9 @@ class KinovaGripperVecEnv:
         With several objects loaded every reset env draws its
         object from `shape_keys` (default: all loaded) - Latin-square queue first, see select_object.
         Slide offsets of the 'rotated' / 'top' hands: see `hand_offsets` of the constructor.
-        with_noise=True (the default, as in the reference, ENV:1310): the reference's start states AS THEY ARE - object position AND hand
+        mode ("train" / "test", ENV:1241-1245): which of the reference's two sets of coordinate files the rows come from (<noise>/train_coords: 4499 rows per
+        file, <noise>/test_coords: 499).
+        with_noise=True (the default, as in the reference, ENV:1310; any non-string flag counts by its truth value): the reference's start states AS THEY ARE - object position AND hand
         Euler triple of a random row of the shape's with_noise coordinate file (ENV:1019-1021, 1254-1255; `scenarios.noisy_start_table`),
         the Euler triple through the reference's 5-character truncation (ENV:870-874); the tables' bias of -0.087 rad and the swap
         between the normal / top classes (SURVEY note N5; generator rotation_generation.py:20-25) are the reference's and are kept.
@@ -212,11 +214,13 @@ class KinovaGripperVecEnv:
         ZERO-MEAN N(0, 0.087 rad) per axis drawn from the env's np_random, then the 5-character truncation; object coordinates from the
         no_noise tables."""
         from .model_compiler import euler_to_quat, truncated_euler
-        if with_noise is True:
-            with_noise = "tables"
+        if not isinstance(with_noise, str):                     # bool / np.bool_ / int flags forwarded by a driver (argparse, numpy): truth value
+            with_noise = "tables" if bool(with_noise) else False
         if with_noise not in (False, "tables", "zero-mean"):
             raise ValueError('reset: with_noise is True (the reference\'s with_noise files; alias "tables"), False or "zero-mean" (extension)')
-        self.with_noise = with_noise
+        if mode not in ("train", "test"):
+            raise ValueError(f"reset: mode is 'train' or 'test' (the coordinate files' directory, ENV:1241-1245), not {mode!r}")
+        self.with_noise, self.mode = with_noise, mode
         self.set_with_grasp_reward(with_grasp)
         ids = np.arange(self.n_envs) if env_ids is None else np.asarray(env_ids)
         n = len(ids)
@@ -253,7 +257,7 @@ class KinovaGripperVecEnv:
                     return self.np_random.randint(0, int(((tab[:, 0] >= lo) & (tab[:, 0] <= hi)).sum()))     # (sic: an index INTO the region's rows,
                 return self.np_random.randint(0, len(tab))                                                 #  used on the whole file)
 
-            noisy = scenarios.noisy_start_table(shape, o) if (with_noise == "tables" and start_pos is None) else None
+            noisy = scenarios.noisy_start_table(shape, o, mode) if (with_noise == "tables" and start_pos is None) else None
             if noisy is not None:
                 row = pick_row(noisy)
                 eul = truncated_euler(noisy[row, 3:6]) if row >= 0 else np.zeros(3)                          # (origin: hand Euler 0, 0, 0, ENV:1040)
@@ -275,8 +279,8 @@ class KinovaGripperVecEnv:
                 else:
                     raise ValueError("reset: a start_pos row has 3, 2 or 9 values")
                 self.orientation_idx[e] = -1
-            elif scenarios.has_start_table(shape, o):
-                tab = scenarios.start_coord_table(shape, o)
+            elif scenarios.has_start_table(shape, o, mode):
+                tab = scenarios.start_coord_table(shape, o, mode)
                 row = pick_row(tab)
                 q[9:12, k] = tab[row] if row >= 0 else [0.0, 0.0, tab[0][2]]
                 self.orientation_idx[e] = row

@@ -16,9 +16,10 @@
  *     sec. 4, 8c); its tree does hold four sets of recorded MuJoCo 1.50 output (a 63-row x 48-column
  *     contact trajectory - box pushed, grasped and lifted -, finger joint traces, ten demonstrations,
  *     success / failure maps): the physics is PINNED to those (tests/test_mujoco_recorded.py,
- *     the contact trajectory to 1.9e-10 in every column for its first 22 rows,
- *     84 substeps with 18 rows of finger-box contact; first row beyond 1e-6: row 22).  Contact
- *     forces and velocities of real MuJoCo were never recorded.
+ *     the contact trajectory, replayed free-running, to 1.05e-10 in every column
+ *     through row 40 - push, grasp, first centimetres of the lift -, 8e-8 through row 45, 5.5e-4 for the
+ *     rest of the lift; ko_physics.c's header has the list).  Contact forces and velocities of real
+ *     MuJoCo were never recorded.
  *   - multi-geom objects (Bottle / TBottle / Bowl / RBowl: `object` + jointless child bodies, ..._sbottle.xml:158-186): PARITY
  *     UNPINNED for what is specific to them - the reference tree holds no MuJoCo output of these models.  The restatement follows
  *     MuJoCo's documented semantics (welded children = one rigid body with the composite inertial; their geoms collide dynamically

@@ -4,11 +4,20 @@
  * Reference call site: kinova_gripper_env.py:1535 (`self._sim.step()`), :703/:353 (`forward`).
  * The arithmetic itself is third-party (MuJoCo 1.50, not vendored, not installable here): this
  * file restates MuJoCo's published pipeline (documentation, "Computation" chapter; SURVEY.md
- * Appendix B) stage by stage.  PINNED IN PART against real MuJoCo 1.50 output recorded by the reference's authors and left in
- * their tree (tests/golden/mujoco_recorded.npz, tests/test_mujoco_recorded.py): free-closing finger joint traces to 3e-5 rad
- * (Old Code/Pose_file.csv: actuators, damping, armature, soft tendon equality, gravity, sensor lag), ten recorded demonstrations
- * and the naive-controller success / failure maps (expert_plots/: outcome agreement outside one stated zone).  Contact forces
- * and velocities of real MuJoCo are not available anywhere: for those, PARITY UNPINNED.
+ * Appendix B) stage by stage.  PINNED against every number of real MuJoCo 1.50 output the reference's authors recorded and left in their
+ * tree (tests/golden/mujoco_recorded.npz, tests/test_mujoco_recorded.py, tests/old_env.py):
+ *   - Old Code/Pose_file_2.csv, the one recorded CONTACT trajectory (63 rows x 48 columns, one row per env.step()): replayed free-running - only the four
+ *     un-recorded commands of a row are recovered from its four actuated joint angles, the other 44 columns are predictions - rows 0-40 agree in all
+ *     48 columns to 1.05e-10 (the recording's ten decimals): release inside the floor, a box pushed 5 cm on its edge with sliding friction, a grasp
+ *     between two finger pads, the first 2 cm of lift; rows 41-45 (third finger arrives, lift to 0.10 m) to 8e-8; rows 46-62 (rest of the lift) to
+ *     5.5e-4 (object 1.05e-4) - there finger 1's pad rolls over the box's vertical edge and MuJoCo's own choice among 4-way ties of its analytic box
+ *     support decides the portal (docs/recorded_mujoco.md; a searched tie pattern reproduces rows 46-47 to 3e-8);
+ *   - Old Code/Pose_file.csv: free-closing finger joint traces to 3.3e-5 rad (actuators, damping, armature, soft tendon equality, gravity, sensor lag);
+ *   - expert_plots/: ten recorded demonstrations (8 of 10 outcomes, the 6 common lifts to the env-step) and the naive controller's success / failure maps.
+ * So the kinematics, the legacy mesh inertia, the explicit pairs' margin 0, the operand order of the convex queries, the contact model (impedance,
+ * pyramid rows), Newton and the Euler step are pinned by positions through 45 rows of contact, grasp and lift.  NOT pinned, because no MuJoCo datum
+ * exists for them anywhere under /root/reference: contact FORCES and qvel as such, mesh objects other than the primitive box, the rotated / top hand
+ * poses, and everything specific to the multi-geom objects (ko_model.c: PARITY UNPINNED for those).
  *
  * Deliberately written in the plainest dense form (15x15 matrices, full Jacobians) so that it
  * is an independent check of the specialised HIP kernels.

@@ -31,27 +31,33 @@ def main():
         mc.write_blob(M, OUT / f"{shape}.ksm")
         info = M["mesh_info"]
         print(shape, "hull verts", info[:, 1].astype(int), "obj inertia", M["body_inertia"][9], "size_obs", M["obj_size_obs"])
-    # start-coordinate tables (no_noise; SURVEY note N5), float64 [rows,3]
-    tables = {}
-    for orient in ["Normal", "Rotated", "Top"]:
-        for shape in SHAPES + MEDIUM + list(EXTRA) + list(MULTI_GEOM):
-            p = KD / "obj_hand_coords" / "no_noise" / "train_coords" / orient / f"{shape}.txt"
-            if p.exists():
-                tables[f"{orient}/{shape}"] = mc.load_coords_table(p)[:, :3].astype(np.float32)
-    np.savez_compressed(OUT / "start_coords_no_noise_train.npz", **tables)
-    print("tables:", {k: v.shape for k, v in list(tables.items())[:4]}, "...", len(tables))
-    # the reference's with_noise tables (its default, kinova_gripper_env.py:1310): object x, y, z + the hand's Euler triple per row
-    # (kinova_gripper_env.py:1019-1021, 1254-1255; lower-case class directories).  SURVEY note N5 shows them to be biased and swapped
-    # between classes; they are shipped so that reset(with_noise="tables") can reproduce the reference's default start states as they are.
-    noisy = {}
-    for orient in ["normal", "rotated", "top"]:
-        for shape in SHAPES + MEDIUM + list(EXTRA):
-            p = KD / "obj_hand_coords" / "with_noise" / "train_coords" / orient / f"{shape}.txt"
-            if p.exists():
-                noisy[f"{orient}/{shape}"] = mc.load_coords_table(p)[:, :6].astype(np.float32)
-    np.savez_compressed(OUT / "start_coords_with_noise_train.npz", **noisy)
-    print("with_noise tables:", {k: v.shape for k, v in list(noisy.items())[:3]}, "...", len(noisy))
+    coordinate_tables()
+
+
+def coordinate_tables():
+    """start-coordinate tables of the reference (obj_hand_coords/<noise>/<train|test>_coords/<orient>/<shape>.txt; kinova_gripper_env.py:1241-1255),
+    re-encoded as float32 arrays: no_noise [rows, 3] (object x, y, z; SURVEY note N5), with_noise [rows, 6] (+ the hand's Euler triple of the row -
+    its default, kinova_gripper_env.py:1310, 1019-1021; lower-case class directories).  SURVEY note N5 shows the with_noise tables to be biased and
+    swapped between classes; they are shipped so that reset(with_noise=True) reproduces the reference's default start states as they are.  The test
+    tables are what reset(mode="test") reads."""
+    for split in ("train", "test"):
+        tables = {}
+        for orient in ["Normal", "Rotated", "Top"]:
+            for shape in SHAPES + MEDIUM + list(EXTRA) + list(MULTI_GEOM):
+                p = KD / "obj_hand_coords" / "no_noise" / f"{split}_coords" / orient / f"{shape}.txt"
+                if p.exists():
+                    tables[f"{orient}/{shape}"] = mc.load_coords_table(p)[:, :3].astype(np.float32)
+        np.savez_compressed(OUT / f"start_coords_no_noise_{split}.npz", **tables)
+        print(split, "tables:", {k: v.shape for k, v in list(tables.items())[:4]}, "...", len(tables))
+        noisy = {}
+        for orient in ["normal", "rotated", "top"]:
+            for shape in SHAPES + MEDIUM + list(EXTRA):
+                p = KD / "obj_hand_coords" / "with_noise" / f"{split}_coords" / orient / f"{shape}.txt"
+                if p.exists():
+                    noisy[f"{orient}/{shape}"] = mc.load_coords_table(p)[:, :6].astype(np.float32)
+        np.savez_compressed(OUT / f"start_coords_with_noise_{split}.npz", **noisy)
+        print(split, "with_noise tables:", {k: v.shape for k, v in list(noisy.items())[:3]}, "...", len(noisy))
 
 
 if __name__ == "__main__":
-    main()
+    coordinate_tables() if "--tables" in sys.argv else main()
