@@ -214,6 +214,7 @@ def main():
                          "env-step for all envs (pipeline.GraphedTrainer, rounds 1-2; bit-reproducible).  'auto' (default): free where it pays - the "
                          "learner is LDS-free (256-256) and the envs fit the GPU's CUs in one round of workgroups (<= 16 envs x CUs: config 3 / 4) - "
                          "else lockstep (config 5's 8192 envs, 400-300, --eager, --serial-learner).  The JSON line says which (`config.launch`).")
+    ap.add_argument("--repeats", type=int, default=3, help="timed windows of --steps env-steps each; the line reports the median window (all are listed)")
     ap.add_argument("--chunk", type=int, default=60, help="free-running rollout: at most this many env-steps per launch (learner and rollout streams meet between launches); "
                     "a launch lasts as long as its slowest workgroup, whose lead over the mean workgroup shrinks with the square root of the steps per launch; the "
                     "learner's stream is paced on the envs' step counters (pipeline.AsyncTrainer.run, kr_wait_min), so finished episodes are collected all the way whatever the length; 60 is kept as the default because the launch pattern of the pre-training decides which policy emerges "
@@ -318,11 +319,11 @@ def main():
             from kinovagrasping_amd.pipeline import AsyncTrainer, GraphedTrainer
             eng = RolloutEngine(sim, policy, replay, expl_noise=0.1)
             eng.start(obs0)
-            cus = torch.cuda.get_device_properties(dev).multi_processor_count
-            groups = (n + 15) // 16 if not mixed else int(sum((np.bincount(oid_all[sl], minlength=len(scenarios.SHAPES)) + 15) // 16))
-            # round 5: with more groups than compute units the persistent kernel takes them from a ready queue (k_rollout), so an uneven count - config 5
-            # drawn per env: 526 groups on 256 CUs - no longer paces the launch at its fullest workgroup; the fixed deals (KS_ROLLOUT_DEAL=static / rr) do
-            fits = groups <= cus or groups % cus == 0 or os.environ.get("KS_ROLLOUT_DEAL", "queue") == "queue"
+            # how the library itself would schedule this context's env groups in a free-running launch (ks_rollout_plan; ADVICE r5: not re-derived here):
+            # a fixed deal ("runs" / "round-robin": KS_ROLLOUT_DEAL, the multi-geom library's default) paces the launch at the workgroup with the most
+            # groups unless they divide evenly
+            plan, groups, wgs = sim.rollout_plan()
+            fits = plan in ("waves", "workgroups", "queue") or groups % wgs == 0
             free_running = not args.serial_learner and (args.rollout == "free" or (args.rollout == "auto" and fits and tuple(args.hidden) in ((256, 256), (128, 128), (64, 64))))
             if free_running:
                 try:
@@ -386,8 +387,11 @@ def main():
                 step_fn(k); k += 1
             return
         left = n_steps
+        # (nccl without peer mapping: the per-update library all-reduce only executes between launches - short launches bound the learner's lag;
+        #  pipeline.AsyncTrainer.library_allreduce_chunk)
+        chunk = min(args.chunk, getattr(trainer, "library_allreduce_chunk", None) or args.chunk)
         while left > 0:
-            c = min(left, args.chunk)
+            c = min(left, chunk)
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 trainer.main.wait_stream(trainer.side)
@@ -442,30 +446,42 @@ def main():
             out["lift_fraction_all_finished_episodes"] = round((count1["lifted"] - count0["lifted"]) / max(1, fin), 4)
         return out
 
-    head_t0 = ring_mark()
-    cnt_t0 = trainer.counts() if free_running else None
-    sim.kernel_time(reset=True)
-    upd0 = updates
-    t0 = time.perf_counter()
-    advance(args.steps, timed=True)
-    if trainer is not None:
-        trainer.flush()                                    # the last step's deferred replay-ring update belongs to the timed work
-    t_issue = time.perf_counter() - t0                 # host time to issue the timed steps (before the device catches up)
-    barrier()
-    dt = time.perf_counter() - t0
-    kern_ms, launches = sim.kernel_time()
-    regime_timed = window_regime(head_t0, ring_mark(), cnt_t0, trainer.counts() if free_running else None) if args.mode == "ddpg" else None
-    if free_running:                     # per env-step: the persistent launches' durations / their env-steps
-        tot = sum(e0.elapsed_time(e1) for e0, e1, _ in rollout_ms)
-        kern_ms, launches = tot / max(1, sum(c for _, _, c in rollout_ms)), len(rollout_ms)
-        timed_launches = "+".join(str(c) for _, _, c in rollout_ms)
-        timed_first = len(all_launches) - len(rollout_ms)          # index of the first timed launch among all k_rollout launches
-        rollout_ms.clear()
-    timed_updates = updates - upd0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+    # The timed region, `--repeats` times (the headline used to be ONE launch of 20 env-steps): each window is EXACTLY `--steps`
+    # env-steps of every env (+ the learner's updates) between a barrier + synchronize on both sides; the line reports the window of MEDIAN duration
+    # and lists all of them (`timed_windows_ms_per_step`).
+    windows = []
+    for rep in range(max(1, args.repeats)):
+        head_t0 = ring_mark()
+        cnt_t0 = trainer.counts() if free_running else None
+        sim.kernel_time(reset=True)
+        upd0 = updates
+        t0 = time.perf_counter()
+        advance(args.steps, timed=True)
+        if trainer is not None:
+            trainer.flush()                                    # the last step's deferred replay-ring update belongs to the timed work
+        t_issue = time.perf_counter() - t0                 # host time to issue the timed steps (before the device catches up)
+        barrier()
+        dt = time.perf_counter() - t0
+        kern_ms, launches = sim.kernel_time()
+        regime_timed = window_regime(head_t0, ring_mark(), cnt_t0, trainer.counts() if free_running else None) if args.mode == "ddpg" else None
+        if free_running:                     # per env-step: the persistent launches' durations / their env-steps
+            tot = sum(e0.elapsed_time(e1) for e0, e1, _ in rollout_ms)
+            kern_ms, launches = tot / max(1, sum(c for _, _, c in rollout_ms)), len(rollout_ms)
+            timed_launches = "+".join(str(c) for _, _, c in rollout_ms)
+            timed_first = len(all_launches) - len(rollout_ms)          # index of the first timed launch among all k_rollout launches
+            rollout_ms.clear()
+        timed_updates = updates - upd0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = tt.item()
+        windows.append(dict(dt=dt, t_issue=t_issue, kern_ms=kern_ms, launches=launches, regime_timed=regime_timed, timed_updates=timed_updates,
+                            timed_launches=timed_launches if free_running else None, timed_first=timed_first if free_running else None))
+    pick = sorted(windows, key=lambda w: w["dt"])[len(windows) // 2]
+    dt, t_issue, kern_ms, launches, regime_timed, timed_updates = (pick[k_] for k_ in ("dt", "t_issue", "kern_ms", "launches", "regime_timed", "timed_updates"))
+    if free_running:
+        timed_launches, timed_first = pick["timed_launches"], pick["timed_first"]
+    upd0 = updates - timed_updates
     # ---- the learner's MLP kernels against the fp32 MFMA peak: the update's graphs replayed ALONE (no simulator beside
     # them), HIP-graph launch gaps and the small glue kernels (sampling, loss gradient, Adam) included
     mfma = None
@@ -537,7 +553,7 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/pmc_run.sh);
         # the committed summary applies to the 4096-env workload only
         traffic, traffic_note, issue = None, "no PMC summary for this workload", None
-        pmc = ROOT / "profiles" / ("r05_pmc_sim.json" if args.mode == "sim" else "r05_pmc_free.json" if free_running else "r05_pmc_ddpg.json")     # counters of THIS workload and THIS kernel (k_rollout's are per env-step)
+        pmc = ROOT / "profiles" / ("r06_pmc_sim.json" if args.mode == "sim" else "r06_pmc_free.json" if free_running else "r06_pmc_ddpg.json")     # counters of THIS workload and THIS kernel (k_rollout's are per env-step)
         if pmc.exists() and n == 4096 and not mixed and args.shape == "CubeS":
             pj = json.loads(pmc.read_text())
             traffic, traffic_note = pj["hbm_bytes_per_launch"], pj["note"]
@@ -546,6 +562,10 @@ def main():
                 issue = {"bound": "valu-issue", "valu_busy_frac_of_wave_cycles": round(pl["SQ_ACTIVE_INST_VALU"] / pl["SQ_WAVE_CYCLES"], 3),
                          "waiting_frac_of_wave_cycles": round(pl["SQ_WAIT_ANY"] / pl["SQ_WAVE_CYCLES"], 3),
                          "valu_instructions_per_wave": round(pl["SQ_INSTS_VALU"] / pl["SQ_WAVES"]), "waves_per_simd": 1,
+                         # useful lane-operations per launch against what 1024 SIMDs x 16 lanes could issue in the launch's cycles (GRBM_GUI_ACTIVE is summed
+                         # over the 8 XCDs): the un-packed VALU issue rate actually used
+                         "valu_issue_frac": (round(pl["SQ_INSTS_VALU"] * 64.0 * pj.get("valu_lane_efficiency", 0.0) / (1024 * 16 * pl["GRBM_GUI_ACTIVE"] / 8.0), 4)
+                                             if pl.get("GRBM_GUI_ACTIVE") else None),
                          "valu_lane_efficiency": round(pj.get("valu_lane_efficiency", 0.0), 3),
                          "lds_bank_conflict_frac": round(pj.get("lds_bank_conflict_frac", 0.0), 3),
                          "l2_hit_rate": round(pj.get("l2_hit_rate", 0.0), 3),
@@ -588,6 +608,7 @@ def main():
             "steady_state": steady,
             # every env runs the same 30-step episode clock (auto-reset), and an env-step costs more late in an episode (hands
             # closed, more contacts) than early: a window that is not whole episodes is not an average
+            "timed_windows_ms_per_step": [round(w["dt"] / args.steps * 1e3, 4) for w in windows],      # every window of --steps env-steps; the line is the median one
             "timed_window": {"after_learner_updates": upd0, "pretrain_updates": pretrained, "steps": args.steps,
                              "episode_clock_histogram": clock_hist, "regime": regime_timed,
                              "note": ("timed after the untimed pre-training: trained policy, contact-rich grasps, env episode clocks spread over the 30 "
@@ -602,7 +623,8 @@ def main():
             "rccl": ({"ranks": world, "backend": os.environ.get("KS_DIST_BACKEND", "nccl"), "NCCL_ALGO": os.environ.get("NCCL_ALGO", "default"), "NCCL_PROTO": os.environ.get("NCCL_PROTO", "default"),
                       "allreduces_per_update": 2, "bytes_per_allreduce": int(policy._flat_params["critic"].numel() * 4),
                       "exchange": getattr(trainer, "exchange_note", None),
-                      "replica_sync": getattr(trainer, "replica_sync", "per-update") if trainer is not None else None,   # "average-per-launch": pipeline.AsyncTrainer without peer mapping
+                      "replica_sync": getattr(trainer, "replica_sync", "per-update") if trainer is not None else None,   # "average-per-launch": KS_ASYNC_SYNC=average (opt-in local SGD)
+                      "launch_chunk": (min(args.chunk, getattr(trainer, "library_allreduce_chunk", None) or args.chunk) if free_running else None),
                       "exchange_failed_call": (trainer.native.exchange.failed_epoch() if getattr(trainer, "native", None) is not None
                                                and trainer.native.exchange is not None else None)}
                      if world > 1 and args.mode == "ddpg" else None),

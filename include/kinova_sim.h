@@ -203,6 +203,17 @@ typedef struct {
 } ks_rollout_args;
 int ks_rollout(ks_ctx *ctx, int32_t n_iter, const ks_rollout_args *args_host, void *stream);
 
+/* How ks_rollout would schedule this context's env groups (16 envs sharing one object's hull tables) on the device it runs on - the library's
+ * own decision, for callers that report or warn about it (bench.py, pipeline.AsyncTrainer; ADVICE r5: they used to re-derive it from environment
+ * variables).  *mode: KS_PLAN_WAVES one group per persistent workgroup, its four waves run free (no barrier inside a launch);
+ * KS_PLAN_WORKGROUPS one group per workgroup, the waves joined by barriers at every phase (KS_ROLLOUT_WAVES=0, or a context the wave form cannot
+ * hold); KS_PLAN_QUEUE more groups than resident workgroups, taken from a ready queue; KS_PLAN_RUNS / KS_PLAN_ROUND_ROBIN more groups than
+ * workgroups in a fixed deal (contiguous runs / round-robin: KS_ROLLOUT_DEAL=static / rr, and the multi-geom library's default) - a launch then
+ * runs at the pace of the workgroup with the most groups.  *groups: 16-env groups incl. the partly filled one of every object;
+ * *workgroups: persistent workgroups of a launch.  After ks_load_model(s). */
+enum { KS_PLAN_WAVES = 0, KS_PLAN_WORKGROUPS = 1, KS_PLAN_QUEUE = 2, KS_PLAN_RUNS = 3, KS_PLAN_ROUND_ROBIN = 4 };
+int ks_rollout_plan(ks_ctx *ctx, int32_t *mode, int32_t *groups, int32_t *workgroups);
+
 /* HIP event timing of the dominant kernel: average duration (ms) of the env-step kernel launches
  * since the last call with reset != 0, measured with hipEvents on the launch stream - every 4th launch is sampled (the two
  * event records cost ~8 us of stream time per sampled launch; KS_EVENT_STRIDE=1 samples all of them).  Host sync.

@@ -1583,6 +1583,7 @@ struct CtxBase {
     virtual int obs_from_snapshot(const void* snap, const void* rays, void* obs, void* reward, uint8_t* done, void* info, hipStream_t s) = 0;
     virtual int kernel_time(int reset, double* avg_ms, int64_t* launches) = 0;
     virtual int rollout(int n_iter, const ks_rollout_args* args, hipStream_t s) = 0;
+    virtual int rollout_plan(int32_t* mode, int32_t* groups, int32_t* workgroups) = 0;
 };
 
 #define HIPCHK(expr)                                                                         \
@@ -1912,11 +1913,8 @@ template <typename T> struct Ctx : CtxBase {
             *rslot = *ra;
             HIPCHK(hipMemcpyAsync(d_ra, rslot, sizeof *ra, hipMemcpyHostToDevice, s));
             // more groups than resident workgroups: the ready queue (k_rollout); else one group per workgroup, nothing to deal
-            const bool use_queue = rollout_queue && n_wg > resident_wgs && n_wg <= ROLLOUT_QCAP;
-            // one group per workgroup: its four waves run free (k_rollout, round 6); KS_ROLLOUT_WAVES=0 keeps them joined by barriers
-            const bool wave_free = rollout_waves && !use_queue && n_wg <= resident_wgs && lpw == EPW_MAX && LANE_STRIDE == SUBS &&
-                                   (size_t)(wg_rays_words(4, WAVE) + wg_obs_words(4) + 4) <= (size_t)SCR_TOTAL * 4 &&
-                                   (size_t)(((ra->h1 + 15) / 16 + (ra->h2 + 15) / 16) * 4) * 4 * 16 <= (size_t)SCR_TOTAL * 4 * sizeof(T);
+            const bool use_queue = plan_queue();
+            const bool wave_free = plan_waves() && (size_t)(((ra->h1 + 15) / 16 + (ra->h2 + 15) / 16) * 4) * 4 * 16 <= (size_t)SCR_TOTAL * 4 * sizeof(T);
             if (use_queue) {
                 hipLaunchKernelGGL(k_rollout_queue_init, dim3(1), dim3(256), 0, s, d_queue, n_wg);
             }
@@ -1937,6 +1935,20 @@ template <typename T> struct Ctx : CtxBase {
             error = "ks_rollout: hidden widths must be 256-256, 400-300, 128-128 or 64-64";
             return KS_ERR_INVALID;
         }
+    }
+    // more groups than resident workgroups: the ready queue (k_rollout); else one group per workgroup, nothing to deal
+    bool plan_queue() const { return rollout_queue && n_wg > resident_wgs && n_wg <= ROLLOUT_QCAP; }
+    // one group per workgroup: its four waves run free (k_rollout, round 6); KS_ROLLOUT_WAVES=0 keeps them joined by barriers
+    bool plan_waves() const {
+        return rollout_waves && !plan_queue() && n_wg <= resident_wgs && lpw == EPW_MAX && LANE_STRIDE == SUBS &&
+               (size_t)(wg_rays_words(4, WAVE) + wg_obs_words(4) + 4) <= (size_t)SCR_TOTAL * 4;
+    }
+    int rollout_plan(int32_t* mode, int32_t* groups, int32_t* workgroups) override {
+        if (!model_loaded) { error = "ks_rollout_plan before ks_load_model"; return KS_ERR_STATE; }
+        if (mode) *mode = plan_waves() ? KS_PLAN_WAVES : (n_wg <= resident_wgs ? KS_PLAN_WORKGROUPS : (plan_queue() ? KS_PLAN_QUEUE : (rollout_round_robin ? KS_PLAN_ROUND_ROBIN : KS_PLAN_RUNS)));
+        if (groups) *groups = n_wg;
+        if (workgroups) *workgroups = n_wg < resident_wgs ? n_wg : resident_wgs;
+        return KS_OK;
     }
     int substep(const void* ctrl, hipStream_t s) override {
         if (!model_loaded) { error = "ks_substep before ks_load_model"; return KS_ERR_STATE; }
@@ -2088,6 +2100,10 @@ int ks_set_env_params(ks_ctx* ctx, const void* obj_mass, const void* obj_mu, voi
 int ks_rollout(ks_ctx* ctx, int32_t n_iter, const ks_rollout_args* args_host, void* stream) {
     if (!ctx) return KS_ERR_INVALID;
     return ctx->impl->rollout(n_iter, args_host, (hipStream_t)stream);
+}
+int ks_rollout_plan(ks_ctx* ctx, int32_t* mode, int32_t* groups, int32_t* workgroups) {
+    if (!ctx) return KS_ERR_INVALID;
+    return ctx->impl->rollout_plan(mode, groups, workgroups);
 }
 int ks_substep(ks_ctx* ctx, const void* ctrl, void* stream) {
     if (!ctx) return KS_ERR_INVALID;

@@ -1752,11 +1752,12 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     const D bd_lane = bd;
     team.argmin(bd, best);
     if (bd > marginD) return 0;
-    // Ties between equally deep vertices (a standing cylinder's rim, a landing cube's four corners) are decided by rounding.  The fp64
-    // instantiation - the parity instrument - shares the oracle's rule (ko_physics.c collide_plane_hull): the first contact is the
-    // LOWEST-INDEX vertex within 1e-12 m of the deepest one, so that the two agree whatever the order of their arithmetic; in fp32 the
-    // band is below the rounding of these distances and the team's arg-min stands.  (A physical dead band of 1 um was measured in round 3
-    // and NOT kept: tools/experiments/r03_plane_tie_rule.patch)
+    // Ties between equally deep vertices (a standing cylinder's rim, a landing cube's four corners) are decided by rounding.  Wherever the
+    // distances are formed in fp64 (D = double: the fp64 instantiation - the parity instrument - AND, since round 5, the fp32 product with
+    // KS_PLANE_F64 = 2, its default) the oracle's rule applies (ko_physics.c collide_plane_hull): the first contact is the LOWEST-INDEX
+    // vertex within 1e-12 m of the deepest one, so that oracle and kernels agree whatever the order of their arithmetic.  Only an fp32 scan
+    // (KS_PLANE_F64 < 2) keeps the team's arg-min: the band is below the rounding of fp32 distances.  (A physical dead band of 1 um was
+    // measured in round 3 and NOT kept: tools/experiments/r03_plane_tie_rule.patch)
     if constexpr (TIE_RULE) {
         const D lim = bd + TIE_EPS;
         int first = 0x7fffffff;

@@ -356,26 +356,33 @@ class AsyncTrainer(GraphedTrainer):
         if not self.native.lds_free:
             raise ValueError("AsyncTrainer needs the LDS-free learner kernels (hidden widths 256-256 / 128-128 / 64-64): the persistent rollout kernel "
                              "holds every CU's LDS for the whole launch, a learner built on library GEMMs could only run behind it")
-        # How the replicas are kept together (SURVEY 8e; VERDICT r4 next #8):
-        #   "per-update"         every update's two gradient buffers are averaged over the ranks before Adam (north_star's scheme): through the
-        #                        LDS-free peer exchange beside the persistent kernel, or through a host-side backend (gloo);
-        #   "average-per-launch" the ranks cannot map each other's memory and the process group's collectives are library KERNELS (RCCL) that need
-        #                        LDS - which the persistent rollout kernel holds on every CU until its launch ends.  Rather than falling back to lock
-        #                        step, each rank applies the updates of a launch (<= `chunk` env-steps) with its LOCAL gradients, beside its own
-        #                        free-running rollout, and at the END of the launch - where the library kernels can run - parameters, target
-        #                        parameters and Adam moments are averaged over the ranks (one all-reduce of 8 flat buffers, 5.6 MB at 256-256) and the
-        #                        averaged actor is published.  Replicas are bit-identical at every launch boundary and at most one launch of local
-        #                        updates apart in between (periodic model averaging / local SGD: NOT the per-update gradient all-reduce - stated in
-        #                        the bench line as config.replica_sync).  KS_ASYNC_SYNC=average forces it (tests), KS_ASYNC_LIBRARY_ALLREDUCE=1 keeps
-        #                        the per-update library all-reduce (it then only runs between launches: the learner lags a whole launch).
+        # How the replicas are kept together (SURVEY 8e; VERDICT r5 next #6):
+        #   "per-update"         every update's two gradient buffers are averaged over the ranks before Adam (north_star's scheme).  Beside the
+        #                        persistent kernel that is the LDS-free peer exchange (or a host-side backend: gloo).  When the ranks cannot map each
+        #                        other's memory under nccl, the collectives are library KERNELS (RCCL) that need LDS - which the persistent rollout
+        #                        kernel holds on every CU until its launch ends: the learner's stream then only advances BETWEEN launches.  The
+        #                        algorithm stays north_star's; callers bound the learner's lag by keeping launches short (`library_allreduce_chunk`
+        #                        env-steps: bench.py lowers --chunk to it).  The default since round 6.
+        #   "average-per-launch" opt-in (KS_ASYNC_SYNC=average): each rank applies the updates of a launch with its LOCAL gradients beside its own
+        #                        rollout, and at the END of the launch parameters, target parameters and Adam moments are averaged over the ranks
+        #                        (one all-reduce of the flat buffers) and the averaged actor is published.  Periodic model averaging / local SGD: a
+        #                        DIFFERENT algorithm from the per-update gradient all-reduce - it warns when chosen and the bench line names it.
         self.replica_sync = "per-update" if self.distributed else "single rank"
+        self.library_allreduce_chunk = None
         if self.distributed and self.native.exchange is None:
             import torch.distributed as dist
             forced = os.environ.get("KS_ASYNC_SYNC", "")
-            if forced == "average" or (dist.get_backend(policy.process_group) == "nccl" and os.environ.get("KS_ASYNC_LIBRARY_ALLREDUCE", "0") == "0"):
+            if forced == "average":
+                import warnings
+                warnings.warn("AsyncTrainer: KS_ASYNC_SYNC=average - replicas apply LOCAL updates and are averaged at every launch boundary (periodic model "
+                              "averaging), not north_star's per-update gradient all-reduce", RuntimeWarning)
                 self.replica_sync = "average-per-launch"
                 self.native.local_gradients = True                       # native.allreduce() becomes a no-op: the body applies local gradients
                 self.exchange_note += "; free-running rollout kept: local updates, replicas averaged at every launch boundary"
+            elif dist.get_backend(policy.process_group) == "nccl":
+                self.library_allreduce_chunk = int(os.environ.get("KS_ASYNC_LIBRARY_CHUNK", "6"))
+                self.exchange_note += (f"; no peer mapping: per-update library all-reduce, which executes between launches - keep launches at <= "
+                                       f"{self.library_allreduce_chunk} env-steps (the learner lags by at most one launch)")
         if not (eng.native and eng.device_noise and eng._fused_actor_layers() is not None and sim.cfg.auto_reset and sim.obs_env_major):
             raise ValueError("AsyncTrainer needs the fused actor path (3-layer MLP at a supported width, in-kernel noise), auto_reset and env-major obs")
         flat = policy._flat_params["actor"]
@@ -420,15 +427,13 @@ class AsyncTrainer(GraphedTrainer):
         # The persistent launch has one workgroup per compute unit at most; with more 16-env groups than CUs (BASELINE config 5: 8192 envs)
         # every workgroup steps two or three groups in turn (k_rollout).  Balanced only when the groups divide evenly over the CUs: a
         # workgroup with one group more than the others sets the launch's pace - say so.
-        n_groups = (eng.n + 15) // 16 + max(0, len(getattr(sim, "models", [1])) - 1)       # upper bound (one partly filled group per object)
-        cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        self.groups_per_workgroup = (n_groups + cus - 1) // cus
-        if n_groups > cus and n_groups % cus and os.environ.get("KS_ROLLOUT_DEAL", "rr" if getattr(sim, "multi_geom", False) else "queue") != "queue":
-            # (the ready queue of round 5 - the standard library's default - balances any count)
+        self.rollout_plan, n_groups, n_wgs = sim.rollout_plan()              # the library's own decision (ks_rollout_plan)
+        self.groups_per_workgroup = (n_groups + n_wgs - 1) // n_wgs
+        if self.rollout_plan in ("runs", "round-robin") and n_groups % n_wgs:
             import warnings
-            warnings.warn(f"AsyncTrainer: up to {n_groups} env groups on {cus} compute units: some persistent workgroups step {self.groups_per_workgroup} groups per "
-                          f"env-step, others {self.groups_per_workgroup - 1} - the launch runs at the pace of the former (GraphedTrainer's lock-step launches balance "
-                          "such a batch dynamically)", RuntimeWarning)
+            warnings.warn(f"AsyncTrainer: {n_groups} env groups dealt to {n_wgs} persistent workgroups ({self.rollout_plan}): some step {self.groups_per_workgroup} groups per "
+                          f"env-step, others {self.groups_per_workgroup - 1} - the launch runs at the pace of the former (the ready queue, KS_ROLLOUT_DEAL=queue, and "
+                          "GraphedTrainer's lock-step launches balance such a batch dynamically)", RuntimeWarning)
 
     def publish(self):
         """make the actor's current weights the newest published version: copy into the buffer two behind the one in use, then
@@ -536,9 +541,15 @@ class AsyncTrainer(GraphedTrainer):
         world = dist.get_world_size(pol.process_group)
         bufs = [pol._flat_params[k] for k in ("actor", "critic", "actor_target", "critic_target")]
         bufs += [b for net in (nat.actor, nat.critic) for b in (net.exp_avg, net.exp_avg_sq)]
+        # ONE all-reduce: the eight flat buffers packed into one (5.6 MB at 256-256), averaged, unpacked (it was eight blocking
+        # all-reduces and eight scaling kernels per launch boundary)
+        flat = torch.cat([b.reshape(-1) for b in bufs])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=pol.process_group)
+        flat.div_(world)
+        off = 0
         for b in bufs:
-            dist.all_reduce(b, op=dist.ReduceOp.SUM, group=pol.process_group)
-            b.div_(world)
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
         self.publish()
 
     def step(self):

@@ -45,7 +45,7 @@ class KsRolloutArgs(C.Structure):
 
 
 EXPORTS = ["ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_load_model", "ks_load_models", "ks_reset", "ks_reset_objects", "ks_step",
-           "ks_get_state", "ks_set_state", "ks_set_env_params", "ks_substep", "ks_rollout", "ks_obs_from_snapshot", "ks_kernel_time", "ks_version"]
+           "ks_get_state", "ks_set_state", "ks_set_env_params", "ks_substep", "ks_rollout", "ks_rollout_plan", "ks_obs_from_snapshot", "ks_kernel_time", "ks_version"]
 # include/kinova_rollout.h
 ROLLOUT_EXPORTS = ["kr_select_action", "kr_store_transition", "kr_rank_episodes", "kr_wait_min", "kr_wait_min_counted", "kr_commit_episodes", "kr_advance_ring",
                    "kr_sample_windows", "kr_sample_windows_draw", "kr_sample_windows_mixed", "kr_xchg_create", "kr_xchg_connect", "kr_xchg_allreduce_mean", "kr_xchg_status",
@@ -113,6 +113,7 @@ def _bind(L):
     L.ks_rollout.argtypes = [vp, C.c_int32, C.POINTER(KsRolloutArgs), vp]
     L.ks_obs_from_snapshot.argtypes = [vp] * 8
     L.ks_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.ks_rollout_plan.argtypes = [vp, i32p, i32p, i32p]
     i32, f32 = C.c_int32, C.c_float
     L.kr_select_action.argtypes = [i32] + [vp] * 7 + [f32, f32, i32] + [vp] * 4
     L.kr_store_transition.argtypes = [i32] * 5 + [vp] * 21
@@ -288,6 +289,16 @@ class KinovaSim:
                 raise ValueError("set_env_params: one value per env")
         self._check(self.lib.ks_set_env_params(self.ctx, _ptr(ts[0]), _ptr(ts[1]), self._stream()))
         torch.cuda.current_stream(self.device).synchronize()
+
+    ROLLOUT_PLANS = ("waves", "workgroups", "queue", "runs", "round-robin")
+
+    def rollout_plan(self):
+        """(plan, groups, workgroups): how ks_rollout schedules this context's 16-env groups (include/kinova_sim.h: ks_rollout_plan) - "waves" / "workgroups":
+        one group per persistent workgroup (waves free / joined by barriers); "queue": more groups than workgroups, from a ready queue; "runs" /
+        "round-robin": a fixed deal - the launch runs at the pace of the workgroup with the most groups."""
+        m, g, w = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.ks_rollout_plan(self.ctx, C.byref(m), C.byref(g), C.byref(w)))
+        return self.ROLLOUT_PLANS[m.value], g.value, w.value
 
     def kernel_time(self, reset: bool = False):
         """(average ms of the env-step kernel measured with HIP events on the launch stream, launches)."""

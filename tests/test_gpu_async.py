@@ -44,6 +44,21 @@ def _ring_episodes(replay):
                                                         ((256, 256), False, 30, 13, 272), ((256, 256), False, 30, 12, 4096),
                                                         ((256, 256), "cohort", 30, 7, 8192), ((256, 256), True, 12, 5, 4400)])
 def test_free_running_rollout_equals_the_lock_step_calls(hidden, mixed, horizon, per, n):
+    _free_running_equals_lock_step(hidden, mixed, horizon, per, n)
+
+
+@pytest.mark.parametrize("env,n,mixed,plan", [({"KS_ROLLOUT_WAVES": "0"}, 272, False, "workgroups"), ({"KS_ROLLOUT_DEAL": "static"}, 4400, True, "runs"),
+                                              ({"KS_ROLLOUT_DEAL": "rr"}, 4400, True, "round-robin"), ({}, 4400, True, "queue"), ({}, 272, False, "waves")])
+def test_every_scheduling_form_of_the_rollout_kernel_equals_lock_step(monkeypatch, env, n, mixed, plan):
+    """the fixed deals of rounds 3-4 (KS_ROLLOUT_DEAL=static / rr - still the multi-geom library's default) and the barrier-joined
+    workgroup form (KS_ROLLOUT_WAVES=0) are no longer anybody's default in the standard library: exercised here explicitly, with the library's own
+    report of what it runs (ks_rollout_plan)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _free_running_equals_lock_step((256, 256), mixed, 12, 5, n, expect_plan=plan)
+
+
+def _free_running_equals_lock_step(hidden, mixed, horizon, per, n, expect_plan=None):
     """horizon 12: every env runs into the time limit three times in 45 env-steps; horizon 30, 65 env-steps: the (bias-pushed) actor closes
     the hand, check_grasp fires, the scripted lift ends episodes early - the un-stored lift steps and the overwrite of the last stored
     transition (utils.py:309-343) are part of what must match.  n = 4096: the bench's shape (BASELINE config 3: one workgroup on every CU).
@@ -67,6 +82,8 @@ def test_free_running_rollout_equals_the_lock_step_calls(hidden, mixed, horizon,
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)          # (the uneven 4400-env case warns about its imbalance)
         tr = AsyncTrainer(sim, policy, replay, eng, batch_episodes=16)
+    if expect_plan is not None:
+        assert sim.rollout_plan()[0] == expect_plan == tr.rollout_plan, (sim.rollout_plan(), expect_plan)
     for _ in range(chunks):
         sim.rollout(per, tr.args)
         replay.commit_published()

@@ -111,10 +111,17 @@ def test_multi_geom_env_steps_rays_and_observation(shape, precision, tol):
         got = ob.double().cpu().numpy()
         assert np.array_equal(got[0], got[1])                       # two envs, same inputs: identical
         err = np.abs(got[0] - ro)
-        err[48:50] *= 0.1 if precision == 32 else 1.0       # x / z angle of the object about the wrist (atan2 of ~2 cm offsets: ~50 x their error; BowlM 4.2e-3)
-        ray_slots = np.r_[50:67, 70:73]                               # (the 17 rangefinder slots and the three distances derived from them)
-        if precision == 32 and (err[ray_slots] >= tol).sum() == 1:    # one ray may graze a piece's edge on the other side of it (BowlM: slot 71, 1.1e-2)
-            err[ray_slots[int(err[ray_slots].argmax())]] = 0.0
+        # the two excused quantities are bounded explicitly instead of being scaled / zeroed
+        #  - slots 48-49, x / z angle of the object about the wrist: atan2 of ~2 cm offsets, ~50 x their error (BowlM fp32: 4.2e-3)
+        #  - ONE grazing ray in fp32: a ray that passes a piece's edge within rounding hits the other side of it (BowlM: slot 71 = the averaged hit
+        #    coordinate of the palm sensors, 1.1e-2); any OTHER slot, a second ray, or an error beyond 2e-2 fails
+        if precision == 32:
+            assert err[48:50].max() < 10 * tol, (t, err[48:50])
+            err[48:50] = 0.0
+            ray_slots = np.r_[50:67, 70:73]                           # (the 17 rangefinder slots and the three distances derived from them)
+            over = ray_slots[err[ray_slots] >= tol]
+            if len(over) == 1 and shape.startswith("Bowl") and err[over[0]] < 2e-2:
+                err[over[0]] = 0.0
         worst = max(worst, err.max())
         assert err.max() < tol, (t, int(err.argmax()), err.max())
         assert float(rew[0]) == rr and bool(done[0] & 1) == rd
