@@ -87,11 +87,14 @@ def test_multi_geom_one_step_matches_oracle(shape, pose):
     eq, ev, ncon, onc, status = teacher_forced(shape, 32, hq, rec)
     print(f"{shape}: fp32 one-step |dqpos| median {np.median(eq):.2e} p95 {np.percentile(eq, 95):.2e} max {eq.max():.2e}; contact-count mismatches {int((ncon != onc).sum())}/{len(onc)}")
     assert (status == 0).all()
-    assert np.median(eq) <= 2e-7 and np.percentile(eq, 90) <= 2e-6 and eq.max() <= 3e-3
-    assert (ncon != onc).mean() <= 0.03
+    # (round 6: median 3.6 - 9.1e-8, p95 <= 1.5e-6 (BottleS rotated; <= 2.5e-7 elsewhere), max 1.7e-4 (HourB), 4.6e-5 (BottleS), 3.7e-5 (BowlS normal), no
+    #  contact-count mismatch; thresholds = worst x 3 - they were 2e-7 / p90 2e-6 / 3e-3 / 3 % mismatches)
+    assert np.median(eq) <= 2e-7 and np.percentile(eq, 95) <= 4.5e-6 and eq.max() <= 5e-4
+    assert (ncon != onc).sum() == 0
 
 
-@pytest.mark.parametrize("shape,precision,tol", [("BottleS", 64, 1e-8), ("RBowlS", 64, 1e-8), ("TBottleS", 32, 2e-3), ("BowlM", 32, 2e-3)])
+# (fp32, round 6, after the two excused quantities below: TBottleS 2.6e-6, BowlM 1.0e-5 - tolerance = the worse x 5; it was 2e-3: VERDICT r5 next #4)
+@pytest.mark.parametrize("shape,precision,tol", [("BottleS", 64, 1e-8), ("RBowlS", 64, 1e-8), ("TBottleS", 32, 5e-5), ("BowlM", 32, 5e-5)])
 def test_multi_geom_env_steps_rays_and_observation(shape, precision, tol):
     """reset + 6 env.step()s of a closing-and-lifting action stream: observation (incl. the 17 rangefinder slots, which see every piece),
     reward and done of every step against the oracle's env_step"""
@@ -103,7 +106,7 @@ def test_multi_geom_env_steps_rays_and_observation(shape, precision, tol):
     obs = sim.reset(torch.as_tensor(np.stack([q0, q0], 1)), torch.as_tensor(np.repeat(hq[:, None], 2, 1))).double().cpu().numpy()
     ref = o.env_reset(q0)
     worst = np.abs(obs[0] - ref).max()
-    assert np.abs(obs[0] - ref).max() < max(tol * 1e-2, 1e-9 if precision == 64 else 2e-5), np.abs(obs[0] - ref).max()
+    assert np.abs(obs[0] - ref).max() < (1e-9 if precision == 64 else 2e-5), np.abs(obs[0] - ref).max()
     for t in range(6):
         a = np.array([0.0, 0.6, 0.6, 0.6]) if t < 4 else np.array([0.6, 0.6, 0.6, 0.6])
         ob, rew, done, info = sim.step(torch.as_tensor(np.stack([a, a], 1)))
@@ -116,7 +119,7 @@ def test_multi_geom_env_steps_rays_and_observation(shape, precision, tol):
         #  - ONE grazing ray in fp32: a ray that passes a piece's edge within rounding hits the other side of it (BowlM: slot 71 = the averaged hit
         #    coordinate of the palm sensors, 1.1e-2); any OTHER slot, a second ray, or an error beyond 2e-2 fails
         if precision == 32:
-            assert err[48:50].max() < 10 * tol, (t, err[48:50])
+            assert err[48:50].max() < 2e-2, (t, err[48:50])
             err[48:50] = 0.0
             ray_slots = np.r_[50:67, 70:73]                           # (the 17 rangefinder slots and the three distances derived from them)
             over = ray_slots[err[ray_slots] >= tol]

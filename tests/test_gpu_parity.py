@@ -92,10 +92,10 @@ def test_one_step_fp32_matches_oracle(cube):
     # median 3.2e-8, p95 9.3e-8, max 5.0e-7, no state above 1e-5, no contact-count mismatch (round 4: p95 <= 5e-7, 3 % above 1e-5, max 3e-3 allowed)
     assert np.median(eq) <= 1e-7
     assert np.percentile(eq, 95) <= 2.5e-7
-    # the tail: single-point contact POSITION on parallel features (DESIGN.md "known limits" (i)) - a state or two at most, bounded
-    assert tail.mean() <= 0.01
-    assert eq.max() <= 2e-4
-    assert (ncon != onc).sum() <= 1
+    # thresholds = measured x 3 (round 6 measures the same 3.2e-8 / 9.3e-8 / 5.0e-7): no state above 1e-5 any more
+    assert tail.sum() == 0
+    assert eq.max() <= 1.5e-6
+    assert (ncon != onc).sum() == 0
 
 
 @pytest.mark.parametrize("shape", ["mbox", "bbox", "scyl", "mcyl", "bcyl"])
@@ -138,7 +138,8 @@ def test_primitive_objects_one_step_matches_oracle(shape):
     # flat faces resting on the plane and against the finger pads: more states with parallel features than the cube in a pinch;
     # the standing cylinder's rim tie (above) is broken differently in every fp32 state
     # (measured, end of round 5: median 2.0e-8, p95 9e-8 for all five primitives, max 1.0e-5 (mbox) / <= 1.9e-6 (the others), no contact-count mismatch)
-    assert np.median(eq) <= 1e-7 and np.percentile(eq, 95) <= 5e-7 and eq.max() <= 2e-4 and (ncon != onc).mean() <= 0.007
+    # (round 6, the penetration query on fp64 points: max 1.0e-6 (mbox), 1.9e-6 (bbox), 1.7e-6 (scyl), <= 2.8e-7 (mcyl, bcyl); threshold = worst x 3)
+    assert np.median(eq) <= 6e-8 and np.percentile(eq, 95) <= 3e-7 and eq.max() <= 6e-6 and (ncon != onc).sum() == 0
 
 
 def test_config1_episode_free_running(cube):
@@ -196,7 +197,8 @@ def test_batch_config2_first_steps(cube):
         # tail (measured 0.977 / 0.969 / 0.969 of 128 in the middle of round 5; 1.000 with max 9.4e-7 at its end): a finger link that touches the cube's vertical edge a few um deep - libccd's
         # penetration direction is the direction of the closest point of the final portal, ill-conditioned as the depth approaches MPR's
         # 1e-6 tolerance: same point, same depth, normal 2.6 degrees apart between fp32 and fp64 (env 112, substep 3: depth 5.0e-6)
-        assert (rel < 1e-4).mean() > 0.98 and rel.max() < 5e-3, (t, (rel < 1e-4).mean(), rel.max())
+        # (round 6: 1.000 / max 8.6e-7, 2.5e-7, 6.1e-7 over the three env-steps; threshold = measured x 3)
+        assert (rel < 1e-4).mean() >= 0.99 and rel.max() < 3e-6, (t, (rel < 1e-4).mean(), rel.max())
     print("config2 x128: worst median relative qpos error over 3 env-steps", worst)
     sim.close()
 

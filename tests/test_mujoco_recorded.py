@@ -332,7 +332,7 @@ def test_gpu_replays_the_recorded_demonstrations(rec):
     from kinovagrasping_amd.sim import KinovaSim
     sim = KinovaSim(10, "CubeS", solver_iterations=SOLVER_ITERATIONS, horizon=30)
     succ, steps = _demo_episodes(sim, rec)
-    _check_demos(succ, steps, rec, min_exact=5)          # (fp32: one of the six may end a step early)
+    _check_demos(succ, steps, rec, min_exact=6)          # (round 6, fp32: the six common lifts last exactly as long as recorded - 23 24 . 23 23 . 28 24)
     sim.close()
 
 
@@ -401,7 +401,8 @@ def test_kernel_source_replays_the_recorded_mujoco_contact_trajectory_on_the_hos
     hq = scenarios.hand_quat_for("normal")
     ref_cols = list(range(24, 31)) + [21, 22, 23]
     cols = [2, 3, 5, 7, 4, 6, 8, 9, 10, 11]
-    for prec, tol_exact, tol_close, tol_all in ((64, 1e-9, 2e-7, 8e-4), (32, 3e-5, 3e-5, 3e-3)):
+    # (fp32 host lane, round 6: rows 1-40 3.7e-7, rows 41-45 7.3e-7 - thresholds = measured x 3; the GPU asserts 6e-7 / row)
+    for prec, tol_exact, tol_close, tol_all in ((64, 1e-9, 2e-7, 8e-4), (32, 1.2e-6, 2.2e-6, 1e-3)):
         lane = Lane(old_env.old_env_blob(), prec, iters=100)
         st = (old_env.start_qpos(pf2[0]), np.zeros(15), np.zeros(15))
         got = [np.zeros(10)]
