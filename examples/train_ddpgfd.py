@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--tau", type=float, default=0.001, help="soft target update rate (reference: 0.0005, main_DDPGfD.py:894 - for 100 updates per episode of one env)")
     ap.add_argument("--target-every", type=int, default=1, help="target networks follow every this many updates (reference: 10, DDPGfD.py:64-66,360-366)")
     ap.add_argument("--expl-noise", type=float, default=0.1, help="exploration noise, std = 0.8 x this (main_DDPGfD.py:443-446: 0.1)")
+    ap.add_argument("--dump-replay", default=None, help="write the replay (last 1500 agent + first 400 expert episodes) and the four networks as one .npz "
+                    "(tools/r06/reference_learner_on_replay.py runs the REFERENCE's train_batch on it)")
     ap.add_argument("--save", default=None, help="write the trained policy as the reference's 4-file checkpoint with this prefix")
     args = ap.parse_args()
     torch.manual_seed(args.seed)
@@ -135,6 +137,21 @@ def main():
             ev = f"  eval (no noise, 1024 starts): lift success {res['num_success'] / 1024:.3f}"
             t_eval += time.perf_counter() - te
         print(f"step {it + 60:5d}  episodes {d_ep:7d}  training lift rate {d_lift / max(1, d_ep):.3f}  critic loss {ls[0]:9.3f}  {n * (it + 60) / dt:9.0f} env-steps/s{ev}")
+    if args.dump_replay:
+        tr.flush(finish_update=True)
+        torch.cuda.synchronize()
+        out = {}
+        for name, rep, keep in (("agent", agent, slice(-1500, None)), ("expert", expert, slice(0, 400))):
+            eps = rep.host_episodes()[keep] if rep is not None else []
+            out[f"{name}_lens"] = np.array([len(e["reward"]) for e in eps])
+            for f in ("state", "action", "next_state", "reward"):
+                out[f"{name}_{f}"] = np.concatenate([np.asarray(e[f], dtype=np.float32) for e in eps]) if eps else np.zeros(0, np.float32)
+        for name, net in (("actor", policy.actor), ("critic", policy.critic), ("actor_target", policy.actor_target), ("critic_target", policy.critic_target)):
+            for k, v in net.state_dict().items():
+                out[f"{name}.{k}"] = v.detach().cpu().numpy()
+        out["updates"] = np.array(tr.updates)
+        np.savez_compressed(args.dump_replay, **out)
+        print("dumped", args.dump_replay, {k: v.shape for k, v in out.items() if k.endswith("_lens")}, "after", tr.updates, "updates")
     if args.save:
         tr.flush(finish_update=True)
         policy.save(args.save)

@@ -944,9 +944,12 @@ template <typename T> KS_HD void hull_point(const T* R, const T* p, KS_TAB const
 #ifndef KS_MPR_SM
 #define KS_MPR_SM 1             // 0: the fp32 product runs the template above (fp32 points, cold unless KS_MPR_WARM=1): A/B and the divergence study
 #endif
-// The query is an out-of-line function with the support inlined (KS_FN).  Inlined into `collision` it took the stepping kernels past their register
-// budget (the learner's waves no longer fit beside them: training at 0.7 x); with the SUPPORT out of line instead - the pair record then lives in
-// private memory - sim-only fell from 3.1 to 2.5 M env-steps/s.
+// The query is inlined into `collision` like the other narrow-phase queries.  That takes the stepping kernels' own register count past what leaves room
+// for the learner's waves beside them (k_rollout 256 + 122 where 376 is the limit: training at 0.7 x) - the kernels' budgets are therefore SET in the
+// source (ks_api.hip: KS_ROLLOUT_NUM_VGPR / KS_STEP_NUM_VGPR) and the excess is spilled.  Measured alternatives: the query out of line - every call
+// saves 34 callee-saved registers of all 64 lanes for the two or three lanes that have a query, 110 MB of write-backs per env-step of 4096 envs
+// (k_rollout's WRITE_SIZE 144 MB against 45 MB inlined), -1.7 % in training; the SUPPORT out of line - the pair record then lives in private
+// memory -: sim-only 3.1 -> 2.5 M env-steps/s.
 struct SuppD {
     double v[3];
     int i1, i2;
@@ -1085,8 +1088,8 @@ KS_HD bool mpr_readoff_f64(const PairGeo<T>& g, const SuppD& v0, const SuppD& v1
 // stand on the same portal (tests/studies/divergence_table.py: 162 of 168 grasp-and-lift envs within 1e-4 after 200 substeps; fp32 points: 146).
 enum { MPR_S_V1 = 0, MPR_S_V2 = 1, MPR_S_V3 = 2, MPR_S_INSIDE = 3, MPR_S_REFINE = 4 };
 template <typename T>
-KS_FN bool mpr_penetration_sm(PairGeo<T>& g_io, T tol_, int max_iter, T* depth_o, T* dir_o, T* pos_o) {
-    // (an out-of-line function: the caller's pair record and result slots are private MEMORY from here - worked on in registers, written once)
+KS_NARROW bool mpr_penetration_sm(PairGeo<T>& g_io, T tol_, int max_iter, T* depth_o, T* dir_o, T* pos_o) {
+    // (the pair record and the result slots are worked on in local copies and written once at the end)
     PairGeo<T> g = g_io;
     T depth_[1] = {0}, dir[3] = {0, 0, 0}, pos[3] = {0, 0, 0};
     T* depth = depth_;
