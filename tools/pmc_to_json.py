@@ -20,7 +20,7 @@ out = {
     "workload": ("bench.py --mode sim, 4096 envs, CubeS" if workload == "sim" else
                  "bench.py --mode sim --shape BowlS, 4096 envs: libkinova_sim_mg.so (hull tables in global memory, 9 hulls on the floor, ~15 contacts per env at rest)" if workload == "mg" else
                  "bench.py --rollout free (config 3: DDPG training, 4096 envs, free-running rollout kernel, learner HIP graphs; counters on every dispatch, "
-                 "dispatches serialised by the collector so k_rollout runs alone; per-launch figures divided by the 10 env-steps of a launch) after 150 pre-training updates from the committed bench policy (the collector segfaults with 600)" if workload == "free" else
+                 "dispatches serialised by the collector so k_rollout runs alone; per-launch figures divided by the 10 env-steps of a launch) after 150 pre-training updates from the committed bench policy + the bench's own 300 (the collector segfaults with 600 more; the regime is pinned by the committed policy, not by their number)" if workload == "free" else
                  "bench.py --eager (config 3: DDPG training, 4096 envs, learner launched op by op - counter collection with the kernel filter segfaults when the learner runs from HIP graphs) after 600 pre-training updates") +
                 " (tools/pmc_run.sh: rocprofv3 --kernel-trace --pmc, one counter set per pass, last 40 launches of each pass; free: last 2 launches = 20 env-steps)",
     "source": src,
@@ -36,8 +36,9 @@ out = {
     "note": ("per env-step of k_rollout: fetch = the actor's weights for every workgroup and env-step (L2 hits) + env state + pair memory + the rays' mesh nodes + "
              "1/10 of the per-launch staging of the hull / model tables; write = state + body-pose snapshot + rays + observation (x3: output, next policy input, "
              "terminal) + replay row + pair memory, stored as 4-byte columns of [field][env] arrays (~12 MB of output stores per env-step) + write-backs of the "
-             "private-memory frame (312 B per lane: spilled values of the inlined solver, a 12-word indexed array in `collision`; evicted lines, not a count of the "
-             "stores - what the frame costs is measured in profiles/r05_scratch_probe.txt), DESIGN section 5.  The counters sit on the L2's memory side: Infinity-Cache hits are included, "
+             "private-memory frame (round 6: 424 B per lane under the kernel's register budget - spilled values of the inlined solver and of the fp64 penetration query, a "
+             "12-word indexed array in `collision`; evicted lines, not a count of the stores - what a frame costs was measured in profiles/r05_scratch_probe.txt; with the "
+             "query out of line its 34 callee-saved registers alone made this 144 MB: profiles/r06_mpr_variants.txt), DESIGN section 5.  The counters sit on the L2's memory side: Infinity-Cache hits are included, "
              "so this is an upper bound on HBM traffic.") if workload == "free" else
             "fetch = per-workgroup staging of the hull / model tables (256 workgroups x ~50 KB, L2 / MALL hits count) + env state + "
             "pair memory + the in-step rays' mesh nodes; write = state + snapshot + rays + pair memory (4.9 MB) + write-through of the "
