@@ -6,7 +6,10 @@ examples/train_ddpgfd.py in the reference's schedule (107 updates per env-step o
 reference's to 1e-6 per call (tests/test_learner_golden.py), which makes a bug of ours unlikely but does not show that DDPGfD.py behaves the same over
 100 k updates.  Here both learners continue FROM THE SAME STATE on THE SAME REPLAY: the replay and the four networks dumped from a GPU run
 (examples/train_ddpgfd.py --dump-replay) are loaded into the reference's ReplayBuffer_Queue + DDPGfD and into this repo's HostEpisodeReplay + DDPGfD
-(autograd implementation, CPU), and each runs N more updates on the now static replay with its own np.random stream.
+(autograd implementation, CPU), and each runs N more updates on the now static replay with its own np.random stream.  The reference's train_batch is
+given THIS repo's HostEpisodeReplay as its buffers: its own sampler builds tensors from lists of arrays (~1 s per batch of 1600 windows); HostEpisodeReplay draws
+the same windows from the same np.random stream bit for bit (tests/test_learner_golden.py::test_sampler_consumes_the_same_random_stream).  The update rule -
+targets, n-step returns, losses, optimiser steps, target schedule - is the reference's code.
 usage: python tools/r06/reference_learner_on_replay.py gpurun_out/r06/ref_schedule_replay.npz [updates]"""
 import sys, time
 from pathlib import Path
@@ -20,7 +23,7 @@ import utils as ref_utils          # noqa: E402
 from kinovagrasping_amd.ddpgfd import DDPGfD      # noqa: E402
 from kinovagrasping_amd.replay import HostEpisodeReplay      # noqa: E402
 
-D = np.load(sys.argv[1])
+D = dict(np.load(sys.argv[1]))          # (every array decompressed once)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 torch.set_num_threads(4)
 
@@ -53,28 +56,24 @@ load_nets(ref)
 ref.actor_optimizer = torch.optim.Adam(ref.actor.parameters(), lr=1e-4)
 ref.critic_optimizer = torch.optim.Adam(ref.critic.parameters())
 ref_utils.device = ref_ddpg.device = torch.device("cpu")
-rb = {k: ref_utils.ReplayBuffer_Queue(82, 4, 100000, 5) for k in ("agent", "expert")}
 ours_b = {k: HostEpisodeReplay() for k in ("agent", "expert")}
-for k in rb:
+for k in ours_b:
     for ep in episodes(k):
         L = len(ep["reward"])
-        rb[k].add_episode(1)
-        for t in range(L):
-            rb[k].add(ep["state"][t], ep["action"][t], ep["next_state"][t], ep["reward"][t], float(t == L - 1))
-        rb[k].add_episode(0)
         nd = np.ones(L, np.float32); nd[-1] = 0
         ours_b[k].add_episode_arrays(ep["state"], ep["action"], ep["next_state"], ep["reward"], nd)
 ours = DDPGfD(82, 4, 0.8, 5, tau=0.0005, batch_size=64, hidden=(h1, h2))
 load_nets(ours)
-print(f"replay: agent {rb['agent'].replay_ep_num} episodes, expert {rb['expert'].replay_ep_num}; networks after {int(D['updates'])} updates of the GPU run; {N} more updates each "
+print(f"replay: agent {ours_b['agent'].replay_ep_num} episodes, expert {ours_b['expert'].replay_ep_num}; networks after {int(D['updates'])} updates of the GPU run; {N} more updates each "
       f"on the static replay (64 episodes x 25 five-step windows per update, 30 % expert, targets every 10th update at tau 0.0005)")
+sys.stdout.flush()
 print(f"{'updates':>8} {'reference critic loss':>22} {'ours critic loss':>18}   {'reference |Q| mean':>18} {'ours |Q| mean':>14}")
 st_r, st_o = np.random.RandomState(1).get_state(), np.random.RandomState(1).get_state()
 acc_r, acc_o, t0 = [], [], time.time()
 probe = torch.from_numpy(np.concatenate([e["state"] for _, e in zip(range(50), episodes("agent"))]))
 for it in range(1, N + 1):
     np.random.set_state(st_r)
-    lr_ = ref.train_batch(30, rb["expert"], rb["agent"], 5, prob=0.3)
+    lr_ = ref.train_batch(30, ours_b["expert"], ours_b["agent"], 5, prob=0.3)
     st_r = np.random.get_state()
     np.random.set_state(st_o)
     lo_ = ours.train_batch(30, ours_b["expert"], ours_b["agent"], 5, prob=0.3)
