@@ -14,10 +14,11 @@ the rank.  4096 envs per GPU (BASELINE metric), CubeS, 'normal' hand pose, env i
 
 Timed region (round 3): in ddpg mode the policy is first trained for `--pretrain-updates` (1500) untimed env-steps - the hands
 then close into contact-rich grasps and the envs' episode clocks are spread over the 30 phases - then W warm-up steps, then
-EXACTLY K timed steps.  (Rounds 1-2 timed the first episodes of a random policy, the cheapest regime.)
+`--repeats` (3) timed windows of EXACTLY K steps each, every one between a barrier + synchronize; the line is the window of median duration
+(`timed_windows_ms_per_step` lists all).  (Rounds 1-2 timed the first episodes of a random policy, the cheapest regime.)
 
-Rollout form (--rollout, default auto): the free-running per-workgroup kernel k_rollout (actor + 15 substeps + rays + observation + replay
-write in one persistent launch of --chunk env-steps, learner graphs beside it) when the widths are LDS-free (256-256 / 128-128 / 64-64) and
+Rollout form (--rollout, default auto): the free-running kernel k_rollout (actor + 15 substeps + rays + observation + replay write in one
+persistent launch of --chunk env-steps in which every wave loops over its own four envs, learner graphs beside it) when the widths are LDS-free (256-256 / 128-128 / 64-64) and
 every workgroup is resident in one round; otherwise - config 5, 400-300, --eager, --serial-learner, or --rollout lockstep - one k_env_step
 launch per env-step from HIP graphs.  `config.launch` says which one ran.
 

@@ -639,9 +639,6 @@ template <typename T> KS_HD int support_cell(const T* ld) {
     return ((2 * axis + (major < 0 ? 1 : 0)) * SUPPORT_R + iu) * SUPPORT_R + iv;
 }
 
-#ifdef KS_COUNT_CLIMB
-static long ks_climb_rounds = 0, ks_mpr_supports = 0, ks_mpr_queries = 0, ks_mpr_hinted = 0;     // host-only study counters (tools/r06)
-#endif
 // the climb: from the better of `hint` (the previous support vertex) and `tab` (the support vertex of the cube-map cell
 // the direction falls in) to the support vertex along the hull-frame direction ld
 template <typename T>
@@ -664,9 +661,6 @@ KS_HD void hull_climb(const T* R, const T* p, KS_TAB const T* V, KS_TAB const un
     bool tab_pending = true;
 #endif
     for (int guard = 0; guard < 4096; guard++) {
-#ifdef KS_COUNT_CLIMB
-        ks_climb_rounds++;
-#endif
         const int c0 = off[cur], c1 = off[cur + 1];
         int nxt = cur;
         for (int c = c0; c < c1; c += 2) {
@@ -780,9 +774,6 @@ template <typename T> KS_HD void minkowski_point_ids(const PairGeo<T>& g, int i,
 }
 
 template <typename T> KS_HD void mpr_support(PairGeo<T>& g, const T* dir, Supp<T>& o) {
-#ifdef KS_COUNT_CLIMB
-    ks_mpr_supports++;
-#endif
 #ifdef KS_STAMP_HULL
     const int h1_ = g.hint1, h2_ = g.hint2;
 #endif

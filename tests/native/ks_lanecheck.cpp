@@ -246,9 +246,6 @@ int lc_reset_obs(void* h, int prec, double* qpos, double* qvel, double* warm, co
                       : env_step_t<float>(l->f.m, qpos, qvel, warm, hq, nullptr, 0, 0, obs, reward, done, rays, 1);
 }
 void lc_set_warm(void* h, int on) { LC* l = (LC*)h; l->warm = on != 0; std::memset(l->gw, 0, sizeof l->gw); }
-#ifdef KS_COUNT_CLIMB
-void lc_counters(long* out) { out[0] = ks_climb_rounds; out[1] = ks_mpr_supports; out[2] = ks_mpr_queries; out[3] = ks_mpr_hinted; }
-#endif
 void lc_set_mixed_variant(int v) { g_mixed_variant = v % 10; g_state_rounding = v / 10; }
 int lc_con_stride() { return CON_STRIDE; }
 int lc_ncon_max() { return NCON_MAX; }

@@ -1,6 +1,6 @@
-"""The free-running rollout kernel (ks_rollout / pipeline.AsyncTrainer): every stepping workgroup loops over its own 16 envs -
-in-kernel actor forward + noise + selection rule, 15 substeps, rays, observation, replay write - without waiting for any other
-workgroup.  Scheduling is the only thing that changes: per env, the trajectory, the noise stream and the stored transitions are
+"""The free-running rollout kernel (ks_rollout / pipeline.AsyncTrainer): every stepping wave loops over its own 4 envs (round 6; with more 16-env
+groups than compute units: every workgroup over its groups, from a ready queue or a fixed deal) - in-kernel actor forward + noise + selection
+rule, 15 substeps, rays, observation, replay write - without waiting for any other wave or workgroup.  Scheduling is the only thing that changes: per env, the trajectory, the noise stream and the stored transitions are
 those of the lock-step calls (kr_actor_select -> ks_step -> kr_store_transition), bit for bit, for the same weights."""
 import numpy as np
 import pytest
