@@ -275,6 +275,40 @@ def test_long_horizon_parity_through_the_env_step_path_210_substeps():
     assert sum(within.values()) >= sum(ENVSTEP_LONG_HORIZON_MEASURED.values()) - 2
 
 
+def test_env_step_path_equals_fifteen_substep_calls(cube):
+    """ks_step (15 substeps in one launch, pair memory carried along) against 15 ks_substep calls with the controls the env layer derives from the same
+    action (cold queries, nothing remembered): since round 6 the penetration query remembers nothing, so the two paths differ only by the distance query's
+    remembered simplex - which does not change what it converges to.  256 CubeS envs, closing grasp + lift script, 12 env-steps = 180 substeps of
+    approach, contact and lift.  (With round 5's warm-started penetration query the two paths parted at the first flat contact.)"""
+    n, T = 256, 12
+    q0, hq = scenarios.config2_states(n)
+    script = np.array([[0.0, 0.6, 0.5, 0.7]] * 9 + [[0.6, 0.5, 0.5, 0.5]] * (T - 9))
+    o = ko.OracleSim(cube, hq[:, 0].copy(), solver_iterations=SOLVER_ITERATIONS)
+    o.env_reset(q0[:, 0].copy())
+    a_sim = _sim(n, "CubeS", solver_iterations=SOLVER_ITERATIONS, horizon=0)
+    b_sim = _sim(n, "CubeS", solver_iterations=SOLVER_ITERATIONS, horizon=0)
+    for s_ in (a_sim, b_sim):
+        s_.reset(torch.as_tensor(q0), torch.as_tensor(hq))
+    worst = []
+    for t in range(T):
+        a = np.repeat(script[t][:, None], n, 1)
+        a_sim.step(torch.as_tensor(a))
+        ctrl = ko.env_ctrl(o.view("geom_xpos").reshape(-1, 3)[1], o.view("geom_xmat").reshape(-1, 9)[1], script[t])[2]       # (the hand's rotation is constant)
+        ct = torch.as_tensor(np.repeat(ctrl[:, None], n, 1))
+        for _ in range(15):
+            b_sim.substep(ct)
+        qa = a_sim.get_state()["qpos"].double().cpu().numpy()
+        qb = b_sim.get_state()["qpos"].double().cpu().numpy()
+        rel = np.abs(qa - qb).max(0) / np.maximum(1e-3, np.abs(qb).max(0))
+        worst.append(rel)
+    rel = np.array(worst)
+    ncon = a_sim.get_state()["ncon"].float().mean().item()
+    print(f"ks_step vs 15 x ks_substep over {T} env-steps: median {np.median(rel[-1]):.1e}, p95 {np.percentile(rel[-1], 95):.1e}, max {rel.max():.1e}; "
+          f"envs within 1e-5 at the end {np.mean(rel[-1] <= 1e-5):.3f}; contacts per env at the end {ncon:.2f}")
+    assert np.median(rel[-1]) < 1e-6 and np.mean(rel[-1] <= 1e-4) >= 0.97
+    a_sim.close(); b_sim.close()
+
+
 def test_fp64_kernels_track_the_oracle_free_running_for_200_substeps():
     """What remains of the long-horizon gap when rounding is taken away: the fp64 instantiation of the SAME kernels, free running
     (no teacher forcing) for 200 consecutive substeps on all 168 grasp-and-lift envs of the test above - 14 shapes x 3 poses x 4
