@@ -157,7 +157,8 @@ int ks_obs_from_snapshot(ks_ctx *ctx, const void *snap, const void *rays, void *
  *     check_grasp / scripted-lift rule  ->  15 substeps  ->  rangefinder rays  ->  observation / reward / done / auto-reset
  *     ->  replay write (open-episode buffers) + episode hand-over
  * i.e. what kr_actor_select + ks_step + kr_store_transition do per env-step (main_DDPGfD.py:424-464 around ENV:1495-1552), fused.
- * A lock-step launch lasts as long as its slowest wave (1.6 - 1.9 x the median); here a workgroup starts its next env-step the
+ * A lock-step launch lasts as long as its slowest wave (1.6 - 1.9 x the median); here a wave (round 6: with one 16-env group per
+ * workgroup the four waves of a workgroup never meet inside a launch; otherwise a workgroup) starts its next env-step the
  * moment it has finished the last.  Per env the arithmetic, the noise stream (Philox keyed by seed, the env's own step count,
  * env) and therefore the trajectory are those of the lock-step calls for the same weights.
  * A context with more 16-env groups than the GPU has compute units (8192 envs; many objects: one partly filled group per object)
@@ -200,6 +201,13 @@ typedef struct {
     uint8_t *cur_sel;                /* [n] */
     int64_t *pub_len;                /* [2][n] */
     int64_t *counters;               /* [4]: episodes finished, lifted, kept, dropped (a -DKS_ROLLOUT_STAMP diagnostic build writes [8 + 4 * 512 + 8]) */
+    /* Round 6, opt-in: 0 = every env does exactly n_iter env-steps (the default and what every parity test runs).  > 0: a TIME budget in ticks of the
+     * 100 MHz device clock - a wave starts no further env-step of its four envs once that long has passed since it entered the launch, so envs advance
+     * by time: between 1 and n_iter env-steps each, steps_total[] says how many.  Per env the trajectory is still the lock-step one (same arithmetic, noise
+     * keyed by the env's own step count).  For contexts whose objects differ widely in cost (a curriculum stage holding bowls and cubes: the slowest
+     * object otherwise paces every env) - at the price of an uneven object mix in what is collected.  Needs the wave form (ks_rollout_plan:
+     * KS_PLAN_WAVES), KS_ERR_STATE otherwise. */
+    int64_t budget_ticks;
 } ks_rollout_args;
 int ks_rollout(ks_ctx *ctx, int32_t n_iter, const ks_rollout_args *args_host, void *stream);
 

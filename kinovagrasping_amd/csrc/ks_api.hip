@@ -56,6 +56,7 @@ template <typename T> struct Buffers {
     int32_t *obj_id;              // [N]
     int32_t *slot_env;            // [n_wg * epw]
     int32_t *wg_model;            // [n_wg]
+    int32_t *n_used;              // [1] groups of the list that hold envs (k_slots)
     T *nominal;                   // [n_models][2] object mass / object-hand friction of every model as compiled
     // the ray pool of a stepping launch (wg_ray_pool): [0] tickets published, [1] tickets claimed, [2] workgroups that have left,
     // [3] workgroups that have started,
@@ -1075,8 +1076,11 @@ __global__ __launch_bounds__(WG) KS_ROLLOUT_REGS void k_rollout(const Model<floa
     if (wave_free) {
         // ---- ONE GROUP PER WORKGROUP (4096 envs on 256 CUs, the metric's shape), round 6: from here on the four waves never meet again -
         // each loops over its own four envs (rollout_iter_wave) and leaves when it has done its n_iter env-steps.
+        // (opt-in time budget, ks_rollout_args.budget_ticks: the wave starts no further env-step once the budget has passed - at least one)
+        const long long budget = rap->budget_ticks, t_end = wall_clock64() + budget;
 #pragma clang loop unroll(disable)
         for (int it = 0; it < n_iter; it++) {
+            if (budget > 0 && it > 0 && wall_clock64() - t_end > 0) break;
             const Model<T>* mi = ml;
             Hulls<T>* hi = hup;
             const Buffers<T>* bi = bdev;
@@ -1293,7 +1297,7 @@ __global__ void k_store_init(Buffers<T> b, const int32_t* __restrict__ env_ids, 
 // padded to whole workgroups with -1.  One workgroup of 256 threads; thread t owns a contiguous chunk of envs.
 constexpr int SLOT_THREADS = 256, MODELS_MAX = 48;      // (48: the reference's whole object table - 42 keys - fits one context)
 __global__ __launch_bounds__(SLOT_THREADS) void k_slots(const int32_t* __restrict__ obj_id, int N, int n_models, int epw, int n_wg,
-                                                          int32_t* __restrict__ slot_env, int32_t* __restrict__ wg_model) {
+                                                          int32_t* __restrict__ slot_env, int32_t* __restrict__ wg_model, int32_t* __restrict__ n_used) {
     __shared__ int cnt[SLOT_THREADS][MODELS_MAX + 1];     // +1: odd stride
     __shared__ int base[MODELS_MAX + 1];
     const int t = threadIdx.x, chunk = (N + SLOT_THREADS - 1) / SLOT_THREADS, e0 = t * chunk, e1 = e0 + chunk < N ? e0 + chunk : N;
@@ -1313,6 +1317,7 @@ __global__ __launch_bounds__(SLOT_THREADS) void k_slots(const int32_t* __restric
         for (int m = 0; m < n_models; m++)
             for (int w = base[m] / epw; w < base[m + 1] / epw && w < n_wg; w++) wg_model[w] = m;
         for (int w = base[n_models] / epw; w < n_wg; w++) wg_model[w] = 0;        // idle workgroups
+        *n_used = base[n_models] / epw < n_wg ? base[n_models] / epw : n_wg;      // groups that hold envs (the list is sized for one partly filled group per object)
     }
     __syncthreads();
     for (int e = e0; e < e1; e++) {
@@ -1625,6 +1630,7 @@ template <typename T> struct Ctx : CtxBase {
     }
     Model<T>* d_model = nullptr;          // [n_models] model table
     int n_models = 0, n_wg = 0;
+    int32_t n_groups = 0;                 // groups of the slot list that hold envs (<= n_wg): what ks_rollout deals
     std::map<std::pair<size_t, uint64_t>, void*> shared;      // uploaded arrays by (bytes, content hash): the hand's meshes are
                                                               // the same in every object's blob and are kept once
     std::vector<void*> allocs;
@@ -1758,14 +1764,16 @@ template <typename T> struct Ctx : CtxBase {
         n_wg = (cfg.n_envs + lpw - 1) / lpw + (nm - 1);
         if ((r = alloc(&b.slot_env, (size_t)n_wg * lpw))) return r;
         if ((r = alloc(&b.wg_model, (size_t)n_wg))) return r;
+        if ((r = alloc(&b.n_used, (size_t)1))) return r;
         if ((r = alloc(&b.rayq, (size_t)4 + 2 * (size_t)n_wg))) return r;
         // the rays pooled over the launch (wg_ray_pool); KS_RAY_POOL=0 makes every workgroup cast its own envs' rays
         if (obs_in_step && cfg.frame_skip >= 1 && !(getenv("KS_RAY_POOL") && getenv("KS_RAY_POOL")[0] == '0')) {
             ray_pool = 2;
         }
-        hipLaunchKernelGGL(k_slots, dim3(1), dim3(SLOT_THREADS), 0, 0, b.obj_id, cfg.n_envs, n_models, lpw, n_wg, b.slot_env, b.wg_model);
+        hipLaunchKernelGGL(k_slots, dim3(1), dim3(SLOT_THREADS), 0, 0, b.obj_id, cfg.n_envs, n_models, lpw, n_wg, b.slot_env, b.wg_model, b.n_used);
         HIPCHK(hipGetLastError());
         HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(&n_groups, b.n_used, sizeof(int32_t), hipMemcpyDeviceToHost));
         if ((r = alloc(&d_b, (size_t)1))) return r;
         if ((r = alloc(&d_out, (size_t)1))) return r;
         if (!h_out) HIPCHK(hipHostMalloc((void**)&h_out, (H_OUT_RING + CAPTURE_RECORDS) * sizeof(ObsOut<T>), hipHostMallocDefault));
@@ -1844,7 +1852,15 @@ template <typename T> struct Ctx : CtxBase {
                            (const T*)mass_friction, n_models, cfg.n_envs);
         // objects changed: regroup the stepping kernel's work list by object
         if (object_id && n_models > 1)
-            hipLaunchKernelGGL(k_slots, dim3(1), dim3(SLOT_THREADS), 0, s, b.obj_id, cfg.n_envs, n_models, lpw, n_wg, b.slot_env, b.wg_model);
+        {
+            hipLaunchKernelGGL(k_slots, dim3(1), dim3(SLOT_THREADS), 0, s, b.obj_id, cfg.n_envs, n_models, lpw, n_wg, b.slot_env, b.wg_model, b.n_used);
+            // how many groups hold envs decides how ks_rollout schedules them (one group per workgroup: free waves): read it back - a reset that
+            // changes objects is not a hot path; under stream capture the conservative count (every slot of the list) stands
+            if (!stream_is_capturing(s)) {
+                HIPCHK(hipMemcpyAsync(&n_groups, b.n_used, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+            } else n_groups = n_wg;
+        }
         return post_reset(obs, s);
     }
     int step(const void* action, void* obs, void* reward, uint8_t* done, void* info, void* final_obs, hipStream_t s) override {
@@ -1901,6 +1917,10 @@ template <typename T> struct Ctx : CtxBase {
             if ((ra->h1 | ra->h2) & 3) { error = "ks_rollout: hidden widths must be multiples of 4"; return KS_ERR_INVALID; }
             if ((size_t)(((ra->h1 + 15) / 16 + (ra->h2 + 15) / 16) * 4 + 4) * 16 * 16 + 16 > (size_t)SCR_TOTAL * lpw * sizeof(T)) { error = "ks_rollout: no LDS for the policy"; return KS_ERR_STATE; }
             const int N = cfg.n_envs;
+            if (ra->budget_ticks != 0 && (ra->budget_ticks < 0 || !(plan_waves() && (size_t)(((ra->h1 + 15) / 16 + (ra->h2 + 15) / 16) * 4) * 4 * 16 <= (size_t)SCR_TOTAL * 4 * sizeof(T)))) {
+                error = "ks_rollout: a time budget needs the wave form of the rollout kernel (ks_rollout_plan: KS_PLAN_WAVES)";
+                return KS_ERR_STATE;
+            }
             const ObsOut<T> out{(T*)ra->sim_obs, (T*)ra->sim_reward, ra->sim_done, (T*)ra->sim_info, (T*)ra->sim_final_obs, cfg.horizon, cfg.auto_reset, cfg.obs_env_major};
             const bool capturing = stream_is_capturing(s);
             ObsOut<T>* slot = pinned_record(capturing, h_out, (unsigned)h_out_next++, captured_out);
@@ -1916,14 +1936,14 @@ template <typename T> struct Ctx : CtxBase {
             const bool use_queue = plan_queue();
             const bool wave_free = plan_waves() && (size_t)(((ra->h1 + 15) / 16 + (ra->h2 + 15) / 16) * 4) * 4 * 16 <= (size_t)SCR_TOTAL * 4 * sizeof(T);
             if (use_queue) {
-                hipLaunchKernelGGL(k_rollout_queue_init, dim3(1), dim3(256), 0, s, d_queue, n_wg);
+                hipLaunchKernelGGL(k_rollout_queue_init, dim3(1), dim3(256), 0, s, d_queue, n_groups);
             }
 #define KS_ROLLOUT_CASE(A, B)                                                                                                                         \
     if ((ra->h1 + 15) / 16 == A && (ra->h2 + 15) / 16 == B) {                                                                                                 \
         HIPCHK(hipFuncSetAttribute((const void*)k_rollout<A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));                        \
-        hipLaunchKernelGGL((k_rollout<A, B>), dim3(n_wg < resident_wgs ? n_wg : resident_wgs), dim3(WG), step_lds, s, d_model, b, (const Buffers<T>*)d_b, N, cfg.frame_skip,              \
+        hipLaunchKernelGGL((k_rollout<A, B>), dim3(n_groups < resident_wgs ? n_groups : resident_wgs), dim3(WG), step_lds, s, d_model, b, (const Buffers<T>*)d_b, N, cfg.frame_skip,              \
                            cfg.solver_iterations, lpw, (int)cfg.pair_memory, (const ObsOut<T>*)d_out, (const ks_rollout_args*)d_ra, n_iter,                                              \
-                           (use_queue || !rollout_round_robin) ? n_wg : -n_wg, use_queue ? d_queue : (int*)nullptr, (int)wave_free);                                                                       \
+                           (use_queue || !rollout_round_robin) ? n_groups : -n_groups, use_queue ? d_queue : (int*)nullptr, (int)wave_free);                                                                       \
         HIPCHK(hipGetLastError());                                                                                                                    \
         return KS_OK;                                                                                                                                 \
     }
@@ -1937,17 +1957,17 @@ template <typename T> struct Ctx : CtxBase {
         }
     }
     // more groups than resident workgroups: the ready queue (k_rollout); else one group per workgroup, nothing to deal
-    bool plan_queue() const { return rollout_queue && n_wg > resident_wgs && n_wg <= ROLLOUT_QCAP; }
+    bool plan_queue() const { return rollout_queue && n_groups > resident_wgs && n_groups <= ROLLOUT_QCAP; }
     // one group per workgroup: its four waves run free (k_rollout, round 6); KS_ROLLOUT_WAVES=0 keeps them joined by barriers
     bool plan_waves() const {
-        return rollout_waves && !plan_queue() && n_wg <= resident_wgs && lpw == EPW_MAX && LANE_STRIDE == SUBS &&
+        return rollout_waves && !plan_queue() && n_groups <= resident_wgs && lpw == EPW_MAX && LANE_STRIDE == SUBS &&
                (size_t)(wg_rays_words(4, WAVE) + wg_obs_words(4) + 4) <= (size_t)SCR_TOTAL * 4;
     }
     int rollout_plan(int32_t* mode, int32_t* groups, int32_t* workgroups) override {
         if (!model_loaded) { error = "ks_rollout_plan before ks_load_model"; return KS_ERR_STATE; }
-        if (mode) *mode = plan_waves() ? KS_PLAN_WAVES : (n_wg <= resident_wgs ? KS_PLAN_WORKGROUPS : (plan_queue() ? KS_PLAN_QUEUE : (rollout_round_robin ? KS_PLAN_ROUND_ROBIN : KS_PLAN_RUNS)));
-        if (groups) *groups = n_wg;
-        if (workgroups) *workgroups = n_wg < resident_wgs ? n_wg : resident_wgs;
+        if (mode) *mode = plan_waves() ? KS_PLAN_WAVES : (n_groups <= resident_wgs ? KS_PLAN_WORKGROUPS : (plan_queue() ? KS_PLAN_QUEUE : (rollout_round_robin ? KS_PLAN_ROUND_ROBIN : KS_PLAN_RUNS)));
+        if (groups) *groups = n_groups;
+        if (workgroups) *workgroups = n_groups < resident_wgs ? n_groups : resident_wgs;
         return KS_OK;
     }
     int substep(const void* ctrl, hipStream_t s) override {

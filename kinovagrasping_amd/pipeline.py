@@ -496,9 +496,15 @@ class AsyncTrainer(GraphedTrainer):
             self.g_learn.append(g)
         torch.cuda.synchronize(self.dev)
 
-    def run(self, n_steps: int, learn: bool = True):
+    def run(self, n_steps: int, learn: bool = True, budget_ms: float | None = None, updates: int | None = None):
         """n_steps env-steps of EVERY env (one persistent launch on the main stream) and, beside it on the learner's stream, n_steps
-        updates: [episodes published so far -> ring, actor step + targets + sampling, publish the actor, body].  Returns after
+        updates (`updates` overrides their number).
+        budget_ms (opt-in, round 6; needs the wave form of the kernel, ks_rollout_plan): a TIME budget for the launch instead - every wave steps
+        its four envs until the budget has passed (at most n_steps env-steps, at least one), so envs advance by time and `steps_total` says how far
+        each got.  For contexts whose objects differ widely in cost (a curriculum stage with bowls and cubes: the slowest object otherwise paces
+        every env); what is collected then holds more transitions of the cheap objects.  The learner is no longer paced on the envs' step counters
+        from the first budgeted launch on.
+        Beside the launch: [episodes published so far -> ring, actor step + targets + sampling, publish the actor, body].  Returns after
         ENQUEUEING both; synchronise (or call again) to wait.  The two streams only meet at the start of the next run().
         The learner's stream is the faster one; it is paced on the envs' step counters (update k starts when every env has done
         k - KS_ASYNC_LEAD env-steps, default 8), so published episodes keep being collected until a launch of any length
@@ -509,10 +515,16 @@ class AsyncTrainer(GraphedTrainer):
         main, side = self.main, self.side
         side.wait_stream(main)
         main.wait_stream(side)
-        self.sim.rollout(n_steps, self.args)
+        if budget_ms is not None:
+            self.args.budget_ticks = max(1, int(budget_ms * 1e5))           # 100 MHz device clock
+            self.pace_lead = -1                                             # the envs' counters are uneven from here on
+        try:
+            self.sim.rollout(n_steps, self.args)
+        finally:
+            self.args.budget_ticks = 0
         n, done = self.eng.n, self.env_steps
         with torch.cuda.stream(side):
-            for k in range(n_steps):
+            for k in range(n_steps if updates is None else updates):
                 if self.pace_lead >= 0 and k > self.pace_lead and (k - self.pace_lead) % 4 == 1:      # (every 4th update: the lead varies between 8 and 11)
                     self._lib.kr_wait_min_counted(self.steps_total.data_ptr(), n, done + k - self.pace_lead, 5.0, self.pace_timeouts.data_ptr(),
                                                   torch.cuda.current_stream(self.dev).cuda_stream)

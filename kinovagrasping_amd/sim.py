@@ -41,7 +41,8 @@ class KsRolloutArgs(C.Structure):
                 [(k, C.c_void_p) for k in ("obs", "prev_obs", "has_prev", "ready", "lifting", "t", "steps_total", "action", "action_t", "reward_out",
                                            "done_out", "sim_obs", "sim_reward", "sim_done", "sim_info", "sim_final_obs")] +
                 [("horizon", C.c_int32), ("n_steps", C.c_int32)] +
-                [(k, C.c_void_p) for k in ("cur_state", "cur_next", "cur_action", "cur_reward", "cur_not_done", "cur_len", "cur_sel", "pub_len", "counters")])
+                [(k, C.c_void_p) for k in ("cur_state", "cur_next", "cur_action", "cur_reward", "cur_not_done", "cur_len", "cur_sel", "pub_len", "counters")] +
+                [("budget_ticks", C.c_int64)])
 
 
 EXPORTS = ["ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_load_model", "ks_load_models", "ks_reset", "ks_reset_objects", "ks_step",

@@ -231,3 +231,46 @@ def test_trainer_picks_a_learner_stream_that_overlaps_the_rollout_stream():
     assert tr.streams_overlap is True
     del junk
     sim.close()
+
+
+def test_time_budgeted_launch_advances_envs_by_time_on_their_lock_step_trajectories():
+    """ks_rollout_args.budget_ticks (opt-in, round 6): a wave starts no further env-step once the launch's time budget has passed, so envs do between 1
+    and n_iter env-steps - and every env is exactly where the lock-step calls put it after as many env-steps as it did (same arithmetic, the noise
+    keyed by the env's own step count).  The workgroup forms of the kernel refuse a budget."""
+    from kinovagrasping_amd.pipeline import AsyncTrainer
+    n, horizon, K = 1024, 30, 14
+    sim, policy, replay, eng = _setup(n, horizon)
+    hist = [sim.get_state()["qpos"].clone()]
+    obs_hist = [eng.obs.clone()]
+    for _ in range(K):
+        eng.step()
+        hist.append(sim.get_state()["qpos"].clone()); obs_hist.append(eng.obs.clone())
+    torch.cuda.synchronize()
+    sim.close()
+    sim, policy, replay, eng = _setup(n, horizon)
+    tr = AsyncTrainer(sim, policy, replay, eng, batch_episodes=16)
+    assert sim.rollout_plan()[0] == "waves"
+    tr.args.budget_ticks = 600_000                          # 6 ms of the 100 MHz clock: about half of what 14 env-steps take
+    sim.rollout(K, tr.args)
+    tr.args.budget_ticks = 0
+    torch.cuda.synchronize()
+    done = tr.steps_total.cpu().numpy()
+    print(f"time-budgeted launch: env-steps per env min {done.min()} mean {done.mean():.2f} max {done.max()} of at most {K}")
+    assert done.min() >= 1 and done.max() <= K and done.min() < done.max() and (done.reshape(-1, 4) == done.reshape(-1, 4)[:, :1]).all()   # (the four envs of a wave advance together)
+    q = sim.get_state()["qpos"]
+    H, OH = torch.stack(hist), torch.stack(obs_hist)        # [K + 1, 16, n], [K + 1, n, 82]
+    idx = torch.as_tensor(done, device=q.device)
+    assert torch.equal(q, H[idx, :, torch.arange(n, device=q.device)].T)
+    assert torch.equal(eng.obs, OH[idx, torch.arange(n, device=q.device)])
+    assert (sim.get_state()["status"] == 0).all() and tr.counts()["episodes_dropped"] == 0
+    sim.close()
+    # a context with more groups than compute units (ready queue): refused
+    sim, policy, replay, eng = _setup(4400, 12, mixed=True)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        tr = AsyncTrainer(sim, policy, replay, eng, batch_episodes=16)
+    tr.args.budget_ticks = 1000
+    with pytest.raises(RuntimeError):
+        sim.rollout(3, tr.args)
+    sim.close()

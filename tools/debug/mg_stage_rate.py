@@ -73,3 +73,26 @@ torch.cuda.synchronize()
 dt = time.time() - t0
 st = sim.get_state()
 print(f"free running: {n * K / dt / 1e6:.3f} M env-steps/s ({dt / K * 1e3:.3f} ms per env-step), {tr.counts()}, status {sorted(set(st['status'].cpu().numpy().tolist()))}")
+# round 6, opt-in: launches with a TIME budget (ks_rollout_args.budget_ticks) - every wave steps its four envs until the budget has passed, so the cubes are
+# not paced by the bowls; the rate is the env-steps actually done per second, and the object mix of what is collected is uneven (printed)
+print("rollout plan:", sim.rollout_plan())
+if sim.rollout_plan()[0] == "waves":
+    s0 = tr.steps_total.clone()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(6):
+        tr.args.budget_ticks = 6_000_000                     # 60 ms per launch
+        sim.rollout(200, tr.args)
+        tr.args.budget_ticks = 0
+        replay.commit_published()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    d = (tr.steps_total - s0).cpu().numpy()
+    st = sim.get_state()
+    oid = sim.get_state().get("obj_id") if isinstance(sim.get_state(), dict) and "obj_id" in sim.get_state() else None
+    per = n // 16 // len(shapes) * 16
+    oid = np.repeat(np.arange(len(shapes)), per)
+    oid = np.sort(np.concatenate([oid, np.repeat(np.arange(len(shapes)), 16)[: n - len(oid)]]))
+    mix = {shapes[k]: round(float(d[oid == k].mean()), 1) for k in range(len(shapes))}
+    print(f"time-budgeted (6 launches of 60 ms): {d.sum() / dt / 1e6:.3f} M env-steps/s; env-steps per env min {d.min()} mean {d.mean():.1f} max {d.max()}; mean per object {mix}; "
+          f"{tr.counts()}, status {sorted(set(st['status'].cpu().numpy().tolist()))}")
