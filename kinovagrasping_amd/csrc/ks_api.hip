@@ -1094,6 +1094,11 @@ __global__ __launch_bounds__(WG) KS_ROLLOUT_REGS void k_rollout(const Model<floa
         }
         return;
     }
+#ifdef KS_ROLLOUT_WAVES_ONLY
+    // (A/B build, tools/r06: only the free-wave form is compiled in - ONE inlined copy of the env-step body instead of three - to measure what the
+    // scalar-register spills of the three-copy kernel cost; such a build cannot run contexts with more groups than workgroups)
+    return;
+#else
     if (queue != nullptr) {
         // ---- MORE GROUPS THAN RESIDENT WORKGROUPS, round 5: a FIFO of READY groups instead of a fixed deal.  The ring starts with every group
         // (k_rollout_queue_init); a workgroup pops the group at the head, steps it ONCE, and - unless that was the group's last env-step of the
@@ -1198,6 +1203,7 @@ __global__ __launch_bounds__(WG) KS_ROLLOUT_REGS void k_rollout(const Model<floa
         rap->counters[8 + 1024 + blockIdx.x] = wk_end - wk_loop;
         rap->counters[8 + 1536 + blockIdx.x] = clock64() - ck_loop;        // shader-clock cycles of the loop: / its wall time = the clock the CU ran at
     }
+#endif
 #endif
 }
 
