@@ -111,7 +111,8 @@ int ks_reset(ks_ctx *ctx, const int32_t *env_ids, int32_t n, const void *qpos0, 
  * mass_friction: device [2, n] (row 0 object mass in kg - the inertia scales with it -, row 1 friction of the seven
  * object-hand pairs), or NULL: an env whose object is (re)assigned takes that object's compiled mass / friction, other
  * envs keep theirs.  (Mass / friction randomisation is an extension: the reference fixes 0.1 kg, XML:153, and mu 1,
- * XML:160-166.) */
+ * XML:160-166.)  With object_id in a context of several models the call regroups the stepping kernels' work list and - round 6, unless the
+ * stream is being captured - WAITS for the stream once to read back how many 16-env groups hold envs (what ks_rollout schedules: ks_rollout_plan). */
 int ks_reset_objects(ks_ctx *ctx, const int32_t *env_ids, int32_t n, const void *qpos0, const void *hand_quat, const int32_t *object_id,
                      const void *mass_friction, void *obs, void *stream);
 
