@@ -215,6 +215,8 @@ def main():
                          "env-step for all envs (pipeline.GraphedTrainer, rounds 1-2; bit-reproducible).  'auto' (default): free where it pays - the "
                          "learner is LDS-free (256-256) and the envs fit the GPU's CUs in one round of workgroups (<= 16 envs x CUs: config 3 / 4) - "
                          "else lockstep (config 5's 8192 envs, 400-300, --eager, --serial-learner).  The JSON line says which (`config.launch`).")
+    ap.add_argument("--budget-ms", type=float, default=0.0, help="extra measurement (not the metric): launches with a TIME budget of this many ms instead of a step count "
+                    "(free-running wave form only): what the exact count's launch tail costs")
     ap.add_argument("--repeats", type=int, default=3, help="timed windows of --steps env-steps each; the line reports the median window (all are listed)")
     ap.add_argument("--chunk", type=int, default=60, help="free-running rollout: at most this many env-steps per launch (learner and rollout streams meet between launches); "
                     "a launch lasts as long as its slowest workgroup, whose lead over the mean workgroup shrinks with the square root of the steps per launch; the "
@@ -534,6 +536,26 @@ def main():
         steady = {"value": round(n * world * args.steady_steps / dts, 1), "unit": "env-steps/s", "steps": args.steady_steps,
                   "after_updates": u0, "learner_updates_timed": updates - u0, "ms_per_step": round(dts / args.steady_steps * 1e3, 4),
                   "k_env_step_avg_launch_ms": round(ks_ms, 4), "launches_timed": ks_n, "regime": regime_steady}
+    # ---- opt-in extra (`--budget-ms`): the same loop with TIME-budgeted launches (ks_rollout_args.budget_ticks) - every wave steps its envs until a launch's
+    # budget has passed, so nobody waits for the launch's slowest chain of env-steps; the rate is the env-steps actually done per second.  NOT the metric (the
+    # envs no longer advance by the same count): it measures what the exact count costs - the launch tail.
+    budgeted = None
+    if args.budget_ms > 0 and free_running and world == 1 and getattr(trainer, "rollout_plan", "") == "waves":
+        barrier()
+        s0 = trainer.steps_total.clone()
+        u0b, tb = trainer.updates, time.perf_counter()
+        n_launch = 10
+        per_launch = max(1, int(args.budget_ms / (dt / args.steps * 1e3)))         # updates beside a launch: about one per env-step of the mean env
+        for _ in range(n_launch):
+            trainer.run(4 * per_launch + 8, budget_ms=args.budget_ms, updates=per_launch)
+        trainer.flush()
+        barrier()
+        dtb = time.perf_counter() - tb
+        d = (trainer.steps_total - s0).float()
+        budgeted = {"value": round(float(d.sum()) / dtb, 1), "unit": "env-steps/s", "launches": n_launch, "budget_ms_per_launch": args.budget_ms,
+                    "env_steps_per_env": {"min": int(d.min()), "mean": round(float(d.mean()), 1), "max": int(d.max())}, "learner_updates": trainer.updates - u0b,
+                    "note": "envs advance by time, not by count: not the metric; value / the line's value = what the launch tail of the exact count costs"}
+        updates = trainer.updates
     status = sim.get_state()["status"]
     bad = int((status & 2).ne(0).sum().item())
     # replicas must hold bit-identical weights after the all-reduced updates: spread of two checksums over the ranks
@@ -607,6 +629,7 @@ def main():
                          "issue_bound": issue},
             "mfma": mfma,
             "steady_state": steady,
+            "time_budgeted": budgeted,
             # every env runs the same 30-step episode clock (auto-reset), and an env-step costs more late in an episode (hands
             # closed, more contacts) than early: a window that is not whole episodes is not an average
             "timed_windows_ms_per_step": [round(w["dt"] / args.steps * 1e3, 4) for w in windows],      # every window of --steps env-steps; the line is the median one
