@@ -1087,6 +1087,9 @@ KS_NARROW bool mpr_penetration_sm(PairGeo<T>& g_io, T tol_, int max_iter, T* dep
     struct Out {
         PairGeo<T>& g_io; const PairGeo<T>& g; T* depth_o; T* dir_o; T* pos_o; const T* depth; const T* dir; const T* pos;
         KS_HD ~Out() {
+#ifdef KS_STAMP_HULL
+            g_io.t_clo = g.t_clo; g_io.cnt_support = g.cnt_support;
+#endif
             g_io.hint1 = g.hint1; g_io.hint2 = g.hint2; *depth_o = *depth; dir_o[0] = dir[0]; dir_o[1] = dir[1]; dir_o[2] = dir[2]; pos_o[0] = pos[0]; pos_o[1] = pos[1]; pos_o[2] = pos[2];
         }
     } out_{g_io, g, depth_o, dir_o, pos_o, depth, dir, pos};
@@ -1112,7 +1115,13 @@ KS_NARROW bool mpr_penetration_sm(PairGeo<T>& g_io, T tol_, int max_iter, T* dep
                 if (is_zero(dt) || dt > 0) { state = MPR_S_REFINE; it = 0; }
             }
         } else if (state == MPR_S_V3 && it > 100) return false;
+#if defined(KS_STAMP_HULL) && defined(__HIP_DEVICE_COMPILE__)
+        const long long tsup0_ = clock64();
+#endif
         support_f64(g, d, v4);                                  // THE support site
+#if defined(KS_STAMP_HULL) && defined(__HIP_DEVICE_COMPILE__)
+        g.t_clo += clock64() - tsup0_; g.cnt_support += 2;        // (diagnostic: cycles inside the supports of this query)
+#endif
         const double dv = dot3(v4.v, d);
         if (state == MPR_S_V1) {
             v1 = v4;
@@ -2001,7 +2010,7 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
         T mdir[3], mpos[3];
         bool hit;
 #ifdef KS_STAMP_HULL
-        const long long tm0 = clock64();
+        const long long tm0 = clock64(), clo0 = pg.t_clo;
         const int sup0 = pg.cnt_support;
 #endif
         if constexpr (use_sm) {
@@ -2011,7 +2020,7 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
             hit = mpr_penetration(pg, m.mpr_tol, m.mpr_iters, &depth, mdir, mpos, ws);
         }
 #ifdef KS_STAMP_HULL
-        if (prof) { prof[7] += (float)(clock64() - tm0); prof[22] += (float)(pg.cnt_support - sup0) * 0.5f; prof[26] += 1.f; }     // MPR cycles, support pairs, queries (diagnostic)
+        if (prof) { prof[7] += (float)(clock64() - tm0); prof[22] += (float)(pg.cnt_support - sup0) * 0.5f; prof[26] += 1.f; prof[29] += (float)(pg.t_clo - clo0); }     // MPR cycles, support pairs, queries, cycles inside its supports (diagnostic)
 #endif
         h1_out = pg.hint1 <= PC_HINT_MAX ? pg.hint1 : 0; h2_out = pg.hint2 <= PC_HINT_MAX ? pg.hint2 : 0;   // (a vertex id beyond the 10-bit field is not remembered: start 0, not a masked id)
         if (hit) {

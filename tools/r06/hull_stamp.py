@@ -32,9 +32,9 @@ for t in range(60):
     prof = st["contact"].reshape(-1, n)[:480].cpu().numpy().reshape(16, 30, n)
     hist_all.append((prof[:, 7] > 0).sum(0).astype(int))
     acc.append([prof[0, 6].mean(), prof[0, 9].mean(), prof[:, 27].max(0).mean(), prof[:, 7].max(0).mean(), prof[:, 7].sum(0).mean(), prof[:, 22].sum(0).mean(), prof[:, 28].max(0).mean(),
-                (prof[:, 7] > 0).sum(0).mean()])
+                (prof[:, 7] > 0).sum(0).mean(), prof[:, 29].sum(0).mean()])
 hist = np.bincount(np.concatenate(hist_all), minlength=8)[:8]
 print("lanes of an env that ran a penetration query during an env-step: share of (env, env-step) with 0, 1, 2 ... lanes:", np.round(hist / hist.sum(), 3))
 a = np.mean(acc, 0)
 print(f"per env-step (k cycles): total {a[0]/1e3:.0f}, hull-pair phase {a[1]/1e3:.0f}; busiest lane of an env: distance queries {a[2]/1e3:.0f} (supports {a[6]/1e3:.0f}), penetration queries {a[3]/1e3:.0f}; "
-      f"penetration queries summed over the env's lanes {a[4]/1e3:.0f} with {a[5]:.1f} support pairs -> {a[4]/max(a[5],1e-9):.0f} cycles per support pair; lanes with a penetration query {a[7]:.2f}")
+      f"penetration queries summed over the env's lanes {a[4]/1e3:.0f} with {a[5]:.1f} support pairs -> {a[4]/max(a[5],1e-9):.0f} cycles per support pair; lanes with a penetration query {a[7]:.2f}; of the penetration queries' {a[4]/1e3:.0f} k cycles {a[8]/1e3:.0f} k are inside their supports")
