@@ -20,7 +20,7 @@ out = {
     "workload": ("bench.py --mode sim, 4096 envs, CubeS" if workload == "sim" else
                  "bench.py --mode sim --shape BowlS, 4096 envs: libkinova_sim_mg.so (hull tables in global memory, 9 hulls on the floor, ~15 contacts per env at rest)" if workload == "mg" else
                  "bench.py --rollout free (config 3: DDPG training, 4096 envs, free-running rollout kernel, learner HIP graphs; counters on every dispatch, "
-                 "dispatches serialised by the collector so k_rollout runs alone; per-launch figures divided by the 10 env-steps of a launch) after 150 pre-training updates from the committed bench policy + the bench's own 300 (the collector segfaults with 600 more; the regime is pinned by the committed policy, not by their number)" if workload == "free" else
+                 "dispatches serialised by the collector so k_rollout runs alone; per-launch figures divided by the 10 env-steps of a launch) after 150 pre-training updates from the committed bench policy (bench.py's default is 300: with 300 the collector hangs - round 6, a run killed at the 30-minute limit - and with 600 it segfaults; the regime is pinned by the committed policy, not by their number)" if workload == "free" else
                  "bench.py --eager (config 3: DDPG training, 4096 envs, learner launched op by op - counter collection with the kernel filter segfaults when the learner runs from HIP graphs) after 600 pre-training updates") +
                 " (tools/pmc_run.sh: rocprofv3 --kernel-trace --pmc, one counter set per pass, last 40 launches of each pass; free: last 2 launches = 20 env-steps)",
     "source": src,
