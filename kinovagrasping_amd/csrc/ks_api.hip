@@ -1332,6 +1332,31 @@ __global__ __launch_bounds__(SLOT_THREADS) void k_slots(const int32_t* __restric
     }
 }
 
+// Round 6, free-running waves of a ONE-object context: the slot list re-sorted by episode step before every ks_rollout launch, so that the four envs
+// of a wave are in the same phase of their episodes.  A wave's lanes run in lock step, so an env-step costs it its most expensive env - and what an
+// env-step costs is mostly decided by where the env is in its episode (approach: no contact; grasp and lift: penetration queries in every substep).
+// Dealt in env order a wave nearly always holds an env of the expensive phases; sorted, it pays for them only while its own envs are there
+// (profiles/r06_wave_chains.txt, the model on measured counters: slowest wave chain of a 20-step launch -5 %, mean wave -7 %).  Per env nothing
+// changes: state, pair memory, noise stream and replay rows are all indexed by env id, a slot only says which lanes step the env
+// (test_every_scheduling_form_of_the_rollout_kernel_equals_lock_step).  One workgroup; rank of (t, env) by counting, envs first, padding (-1) last.
+constexpr int PHASE_THREADS = 1024, PHASE_ENVS_MAX = 4096;
+__global__ __launch_bounds__(PHASE_THREADS) void k_slots_by_phase(const int64_t* __restrict__ t, int N, int n_slots, int32_t* __restrict__ slot_env) {
+    __shared__ unsigned key[PHASE_ENVS_MAX];
+    for (int e = threadIdx.x; e < N; e += PHASE_THREADS) {
+        long long te = t[e];
+        te = te < 0 ? 0 : (te > 0x7fff ? 0x7fff : te);
+        key[e] = ((unsigned)te << 16) | (unsigned)e;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < N; e += PHASE_THREADS) {
+        const unsigned k = key[e];
+        int rank = 0;
+        for (int j = 0; j < N; j++) rank += key[j] < k ? 1 : 0;
+        slot_env[rank] = e;
+    }
+    for (int s = N + threadIdx.x; s < n_slots; s += PHASE_THREADS) slot_env[s] = -1;
+}
+
 // one (env, ray, geom) per lane: eight envs per wave, the eight mesh geoms of an env in adjacent lanes (lane 0 of the
 // group also takes the ground plane), nearest hit by a 3-step butterfly.  The ray index is uniform per workgroup.
 // pruning distance shared by the eight lanes of one (env, ray): the minimum of their nearest hits so far, published in
@@ -1800,6 +1825,7 @@ template <typename T> struct Ctx : CtxBase {
                                           // (measured, round 5).  That context is bound by its slowest groups' SEQUENTIAL env-steps anyway (every env does the
                                           // same number of env-steps per launch): no dealing helps it.  KS_ROLLOUT_DEAL=queue forces the queue.
     bool rollout_waves = !(getenv("KS_ROLLOUT_WAVES") && getenv("KS_ROLLOUT_WAVES")[0] == '0');      // free-running waves (one group per workgroup)
+    bool rollout_phase_deal = !(getenv("KS_ROLLOUT_PHASE_DEAL") && getenv("KS_ROLLOUT_PHASE_DEAL")[0] == '0');      // free waves, one object: slots sorted by episode step before every launch (k_slots_by_phase)
     bool rollout_round_robin = false;     // how k_rollout deals the env groups to its persistent workgroups: contiguous runs (default) or round-robin (KS_ROLLOUT_DEAL=rr)
     int lpw = WAVE;
     bool rays_in_step = false, obs_in_step = false;
@@ -1944,6 +1970,8 @@ template <typename T> struct Ctx : CtxBase {
             if (use_queue) {
                 hipLaunchKernelGGL(k_rollout_queue_init, dim3(1), dim3(256), 0, s, d_queue, n_groups);
             }
+            if (wave_free && rollout_phase_deal && n_models == 1 && N <= PHASE_ENVS_MAX && ra->budget_ticks == 0)
+                hipLaunchKernelGGL(k_slots_by_phase, dim3(1), dim3(PHASE_THREADS), 0, s, (const int64_t*)ra->t, N, n_wg * lpw, b.slot_env);
 #define KS_ROLLOUT_CASE(A, B)                                                                                                                         \
     if ((ra->h1 + 15) / 16 == A && (ra->h2 + 15) / 16 == B) {                                                                                                 \
         HIPCHK(hipFuncSetAttribute((const void*)k_rollout<A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));                        \

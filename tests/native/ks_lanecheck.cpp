@@ -211,6 +211,30 @@ static int plane_hook(int g2, const double* R, const double* p, int coarse) {
     return coarse;
 }
 #endif
+#ifdef KS_PATH_STUDY
+// tests/studies/path_stability.py: the sequence of support pairs of every penetration query, compared with the pair's previous query
+namespace ks { void (*ks_path_hook)(const void*, int, int, int) = nullptr; const void* ks_path_pair = nullptr; }
+#include <map>
+struct PathRec { std::vector<int> cur, prev; long prev_tick = -1; };
+static std::map<const void*, PathRec> g_paths;
+static long g_tick = 0;
+static std::vector<int> g_path_log;     // per query: tick gap to the pair's previous query, its length, this length, common prefix, same result
+static void path_hook(const void* pair, int state, int i1, int i2) {
+    PathRec& r = g_paths[pair];
+    if (state >= 0) { r.cur.push_back(state | (i1 << 3) | (i2 << 17)); return; }
+    r.cur.push_back(state);
+    int k = 0;
+    while (k < (int)r.cur.size() && k < (int)r.prev.size() && r.cur[k] == r.prev[k]) k++;
+    g_path_log.push_back(r.prev_tick < 0 ? -1 : (int)(g_tick - r.prev_tick)); g_path_log.push_back((int)r.prev.size()); g_path_log.push_back((int)r.cur.size());
+    g_path_log.push_back(k); g_path_log.push_back((int)(g_tick));
+    r.prev.swap(r.cur); r.cur.clear(); r.prev_tick = g_tick;
+}
+extern "C" {
+void lc_path_reset() { g_paths.clear(); g_path_log.clear(); g_tick = 0; ks::ks_path_hook = path_hook; }
+void lc_path_tick() { g_tick++; }
+int lc_path_log(int* out, int cap) { int n = (int)g_path_log.size(); for (int i = 0; i < n && i < cap; i++) out[i] = g_path_log[i]; return n; }
+}
+#endif
 extern "C" {
 void* lc_create(const void* blob, size_t n) {
     LC* h = new LC();
