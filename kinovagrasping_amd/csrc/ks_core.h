@@ -1185,6 +1185,216 @@ KS_NARROW bool mpr_penetration_sm(PairGeo<T>& g_io, T tol_, int max_iter, T* dep
     }
 }
 
+// ---- The same query on TWO lanes (round 6, fp32 product on the GPU, 16-lane teams): the lane that owns the pair and the team lane 8 places
+// away (sub ^ 8, one DPP row_ror:8 mov per word).  A turn of the query above is ~8 k cycles of a wave in which two or three lanes work: the instruction
+// stream is issue-bound (one wave per SIMD: ~5 cycles per vector instruction, 64 per dependent LDS read - tools/r06/ubench/lat.hip), and more than
+// half of a turn is its support - two hill climbs, one per hull, one after the other.  Here the OWNER climbs hull 1 and the HELPER hull 2 in the same
+// instructions: each lane holds ONE hull (pose, tables, last support vertex), forms its own hull-frame direction, reads its own cube-map cell, climbs,
+// and forms its own world point R V[i] in fp64; the two exchange point and vertex id, and both form the Minkowski point (w1 - w2) + (p1 - p2) - the
+// helper as -(w2 - w1), the same bits.  The state machine around the support runs on BOTH lanes, on the same values: every decision falls alike, the
+// pair leaves the loop together, and the owner reads the result off the final portal (the helper's hull re-fetched by DPP).  Bit-identical to
+// mpr_penetration_sm by construction: the same operations on the same operands in the same order, on another lane.
+// Both lanes of a pair must be active in every exchange: the caller brings them here together (collide_hull_hull_split).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename X> __device__ __forceinline__ X dpp_partner(X x) {      // x of team lane sub ^ 8
+    if constexpr (sizeof(X) == 4) return __builtin_bit_cast(X, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));
+    else {
+        static_assert(sizeof(X) == 8, "32- or 64-bit values");
+        struct P2 { int lo, hi; };
+        P2 q = __builtin_bit_cast(P2, x);
+        q.lo = __builtin_amdgcn_update_dpp(0, q.lo, 0x128, 0xf, 0xf, false);
+        q.hi = __builtin_amdgcn_update_dpp(0, q.hi, 0x128, 0xf, 0xf, false);
+        return __builtin_bit_cast(X, q);
+    }
+}
+// One hull of a pair as the lane that climbs it holds it
+template <typename T> struct HullGeo {
+    T R[9], p[3], po[3];                // pose of MY hull, position of the OTHER one
+    KS_TAB const T* V; KS_TAB const unsigned short* off; KS_TAB const unsigned short* adj;
+    const unsigned short* dir;
+    int hint;
+};
+// The portal's three corners live in LDS (24 words per lane in the env's contact region, dead until the collision stage merges its
+// staged records).  In mpr_penetration_sm the compiler keeps v1 .. v3 in PRIVATE memory (expand_portal_d's `v1 = v4 / v3 = v4` becomes one store
+// through a selected pointer): every turn stores a corner and the next turn loads all three back - a round trip through the vector memory path
+// (a written line is not held by the L1) where an LDS read costs 64 cycles.  Forcing them into registers was measured slower (the state machine's
+// merges then copy 24 registers per path: 2.37 -> 2.24 M env-steps/s); the two-lane query with its portal in private memory: the same bits,
+// sim-only 3.50 against 3.55 M.  Same operations on the same operands: bit-identical.
+struct PortalLds {
+    KS_LDS double* b;       // corner c (0: v1, 1: v2, 2: v3) at b + 4 c: v[3], then the two vertex ids in the fourth slot
+    __device__ __forceinline__ void getv(int c, double* v) const { v[0] = b[4 * c]; v[1] = b[4 * c + 1]; v[2] = b[4 * c + 2]; }
+    __device__ __forceinline__ SuppD get(int c) const {
+        SuppD s;
+        getv(c, s.v);
+        KS_LDS const int* q = (KS_LDS const int*)(b + 4 * c + 3);
+        s.i1 = q[0]; s.i2 = q[1];
+        return s;
+    }
+    __device__ __forceinline__ void put(int c, const SuppD& s) const {
+        b[4 * c] = s.v[0]; b[4 * c + 1] = s.v[1]; b[4 * c + 2] = s.v[2];
+        KS_LDS int* q = (KS_LDS int*)(b + 4 * c + 3);
+        q[0] = s.i1; q[1] = s.i2;
+    }
+};
+template <typename T>
+__device__ __forceinline__ bool mpr_penetration_pair(const PairGeo<T>& g_own, bool own, KS_LDS double* portal, T tol_, int max_iter, int& hint1_o, int& hint2_o, T* depth_o,
+                                                         T* dir_o, T* pos_o) {
+    HullGeo<T> h;
+    KS_UNROLL
+    for (int k = 0; k < 9; k++) { const T o = dpp_partner(g_own.R2[k]); h.R[k] = own ? g_own.R1[k] : o; }
+    KS_UNROLL
+    for (int k = 0; k < 3; k++) {
+        const T o2 = dpp_partner(g_own.p2[k]), o1 = dpp_partner(g_own.p1[k]);
+        h.p[k] = own ? g_own.p1[k] : o2;
+        h.po[k] = own ? g_own.p2[k] : o1;
+    }
+    { const auto o = dpp_partner(g_own.V2); h.V = own ? g_own.V1 : o; }
+    { const auto o = dpp_partner(g_own.off2); h.off = own ? g_own.off1 : o; }
+    { const auto o = dpp_partner(g_own.adj2); h.adj = own ? g_own.adj1 : o; }
+    { const auto o = dpp_partner(g_own.dir2); h.dir = own ? g_own.dir1 : o; }
+    { const int o = dpp_partner(g_own.hint2); h.hint = own ? g_own.hint1 : o; }
+    const PortalLds P{portal};
+    const double sgn = own ? 1.0 : -1.0;
+    SuppD v0, v4;
+    double d[3], va[3], vb[3], c1[3], c2[3], c3[3];
+    const double tol = (double)tol_;
+    KS_UNROLL
+    for (int k = 0; k < 3; k++) v0.v[k] = sgn * ((double)h.p[k] - (double)h.po[k]);
+    if (vec_is_zero(v0.v)) v0.v[0] += 1e-5;
+    v0.i1 = 0; v0.i2 = 0;
+    P.put(0, v0); P.put(1, v0); P.put(2, v0);
+    KS_UNROLL
+    for (int k = 0; k < 3; k++) d[k] = -v0.v[k];
+    normalize3(d);
+    int state = MPR_S_V1, it = 0;
+    bool hit = false;
+    for (;;) {
+        if (state >= MPR_S_INSIDE) {
+            P.getv(0, c1); P.getv(1, c2); P.getv(2, c3);
+            sub3(va, c2, c1);
+            sub3(vb, c3, c1);
+            cross3(d, va, vb);
+            normalize3(d);
+            if (state == MPR_S_INSIDE) {
+                if (it > 100) break;
+                const double dt = dot3(d, c1);
+                if (is_zero(dt) || dt > 0) { state = MPR_S_REFINE; it = 0; }
+            }
+        } else if (state == MPR_S_V3 && it > 100) break;
+        {
+            double ld[3];
+            KS_UNROLL
+            for (int k = 0; k < 3; k++) {
+                const double a = (double)h.R[k] * d[0] + (double)h.R[3 + k] * d[1] + (double)h.R[6 + k] * d[2];
+                ld[k] = own ? a : -a;
+            }
+            const double s1 = SUPPORT_SKEW * (kabs(ld[0]) + kabs(ld[1]) + kabs(ld[2]));
+            ld[0] += s1 * SKEW_X; ld[1] += s1 * SKEW_Y; ld[2] += s1 * SKEW_Z;
+            const T f1[3] = {(T)ld[0], (T)ld[1], (T)ld[2]};
+            const int tab = (int)h.dir[support_cell(f1)];
+            h.hint = climb_f64(h.V, h.off, h.adj, h.hint, tab, ld);
+            const double a[3] = {(double)h.V[4 * h.hint], (double)h.V[4 * h.hint + 1], (double)h.V[4 * h.hint + 2]};
+            const int io = dpp_partner(h.hint);
+            v4.i1 = own ? h.hint : io; v4.i2 = own ? io : h.hint;
+            KS_UNROLL
+            for (int k = 0; k < 3; k++) {
+                const double w = (double)h.R[3 * k] * a[0] + (double)h.R[3 * k + 1] * a[1] + (double)h.R[3 * k + 2] * a[2];
+                const double wo = dpp_partner(w);
+                v4.v[k] = sgn * (w - wo) + sgn * ((double)h.p[k] - (double)h.po[k]);
+            }
+        }
+        const double dv = dot3(v4.v, d);
+        if (state == MPR_S_V1) {
+            P.put(0, v4);                                           // v1 = v4
+            if (is_zero(dv) || dv < 0) break;
+            cross3(d, v0.v, v4.v);
+            if (vec_is_zero(d)) {
+                if (vec_is_zero(v4.v)) break;
+                const double nn = std::sqrt(dot3(v4.v, v4.v));
+                *depth_o = (T)nn;
+                KS_UNROLL
+                for (int k = 0; k < 3; k++) dir_o[k] = (T)(v4.v[k] / nn);
+                T a[3], b[3];
+                hull_point(h.R, h.p, h.V, h.hint, a);
+                KS_UNROLL
+                for (int k = 0; k < 3; k++) b[k] = dpp_partner(a[k]);
+                KS_UNROLL
+                for (int k = 0; k < 3; k++) pos_o[k] = T(0.5) * (a[k] + b[k]);
+                hit = true;
+                break;
+            }
+            normalize3(d);
+            state = MPR_S_V2;
+        } else if (state == MPR_S_V2) {
+            if (is_zero(dv) || dv < 0) { P.put(1, v4); break; }
+            const SuppD o1 = P.get(0);
+            sub3(va, o1.v, v0.v);
+            sub3(vb, v4.v, v0.v);
+            cross3(d, va, vb);
+            normalize3(d);
+            if (dot3(d, v0.v) > 0) {
+                P.put(0, v4); P.put(1, o1);                         // v1 <-> v2
+                d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2];
+            } else P.put(1, v4);                                    // v2 = v4
+            state = MPR_S_V3; it = 0;
+        } else if (state == MPR_S_V3) {
+            if (is_zero(dv) || dv < 0) break;
+            bool cont = false;
+            P.getv(0, c1); P.getv(1, c2);
+            cross3(va, c1, v4.v);
+            double dt = dot3(va, v0.v);
+            if (dt < 0 && !is_zero(dt)) { P.put(1, v4); copy3(c2, v4.v); cont = true; }                 // v2 = v3
+            if (!cont) {
+                cross3(va, v4.v, c2);
+                dt = dot3(va, v0.v);
+                if (dt < 0 && !is_zero(dt)) { P.put(0, v4); copy3(c1, v4.v); cont = true; }             // v1 = v3
+            }
+            if (cont) {
+                sub3(va, c1, v0.v);
+                sub3(vb, c2, v0.v);
+                cross3(d, va, vb);
+                normalize3(d);
+                it++;
+            } else { P.put(2, v4); state = MPR_S_INSIDE; it = 0; }                                      // v3 = v4
+        } else {
+            if (state == MPR_S_INSIDE && !(is_zero(dv) || dv > 0)) break;
+            P.getv(0, c1); P.getv(1, c2); P.getv(2, c3);
+            // portal_reach_tol_d
+            bool reached;
+            {
+                const double dv4 = dot3(v4.v, d);
+                const double d1 = dv4 - dot3(c1, d), d2 = dv4 - dot3(c2, d), d3 = dv4 - dot3(c3, d);
+                double dm = d1 < d2 ? d1 : d2;
+                dm = dm < d3 ? dm : d3;
+                reached = is_zero(dm) || dm < tol;
+            }
+            if (state == MPR_S_INSIDE) { if (reached) break; }
+            else if (reached || it > max_iter) {
+                PairGeo<T> g;
+                KS_UNROLL
+                for (int k = 0; k < 9; k++) { const T o = dpp_partner(h.R[k]); g.R1[k] = own ? h.R[k] : o; g.R2[k] = own ? o : h.R[k]; }
+                KS_UNROLL
+                for (int k = 0; k < 3; k++) { g.p1[k] = own ? h.p[k] : h.po[k]; g.p2[k] = own ? h.po[k] : h.p[k]; }
+                { const auto o = dpp_partner(h.V); g.V1 = own ? h.V : o; g.V2 = own ? o : h.V; }
+                const SuppD q1 = P.get(0), q2 = P.get(1), q3 = P.get(2);
+                hit = mpr_readoff_f64(g, v0, q1, q2, q3, depth_o, dir_o, pos_o);
+                break;
+            }
+            // expand_portal_d
+            {
+                double cc[3];
+                cross3(cc, v4.v, v0.v);
+                const int w = dot3(c1, cc) > 0 ? (dot3(c2, cc) > 0 ? 0 : 2) : (dot3(c3, cc) > 0 ? 1 : 0);
+                P.put(w, v4);
+            }
+            it++;
+        }
+    }
+    { const int o = dpp_partner(h.hint); hint1_o = own ? h.hint : o; hint2_o = own ? o : h.hint; }
+    return hit;
+}
+#endif
+
 template <typename T>
 KS_NARROW bool mpr_penetration(PairGeo<T>& g, T tol, int max_iter, T* depth, T* dir, T* pos, PairWarm* ws = nullptr) {
     Supp<T> v0, v1, v2, v3, v4;
@@ -2034,6 +2244,115 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
     return 0;
 }
 
+// ---- collide_hull_hull for the two-lane penetration query (mpr_penetration_pair): entered by EVERY lane of the wave; `have` says whether the
+// lane has a live pair in this pass.  Culls and the distance query as above, on the owner alone; then the lanes whose pair overlaps take the team
+// lane 8 places away as their helper - when both lanes of such a couple have an overlapping pair the lower one goes first and helps the other
+// afterwards (a second turn of the loop below, rare: the pairs that overlap together - object against finger links - sit on neighbouring lanes).
+static_assert(NCON_MAX * CON_STRIDE >= 16 * 24, "the contact region holds a 24-word portal per lane of a team");
+#ifndef KS_MPR_SPLIT
+#define KS_MPR_SPLIT 1          // 0: every penetration query on its owner's lane alone (mpr_penetration_sm), the A/B of the two-lane query
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename T, typename S, int SUBS>
+__device__ __forceinline__ int collide_hull_hull_split(const Model<T>& m, const unsigned short* dirtab, S scr, Team<SUBS> team, bool have, KS_LDS const PairRec<T>* prp,
+                                                       int slot, int packed_in, int& h1_out, int& h2_out, PairWarm* ws) {
+    static_assert(SUBS == 16 && KS_MPR_FIRST == 0, "the two-lane query: 16-lane teams, the distance query first");
+    KS_LDS const PairRec<T>& pr = *prp;
+    PairGeo<T> pg;
+    int r = 0, c = 0;
+    bool obj_first = false;
+    T dist = 0, dir[3] = {0, 0, 0}, pos[3] = {0, 0, 0};
+    h1_out = (packed_in >> 3) & PC_HINT_MAX;
+    h2_out = (packed_in >> (3 + PC_HINT_BITS)) & PC_HINT_MAX;
+    if (have) {
+        const int g1 = pr.g1, g2 = pr.g2;
+        const int flags = pr.obj_hand;
+        const T margin = pr.margin;
+        obj_first = (KS_OBJ_FIRST != 0) && (g2 == OBJ_GEOM);       // (operand order: see collide_hull_hull)
+        if (obj_first) {
+            pg.V1 = pr.V2; pg.n1 = pr.n2; pg.off1 = pr.off2; pg.adj1 = pr.adj2;
+            pg.V2 = pr.V1; pg.n2 = pr.n1; pg.off2 = pr.off1; pg.adj2 = pr.adj1;
+            pg.dir1 = dirtab + SUPPORT_CELLS * ((flags >> 8) & 15);
+            pg.dir2 = dirtab + SUPPORT_CELLS * ((flags >> 4) & 15);
+            geom_pose_cached(scr, g2, pg.R1, pg.p1);
+            geom_pose_cached(scr, g1, pg.R2, pg.p2);
+        } else {
+            pg.V1 = pr.V1; pg.n1 = pr.n1; pg.off1 = pr.off1; pg.adj1 = pr.adj1;
+            pg.V2 = pr.V2; pg.n2 = pr.n2; pg.off2 = pr.off2; pg.adj2 = pr.adj2;
+            pg.dir1 = dirtab + SUPPORT_CELLS * ((flags >> 4) & 15);
+            pg.dir2 = dirtab + SUPPORT_CELLS * ((flags >> 8) & 15);
+            geom_pose_cached(scr, g1, pg.R1, pg.p1);
+            geom_pose_cached(scr, g2, pg.R2, pg.p2);
+        }
+        pg.hint1 = h1_out < pg.n1 ? h1_out : 0;
+        pg.hint2 = h2_out < pg.n2 ? h2_out : 0;
+        pg.half_margin = T(0);
+        r = gjk_distance(pg, margin, &dist, dir, pos, ws);
+        h1_out = pg.hint1 <= PC_HINT_MAX ? pg.hint1 : 0; h2_out = pg.hint2 <= PC_HINT_MAX ? pg.hint2 : 0;
+        if (obj_first && (r == 1 || r == 3)) { dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
+        if (r < 2 && ws != nullptr) ws->w[2] = 0u;
+        if (r == 1) {
+            const T mu = (flags & 1) ? T(scr(SCR_ENVP + 1)) : pr.mu;
+            stage_contact(scr, slot, pr.body1, pr.body2, (flags >> 12) & PAIR_INDEX_MASK, mu, dist, pos, dir);
+            c = 1;
+        }
+    }
+    // the penetration queries of this pass: owner + helper
+    bool pending = have && r >= 2, hit = false;
+    T depth = 0, mdir[3] = {0, 0, 0}, mpos[3] = {0, 0, 0};
+#pragma clang loop unroll(disable)
+    while (__any(pending)) {
+        const bool partner_pending = dpp_partner(pending ? 1 : 0) != 0;
+        const bool own = pending && (!partner_pending || (team.sub & 8) == 0);
+        const bool help = dpp_partner(own ? 1 : 0) != 0;
+        if (own || help) {
+            int hh1 = 0, hh2 = 0;
+            T dd = 0, md[3] = {0, 0, 0}, mp[3] = {0, 0, 0};
+#ifdef KS_SPLIT_USE_SM
+            // diagnostic build: the split caller around the ONE-lane query (what the change of the caller alone does to the bits)
+            bool ht = false;
+            if (own) { PairGeo<T> pc = pg; ht = mpr_penetration_sm(pc, m.mpr_tol, m.mpr_iters, &dd, md, mp); hh1 = pc.hint1; hh2 = pc.hint2; }
+#else
+            const bool ht = mpr_penetration_pair(pg, own, (KS_LDS double*)(scr.base + SCR_CON + 24 * team.sub), m.mpr_tol, m.mpr_iters, hh1, hh2, &dd, md, mp);
+#endif
+#ifdef KS_SPLIT_CHECK
+            if (own) {      // diagnostic build: the one-lane query on the same pair record must return the same bits
+                PairGeo<T> pc = pg;
+                T d1 = 0, m1[3] = {0, 0, 0}, p1[3] = {0, 0, 0};
+                const bool h1 = mpr_penetration_sm(pc, m.mpr_tol, m.mpr_iters, &d1, m1, p1);
+                if (h1 != ht || (ht && (d1 != dd || m1[0] != md[0] || m1[1] != md[1] || m1[2] != md[2] || p1[0] != mp[0] || p1[1] != mp[1] || p1[2] != mp[2])) || pc.hint1 != hh1 || pc.hint2 != hh2)
+                    printf("split mismatch lane %d: hit %d/%d depth %.9g/%.9g dir %.9g %.9g %.9g / %.9g %.9g %.9g pos %.9g %.9g %.9g / %.9g %.9g %.9g hints %d %d / %d %d\n", (int)threadIdx.x, (int)h1, (int)ht, (double)d1, (double)dd,
+                           (double)m1[0], (double)m1[1], (double)m1[2], (double)md[0], (double)md[1], (double)md[2], (double)p1[0], (double)p1[1], (double)p1[2], (double)mp[0], (double)mp[1], (double)mp[2], pc.hint1, pc.hint2, hh1, hh2);
+            }
+#endif
+            if (own) {
+                hit = ht; depth = dd;
+                KS_UNROLL
+                for (int k = 0; k < 3; k++) { mdir[k] = md[k]; mpos[k] = mp[k]; }
+                pg.hint1 = hh1; pg.hint2 = hh2;
+                pending = false;
+            }
+        }
+    }
+    if (have && r >= 2) {
+        if (ws != nullptr) ws->w[2] = 1u;
+        h1_out = pg.hint1 <= PC_HINT_MAX ? pg.hint1 : 0; h2_out = pg.hint2 <= PC_HINT_MAX ? pg.hint2 : 0;
+        const int flags = pr.obj_hand;
+        const T mu = (flags & 1) ? T(scr(SCR_ENVP + 1)) : pr.mu;
+        const int pi = (flags >> 12) & PAIR_INDEX_MASK;
+        if (hit) {
+            if (obj_first) { mdir[0] = -mdir[0]; mdir[1] = -mdir[1]; mdir[2] = -mdir[2]; }
+            stage_contact(scr, slot, pr.body1, pr.body2, pi, mu, -depth, mpos, mdir);
+            c = 1;
+        } else if (r == 3) {
+            stage_contact(scr, slot, pr.body1, pr.body2, pi, mu, dist, pos, dir);
+            c = 1;
+        }
+    }
+    return c;
+}
+#endif
+
 // the per-pair words (contact count + support hints) must start from zero once per launch: the hints of a fresh
 // LDS block are garbage
 template <typename T, typename S, int SUBS> KS_HD void reset_pair_words(S scr, Team<SUBS> team) {
@@ -2143,6 +2462,33 @@ KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Tea
             prof[27] += (float)(todo & 1u); prof[28] += (float)((todo >> 1) & 1u);      // this lane's pair of round 0 / round 1 live
         }
 #endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KS_STAMP_HULL)
+        constexpr bool split_queries = (KS_MPR_SPLIT != 0) && (KS_MPR_SM != 0) && sizeof(T) == 4 && SUBS == 16 && KS_MPR_FIRST == 0;
+#else
+        constexpr bool split_queries = false;
+#endif
+        if constexpr (split_queries) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            // the two-lane penetration query: every lane of the wave takes every turn (a lane without a live pair may be its partner's helper)
+            while (__any(todo != 0)) {
+                const bool have = todo != 0;
+                int r = 0, pi_r = pi_[0], word_r = word_[0], slot_r = slot_[0];
+                if constexpr (HPL == 2) { r = (todo & 1u) ? 0 : 1; pi_r = r ? pi_[1] : pi_[0]; word_r = r ? word_[1] : word_[0]; slot_r = r ? slot_[1] : slot_[0]; }
+                else {
+                    r = have ? kctz(todo) : 0;
+                    KS_UNROLL
+                    for (int q = 1; q < HPL; q++)
+                        if (q == r) { pi_r = pi_[q]; word_r = word_[q]; slot_r = slot_[q]; }
+                }
+                int h1 = 0, h2 = 0;
+                const int c = collide_hull_hull_split(m, dirtab, scr, team, have, pairs + pi_r, DYNAMIC_SLOTS ? slot_r : pairs[pi_r].slot, word_r, h1, h2, warm ? warm + r : nullptr);
+                if (have) {
+                    scr(SCR_PC + pi_r) = T(pc_pack(c, h1, h2));
+                    todo &= todo - 1;
+                }
+            }
+#endif
+        } else
         // one call site: as many turns as the busiest lane of the wave has live pairs
         while (todo != 0) {
             int r = 0, pi_r = pi_[0], word_r = word_[0], slot_r = slot_[0];
