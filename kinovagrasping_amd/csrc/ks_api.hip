@@ -1336,11 +1336,15 @@ __global__ __launch_bounds__(SLOT_THREADS) void k_slots(const int32_t* __restric
 // of a wave are in the same phase of their episodes.  A wave's lanes run in lock step, so an env-step costs it its most expensive env - and what an
 // env-step costs is mostly decided by where the env is in its episode (approach: no contact; grasp and lift: penetration queries in every substep).
 // Dealt in env order a wave nearly always holds an env of the expensive phases; sorted, it pays for them only while its own envs are there
-// (profiles/r06_wave_chains.txt, the model on measured counters: slowest wave chain of a 20-step launch -5 %, mean wave -7 %).  Per env nothing
-// changes: state, pair memory, noise stream and replay rows are all indexed by env id, a slot only says which lanes step the env
-// (test_every_scheduling_form_of_the_rollout_kernel_equals_lock_step).  One workgroup; rank of (t, env) by counting, envs first, padding (-1) last.
+// (profiles/r06_wave_chains.txt, the model on measured counters: mean wave -7 % sorted over the whole context, -5 % sorted within the workgroups).
+// Per env nothing changes: state, pair memory, noise stream and replay rows are all indexed by env id, a slot only says which lanes step the env
+// (test_every_scheduling_form_of_the_rollout_kernel_equals_lock_step).
+// DEFAULT (KS_ROLLOUT_PHASE_DEAL=1): every workgroup's OWN sixteen slots sorted - its envs stay the sixteen neighbours in memory they were, whose
+// [field][env] columns share one 64-byte line per field.  KS_ROLLOUT_PHASE_DEAL=2 sorts the whole list: measured +2.8 % (default form) against
+// env order, but a workgroup's envs are then scattered over the columns and k_rollout's FETCH_SIZE rises from 10.9 to 39.8 MB per env-step.
 constexpr int PHASE_THREADS = 1024, PHASE_ENVS_MAX = 4096;
 __global__ __launch_bounds__(PHASE_THREADS) void k_slots_by_phase(const int64_t* __restrict__ t, int N, int n_slots, int32_t* __restrict__ slot_env) {
+    // the whole list: rank of (t, env) by counting, envs first, padding (-1) last.  One workgroup.
     __shared__ unsigned key[PHASE_ENVS_MAX];
     for (int e = threadIdx.x; e < N; e += PHASE_THREADS) {
         long long te = t[e];
@@ -1355,6 +1359,26 @@ __global__ __launch_bounds__(PHASE_THREADS) void k_slots_by_phase(const int64_t*
         slot_env[rank] = e;
     }
     for (int s = N + threadIdx.x; s < n_slots; s += PHASE_THREADS) slot_env[s] = -1;
+}
+__global__ void k_slots_by_phase_in_groups(const int64_t* __restrict__ t, int n_groups, int epw, int32_t* __restrict__ slot_env) {
+    // every group of epw (<= 16) slots on its own: one thread per group, insertion sort by (t, env), padding (-1) last
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    int32_t* sl = slot_env + (long)g * epw;
+    unsigned long long key[16];
+    for (int i = 0; i < epw; i++) {
+        const int e = sl[i];
+        long long te = e >= 0 ? t[e] : 0x7fff;
+        te = te < 0 ? 0 : (te > 0x7fff ? 0x7fff : te);
+        key[i] = e >= 0 ? (((unsigned long long)te << 32) | (unsigned)e) : ~0ull;
+    }
+    for (int i = 1; i < epw; i++) {
+        const unsigned long long k = key[i];
+        int j = i - 1;
+        while (j >= 0 && key[j] > k) { key[j + 1] = key[j]; j--; }
+        key[j + 1] = k;
+    }
+    for (int i = 0; i < epw; i++) sl[i] = key[i] == ~0ull ? -1 : (int)(unsigned)(key[i] & 0xffffffffull);
 }
 
 // one (env, ray, geom) per lane: eight envs per wave, the eight mesh geoms of an env in adjacent lanes (lane 0 of the
@@ -1825,7 +1849,7 @@ template <typename T> struct Ctx : CtxBase {
                                           // (measured, round 5).  That context is bound by its slowest groups' SEQUENTIAL env-steps anyway (every env does the
                                           // same number of env-steps per launch): no dealing helps it.  KS_ROLLOUT_DEAL=queue forces the queue.
     bool rollout_waves = !(getenv("KS_ROLLOUT_WAVES") && getenv("KS_ROLLOUT_WAVES")[0] == '0');      // free-running waves (one group per workgroup)
-    bool rollout_phase_deal = !(getenv("KS_ROLLOUT_PHASE_DEAL") && getenv("KS_ROLLOUT_PHASE_DEAL")[0] == '0');      // free waves, one object: slots sorted by episode step before every launch (k_slots_by_phase)
+    int rollout_phase_deal = getenv("KS_ROLLOUT_PHASE_DEAL") ? atoi(getenv("KS_ROLLOUT_PHASE_DEAL")) : 1;      // free waves, one object: slots sorted by episode step before every launch (1: within every workgroup's sixteen, 2: the whole list, 0: env order)
     bool rollout_round_robin = false;     // how k_rollout deals the env groups to its persistent workgroups: contiguous runs (default) or round-robin (KS_ROLLOUT_DEAL=rr)
     int lpw = WAVE;
     bool rays_in_step = false, obs_in_step = false;
@@ -1970,8 +1994,10 @@ template <typename T> struct Ctx : CtxBase {
             if (use_queue) {
                 hipLaunchKernelGGL(k_rollout_queue_init, dim3(1), dim3(256), 0, s, d_queue, n_groups);
             }
-            if (wave_free && rollout_phase_deal && n_models == 1 && N <= PHASE_ENVS_MAX && ra->budget_ticks == 0)
-                hipLaunchKernelGGL(k_slots_by_phase, dim3(1), dim3(PHASE_THREADS), 0, s, (const int64_t*)ra->t, N, n_wg * lpw, b.slot_env);
+            if (wave_free && rollout_phase_deal != 0 && n_models == 1 && ra->budget_ticks == 0) {
+                if (rollout_phase_deal == 2 && N <= PHASE_ENVS_MAX) hipLaunchKernelGGL(k_slots_by_phase, dim3(1), dim3(PHASE_THREADS), 0, s, (const int64_t*)ra->t, N, n_wg * lpw, b.slot_env);
+                else if (lpw <= 16) hipLaunchKernelGGL(k_slots_by_phase_in_groups, dim3((n_groups + 255) / 256), dim3(256), 0, s, (const int64_t*)ra->t, n_groups, lpw, b.slot_env);
+            }
 #define KS_ROLLOUT_CASE(A, B)                                                                                                                         \
     if ((ra->h1 + 15) / 16 == A && (ra->h2 + 15) / 16 == B) {                                                                                                 \
         HIPCHK(hipFuncSetAttribute((const void*)k_rollout<A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));                        \

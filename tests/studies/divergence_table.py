@@ -244,7 +244,10 @@ def mixed_precision(only=None):
                           (32, "fp32 state and kinematics, the whole COLLISION stage fp64 on those poses"),
                           (33, "fp32 state and kinematics, HULL pairs (GJK / MPR) from an fp64 collision on those poses, plane pairs the product's"),
                           (34, "fp32 state and kinematics, PLANE pairs from an fp64 collision on those poses, hull pairs the product's (~ the product, 146 on the fp32 lane: rows that differ by < 8 differ by the noise of this count)"),
-                          (2, "as 32 with qpos / qvel accumulated in fp64 over the substeps")):
+                          (2, "as 32 with qpos / qvel accumulated in fp64 over the substeps"),
+                          (5, "the product's fp32 stages, qpos AND qvel accumulated in fp64 over the substeps (the one-step increments are the fp32 product's)"),
+                          (6, "... qpos accumulated in fp64, qvel rounded to fp32 after every substep"),
+                          (7, "... qvel accumulated in fp64, qpos rounded to fp32 after every substep")):
         if only is not None and variant not in only:
             continue
         jobs = []

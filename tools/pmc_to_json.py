@@ -36,8 +36,8 @@ out = {
     "note": ("per env-step of k_rollout: fetch = the actor's weights for every workgroup and env-step (L2 hits) + env state + pair memory + the rays' mesh nodes + "
              "1/10 of the per-launch staging of the hull / model tables; write = state + body-pose snapshot + rays + observation (x3: output, next policy input, "
              "terminal) + replay row + pair memory, stored as 4-byte columns of [field][env] arrays (~12 MB of output stores per env-step) + write-backs of the "
-             "private-memory frame (round 6: 424 B per lane under the kernel's register budget - spilled values of the inlined solver and of the fp64 penetration query, a "
-             "12-word indexed array in `collision`; evicted lines, not a count of the stores - what a frame costs was measured in profiles/r05_scratch_probe.txt; with the "
+             "private-memory frame (round 6, final: 360 B per lane under the kernel's register budget - spilled values of the inlined solver and of the fp64 penetration query; the two-lane query keeps its "
+             "portal in LDS, the one-lane form's 96-byte private array is gone; evicted lines, not a count of the stores - what a frame costs was measured in profiles/r05_scratch_probe.txt; with the "
              "query out of line its 34 callee-saved registers alone made this 144 MB: profiles/r06_mpr_variants.txt), DESIGN section 5.  The counters sit on the L2's memory side: Infinity-Cache hits are included, "
              "so this is an upper bound on HBM traffic.") if workload == "free" else
             "fetch = per-workgroup staging of the hull / model tables (256 workgroups x ~50 KB, L2 / MALL hits count) + env state + "
