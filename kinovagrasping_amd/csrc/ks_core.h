@@ -2250,7 +2250,11 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
 // afterwards (a second turn of the loop below, rare: the pairs that overlap together - object against finger links - sit on neighbouring lanes).
 static_assert(NCON_MAX * CON_STRIDE >= 16 * 24, "the contact region holds a 24-word portal per lane of a team");
 #ifndef KS_MPR_SPLIT
+#ifdef KS_MULTI_GEOM
+#define KS_MPR_SPLIT 0          // the multi-geom build keeps the one-lane query: measured with the two-lane one BottleS 3.09 -> 3.02 M, BowlS 2.07 -> 2.03 M env-steps/s, the 14-key
+#else                           //  stage context 0.545 -> 0.543 M (up to six passes per substep that every lane of the wave now takes, hull tables in global memory)
 #define KS_MPR_SPLIT 1          // 0: every penetration query on its owner's lane alone (mpr_penetration_sm), the A/B of the two-lane query
+#endif
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 template <typename T, typename S, int SUBS>
