@@ -48,11 +48,13 @@ def test_free_running_rollout_equals_the_lock_step_calls(hidden, mixed, horizon,
 
 
 @pytest.mark.parametrize("env,n,mixed,plan", [({"KS_ROLLOUT_WAVES": "0"}, 272, False, "workgroups"), ({"KS_ROLLOUT_DEAL": "static"}, 4400, True, "runs"),
-                                              ({"KS_ROLLOUT_DEAL": "rr"}, 4400, True, "round-robin"), ({}, 4400, True, "queue"), ({}, 272, False, "waves")])
+                                              ({"KS_ROLLOUT_DEAL": "rr"}, 4400, True, "round-robin"), ({}, 4400, True, "queue"), ({}, 272, False, "waves"),
+                                              ({"KS_ROLLOUT_PHASE_DEAL": "0"}, 272, False, "waves"), ({"KS_ROLLOUT_PHASE_DEAL": "2"}, 272, False, "waves")])
 def test_every_scheduling_form_of_the_rollout_kernel_equals_lock_step(monkeypatch, env, n, mixed, plan):
     """the fixed deals of rounds 3-4 (KS_ROLLOUT_DEAL=static / rr - still the multi-geom library's default) and the barrier-joined
     workgroup form (KS_ROLLOUT_WAVES=0) are no longer anybody's default in the standard library: exercised here explicitly, with the library's own
-    report of what it runs (ks_rollout_plan)."""
+    report of what it runs (ks_rollout_plan).  Round 6: the free waves' slot list in env order / sorted by episode step over the whole list
+    (KS_ROLLOUT_PHASE_DEAL=0 / 2; the default - sorted within every workgroup - runs in every "waves" case): a slot only says which lanes step an env."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     _free_running_equals_lock_step((256, 256), mixed, 12, 5, n, expect_plan=plan)
