@@ -1238,7 +1238,7 @@ struct PortalLds {
 };
 template <typename T>
 __device__ __forceinline__ bool mpr_penetration_pair(const PairGeo<T>& g_own, bool own, KS_LDS double* portal, T tol_, int max_iter, int& hint1_o, int& hint2_o, T* depth_o,
-                                                         T* dir_o, T* pos_o) {
+                                                         T* dir_o, T* pos_o, int* turns_o = nullptr) {
     HullGeo<T> h;
     KS_UNROLL
     for (int k = 0; k < 9; k++) { const T o = dpp_partner(g_own.R2[k]); h.R[k] = own ? g_own.R1[k] : o; }
@@ -1269,6 +1269,9 @@ __device__ __forceinline__ bool mpr_penetration_pair(const PairGeo<T>& g_own, bo
     int state = MPR_S_V1, it = 0;
     bool hit = false;
     for (;;) {
+#ifdef KS_STAMP_SPLIT
+        if (turns_o) (*turns_o)++;
+#endif
         if (state >= MPR_S_INSIDE) {
             P.getv(0, c1); P.getv(1, c2); P.getv(2, c3);
             sub3(va, c2, c1);
@@ -2259,8 +2262,11 @@ static_assert(NCON_MAX * CON_STRIDE >= 16 * 24, "the contact region holds a 24-w
 #if defined(__HIP_DEVICE_COMPILE__)
 template <typename T, typename S, int SUBS>
 __device__ __forceinline__ int collide_hull_hull_split(const Model<T>& m, const unsigned short* dirtab, S scr, Team<SUBS> team, bool have, KS_LDS const PairRec<T>* prp,
-                                                       int slot, int packed_in, int& h1_out, int& h2_out, PairWarm* ws) {
+                                                       int slot, int packed_in, int& h1_out, int& h2_out, PairWarm* ws, float* prof = nullptr) {
     static_assert(SUBS == 16 && KS_MPR_FIRST == 0, "the two-lane query: 16-lane teams, the distance query first");
+#ifdef KS_STAMP_SPLIT
+    const long long ts0_ = clock64();     // diagnostic build (tools/r06/split_stamp.py): wave-level cycles of the distance-query part and of the penetration part of a pass
+#endif
     KS_LDS const PairRec<T>& pr = *prp;
     PairGeo<T> pg;
     int r = 0, c = 0;
@@ -2303,6 +2309,10 @@ __device__ __forceinline__ int collide_hull_hull_split(const Model<T>& m, const 
     }
     // the penetration queries of this pass: owner + helper
     bool pending = have && r >= 2, hit = false;
+#ifdef KS_STAMP_SPLIT
+    const long long ts1_ = clock64();
+    if (prof) { prof[27] += (float)(ts1_ - ts0_); prof[24] += have ? 1.f : 0.f; prof[25] += pending ? 1.f : 0.f; prof[26] += __any(pending) ? 1.f : 0.f; }
+#endif
     T depth = 0, mdir[3] = {0, 0, 0}, mpos[3] = {0, 0, 0};
 #pragma clang loop unroll(disable)
     while (__any(pending)) {
@@ -2317,7 +2327,13 @@ __device__ __forceinline__ int collide_hull_hull_split(const Model<T>& m, const 
             bool ht = false;
             if (own) { PairGeo<T> pc = pg; ht = mpr_penetration_sm(pc, m.mpr_tol, m.mpr_iters, &dd, md, mp); hh1 = pc.hint1; hh2 = pc.hint2; }
 #else
+#ifdef KS_STAMP_SPLIT
+            int turns_ = 0;
+            const bool ht = mpr_penetration_pair(pg, own, (KS_LDS double*)(scr.base + SCR_CON + 24 * team.sub), m.mpr_tol, m.mpr_iters, hh1, hh2, &dd, md, mp, &turns_);
+            if (prof && own) prof[29] += (float)turns_;
+#else
             const bool ht = mpr_penetration_pair(pg, own, (KS_LDS double*)(scr.base + SCR_CON + 24 * team.sub), m.mpr_tol, m.mpr_iters, hh1, hh2, &dd, md, mp);
+#endif
 #endif
 #ifdef KS_SPLIT_CHECK
             if (own) {      // diagnostic build: the one-lane query on the same pair record must return the same bits
@@ -2338,6 +2354,9 @@ __device__ __forceinline__ int collide_hull_hull_split(const Model<T>& m, const 
             }
         }
     }
+#ifdef KS_STAMP_SPLIT
+    if (prof) prof[28] += (float)(clock64() - ts1_);
+#endif
     if (have && r >= 2) {
         if (ws != nullptr) ws->w[2] = 1u;
         h1_out = pg.hint1 <= PC_HINT_MAX ? pg.hint1 : 0; h2_out = pg.hint2 <= PC_HINT_MAX ? pg.hint2 : 0;
@@ -2457,7 +2476,7 @@ KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Tea
                 todo |= live_r ? (1u << r) : 0u;
             }
         }
-#if defined(KS_STAMP) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(KS_STAMP) && defined(__HIP_DEVICE_COMPILE__) && !defined(KS_STAMP_SPLIT)
         if (prof) {     // diagnostic build: live hull pairs of this lane / of the busiest lane of the wave (= narrow-phase passes of the wave) / of the team
             const int np = __builtin_popcount(todo);
             int wm = np;
@@ -2485,7 +2504,7 @@ KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Tea
                         if (q == r) { pi_r = pi_[q]; word_r = word_[q]; slot_r = slot_[q]; }
                 }
                 int h1 = 0, h2 = 0;
-                const int c = collide_hull_hull_split(m, dirtab, scr, team, have, pairs + pi_r, DYNAMIC_SLOTS ? slot_r : pairs[pi_r].slot, word_r, h1, h2, warm ? warm + r : nullptr);
+                const int c = collide_hull_hull_split(m, dirtab, scr, team, have, pairs + pi_r, DYNAMIC_SLOTS ? slot_r : pairs[pi_r].slot, word_r, h1, h2, warm ? warm + r : nullptr, prof);
                 if (have) {
                     scr(SCR_PC + pi_r) = T(pc_pack(c, h1, h2));
                     todo &= todo - 1;
