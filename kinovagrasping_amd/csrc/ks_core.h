@@ -595,9 +595,10 @@ template <typename T> struct Supp {
     int i1, i2;                // hull vertex ids of v1 / v2 (support points only)
 };
 
-template <typename T> struct PairGeo {
+// (TV: the hull tables' element type - T everywhere but in the multi-geom build's fp64 distance query, which runs on the fp32 tables: KS_MG_GJK_F64)
+template <typename T, typename TV = T> struct PairGeo {
     T R1[9], p1[3], R2[9], p2[3];
-    KS_TAB const T* V1; KS_TAB const T* V2;
+    KS_TAB const TV* V1; KS_TAB const TV* V2;
     KS_TAB const unsigned short* off1; KS_TAB const unsigned short* adj1;
     KS_TAB const unsigned short* off2; KS_TAB const unsigned short* adj2;
     const unsigned short* dir1; const unsigned short* dir2;   // cube-map support start tables of the two hulls (global memory)
@@ -641,8 +642,8 @@ template <typename T> KS_HD int support_cell(const T* ld) {
 
 // the climb: from the better of `hint` (the previous support vertex) and `tab` (the support vertex of the cube-map cell
 // the direction falls in) to the support vertex along the hull-frame direction ld
-template <typename T>
-KS_HD void hull_climb(const T* R, const T* p, KS_TAB const T* V, KS_TAB const unsigned short* off, KS_TAB const unsigned short* adj, int tab, int& hint,
+template <typename T, typename TV>
+KS_HD void hull_climb(const T* R, const T* p, KS_TAB const TV* V, KS_TAB const unsigned short* off, KS_TAB const unsigned short* adj, int tab, int& hint,
                       const T* ld, const T* dir, T hm, T* out) {
     int cur = hint;
     T best = V[4 * cur] * ld[0] + V[4 * cur + 1] * ld[1] + V[4 * cur + 2] * ld[2];
@@ -697,8 +698,8 @@ KS_HD void hull_climb(const T* R, const T* p, KS_TAB const T* V, KS_TAB const un
 #define KS_SCAN_MAX 0           // experiment (round 4), OFF: with 32 the cubes' 24 vertices are scanned - sim-only 4.24 M against 4.30 M with the climb
 #endif
 constexpr int SCAN_MAX = KS_SCAN_MAX;
-template <typename T>
-KS_HD void hull_scan(const T* R, const T* p, KS_TAB const T* V, int n, int& hint, const T* ld, const T* dir, T hm, T* out) {
+template <typename T, typename TV>
+KS_HD void hull_scan(const T* R, const T* p, KS_TAB const TV* V, int n, int& hint, const T* ld, const T* dir, T hm, T* out) {
     int cur = 0;
     T best = V[0] * ld[0] + V[1] * ld[1] + V[2] * ld[2];
     for (int i0 = 0; i0 < n; i0 += HULL_CHUNK) {
@@ -719,7 +720,7 @@ KS_HD void hull_scan(const T* R, const T* p, KS_TAB const T* V, int n, int& hint
 // Support points of BOTH hulls of a pair along dir / -dir.  The two cube-map reads (global memory, L2 resident, ~10x
 // the latency of an LDS round) are issued first, back to back, so that the second one is in flight while the first
 // hull is climbed.
-template <typename T> KS_HD void pair_support(PairGeo<T>& g, const T* dir, T hm, T* out1, T* out2) {
+template <typename T, typename TV> KS_HD void pair_support(PairGeo<T, TV>& g, const T* dir, T hm, T* out1, T* out2) {
     const T nd[3] = {-dir[0], -dir[1], -dir[2]};
     T ld1[3], ld2[3];
     mulRtv(ld1, g.R1, dir);
@@ -755,9 +756,9 @@ template <typename T> KS_HD void pair_support(PairGeo<T>& g, const T* dir, T hm,
 #ifndef KS_MINK_F64
 #define KS_MINK_F64 0
 #endif
-template <typename T> KS_HD void minkowski_point_ids(const PairGeo<T>& g, int i, int j, const T* v1, const T* v2, T* v);
-template <typename T> KS_HD void minkowski_point(const PairGeo<T>& g, const T* v1, const T* v2, T* v) { minkowski_point_ids(g, g.hint1, g.hint2, v1, v2, v); }
-template <typename T> KS_HD void minkowski_point_ids(const PairGeo<T>& g, int i, int j, const T* v1, const T* v2, T* v) {
+template <typename T, typename TV> KS_HD void minkowski_point_ids(const PairGeo<T, TV>& g, int i, int j, const T* v1, const T* v2, T* v);
+template <typename T, typename TV> KS_HD void minkowski_point(const PairGeo<T, TV>& g, const T* v1, const T* v2, T* v) { minkowski_point_ids(g, g.hint1, g.hint2, v1, v2, v); }
+template <typename T, typename TV> KS_HD void minkowski_point_ids(const PairGeo<T, TV>& g, int i, int j, const T* v1, const T* v2, T* v) {
     if constexpr (sizeof(T) == 4 && (KS_MINK_F64 != 0)) {
         const double a[3] = {(double)g.V1[4 * i], (double)g.V1[4 * i + 1], (double)g.V1[4 * i + 2]};
         const double b[3] = {(double)g.V2[4 * j], (double)g.V2[4 * j + 1], (double)g.V2[4 * j + 2]};
@@ -908,7 +909,7 @@ KS_HD void unpack3(unsigned w, int* ids, int& top) {
 // Minkowski Portal Refinement penetration query (same decision structure as the oracle's mpr_penetration, i.e. the
 // published algorithm of libccd's ccdMPRPenetration - libccd is (c) D. Fiser, BSD-3; it is a dependency of MuJoCo, not
 // part of /root/reference, and no code of it is used here).  Returns true on overlap.
-template <typename T> KS_HD void hull_point(const T* R, const T* p, KS_TAB const T* V, int i, T* out) {
+template <typename T, typename TV> KS_HD void hull_point(const T* R, const T* p, KS_TAB const TV* V, int i, T* out) {
     const T v[3] = {V[4 * i], V[4 * i + 1], V[4 * i + 2]};
     mulRv(out, R, v);
     add3(out, out, p);
@@ -1555,7 +1556,7 @@ template <typename T> struct Simplex {
     int n;
 };
 
-template <typename T> KS_HD void gjk_support(PairGeo<T>& g, const T* dir, T* y, T* a, T* b) {
+template <typename T, typename TV> KS_HD void gjk_support(PairGeo<T, TV>& g, const T* dir, T* y, T* a, T* b) {
 #if defined(KS_STAMP_HULL) && defined(__HIP_DEVICE_COMPILE__)
     const long long ts0 = clock64();
 #endif
@@ -1694,7 +1695,7 @@ template <typename T> KS_HD void gjk_remember(PairWarm* ws, const Simplex<T>& S)
     ws->w[1] = pack3(S.ib[0], S.ib[1], S.ib[2], 0);
 }
 
-template <typename T> KS_NARROW int gjk_distance(PairGeo<T>& g, T margin, T* dist, T* normal, T* pos, PairWarm* ws = nullptr) {
+template <typename T, typename TV> KS_NARROW int gjk_distance(PairGeo<T, TV>& g, T margin, T* dist, T* normal, T* pos, PairWarm* ws = nullptr) {
     Simplex<T> S;
     T lam[4] = {1, 0, 0, 0}, v[3], d[3];
 #ifndef KS_GJK_TOL
@@ -2112,6 +2113,61 @@ KS_HD int collide_plane_hull(S scr, Team<SUBS> team, KS_LDS const PairRec<T>* pr
     return nc;
 }
 
+// hull tables, cube maps, poses and support hints of a pair in the operand order of the convex queries (obj_first: see collide_hull_hull)
+template <typename T, typename S>
+KS_HD void fill_pair_geo(PairGeo<T>& pg, const unsigned short* dirtab, S scr, KS_LDS const PairRec<T>& pr, bool obj_first, int h1, int h2) {
+    const int g1 = pr.g1, g2 = pr.g2, flags = pr.obj_hand;
+    if (obj_first) {
+        pg.V1 = pr.V2; pg.n1 = pr.n2; pg.off1 = pr.off2; pg.adj1 = pr.adj2;
+        pg.V2 = pr.V1; pg.n2 = pr.n1; pg.off2 = pr.off1; pg.adj2 = pr.adj1;
+        pg.dir1 = dirtab + SUPPORT_CELLS * ((flags >> 8) & 15);
+        pg.dir2 = dirtab + SUPPORT_CELLS * ((flags >> 4) & 15);
+        geom_pose_cached(scr, g2, pg.R1, pg.p1);
+        geom_pose_cached(scr, g1, pg.R2, pg.p2);
+    } else {
+        pg.V1 = pr.V1; pg.n1 = pr.n1; pg.off1 = pr.off1; pg.adj1 = pr.adj1;
+        pg.V2 = pr.V2; pg.n2 = pr.n2; pg.off2 = pr.off2; pg.adj2 = pr.adj2;
+        pg.dir1 = dirtab + SUPPORT_CELLS * ((flags >> 4) & 15);
+        pg.dir2 = dirtab + SUPPORT_CELLS * ((flags >> 8) & 15);
+        geom_pose_cached(scr, g1, pg.R1, pg.p1);
+        geom_pose_cached(scr, g2, pg.R2, pg.p2);
+    }
+    pg.hint1 = h1 < pg.n1 ? h1 : 0;
+    pg.hint2 = h2 < pg.n2 ? h2 : 0;
+    pg.half_margin = T(0);
+#ifdef KS_STAMP_HULL
+    pg.cnt_support = 0; pg.cnt_steps = 0; pg.t_sup = 0; pg.t_clo = 0;
+#endif
+}
+// The multi-geom build's fp64 distance query of the fp32 product (KS_MG_GJK_F64, see collide_hull_hull): OUT OF LINE, and it reads the pair's record itself.
+// Inlined into `collision` its fp64 simplex takes that function to 256 + 156 registers - past the stepping kernels' budget (ks_api.hip: KS_ROLLOUT_NUM_VGPR),
+// the learner's waves no longer fit beside them and its stream falls behind (episodes dropped); with `collision` itself inlined into the kernels the budget
+// holds but everything spills (BottleS 3.09 -> 2.46 M env-steps/s); out of line with the caller's pair record live across the call 256 + 134.
+template <typename T, typename S>
+KS_FN int gjk_distance_f64(const unsigned short* dirtab, S scr, KS_LDS const PairRec<T>* prp, bool obj_first, int& h1, int& h2, T* dist, T* dir, T* pos, PairWarm* ws) {
+    PairGeo<double, T> pd;
+    {
+        PairGeo<T> pg;
+        fill_pair_geo(pg, dirtab, scr, *prp, obj_first, h1, h2);
+        KS_UNROLL
+        for (int k = 0; k < 9; k++) { pd.R1[k] = (double)pg.R1[k]; pd.R2[k] = (double)pg.R2[k]; }
+        KS_UNROLL
+        for (int k = 0; k < 3; k++) { pd.p1[k] = (double)pg.p1[k]; pd.p2[k] = (double)pg.p2[k]; }
+        pd.V1 = pg.V1; pd.V2 = pg.V2; pd.off1 = pg.off1; pd.adj1 = pg.adj1; pd.off2 = pg.off2; pd.adj2 = pg.adj2; pd.dir1 = pg.dir1; pd.dir2 = pg.dir2;
+        pd.n1 = pg.n1; pd.n2 = pg.n2; pd.hint1 = pg.hint1; pd.hint2 = pg.hint2; pd.half_margin = 0.0;
+#ifdef KS_STAMP_HULL
+        pd.cnt_support = 0; pd.cnt_steps = 0; pd.t_sup = 0; pd.t_clo = 0;
+#endif
+    }
+    double dist_d = 0, dir_d[3] = {0, 0, 0}, pos_d[3] = {0, 0, 0};
+    const int r = gjk_distance(pd, (double)prp->margin, &dist_d, dir_d, pos_d, ws);
+    h1 = pd.hint1; h2 = pd.hint2;
+    *dist = (T)dist_d;
+    KS_UNROLL
+    for (int k = 0; k < 3; k++) { dir[k] = (T)dir_d[k]; pos[k] = (T)pos_d[k]; }
+    return r;
+}
+
 // hull vs hull (one lane): bounding spheres, exact OBB test, GJK distance for the margin zone, MPR on overlap
 // Hull pairs keep the support vertices their last GJK / MPR query ended on as the hill-climbing start of the next
 // substep (two 10-bit vertex ids packed above the 3-bit contact count in the pair's SCR_PC word): the climb is
@@ -2152,9 +2208,11 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
     h1_out = (packed_in >> 3) & PC_HINT_MAX;
     h2_out = (packed_in >> (3 + PC_HINT_BITS)) & PC_HINT_MAX;
     // the whole record first: one burst of LDS reads, one wait
-    const int g1 = pr.g1, g2 = pr.g2, body1 = pr.body1, body2 = pr.body2;
-    const int flags = pr.obj_hand;
-    const T margin = pr.margin, mu = (flags & 1) ? T(scr(SCR_ENVP + 1)) : pr.mu;
+    const int g1 = pr.g1, g2 = pr.g2;
+    int body1 = pr.body1, body2 = pr.body2;
+    int flags = pr.obj_hand;
+    const T margin = pr.margin;
+    T mu = (flags & 1) ? T(scr(SCR_ENVP + 1)) : pr.mu;
     // Operand order of the convex queries = MuJoCo's (oracle/ko_physics.c: collide_hull_hull): an explicit <pair geom1="object" geom2=hand geom>
     // reaches libccd with the OBJECT as obj1; the model stores the pair as (hand geom, object).  MPR is not symmetric in its operands
     // (within its 1e-6 tolerance the portal path - the contact point of a pad-on-face contact - depends on the order): rows 35-45 of the
@@ -2165,29 +2223,16 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
 #define KS_OBJ_FIRST 1          // 0: the operand order of rounds 1-4 (diagnostic A/B only: tools/r05/operand_order_fp32.py)
 #endif
     const bool obj_first = (KS_OBJ_FIRST != 0) && (g2 == OBJ_GEOM);
-    if (obj_first) {
-        pg.V1 = pr.V2; pg.n1 = pr.n2; pg.off1 = pr.off2; pg.adj1 = pr.adj2;
-        pg.V2 = pr.V1; pg.n2 = pr.n1; pg.off2 = pr.off1; pg.adj2 = pr.adj1;
-        pg.dir1 = dirtab + SUPPORT_CELLS * ((flags >> 8) & 15);
-        pg.dir2 = dirtab + SUPPORT_CELLS * ((flags >> 4) & 15);
-        geom_pose_cached(scr, g2, pg.R1, pg.p1);
-        geom_pose_cached(scr, g1, pg.R2, pg.p2);
-    } else {
-        pg.V1 = pr.V1; pg.n1 = pr.n1; pg.off1 = pr.off1; pg.adj1 = pr.adj1;
-        pg.V2 = pr.V2; pg.n2 = pr.n2; pg.off2 = pr.off2; pg.adj2 = pr.adj2;
-        pg.dir1 = dirtab + SUPPORT_CELLS * ((flags >> 4) & 15);
-        pg.dir2 = dirtab + SUPPORT_CELLS * ((flags >> 8) & 15);
-        geom_pose_cached(scr, g1, pg.R1, pg.p1);
-        geom_pose_cached(scr, g2, pg.R2, pg.p2);
-    }
-    // hints are only meaningful when they index the pair's own hulls (always, unless a hull has > 1024 vertices)
-    pg.hint1 = h1_out < pg.n1 ? h1_out : 0;
-    pg.hint2 = h2_out < pg.n2 ? h2_out : 0;
-    pg.half_margin = T(0);
-#ifdef KS_STAMP_HULL
-    pg.cnt_support = 0; pg.cnt_steps = 0; pg.t_sup = 0; pg.t_clo = 0;
+#ifndef KS_MG_GJK_F64
+#define KS_MG_GJK_F64 1         // 0: the fp32 distance query (first half of round 6: 37 of 48 long-horizon envs, 10 - 12 % faster)
 #endif
+    // Multi-geom build, fp32 product (KS_MG_GJK_F64): the DISTANCE query in fp64 arithmetic on the fp32 poses and the fp32 hull tables - what the fp64
+    // instantiation runs.  These objects' pieces collide dynamically in the 1 mm margin zone, where the closest-feature query decides which contact exists; with
+    // the penetration query already on fp64 points this is the host study's "hull pairs from an fp64 collision stage" (tools/r06/mg_host_study.py: 44 of 48;
+    // on the GPU 43 of 48 through ks_step against 37).  The query runs out of line on its own copy of the pair record (gjk_distance_f64); this function's
+    // record is only filled when the penetration query needs it.
     T depth, dist, dir[3], pos[3];
+    int r = 2;
 #ifdef KS_STAMP_HULL
     const long long th1 = clock64();
 #endif
@@ -2208,8 +2253,39 @@ KS_HD int collide_hull_hull(const Model<T>& m, const unsigned short* dirtab, S s
     const bool mpr_first = (KS_MPR_FIRST == 3) ? (use_sm && ws != nullptr && ws->w[2] != 0u && !(margin > T(0)))
                          : (KS_MPR_FIRST == 2) ? (sizeof(T) == 4 && !(margin > T(0)))
                                                : ((KS_MPR_FIRST != 0) && (KS_MPR_WARM != 0) && sizeof(T) == 4 && ws != nullptr && (ws->w[2] >> 30) == 3u && !(margin > T(0)));
-    int r = 2;
-    if (!mpr_first) r = gjk_distance(pg, margin, &dist, dir, pos, ws);
+    constexpr bool gjk_f64 = MULTI_GEOM && (KS_MG_GJK_F64 != 0) && sizeof(T) == 4 && (KS_MPR_FIRST == 0);
+    if constexpr (gjk_f64) {
+        int hh1 = h1_out, hh2 = h2_out;
+        r = gjk_distance_f64(dirtab, scr, prp, obj_first, hh1, hh2, &dist, dir, pos, ws);
+        fill_pair_geo(pg, dirtab, scr, pr, obj_first, hh1, hh2);        // (this function's own record: for the penetration query, should it come to that)
+        // (... and the record's other fields read again rather than held across the call: `collision` must stay inside the stepping kernels' register budget)
+        body1 = pr.body1; body2 = pr.body2; flags = pr.obj_hand;
+        mu = (flags & 1) ? T(scr(SCR_ENVP + 1)) : pr.mu;
+    } else {
+        if (obj_first) {
+            pg.V1 = pr.V2; pg.n1 = pr.n2; pg.off1 = pr.off2; pg.adj1 = pr.adj2;
+            pg.V2 = pr.V1; pg.n2 = pr.n1; pg.off2 = pr.off1; pg.adj2 = pr.adj1;
+            pg.dir1 = dirtab + SUPPORT_CELLS * ((flags >> 8) & 15);
+            pg.dir2 = dirtab + SUPPORT_CELLS * ((flags >> 4) & 15);
+            geom_pose_cached(scr, g2, pg.R1, pg.p1);
+            geom_pose_cached(scr, g1, pg.R2, pg.p2);
+        } else {
+            pg.V1 = pr.V1; pg.n1 = pr.n1; pg.off1 = pr.off1; pg.adj1 = pr.adj1;
+            pg.V2 = pr.V2; pg.n2 = pr.n2; pg.off2 = pr.off2; pg.adj2 = pr.adj2;
+            pg.dir1 = dirtab + SUPPORT_CELLS * ((flags >> 4) & 15);
+            pg.dir2 = dirtab + SUPPORT_CELLS * ((flags >> 8) & 15);
+            geom_pose_cached(scr, g1, pg.R1, pg.p1);
+            geom_pose_cached(scr, g2, pg.R2, pg.p2);
+        }
+        // hints are only meaningful when they index the pair's own hulls (always, unless a hull has > 1024 vertices)
+        pg.hint1 = h1_out < pg.n1 ? h1_out : 0;
+        pg.hint2 = h2_out < pg.n2 ? h2_out : 0;
+        pg.half_margin = T(0);
+#ifdef KS_STAMP_HULL
+        pg.cnt_support = 0; pg.cnt_steps = 0; pg.t_sup = 0; pg.t_clo = 0;
+#endif
+        if (!mpr_first) r = gjk_distance(pg, margin, &dist, dir, pos, ws);
+    }
 #ifdef KS_STAMP_HULL
     if (prof) { prof[24] += 1.f; prof[25] += (float)pg.cnt_support; prof[27] += (float)(clock64() - th1); prof[28] += (float)pg.t_sup; prof[29] += (float)pg.t_clo; }
 #endif
@@ -2518,9 +2594,18 @@ KS_FN_COLLISION void collision(const Model<T>& m, const Hulls<T>& hu, S scr, Tea
             if constexpr (HPL == 2) { r = (todo & 1u) ? 0 : 1; pi_r = r ? pi_[1] : pi_[0]; word_r = r ? word_[1] : word_[0]; slot_r = r ? slot_[1] : slot_[0]; }
             else {
                 r = kctz(todo);
-                KS_UNROLL
-                for (int q = 1; q < HPL; q++)
-                    if (q == r) { pi_r = pi_[q]; word_r = word_[q]; slot_r = slot_[q]; }
+                if constexpr (MULTI_GEOM && (KS_MG_GJK_F64 != 0) && sizeof(T) == 4) {
+                    // (the pair of round r re-derived from the lists in LDS instead of kept in 3 x HPL registers across the out-of-line distance query:
+                    //  what `collision` holds across that call decides whether the stepping kernels stay inside their register budget)
+                    const int left = nhull - r * SUBS, cnt = left < SUBS ? left : SUBS;
+                    pi_r = hu.hull_pi[r == 0 ? team.sub : r * SUBS + team.sub - (SUBS - cnt)];
+                    word_r = (int)scr(SCR_PC + pi_r);
+                    slot_r = DYNAMIC_SLOTS ? (int)scr(SCR_SLOT + pi_r) : 0;
+                } else {
+                    KS_UNROLL
+                    for (int q = 1; q < HPL; q++)
+                        if (q == r) { pi_r = pi_[q]; word_r = word_[q]; slot_r = slot_[q]; }
+                }
             }
             int h1 = 0, h2 = 0;
             const int c = collide_hull_hull(m, dirtab, scr, pairs + pi_r, DYNAMIC_SLOTS ? slot_r : pairs[pi_r].slot, word_r, h1, h2, warm ? warm + r : nullptr, prof);
